@@ -1,0 +1,37 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+@pytest.fixture
+def load_golden():
+    return golden
+
+
+def assert_close(a, b, rtol, atol, what=""):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
+    err = np.abs(a - b)
+    tol = atol + rtol * np.abs(b)
+    if not (err <= tol).all():
+        i = np.unravel_index(np.argmax(err - tol), err.shape)
+        raise AssertionError(f"{what}: max violation at {i}: got {a[i]!r} want {b[i]!r} (|err|={err[i]:.3e}, "
+                             f"tol={tol[i]:.3e}); max abs err {err.max():.3e}")

