@@ -1,0 +1,121 @@
+"""ctypes loader of libdimsum_hip.so + mirrors of the C structs in include/dimsum_hip.h."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdimsum_hip.so")
+
+F32, F16, BF16 = 0, 1, 2
+i32, i64, vp, f32 = C.c_int32, C.c_int64, C.c_void_p, C.c_float
+
+
+class SsmParams(C.Structure):
+    _fields_ = ([(n, i32) for n in ("batch", "dim", "seqlen", "dstate", "n_groups", "n_chunks", "delta_softplus", "dtype")]
+                + [(n, i64) for n in ("A_d_stride", "A_dstate_stride", "B_batch_stride", "B_group_stride",
+                                      "B_dstate_stride", "C_batch_stride", "C_group_stride", "C_dstate_stride",
+                                      "u_batch_stride", "u_d_stride", "delta_batch_stride", "delta_d_stride",
+                                      "z_batch_stride", "z_d_stride", "out_batch_stride", "out_d_stride",
+                                      "out_z_batch_stride", "out_z_d_stride")]
+                + [(n, vp) for n in ("A_ptr", "B_ptr", "C_ptr", "D_ptr", "u_ptr", "delta_ptr", "delta_bias_ptr",
+                                     "z_ptr", "out_ptr", "x_ptr", "out_z_ptr")])
+
+
+class SsmBwdParams(C.Structure):
+    _fields_ = ([("fwd", SsmParams)]
+                + [(n, i64) for n in ("dout_batch_stride", "dout_d_stride", "dA_d_stride", "dA_dstate_stride",
+                                      "dB_batch_stride", "dB_group_stride", "dB_dstate_stride", "dC_batch_stride",
+                                      "dC_group_stride", "dC_dstate_stride", "du_batch_stride", "du_d_stride",
+                                      "dz_batch_stride", "dz_d_stride", "ddelta_batch_stride", "ddelta_d_stride")]
+                + [(n, vp) for n in ("dout_ptr", "dA_ptr", "dB_ptr", "dC_ptr", "dD_ptr", "du_ptr", "dz_ptr",
+                                     "ddelta_ptr", "ddelta_bias_ptr")])
+
+
+class ConvParams(C.Structure):
+    _fields_ = ([(n, i32) for n in ("batch", "dim", "seqlen", "width", "silu_activation", "dtype")]
+                + [(n, i64) for n in ("x_batch_stride", "x_c_stride", "weight_c_stride", "weight_width_stride",
+                                      "out_batch_stride", "out_c_stride")]
+                + [(n, vp) for n in ("x_ptr", "weight_ptr", "bias_ptr", "out_ptr")])
+
+
+class ConvBwdParams(C.Structure):
+    _fields_ = ([("fwd", ConvParams)]
+                + [(n, i64) for n in ("dout_batch_stride", "dout_c_stride", "dx_batch_stride", "dx_c_stride",
+                                      "dweight_c_stride", "dweight_width_stride")]
+                + [(n, vp) for n in ("dout_ptr", "dx_ptr", "dweight_ptr", "dbias_ptr")])
+
+
+class NormParams(C.Structure):
+    _fields_ = ([(n, i32) for n in ("rows", "cols", "is_rms_norm", "x_dtype", "residual_dtype", "out_dtype")]
+                + [("eps", f32)]
+                + [(n, i64) for n in ("x_row_stride", "residual_row_stride", "y_row_stride", "residual_out_row_stride")]
+                + [(n, vp) for n in ("x_ptr", "residual_ptr", "weight_ptr", "bias_ptr", "y_ptr", "residual_out_ptr",
+                                     "mean_ptr", "rstd_ptr")])
+
+
+class NormBwdParams(C.Structure):
+    _fields_ = ([(n, i32) for n in ("rows", "cols", "is_rms_norm")] + [("eps", f32)]
+                + [(n, i64) for n in ("r_row_stride", "dy_row_stride", "dres_row_stride", "dx_row_stride")]
+                + [(n, vp) for n in ("r_ptr", "weight_ptr", "mean_ptr", "rstd_ptr", "dy_ptr", "dres_ptr", "dx_ptr",
+                                     "dweight_ptr", "dbias_ptr")])
+
+
+class TtParams(C.Structure):
+    _fields_ = ([(n, i32) for n in ("batch", "tokens", "channels", "grid", "kind", "transform_first")]
+                + [(n, i64) for n in ("x_batch_stride", "x_token_stride", "base_batch_stride", "base_token_stride",
+                                      "y_batch_stride", "y_token_stride")]
+                + [(n, vp) for n in ("x_ptr", "gather_ptr", "scale_ptr", "shift_ptr", "gate_ptr", "base_ptr")]
+                + [("mod_batch_stride", i64), ("y_ptr", vp)])
+
+
+class XattnParams(C.Structure):
+    _fields_ = ([(n, i32) for n in ("batch", "seqlen", "heads", "head_dim")] + [("scale", f32)]
+                + [(n, i64) for n in ("qkv_batch_stride", "qkv_token_stride", "out_batch_stride", "out_token_stride")]
+                + [(n, vp) for n in ("qkv1_ptr", "qkv2_ptr", "out_ptr", "lse_ptr")])
+
+
+# every symbol include/dimsum_hip.h declares (tests check the library exports all of them)
+EXPORTS = (
+    "dimsum_status_string", "dimsum_abi_version", "dimsum_target_arch",
+    "dimsum_ssm_scan_fwd", "dimsum_ssm_scan_bwd", "dimsum_causal_conv1d_fwd", "dimsum_causal_conv1d_bwd",
+    "dimsum_norm_fwd", "dimsum_norm_bwd", "dimsum_token_transform", "dimsum_xattn_fusion_fwd",
+    "dimsum_gated_gelu_fwd", "dimsum_gated_gelu_bwd",
+)
+
+_lib = None
+
+
+def load():
+    """Loads the HIP library. Raises RuntimeError (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"dimsum_amd: {LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; "
+                           f"g.build()'` or `make -C dimsum_amd/csrc`. There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.dimsum_status_string.restype = C.c_char_p
+    lib.dimsum_status_string.argtypes = [C.c_int]
+    lib.dimsum_target_arch.restype = C.c_char_p
+    lib.dimsum_abi_version.restype = C.c_int
+    for name, ptype in (("dimsum_ssm_scan_fwd", SsmParams), ("dimsum_ssm_scan_bwd", SsmBwdParams),
+                        ("dimsum_causal_conv1d_fwd", ConvParams), ("dimsum_causal_conv1d_bwd", ConvBwdParams),
+                        ("dimsum_norm_fwd", NormParams), ("dimsum_norm_bwd", NormBwdParams),
+                        ("dimsum_token_transform", TtParams), ("dimsum_xattn_fusion_fwd", XattnParams)):
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype = C.c_int
+            fn.argtypes = [C.POINTER(ptype), vp]
+    for name, nptr in (("dimsum_gated_gelu_fwd", 2), ("dimsum_gated_gelu_bwd", 3)):
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype = C.c_int
+            fn.argtypes = [vp] * nptr + [i64, i64, vp]
+    if lib.dimsum_abi_version() != 1:
+        raise RuntimeError("dimsum_amd: libdimsum_hip.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError(f"{what}: {load().dimsum_status_string(status).decode()} (status {status})")

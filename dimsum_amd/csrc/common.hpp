@@ -1,0 +1,90 @@
+// common.hpp -- shared device/host helpers for libdimsum_hip (gfx950 only; wave64 hard-coded).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+#include "../../include/dimsum_hip.h"
+
+namespace dimsum {
+
+constexpr int kWave = 64;
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+struct alignas(16) f32x4 { float v[4]; };
+
+// ---- 4-element vector load/store of the I/O dtype, widened to f32 ------------------------------------------------
+template <typename T> struct Raw4;                                   // raw register image of 4 elements
+template <> struct Raw4<float> { float4 r; };
+template <> struct Raw4<__half> { uint2 r; };
+template <> struct Raw4<__hip_bfloat16> { uint2 r; };
+
+template <typename T> __device__ __forceinline__ Raw4<T> ld4(const T *p);
+template <> __device__ __forceinline__ Raw4<float> ld4<float>(const float *p) { return {*reinterpret_cast<const float4 *>(p)}; }
+template <> __device__ __forceinline__ Raw4<__half> ld4<__half>(const __half *p) { return {*reinterpret_cast<const uint2 *>(p)}; }
+template <> __device__ __forceinline__ Raw4<__hip_bfloat16> ld4<__hip_bfloat16>(const __hip_bfloat16 *p) { return {*reinterpret_cast<const uint2 *>(p)}; }
+
+__device__ __forceinline__ f32x4 widen(const Raw4<float> &a) { return {{a.r.x, a.r.y, a.r.z, a.r.w}}; }
+__device__ __forceinline__ f32x4 widen(const Raw4<__half> &a) {
+    const __half2 lo = *reinterpret_cast<const __half2 *>(&a.r.x), hi = *reinterpret_cast<const __half2 *>(&a.r.y);
+    const float2 l = __half22float2(lo), h = __half22float2(hi);
+    return {{l.x, l.y, h.x, h.y}};
+}
+__device__ __forceinline__ f32x4 widen(const Raw4<__hip_bfloat16> &a) {
+    return {{__uint_as_float(a.r.x << 16), __uint_as_float(a.r.x & 0xffff0000u), __uint_as_float(a.r.y << 16),
+             __uint_as_float(a.r.y & 0xffff0000u)}};
+}
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<__half>(__half v) { return __half2float(v); }
+template <> __device__ __forceinline__ float to_f32<__hip_bfloat16>(__hip_bfloat16 v) { return __bfloat162float(v); }
+
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ __half from_f32<__half>(float v) { return __float2half_rn(v); }
+template <> __device__ __forceinline__ __hip_bfloat16 from_f32<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
+
+template <typename T> __device__ __forceinline__ void st4(T *p, const f32x4 &a);
+template <> __device__ __forceinline__ void st4<float>(float *p, const f32x4 &a) {
+    *reinterpret_cast<float4 *>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+}
+template <> __device__ __forceinline__ void st4<__half>(__half *p, const f32x4 &a) {
+    const __half2 lo = __floats2half2_rn(a.v[0], a.v[1]), hi = __floats2half2_rn(a.v[2], a.v[3]);
+    uint2 r;
+    r.x = *reinterpret_cast<const uint32_t *>(&lo);
+    r.y = *reinterpret_cast<const uint32_t *>(&hi);
+    *reinterpret_cast<uint2 *>(p) = r;
+}
+template <> __device__ __forceinline__ void st4<__hip_bfloat16>(__hip_bfloat16 *p, const f32x4 &a) {
+    __hip_bfloat16 t[4] = {__float2bfloat16(a.v[0]), __float2bfloat16(a.v[1]), __float2bfloat16(a.v[2]), __float2bfloat16(a.v[3])};
+    *reinterpret_cast<uint2 *>(p) = *reinterpret_cast<const uint2 *>(t);
+}
+
+// ---- math --------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }        // v_exp_f32
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * kLn2; }   // v_log_f32
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sigmoidf_fast(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
+
+// softplus with the reference's threshold (selective_scan_fwd_kernel.cuh:153-155): x <= 20 ? log1p(exp(x)) : x.
+// log1p(e) ~= log(w) + (e - (w - 1)) / w with w = 1 + e recovers the bits 1 + e rounds away (e can be ~1e-3 here:
+// dt_min = 0.001), keeping the relative error of a small step size at fp32 roundoff.
+// The correction (e - (w-1)) is at most one ulp of w, so 1/w is replaced by max(2 - w, 0): exact at w = 1 where the
+// correction matters, within 2e-8 absolute elsewhere -- and no v_rcp_f32 (8 issue cycles) on the per-step path.
+__device__ __forceinline__ float softplus_ref(float x) {
+    const float e = fast_exp(x);
+    const float w = 1.0f + e;
+    const float r = fmaf(e - (w - 1.0f), fmaxf(2.0f - w, 0.0f), fast_log(w));
+    return x <= 20.0f ? r : x;
+}
+
+// ---- host ----------------------------------------------------------------------------------------------------------
+inline int launch_status() { return hipGetLastError() == hipSuccess ? DIMSUM_OK : DIMSUM_ERR_LAUNCH; }
+
+template <typename T> inline bool aligned_to(const void *p, size_t bytes) { return (reinterpret_cast<uintptr_t>(p) % bytes) == 0; }
+
+}  // namespace dimsum

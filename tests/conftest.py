@@ -26,11 +26,14 @@ def load_golden():
     return golden
 
 
-def assert_close(a, b, rtol, atol, what=""):
+def assert_close(a, b, rtol, atol, what="", scale_atol=0.0):
+    """|a - b| <= atol + scale_atol * max|b| + rtol * |b| elementwise.
+    `scale_atol` makes the absolute part relative to the tensor's magnitude: sums of many O(1) terms (scan outputs,
+    attention rows) cancel to small elements whose error is set by the size of the terms, not of the element."""
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
     err = np.abs(a - b)
-    tol = atol + rtol * np.abs(b)
+    tol = atol + scale_atol * (np.abs(b).max() if b.size else 0.0) + rtol * np.abs(b)
     if not (err <= tol).all():
         i = np.unravel_index(np.argmax(err - tol), err.shape)
         raise AssertionError(f"{what}: max violation at {i}: got {a[i]!r} want {b[i]!r} (|err|={err[i]:.3e}, "

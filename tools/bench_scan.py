@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the selective-scan forward kernel at the BASELINE config-2 shape (GPU box)."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dimsum_amd import native  # noqa: E402
+
+
+def scan_bytes(B, D, L, N, G=1, s=4):
+    # 5 B D L s + 2 B G N L s + B D ceil(L/2048) 2N 4 + (D N + 2 D) 4
+    return 5 * B * D * L * s + 2 * B * G * N * L * s + B * D * ((L + 2047) // 2048) * 2 * N * 4 + (D * N + 2 * D) * 4
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=256)
+    ap.add_argument("--D", type=int, default=1024)
+    ap.add_argument("--L", type=int, default=256)
+    ap.add_argument("--N", type=int, default=16)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--dtype", default="float32")
+    a = ap.parse_args()
+    dt = getattr(torch, a.dtype)
+    B, D, L, N = a.B, a.D, a.L, a.N
+    dev = "cuda"
+    xz = torch.randn(B, 2 * D, L, device=dev, dtype=dt)
+    u = torch.randn(B, D, L, device=dev, dtype=dt)
+    delta = (0.5 * torch.rand(D, B, L, device=dev)).to(dt).permute(1, 0, 2)   # d-major like MambaInnerFn
+    A = -0.5 * torch.rand(D, N, device=dev)
+    Bm, Cm = torch.randn(B, 1, N, L, device=dev, dtype=dt), torch.randn(B, 1, N, L, device=dev, dtype=dt)
+    Dv, bias = torch.randn(D, device=dev), 0.5 * torch.rand(D, device=dev)
+    z = xz.chunk(2, 1)[1]
+    for _ in range(3):
+        native.selective_scan_fwd(u, delta, A, Bm, Cm, Dv, z, bias, True)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.iters)]
+    for s, e in evs:
+        s.record()
+        native.selective_scan_fwd(u, delta, A, Bm, Cm, Dv, z, bias, True)
+        e.record()
+    torch.cuda.synchronize()
+    ms = sorted(s.elapsed_time(e) for s, e in evs)
+    med = ms[len(ms) // 2]
+    nbytes = scan_bytes(B, D, L, N, 1, u.element_size())
+    print(json.dumps({"shape": [B, D, L, N], "dtype": a.dtype, "ms_median": med, "ms_min": ms[0], "algorithmic_GB": nbytes / 1e9,
+                      "GBps": nbytes / med / 1e6, "frac_of_8TBps": nbytes / med / 1e6 / 8000}))
+
+
+if __name__ == "__main__":
+    main()
