@@ -1,0 +1,249 @@
+// norm.hip -- fused residual-add + RMSNorm / LayerNorm, forward and backward, for gfx950.
+//
+// Replaces the Triton kernels the reference uses unconditionally for RMSNorm (mamba/mamba_ssm/ops/triton/layernorm.py:
+// _layer_norm_fwd_1pass_kernel :61-117, _layer_norm_bwd_kernel :190-285; semantics = rms_norm_ref/layer_norm_ref :19-45):
+//     r = x (+ residual)           residual_out = r   (fp32 when residual_in_fp32)
+//     RMS: y = r * rsqrt(mean(r^2) + eps) * w (+ b)      LN: y = (r - mean) * rsqrt(var + eps) * w + b
+// Streaming op: forward prenorm moves 4*M*N*4 bytes (x, residual in; y, residual_out out).
+//
+// MI355X design: one wave64 per row, the row lives in registers (16 B per lane per piece, up to 8 pieces = 2048 columns;
+// wider rows take a re-reading path), statistics by cross-lane butterflies -- no LDS, no block barrier. The backward
+// keeps per-lane dweight/dbias partial sums in registers over all the rows a wave owns and flushes them with one
+// atomic per column per wave (the Triton reference writes per-SM partials and reduces them on the host).
+#include "common.hpp"
+
+namespace dimsum {
+
+constexpr int kMaxPieces = 8;   // 8 * 256 = 2048 columns held in registers
+
+__device__ __forceinline__ float wave_allsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
+template <typename T> __device__ __forceinline__ f32x4 ld_cols(const T *row, int c, int N, bool vec) {
+    if (vec) return c < N ? widen(ld4<T>(row + c)) : f32x4{{0.f, 0.f, 0.f, 0.f}};
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r.v[e] = (c + e < N) ? to_f32<T>(row[c + e]) : 0.f;
+    return r;
+}
+template <typename T> __device__ __forceinline__ void st_cols(T *row, int c, int N, bool vec, const f32x4 &v) {
+    if (vec) { if (c < N) st4<T>(row + c, v); return; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (c + e < N) row[c + e] = from_f32<T>(v.v[e]);
+}
+
+// TX: dtype of x, TR: dtype of residual / residual_out, TY: dtype of y. Weights fp32.
+template <typename TX, typename TR, typename TY, int kPieces>
+__global__ __launch_bounds__(256) void norm_fwd_kernel(const dimsum_norm_params_t p, const bool vec) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int N = p.cols;
+    const float inv_n = 1.0f / (float)N;
+    const float *w = reinterpret_cast<const float *>(p.weight_ptr);
+    const float *bb = reinterpret_cast<const float *>(p.bias_ptr);
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < p.rows; row += (int64_t)gridDim.x * 4) {
+        const TX *x = reinterpret_cast<const TX *>(p.x_ptr) + row * p.x_row_stride;
+        const TR *res = p.residual_ptr ? reinterpret_cast<const TR *>(p.residual_ptr) + row * p.residual_row_stride : nullptr;
+        TR *ro = p.residual_out_ptr ? reinterpret_cast<TR *>(p.residual_out_ptr) + row * p.residual_out_row_stride : nullptr;
+        TY *y = reinterpret_cast<TY *>(p.y_ptr) + row * p.y_row_stride;
+        f32x4 r[kPieces];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < kPieces; ++i) {
+            const int c = (i * kWave + lane) * 4;
+            r[i] = ld_cols<TX>(x, c, N, vec);
+            if (res) {
+                const f32x4 q = ld_cols<TR>(res, c, N, vec);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[i].v[e] += q.v[e];
+            }
+            if (ro) st_cols<TR>(ro, c, N, vec, r[i]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += p.is_rms_norm ? r[i].v[e] * r[i].v[e] : r[i].v[e];
+        }
+        s = wave_allsum(s);
+        float mean = 0.f, var;
+        if (p.is_rms_norm) {
+            var = s * inv_n;
+        } else {   // two-pass variance on the register copy, like the Triton kernel (layernorm.py:93-96)
+            mean = s * inv_n;
+            float v2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < kPieces; ++i) {
+                const int c = (i * kWave + lane) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float dlt = (c + e < N) ? r[i].v[e] - mean : 0.f; v2 += dlt * dlt; }
+            }
+            var = wave_allsum(v2) * inv_n;
+        }
+        const float rstd = 1.0f / sqrtf(var + p.eps);
+        if (lane == 0) {
+            if (p.rstd_ptr) reinterpret_cast<float *>(p.rstd_ptr)[row] = rstd;
+            if (p.mean_ptr && !p.is_rms_norm) reinterpret_cast<float *>(p.mean_ptr)[row] = mean;
+        }
+#pragma unroll
+        for (int i = 0; i < kPieces; ++i) {
+            const int c = (i * kWave + lane) * 4;
+            if (c < N) {
+                const f32x4 wv = ld_cols<float>(w, c, N, vec);
+                const f32x4 bv = bb ? ld_cols<float>(bb, c, N, vec) : f32x4{{0.f, 0.f, 0.f, 0.f}};
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o.v[e] = (r[i].v[e] - mean) * rstd * wv.v[e] + bv.v[e];
+                st_cols<TY>(y, c, N, vec, o);
+            }
+        }
+    }
+}
+
+// backward (fp32 buffers). dx = (w*dy - xhat*c1 [- c2]) * rstd (+ dres);  c1 = mean(xhat*w*dy), c2 = mean(w*dy)
+template <int kPieces>
+__global__ __launch_bounds__(256) void norm_bwd_kernel(const dimsum_norm_bwd_params_t p, const bool vec) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int N = p.cols;
+    const float inv_n = 1.0f / (float)N;
+    const float *w = reinterpret_cast<const float *>(p.weight_ptr);
+    f32x4 wreg[kPieces], dw[kPieces], db[kPieces];
+#pragma unroll
+    for (int i = 0; i < kPieces; ++i) {
+        const int c = (i * kWave + lane) * 4;
+        wreg[i] = ld_cols<float>(w, c, N, vec);
+        dw[i] = {{0.f, 0.f, 0.f, 0.f}};
+        db[i] = {{0.f, 0.f, 0.f, 0.f}};
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < p.rows; row += (int64_t)gridDim.x * 4) {
+        const float *r = reinterpret_cast<const float *>(p.r_ptr) + row * p.r_row_stride;
+        const float *dy = reinterpret_cast<const float *>(p.dy_ptr) + row * p.dy_row_stride;
+        const float *dres = p.dres_ptr ? reinterpret_cast<const float *>(p.dres_ptr) + row * p.dres_row_stride : nullptr;
+        float *dx = reinterpret_cast<float *>(p.dx_ptr) + row * p.dx_row_stride;
+        const float rstd = reinterpret_cast<const float *>(p.rstd_ptr)[row];
+        const float mean = (p.is_rms_norm || !p.mean_ptr) ? 0.f : reinterpret_cast<const float *>(p.mean_ptr)[row];
+        f32x4 xh[kPieces], wdy[kPieces];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < kPieces; ++i) {
+            const int c = (i * kWave + lane) * 4;
+            const f32x4 rv = ld_cols<float>(r, c, N, vec), g = ld_cols<float>(dy, c, N, vec);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool in = c + e < N;
+                xh[i].v[e] = in ? (rv.v[e] - mean) * rstd : 0.f;
+                wdy[i].v[e] = wreg[i].v[e] * g.v[e];
+                c1 += xh[i].v[e] * wdy[i].v[e];
+                c2 += wdy[i].v[e];
+                dw[i].v[e] = fmaf(g.v[e], xh[i].v[e], dw[i].v[e]);
+                db[i].v[e] += g.v[e];
+            }
+        }
+        c1 = wave_allsum(c1) * inv_n;
+        c2 = p.is_rms_norm ? 0.f : wave_allsum(c2) * inv_n;
+#pragma unroll
+        for (int i = 0; i < kPieces; ++i) {
+            const int c = (i * kWave + lane) * 4;
+            if (c < N) {
+                f32x4 o = dres ? ld_cols<float>(dres, c, N, vec) : f32x4{{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o.v[e] += (wdy[i].v[e] - (xh[i].v[e] * c1 + c2)) * rstd;
+                st_cols<float>(dx, c, N, vec, o);
+            }
+        }
+    }
+    float *dwp = reinterpret_cast<float *>(p.dweight_ptr), *dbp = reinterpret_cast<float *>(p.dbias_ptr);
+#pragma unroll
+    for (int i = 0; i < kPieces; ++i) {
+        const int c = (i * kWave + lane) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c + e < N) {
+                atomicAdd(dwp + c + e, dw[i].v[e]);
+                if (dbp) atomicAdd(dbp + c + e, db[i].v[e]);
+            }
+    }
+}
+
+template <typename TX, typename TR, typename TY>
+static int launch_norm_fwd(const dimsum_norm_params_t &p, hipStream_t s) {
+    const int N = p.cols;
+    bool vec = N % 4 == 0 && aligned_to<TX>(p.x_ptr, 4 * sizeof(TX)) && aligned_to<TY>(p.y_ptr, 4 * sizeof(TY)) &&
+               p.x_row_stride % 4 == 0 && p.y_row_stride % 4 == 0 && aligned_to<float>(p.weight_ptr, 16) &&
+               (!p.bias_ptr || aligned_to<float>(p.bias_ptr, 16));
+    if (p.residual_ptr) vec = vec && aligned_to<TR>(p.residual_ptr, 4 * sizeof(TR)) && p.residual_row_stride % 4 == 0;
+    if (p.residual_out_ptr) vec = vec && aligned_to<TR>(p.residual_out_ptr, 4 * sizeof(TR)) && p.residual_out_row_stride % 4 == 0;
+    const int pieces = (N + 255) / 256;
+    const int64_t blocks = (p.rows + 3) / 4;
+    const dim3 grid((unsigned)(blocks < 256 * 16 ? blocks : 256 * 16)), block(256);
+#define DIMSUM_NF(K) hipLaunchKernelGGL((norm_fwd_kernel<TX, TR, TY, K>), grid, block, 0, s, p, vec)
+    if (pieces <= 1) DIMSUM_NF(1);
+    else if (pieces <= 2) DIMSUM_NF(2);
+    else if (pieces <= 4) DIMSUM_NF(4);
+    else if (pieces <= 5) DIMSUM_NF(5);
+    else if (pieces <= kMaxPieces) DIMSUM_NF(8);
+    else return DIMSUM_ERR_SHAPE;
+#undef DIMSUM_NF
+    return launch_status();
+}
+
+template <typename TX, typename TR>
+static int dispatch_out(const dimsum_norm_params_t &p, hipStream_t s) {
+    switch (p.out_dtype) {
+        case DIMSUM_F32: return launch_norm_fwd<TX, TR, float>(p, s);
+        case DIMSUM_F16: return launch_norm_fwd<TX, TR, __half>(p, s);
+        case DIMSUM_BF16: return launch_norm_fwd<TX, TR, __hip_bfloat16>(p, s);
+        default: return DIMSUM_ERR_DTYPE;
+    }
+}
+template <typename TX>
+static int dispatch_res(const dimsum_norm_params_t &p, hipStream_t s) {
+    switch (p.residual_dtype) {   // the reference keeps the residual stream in fp32 (residual_in_fp32) or in x's dtype
+        case DIMSUM_F32: return dispatch_out<TX, float>(p, s);
+        case DIMSUM_F16: return dispatch_out<TX, __half>(p, s);
+        case DIMSUM_BF16: return dispatch_out<TX, __hip_bfloat16>(p, s);
+        default: return DIMSUM_ERR_DTYPE;
+    }
+}
+
+}  // namespace dimsum
+
+extern "C" int dimsum_norm_fwd(const dimsum_norm_params_t *p, void *stream) {
+    using namespace dimsum;
+    if (!p || !p->x_ptr || !p->weight_ptr || !p->y_ptr) return DIMSUM_ERR_NULL;
+    if (p->rows < 0 || p->cols <= 0) return DIMSUM_ERR_SHAPE;
+    if (p->rows == 0) return DIMSUM_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (p->x_dtype) {
+        case DIMSUM_F32: return dispatch_res<float>(*p, s);
+        case DIMSUM_F16: return dispatch_res<__half>(*p, s);
+        case DIMSUM_BF16: return dispatch_res<__hip_bfloat16>(*p, s);
+        default: return DIMSUM_ERR_DTYPE;
+    }
+}
+
+extern "C" int dimsum_norm_bwd(const dimsum_norm_bwd_params_t *p, void *stream) {
+    using namespace dimsum;
+    if (!p || !p->r_ptr || !p->weight_ptr || !p->rstd_ptr || !p->dy_ptr || !p->dx_ptr || !p->dweight_ptr) return DIMSUM_ERR_NULL;
+    if (p->rows < 0 || p->cols <= 0) return DIMSUM_ERR_SHAPE;
+    if (p->rows == 0) return DIMSUM_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int N = p->cols;
+    bool vec = N % 4 == 0 && aligned_to<float>(p->r_ptr, 16) && aligned_to<float>(p->dy_ptr, 16) && aligned_to<float>(p->dx_ptr, 16) &&
+               aligned_to<float>(p->weight_ptr, 16) && p->r_row_stride % 4 == 0 && p->dy_row_stride % 4 == 0 && p->dx_row_stride % 4 == 0;
+    if (p->dres_ptr) vec = vec && aligned_to<float>(p->dres_ptr, 16) && p->dres_row_stride % 4 == 0;
+    const int pieces = (N + 255) / 256;
+    // few, fat waves: every wave ends with N atomics, so cap the grid at ~2 waves per SIMD
+    const int64_t blocks = (p->rows + 3) / 4;
+    const dim3 grid((unsigned)(blocks < 512 ? blocks : 512)), block(256);
+#define DIMSUM_NB(K) hipLaunchKernelGGL((norm_bwd_kernel<K>), grid, block, 0, s, *p, vec)
+    if (pieces <= 1) DIMSUM_NB(1);
+    else if (pieces <= 2) DIMSUM_NB(2);
+    else if (pieces <= 4) DIMSUM_NB(4);
+    else if (pieces <= 5) DIMSUM_NB(5);
+    else if (pieces <= kMaxPieces) DIMSUM_NB(8);
+    else return DIMSUM_ERR_SHAPE;
+#undef DIMSUM_NB
+    return launch_status();
+}

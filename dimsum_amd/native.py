@@ -106,3 +106,142 @@ def selective_scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus, need
     if z is not None:
         res.append(out_z)
     return res
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# causal_conv1d_cuda.*   (causal-conv1d/csrc/causal_conv1d.cpp:221-577)
+# ---------------------------------------------------------------------------------------------------------------------
+def _check_conv(x, weight, bias):
+    _gpu(x, weight, bias)
+    _check(x.dim() == 3, "causal_conv1d: x must be (batch, dim, seqlen)")
+    _check(x.dtype in _DT, "causal_conv1d: input must be float32, float16 or bfloat16")
+    _check(x.stride(2) == 1 or x.shape[2] == 1, "causal_conv1d: only seqlen-contiguous (batch, dim, seqlen) inputs are "
+                                                "supported here (DiMSUM never feeds channel-last)")
+    dim, width = weight.shape
+    _check(dim == x.shape[1], "causal_conv1d: weight must be (dim, width)")
+    _check(2 <= width <= 4, "causal_conv1d only supports width between 2 and 4")
+    if bias is not None:
+        _check(tuple(bias.shape) == (dim,) and bias.stride(-1) == 1, "causal_conv1d: bias must be (dim,)")
+
+
+def _fill_conv(P, x, weight, bias, silu, out):
+    P.batch, P.dim, P.seqlen = x.shape
+    P.width, P.silu_activation, P.dtype = weight.shape[1], int(bool(silu)), _DT[x.dtype]
+    P.x_batch_stride, P.x_c_stride = x.stride(0), x.stride(1)
+    P.weight_c_stride, P.weight_width_stride = weight.stride(0), weight.stride(1)
+    P.x_ptr, P.weight_ptr, P.bias_ptr = _ptr(x), _ptr(weight), _ptr(bias)
+    if out is not None:
+        P.out_batch_stride, P.out_c_stride, P.out_ptr = out.stride(0), out.stride(1), _ptr(out)
+
+
+def causal_conv1d_fwd(x, weight, bias, silu_activation, out=None):
+    """-> out (batch, dim, seqlen), like causal_conv1d_cuda.causal_conv1d_fwd. Weights are used in fp32."""
+    _check_conv(x, weight, bias)
+    weight = weight.float()
+    bias = bias.float().contiguous() if bias is not None else None
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+    if x.numel() > 0:
+        P = _lib.ConvParams()
+        _fill_conv(P, x, weight, bias, silu_activation, out)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().dimsum_causal_conv1d_fwd(P, _stream(x)), "causal_conv1d_fwd")
+    return out
+
+
+def causal_conv1d_fwd_cond(x, weight, bias, silu_activation, init_x):
+    """causal_conv1d_cuda.causal_conv1d_fwd_cond: the result is written INTO init_x and returned; the values of init_x
+    never enter the computation (causal_conv1d.cpp:326-329, SURVEY finding 1)."""
+    _check(init_x.shape == x.shape and init_x.dtype == x.dtype and init_x.stride(-1) == 1, "causal_conv1d_fwd_cond: bad init_x")
+    return causal_conv1d_fwd(x, weight, bias, silu_activation, out=init_x)
+
+
+def causal_conv1d_bwd(x, weight, bias, dout, dx, silu_activation):
+    """-> [dx, dweight, dbias] like causal_conv1d_cuda.causal_conv1d_bwd (dx may be a caller-provided view)."""
+    _check_conv(x, weight, bias)
+    _gpu(dout, dx)
+    _check(dout.shape == x.shape and dout.dtype == x.dtype and (dout.stride(2) == 1 or dout.shape[2] == 1), "causal_conv1d_bwd: bad dout")
+    if dx is None:
+        dx = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+    else:
+        _check(dx.shape == x.shape and dx.dtype == x.dtype and dx.stride(2) == 1, "causal_conv1d_bwd: bad dx")
+    w32 = weight.float()
+    b32 = bias.float().contiguous() if bias is not None else None
+    dweight = torch.zeros(weight.shape, device=x.device, dtype=torch.float32)   # fp32 accumulate, then cast (cpp:405-425)
+    dbias = torch.zeros(weight.shape[0], device=x.device, dtype=torch.float32) if bias is not None else None
+    if x.numel() > 0:
+        Q = _lib.ConvBwdParams()
+        _fill_conv(Q.fwd, x, w32, b32, silu_activation, None)
+        Q.dout_batch_stride, Q.dout_c_stride = dout.stride(0), dout.stride(1)
+        Q.dx_batch_stride, Q.dx_c_stride = dx.stride(0), dx.stride(1)
+        Q.dweight_c_stride, Q.dweight_width_stride = dweight.stride(0), dweight.stride(1)
+        Q.dout_ptr, Q.dx_ptr, Q.dweight_ptr, Q.dbias_ptr = _ptr(dout), _ptr(dx), _ptr(dweight), _ptr(dbias)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().dimsum_causal_conv1d_bwd(Q, _stream(x)), "causal_conv1d_bwd")
+    return [dx, dweight.to(weight.dtype), dbias.to(bias.dtype) if bias is not None else None]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fused add + RMSNorm / LayerNorm   (Triton _layer_norm_fwd / _layer_norm_bwd, ops/triton/layernorm.py:120-364)
+# ---------------------------------------------------------------------------------------------------------------------
+def layer_norm_fwd(x, weight, bias, eps, residual=None, out_dtype=None, residual_dtype=None, is_rms_norm=False):
+    """x: (M, N) -> (y, mean, rstd, residual_out), like _layer_norm_fwd (layernorm.py:120-187).
+    residual_out is x itself when no residual is added and no dtype change is requested."""
+    _gpu(x, weight, bias, residual)
+    _check(x.dim() == 2 and x.stride(-1) == 1, "layer_norm_fwd: x must be (M, N) with contiguous rows")
+    M, N = x.shape
+    _check(tuple(weight.shape) == (N,), "layer_norm_fwd: weight must be (N,)")
+    if residual is not None:
+        _check(residual.shape == x.shape and residual.stride(-1) == 1, "layer_norm_fwd: bad residual")
+        residual_dtype = residual.dtype
+    y = torch.empty((M, N), device=x.device, dtype=x.dtype if out_dtype is None else out_dtype)
+    need_res_out = residual is not None or (residual_dtype is not None and residual_dtype != x.dtype)
+    residual_out = torch.empty((M, N), device=x.device, dtype=residual_dtype) if need_res_out else None
+    mean = torch.empty((M,), device=x.device, dtype=torch.float32) if not is_rms_norm else None
+    rstd = torch.empty((M,), device=x.device, dtype=torch.float32)
+    if M > 0:
+        P = _lib.NormParams()
+        P.rows, P.cols, P.is_rms_norm, P.eps = M, N, int(is_rms_norm), float(eps)
+        P.x_dtype, P.out_dtype = _DT[x.dtype], _DT[y.dtype]
+        P.residual_dtype = _DT[residual_out.dtype] if residual_out is not None else _DT[x.dtype]
+        P.x_row_stride, P.y_row_stride = x.stride(0), y.stride(0)
+        if residual is not None:
+            P.residual_row_stride = residual.stride(0)
+        if residual_out is not None:
+            P.residual_out_row_stride = residual_out.stride(0)
+        w32 = weight.float().contiguous()
+        b32 = bias.float().contiguous() if bias is not None else None
+        P.x_ptr, P.residual_ptr, P.weight_ptr, P.bias_ptr = _ptr(x), _ptr(residual), _ptr(w32), _ptr(b32)
+        P.y_ptr, P.residual_out_ptr, P.mean_ptr, P.rstd_ptr = _ptr(y), _ptr(residual_out), _ptr(mean), _ptr(rstd)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().dimsum_norm_fwd(P, _stream(x)), "layer_norm_fwd")
+    return y, mean, rstd, residual_out if residual_out is not None else x
+
+
+def layer_norm_bwd(dy, x, weight, bias, eps, mean, rstd, dresidual=None, has_residual=False, is_rms_norm=False, x_dtype=None):
+    """-> (dx, dw, db, dresidual_in), like _layer_norm_bwd (layernorm.py:288-364). `x` is the saved residual_out."""
+    _gpu(dy, x, weight, rstd, dresidual)
+    M, N = x.shape
+    xf = x if x.dtype == torch.float32 else x.float()
+    dyf = dy if dy.dtype == torch.float32 else dy.float()
+    drf = None if dresidual is None else (dresidual if dresidual.dtype == torch.float32 else dresidual.float())
+    dx32 = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    dw = torch.zeros((N,), device=x.device, dtype=torch.float32)
+    db = torch.zeros((N,), device=x.device, dtype=torch.float32) if bias is not None else None
+    if M > 0:
+        P = _lib.NormBwdParams()
+        P.rows, P.cols, P.is_rms_norm, P.eps = M, N, int(is_rms_norm), float(eps)
+        P.r_row_stride, P.dy_row_stride, P.dx_row_stride = xf.stride(0), dyf.stride(0), dx32.stride(0)
+        if drf is not None:
+            P.dres_row_stride = drf.stride(0)
+        w32 = weight.float().contiguous()
+        P.r_ptr, P.weight_ptr, P.mean_ptr, P.rstd_ptr = _ptr(xf), _ptr(w32), _ptr(mean), _ptr(rstd)
+        P.dy_ptr, P.dres_ptr, P.dx_ptr, P.dweight_ptr, P.dbias_ptr = _ptr(dyf), _ptr(drf), _ptr(dx32), _ptr(dw), _ptr(db)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().dimsum_norm_bwd(P, _stream(x)), "layer_norm_bwd")
+    x_dtype = x_dtype or x.dtype
+    dx = dx32 if x_dtype == torch.float32 else dx32.to(x_dtype)
+    dresidual_in = None
+    if has_residual:
+        dresidual_in = dx if dx.dtype == x.dtype else dx32.to(x.dtype)
+    return dx, dw.to(weight.dtype), db.to(bias.dtype) if bias is not None else None, dresidual_in
