@@ -60,11 +60,11 @@ class NormBwdParams(C.Structure):
 
 
 class TtParams(C.Structure):
-    _fields_ = ([(n, i32) for n in ("batch", "tokens", "channels", "grid", "kind", "transform_first")]
-                + [(n, i64) for n in ("x_batch_stride", "x_token_stride", "base_batch_stride", "base_token_stride",
-                                      "y_batch_stride", "y_token_stride")]
-                + [(n, vp) for n in ("x_ptr", "gather_ptr", "scale_ptr", "shift_ptr", "gate_ptr", "base_ptr")]
-                + [("mod_batch_stride", i64), ("y_ptr", vp)])
+    _fields_ = ([(n, i32) for n in ("batch", "tokens", "channels", "grid", "kind", "reserved")]
+                + [(n, i64) for n in ("x_batch_stride", "x_token_stride", "res_batch_stride", "res_token_stride",
+                                      "y_batch_stride", "y_token_stride", "mod_batch_stride")]
+                + [(n, vp) for n in ("x_ptr", "in_index_ptr", "out_index_ptr", "gate_ptr", "scale_ptr", "shift_ptr",
+                                     "residual_ptr", "y_ptr")])
 
 
 class XattnParams(C.Structure):

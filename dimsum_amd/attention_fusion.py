@@ -1,0 +1,52 @@
+"""CrossAttentionFusion -- dimsum/attention_fusion.py:9-84: two qkv projections, swapped-KV attention
+(x12 = softmax(q1 k2^T / sqrt(hd)) v2, x21 = softmax(q2 k1^T / sqrt(hd)) v1), concat, proj.
+The attention core (both directions, straight from the qkv GEMM outputs to the concatenated proj input) is one HIP
+kernel with MFMA QK^T / PV (csrc/xattn_fusion.hip) under inference; under autograd it is torch SDPA on the GPU."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import native
+
+
+class CrossAttentionFusion(nn.Module):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_norm=False, attn_drop=0.0, proj_drop=0.0,
+                 norm_layer=nn.LayerNorm, swap_k=False):
+        super().__init__()
+        assert dim % num_heads == 0, "dim should be divisible by num_heads"
+        self.num_heads = num_heads
+        self.head_dim = dim // 2 // num_heads
+        self.scale = self.head_dim ** -0.5
+        self.swap_k = swap_k
+        self.qkv1 = nn.Linear(dim // 2, dim // 2 * 3, bias=qkv_bias)
+        self.q_norm1 = norm_layer(self.head_dim) if qk_norm else nn.Identity()
+        self.k_norm1 = norm_layer(self.head_dim) if qk_norm else nn.Identity()
+        self.qkv2 = nn.Linear(dim // 2, dim // 2 * 3, bias=qkv_bias)
+        self.q_norm2 = norm_layer(self.head_dim) if qk_norm else nn.Identity()
+        self.k_norm2 = norm_layer(self.head_dim) if qk_norm else nn.Identity()
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self._plain = not qk_norm and not swap_k
+
+    def _split(self, qkv, B, N):
+        return qkv.reshape(B, N, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4).unbind(0)
+
+    def forward(self, x1, x2):
+        B, N, C = x1.shape
+        qkv1, qkv2 = self.qkv1(x1), self.qkv2(x2)
+        drop = self.attn_drop.p if self.training else 0.0
+        if self._plain and drop == 0.0 and not torch.is_grad_enabled() and native.xattn_supported(qkv1, self.head_dim):
+            fused = native.xattn_fusion_fwd(qkv1, qkv2, self.num_heads)          # (B, N, 2C) = cat(x12, x21)
+        else:
+            q1, k1, v1 = self._split(qkv1, B, N)
+            q2, k2, v2 = self._split(qkv2, B, N)
+            q1, k1, q2, k2 = self.q_norm1(q1), self.k_norm1(k1), self.q_norm2(q2), self.k_norm2(k2)
+            if not self.swap_k:
+                x12 = F.scaled_dot_product_attention(q1, k2, v2, dropout_p=drop)
+                x21 = F.scaled_dot_product_attention(q2, k1, v1, dropout_p=drop)
+            else:
+                x12 = F.scaled_dot_product_attention(q2, k1, v2, dropout_p=drop)
+                x21 = F.scaled_dot_product_attention(q1, k2, v1, dropout_p=drop)
+            fused = torch.cat((x12.transpose(1, 2).reshape(B, N, C), x21.transpose(1, 2).reshape(B, N, C)), dim=-1)
+        return self.proj_drop(self.proj(fused))

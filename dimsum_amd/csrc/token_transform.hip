@@ -1,0 +1,329 @@
+// token_transform.hip -- fused token-space transforms of the DiM blocks for gfx950 (see include/dimsum_hip.h).
+//
+// One pass over (batch, L = grid*grid tokens, C channels) fp32:
+//     v[s, c]  = x[b, in_index[s], c] * gate[b, c]
+//     t        = T(v) on every 4x4 token block  (identity | 2-level Haar | its inverse | 4x4 DCT-II | its inverse)
+//     y[b, out_index[s], c] = t[s, c] * (1 + scale[b, c]) + shift[b, c] + residual[b, out_index[s], c]
+// It replaces, per mixer call, the reference's chain of ~10 full-tensor passes: einops rearranges, flips, local_scan,
+// 8 grouped stride-2 convs + cats of the DWT, modulate, and the residual add (dimsum/models_dim.py:572-604, 656-705,
+// 876-928, 1496-1524; dimsum/wavelet_layer.py; dimsum/dct_layer.py). Streaming: 2 (3 with residual) tensors of traffic.
+//
+// Layout: a workgroup owns one 4x4 token block of one batch element; a thread owns 4 adjacent channels (16 B) of all
+// 16 tokens -- every global access is a coalesced 16-B-per-lane row segment; the transform is pure register
+// butterflies (Haar: 64 add/sub per channel; DCT: separable 2 x 16 x 4 FMA).
+//
+// Haar detail (WaveDiMBlock._dwt_fast): after the two DWT levels the reference concatenates the 16 subbands
+// band-major, shuffles them (i -> i%4*4 + i/4) and then regroups the flat (band, channel) axis as (channel', p1, p2):
+// output token p of the block, channel c' holds band q of input channel c with  q*C + c = c'*16 + p.  That regrouping
+// mixes channels across threads, so the coefficients go through an LDS image indexed by the flat j = q*C + c, stored
+// as [c'/4][p][c'%4] with 68-dword rows: 16-B reads by the storing thread (4 channels of one token) are conflict free.
+#include "common.hpp"
+
+namespace dimsum {
+
+constexpr int kTTThreads = 256;
+__device__ __forceinline__ int haar_lds(int j) {      // flat j = c'*16 + p  ->  LDS dword index
+    const int cp = j >> 4, p = j & 15;
+    return (cp >> 2) * 68 + p * 4 + (cp & 3);
+}
+
+// 2x2 Haar butterfly (wavelet_layer.py:8-22): (a b / c d) -> ll, lh (rows high-pass), hl, hh; each * 1/2
+__device__ __forceinline__ void haar2(float a, float b, float c, float d, float &ll, float &lh, float &hl, float &hh) {
+    const float p = a + b, q = a - b, r = c + d, s = c - d;
+    ll = (p + r) * 0.5f; lh = (p - r) * 0.5f; hl = (q + s) * 0.5f; hh = (q - s) * 0.5f;
+}
+// inverse (wavelet_layer.py:41-54)
+__device__ __forceinline__ void ihaar2(float ll, float lh, float hl, float hh, float &a, float &b, float &c, float &d) {
+    const float p = ll + lh, q = ll - lh, r = hl + hh, s = hl - hh;
+    a = (p + r) * 0.5f; b = (p - r) * 0.5f; c = (q + s) * 0.5f; d = (q - s) * 0.5f;
+}
+
+// X[y*4+x] (16 tokens of one channel) -> Y[q] with q = k1*4 + k2 (the shuffled list position), incl. the 1/4 scale
+__device__ __forceinline__ void haar_fwd16(const float *X, float *Y) {
+    float b1[4][4];   // [k1][i*2+j] first-level bands on the 2x2 grid of sub-blocks
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            haar2(X[(2 * i) * 4 + 2 * j], X[(2 * i) * 4 + 2 * j + 1], X[(2 * i + 1) * 4 + 2 * j], X[(2 * i + 1) * 4 + 2 * j + 1],
+                  b1[0][i * 2 + j], b1[1][i * 2 + j], b1[2][i * 2 + j], b1[3][i * 2 + j]);
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) {
+        float o[4];
+        haar2(b1[k1][0], b1[k1][1], b1[k1][2], b1[k1][3], o[0], o[1], o[2], o[3]);   // o[k2]
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) Y[k1 * 4 + k2] = o[k2] * 0.25f;
+    }
+}
+__device__ __forceinline__ void haar_inv16(const float *Y, float *X) {   // Y[q = k1*4 + k2] (already * 4)
+    float b1[4][4];
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1)
+        ihaar2(Y[k1 * 4 + 0], Y[k1 * 4 + 1], Y[k1 * 4 + 2], Y[k1 * 4 + 3], b1[k1][0], b1[k1][1], b1[k1][2], b1[k1][3]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            ihaar2(b1[0][i * 2 + j], b1[1][i * 2 + j], b1[2][i * 2 + j], b1[3][i * 2 + j], X[(2 * i) * 4 + 2 * j],
+                   X[(2 * i) * 4 + 2 * j + 1], X[(2 * i + 1) * 4 + 2 * j], X[(2 * i + 1) * 4 + 2 * j + 1]);
+}
+
+// 4-point DCT-II basis m[v][y] = c_v * cos((2y+1) v pi / 8) * sqrt(2/4)   (dct_layer.py:21-29: (2 C_v C_u / 4) cos cos)
+__device__ __forceinline__ void dct4(const float *in, int stride, float *out, int ostride, bool inverse) {
+    constexpr float kA = 0.5f;                    // sqrt(2/4) * (1/sqrt 2)
+    constexpr float kC1 = 0.6532814824381883f;    // sqrt(2/4) * cos(pi/8)
+    constexpr float kC2 = 0.5f;                   // sqrt(2/4) * cos(2 pi/8)
+    constexpr float kC3 = 0.2705980500730985f;    // sqrt(2/4) * cos(3 pi/8)
+    const float x0 = in[0], x1 = in[stride], x2 = in[2 * stride], x3 = in[3 * stride];
+    if (!inverse) {
+        const float s03 = x0 + x3, d03 = x0 - x3, s12 = x1 + x2, d12 = x1 - x2;
+        out[0] = kA * (s03 + s12);
+        out[ostride] = kC1 * d03 + kC3 * d12;
+        out[2 * ostride] = kC2 * (s03 - s12);
+        out[3 * ostride] = kC3 * d03 - kC1 * d12;
+    } else {      // transpose (orthonormal basis)
+        const float e = kA * x0 + kC2 * x2, f = kA * x0 - kC2 * x2, g = kC1 * x1 + kC3 * x3, h = kC3 * x1 - kC1 * x3;
+        out[0] = e + g;
+        out[ostride] = f + h;
+        out[2 * ostride] = f - h;
+        out[3 * ostride] = e - g;
+    }
+}
+__device__ __forceinline__ void dct16(const float *X, float *Y, bool inverse) {   // X[y*4+x] <-> Y[v*4+u]
+    float t[16];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dct4(X + r * 4, 1, t + r * 4, 1, inverse);       // along x (u)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dct4(t + c, 4, Y + c, 4, inverse);               // along y (v)
+}
+
+template <int KIND, int VEC>
+__global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsum_tt_params_t p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int C = p.channels, G = p.grid;
+    // 16 positions s of this workgroup: a 4x4 block of the grid (or 16 consecutive tokens when KIND == NONE)
+    int s_of[16];
+    if (KIND == DIMSUM_TT_NONE) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s_of[k] = blockIdx.x * 16 + k;
+    } else {
+        const int gb = G / 4, bh = blockIdx.x / gb, bw = blockIdx.x - bh * gb;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s_of[k] = (bh * 4 + (k >> 2)) * G + bw * 4 + (k & 3);
+    }
+    const float *xb = reinterpret_cast<const float *>(p.x_ptr) + (int64_t)b * p.x_batch_stride;
+    float *yb = reinterpret_cast<float *>(p.y_ptr) + (int64_t)b * p.y_batch_stride;
+    const float *rb = p.residual_ptr ? reinterpret_cast<const float *>(p.residual_ptr) + (int64_t)b * p.res_batch_stride : nullptr;
+    const float *gate = p.gate_ptr ? reinterpret_cast<const float *>(p.gate_ptr) + (int64_t)b * p.mod_batch_stride : nullptr;
+    const float *scale = p.scale_ptr ? reinterpret_cast<const float *>(p.scale_ptr) + (int64_t)b * p.mod_batch_stride : nullptr;
+    const float *shift = p.shift_ptr ? reinterpret_cast<const float *>(p.shift_ptr) + (int64_t)b * p.mod_batch_stride : nullptr;
+
+    auto load_vec = [&](const float *ptr, float *dst) {
+        if constexpr (VEC == 4) { const float4 t = *reinterpret_cast<const float4 *>(ptr); dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w; }
+        else dst[0] = *ptr;
+    };
+    auto store_out = [&](int k, int c, const float *val) {       // position k of the block, channels c..c+VEC-1
+        if (s_of[k] >= p.tokens) return;
+        const int tok = p.out_index_ptr ? p.out_index_ptr[s_of[k]] : s_of[k];
+        float o[VEC], t[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] = val[e];
+        if (scale) { load_vec(scale + c, t);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] *= 1.0f + t[e]; }
+        if (shift) { load_vec(shift + c, t);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] += t[e]; }
+        if (rb) { load_vec(rb + (int64_t)tok * p.res_token_stride + c, t);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] += t[e]; }
+        float *dst = yb + (int64_t)tok * p.y_token_stride + c;
+        if constexpr (VEC == 4) *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        else dst[0] = o[0];
+    };
+    auto load_in = [&](int k, int c, float *dst) {               // gated input of position k
+        if (s_of[k] >= p.tokens) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) dst[e] = 0.f;
+            return;
+        }
+        const int tok = p.in_index_ptr ? p.in_index_ptr[s_of[k]] : s_of[k];
+        load_vec(xb + (int64_t)tok * p.x_token_stride + c, dst);
+        if (gate) { float t[VEC]; load_vec(gate + c, t);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) dst[e] *= t[e]; }
+    };
+
+    if constexpr (KIND == DIMSUM_TT_HAAR_INV) {
+        // phase 1: the (token p, channel c') image goes to LDS at flat j = c'*16 + p
+        for (int c = tid * VEC; c < C; c += kTTThreads * VEC) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                float v[VEC];
+                load_in(k, c, v);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) lds[haar_lds((c + e) * 16 + k)] = v[e] * 4.0f;
+            }
+        }
+        __syncthreads();
+    }
+
+    for (int c = tid * VEC; c < C; c += kTTThreads * VEC) {
+        float X[VEC][16], Y[VEC][16];
+        if constexpr (KIND == DIMSUM_TT_HAAR_INV) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) Y[e][q] = lds[haar_lds(q * C + c + e)];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) haar_inv16(Y[e], X[e]);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { float o[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o[e] = X[e][k];
+                store_out(k, c, o); }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { float v[VEC]; load_in(k, c, v);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) X[e][k] = v[e]; }
+            if constexpr (KIND == DIMSUM_TT_HAAR_FWD) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) haar_fwd16(X[e], Y[e]);
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) lds[haar_lds(q * C + c + e)] = Y[e][q];
+            } else {
+                if constexpr (KIND == DIMSUM_TT_DCT_FWD || KIND == DIMSUM_TT_DCT_INV) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) dct16(X[e], Y[e], KIND == DIMSUM_TT_DCT_INV);
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { float o[VEC];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) o[e] = (KIND == DIMSUM_TT_NONE) ? X[e][k] : Y[e][k];
+                    store_out(k, c, o); }
+            }
+        }
+    }
+
+    if constexpr (KIND == DIMSUM_TT_HAAR_FWD) {
+        __syncthreads();
+        // phase 2: output token p, channels c'..c'+VEC-1 <- flat j = c'*16 + p  (16-byte LDS reads when VEC == 4)
+        for (int c = tid * VEC; c < C; c += kTTThreads * VEC) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                float o[VEC];
+                if constexpr (VEC == 4) {
+                    const float4 t = *reinterpret_cast<const float4 *>(&lds[(c >> 2) * 68 + k * 4]);
+                    o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+                } else {
+                    o[0] = lds[haar_lds(c * 16 + k)];
+                }
+                store_out(k, c, o);
+            }
+        }
+    }
+}
+
+template <int VEC>
+static int launch_tt(const dimsum_tt_params_t &p, hipStream_t s) {
+    const bool blocked = p.kind != DIMSUM_TT_NONE;
+    const int nblk = blocked ? (p.grid / 4) * (p.grid / 4) : (p.tokens + 15) / 16;
+    const dim3 grid(nblk, p.batch), block(kTTThreads);
+    const size_t lds = (p.kind == DIMSUM_TT_HAAR_FWD || p.kind == DIMSUM_TT_HAAR_INV) ? (size_t)((p.channels + 3) / 4) * 68 * 4 : 0;
+    if (lds > 160 * 1024) return DIMSUM_ERR_SHAPE;
+#define DIMSUM_TT(K) hipLaunchKernelGGL((token_transform_kernel<K, VEC>), grid, block, lds, s, p)
+    switch (p.kind) {
+        case DIMSUM_TT_NONE: DIMSUM_TT(DIMSUM_TT_NONE); break;
+        case DIMSUM_TT_HAAR_FWD: DIMSUM_TT(DIMSUM_TT_HAAR_FWD); break;
+        case DIMSUM_TT_HAAR_INV: DIMSUM_TT(DIMSUM_TT_HAAR_INV); break;
+        case DIMSUM_TT_DCT_FWD: DIMSUM_TT(DIMSUM_TT_DCT_FWD); break;
+        case DIMSUM_TT_DCT_INV: DIMSUM_TT(DIMSUM_TT_DCT_INV); break;
+        default: return DIMSUM_ERR_SHAPE;
+    }
+#undef DIMSUM_TT
+    return launch_status();
+}
+
+// ---- GatedMLP epilogue (mlp.py:66-70): h = gelu_tanh(x1) * x2 --------------------------------------------------------
+__device__ __forceinline__ float tanh_fast(float x) {           // tanh(x) = 1 - 2 / (exp(2x) + 1)
+    return 1.0f - 2.0f * fast_rcp(fast_exp(2.0f * x) + 1.0f);
+}
+__device__ __forceinline__ float gelu_tanh(float a) {
+    const float u = 0.7978845608028654f * (a + 0.044715f * a * a * a);
+    return 0.5f * a * (1.0f + tanh_fast(u));
+}
+__device__ __forceinline__ float gelu_tanh_grad(float a) {
+    const float u = 0.7978845608028654f * (a + 0.044715f * a * a * a);
+    const float t = tanh_fast(u);
+    return 0.5f * (1.0f + t) + 0.5f * a * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * a * a);
+}
+
+__global__ __launch_bounds__(256) void gated_gelu_fwd_kernel(const float *x12, float *h, int64_t rows, int64_t H) {
+    const int64_t n4 = rows * (H / 4);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / (H / 4), c = (i - r * (H / 4)) * 4;
+        const float4 a = *reinterpret_cast<const float4 *>(x12 + r * 2 * H + c);
+        const float4 g = *reinterpret_cast<const float4 *>(x12 + r * 2 * H + H + c);
+        *reinterpret_cast<float4 *>(h + r * H + c) = make_float4(gelu_tanh(a.x) * g.x, gelu_tanh(a.y) * g.y, gelu_tanh(a.z) * g.z, gelu_tanh(a.w) * g.w);
+    }
+}
+__global__ __launch_bounds__(256) void gated_gelu_bwd_kernel(const float *x12, const float *dh, float *dx12, int64_t rows, int64_t H) {
+    const int64_t n4 = rows * (H / 4);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / (H / 4), c = (i - r * (H / 4)) * 4;
+        const float4 a = *reinterpret_cast<const float4 *>(x12 + r * 2 * H + c);
+        const float4 g = *reinterpret_cast<const float4 *>(x12 + r * 2 * H + H + c);
+        const float4 d = *reinterpret_cast<const float4 *>(dh + r * H + c);
+        *reinterpret_cast<float4 *>(dx12 + r * 2 * H + c) = make_float4(d.x * g.x * gelu_tanh_grad(a.x), d.y * g.y * gelu_tanh_grad(a.y),
+                                                                       d.z * g.z * gelu_tanh_grad(a.z), d.w * g.w * gelu_tanh_grad(a.w));
+        *reinterpret_cast<float4 *>(dx12 + r * 2 * H + H + c) = make_float4(d.x * gelu_tanh(a.x), d.y * gelu_tanh(a.y), d.z * gelu_tanh(a.z), d.w * gelu_tanh(a.w));
+    }
+}
+
+}  // namespace dimsum
+
+extern "C" int dimsum_token_transform(const dimsum_tt_params_t *p, void *stream) {
+    using namespace dimsum;
+    if (!p || !p->x_ptr || !p->y_ptr) return DIMSUM_ERR_NULL;
+    if (p->batch < 0 || p->tokens <= 0 || p->channels <= 0) return DIMSUM_ERR_SHAPE;
+    if (p->kind != DIMSUM_TT_NONE && (p->grid % 4 != 0 || p->grid * p->grid != p->tokens)) return DIMSUM_ERR_SHAPE;
+    if (p->batch == 0) return DIMSUM_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    bool vec = p->channels % 4 == 0 && aligned_to<float>(p->x_ptr, 16) && aligned_to<float>(p->y_ptr, 16) &&
+               p->x_batch_stride % 4 == 0 && p->x_token_stride % 4 == 0 && p->y_batch_stride % 4 == 0 && p->y_token_stride % 4 == 0 &&
+               p->mod_batch_stride % 4 == 0 && (!p->gate_ptr || aligned_to<float>(p->gate_ptr, 16)) &&
+               (!p->scale_ptr || aligned_to<float>(p->scale_ptr, 16)) && (!p->shift_ptr || aligned_to<float>(p->shift_ptr, 16));
+    if (p->residual_ptr) vec = vec && aligned_to<float>(p->residual_ptr, 16) && p->res_batch_stride % 4 == 0 && p->res_token_stride % 4 == 0;
+    return vec ? launch_tt<4>(*p, s) : launch_tt<1>(*p, s);
+}
+
+extern "C" int dimsum_gated_gelu_fwd(const void *x12, void *h, int64_t rows, int64_t hidden, void *stream) {
+    using namespace dimsum;
+    if (!x12 || !h) return DIMSUM_ERR_NULL;
+    if (rows < 0 || hidden <= 0 || hidden % 4 != 0) return DIMSUM_ERR_SHAPE;
+    if (!aligned_to<float>(x12, 16) || !aligned_to<float>(h, 16)) return DIMSUM_ERR_STRIDE;
+    if (rows == 0) return DIMSUM_OK;
+    const int64_t n4 = rows * (hidden / 4);
+    const int grid = (int)((n4 + 255) / 256 < 256 * 16 ? (n4 + 255) / 256 : 256 * 16);
+    hipLaunchKernelGGL(gated_gelu_fwd_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float *>(x12), reinterpret_cast<float *>(h), rows, hidden);
+    return launch_status();
+}
+
+extern "C" int dimsum_gated_gelu_bwd(const void *x12, const void *dh, void *dx12, int64_t rows, int64_t hidden, void *stream) {
+    using namespace dimsum;
+    if (!x12 || !dh || !dx12) return DIMSUM_ERR_NULL;
+    if (rows < 0 || hidden <= 0 || hidden % 4 != 0) return DIMSUM_ERR_SHAPE;
+    if (!aligned_to<float>(x12, 16) || !aligned_to<float>(dh, 16) || !aligned_to<float>(dx12, 16)) return DIMSUM_ERR_STRIDE;
+    if (rows == 0) return DIMSUM_OK;
+    const int64_t n4 = rows * (hidden / 4);
+    const int grid = (int)((n4 + 255) / 256 < 256 * 16 ? (n4 + 255) / 256 : 256 * 16);
+    hipLaunchKernelGGL(gated_gelu_bwd_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float *>(x12), reinterpret_cast<const float *>(dh), reinterpret_cast<float *>(dx12), rows, hidden);
+    return launch_status();
+}

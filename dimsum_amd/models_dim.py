@@ -1,0 +1,599 @@
+"""DiM denoiser -- same module tree, constructor flags and state_dict keys as dimsum/models_dim.py
+(DiM :1557-1930, DiMBlockCombined :974-1117, DiMBlockCombinedFourier :1120-1264, DiMBlockRaw :1402-1529,
+WaveDiMBlock :505-710, DCTBlock :778-933, DiTBlock :1532-1554, embedders/FinalLayer :129-220, create_block :2001-2160,
+zoo :2163-2236), composed from the HIP operators of dimsum_amd.ops.
+
+What is structured differently (results equal to fp32 roundoff; pinned by tests/golden/*):
+  * every chain of token reorders (transpose, continuity flip, sequence flip, 4x4-window scan, zigzag) is composed at
+    construction into one gather table; the pre-mixer path  modulate(P(T(x)))  and the post-mixer path
+    x + T^-1(P^-1(gate * mixer(...)))  are each ONE fused pass (ops/token_ops.py), T = Haar / DCT / identity;
+  * the GatedMLP activation is a fused epilogue; RMSNorm is the HIP fused add+norm, not Triton.
+Out of scope (constructor raises): block types linear/window/combined_einfft, MoE, rope/cpe positional encodings and
+`enable_fourier_layers` -- unused by every published config.
+"""
+import math
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import scanning_orders as so
+from .attention_fusion import CrossAttentionFusion
+from .dct_layer import init_dct_kernel, init_idct_kernel
+from .mlp import GatedMLP
+from .modules.mamba_simple import CondMamba, Mamba
+from .ops import token_ops
+from .ops.layernorm import RMSNorm, layer_norm_fn, rms_norm_fn
+from .wavelet_layer import DWT_2D, IDWT_2D
+
+
+def modulate(x, shift, scale):
+    return x * (1 + scale.unsqueeze(1)) + shift.unsqueeze(1)
+
+
+# ---- fixed 2-D sin-cos positional embedding (models_dim.py:44-91, from MAE) ---------------------------------------------
+def get_1d_sincos_pos_embed_from_grid(embed_dim, pos):
+    omega = 1.0 / 10000 ** (np.arange(embed_dim // 2, dtype=np.float64) / (embed_dim / 2.0))
+    out = np.einsum("m,d->md", pos.reshape(-1), omega)
+    return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+
+def get_2d_sincos_pos_embed(embed_dim, grid_size):
+    gh = np.arange(grid_size, dtype=np.float32)
+    grid = np.stack(np.meshgrid(gh, gh), axis=0).reshape(2, 1, grid_size, grid_size)      # w first
+    return np.concatenate([get_1d_sincos_pos_embed_from_grid(embed_dim // 2, grid[0]),
+                           get_1d_sincos_pos_embed_from_grid(embed_dim // 2, grid[1])], axis=1)
+
+
+def interpolate_pos_embed(model, checkpoint_model):
+    """bicubic resize of a checkpoint's pos_embed to this model's grid (models_dim.py:99-121)."""
+    if "pos_embed" not in checkpoint_model:
+        return
+    pe = checkpoint_model["pos_embed"]
+    n_new = model.x_embedder.num_patches
+    extra = model.pos_embed.shape[-2] - n_new
+    old, new = int((pe.shape[-2] - extra) ** 0.5), int(n_new ** 0.5)
+    if old != new:
+        tok = pe[:, extra:].reshape(-1, old, old, pe.shape[-1]).permute(0, 3, 1, 2)
+        tok = torch.nn.functional.interpolate(tok, size=(new, new), mode="bicubic", align_corners=False)
+        checkpoint_model["pos_embed"] = torch.cat((pe[:, :extra], tok.permute(0, 2, 3, 1).flatten(1, 2)), dim=1)
+
+
+# ---- embedders ----------------------------------------------------------------------------------------------------------
+class PatchEmbed(nn.Module):
+    """timm 0.9.12 PatchEmbed as used at models_dim.py:1620: Conv2d(k = s = patch) -> (B, T, D)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, bias=True):
+        super().__init__()
+        self.img_size, self.patch_size = (img_size, img_size), (patch_size, patch_size)
+        self.grid_size = (img_size // patch_size, img_size // patch_size)
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size, bias=bias)
+        self.norm = nn.Identity()
+
+    def forward(self, x):
+        return self.proj(x).flatten(2).transpose(1, 2)
+
+
+class TimestepEmbedder(nn.Module):
+    def __init__(self, hidden_size, frequency_embedding_size=256):
+        super().__init__()
+        self.mlp = nn.Sequential(nn.Linear(frequency_embedding_size, hidden_size, bias=True), nn.SiLU(),
+                                 nn.Linear(hidden_size, hidden_size, bias=True))
+        self.frequency_embedding_size = frequency_embedding_size
+
+    @staticmethod
+    def timestep_embedding(t, dim, max_period=10000):
+        half = dim // 2
+        freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32) / half).to(t.device)
+        args = t[:, None].float() * freqs[None]
+        emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+        if dim % 2:
+            emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
+        return emb
+
+    def forward(self, t):
+        return self.mlp(self.timestep_embedding(t, self.frequency_embedding_size))
+
+
+class LabelEmbedder(nn.Module):
+    """class embedding with label dropout for classifier-free guidance (models_dim.py:170-202)."""
+
+    def __init__(self, num_classes, hidden_size, dropout_prob):
+        super().__init__()
+        self.in_channels = num_classes + int(dropout_prob > 0)
+        self.embedding_table = nn.Embedding(self.in_channels, hidden_size)
+        self.num_classes, self.dropout_prob = num_classes, dropout_prob
+
+    def token_drop(self, labels, force_drop_ids=None):
+        drop = torch.rand(labels.shape[0], device=labels.device) < self.dropout_prob if force_drop_ids is None else force_drop_ids == 1
+        return torch.where(drop, self.num_classes, labels)
+
+    def forward(self, labels, train, force_drop_ids=None):
+        if (train and self.dropout_prob > 0) or force_drop_ids is not None:
+            labels = self.token_drop(labels, force_drop_ids)
+        return self.embedding_table(labels)
+
+    def get_in_channels(self):
+        return self.in_channels
+
+
+class FinalLayer(nn.Module):
+    def __init__(self, hidden_size, patch_size, out_channels):
+        super().__init__()
+        self.norm_final = nn.LayerNorm(hidden_size, elementwise_affine=False, eps=1e-6)
+        self.linear = nn.Linear(hidden_size, patch_size * patch_size * out_channels, bias=True)
+        self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(hidden_size, 2 * hidden_size, bias=True))
+
+    def forward(self, x, c):
+        shift, scale = self.adaLN_modulation(c).chunk(2, dim=1)
+        return self.linear(modulate(self.norm_final(x), shift, scale))
+
+
+class Attention(nn.Module):
+    """timm 0.9.12 vision_transformer.Attention (qkv -> SDPA -> proj), as used by DiTBlock (models_dim.py:1540)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, **_):
+        super().__init__()
+        self.num_heads, self.head_dim = num_heads, dim // num_heads
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        q, k, v = self.qkv(x).reshape(B, N, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4).unbind(0)
+        x = torch.nn.functional.scaled_dot_product_attention(q, k, v)
+        return self.proj(x.transpose(1, 2).reshape(B, N, C))
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
+def drop_path(x, drop_prob=0.0, training=False, scale_by_keep=True):
+    if drop_prob == 0.0 or not training:
+        return x
+    keep = 1 - drop_prob
+    mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+    if keep > 0.0 and scale_by_keep:
+        mask.div_(keep)
+    return x * mask
+
+
+class DropPath(nn.Module):
+    def __init__(self, drop_prob=0.0, scale_by_keep=True):
+        super().__init__()
+        self.drop_prob, self.scale_by_keep = drop_prob, scale_by_keep
+
+    def forward(self, x):
+        return drop_path(x, self.drop_prob, self.training, self.scale_by_keep)
+
+
+_approx_gelu = lambda: nn.GELU(approximate="tanh")  # noqa: E731
+
+
+def _make_mlp(dim, use_gated_mlp=True):
+    cls = GatedMLP if use_gated_mlp else Mlp
+    return cls(in_features=dim, hidden_features=int(dim * 4), act_layer=_approx_gelu, drop=0)
+
+
+# ---- shared block plumbing ----------------------------------------------------------------------------------------------
+class _BlockBase(nn.Module):
+    """Add -> Norm prologue shared by all blocks (e.g. models_dim.py:1460-1494) + cached gather tables."""
+
+    def _prenorm(self, hidden_states, residual):
+        if not self.fused_add_norm:
+            residual = hidden_states if residual is None else residual + self.drop_path(hidden_states)
+            hidden_states = (self.norm(residual) if isinstance(self.norm, nn.Identity)
+                             else self.norm(residual.to(dtype=self.norm.weight.dtype)))
+            if self.residual_in_fp32:
+                residual = residual.to(torch.float32)
+            return hidden_states, residual
+        fn = rms_norm_fn if isinstance(self.norm, RMSNorm) else layer_norm_fn
+        x = hidden_states if residual is None else self.drop_path(hidden_states)
+        return fn(x, self.norm.weight, self.norm.bias, residual=residual, prenorm=True,
+                  residual_in_fp32=self.residual_in_fp32, eps=self.norm.eps)
+
+    def _table(self, L, device, build):
+        """gather tables for sequence length L, built once per (L, device): fwd (int64), inv (int64), inv32 (int32)"""
+        cache = self.__dict__.setdefault("_tables", {})
+        key = (L, str(device))
+        if key not in cache:
+            fwd = build(math.isqrt(L))
+            if fwd is None:
+                cache[key] = None
+            else:
+                inv = so.reverse_permut_np(fwd)
+                cache[key] = {"fwd": so.as_index(fwd, device), "inv": so.as_index(inv, device),
+                              "inv32": torch.as_tensor(inv.astype(np.int32), device=device)}
+        return cache[key]
+
+    def allocate_inference_cache(self, *a, **k):
+        raise NotImplementedError("autoregressive decode caches are outside the denoiser hot path")
+
+
+class DiMBlockRaw(_BlockBase):
+    """spatial Mamba branch: reorder -> h + gate * mixer(modulate(h)) -> undo (models_dim.py:1402-1529)."""
+
+    def __init__(self, dim, mixer_cls, norm_cls=nn.LayerNorm, fused_add_norm=False, residual_in_fp32=False, drop_path=0.0,
+                 reverse=False, transpose=False, scanning_continuity=False, c_dim=None):
+        super().__init__()
+        self.residual_in_fp32, self.fused_add_norm = residual_in_fp32, fused_add_norm
+        self.reverse, self.transpose, self.scanning_continuity = reverse, transpose, scanning_continuity
+        c_dim = dim if c_dim is None else c_dim
+        self.mixer = mixer_cls(dim)
+        self.norm = norm_cls(dim)
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(c_dim, 3 * dim, bias=True))
+
+    def _order(self, H):
+        if not (self.reverse or self.transpose or self.scanning_continuity):
+            return None
+        return so.block_order_table(H, self.reverse, self.transpose, self.scanning_continuity)
+
+    def forward(self, hidden_states, residual=None, c=None, inference_params=None):
+        hidden_states, residual = self._prenorm(hidden_states, residual)
+        table = self._table(hidden_states.shape[1], hidden_states.device, self._order)
+        shift, scale, gate = self.adaLN_modulation(c).chunk(3, dim=1)
+        m = self.mixer(token_ops.pre_mixer(hidden_states, "none", table, shift, scale), c)
+        return token_ops.post_mixer(hidden_states, m, gate, "none", table), residual
+
+
+class _FreqBlock(_BlockBase):
+    """frequency branch shared by WaveDiMBlock (Haar) and DCTBlock (DCT): T -> reorder -> mixer -> undo -> T^-1."""
+    kind = "none"
+
+    def _init_common(self, dim, mixer_cls, norm_cls, fused_add_norm, residual_in_fp32, drop_path, reverse, transpose,
+                     scanning_continuity, no_ffn, c_dim):
+        self.residual_in_fp32, self.fused_add_norm = residual_in_fp32, fused_add_norm
+        self.reverse, self.transpose, self.scanning_continuity, self.no_ffn = reverse, transpose, scanning_continuity, no_ffn
+        self._c_dim = dim if c_dim is None else c_dim
+
+    def _finish_common(self, dim, norm_cls, drop_path):
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(self._c_dim, 6 * dim if not self.no_ffn else 3 * dim, bias=True))
+        if not self.no_ffn:
+            self.norm_2 = norm_cls(dim)
+            self.mlp = _make_mlp(dim)
+
+    def forward(self, hidden_states, residual=None, c=None, inference_params=None):
+        hidden_states, residual = self._prenorm(hidden_states, residual)
+        table = self._table(hidden_states.shape[1], hidden_states.device, self._order)
+        mods = self.adaLN_modulation(c).chunk(3 if self.no_ffn else 6, dim=1)
+        shift, scale, gate = mods[:3]
+        if self.no_ffn:
+            m = self.mixer(token_ops.pre_mixer(hidden_states, self.kind, table, shift, scale), c)
+            return token_ops.post_mixer(hidden_states, m, gate, self.kind, table), residual
+        # with an FFN the reference keeps working in the transformed / reordered token space (models_dim.py:678-684)
+        t = token_ops.pre_mixer(hidden_states, self.kind, table, torch.zeros_like(shift), torch.zeros_like(scale))
+        t = t + gate.unsqueeze(1) * self.mixer(modulate(t, shift, scale), c)
+        t = t + mods[5].unsqueeze(1) * self.mlp(modulate(self.norm_2(t), mods[3], mods[4]))
+        zero = torch.zeros_like(hidden_states)
+        return token_ops.post_mixer(zero, t, torch.ones_like(gate), self.kind, table), residual
+
+
+class WaveDiMBlock(_FreqBlock):
+    """2-level Haar branch (models_dim.py:505-710)."""
+    kind = "haar"
+
+    def __init__(self, dim, mixer_cls, norm_cls=nn.LayerNorm, fused_add_norm=False, residual_in_fp32=False, drop_path=0.0,
+                 reverse=False, transpose=False, scanning_continuity=False, skip=False, no_ffn=False, c_dim=None,
+                 window_scan=True, num_wavelet_lv=2):
+        super().__init__()
+        assert num_wavelet_lv == 2, "only the two-level transform of the published configs is implemented"
+        self._init_common(dim, mixer_cls, norm_cls, fused_add_norm, residual_in_fp32, drop_path, reverse, transpose,
+                          scanning_continuity, no_ffn, c_dim)
+        self.window_scan, self.num_wavelet_lv = window_scan, num_wavelet_lv
+        self.mixer = mixer_cls(dim)
+        self.norm = norm_cls(dim)
+        self.dwt, self.idwt = DWT_2D(wave="haar"), IDWT_2D(wave="haar")
+        self._finish_common(dim, norm_cls, drop_path)
+
+    def _order(self, H):
+        if self.window_scan:      # local_scan(w = W // 4, column_first = transpose)  (models_dim.py:659-664)
+            tab = so.local_scan_table(H, H // 4, column_first=bool(self.transpose))
+        else:
+            tab = so.block_order_table(H, False, self.transpose, False)
+        return so.compose(tab, so.block_order_table(H, self.reverse, False, self.scanning_continuity))
+
+
+class DCTBlock(_FreqBlock):
+    """4x4 block-DCT branch (models_dim.py:778-933)."""
+    kind = "dct"
+
+    def __init__(self, dim, mixer_cls, fused_add_norm=False, residual_in_fp32=False, drop_path=0.0, norm_cls=nn.LayerNorm,
+                 dct_size=2, reverse=False, transpose=False, scanning_continuity=False, no_ffn=False, c_dim=None):
+        super().__init__()
+        assert dct_size == 4, "only the 4x4 DCT of DiMBlockCombinedFourier is implemented"
+        self._init_common(dim, mixer_cls, norm_cls, fused_add_norm, residual_in_fp32, drop_path, reverse, transpose,
+                          scanning_continuity, no_ffn, c_dim)
+        self.dim, self.dct_size, self.reserve_kernel = dim, dct_size, dct_size
+        self.norm = norm_cls(dim)
+        self.mixer = mixer_cls(dim)
+        self._finish_common(dim, norm_cls, drop_path)
+        self.dct_conv = init_dct_kernel(dim, dct_size, dct_size)
+        self.idct_conv = nn.Sequential(init_idct_kernel(dim, dct_size, dct_size), nn.PixelShuffle(dct_size))
+
+    def _order(self, H):
+        if not (self.reverse or self.transpose or self.scanning_continuity):
+            return None
+        return so.block_order_table(H, self.reverse, self.transpose, self.scanning_continuity)
+
+
+class _CombinedBase(_BlockBase):
+    def _init_tail(self, dim, norm_cls, drop_path, use_gated_mlp, swap_k_kw):
+        self.proj = CrossAttentionFusion(dim, num_heads=8, qkv_bias=True, **swap_k_kw)
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.norm_2 = norm_cls(dim)
+        self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(dim, 3 * dim, bias=True))
+        self.mlp = _make_mlp(dim, use_gated_mlp)
+
+    def forward(self, hidden_states, residual=None, c=None, inference_params=None):
+        hidden_states, residual = self._prenorm(hidden_states, residual)
+        x1, x2 = hidden_states.chunk(2, dim=2)
+        x1, _ = self.spatial_mamba(x1, None, c, inference_params)
+        x2, _ = self.freq_mamba(x2, None, c, inference_params)
+        hidden_states = hidden_states + self.proj(x1, x2)
+        shift, scale, gate = self.adaLN_modulation(c).chunk(3, dim=1)
+        hidden_states = hidden_states + gate.unsqueeze(1) * self.mlp(modulate(self.norm_2(hidden_states), shift, scale))
+        return hidden_states, residual
+
+
+class DiMBlockCombined(_CombinedBase):
+    """spatial Mamba || Haar-frequency Mamba -> cross-attention fusion -> gated MLP (models_dim.py:974-1117)."""
+
+    def __init__(self, dim, mixer_cls, norm_cls=nn.LayerNorm, fused_add_norm=False, residual_in_fp32=False, drop_path=0.0,
+                 reverse=False, transpose=False, scanning_continuity=False, use_gated_mlp=True):
+        super().__init__()
+        self.residual_in_fp32, self.fused_add_norm = residual_in_fp32, fused_add_norm
+        self.reverse, self.transpose, self.scanning_continuity = reverse, transpose, scanning_continuity
+        self.norm = norm_cls(dim)
+        kw = dict(norm_cls=nn.Identity, drop_path=0.0, fused_add_norm=False, residual_in_fp32=residual_in_fp32,
+                  scanning_continuity=scanning_continuity, c_dim=dim)
+        self.spatial_mamba = DiMBlockRaw(dim // 2, mixer_cls, reverse=reverse, transpose=transpose, **kw)
+        self.freq_mamba = WaveDiMBlock(dim // 2, mixer_cls, reverse=False, transpose=reverse, no_ffn=True, num_wavelet_lv=2, **kw)
+        self._init_tail(dim, norm_cls, drop_path, use_gated_mlp, dict(swap_k=False))
+
+
+class DiMBlockCombinedFourier(_CombinedBase):
+    """spatial Mamba || DCT-frequency Mamba (jpeg_2 zigzag mixer) (models_dim.py:1120-1264)."""
+
+    def __init__(self, dim, mixer_cls, mixer_cls_2, norm_cls=nn.LayerNorm, fused_add_norm=False, residual_in_fp32=False,
+                 drop_path=0.0, reverse=False, transpose=False, scanning_continuity=False, use_gated_mlp=True):
+        super().__init__()
+        self.residual_in_fp32, self.fused_add_norm = residual_in_fp32, fused_add_norm
+        self.reverse, self.transpose, self.scanning_continuity = reverse, transpose, scanning_continuity
+        self.norm = norm_cls(dim)
+        kw = dict(norm_cls=nn.Identity, drop_path=0.0, fused_add_norm=False, residual_in_fp32=residual_in_fp32,
+                  scanning_continuity=scanning_continuity, c_dim=dim)
+        self.spatial_mamba = DiMBlockRaw(dim // 2, mixer_cls, reverse=reverse, transpose=transpose, **kw)
+        self.freq_mamba = DCTBlock(dim // 2, mixer_cls_2, reverse=False, transpose=False, no_ffn=True, dct_size=4, **kw)
+        self._init_tail(dim, norm_cls, drop_path, use_gated_mlp, {})
+
+
+class DiTBlock(nn.Module):
+    """adaLN-Zero transformer block shared every k layers (models_dim.py:1532-1554)."""
+
+    def __init__(self, hidden_size, num_heads, mlp_ratio=4.0, use_gated_mlp=True, **block_kwargs):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(hidden_size, elementwise_affine=False, eps=1e-6)
+        self.attn = Attention(hidden_size, num_heads=num_heads, qkv_bias=True, **block_kwargs)
+        self.norm2 = nn.LayerNorm(hidden_size, elementwise_affine=False, eps=1e-6)
+        cls = GatedMLP if use_gated_mlp else Mlp
+        self.mlp = cls(in_features=hidden_size, hidden_features=int(hidden_size * mlp_ratio), act_layer=_approx_gelu, drop=0)
+        self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(hidden_size, 6 * hidden_size, bias=True))
+
+    def forward(self, x, c=None, **kwargs):
+        sa, ca, ga, sm, cm, gm = self.adaLN_modulation(c).chunk(6, dim=1)
+        x = x + ga.unsqueeze(1) * self.attn(modulate(self.norm1(x), sa, ca))
+        return x + gm.unsqueeze(1) * self.mlp(modulate(self.norm2(x), sm, cm))
+
+
+def _init_weights(module, n_layer, initializer_range=0.02, rescale_prenorm_residual=True, n_residuals_per_layer=1):
+    """GPT-2 style init (models_dim.py:1969-1998): zero Linear biases (except dt_proj), scaled out_proj/fc2."""
+    if isinstance(module, nn.Linear):
+        if module.bias is not None and not getattr(module.bias, "_no_reinit", False):
+            nn.init.zeros_(module.bias)
+    elif isinstance(module, nn.Embedding):
+        nn.init.normal_(module.weight, std=initializer_range)
+    if rescale_prenorm_residual:
+        for name, p in module.named_parameters():
+            if name in ("out_proj.weight", "fc2.weight"):
+                nn.init.kaiming_uniform_(p, a=math.sqrt(5))
+                with torch.no_grad():
+                    p /= math.sqrt(n_residuals_per_layer * n_layer)
+
+
+def create_block(d_model, ssm_cfg=None, norm_epsilon=1e-5, drop_path=0.0, rms_norm=False, residual_in_fp32=True,
+                 fused_add_norm=False, layer_idx=None, device=None, dtype=None, scan_type="none", add_bias_linear=False,
+                 gated_linear_unit=True, routing_mode="sinkhorn", num_moe_experts=8, mamba_moe_layers=None, is_moe=False,
+                 block_type="linear", reverse=False, transpose=False, cond_mamba=False, scanning_continuity=False,
+                 skip=False, use_gated_mlp=True, block_kwargs={}, block_kwargs2={}):
+    if is_moe:
+        raise NotImplementedError("MoE blocks are outside the denoiser hot path (never enabled by a published config)")
+    ssm_cfg = ssm_cfg or {}
+    fk = {"device": device, "dtype": dtype}
+    norm_cls = partial(nn.LayerNorm if not rms_norm else RMSNorm, eps=norm_epsilon, **fk)
+    if cond_mamba:
+        # the reference passes scan_type twice here when block_kwargs carries one (SURVEY finding 2); block_kwargs wins
+        kw = dict(layer_idx=layer_idx, scan_type=scan_type, d_cond=d_model, **ssm_cfg, **fk)
+        kw.update(block_kwargs)
+        mixer_cls = partial(CondMamba, **kw)
+    else:
+        mixer_cls = partial(Mamba, layer_idx=layer_idx, scan_type=scan_type, **ssm_cfg, **fk)
+    common = dict(norm_cls=norm_cls, drop_path=drop_path, fused_add_norm=fused_add_norm, residual_in_fp32=residual_in_fp32,
+                  scanning_continuity=scanning_continuity)
+    if block_type == "raw":
+        block = DiMBlockRaw(d_model, mixer_cls, reverse=reverse, transpose=transpose, **common)
+    elif block_type == "wave":
+        block = WaveDiMBlock(d_model, mixer_cls, reverse=reverse, transpose=transpose, skip=skip, window_scan=False, **common)
+    elif block_type == "combined":
+        block = DiMBlockCombined(d_model, mixer_cls, reverse=reverse, transpose=transpose, use_gated_mlp=use_gated_mlp, **common)
+    elif block_type == "combined_fourier":
+        mixer_cls_2 = partial(CondMamba, layer_idx=layer_idx, d_cond=d_model, **ssm_cfg, **block_kwargs2, **fk)
+        block = DiMBlockCombinedFourier(d_model, mixer_cls, mixer_cls_2, reverse=reverse, transpose=transpose,
+                                        use_gated_mlp=use_gated_mlp, **common)
+    else:
+        raise NotImplementedError(f"block_type={block_type!r} is outside the denoiser hot path "
+                                  "(published configs use 'combined'; also available: raw, wave, combined_fourier)")
+    block.layer_idx = layer_idx
+    return block
+
+
+class DiM(nn.Module):
+    def __init__(self, img_resolution=32, patch_size=2, in_channels=4, hidden_size=1024, depth=16, label_dropout=0.1,
+                 num_classes=1000, learn_sigma=False, ssm_cfg=None, rms_norm=False, residual_in_fp32=True,
+                 fused_add_norm=False, scan_type="none", initializer_cfg=None, num_moe_experts=8, mamba_moe_layers=None,
+                 add_bias_linear=False, gated_linear_unit=True, routing_mode="top1", is_moe=False, pe_type="ape",
+                 block_type="linear", cond_mamba=False, scanning_continuity=False, enable_fourier_layers=False,
+                 learnable_pe=False, skip=False, drop_path=0.0, use_final_norm=False, use_attn_every_k_layers=-1,
+                 use_gated_mlp=True, use_independent_attn=False):
+        super().__init__()
+        if pe_type != "ape":
+            raise NotImplementedError("only the absolute positional embedding of the published configs is implemented")
+        if enable_fourier_layers:
+            raise NotImplementedError("enable_fourier_layers is broken in the reference (models_dim.py:1702) and unused")
+        self.depth = int(depth * 3) if block_type == "raw" else depth
+        self.learn_sigma, self.in_channels = learn_sigma, in_channels
+        self.out_channels = in_channels * 2 if learn_sigma else in_channels
+        self.patch_size, self.num_classes, self.initializer_cfg = patch_size, num_classes, initializer_cfg
+        self.enable_fourier_layers, self.fused_add_norm, self.residual_in_fp32 = False, fused_add_norm, residual_in_fp32
+        self.use_attn_every_k_layers, self.use_independent_attn = use_attn_every_k_layers, use_independent_attn
+        self.pe_type, self.block_type = pe_type, block_type
+        if use_independent_attn:
+            n_tb = self.depth // use_attn_every_k_layers - 1
+            self.depth = self.depth - self.depth // use_attn_every_k_layers
+
+        self.x_embedder = PatchEmbed(img_resolution, patch_size, in_channels, hidden_size)
+        self.t_embedder = TimestepEmbedder(hidden_size)
+        self.y_embedder = LabelEmbedder(num_classes, hidden_size, label_dropout)
+        num_patches = self.x_embedder.num_patches
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches, hidden_size), requires_grad=learnable_pe)
+        dpr = [x.item() for x in torch.linspace(0, drop_path, self.depth, device="cpu")]
+        inter_dpr = [0.0] + dpr
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        grid = int(math.sqrt(num_patches))
+
+        def gen_paths(N, st):           # models_dim.py:1640-1658
+            kind, n = st.split("_")[0], int(st.split("_")[1])
+            zz = so.SCAN_ZOO[kind](N)[:n]
+            rev = [so.reverse_permut_np(p) for p in zz]
+            return dict(zigzag_paths=torch.cat([torch.from_numpy(p)[None] for p in zz] * self.depth, dim=0),
+                        zigzag_paths_reverse=torch.cat([torch.from_numpy(p)[None] for p in rev] * self.depth, dim=0),
+                        scan_type=st)
+
+        block_kwargs = gen_paths(grid, scan_type) if scan_type.startswith(("zigma", "sweep", "jpeg")) else {}
+        block_kwargs2 = gen_paths(grid, "jpeg_2")       # fixed (models_dim.py:1664)
+        self.blocks = nn.ModuleList([
+            create_block(hidden_size, ssm_cfg=ssm_cfg, norm_epsilon=1e-5, rms_norm=rms_norm, residual_in_fp32=residual_in_fp32,
+                         fused_add_norm=fused_add_norm, layer_idx=i, scan_type=scan_type, drop_path=inter_dpr[i],
+                         num_moe_experts=num_moe_experts, mamba_moe_layers=mamba_moe_layers, add_bias_linear=add_bias_linear,
+                         gated_linear_unit=gated_linear_unit, routing_mode=routing_mode, is_moe=is_moe, block_type=block_type,
+                         reverse=(scan_type == "none") and (i % 2 > 0), transpose=(scan_type == "none") and (i % 4 >= 2),
+                         cond_mamba=cond_mamba, scanning_continuity=scanning_continuity, use_gated_mlp=use_gated_mlp,
+                         block_kwargs=block_kwargs, block_kwargs2=block_kwargs2)
+            for i in range(self.depth)])
+        if use_attn_every_k_layers > 0:
+            if use_independent_attn:
+                self.attn_block = nn.ModuleList([DiTBlock(hidden_size, 16, use_gated_mlp=use_gated_mlp) for _ in range(n_tb)])
+            else:
+                self.attn_block = DiTBlock(hidden_size, 16, use_gated_mlp=use_gated_mlp)
+        self.norm_f = (nn.LayerNorm if not rms_norm else RMSNorm)(hidden_size, eps=1e-5) if use_final_norm else None
+        self.final_layer = FinalLayer(hidden_size, patch_size, self.out_channels)
+        self.initialize_weights()
+
+    def initialize_weights(self):
+        """models_dim.py:1744-1779 (adaLN-zero: a freshly initialised model outputs exactly 0)."""
+        pe = get_2d_sincos_pos_embed(self.pos_embed.shape[-1], int(self.x_embedder.num_patches ** 0.5))
+        self.pos_embed.data.copy_(torch.from_numpy(pe).float().unsqueeze(0))
+        w = self.x_embedder.proj.weight.data
+        nn.init.xavier_uniform_(w.view([w.shape[0], -1]))
+        nn.init.constant_(self.x_embedder.proj.bias, 0)
+        nn.init.normal_(self.y_embedder.embedding_table.weight, std=0.02)
+        nn.init.normal_(self.t_embedder.mlp[0].weight, std=0.02)
+        nn.init.normal_(self.t_embedder.mlp[2].weight, std=0.02)
+        for block in self.blocks:
+            nn.init.constant_(block.adaLN_modulation[-1].weight, 0)
+            nn.init.constant_(block.adaLN_modulation[-1].bias, 0)
+        nn.init.constant_(self.final_layer.adaLN_modulation[-1].weight, 0)
+        nn.init.constant_(self.final_layer.adaLN_modulation[-1].bias, 0)
+        nn.init.constant_(self.final_layer.linear.weight, 0)
+        nn.init.constant_(self.final_layer.linear.bias, 0)
+        self.apply(partial(_init_weights, n_layer=self.depth, **(self.initializer_cfg or {})))
+
+    def unpatchify(self, x):
+        c, p = self.out_channels, self.x_embedder.patch_size[0]
+        h = w = int(x.shape[1] ** 0.5)
+        assert h * w == x.shape[1]
+        x = x.reshape(x.shape[0], h, w, p, p, c)
+        return torch.einsum("nhwpqc->nchpwq", x).reshape(x.shape[0], c, h * p, h * p)
+
+    def forward(self, x, t, y=None, inference_params=None, **kwargs):
+        """x: (N, C, H, W) latents, t: (N,) times, y: (N,) labels -> (N, out_channels, H, W)."""
+        if t is None:
+            t = torch.randint(0, 1000, (x.shape[0],), device=x.device)
+        if y is None:
+            y = torch.ones(x.size(0), dtype=torch.long, device=x.device) * (self.y_embedder.get_in_channels() - 1)
+        c = self.t_embedder(t) + self.y_embedder(y, self.training)
+        x = self.x_embedder(x) + self.pos_embed
+        residual = None
+        for idx, block in enumerate(self.blocks):
+            x, residual = block(x, residual, c, inference_params=inference_params)
+            if self.use_attn_every_k_layers > 0 and (idx + 1) % self.use_attn_every_k_layers == 0:
+                if self.use_independent_attn:
+                    x = self.attn_block[(idx + 1) // self.use_attn_every_k_layers - 1](x, c)
+                else:
+                    x = self.attn_block(x, c)
+        if self.norm_f is not None:
+            if not self.fused_add_norm:
+                residual = x if residual is None else residual + self.drop_path(x)
+                x = self.norm_f(residual.to(dtype=self.norm_f.weight.dtype))
+            else:
+                fn = rms_norm_fn if isinstance(self.norm_f, RMSNorm) else layer_norm_fn
+                x = fn(self.drop_path(x), self.norm_f.weight, self.norm_f.bias, eps=self.norm_f.eps, residual=residual,
+                       prenorm=False, residual_in_fp32=self.residual_in_fp32)
+        return self.unpatchify(self.final_layer(x, c))
+
+    def forward_with_cfg(self, x, t, y=None, inference_params=None, cfg_scale=1.0, **kwargs):
+        """classifier-free guidance on a [cond | uncond] batch (models_dim.py:1886-1902)."""
+        half = x[: len(x) // 2]
+        out = self.forward(torch.cat([half, half], dim=0), t, y, inference_params)
+        eps, rest = out[:, : self.in_channels], out[:, self.in_channels:]
+        cond, uncond = torch.split(eps, len(eps) // 2, dim=0)
+        g = uncond + cfg_scale * (cond - uncond)
+        return torch.cat([torch.cat([g, g], dim=0), rest], dim=1)
+
+    def forward_with_adacfg(self, x, t, y=None, inference_params=None, cfg_scale=3.8, scale_pow=4.0, **kwargs):
+        """time-dependent (power-cosine) guidance scale (models_dim.py:1904-1924)."""
+        if cfg_scale is None:
+            return self.forward(x, t, y, inference_params)
+        half = x[: len(x) // 2]
+        out = self.forward(torch.cat([half, half], dim=0), t, y, inference_params)
+        eps, rest = out[:, : self.in_channels], out[:, self.in_channels:]
+        cond, uncond = torch.split(eps, len(eps) // 2, dim=0)
+        step = (1 - torch.cos(((1 - t) ** scale_pow) * math.pi)) / 2
+        s = ((cfg_scale - 1) * step + 1)[: len(x) // 2].view(-1, 1, 1, 1)
+        g = uncond + s * (cond - uncond)
+        return torch.cat([torch.cat([g, g], dim=0), rest], dim=1)
+
+
+def _zoo(depth, hidden_size, patch_size):
+    def make(**kwargs):
+        return DiM(depth=depth, hidden_size=hidden_size, patch_size=patch_size, initializer_cfg=None, ssm_cfg=None, **kwargs)
+    return make
+
+
+DiM_XL_2, DiM_L_2, DiM_L_2_v1 = _zoo(24, 1152, 2), _zoo(16, 1024, 2), _zoo(20, 1024, 2)
+DiM_B_2, DiM_L_4, DiM_L_4_v1 = _zoo(12, 768, 2), _zoo(16, 1024, 4), _zoo(20, 1024, 4)
+DiM_S_2 = _zoo(12, 384, 2)      # not in the reference zoo: DiT-S analogy used by BASELINE config 1 (SURVEY finding 6)
+
+DiM_models = {"DiM-XL/2": DiM_XL_2, "DiM-L/2": DiM_L_2, "DiM-L/2-v1": DiM_L_2_v1, "DiM-B/2": DiM_B_2,
+              "DiM-L/4": DiM_L_4, "DiM-L/4-v1": DiM_L_4_v1, "DiM-S/2": DiM_S_2}

@@ -140,7 +140,7 @@ def causal_conv1d_fwd(x, weight, bias, silu_activation, out=None):
     weight = weight.float()
     bias = bias.float().contiguous() if bias is not None else None
     if out is None:
-        out = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+        out = torch.empty_like(x)       # inherits x's layout like the reference (causal_conv1d.cpp:262): d-major in Mamba
     if x.numel() > 0:
         P = _lib.ConvParams()
         _fill_conv(P, x, weight, bias, silu_activation, out)
@@ -245,3 +245,143 @@ def layer_norm_bwd(dy, x, weight, bias, eps, mean, rstd, dresidual=None, has_res
     if has_residual:
         dresidual_in = dx if dx.dtype == x.dtype else dx32.to(x.dtype)
     return dx, dw.to(weight.dtype), db.to(bias.dtype) if bias is not None else None, dresidual_in
+
+
+def selective_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, dz, delta_softplus, recompute_out_z):
+    """-> [du, ddelta, dA, dB, dC, dD, ddelta_bias, (dz), (out_z)] exactly like selective_scan_cuda.bwd
+    (selective_scan.cpp:338-492). dz may be a caller-provided view (fused chunk backward, :433-441)."""
+    _check_ssm(u, delta, A, B, C, D, z, delta_bias)
+    _gpu(dout, x, out, dz)
+    batch, dim, seqlen = u.shape
+    _check(tuple(dout.shape) == (batch, dim, seqlen) and dout.dtype == u.dtype and (dout.stride(-1) == 1 or seqlen == 1),
+           "selective_scan_bwd: bad dout")
+    has_z = z is not None
+    if has_z:
+        _check(out is not None and out.shape == u.shape and out.stride(-1) == 1, "selective_scan_bwd: `out` of the forward is required with z")
+        if dz is None:
+            dz = torch.empty_like(z)
+        else:
+            _check(dz.shape == z.shape and dz.dtype == z.dtype and dz.stride(-1) == 1, "selective_scan_bwd: bad dz")
+    out_z = torch.empty_like(out) if (has_z and recompute_out_z) else None
+    du = torch.empty_like(u)
+    ddelta = torch.empty_like(delta)
+    dA = torch.zeros_like(A)
+    dB = torch.zeros(B.shape, device=u.device, dtype=torch.float32)      # fp32 accumulate then cast (cpp:461-462,488)
+    dC = torch.zeros(C.shape, device=u.device, dtype=torch.float32)
+    dD = torch.zeros_like(D) if D is not None else None
+    ddelta_bias = torch.zeros_like(delta_bias) if delta_bias is not None else None
+    if u.numel() > 0:
+        Q = _lib.SsmBwdParams()
+        _fill_ssm(Q.fwd, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, x, out_z)
+        Q.dout_batch_stride, Q.dout_d_stride = dout.stride(0), dout.stride(1)
+        Q.dA_d_stride, Q.dA_dstate_stride = dA.stride(0), dA.stride(1)
+        Q.dB_batch_stride, Q.dB_group_stride, Q.dB_dstate_stride = dB.stride(0), dB.stride(1), dB.stride(2)
+        Q.dC_batch_stride, Q.dC_group_stride, Q.dC_dstate_stride = dC.stride(0), dC.stride(1), dC.stride(2)
+        Q.du_batch_stride, Q.du_d_stride = du.stride(0), du.stride(1)
+        Q.ddelta_batch_stride, Q.ddelta_d_stride = ddelta.stride(0), ddelta.stride(1)
+        if dz is not None:
+            Q.dz_batch_stride, Q.dz_d_stride = dz.stride(0), dz.stride(1)
+        Q.dout_ptr, Q.dA_ptr, Q.dB_ptr, Q.dC_ptr, Q.dD_ptr = _ptr(dout), _ptr(dA), _ptr(dB), _ptr(dC), _ptr(dD)
+        Q.du_ptr, Q.dz_ptr, Q.ddelta_ptr, Q.ddelta_bias_ptr = _ptr(du), _ptr(dz), _ptr(ddelta), _ptr(ddelta_bias)
+        with torch.cuda.device(u.device):
+            _lib.check(_lib.load().dimsum_ssm_scan_bwd(Q, _stream(u)), "selective_scan_bwd")
+    res = [du, ddelta, dA, dB.to(B.dtype), dC.to(C.dtype), dD, ddelta_bias]
+    if has_z:
+        res.append(dz)
+    if out_z is not None:
+        res.append(out_z)
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fused token-space transform (csrc/token_transform.hip) and GatedMLP epilogue
+# ---------------------------------------------------------------------------------------------------------------------
+_TT_KIND = {("none", True): 0, ("none", False): 0, ("haar", True): 1, ("haar", False): 2, ("dct", True): 3, ("dct", False): 4}
+
+
+def token_transform(x, kind, forward, in_index=None, out_index=None, gate=None, scale=None, shift=None, residual=None):
+    """y[b, out_index[s], c] = T(x[b, in_index[s], c] * gate[b, c])[s] * (1 + scale[b, c]) + shift[b, c] + residual[b, out_index[s], c]
+    x: (B, L, C) fp32 with unit channel stride (may be a channel slice of a wider tensor); index tables int32 (L,)."""
+    _gpu(x, in_index, out_index, gate, scale, shift, residual)
+    _check(x.dim() == 3 and x.dtype == torch.float32 and x.stride(2) == 1, "token_transform: x must be (B, L, C) float32, channel-contiguous")
+    B, L, C = x.shape
+    grid = int(round(L ** 0.5))
+    if kind != "none":
+        _check(grid * grid == L and grid % 4 == 0, "token_transform: the token grid must be square with side % 4 == 0")
+    y = torch.empty((B, L, C), device=x.device, dtype=torch.float32)
+    mods = [m for m in (gate, scale, shift) if m is not None]
+    mstride = 0
+    for m in mods:
+        _check(m.dtype == torch.float32 and tuple(m.shape) == (B, C) and m.stride(1) == 1, "token_transform: gate/scale/shift must be (B, C) float32")
+        _check(mstride in (0, m.stride(0)), "token_transform: gate/scale/shift must share one row stride")
+        mstride = m.stride(0)
+    for t in (in_index, out_index):
+        if t is not None:
+            _check(t.dtype == torch.int32 and t.numel() == L and t.is_contiguous(), "token_transform: index tables must be int32 (L,)")
+    if residual is not None:
+        _check(residual.shape == x.shape and residual.dtype == torch.float32 and residual.stride(2) == 1, "token_transform: bad residual")
+    if B > 0:
+        P = _lib.TtParams()
+        P.batch, P.tokens, P.channels, P.grid, P.kind = B, L, C, grid, _TT_KIND[(kind, bool(forward))]
+        P.x_batch_stride, P.x_token_stride = x.stride(0), x.stride(1)
+        P.y_batch_stride, P.y_token_stride = y.stride(0), y.stride(1)
+        if residual is not None:
+            P.res_batch_stride, P.res_token_stride = residual.stride(0), residual.stride(1)
+        P.mod_batch_stride = mstride
+        P.x_ptr, P.in_index_ptr, P.out_index_ptr = _ptr(x), _ptr(in_index), _ptr(out_index)
+        P.gate_ptr, P.scale_ptr, P.shift_ptr, P.residual_ptr, P.y_ptr = _ptr(gate), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(y)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().dimsum_token_transform(P, _stream(x)), "token_transform")
+    return y
+
+
+def gated_gelu_fwd(x12):
+    """x12: (..., 2H) fp32 contiguous -> gelu_tanh(x12[..., :H]) * x12[..., H:]   (mlp.py:66-70)"""
+    _gpu(x12)
+    _check(x12.dtype == torch.float32 and x12.is_contiguous() and x12.shape[-1] % 8 == 0, "gated_gelu: x12 must be contiguous float32 with 2H % 8 == 0")
+    H = x12.shape[-1] // 2
+    h = torch.empty(x12.shape[:-1] + (H,), device=x12.device, dtype=torch.float32)
+    rows = x12.numel() // (2 * H)
+    with torch.cuda.device(x12.device):
+        _lib.check(_lib.load().dimsum_gated_gelu_fwd(_ptr(x12), _ptr(h), rows, H, _stream(x12)), "gated_gelu_fwd")
+    return h
+
+
+def gated_gelu_bwd(x12, dh):
+    _gpu(x12, dh)
+    dh = dh.contiguous()
+    H = x12.shape[-1] // 2
+    dx12 = torch.empty_like(x12)
+    rows = x12.numel() // (2 * H)
+    with torch.cuda.device(x12.device):
+        _lib.check(_lib.load().dimsum_gated_gelu_bwd(_ptr(x12), _ptr(dh), _ptr(dx12), rows, H, _stream(x12)), "gated_gelu_bwd")
+    return dx12
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# cross-attention fusion core (csrc/xattn_fusion.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+def xattn_supported(qkv, head_dim):
+    """the MFMA kernel handles fp32 qkv rows with head_dim % 8 == 0 (24, 48, 64, 72 in the DiM zoo)"""
+    return (qkv.is_cuda and qkv.dtype == torch.float32 and qkv.stride(-1) == 1 and head_dim % 8 == 0 and head_dim <= 128
+            and hasattr(_lib.load(), "dimsum_xattn_fusion_fwd"))
+
+
+def xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=False):
+    """qkv*: (B, L, 3*heads*hd) -> (B, L, 2*heads*hd) = cat(softmax(q1 k2^T/sqrt(hd)) v2, softmax(q2 k1^T/sqrt(hd)) v1)."""
+    _gpu(qkv1, qkv2)
+    B, L, W = qkv1.shape
+    hd = W // (3 * heads)
+    _check(qkv1.shape == qkv2.shape and qkv1.dtype == torch.float32 and qkv2.dtype == torch.float32, "xattn_fusion: bad qkv")
+    _check(qkv1.stride(2) == 1 and qkv2.stride(2) == 1 and qkv1.stride() == qkv2.stride(), "xattn_fusion: qkv1/qkv2 must share strides")
+    out = torch.empty((B, L, 2 * heads * hd), device=qkv1.device, dtype=torch.float32)
+    lse = torch.empty((B, 2, heads, L), device=qkv1.device, dtype=torch.float32) if need_lse else None
+    if B > 0:
+        P = _lib.XattnParams()
+        P.batch, P.seqlen, P.heads, P.head_dim, P.scale = B, L, heads, hd, hd ** -0.5
+        P.qkv_batch_stride, P.qkv_token_stride = qkv1.stride(0), qkv1.stride(1)
+        P.out_batch_stride, P.out_token_stride = out.stride(0), out.stride(1)
+        P.qkv1_ptr, P.qkv2_ptr, P.out_ptr, P.lse_ptr = _ptr(qkv1), _ptr(qkv2), _ptr(out), _ptr(lse)
+        with torch.cuda.device(qkv1.device):
+            _lib.check(_lib.load().dimsum_xattn_fusion_fwd(P, _stream(qkv1)), "xattn_fusion_fwd")
+    return (out, lse) if need_lse else out

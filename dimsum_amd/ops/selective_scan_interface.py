@@ -1,0 +1,203 @@
+"""Autograd front-ends of the selective scan and of the fused Mamba inner block -- same names, argument order and
+return conventions as mamba/mamba_ssm/ops/selective_scan_interface.py, implemented on dimsum_amd.native (HIP, gfx950).
+
+  selective_scan_fn                      <- :94-101   (SelectiveScanFn :12-91)
+  mamba_inner_fn[_cond]                  <- :1277-1348 (MambaInnerFn :579-790, MambaInnerFnCond :793-1007)
+  mamba_inner_fn_no_out_proj[_cond]      <- :1389-1452 (MambaInnerFnNoOutProj[Cond] :174-576)
+
+The four fused variants of the reference are four near-identical 200-line classes; here they are ONE Function with two
+switches (out-projection, conditional conv entry). Semantics kept: checkpoint_lvl=1 recomputation of conv1d_out and
+delta in the backward, dx/dz written side by side into one `dxz`, `dcond = None` (SURVEY finding 1), fp32 dB/dC
+accumulation cast back to the input dtype, autocast-aware weight casts.
+
+Not implemented (raise): complex A, constant (non input-dependent) B/C -- unused by DiMSUM (mamba_simple.py:586,602-603).
+"""
+import torch
+import torch.nn.functional as F
+from torch.amp import custom_bwd, custom_fwd
+
+from .. import native
+
+
+def _last_contig(t):
+    return t if t is None or t.stride(-1) == 1 else t.contiguous()
+
+
+class SelectiveScanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, return_last_state=False):
+        u, delta, B, C, z = (_last_contig(t) for t in (u, delta, B, C, z))
+        D = D.contiguous() if D is not None else None
+        if B.dim() < 3 or C.dim() < 3:
+            raise NotImplementedError("selective_scan_fn: constant B/C (shape (dim, dstate)) is outside this build's scope")
+        ctx.squeeze_B, ctx.squeeze_C = B.dim() == 3, C.dim() == 3
+        if ctx.squeeze_B:
+            B = B.unsqueeze(1)
+        if ctx.squeeze_C:
+            C = C.unsqueeze(1)
+        out, x, *rest = native.selective_scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus)
+        ctx.delta_softplus = delta_softplus
+        ctx.has_z = z is not None
+        ctx.has_D, ctx.has_bias = D is not None, delta_bias is not None
+        last_state = x[:, :, -1, 1::2]                     # (batch, dim, dstate)   (:39)
+        ctx.save_for_backward(u, delta, A, B, C, D, z, delta_bias, x, out if ctx.has_z else None)
+        res = rest[0] if ctx.has_z else out
+        return res if not return_last_state else (res, last_state)
+
+    @staticmethod
+    def backward(ctx, dout, *args):
+        u, delta, A, B, C, D, z, delta_bias, x, out = ctx.saved_tensors
+        dout = _last_contig(dout)
+        du, ddelta, dA, dB, dC, dD, ddelta_bias, *rest = native.selective_scan_bwd(
+            u, delta, A, B, C, D, z, delta_bias, dout, x, out, None, ctx.delta_softplus, False)
+        dz = rest[0] if ctx.has_z else None
+        dB = dB.squeeze(1) if ctx.squeeze_B else dB
+        dC = dC.squeeze(1) if ctx.squeeze_C else dC
+        return (du, ddelta, dA, dB, dC, dD if ctx.has_D else None, dz, ddelta_bias if ctx.has_bias else None, None, None)
+
+
+def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, return_last_state=False):
+    """out (or (out, last_state)); the gradient of last_state is not propagated (as in the reference)."""
+    return SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
+
+
+def _rows(t):   # "b d l -> d (b l)" as a view-friendly reshape
+    b, d, l = t.shape
+    return t.permute(1, 0, 2).reshape(d, b * l)
+
+
+class _MambaInner(torch.autograd.Function):
+    """conv1d(silu) -> x_proj -> dt_proj -> selective scan (+ silu(z) gate) [-> out_proj]."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda")
+    def forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
+                A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, init_states, has_out_proj, checkpoint_lvl):
+        assert checkpoint_lvl in (0, 1)
+        if A.is_complex():
+            raise NotImplementedError("mamba_inner_fn: complex A is outside this build's scope")
+        if B is not None or C is not None:
+            raise NotImplementedError("mamba_inner_fn: constant B/C is outside this build's scope")
+        L = xz.shape[-1]
+        R = delta_proj_weight.shape[1]
+        N = A.shape[-1]
+        if torch.is_autocast_enabled("cuda"):
+            adt = torch.get_autocast_dtype("cuda")
+            x_proj_weight, delta_proj_weight = x_proj_weight.to(adt), delta_proj_weight.to(adt)
+            if has_out_proj:
+                out_proj_weight = out_proj_weight.to(adt)
+                out_proj_bias = out_proj_bias.to(adt) if out_proj_bias is not None else None
+        xz = _last_contig(xz)
+        conv_w = conv1d_weight.reshape(conv1d_weight.shape[0], conv1d_weight.shape[-1])     # "d 1 w -> d w"
+        conv_b = conv1d_bias.contiguous() if conv1d_bias is not None else None
+        x, z = xz.chunk(2, dim=1)
+        # `init_states` is numerically dead in the reference (its buffer is overwritten with the plain conv result,
+        # causal_conv1d.cpp:326-329). A full-size buffer is honoured as the output buffer; anything else (e.g. the
+        # (batch, d_inner) cond_proj output CondMamba passes) only keeps the autograd edge.
+        if init_states is not None and init_states.shape == x.shape and init_states.dtype == x.dtype and init_states.stride(-1) == 1:
+            conv_out = native.causal_conv1d_fwd_cond(x, conv_w, conv_b, True, init_states)
+        else:
+            conv_out = native.causal_conv1d_fwd(x, conv_w, conv_b, True)
+        bsz, d_inner = conv_out.shape[0], conv_out.shape[1]
+        # layouts chosen like the reference (:622-626): the GEMM writes delta d-major so that it needs no transpose
+        x_dbl = F.linear(conv_out.transpose(1, 2).reshape(bsz * L, d_inner), x_proj_weight)            # (b l, R + 2N)
+        delta = (delta_proj_weight @ x_dbl[:, :R].t()).view(d_inner, bsz, L).permute(1, 0, 2)           # (b, d, l), strides (L, bL, 1)
+        Bm = x_dbl[:, R:R + N]
+        Cm = x_dbl[:, -N:]
+        if B_proj_bias is not None:
+            Bm = Bm + B_proj_bias.to(Bm.dtype)
+        if C_proj_bias is not None:
+            Cm = Cm + C_proj_bias.to(Cm.dtype)
+        Bm = Bm.reshape(bsz, L, N).permute(0, 2, 1).unsqueeze(1).contiguous()                           # (b, 1, N, l)
+        Cm = Cm.reshape(bsz, L, N).permute(0, 2, 1).unsqueeze(1).contiguous()
+        D = D.contiguous() if D is not None else None
+        out, scan_x, out_z = native.selective_scan_fwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus)
+        ctx.delta_softplus, ctx.has_out_proj, ctx.checkpoint_lvl = delta_softplus, has_out_proj, checkpoint_lvl
+        ctx.flags = (conv1d_bias is not None, D is not None, delta_bias is not None, B_proj_bias is not None,
+                     C_proj_bias is not None, has_out_proj and out_proj_bias is not None)
+        if checkpoint_lvl >= 1:
+            conv_out, delta = None, None            # recomputed in the backward (:663-664)
+        ctx.save_for_backward(xz, conv_w, conv_b, x_dbl, x_proj_weight, delta_proj_weight,
+                              out_proj_weight if has_out_proj else None, conv_out, delta, A, Bm, Cm, D, delta_bias, scan_x, out)
+        if not has_out_proj:
+            return out_z                                                                                # (b, d, l)
+        return F.linear(out_z.transpose(1, 2), out_proj_weight, out_proj_bias)                          # (b, l, d_model)
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, dout):
+        (xz, conv_w, conv_b, x_dbl, x_proj_weight, delta_proj_weight, out_proj_weight, conv_out, delta, A, Bm, Cm, D,
+         delta_bias, scan_x, out) = ctx.saved_tensors
+        has_conv_b, has_D, has_dbias, has_Bb, has_Cb, has_ob = ctx.flags
+        L = xz.shape[-1]
+        R = delta_proj_weight.shape[1]
+        N = A.shape[-1]
+        x, z = xz.chunk(2, dim=1)
+        bsz, d_inner = x.shape[0], x.shape[1]
+        dout = _last_contig(dout)
+        if ctx.checkpoint_lvl == 1:
+            conv_out = native.causal_conv1d_fwd(x, conv_w, conv_b, True)         # the NON-cond entry, as in :929
+            delta = (delta_proj_weight @ x_dbl[:, :R].t()).view(d_inner, bsz, L).permute(1, 0, 2)
+        dxz = torch.empty_like(xz)
+        dx, dz = dxz.chunk(2, dim=1)
+        if ctx.has_out_proj:
+            dout2 = dout.reshape(bsz * L, -1).t()                                                       # "b l e -> e (b l)"
+            dout_y = (out_proj_weight.t() @ dout2).view(d_inner, bsz, L).permute(1, 0, 2)               # d-major like delta
+        else:
+            dout_y = dout
+        dconv_out, ddelta, dA, dB, dC, dD, ddelta_bias, dz, out_z = native.selective_scan_bwd(
+            conv_out, delta, A, Bm, Cm, D, z, delta_bias, dout_y, scan_x, out, dz, ctx.delta_softplus, True)
+        dout_proj_weight = dout_proj_bias = None
+        if ctx.has_out_proj:
+            dout_proj_weight = dout2 @ _rows(out_z).t()                                                 # "eB,dB->ed"
+            dout_proj_bias = dout.sum(dim=(0, 1)) if has_ob else None
+        dx_dbl = torch.empty_like(x_dbl)
+        dBf = dB.squeeze(1).permute(0, 2, 1).reshape(bsz * L, N)                                        # "b 1 n l -> (b l) n"
+        dCf = dC.squeeze(1).permute(0, 2, 1).reshape(bsz * L, N)
+        dB_proj_bias = dBf.sum(0) if has_Bb else None
+        dC_proj_bias = dCf.sum(0) if has_Cb else None
+        dx_dbl[:, R:R + N] = dBf
+        dx_dbl[:, -N:] = dCf
+        ddelta2 = _rows(ddelta)                                                                         # (d, b l)
+        ddelta_proj_weight = ddelta2 @ x_dbl[:, :R]                                                     # "dB,Br->dr"
+        dx_dbl[:, :R] = ddelta2.t() @ delta_proj_weight                                                 # "dB,dr->Br"
+        dconv2 = _rows(dconv_out)                                                                       # (d, b l)
+        dx_proj_weight = dx_dbl.t() @ _rows(conv_out).t()                                               # "Br,Bd->rd"
+        dconv2 = torch.addmm(dconv2, x_proj_weight.t(), dx_dbl.t())
+        dconv_out = dconv2.view(d_inner, bsz, L).permute(1, 0, 2)
+        _, dconv_w, dconv_b = native.causal_conv1d_bwd(x, conv_w, conv_b, dconv_out, dx, True)
+        return (dxz, dconv_w.unsqueeze(1), dconv_b if has_conv_b else None, dx_proj_weight, ddelta_proj_weight,
+                dout_proj_weight, dout_proj_bias, dA, None, None, dD if has_D else None,
+                ddelta_bias if has_dbias else None, dB_proj_bias, dC_proj_bias, None, None, None, None)
+
+
+def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias, A,
+                   B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True):
+    return _MambaInner.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
+                             out_proj_bias, A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, None, True, 1)
+
+
+def mamba_inner_fn_cond(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
+                        A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None,
+                        delta_softplus=True, init_states=None):
+    return _MambaInner.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
+                             out_proj_bias, A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, init_states,
+                             True, 1)
+
+
+def mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B=None, C=None,
+                               D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True):
+    return _MambaInner.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, None, None, A, B, C, D,
+                             delta_bias, B_proj_bias, C_proj_bias, delta_softplus, None, False, 1)
+
+
+def mamba_inner_fn_no_out_proj_cond(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B=None, C=None,
+                                    D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True,
+                                    init_states=None):
+    return _MambaInner.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, None, None, A, B, C, D,
+                             delta_bias, B_proj_bias, C_proj_bias, delta_softplus, init_states, False, 1)
+
+
+def bimamba_inner_fn(*args, **kwargs):
+    raise NotImplementedError("bimamba_inner_fn is defined by the reference but never called by its modules "
+                              "(mamba_simple.py uses two mamba_inner_fn_no_out_proj calls for scan_type='v2')")

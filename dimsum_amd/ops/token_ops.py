@@ -1,0 +1,137 @@
+"""Token-space operators of the DiM blocks on (batch, L = H*H tokens, channels) tensors:
+
+  reorder(x, table)            one gather for a whole chain of transpose / continuity / flip / window-scan / zigzag
+  haar_dwt_tokens / haar_idwt_tokens      WaveDiMBlock._dwt_fast / _idwt_fast            (dimsum/models_dim.py:572-604)
+  dct_tokens / idct_tokens                DCTBlock's 4x4 DCT-II conv + rearranges          (dimsum/models_dim.py:876-882,919-928)
+  pre_mixer / post_mixer       the fused forms used by the blocks:
+        pre :  y = modulate(P(T(x)), shift, scale)                         (models_dim.py:658-680, 1498-1511)
+        post:  y = x + T^-1(P^-1(gate * m))                                (models_dim.py:679-705, 1510-1524)
+               (the reference computes T^-1(P^-1(P(T(x)) + gate*m)); T and P are linear/orthogonal, so the two agree to
+               fp32 roundoff and the pre-mixer intermediate need not be kept)
+
+Two execution paths with identical results:
+  * inference (no autograd): ONE fused HIP kernel per call (csrc/token_transform.hip) through dimsum_amd.native;
+  * under autograd: the same math expressed with differentiable torch ops on the GPU (reshape/sum butterflies and
+    index_select), so gradients need no hand-written adjoint. Neither path touches the CPU.
+"""
+import math
+
+import torch
+
+_S = [q % 4 * 4 + q // 4 for q in range(16)]   # subband shuffle of models_dim.py:580-583
+
+
+def reorder(x, table):
+    return x if table is None else x.index_select(1, table)
+
+
+def modulate(x, shift, scale):
+    return x * (1 + scale.unsqueeze(1)) + shift.unsqueeze(1)
+
+
+# ---- 2-level Haar on the token grid --------------------------------------------------------------------------------
+def _dwt_level(img):
+    """(B, C, H, W) -> (B, 4C, H/2, W/2), bands [ll | lh | hl | hh]; rows get the high-pass in `lh`
+    (wavelet_layer.py:8-22 with dec_lo[::-1] = [s, s], dec_hi[::-1] = [s, -s])."""
+    a, b = img[:, :, 0::2, 0::2], img[:, :, 0::2, 1::2]
+    c, d = img[:, :, 1::2, 0::2], img[:, :, 1::2, 1::2]
+    p, q, r, s = a + b, a - b, c + d, c - d
+    return torch.cat([(p + r) * 0.5, (p - r) * 0.5, (q + s) * 0.5, (q - s) * 0.5], dim=1)
+
+
+def _idwt_level(sub):
+    """(B, 4C, H, W) -> (B, C, 2H, 2W)  (wavelet_layer.py:41-54)."""
+    B, C4, H, W = sub.shape
+    C = C4 // 4
+    ll, lh, hl, hh = sub[:, :C], sub[:, C:2 * C], sub[:, 2 * C:3 * C], sub[:, 3 * C:]
+    p, q, r, s = ll + lh, ll - lh, hl + hh, hl - hh
+    top = torch.stack([(p + r) * 0.5, (p - r) * 0.5], dim=-1).flatten(-2)       # (B, C, H, 2W): even rows
+    bot = torch.stack([(q + s) * 0.5, (q - s) * 0.5], dim=-1).flatten(-2)
+    return torch.stack([top, bot], dim=-2).reshape(B, C, 2 * H, 2 * W)
+
+
+def haar_dwt_tokens(x):
+    B, L, C = x.shape
+    H = math.isqrt(L)
+    h = H // 4
+    sub = _dwt_level(_dwt_level(x.transpose(1, 2).reshape(B, C, H, H))) * 0.25              # (B, 16C, h, h)
+    sub = sub.reshape(B, 16, C, h, h)[:, _S].reshape(B, C, 4, 4, h, h)                      # "(c p1 p2)" regrouping
+    return sub.permute(0, 4, 2, 5, 3, 1).reshape(B, L, C)                                    # "b (h p1 w p2) c"
+
+
+def haar_idwt_tokens(x):
+    B, L, C = x.shape
+    H = math.isqrt(L)
+    h = H // 4
+    sub = (x * 4.0).reshape(B, h, 4, h, 4, C).permute(0, 5, 2, 4, 1, 3).reshape(B, 16, C, h, h)[:, _S]
+    img = _idwt_level(_idwt_level(sub.reshape(B, 16 * C, h, h)))
+    return img.reshape(B, C, L).transpose(1, 2)
+
+
+# ---- 4x4 block DCT-II on the token grid ------------------------------------------------------------------------------
+_DCT = {}
+
+
+def dct_matrix(device, dtype=torch.float32):
+    """M[v*4+u, y*4+x] = (2 C_v C_u / 4) cos((2y+1) v pi / 8) cos((2x+1) u pi / 8)   (dct_layer.py:21-29)."""
+    key = (str(device), dtype)
+    if key not in _DCT:
+        k = torch.arange(4, dtype=torch.float64)
+        cn = torch.ones(4, dtype=torch.float64)
+        cn[0] = 1 / math.sqrt(2)
+        basis = torch.cos((2 * k[None, :] + 1) * k[:, None] * math.pi / 8)                  # [v, y]
+        m = (2 * cn[:, None, None, None] * cn[None, :, None, None] / 4) * basis[:, None, :, None] * basis[None, :, None, :]
+        _DCT[key] = m.reshape(16, 16).to(device=device, dtype=dtype)                         # [(v u), (y x)]
+    return _DCT[key]
+
+
+def _blocks(x):
+    B, L, C = x.shape
+    H = math.isqrt(L)
+    h = H // 4
+    return x.reshape(B, h, 4, h, 4, C).permute(0, 1, 3, 5, 2, 4).reshape(B, h, h, C, 16), (B, L, C, h)
+
+
+def _unblocks(blk, meta):
+    B, L, C, h = meta
+    return blk.reshape(B, h, h, C, 4, 4).permute(0, 1, 4, 2, 5, 3).reshape(B, L, C)
+
+
+def dct_tokens(x):
+    blk, meta = _blocks(x)
+    return _unblocks(blk @ dct_matrix(x.device, x.dtype).t(), meta)
+
+
+def idct_tokens(x):
+    blk, meta = _blocks(x)
+    return _unblocks(blk @ dct_matrix(x.device, x.dtype), meta)
+
+
+def _require_gpu(x):
+    if not x.is_cuda:
+        raise RuntimeError("dimsum_amd.ops.token_ops: expected a GPU tensor (there is no CPU fallback; the CPU oracle "
+                           "lives under oracle/ and is test infrastructure only)")
+
+
+_FWD = {"none": None, "haar": haar_dwt_tokens, "dct": dct_tokens}
+_INV = {"none": None, "haar": haar_idwt_tokens, "dct": idct_tokens}
+
+
+def pre_mixer(x, kind, table, shift, scale):
+    """y = modulate(P(T(x)))."""
+    from .. import native
+    _require_gpu(x)
+    if not torch.is_grad_enabled() and x.is_cuda:
+        return native.token_transform(x, kind, True, out_index=None if table is None else table["inv32"], scale=scale, shift=shift)
+    t = _FWD[kind](x) if _FWD[kind] is not None else x
+    return modulate(reorder(t, None if table is None else table["fwd"]), shift, scale)
+
+
+def post_mixer(x, m, gate, kind, table):
+    """y = x + T^-1(P^-1(gate * m))."""
+    from .. import native
+    _require_gpu(x)
+    if not torch.is_grad_enabled() and x.is_cuda:
+        return native.token_transform(m, kind, False, in_index=None if table is None else table["inv32"], gate=gate, residual=x)
+    t = reorder(gate.unsqueeze(1) * m, None if table is None else table["inv"])
+    return x + (_INV[kind](t) if _INV[kind] is not None else t)

@@ -165,30 +165,33 @@ int dimsum_norm_fwd(const dimsum_norm_params_t *p, void *stream);
 int dimsum_norm_bwd(const dimsum_norm_bwd_params_t *p, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
- * Token-space transforms on (batch, L = H*H tokens, channels) f32 tensors: one pass that fuses
- *   [4x4-block transform: none | 2-level Haar DWT | inverse | 4x4 DCT-II | inverse]  (models_dim.py:572-604, 876-928)
- *   o a token permutation given as an int32 gather table (sweep/zigma/jpeg paths, transpose, continuity, flip,
- *     local_scan windows; built on the host by dimsum_amd.scanning_orders)
- *   o the adaLN affine  y = t(x) * (1 + scale[b,c]) + shift[b,c]                    (modulate, models_dim.py:34-35)
- *   o or the gated residual  y = t(base + gate[b,c] * x)                             (models_dim.py:1510-1512)
- * out[b, j, c] = post( sum_k M[j%16... see kernels/token_transform.hip ), exact order documented there.
+ * Token-space transforms on (batch, L = grid*grid tokens, channels) f32 tensors: ONE pass that fuses
+ *   - a per-channel gate at load:             v[s, c] = x[b, in_index[s], c] * gate[b, c]
+ *   - a transform T on every 4x4 token block of the grid (position s = row-major grid index):
+ *       HAAR_FWD / HAAR_INV : 2-level Haar DWT / inverse incl. the reference's subband->channel regrouping
+ *                             (WaveDiMBlock._dwt_fast / _idwt_fast, dimsum/models_dim.py:572-604)
+ *       DCT_FWD / DCT_INV   : 4x4 DCT-II / inverse (dimsum/dct_layer.py:6-84, models_dim.py:876-882, 919-928)
+ *   - a token permutation at load (in_index) and/or at store (out_index): int32 tables composed on the host from
+ *     transpose / continuity / flip / window-scan / zigzag orders (dimsum/scanning_orders.py, models_dim.py:1496-1524)
+ *   - the adaLN affine and a residual at store:
+ *       y[b, out_index[s], c] = T(v)[s, c] * (1 + scale[b, c]) + shift[b, c] + residual[b, out_index[s], c]
+ * Every optional pointer may be NULL (identity / 0). Streaming op: 2*B*L*C*4 bytes (+ residual).
  * ------------------------------------------------------------------------------------------------------------- */
 typedef enum {
     DIMSUM_TT_NONE = 0, DIMSUM_TT_HAAR_FWD = 1, DIMSUM_TT_HAAR_INV = 2, DIMSUM_TT_DCT_FWD = 3, DIMSUM_TT_DCT_INV = 4
 } dimsum_tt_kind_t;
 
 typedef struct {
-    int32_t batch, tokens, channels, grid; /* tokens = grid*grid */
-    int32_t kind;                          /* dimsum_tt_kind_t, applied on 4x4 token blocks of the grid */
-    int32_t transform_first;               /* 1: y = P(T(x)) (pre-mixer), 0: y = T(P(x)) (post-mixer) */
-    int64_t x_batch_stride, x_token_stride;     /* channel stride 1 */
-    int64_t base_batch_stride, base_token_stride;
+    int32_t batch, tokens, channels, grid; /* tokens = grid*grid, grid % 4 == 0 unless kind == NONE */
+    int32_t kind;                          /* dimsum_tt_kind_t */
+    int32_t reserved;
+    int64_t x_batch_stride, x_token_stride;           /* channel stride 1 everywhere */
+    int64_t res_batch_stride, res_token_stride;
     int64_t y_batch_stride, y_token_stride;
+    int64_t mod_batch_stride;                         /* row stride of gate / scale / shift, each (batch, channels) */
     const void *x_ptr;
-    const int32_t *gather_ptr;  /* (tokens) y_token[j] = src_token[gather[j]]; NULL = identity */
-    const void *scale_ptr, *shift_ptr; /* (batch, channels) with row stride mod_batch_stride, or NULL */
-    const void *gate_ptr, *base_ptr;   /* x' = base + gate*x applied BEFORE everything else, or NULL */
-    int64_t mod_batch_stride;
+    const int32_t *in_index_ptr, *out_index_ptr;      /* (tokens) or NULL */
+    const void *gate_ptr, *scale_ptr, *shift_ptr, *residual_ptr;
     void *y_ptr;
 } dimsum_tt_params_t;
 

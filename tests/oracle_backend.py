@@ -1,0 +1,145 @@
+"""CPU stand-in for dimsum_amd.native built on oracle/ -- TEST INFRASTRUCTURE.
+
+`with cpu_oracle_backend():` monkeypatches the tensor-level native entry points (same signatures) with implementations
+that run the CPU oracle, and lifts the GPU-only guard of the differentiable torch path of ops/token_ops.py. This lets
+the `-m "not gpu"` suite exercise the host logic of dimsum_amd (autograd Functions, layouts, module composition,
+state_dict keys) against the reference goldens. The product never enables this itself."""
+import contextlib
+
+import numpy as np
+import torch
+
+from oracle import c_ops, np_ops
+
+
+def _np(t):
+    return None if t is None else t.detach().float().cpu().numpy()
+
+
+def _like(a, ref, dtype=None):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dtype or ref.dtype)
+
+
+def selective_scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus, need_out=True, need_x=True):
+    y, oz, x = c_ops.selective_scan_fwd(_np(u), _np(delta), _np(A), _np(B), _np(C), _np(D), _np(z), _np(delta_bias), delta_softplus)
+    out = torch.empty_like(delta)
+    out.copy_(_like(y, u))
+    res = [out, torch.from_numpy(x)]
+    if z is not None:
+        out_z = torch.empty_like(z)
+        out_z.copy_(_like(oz, u))
+        res.append(out_z)
+    return res
+
+
+def selective_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, dz, delta_softplus, recompute_out_z):
+    r = c_ops.selective_scan_bwd(_np(u), _np(delta), _np(A), _np(B), _np(C), _np(D), _np(z), _np(delta_bias), delta_softplus, _np(dout))
+    du = torch.empty_like(u).copy_(_like(r["du"], u))
+    ddelta = torch.empty_like(delta).copy_(_like(r["ddelta"], u))
+    res = [du, ddelta, _like(r["dA"], A), _like(r["dB"], B), _like(r["dC"], C),
+           _like(r["dD"], D) if D is not None else None, _like(r["ddelta_bias"], delta_bias) if delta_bias is not None else None]
+    if z is not None:
+        if dz is None:
+            dz = torch.empty_like(z)
+        dz.copy_(_like(r["dz"], z))
+        res.append(dz)
+        if recompute_out_z:
+            zz = z.float()
+            res.append((out.float() * zz * torch.sigmoid(zz)).to(out.dtype))
+    return res
+
+
+def causal_conv1d_fwd(x, weight, bias, silu_activation, out=None):
+    o = c_ops.causal_conv1d_fwd(_np(x), _np(weight), _np(bias), silu_activation)
+    if out is None:
+        out = torch.empty_like(x)
+    out.copy_(_like(o, x))
+    return out
+
+
+def causal_conv1d_fwd_cond(x, weight, bias, silu_activation, init_x):
+    return causal_conv1d_fwd(x, weight, bias, silu_activation, out=init_x)
+
+
+def causal_conv1d_bwd(x, weight, bias, dout, dx, silu_activation):
+    rdx, rdw, rdb = c_ops.causal_conv1d_bwd(_np(x), _np(weight), _np(bias), _np(dout), silu_activation)
+    if dx is None:
+        dx = torch.empty_like(x)
+    dx.copy_(_like(rdx, x))
+    return [dx, _like(rdw, weight), _like(rdb, bias) if bias is not None else None]
+
+
+def layer_norm_fwd(x, weight, bias, eps, residual=None, out_dtype=None, residual_dtype=None, is_rms_norm=False):
+    y, ro, mean, rstd = c_ops.norm_fwd(_np(x), _np(weight), _np(bias), _np(residual), eps, is_rms_norm)
+    if residual is not None:
+        residual_dtype = residual.dtype
+    need = residual is not None or (residual_dtype is not None and residual_dtype != x.dtype)
+    res_out = torch.from_numpy(ro).to(residual_dtype) if need else x
+    return (torch.from_numpy(y).to(out_dtype or x.dtype), None if is_rms_norm else torch.from_numpy(mean), torch.from_numpy(rstd), res_out)
+
+
+def layer_norm_bwd(dy, x, weight, bias, eps, mean, rstd, dresidual=None, has_residual=False, is_rms_norm=False, x_dtype=None):
+    dr, dw, db = c_ops.norm_bwd(_np(x), _np(weight), _np(dy), _np(dresidual), eps, is_rms_norm)
+    dx = torch.from_numpy(dr).to(x_dtype or x.dtype)
+    return dx, _like(dw, weight), _like(db, bias) if bias is not None else None, (torch.from_numpy(dr).to(x.dtype) if has_residual else None)
+
+
+def gated_gelu_fwd(x12):
+    return torch.from_numpy(np_ops.gated_gelu(_np(x12)))
+
+
+def gated_gelu_bwd(x12, dh):
+    xr = x12.detach().clone().requires_grad_()
+    H = xr.shape[-1] // 2
+    with torch.enable_grad():
+        (torch.nn.functional.gelu(xr[..., :H], approximate="tanh") * xr[..., H:]).backward(dh)
+    return xr.grad
+
+
+def token_transform(x, kind, forward, in_index=None, out_index=None, gate=None, scale=None, shift=None, residual=None):
+    v = _np(x)
+    if gate is not None:
+        v = v * _np(gate)[:, None]
+    if in_index is not None:
+        v = v[:, in_index.cpu().numpy()]
+    T = {("haar", True): np_ops.haar_dwt_tokens, ("haar", False): np_ops.haar_idwt_tokens, ("dct", True): np_ops.dct_tokens,
+         ("dct", False): np_ops.idct_tokens}.get((kind, bool(forward)), lambda a: a)
+    t = T(np.ascontiguousarray(v))
+    if scale is not None:
+        t = t * (1 + _np(scale)[:, None])
+    if shift is not None:
+        t = t + _np(shift)[:, None]
+    y = np.empty_like(t)
+    if out_index is not None:
+        y[:, out_index.cpu().numpy()] = t
+    else:
+        y = t
+    if residual is not None:
+        y = y + _np(residual)
+    return torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32))
+
+
+def xattn_supported(qkv, head_dim):
+    return False
+
+
+@contextlib.contextmanager
+def cpu_oracle_backend():
+    from dimsum_amd import native
+    from dimsum_amd.ops import token_ops
+    names = ["selective_scan_fwd", "selective_scan_bwd", "causal_conv1d_fwd", "causal_conv1d_fwd_cond", "causal_conv1d_bwd",
+             "layer_norm_fwd", "layer_norm_bwd", "gated_gelu_fwd", "gated_gelu_bwd", "token_transform", "xattn_supported"]
+    saved = {n: getattr(native, n, None) for n in names}
+    guard = token_ops._require_gpu
+    try:
+        for n in names:
+            setattr(native, n, globals()[n])
+        token_ops._require_gpu = lambda x: None
+        yield
+    finally:
+        for n, f in saved.items():
+            if f is None:
+                delattr(native, n)
+            else:
+                setattr(native, n, f)
+        token_ops._require_gpu = guard

@@ -1,0 +1,89 @@
+"""GPU parity: fused token-transform kernel and gated GeLU (through the C ABI) vs the numpy oracle and the reference
+goldens (haar.npz / dct.npz / block_orders). Permutations are pure moves: bit-exact. Transforms: rtol 1e-5 + 1e-6 * max."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close, golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _g(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("H", [16, 32, 4])
+def test_haar_vs_golden(H):
+    from dimsum_amd import native
+    g = golden("haar")
+    y = native.token_transform(_g(g[f"H{H}_x"]), "haar", True)
+    assert_close(y.cpu().numpy(), g[f"H{H}_dwt"], 1e-5, 0, "dwt", scale_atol=1e-6)
+    xi = native.token_transform(_g(g[f"H{H}_y2"]), "haar", False)
+    assert_close(xi.cpu().numpy(), g[f"H{H}_idwt"], 1e-5, 0, "idwt", scale_atol=1e-6)
+    rt = native.token_transform(native.token_transform(_g(g[f"H{H}_x"]), "haar", True), "haar", False)
+    assert_close(rt.cpu().numpy(), g[f"H{H}_x"], 1e-5, 0, "roundtrip", scale_atol=1e-6)
+
+
+@pytest.mark.parametrize("H", [16, 32])
+def test_dct_vs_golden(H):
+    from dimsum_amd import native
+    g = golden("dct")
+    y = native.token_transform(_g(g[f"H{H}_x"]), "dct", True)
+    assert_close(y.cpu().numpy(), g[f"H{H}_dct"], 1e-5, 0, "dct", scale_atol=2e-6)
+    back = native.token_transform(y, "dct", False)
+    assert_close(back.cpu().numpy(), g[f"H{H}_roundtrip"], 1e-5, 0, "idct", scale_atol=2e-6)
+
+
+@pytest.mark.parametrize("C,H,kind", [(512, 16, "haar"), (576, 32, "haar"), (192, 16, "haar"), (512, 16, "dct"), (512, 16, "none"), (20, 8, "haar")])
+def test_fused_pre_post_vs_oracle(C, H, kind):
+    """pre: y = modulate(P(T(x))) on a channel-slice view; post: y = x + T^-1(P^-1(gate*m))."""
+    from dimsum_amd import native, scanning_orders as so
+    from oracle import np_ops
+    rs = np.random.RandomState(C + H)
+    B, L = 3, H * H
+    full = rs.standard_normal((B, L, 2 * C)).astype(np.float32)
+    x = full[:, :, C:]                                     # like x2 = hidden.chunk(2, dim=2)[1]
+    shift, scale, gate = (rs.standard_normal((B, 3 * C)).astype(np.float32)[:, i * C:(i + 1) * C] for i in range(3))
+    table = so.compose(so.local_scan_table(H, H // 4, True), so.block_order_table(H, True, False, True))
+    inv = so.reverse_permut_np(table)
+    T = {"haar": np_ops.haar_dwt_tokens, "dct": np_ops.dct_tokens, "none": lambda a: a}[kind]
+    Ti = {"haar": np_ops.haar_idwt_tokens, "dct": np_ops.idct_tokens, "none": lambda a: a}[kind]
+    full_g = _g(full)
+    mods = _g(np.concatenate([shift, scale, gate], 1))     # one (B, 3C) adaLN output, sliced like .chunk(3, dim=1)
+    sh_g, sc_g, ga_g = mods[:, :C], mods[:, C:2 * C], mods[:, 2 * C:]
+    inv32 = torch.from_numpy(inv.astype(np.int32)).cuda()
+    y = native.token_transform(full_g[:, :, C:], kind, True, out_index=inv32, scale=sc_g, shift=sh_g)
+    ref = T(np.ascontiguousarray(x))[:, table] * (1 + scale[:, None]) + shift[:, None]
+    assert_close(y.cpu().numpy(), ref, 1e-5, 0, "pre", scale_atol=1e-6)
+    m = rs.standard_normal((B, L, C)).astype(np.float32)
+    out = native.token_transform(_g(m), kind, False, in_index=inv32, gate=ga_g, residual=full_g[:, :, C:])
+    ref2 = x + Ti(np.ascontiguousarray((gate[:, None] * m)[:, inv]))
+    assert_close(out.cpu().numpy(), ref2, 1e-5, 0, "post", scale_atol=1e-6)
+
+
+def test_pure_permutation_is_bit_exact():
+    from dimsum_amd import native, scanning_orders as so
+    x = torch.randn(2, 256, 64, device="cuda")
+    for r in (0, 1):
+        for t in (0, 1):
+            for c in (0, 1):
+                tab = so.block_order_table(16, r, t, c)
+                inv32 = torch.from_numpy(so.reverse_permut_np(tab).astype(np.int32)).cuda()
+                y = native.token_transform(x, "none", True, out_index=inv32)
+                assert torch.equal(y, x[:, torch.from_numpy(tab).cuda()])
+                back = native.token_transform(y, "none", False, in_index=inv32)
+                assert torch.equal(back, x)
+
+
+def test_gated_gelu():
+    from dimsum_amd import native
+    from oracle import np_ops
+    x = torch.randn(37, 2 * 96, device="cuda") * 2
+    h = native.gated_gelu_fwd(x)
+    assert_close(h.cpu().numpy(), np_ops.gated_gelu(x.cpu().numpy()), 1e-5, 1e-6, "fwd")
+    xr = x.detach().clone().requires_grad_()
+    ref = torch.nn.functional.gelu(xr[:, :96], approximate="tanh") * xr[:, 96:]
+    dh = torch.randn_like(ref)
+    ref.backward(dh)
+    assert_close(native.gated_gelu_bwd(x, dh).cpu().numpy(), xr.grad.cpu().numpy(), 1e-4, 1e-5, "bwd")

@@ -295,17 +295,8 @@ def gen_mixer(ns):
         procedural_fill(m, seed=7)
         x = T(seeded((B, L, d_model), 41)).requires_grad_()
         c = T(seeded((B, 48), 42))
-        if kw["scan_type"] == "none":
-            y = m(x, c) if kw["cls"] == "CondMamba" else m(x)
-        else:
-            # intended fast-path semantics (mamba_simple.py:627-657): gather xz along L, mix, inverse-gather out.
-            # gathering xz columns == gathering the tokens before in_proj (in_proj is per-token).
-            perm = m.zigzag_paths[m.layer_idx]
-            rev = m.zigzag_paths_reverse[m.layer_idx]
-            st = m.scan_type
-            m.scan_type = "none"
-            y = m(x[:, perm], c)[:, rev]
-            m.scan_type = st
+        ref_shim.slow_path(m)          # wraps the zigzag gather around the slow path (mamba_simple.py:627-657)
+        y = m(x, c) if kw["cls"] == "CondMamba" else m(x)
         g = T(seeded(tuple(y.shape), 43))
         y.backward(g)
         save(name, "CondMamba/Mamba.forward slow path (mamba/mamba_ssm/modules/mamba_simple.py:562-701); zigzag per "

@@ -166,10 +166,25 @@ def load():
 
 
 def slow_path(model):
-    """Force every mixer onto the pure-PyTorch path (mamba_simple.py:658-700)."""
+    """Force every mixer onto the pure-PyTorch path (mamba_simple.py:658-700). The slow path drops the zigzag gather
+    that the fast path applies around mamba_inner_fn (mamba_simple.py:627-657, SURVEY finding 3), so mixers with a
+    zigzag scan_type get their forward wrapped: gather tokens by perm -> slow path -> inverse gather. Gathering the
+    columns of xz equals gathering the tokens before the per-token in_proj."""
+    import types as _t
     for m in model.modules():
         if hasattr(m, "use_fast_path"):
             m.use_fast_path = False
+            st = getattr(m, "scan_type", "none")
+            if st.startswith(("zigma", "sweep", "jpeg")) and not getattr(m, "_zigzag_wrapped", False):
+                inner = m.forward
+
+                def fwd(self, hidden_states, *a, _inner=inner, **k):
+                    perm = self.zigzag_paths[self.layer_idx]
+                    rev = self.zigzag_paths_reverse[self.layer_idx]
+                    return _inner(hidden_states[:, perm], *a, **k)[:, rev]
+
+                m.forward = _t.MethodType(fwd, m)
+                m._zigzag_wrapped = True
     return model
 
 
