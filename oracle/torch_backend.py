@@ -1,4 +1,4 @@
-"""CPU stand-in for dimsum_amd.native built on oracle/ -- TEST INFRASTRUCTURE.
+"""CPU stand-in for dimsum_amd.native built on oracle/ -- TEST INFRASTRUCTURE (tests/, smoke(), bench.py cpu_baseline).
 
 `with cpu_oracle_backend():` monkeypatches the tensor-level native entry points (same signatures) with implementations
 that run the CPU oracle, and lifts the GPU-only guard of the differentiable torch path of ops/token_ops.py. This lets
@@ -9,7 +9,7 @@ import contextlib
 import numpy as np
 import torch
 
-from oracle import c_ops, np_ops
+from . import c_ops, np_ops
 
 
 def _np(t):

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from conftest import assert_close, golden
-from oracle_backend import cpu_oracle_backend
+from oracle.torch_backend import cpu_oracle_backend
 from procedural import procedural_fill, seeded
 
 T = torch.from_numpy
