@@ -27,7 +27,8 @@ class SsmBwdParams(C.Structure):
                                       "dC_group_stride", "dC_dstate_stride", "du_batch_stride", "du_d_stride",
                                       "dz_batch_stride", "dz_d_stride", "ddelta_batch_stride", "ddelta_d_stride")]
                 + [(n, vp) for n in ("dout_ptr", "dA_ptr", "dB_ptr", "dC_ptr", "dD_ptr", "du_ptr", "dz_ptr",
-                                     "ddelta_ptr", "ddelta_bias_ptr")])
+                                     "ddelta_ptr", "ddelta_bias_ptr", "workspace_ptr")]
+                + [("workspace_bytes", i64)])
 
 
 class ConvParams(C.Structure):
@@ -76,7 +77,7 @@ class XattnParams(C.Structure):
 # every symbol include/dimsum_hip.h declares (tests check the library exports all of them)
 EXPORTS = (
     "dimsum_status_string", "dimsum_abi_version", "dimsum_target_arch",
-    "dimsum_ssm_scan_fwd", "dimsum_ssm_scan_bwd", "dimsum_causal_conv1d_fwd", "dimsum_causal_conv1d_bwd",
+    "dimsum_ssm_scan_fwd", "dimsum_ssm_scan_bwd", "dimsum_ssm_scan_bwd_workspace_bytes", "dimsum_causal_conv1d_fwd", "dimsum_causal_conv1d_bwd",
     "dimsum_norm_fwd", "dimsum_norm_bwd", "dimsum_token_transform", "dimsum_xattn_fusion_fwd",
     "dimsum_gated_gelu_fwd", "dimsum_gated_gelu_bwd",
 )
@@ -110,6 +111,9 @@ def load():
             fn = getattr(lib, name)
             fn.restype = C.c_int
             fn.argtypes = [vp] * nptr + [i64, i64, vp]
+    if hasattr(lib, "dimsum_ssm_scan_bwd_workspace_bytes"):
+        lib.dimsum_ssm_scan_bwd_workspace_bytes.restype = i64
+        lib.dimsum_ssm_scan_bwd_workspace_bytes.argtypes = [i32] * 5
     if lib.dimsum_abi_version() != 1:
         raise RuntimeError("dimsum_amd: libdimsum_hip.so ABI version mismatch; rebuild")
     _lib = lib

@@ -350,9 +350,9 @@ static int dispatch_n(const dimsum_ssm_params_t &p, hipStream_t stream) {
     }
 }
 
-int ssm_check(const dimsum_ssm_params_t *p) {
+int ssm_check(const dimsum_ssm_params_t *p, bool forward) {
     if (!p || !p->A_ptr || !p->B_ptr || !p->C_ptr || !p->u_ptr || !p->delta_ptr) return DIMSUM_ERR_NULL;
-    if (p->z_ptr && !p->out_z_ptr) return DIMSUM_ERR_NULL;
+    if (forward && p->z_ptr && !p->out_z_ptr) return DIMSUM_ERR_NULL;   // in the backward out_z is the optional recompute
     if (p->batch <= 0 || p->dim <= 0 || p->seqlen <= 0 || p->n_groups <= 0 || p->dim % p->n_groups != 0) return DIMSUM_ERR_SHAPE;
     if (p->dstate > 256) return DIMSUM_ERR_SHAPE;  // selective_scan.cpp:262
     if (p->n_chunks != (p->seqlen + 2047) / 2048) return DIMSUM_ERR_SHAPE;
@@ -370,7 +370,7 @@ extern "C" int dimsum_debug_scan_fwd_occupancy(void) {
 
 extern "C" int dimsum_ssm_scan_fwd(const dimsum_ssm_params_t *p, void *stream) {
     using namespace dimsum;
-    const int rc = ssm_check(p);
+    const int rc = ssm_check(p, true);
     if (rc != DIMSUM_OK) return rc;
     if (p->batch == 0) return DIMSUM_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -283,8 +283,12 @@ def selective_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, dz, de
             Q.dz_batch_stride, Q.dz_d_stride = dz.stride(0), dz.stride(1)
         Q.dout_ptr, Q.dA_ptr, Q.dB_ptr, Q.dC_ptr, Q.dD_ptr = _ptr(dout), _ptr(dA), _ptr(dB), _ptr(dC), _ptr(dD)
         Q.du_ptr, Q.dz_ptr, Q.ddelta_ptr, Q.ddelta_bias_ptr = _ptr(du), _ptr(dz), _ptr(ddelta), _ptr(ddelta_bias)
+        lib = _lib.load()
+        nbytes = lib.dimsum_ssm_scan_bwd_workspace_bytes(batch, dim, seqlen, A.shape[1], B.shape[1])
+        ws = torch.empty((nbytes + 3) // 4, device=u.device, dtype=torch.float32)       # tile-boundary states
+        Q.workspace_ptr, Q.workspace_bytes = _ptr(ws), nbytes
         with torch.cuda.device(u.device):
-            _lib.check(_lib.load().dimsum_ssm_scan_bwd(Q, _stream(u)), "selective_scan_bwd")
+            _lib.check(lib.dimsum_ssm_scan_bwd(Q, _stream(u)), "selective_scan_bwd")
     res = [du, ddelta, dA, dB.to(B.dtype), dC.to(C.dtype), dD, ddelta_bias]
     if has_z:
         res.append(dz)

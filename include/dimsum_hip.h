@@ -96,10 +96,15 @@ typedef struct {
     void *dD_ptr;          /* (dim) f32 zero-filled, or NULL */
     void *du_ptr, *dz_ptr, *ddelta_ptr;
     void *ddelta_bias_ptr; /* (dim) f32 zero-filled, or NULL */
+    void *workspace_ptr;   /* scratch for the tile-boundary states, >= dimsum_ssm_scan_bwd_workspace_bytes(...) bytes,
+                              16-byte aligned, contents undefined on entry and exit (the reference keeps the equivalent
+                              in shared memory because it re-scans a whole row per block) */
+    int64_t workspace_bytes;
 } dimsum_ssm_bwd_params_t;
 
 int dimsum_ssm_scan_fwd(const dimsum_ssm_params_t *p, void *stream);
 int dimsum_ssm_scan_bwd(const dimsum_ssm_bwd_params_t *p, void *stream);
+int64_t dimsum_ssm_scan_bwd_workspace_bytes(int32_t batch, int32_t dim, int32_t seqlen, int32_t dstate, int32_t n_groups);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Causal depthwise conv1d, width 2..4, optional bias, optional SiLU.  Mirrors ConvParamsBase / ConvParamsBwd

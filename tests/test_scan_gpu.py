@@ -115,3 +115,85 @@ def test_errors_are_loud():
     ug = u.cuda()
     with pytest.raises(RuntimeError):  # dstate 3 unsupported
         native.selective_scan_fwd(ug, ug, torch.randn(4, 3).cuda(), torch.randn(1, 1, 3, 8).cuda(), torch.randn(1, 1, 3, 8).cuda(), None, None, None, True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# backward
+# ---------------------------------------------------------------------------------------------------------------------
+def _bwd_tol(L, weight=False):
+    # reference test: grads rtol x2..x10, atol 2e-3..1e-2 (mamba/tests/ops/test_selective_scan.py:158-172)
+    if weight:
+        return dict(rtol=1e-3, atol=0.0, scale_atol=2e-4 if L <= 512 else 1e-3)
+    return dict(rtol=5e-4, atol=0.0, scale_atol=2e-5) if L <= 512 else dict(rtol=2e-3, atol=0.0, scale_atol=2e-4)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_bwd_vs_golden(name):
+    from dimsum_amd import native
+    g = golden(name)
+    L = g["u"].shape[-1]
+    u, delta, A, B, C = (_t(g[k]) for k in ("u", "delta", "A", "B", "C"))
+    D, z, bias = (_t(_opt(g, k)) for k in ("D", "z", "delta_bias"))
+    sp = bool(g["softplus"])
+    out, x, *rest = native.selective_scan_fwd(u, delta, A, B, C, D, z, bias, sp)
+    res = native.selective_scan_bwd(u, delta, A, B, C, D, z, bias, _t(g["dout"]), x, out if z is not None else None, None, sp, z is not None)
+    du, ddelta, dA, dB, dC, dD, dbias = res[:7]
+    torch.cuda.synchronize()
+    for name_, got in (("du", du), ("ddelta", ddelta), ("dB", dB), ("dC", dC)):
+        assert_close(got.cpu().numpy(), g[name_], what=name_, **_bwd_tol(L))
+    assert_close(dA.cpu().numpy(), g["dA"], what="dA", **_bwd_tol(L, True))
+    if D is not None:
+        assert_close(dD.cpu().numpy(), g["dD"], what="dD", **_bwd_tol(L, True))
+    if bias is not None:
+        assert_close(dbias.cpu().numpy(), g["ddelta_bias"], what="ddelta_bias", **_bwd_tol(L, True))
+    if z is not None:
+        assert_close(res[7].cpu().numpy(), g["dz"], what="dz", **_bwd_tol(L))
+        assert_close(res[8].cpu().numpy(), g["out"], what="recomputed out_z", **tol(L))
+
+
+@pytest.mark.parametrize("B,D,L,N", [(3, 192, 256, 16), (2, 70, 100, 16), (1, 64, 1024, 8)])
+def test_bwd_vs_oracle_mamba_layout(B, D, L, N):
+    """d-major delta / dout / ddelta and a caller-provided dz view into dxz, as in MambaInnerFn.backward (:933-953)."""
+    from dimsum_amd import native
+    from oracle import c_ops
+    gen = torch.Generator().manual_seed(B + D + L)
+    xz = torch.randn(B, 2 * D, L, generator=gen)
+    u = torch.randn(B, D, L, generator=gen)
+    delta_dm = 0.5 * torch.rand(D, B, L, generator=gen)
+    dout_dm = torch.randn(D, B, L, generator=gen)
+    A = -0.5 * torch.rand(D, N, generator=gen)
+    Bm, Cm = torch.randn(B, 1, N, L, generator=gen), torch.randn(B, 1, N, L, generator=gen)
+    Dv, bias = torch.randn(D, generator=gen), 0.5 * torch.rand(D, generator=gen)
+    xz_g = xz.cuda()
+    z_g = xz_g.chunk(2, 1)[1]
+    delta_g, dout_g = delta_dm.cuda().permute(1, 0, 2), dout_dm.cuda().permute(1, 0, 2)
+    out, x, out_z = native.selective_scan_fwd(u.cuda(), delta_g, A.cuda(), Bm.cuda(), Cm.cuda(), Dv.cuda(), z_g, bias.cuda(), True)
+    dxz = torch.full_like(xz_g, float("nan"))
+    dz_view = dxz.chunk(2, 1)[1]
+    du, ddelta, dA, dB, dC, dD, dbias, dz, oz = native.selective_scan_bwd(u.cuda(), delta_g, A.cuda(), Bm.cuda(), Cm.cuda(), Dv.cuda(), z_g,
+                                                                          bias.cuda(), dout_g, x, out, dz_view, True, True)
+    assert dz.data_ptr() == dz_view.data_ptr() and ddelta.stride() == delta_g.stride()
+    r = c_ops.selective_scan_bwd(u.numpy(), delta_dm.permute(1, 0, 2).numpy(), A.numpy(), Bm.numpy(), Cm.numpy(), Dv.numpy(),
+                                 xz[:, D:].numpy(), bias.numpy(), True, dout_dm.permute(1, 0, 2).numpy())
+    for k, got in (("du", du), ("ddelta", ddelta), ("dB", dB), ("dC", dC), ("dz", dxz[:, D:])):
+        assert_close(got.cpu().numpy(), r[k], what=k, **_bwd_tol(L))
+    for k, got in (("dA", dA), ("dD", dD), ("ddelta_bias", dbias)):
+        assert_close(got.cpu().numpy(), r[k], what=k, **_bwd_tol(L, True))
+    assert torch.isnan(dxz[:, :D]).all()
+    assert_close(oz.cpu().numpy(), out_z.cpu().numpy(), 1e-6, 1e-6, "recomputed out_z")
+
+
+def test_selective_scan_fn_autograd():
+    """the public op end to end (fwd + bwd through autograd) against the golden of the reference's selective_scan_ref"""
+    from dimsum_amd.ops import selective_scan_fn
+    g = golden("scan_main")
+    leaves = {k: _t(g[k]).requires_grad_() for k in ("u", "delta", "A", "B", "C", "D", "z", "delta_bias")}
+    out, last = selective_scan_fn(leaves["u"], leaves["delta"], leaves["A"], leaves["B"], leaves["C"], leaves["D"], leaves["z"],
+                                  leaves["delta_bias"], delta_softplus=True, return_last_state=True)
+    out.backward(_t(g["dout"]))
+    assert_close(out.detach().cpu().numpy(), g["out"], what="out", **tol(256))
+    assert_close(last.detach().cpu().numpy(), g["last_state"], what="last_state", **tol(256))
+    for k, gk in (("u", "du"), ("delta", "ddelta"), ("B", "dB"), ("C", "dC"), ("z", "dz")):
+        assert_close(leaves[k].grad.cpu().numpy(), g[gk], what=gk, **_bwd_tol(256))
+    for k, gk in (("A", "dA"), ("D", "dD"), ("delta_bias", "ddelta_bias")):
+        assert_close(leaves[k].grad.cpu().numpy(), g[gk], what=gk, **_bwd_tol(256, True))

@@ -79,11 +79,11 @@ def test_pure_permutation_is_bit_exact():
 def test_gated_gelu():
     from dimsum_amd import native
     from oracle import np_ops
-    x = torch.randn(37, 2 * 96, device="cuda") * 2
+    x = (torch.randn(37, 2 * 96, generator=torch.Generator().manual_seed(0)) * 2).cuda()
     h = native.gated_gelu_fwd(x)
-    assert_close(h.cpu().numpy(), np_ops.gated_gelu(x.cpu().numpy()), 1e-5, 1e-6, "fwd")
+    assert_close(h.cpu().numpy(), np_ops.gated_gelu(x.cpu().numpy()), 1e-5, 0, "fwd", scale_atol=1e-6)
     xr = x.detach().clone().requires_grad_()
     ref = torch.nn.functional.gelu(xr[:, :96], approximate="tanh") * xr[:, 96:]
-    dh = torch.randn_like(ref)
+    dh = torch.randn(ref.shape, generator=torch.Generator().manual_seed(1)).cuda()
     ref.backward(dh)
-    assert_close(native.gated_gelu_bwd(x, dh).cpu().numpy(), xr.grad.cpu().numpy(), 1e-4, 1e-5, "bwd")
+    assert_close(native.gated_gelu_bwd(x, dh).cpu().numpy(), xr.grad.cpu().numpy(), 1e-4, 0, "bwd", scale_atol=1e-5)
