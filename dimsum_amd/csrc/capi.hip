@@ -6,7 +6,7 @@ extern "C" const char *dimsum_status_string(int status) {
         case DIMSUM_OK: return "ok";
         case DIMSUM_ERR_NULL: return "a required pointer is NULL";
         case DIMSUM_ERR_DTYPE: return "unsupported dtype (expected float32, float16 or bfloat16)";
-        case DIMSUM_ERR_SHAPE: return "unsupported shape (dstate must be 4, 8, 16 or 32; conv width 2..4; dim % n_groups == 0)";
+        case DIMSUM_ERR_SHAPE: return "unsupported shape (scan: dstate in {4, 8, 16, 32}, dim % n_groups == 0; conv: width 2..4; attention: head_dim in {24, 32, 48, 64, 72}; norm: cols <= 2048)";
         case DIMSUM_ERR_STRIDE: return "unsupported stride or alignment (innermost stride must be 1; in-tile offsets must fit 31 bits)";
         case DIMSUM_ERR_UNSUPPORTED: return "valid in the reference but out of scope here (complex A, constant B/C)";
         case DIMSUM_ERR_LAUNCH: return "HIP kernel launch failed";

@@ -1,0 +1,194 @@
+// xattn_fusion.hip -- cross-attention fusion core on the matrix cores (gfx950), fp32 in / fp32 out.
+//
+// Replaces the two F.scaled_dot_product_attention calls + transposes + concat of CrossAttentionFusion.forward
+// (dimsum/attention_fusion.py:64-79, swap_k = False), reading q/k/v straight from the qkv GEMM outputs
+// (batch, L, 3*heads*hd laid out [q | k | v], head-major) and writing the concatenated proj input (batch, L, 2*heads*hd):
+//     out[b, i, h*hd + e]       = sum_j softmax_j(q1_i . k2_j / sqrt(hd)) v2_j[e]      ("x12")
+//     out[b, i, C + h*hd + e]   = sum_j softmax_j(q2_i . k1_j / sqrt(hd)) v1_j[e]      ("x21")
+//
+// MFMA mapping (v_mfma_f32_16x16x4_f32: exact fp32 products and accumulation, 157 TFLOP/s peak = the fp32 vector rate,
+// MI355X_MICROARCH.md) -- everything is computed TRANSPOSED so that no operand ever changes layout:
+//     S^T (keys x queries) = K Q^T     A = K[key = lane&15][e],  B = Q^T[e][query = lane&15]
+//         C layout: lane holds query (lane&15) and keys (lane>>4)*4 + r, r = 0..3 of each 16-key tile
+//     O^T (hd x queries)   = V^T P^T   B operand of K-step r  ==  C register r of the S^T tile, untouched
+//                                      (the 4 keys of a K-step are {r, 4+r, 8+r, 12+r}), A = V^T[e = lane&15][those keys]
+// so a lane only ever works for ONE query: softmax statistics are an in-lane reduction + two cross-lane steps
+// (lanes l, l^16, l^32, l^48), and the online-softmax rescale of O^T is a per-lane scalar.
+// The reduction index e is consumed 16 at a time: one ds_read_b128 of K (4 consecutive e) feeds 4 MFMA K-steps, with the
+// matching 4 consecutive e of Q in registers (any partition of e into groups of 4 is a valid K-step).
+//
+// Workgroup = 4 waves = 64 queries of one (batch, head, direction); K and V^T tiles of 64 keys are staged through LDS
+// once per workgroup (34 KB -> 4 workgroups per CU). 2 * (QK^T + PV) = 4*L*L*hd FLOP per (b, h, direction).
+#include "common.hpp"
+
+namespace dimsum {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+constexpr int kKT = 64;          // keys per tile
+constexpr int kQW = 16;          // queries per wave
+
+template <int HD>
+__global__ __launch_bounds__(256) void xattn_fusion_fwd_kernel(const dimsum_xattn_params_t p) {
+    constexpr int KS = HD + 4;               // K tile row stride (floats): 16-B aligned rows, conflict-free b128 reads
+    constexpr int VS = kKT + 4;              // V^T tile row stride
+    constexpr int ET = (HD + 15) / 16;       // 16-row output tiles along e
+    constexpr int EC = HD / 16;              // full 16-wide chunks of the reduction index
+    constexpr bool kTail8 = (HD % 16) == 8;  // plus one 8-wide chunk (hd = 24, 72)
+    static_assert(HD % 8 == 0, "head_dim must be a multiple of 8");
+    __shared__ __attribute__((aligned(16))) float Ks[kKT * KS];
+    __shared__ __attribute__((aligned(16))) float Vt[ET * 16 * VS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int L = p.seqlen, H = p.heads;
+    const int qblocks = (L + 63) / 64;
+    int idx = blockIdx.x;
+    const int qb = idx % qblocks; idx /= qblocks;
+    const int dir = idx & 1; idx >>= 1;
+    const int h = idx % H;
+    const int b = idx / H;
+    const int C = H * HD;
+    // direction 0: q1, k2, v2   direction 1: q2, k1, v1
+    const float *qsrc = reinterpret_cast<const float *>(dir == 0 ? p.qkv1_ptr : p.qkv2_ptr) + (int64_t)b * p.qkv_batch_stride + h * HD;
+    const float *kvsrc = reinterpret_cast<const float *>(dir == 0 ? p.qkv2_ptr : p.qkv1_ptr) + (int64_t)b * p.qkv_batch_stride + h * HD;
+    const float *ksrc = kvsrc + C, *vsrc = kvsrc + 2 * C;
+    const int64_t ts = p.qkv_token_stride;
+
+    const int qi = lane & 15, kg = lane >> 4;                 // this lane's query (within the wave) and k-index group
+    const int q_tok = qb * 64 + wave * kQW + qi;
+    const int q_ld = min(q_tok, L - 1);
+    const float qscale = p.scale * kLog2e;                    // scores live in the log2 domain
+    // Q^T fragments: chunk c holds e = 16c + 4*kg .. +3
+    f4 qf[EC + (kTail8 ? 1 : 0)];
+#pragma unroll
+    for (int c = 0; c < EC; ++c) {
+        const float4 t = *reinterpret_cast<const float4 *>(qsrc + (int64_t)q_ld * ts + 16 * c + 4 * kg);
+        qf[c] = f4{t.x * qscale, t.y * qscale, t.z * qscale, t.w * qscale};
+    }
+    if constexpr (kTail8) {                                   // 8-wide tail: k-groups 0,1 -> e = 16*EC + 4*(kg&1) ..; groups 2,3 idle
+        const float4 t = *reinterpret_cast<const float4 *>(qsrc + (int64_t)q_ld * ts + 16 * EC + 4 * (kg & 1));
+        const float m = (kg < 2) ? qscale : 0.f;
+        qf[EC] = f4{t.x * m, t.y * m, t.z * m, t.w * m};
+    }
+
+    f4 o[ET];
+#pragma unroll
+    for (int e = 0; e < ET; ++e) o[e] = f4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -1e30f, l_run = 0.f;
+
+    for (int k0 = 0; k0 < L; k0 += kKT) {
+        __syncthreads();
+        // ---- stage K [key][e] and V^T [e][key] for keys k0 .. k0+63 ---------------------------------------------------
+        for (int i = tid; i < kKT * (HD / 4); i += 256) {
+            const int key = i / (HD / 4), e4 = i - key * (HD / 4);
+            const int tok = min(k0 + key, L - 1);
+            const float4 kv = *reinterpret_cast<const float4 *>(ksrc + (int64_t)tok * ts + e4 * 4);
+            const float4 vv = *reinterpret_cast<const float4 *>(vsrc + (int64_t)tok * ts + e4 * 4);
+            *reinterpret_cast<float4 *>(&Ks[key * KS + e4 * 4]) = kv;
+            Vt[(e4 * 4 + 0) * VS + key] = vv.x; Vt[(e4 * 4 + 1) * VS + key] = vv.y;
+            Vt[(e4 * 4 + 2) * VS + key] = vv.z; Vt[(e4 * 4 + 3) * VS + key] = vv.w;
+        }
+        if constexpr (ET * 16 > HD) {                         // zero the padding rows of V^T (e >= hd)
+            for (int i = tid; i < (ET * 16 - HD) * kKT; i += 256) Vt[(HD + i / kKT) * VS + (i % kKT)] = 0.f;
+        }
+        __syncthreads();
+
+        // ---- S^T = K Q^T for the 4 key tiles of 16 ------------------------------------------------------------------
+        f4 s[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+            const float *krow = &Ks[(kt * 16 + qi) * KS];      // A operand row: key = kt*16 + (lane&15)
+#pragma unroll
+            for (int c = 0; c < EC; ++c) {
+                const float4 kf = *reinterpret_cast<const float4 *>(krow + 16 * c + 4 * kg);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[c].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[c].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[c].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[c].w, acc, 0, 0, 0);
+            }
+            if constexpr (kTail8) {
+                const float4 kf = *reinterpret_cast<const float4 *>(krow + 16 * EC + 4 * (kg & 1));
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[EC].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[EC].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[EC].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[EC].w, acc, 0, 0, 0);
+            }
+            s[kt] = acc;                                       // s[kt][r]: key k0 + kt*16 + kg*4 + r, query qi
+        }
+        // ---- online softmax for this lane's query ---------------------------------------------------------------------
+        float mx = -1e30f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (k0 + kt * 16 + kg * 4 + r >= L) s[kt][r] = -1e30f;
+                mx = fmaxf(mx, s[kt][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, kWave));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = fast_exp2(m_run - m_new);
+        float rs = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[kt][r] = fast_exp2(s[kt][r] - m_new); rs += s[kt][r]; }
+        rs += __shfl_xor(rs, 16, kWave);
+        rs += __shfl_xor(rs, 32, kWave);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int e = 0; e < ET; ++e) o[e] *= alpha;
+        // ---- O^T += V^T P^T: K-step (kt, r) covers keys kt*16 + {r, 4+r, 8+r, 12+r}; its B operand is s[kt][r] -------------
+#pragma unroll
+        for (int e = 0; e < ET; ++e) {
+            const float *vrow = &Vt[(e * 16 + qi) * VS];       // A operand row: e = e*16 + (lane&15)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const float4 vf = *reinterpret_cast<const float4 *>(vrow + kt * 16 + kg * 4);   // keys kt*16 + kg*4 + r
+                o[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.x, s[kt][0], o[e], 0, 0, 0);
+                o[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.y, s[kt][1], o[e], 0, 0, 0);
+                o[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.z, s[kt][2], o[e], 0, 0, 0);
+                o[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.w, s[kt][3], o[e], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: O^T C layout = query (lane&15), e = et*16 + kg*4 + r  -> 16-byte stores --------------------------------
+    if (q_tok < L) {
+        const float inv = 1.0f / l_run;
+        float *dst = reinterpret_cast<float *>(p.out_ptr) + (int64_t)b * p.out_batch_stride + (int64_t)q_tok * p.out_token_stride + dir * C + h * HD;
+#pragma unroll
+        for (int e = 0; e < ET; ++e) {
+            const int e0 = e * 16 + kg * 4;
+            if (e0 < HD) *reinterpret_cast<float4 *>(dst + e0) = make_float4(o[e][0] * inv, o[e][1] * inv, o[e][2] * inv, o[e][3] * inv);
+        }
+        if (p.lse_ptr && kg == 0)
+            reinterpret_cast<float *>(p.lse_ptr)[(((int64_t)b * 2 + dir) * H + h) * L + q_tok] = (m_run + __builtin_amdgcn_logf(l_run)) * kLn2;
+    }
+}
+
+}  // namespace dimsum
+
+extern "C" int dimsum_xattn_fusion_fwd(const dimsum_xattn_params_t *p, void *stream) {
+    using namespace dimsum;
+    if (!p || !p->qkv1_ptr || !p->qkv2_ptr || !p->out_ptr) return DIMSUM_ERR_NULL;
+    if (p->batch < 0 || p->seqlen <= 0 || p->heads <= 0) return DIMSUM_ERR_SHAPE;
+    if (!aligned_to<float>(p->qkv1_ptr, 16) || !aligned_to<float>(p->qkv2_ptr, 16) || !aligned_to<float>(p->out_ptr, 16) ||
+        p->qkv_batch_stride % 4 != 0 || p->qkv_token_stride % 4 != 0 || p->out_batch_stride % 4 != 0 || p->out_token_stride % 4 != 0)
+        return DIMSUM_ERR_STRIDE;
+    if (p->batch == 0) return DIMSUM_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t nblk = (int64_t)p->batch * p->heads * 2 * ((p->seqlen + 63) / 64);
+    if (nblk > 0x7fffffff) return DIMSUM_ERR_SHAPE;
+    const dim3 grid((unsigned)nblk), block(256);
+    switch (p->head_dim) {
+        case 24: hipLaunchKernelGGL(xattn_fusion_fwd_kernel<24>, grid, block, 0, s, *p); break;
+        case 32: hipLaunchKernelGGL(xattn_fusion_fwd_kernel<32>, grid, block, 0, s, *p); break;
+        case 48: hipLaunchKernelGGL(xattn_fusion_fwd_kernel<48>, grid, block, 0, s, *p); break;
+        case 64: hipLaunchKernelGGL(xattn_fusion_fwd_kernel<64>, grid, block, 0, s, *p); break;
+        case 72: hipLaunchKernelGGL(xattn_fusion_fwd_kernel<72>, grid, block, 0, s, *p); break;
+        default: return DIMSUM_ERR_SHAPE;
+    }
+    return launch_status();
+}

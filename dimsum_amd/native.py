@@ -366,9 +366,8 @@ def gated_gelu_bwd(x12, dh):
 # cross-attention fusion core (csrc/xattn_fusion.hip)
 # ---------------------------------------------------------------------------------------------------------------------
 def xattn_supported(qkv, head_dim):
-    """the MFMA kernel handles fp32 qkv rows with head_dim % 8 == 0 (24, 48, 64, 72 in the DiM zoo)"""
-    return (qkv.is_cuda and qkv.dtype == torch.float32 and qkv.stride(-1) == 1 and head_dim % 8 == 0 and head_dim <= 128
-            and hasattr(_lib.load(), "dimsum_xattn_fusion_fwd"))
+    """the MFMA kernel is instantiated for the head sizes of the DiM zoo: 24 (S/2), 48 (B/2), 64 (L/*), 72 (XL/2), and 32"""
+    return qkv.is_cuda and qkv.dtype == torch.float32 and qkv.stride(-1) == 1 and head_dim in (24, 32, 48, 64, 72)
 
 
 def xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=False):
