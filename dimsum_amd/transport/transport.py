@@ -1,0 +1,123 @@
+"""Flow-matching transport: training loss and ODE sampler around the denoiser (dimsum/transport/transport.py).
+Velocity prediction (the published configs); the SDE samplers, likelihood ODE and blurring are not part of the
+denoiser hot path and are left out."""
+import enum
+
+import torch as th
+
+from . import path
+from .integrators import ode
+
+
+class ModelType(enum.Enum):
+    NOISE = enum.auto()
+    SCORE = enum.auto()
+    VELOCITY = enum.auto()
+
+
+class PathType(enum.Enum):
+    LINEAR = enum.auto()
+    GVP = enum.auto()
+    VP = enum.auto()
+
+
+class WeightType(enum.Enum):
+    NONE = enum.auto()
+    VELOCITY = enum.auto()
+    LIKELIHOOD = enum.auto()
+
+
+def mean_flat(x):
+    return th.mean(x, dim=list(range(1, x.dim())))
+
+
+class Transport:
+    def __init__(self, *, model_type, path_type, loss_type, train_eps, sample_eps, path_args={}, t_sample_mode="uniform"):
+        plans = {PathType.LINEAR: path.ICPlan, PathType.GVP: path.GVPCPlan, PathType.VP: path.VPCPlan}
+        self.loss_type, self.model_type = loss_type, model_type
+        self.path_sampler = plans[path_type](**path_args)
+        self.train_eps, self.sample_eps, self.t_sample_mode = train_eps, sample_eps, t_sample_mode
+
+    def check_interval(self, train_eps, sample_eps, *, diffusion_form="SBDM", sde=False, reverse=False, eval=False, last_step_size=0.0):
+        """integration interval (transport.py:79-107)"""
+        t0, t1 = 0, 1
+        eps = train_eps if not eval else sample_eps
+        if type(self.path_sampler) is path.VPCPlan:
+            t1 = 1 - eps if (not sde or last_step_size == 0) else 1 - last_step_size
+        elif type(self.path_sampler) in (path.ICPlan, path.GVPCPlan) and (self.model_type != ModelType.VELOCITY or sde):
+            t0 = eps if (diffusion_form == "SBDM" and sde) or self.model_type != ModelType.VELOCITY else 0
+            t1 = 1 - eps if (not sde or last_step_size == 0) else 1 - last_step_size
+        return (1 - t0, 1 - t1) if reverse else (t0, t1)
+
+    def sample(self, x1):
+        """x0 ~ N(0, I), t ~ U(t0, t1) or logit-normal (transport.py:109-125)"""
+        x0 = th.randn_like(x1)
+        t0, t1 = self.check_interval(self.train_eps, self.sample_eps)
+        if self.t_sample_mode == "logitnormal":
+            t = th.sigmoid(th.randn((x1.shape[0],)) - 0.5) * (t1 - t0) + t0
+        else:
+            t = th.rand((x1.shape[0],)) * (t1 - t0) + t0
+        return t.to(x1), x0, x1
+
+    def training_losses(self, model, x1, model_kwargs=None):
+        """mean((model(x_t, t) - u_t)^2) for velocity prediction (transport.py:127-164)"""
+        model_kwargs = model_kwargs or {}
+        t, x0, x1 = self.sample(x1)
+        t, xt, ut = self.path_sampler.plan(t, x0, x1)
+        out = model(xt, t, **model_kwargs)
+        assert out.size() == xt.size()
+        terms = {"pred": out}
+        if self.model_type == ModelType.VELOCITY:
+            terms["loss"] = mean_flat((out - ut) ** 2)
+            return terms
+        _, drift_var = self.path_sampler.compute_drift(xt, t)
+        sigma_t, _ = self.path_sampler.compute_sigma_t(path.expand_t_like_x(t, xt))
+        weight = {WeightType.VELOCITY: (drift_var / sigma_t) ** 2, WeightType.LIKELIHOOD: drift_var / (sigma_t ** 2),
+                  WeightType.NONE: 1}[self.loss_type]
+        if self.model_type == ModelType.NOISE:
+            terms["loss"] = mean_flat(weight * ((out - x0) ** 2))
+        else:
+            terms["loss"] = mean_flat(weight * ((out * sigma_t + x0) ** 2))
+        return terms
+
+    def get_drift(self):
+        """drift of the probability-flow ODE (transport.py:166-197)"""
+        def score_ode(x, t, model, **kw):
+            mean, var = self.path_sampler.compute_drift(x, t)
+            return -mean + var * model(x, t, **kw)
+
+        def noise_ode(x, t, model, **kw):
+            mean, var = self.path_sampler.compute_drift(x, t)
+            sigma_t, _ = self.path_sampler.compute_sigma_t(path.expand_t_like_x(t, x))
+            return -mean + var * (model(x, t, **kw) / -sigma_t)
+
+        def velocity_ode(x, t, model, **kw):
+            return model(x, t, **kw)
+
+        fn = {ModelType.NOISE: noise_ode, ModelType.SCORE: score_ode, ModelType.VELOCITY: velocity_ode}[self.model_type]
+
+        def body_fn(x, t, model, **kw):
+            out = fn(x, t, model, **kw)
+            assert out.shape == x.shape, "Output shape from ODE solver must match input shape"
+            return out
+
+        return body_fn
+
+
+class Sampler:
+    def __init__(self, transport):
+        self.transport = transport
+        self.drift = transport.get_drift()
+
+    def sample_ode(self, *, sampling_method="euler", num_steps=50, atol=1e-6, rtol=1e-3, reverse=False):
+        """-> sample_fn(x, model, **model_kwargs) returning the trajectory (transport.py:343-386)"""
+        if reverse:
+            drift = lambda x, t, model, **kw: self.drift(x, th.ones_like(t) * (1 - t), model, **kw)  # noqa: E731
+        else:
+            drift = self.drift
+        t0, t1 = self.transport.check_interval(self.transport.train_eps, self.transport.sample_eps, sde=False, eval=True,
+                                               reverse=reverse, last_step_size=0.0)
+        return ode(drift=drift, t0=t0, t1=t1, sampler_type=sampling_method, num_steps=num_steps, atol=atol, rtol=rtol).sample
+
+    def sample_sde(self, *a, **k):
+        raise NotImplementedError("SDE sampling is outside the denoiser hot path (SURVEY.md 8 f1)")

@@ -1,0 +1,114 @@
+"""CPU tests of the flow-matching host logic: path plans vs closed forms, Euler stepping count / accuracy on an analytic
+field, GVP training target, and the world_size-2 gloo sharding + all-gather of sample_ddp."""
+import math
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dimsum_amd.transport import Sampler, create_transport
+
+
+def test_gvp_plan_matches_closed_form():
+    tr = create_transport("GVP", "velocity")
+    x0, x1 = torch.randn(5, 4, 8, 8), torch.randn(5, 4, 8, 8)
+    t = torch.rand(5)
+    _, xt, ut = tr.path_sampler.plan(t, x0, x1)
+    tt = t.view(-1, 1, 1, 1)
+    assert torch.allclose(xt, torch.sin(math.pi * tt / 2) * x1 + torch.cos(math.pi * tt / 2) * x0, atol=1e-6)
+    assert torch.allclose(ut, math.pi / 2 * (torch.cos(math.pi * tt / 2) * x1 - torch.sin(math.pi * tt / 2) * x0), atol=1e-6)
+    assert tr.check_interval(tr.train_eps, tr.sample_eps, eval=True) == (0, 1)
+
+
+def test_training_loss_is_mse_to_target():
+    torch.manual_seed(0)
+    tr = create_transport("GVP", "velocity")
+    x1 = torch.randn(6, 4, 8, 8)
+    seen = {}
+
+    def model(xt, t, y=None):
+        seen["t"], seen["xt"] = t, xt
+        return torch.zeros_like(xt)
+
+    torch.manual_seed(1)
+    terms = tr.training_losses(model, x1, dict(y=torch.zeros(6, dtype=torch.long)))
+    torch.manual_seed(1)
+    t, x0, _ = tr.sample(x1)
+    _, xt, ut = tr.path_sampler.plan(t, x0, x1)
+    assert torch.equal(seen["xt"], xt) and torch.equal(seen["t"], t)
+    assert torch.allclose(terms["loss"], (ut ** 2).mean(dim=(1, 2, 3)))
+
+
+@pytest.mark.parametrize("method,nfe_per_step,order", [("euler", 1, 1), ("heun2", 2, 2), ("rk4", 4, 4)])
+def test_fixed_grid_steppers(method, nfe_per_step, order):
+    """dx/dt = -x: x(1) = x(0) e^-1; NFE = (num_steps - 1) * nfe_per_step; error shrinks at the method's order."""
+    calls = []
+
+    def model(x, t, y=None):
+        calls.append(float(t[0]))
+        assert t.shape == (x.shape[0],)
+        return -x
+
+    sampler = Sampler(create_transport("Linear", "velocity"))
+    x0 = torch.ones(3, 2, dtype=torch.float64)
+    errs = []
+    for n in (11, 21):
+        calls.clear()
+        traj = sampler.sample_ode(sampling_method=method, num_steps=n)(x0, model, y=None)
+        assert traj.shape[0] == n and len(calls) == (n - 1) * nfe_per_step
+        errs.append(abs(traj[-1][0, 0].item() - math.exp(-1)))
+    assert errs[1] < errs[0] / (2 ** order) * 1.3
+    if method == "euler":
+        assert calls[0] == 0.0 and abs(calls[-1] - 0.95) < 1e-6          # evaluated at the LEFT end of every interval
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dimsum_amd.sample_ddp import sample_batch, shard_range
+    lo, hi = shard_range(total, rank, world)
+    torch.manual_seed(0 * world + rank)                                   # sample_ddp.py:64 seeding rule
+    z = torch.randn(4, 2, 4, 4)
+    y = torch.full((4,), rank)
+
+    class Field(torch.nn.Module):                                         # analytic velocity field, label dependent
+        in_channels, num_classes = 2, 10
+
+        def forward(self, x, t, y=None):
+            return -x * (1 + y.view(-1, 1, 1, 1).float())
+
+    full = sample_batch(Field(), z, y, num_steps=20, world_size=world)
+    local = sample_batch(Field(), z, y, num_steps=20, world_size=world, gather=False)
+    out_q.put((rank, lo, hi, full, local))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_all_gather():
+    world, total = 2, 9
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, lo0, hi0, full0, loc0), (r1, lo1, hi1, full1, loc1) = res
+    assert (lo0, hi0, lo1, hi1) == (0, 5, 5, 9)                           # contiguous, disjoint, covering
+    assert torch.equal(full0, full1) and full0.shape == (8, 2, 4, 4)      # every rank holds the same gathered tensor
+    assert torch.equal(full0[:4], loc0) and torch.equal(full0[4:], loc1)  # rank-major order
+    assert not torch.equal(loc0, loc1)                                    # rank-dependent seeds / labels
