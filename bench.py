@@ -208,7 +208,7 @@ def main():
                                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                                 "algorithmic_bytes_per_launch": avg_bytes, "avg_launch_ms": avg_ms, "launches_timed": n}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.model, 2, args.image_size)
+            line["cpu_baseline"] = cpu_baseline(args.model, 8, args.image_size)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
