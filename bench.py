@@ -52,36 +52,60 @@ def scan_bytes(B, D, L, N, G=1, s=4):
     return 5 * B * D * L * s + 2 * B * G * N * L * s + B * D * ((L + 2047) // 2048) * 2 * N * 4 + (D * N + 2 * D) * 4
 
 
+def scan_bwd_bytes(B, D, L, N, G=1, s=4):
+    """SURVEY.md 8(d), with the out_z recompute MambaInnerFn always requests: reads u, delta, z, out, dout, B, C, x;
+    writes du, ddelta, dz, out_z, dB, dC (fp32): 9 B D L s + 2 B G N L (s + 4) + x"""
+    return 9 * B * D * L * s + 2 * B * G * N * L * (s + 4) + B * D * ((L + 2047) // 2048) * 2 * N * 4 + (D * N + 2 * D) * 4
+
+
 class ScanTimer:
-    """HIP-event pairs around every selective-scan launch (recorded on torch's current stream = the launch stream)."""
+    """HIP-event pairs around every selective-scan launch (recorded on torch's current stream = the launch stream).
+    The events bracket exactly one kernel launch: native.selective_scan_fwd/_bwd allocate (caching allocator, no
+    device work) and launch; the bwd's accumulator memsets are issued before the first event."""
 
     def __init__(self):
-        self.events, self.bytes, self.enabled = [], [], False
+        self.events, self.bytes, self.enabled = {"fwd": [], "bwd": []}, {"fwd": [], "bwd": []}, False
 
     def install(self):
-        from dimsum_amd import native
-        inner = native.selective_scan_fwd
+        from dimsum_amd import _lib
+        lib = _lib.load()
         timer = self
 
-        def timed(u, delta, A, B, C, D, z, delta_bias, delta_softplus, **kw):
-            if not timer.enabled:
-                return inner(u, delta, A, B, C, D, z, delta_bias, delta_softplus, **kw)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = inner(u, delta, A, B, C, D, z, delta_bias, delta_softplus, **kw)
-            e1.record()
-            timer.events.append((e0, e1))
-            timer.bytes.append(scan_bytes(u.shape[0], u.shape[1], u.shape[2], A.shape[1], B.shape[1], u.element_size()))
-            return r
+        class Timed:
+            """proxy of the ctypes library: times the two scan entry points, forwards everything else"""
 
-        native.selective_scan_fwd = timed
+            def __getattr__(self, name):
+                return getattr(lib, name)
 
-    def summary(self):
-        if not self.events:
+            def _timed(self, which, fn, P, stream):
+                if not timer.enabled:
+                    return fn(P, stream)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = fn(P, stream)
+                e1.record()
+                p = P.fwd if which == "bwd" else P
+                f = scan_bwd_bytes if which == "bwd" else scan_bytes
+                s = {_lib.F32: 4}.get(p.dtype, 2)
+                timer.events[which].append((e0, e1))
+                timer.bytes[which].append(f(p.batch, p.dim, p.seqlen, p.dstate, p.n_groups, s))
+                return rc
+
+            def dimsum_ssm_scan_fwd(self, P, stream):
+                return self._timed("fwd", lib.dimsum_ssm_scan_fwd, P, stream)
+
+            def dimsum_ssm_scan_bwd(self, P, stream):
+                return self._timed("bwd", lib.dimsum_ssm_scan_bwd, P, stream)
+
+        proxy = Timed()
+        _lib.load = lambda: proxy
+
+    def summary(self, which="fwd"):
+        if not self.events[which]:
             return None
-        ms = [a.elapsed_time(b) for a, b in self.events]
+        ms = [a.elapsed_time(b) for a, b in self.events[which]]
         avg_ms = sum(ms) / len(ms)
-        avg_bytes = sum(self.bytes) / len(self.bytes)
+        avg_bytes = sum(self.bytes[which]) / len(self.bytes[which])
         return avg_ms, avg_bytes, len(ms)
 
 
@@ -92,6 +116,20 @@ def build_model(name, device, image_size=256):
     model = create_model(published_config(model=name, image_size=image_size))
     rerandomize_zeros(model, std=0.02, seed=0)       # reference init is adaLN-zero (SURVEY finding 5)
     return model.to(device).eval()
+
+
+def build_block(name, device):
+    """BASELINE configs[2]: one DiMBlockCombined of `name`'s width with the published flags (layer 1: reverse sweep,
+    transposed Haar window scan), weights as in build_model."""
+    from dimsum_amd.models_dim import create_block
+    from dimsum_amd.utils import rerandomize_zeros
+    hidden = {"DiM-S/2": 384, "DiM-B/2": 768, "DiM-L/2": 1024, "DiM-L/4": 1024, "DiM-XL/2": 1152}[name]
+    torch.manual_seed(0)
+    blk = create_block(hidden, norm_epsilon=1e-5, rms_norm=True, residual_in_fp32=True, fused_add_norm=True, layer_idx=1,
+                       scan_type="none", block_type="combined", reverse=True, transpose=False, cond_mamba=True,
+                       scanning_continuity=False, use_gated_mlp=True)
+    rerandomize_zeros(blk, std=0.02, seed=0)
+    return blk.to(device).train(), hidden
 
 
 def cpu_baseline(name, latents=2, image_size=256):
@@ -122,7 +160,9 @@ def main():
     ap.add_argument("--model", default="DiM-L/2")
     ap.add_argument("--batch", type=int, default=256, help="latents per GPU per step")
     ap.add_argument("--image-size", type=int, default=256)
-    ap.add_argument("--mode", choices=["fwd", "sample"], default="fwd")
+    ap.add_argument("--mode", choices=["fwd", "sample", "block"], default="fwd",
+                    help="fwd: denoiser forward (headline, BASELINE configs[1]); sample: --nfe Euler steps + all-gather "
+                         "(configs[3]); block: ONE DiMBlockCombined forward+backward (configs[2])")
     ap.add_argument("--nfe", type=int, default=250)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -140,8 +180,11 @@ def main():
 
     from dimsum_amd import _lib
     _lib.load()                                   # fail loudly if the HIP library is missing
-    model = build_model(args.model, dev, args.image_size)
     r = args.image_size // 8
+    if args.mode == "block":
+        model, hidden = build_block(args.model, dev)
+    else:
+        model = build_model(args.model, dev, args.image_size)
     gen = torch.Generator(device=dev).manual_seed(0 * world + rank)      # sample_ddp.py:64 seeding rule
     x = torch.randn(args.batch, 4, r, r, device=dev, generator=gen)
     t = torch.rand(args.batch, device=dev, generator=gen)
@@ -150,7 +193,21 @@ def main():
     timer = ScanTimer()
     timer.install()
 
-    if args.mode == "fwd":
+    if args.mode == "block":
+        ntok = (r // 2) ** 2
+        hs = torch.randn(args.batch, ntok, hidden, device=dev, generator=gen).requires_grad_()
+        res = torch.randn(args.batch, ntok, hidden, device=dev, generator=gen).requires_grad_()
+        cond = torch.randn(args.batch, hidden, device=dev, generator=gen).requires_grad_()
+        dy = torch.randn(args.batch, ntok, hidden, device=dev, generator=gen)
+
+        def step():
+            for p_ in model.parameters():
+                p_.grad = None
+            hs.grad = res.grad = cond.grad = None
+            out, res_out = model(hs, res, cond)
+            torch.autograd.backward((out, res_out), (dy, dy))
+        units_per_step = args.batch
+    elif args.mode == "fwd":
         def step():
             with torch.no_grad():
                 return model(x, t, y)
@@ -184,30 +241,43 @@ def main():
     if rank == 0:
         value = units_per_step * world * args.steps / elapsed
         fwd_mode = args.mode == "fwd"
+        what = {"fwd": "denoiser forward", "sample": f"denoiser {args.nfe}-NFE Euler sampling",
+                "block": "ONE DiMBlockCombined (scan + Haar + attention fusion + gated MLP) forward+backward"}[args.mode]
         line = {
-            "metric": "denoiser-fwd latents/sec" if fwd_mode else f"{args.nfe}-NFE samples/sec",
-            "value": value, "unit": "latents/s" if fwd_mode else "samples/s", "n_gpus": world, "steps": args.steps,
+            "metric": {"fwd": "denoiser-fwd latents/sec", "sample": f"{args.nfe}-NFE samples/sec",
+                       "block": "block fwd+bwd latents/sec"}[args.mode],
+            "value": value, "unit": "samples/s" if args.mode == "sample" else "latents/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.model} denoiser {'forward' if fwd_mode else f'{args.nfe}-NFE Euler sampling'}, "
+            "config": {"workload": f"{args.model} {what}, "
                                    f"{args.image_size}px (4x{r}x{r} latents, {(r // 2) ** 2} tokens), {args.batch} latents per GPU, "
                                    "random-init weights (reference init, zero tensors re-drawn N(0, 0.02^2))",
                        "global_batch": args.batch * world, "parallelism": f"dp{world} (replicas, independent latents)"},
         }
         if fwd_mode:
             line["samples_per_sec_at_250_nfe"] = value / 250.0
-        s = timer.summary()
-        if s is not None:
+
+        def roof(which, kernel, pmc):
+            s = timer.summary(which)
+            if s is None:
+                return None
             avg_ms, avg_bytes, n = s
             achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
             traffic = None
-            prof = os.path.join(ROOT, "profiles", "scan_fwd_pmc.json")    # HBM bytes per launch from rocprofv3 --pmc
+            prof = os.path.join(ROOT, "profiles", pmc)    # HBM bytes per launch from rocprofv3 --pmc
             if os.path.exists(prof):
                 traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
-            line["roofline"] = {"kernel": "ssm_scan_fwd_kernel<float,16>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                                "algorithmic_bytes_per_launch": avg_bytes, "avg_launch_ms": avg_ms, "launches_timed": n}
-        if world == 1 and not args.no_cpu_baseline:
+            return {"kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "algorithmic_bytes_per_launch": avg_bytes,
+                    "avg_launch_ms": avg_ms, "launches_timed": n}
+
+        rf = roof("fwd", "ssm_scan_fwd_kernel<float,16>", "scan_fwd_pmc.json")
+        if rf is not None:
+            line["roofline"] = rf
+        rb = roof("bwd", "ssm_scan_bwd_kernel<float,16>", "scan_bwd_pmc.json")
+        if rb is not None:
+            line["roofline_bwd"] = rb
+        if world == 1 and not args.no_cpu_baseline and args.mode != "block":
             line["cpu_baseline"] = cpu_baseline(args.model, 8, args.image_size)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -17,7 +17,7 @@ class SsmParams(C.Structure):
                                       "z_batch_stride", "z_d_stride", "out_batch_stride", "out_d_stride",
                                       "out_z_batch_stride", "out_z_d_stride")]
                 + [(n, vp) for n in ("A_ptr", "B_ptr", "C_ptr", "D_ptr", "u_ptr", "delta_ptr", "delta_bias_ptr",
-                                     "z_ptr", "out_ptr", "x_ptr", "out_z_ptr")])
+                                     "z_ptr", "out_ptr", "x_ptr", "out_z_ptr", "ckpt_ptr")])
 
 
 class SsmBwdParams(C.Structure):
@@ -63,9 +63,10 @@ class NormBwdParams(C.Structure):
 class TtParams(C.Structure):
     _fields_ = ([(n, i32) for n in ("batch", "tokens", "channels", "grid", "kind", "reserved")]
                 + [(n, i64) for n in ("x_batch_stride", "x_token_stride", "res_batch_stride", "res_token_stride",
-                                      "y_batch_stride", "y_token_stride", "mod_batch_stride")]
+                                      "y_batch_stride", "y_token_stride", "mod_batch_stride", "w_batch_stride",
+                                      "w_token_stride", "red_batch_stride")]
                 + [(n, vp) for n in ("x_ptr", "in_index_ptr", "out_index_ptr", "gate_ptr", "scale_ptr", "shift_ptr",
-                                     "residual_ptr", "y_ptr")])
+                                     "residual_ptr", "y_ptr", "w_ptr", "wdot_ptr", "wsum_ptr")])
 
 
 class XattnParams(C.Structure):
@@ -114,7 +115,7 @@ def load():
     if hasattr(lib, "dimsum_ssm_scan_bwd_workspace_bytes"):
         lib.dimsum_ssm_scan_bwd_workspace_bytes.restype = i64
         lib.dimsum_ssm_scan_bwd_workspace_bytes.argtypes = [i32] * 5
-    if lib.dimsum_abi_version() != 1:
+    if lib.dimsum_abi_version() != 2:
         raise RuntimeError("dimsum_amd: libdimsum_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -13,29 +13,39 @@
 // MI355X design. Same mapping as the forward (lane = channel, one wave64 = 64 channels of one batch element, sequence
 // walked in registers), which needs the forward states in REVERSE order. Instead of the reference's per-row block-wide
 // forward + reverse parallel scans (about 3x the arithmetic, plus 1024-way global atomic contention on dB/dC):
-//   phase A  one forward sweep over the sequence stores the state at every 16-step tile boundary in a workspace
-//            (B*D*L*N/16 floats = 1/2 of one activation tensor; lane-contiguous so the traffic is fully coalesced);
-//   phase B  tiles are walked backwards. The N state recurrences are independent, so each tile is processed 4 states
-//            at a time: forward sweep (16 steps) keeping h_t[4] in registers (64 VGPRs), then the reverse sweep over
-//            the same registers. Nothing per-(t,n) ever touches memory.
-//   dB / dC  are sums over the wave's 64 channels of per-lane values: they are reduced with a TRANSPOSED butterfly --
-//            64 values per lane go in, one fully reduced value per lane comes out, in 6 levels of
-//            v_permlane32_swap / v_permlane16_swap / DPP adds (~2 VALU ops per value instead of ~12 for 64
-//            independent wave reductions) -- then ONE coalesced atomicAdd per (n, t) per wave (16 waves contend per
-//            address instead of 1024 rows).
-//   u, delta, dy tiles go through an XOR-swizzled LDS transpose like in the forward; dz / out_z are computed in the
-//   coalesced load layout and never touch LDS.
+//   * the state before every 8-step half tile comes from the forward kernel (ckpt_ptr; training callers keep it) or, for
+//     callers with the reference's exact interface, from one extra state-only forward sweep into the workspace;
+//   * 16-step tiles are walked backwards, each as two 8-step halves. The N state recurrences are independent, so a half
+//     is processed 8 states at a time: forward sweep keeping h_t[8 states][8 steps] in 64 VGPRs, then the reverse
+//     sweep over the same registers (a_t h_{t-1} = h_t - b_t: no division). Nothing per-(t, n) ever touches memory.
+//     ~17 VALU ops + 2 v_exp_f32 per (t, n): the kernel is VALU-bound (the forward needs 4 + 1), HBM traffic is the
+//     algorithmic minimum + the states.
+//   * dB / dC are sums over the wave's 64 channels of per-lane values: a TRANSPOSED butterfly -- 64 values per lane go
+//     in, one fully reduced value per lane comes out, in 6 levels of v_permlane32_swap / v_permlane16_swap / DPP adds
+//     (~2.2 VALU ops per value instead of ~12 for 64 independent wave reductions) -- then ONE coalesced atomicAdd per
+//     (n, t) per wave (16 waves contend per address instead of the reference's 1024 rows,
+//     selective_scan_bwd_kernel.cuh:297-316).
+//   * u, delta, dy tiles go through an XOR-swizzled LDS transpose like in the forward; dz / out_z are computed in the
+//     coalesced load layout (16 B per lane in and out) and never touch LDS.
+//   * register budget <= 256 VGPRs (2 waves per SIMD cover each other's tile-staging latency).
 #include "common.hpp"
 
 namespace dimsum {
 
-constexpr int kBT = 16;   // time steps per tile
-constexpr int kBG = 4;    // states processed together
+constexpr int kBT = 16;   // time steps per LDS tile (64 B per row and tensor: one HBM burst)
+constexpr int kBS = 8;    // time steps per register sweep (= distance of the saved states)
 
 // 64 rows x 16 columns fp32, row = 4 slots of 16 B, slots XOR-swizzled by (row >> 2) & 3 (conflict-free b128 both ways)
 __device__ __forceinline__ int btile_off(int row, int col4) { return row * kBT + ((col4 ^ ((row >> 2) & 3)) << 2); }
 
-// ---- transposed butterfly: v[0..63] per lane in -> sum over the 64 lanes of v[lane] out ---------------------------------
+template <typename T> __device__ __forceinline__ const T *at(const T *base, unsigned elem_off) {
+    return reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (unsigned)(elem_off * (unsigned)sizeof(T)));
+}
+template <typename T> __device__ __forceinline__ T *at(T *base, unsigned elem_off) {
+    return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + (unsigned)(elem_off * (unsigned)sizeof(T)));
+}
+
+// ---- transposed butterfly: value i of every lane in -> lane l returns the 64-lane sum of value l ------------------------
 __device__ __forceinline__ void swap32(float &x, float &y) {
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
     x = __uint_as_float(r[0]); y = __uint_as_float(r[1]);
@@ -47,15 +57,20 @@ __device__ __forceinline__ void swap16(float &x, float &y) {
 template <int CTRL> __device__ __forceinline__ float dpp(float v) {
     return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xF, 0xF, true));
 }
-// NV values per lane (64 or 32). After the call v[0] holds, in lane l, the 64-lane sum of value (l % NV).
-template <int NV> __device__ __forceinline__ float transposed_reduce(float *v, int lane) {
+// gen(i), i = 0..NV-1, produces this lane's value i (NV = 64 or 32); the first level is fused with the generation so
+// that only NV/2 temporaries are ever live. Returns, in lane l, the 64-lane sum of value l % NV.
+template <int NV, typename Gen> __device__ __forceinline__ float transposed_reduce(Gen gen, int lane) {
     static_assert(NV == 64 || NV == 32, "");
+    float v[32];
     if constexpr (NV == 64) {
 #pragma unroll
-        for (int i = 0; i < 32; ++i) { swap32(v[i], v[i + 32]); v[i] += v[i + 32]; }     // lane bit 5 <-> value bit 5
+        for (int i = 0; i < 32; ++i) { float a = gen(i), b = gen(i + 32); swap32(a, b); v[i] = a + b; }   // lane bit 5 <-> value bit 5
+    } else {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) v[i] = gen(i);
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { swap16(v[i], v[i + 16]); v[i] += v[i + 16]; }         // lane bit 4 <-> value bit 4
+    for (int i = 0; i < 16; ++i) { swap16(v[i], v[i + 16]); v[i] += v[i + 16]; }                       // lane bit 4 <-> value bit 4
     // in-row levels: a lane keeps the value its bit selects and receives the partner's copy of that same value, i.e. the
     // partner sends the value it does NOT keep
 #pragma unroll
@@ -83,8 +98,19 @@ template <int NV> __device__ __forceinline__ float transposed_reduce(float *v, i
     return r;
 }
 
-template <typename T, int kN, bool kHasZ, bool kVec>
-__global__ __launch_bounds__(kWave, 1) void ssm_scan_bwd_kernel(const dimsum_ssm_bwd_params_t q, float *__restrict__ ws) {
+// sigmoid(x) for dt = softplus(x) = log(1 + e^x):  sigmoid(x) = 1 - exp(-dt)  (for x > 20 the reference takes dt = x and
+// a derivative of 1: 1 - exp(-20) rounds to 1). Small dt: alternating series (the direct form cancels).
+__device__ __forceinline__ float dsoftplus_from_dt(float dt) {
+    const float ser = dt * (1.0f - dt * (0.5f - dt * (1.0f / 6 - dt * (1.0f / 24 - dt * (1.0f / 120 - dt * (1.0f / 720))))));
+    return dt < 0.25f ? ser : 1.0f - fast_exp(-dt);
+}
+
+// kVec : every row base 4-element aligned and L % 4 == 0 -> 16-byte vector I/O.   kFull: all 64 lanes own a live channel.
+template <typename T, int kN, bool kHasZ, bool kVec, bool kFull>
+__global__ __launch_bounds__(kWave, 2) void ssm_scan_bwd_kernel(const dimsum_ssm_bwd_params_t q, const float *__restrict__ ckpt) {
+    constexpr int kBG = 4;                        // states processed together
+    constexpr int NV = kBG * kBS;                 // (state, step) values per transposed reduction
+    static_assert(kN % kBG == 0 && (NV == 64 || NV == 32), "dstate must be a multiple of 4");
     const dimsum_ssm_params_t &p = q.fwd;
     __shared__ __attribute__((aligned(16))) float tU[kWave * kBT], tD[kWave * kBT], tY[kWave * kBT];   // u, dt (softplus'ed), dy
     __shared__ __attribute__((aligned(16))) float tB[kN * kBT], tC[kN * kBT];
@@ -104,9 +130,9 @@ __global__ __launch_bounds__(kWave, 1) void ssm_scan_bwd_kernel(const dimsum_ssm
     const int rem = wg - b * tiles_per_batch;
     const int g = rem / tiles_per_group;
     const int d0 = g * dpg + (rem - g * tiles_per_group) * kWave;
-    const int nd = min(kWave, (g + 1) * dpg - d0);
-    const bool live = lane < nd;
-    const int d = d0 + min(lane, nd - 1);
+    const int nd = kFull ? kWave : min(kWave, (g + 1) * dpg - d0);
+    const bool live = kFull || lane < nd;
+    const int d = d0 + (kFull ? lane : min(lane, nd - 1));
 
     const T *u_base = reinterpret_cast<const T *>(p.u_ptr) + (int64_t)b * p.u_batch_stride + (int64_t)d0 * p.u_d_stride;
     const T *dl_base = reinterpret_cast<const T *>(p.delta_ptr) + (int64_t)b * p.delta_batch_stride + (int64_t)d0 * p.delta_d_stride;
@@ -125,22 +151,27 @@ __global__ __launch_bounds__(kWave, 1) void ssm_scan_bwd_kernel(const dimsum_ssm
     const int y_ds = (int)p.out_d_stride, oz_ds = (int)p.out_z_d_stride, dz_ds = (int)q.dz_d_stride, du_ds = (int)q.du_d_stride;
     const int dd_ds = (int)q.ddelta_d_stride;
     const int Bns = (int)p.B_dstate_stride, Cns = (int)p.C_dstate_stride;
+    const int dBns = (int)q.dB_dstate_stride, dCns = (int)q.dC_dstate_stride;
 
-    float A[kN];
-    const float *Ap = reinterpret_cast<const float *>(p.A_ptr) + (int64_t)d * p.A_d_stride;
+    {
+        const float *Ap = reinterpret_cast<const float *>(p.A_ptr) + (int64_t)d * p.A_d_stride;
 #pragma unroll
-    for (int n = 0; n < kN; ++n) {
-        A[n] = Ap[n * p.A_dstate_stride];
-        sA[n * kWave + lane] = A[n]; sdA[n * kWave + lane] = 0.f; sdh[n * kWave + lane] = 0.f;
+        for (int n = 0; n < kN; ++n) {
+            sA[n * kWave + lane] = Ap[n * p.A_dstate_stride] * kLog2e;    // exp(dt A) = exp2(dt A log2 e)
+            sdA[n * kWave + lane] = 0.f; sdh[n * kWave + lane] = 0.f;
+        }
     }
     const float Dval = p.D_ptr ? reinterpret_cast<const float *>(p.D_ptr)[d] : 0.f;
     const float bias = p.delta_bias_ptr ? reinterpret_cast<const float *>(p.delta_bias_ptr)[d] : 0.f;
     const bool softplus = p.delta_softplus != 0;
     float dD = 0.f, dbias = 0.f;
-    float dtl_next = 0.f;   // dt * log2(e) of the first step of the tile processed before (later in time): a_{t+1} at the seam
+    float dt_next = 0.f;   // dt of the first step of the tile processed before (later in time): a_{t+1} at the seam
 
     const int n_tiles = (L + kBT - 1) / kBT;
-    float *wsw = ws + (int64_t)wg * n_tiles * kN * kWave;     // [tile][n][lane]
+    const int n_halves = (L + kBS - 1) / kBS;
+    // saved states: [b][half tile][n][d]
+    const float *ck_lane = ckpt + (int64_t)b * n_halves * kN * p.dim + d;
+    const int ck_ns = p.dim;                                    // stride between states
     // coalesced tile layout: 64 rows x 16 columns = 4 pieces of (16 rows x 4 lanes-per-row x 4 columns)
     const int lrow = lane >> 2, lc4 = lane & 3, lcol = lc4 * 4;
 
@@ -151,11 +182,11 @@ __global__ __launch_bounds__(kWave, 1) void ssm_scan_bwd_kernel(const dimsum_ssm
             const int row = i * 16 + lrow;
             f32x4 v = {{0.f, 0.f, 0.f, 0.f}};
             if constexpr (kVec) {
-                if (row < nd && t0 + lcol < L) v = widen(ld4<T>(base + (int64_t)row * ds + t0 + lcol));
+                if ((kFull || row < nd) && t0 + lcol < L) v = widen(ld4<T>(at(base + i * 16 * ds, (unsigned)(lrow * ds + t0 + lcol))));
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (row < nd && t0 + lcol + e < L) v.v[e] = to_f32<T>(base[(int64_t)row * ds + t0 + lcol + e]);
+                    if (row < nd && t0 + lcol + e < L) v.v[e] = to_f32<T>(base[(unsigned)(row * ds + t0 + lcol + e)]);
             }
             *reinterpret_cast<f32x4 *>(&dst[btile_off(row, lc4)]) = v;
         }
@@ -165,18 +196,75 @@ __global__ __launch_bounds__(kWave, 1) void ssm_scan_bwd_kernel(const dimsum_ssm
             const int n = idx >> 2, c4 = idx & 3;
             f32x4 vb = {{0.f, 0.f, 0.f, 0.f}}, vc = {{0.f, 0.f, 0.f, 0.f}};
             if constexpr (kVec) {
-                if (t0 + c4 * 4 < L) { vb = widen(ld4<T>(Bp + (int64_t)n * Bns + t0 + c4 * 4)); vc = widen(ld4<T>(Cp + (int64_t)n * Cns + t0 + c4 * 4)); }
+                if (t0 + c4 * 4 < L) { vb = widen(ld4<T>(at(Bp, (unsigned)(n * Bns + t0 + c4 * 4)))); vc = widen(ld4<T>(at(Cp, (unsigned)(n * Cns + t0 + c4 * 4)))); }
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (t0 + c4 * 4 + e < L) { vb.v[e] = to_f32<T>(Bp[(int64_t)n * Bns + t0 + c4 * 4 + e]); vc.v[e] = to_f32<T>(Cp[(int64_t)n * Cns + t0 + c4 * 4 + e]); }
+                    if (t0 + c4 * 4 + e < L) { vb.v[e] = to_f32<T>(Bp[(unsigned)(n * Bns + t0 + c4 * 4 + e)]); vc.v[e] = to_f32<T>(Cp[(unsigned)(n * Cns + t0 + c4 * 4 + e)]); }
             }
             *reinterpret_cast<f32x4 *>(&tB[n * kBT + c4 * 4]) = vb;
             *reinterpret_cast<f32x4 *>(&tC[n * kBT + c4 * 4]) = vc;
         }
     };
-    // in-place: tD <- softplus(delta + bias) (0 beyond L so that dead steps are identities: a = 1, b = 0)
-    auto finish_dt = [&](int t0) {
+
+    // states of the first group to be processed (last half tile, first kBG states); later groups are prefetched one ahead
+    float h_pre[kBG];
+#pragma unroll
+    for (int k = 0; k < kBG; ++k) h_pre[k] = ck_lane[((int64_t)(n_halves - 1) * kN + k) * ck_ns];
+
+#pragma unroll 1
+    for (int tile = n_tiles - 1; tile >= 0; --tile) {
+        const int t0 = tile * kBT;
+        stage(u_base, u_ds, t0, tU);
+        stage(dl_base, dl_ds, t0, tD);
+        stage_bc(t0);
+        // ---- dy = dout * silu(z), dz, optional out_z -- in the coalesced layout; dy goes to LDS ------------------------
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = i * 16 + lrow;
+            f32x4 dy = {{0.f, 0.f, 0.f, 0.f}};
+            if constexpr (kVec) {
+                if ((kFull || row < nd) && t0 + lcol < L) {
+                    const unsigned col = (unsigned)(t0 + lcol);
+                    const f32x4 go = widen(ld4<T>(at(do_base + i * 16 * do_ds, (unsigned)(lrow * do_ds) + col)));
+                    if constexpr (kHasZ) {
+                        const f32x4 zv = widen(ld4<T>(at(z_base + i * 16 * z_ds, (unsigned)(lrow * z_ds) + col)));
+                        const f32x4 yv = widen(ld4<T>(at(y_base + i * 16 * y_ds, (unsigned)(lrow * y_ds) + col)));
+                        f32x4 dz, oz;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float sgz = sigmoidf_fast(zv.v[e]), silu = zv.v[e] * sgz;
+                            dz.v[e] = go.v[e] * yv.v[e] * sgz * (1.0f + zv.v[e] * (1.0f - sgz));
+                            oz.v[e] = yv.v[e] * silu;
+                            dy.v[e] = go.v[e] * silu;
+                        }
+                        st4<T>(at(dz_base + i * 16 * dz_ds, (unsigned)(lrow * dz_ds) + col), dz);
+                        if (oz_base) st4<T>(at(oz_base + i * 16 * oz_ds, (unsigned)(lrow * oz_ds) + col), oz);
+                    } else {
+                        dy = go;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int t = t0 + lcol + e;
+                    if (row < nd && t < L) {
+                        const float go = to_f32<T>(do_base[(unsigned)(row * do_ds + t)]);
+                        if constexpr (kHasZ) {
+                            const float zv = to_f32<T>(z_base[(unsigned)(row * z_ds + t)]), yv = to_f32<T>(y_base[(unsigned)(row * y_ds + t)]);
+                            const float sgz = sigmoidf_fast(zv), silu = zv * sgz;
+                            dz_base[(unsigned)(row * dz_ds + t)] = from_f32<T>(go * yv * sgz * (1.0f + zv * (1.0f - sgz)));
+                            if (oz_base) oz_base[(unsigned)(row * oz_ds + t)] = from_f32<T>(yv * silu);
+                            dy.v[e] = go * silu;
+                        } else {
+                            dy.v[e] = go;
+                        }
+                    }
+                }
+            }
+            *reinterpret_cast<f32x4 *>(&tY[btile_off(row, lc4)]) = dy;
+        }
+        // ---- in place: tD <- softplus(delta + bias) (0 beyond L: dead steps are identities, a = 1, b = 0) ----------------
 #pragma unroll
         for (int j = 0; j < kBT / 4; ++j) {
             f32x4 d4 = *reinterpret_cast<const f32x4 *>(&tD[btile_off(lane, j)]);
@@ -188,213 +276,150 @@ __global__ __launch_bounds__(kWave, 1) void ssm_scan_bwd_kernel(const dimsum_ssm
             }
             *reinterpret_cast<f32x4 *>(&tD[btile_off(lane, j)]) = d4;
         }
-    };
-
-    // =============================== phase A: tile-boundary states ===============================================
-    {
-        float h[kN];
-#pragma unroll
-        for (int n = 0; n < kN; ++n) h[n] = 0.f;
-        for (int tile = 0; tile < n_tiles; ++tile) {
-            const int t0 = tile * kBT;
-#pragma unroll
-            for (int n = 0; n < kN; ++n) wsw[((int64_t)tile * kN + n) * kWave + lane] = h[n];
-            if (tile == n_tiles - 1) break;                    // the last tile's end state is not needed
-            stage(u_base, u_ds, t0, tU);
-            stage(dl_base, dl_ds, t0, tD);
-            stage_bc(t0);
-            finish_dt(t0);
-#pragma unroll 1
-            for (int j = 0; j < kBT / 4; ++j) {
-                const f32x4 u4 = *reinterpret_cast<const f32x4 *>(&tU[btile_off(lane, j)]);
-                const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&tD[btile_off(lane, j)]);
-                float dtl[4], du[4];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) { dtl[s] = d4.v[s] * kLog2e; du[s] = d4.v[s] * u4.v[s]; }
-#pragma unroll
-                for (int n = 0; n < kN; ++n) {
-                    const f32x4 bq = *reinterpret_cast<const f32x4 *>(&tB[n * kBT + j * 4]);
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) h[n] = fmaf(fast_exp2(dtl[s] * A[n]), h[n], bq.v[s] * du[s]);
-                }
-            }
-        }
-    }
-
-    // =============================== phase B: tiles in reverse ===================================================
-    for (int tile = n_tiles - 1; tile >= 0; --tile) {
-        const int t0 = tile * kBT;
-        stage(u_base, u_ds, t0, tU);
-        stage(dl_base, dl_ds, t0, tD);
-        stage_bc(t0);
-        // dy = dout * silu(z), dz, optional out_z -- in the coalesced layout; dy goes to LDS
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = i * 16 + lrow;
-            f32x4 dy = {{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int t = t0 + lcol + e;
-                if (row < nd && t < L) {
-                    const float go = to_f32<T>(do_base[(int64_t)row * do_ds + t]);
-                    if constexpr (kHasZ) {
-                        const float zv = to_f32<T>(z_base[(int64_t)row * z_ds + t]), yv = to_f32<T>(y_base[(int64_t)row * y_ds + t]);
-                        const float sg = sigmoidf_fast(zv), silu = zv * sg;
-                        dz_base[(int64_t)row * dz_ds + t] = from_f32<T>(go * yv * sg * (1.0f + zv * (1.0f - sg)));
-                        if (oz_base) oz_base[(int64_t)row * oz_ds + t] = from_f32<T>(yv * silu);
-                        dy.v[e] = go * silu;
-                    } else {
-                        dy.v[e] = go;
-                    }
-                }
-            }
-            *reinterpret_cast<f32x4 *>(&tY[btile_off(row, lc4)]) = dy;
-        }
-        finish_dt(t0);
-
-        float s1[kBT], s2[kBT];
-#pragma unroll
-        for (int t = 0; t < kBT; ++t) { s1[t] = 0.f; s2[t] = 0.f; }
-        float dtl_first = 0.f;
+        const float dt_first = (*reinterpret_cast<const f32x4 *>(&tD[btile_off(lane, 0)])).v[0];
 
 #pragma unroll 1
-        for (int n0 = 0; n0 < kN; n0 += kBG) {
-            float H[kBT * kBG];       // [t][k]: h_t of state n0+k, later overwritten by the dB terms
-            float hk[kBG], Ak[kBG], dAk[kBG], dhk[kBG];
+        for (int half = kBT / kBS - 1; half >= 0; --half) {
+            const int hidx = tile * (kBT / kBS) + half;          // index of this half tile's saved state
+            const int jb = half * (kBS / 4);                     // first 4-step slot of the half
+            if (hidx >= n_halves) continue;                      // a trailing half entirely beyond L
+            // dt of the step after the half: next slot of the tile, or the seam to the tile processed before
+            const float dt_after = (half == kBT / kBS - 1) ? dt_next : (*reinterpret_cast<const f32x4 *>(&tD[btile_off(lane, jb + kBS / 4)])).v[0];
+            float s1[kBS], s2[kBS];
 #pragma unroll
-            for (int k = 0; k < kBG; ++k) {
-                const int n = min(n0 + k, kN - 1);
-                hk[k] = wsw[((int64_t)tile * kN + n) * kWave + lane];
-                Ak[k] = sA[n * kWave + lane]; dAk[k] = sdA[n * kWave + lane]; dhk[k] = sdh[n * kWave + lane];
-            }
-            // ---- forward sweep -------------------------------------------------------------------------------------
-#pragma unroll
-            for (int j = 0; j < kBT / 4; ++j) {
-                const f32x4 u4 = *reinterpret_cast<const f32x4 *>(&tU[btile_off(lane, j)]);
-                const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&tD[btile_off(lane, j)]);
-#pragma unroll
-                for (int k = 0; k < kBG; ++k) {
-                    const int n = min(n0 + k, kN - 1);
-                    const f32x4 bq = *reinterpret_cast<const f32x4 *>(&tB[n * kBT + j * 4]);
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const float dtl = d4.v[s] * kLog2e, du = d4.v[s] * u4.v[s];
-                        hk[k] = fmaf(fast_exp2(dtl * Ak[k]), hk[k], bq.v[s] * du);
-                        H[(j * 4 + s) * kBG + k] = hk[k];
-                    }
-                }
-            }
-            // ---- dC[n, t] = sum_d dy_t h_t[n]: two transposed reductions of 32 values (k pair x 16 steps) ----------
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                float v[32];
-#pragma unroll
-                for (int j = 0; j < kBT / 4; ++j) {
-                    const f32x4 y4 = *reinterpret_cast<const f32x4 *>(&tY[btile_off(lane, j)]);
-#pragma unroll
-                    for (int s = 0; s < 4; ++s)
-#pragma unroll
-                        for (int kk = 0; kk < 2; ++kk)
-                            v[kk * 16 + j * 4 + s] = live ? y4.v[s] * H[(j * 4 + s) * kBG + half * 2 + kk] : 0.f;
-                }
-                const float r = transposed_reduce<32>(v, lane);
-                const int n = n0 + half * 2 + ((lane >> 4) & 1), t = t0 + (lane & 15);
-                if (lane < 32 && n < kN && t < L) atomicAdd(dCp + (int64_t)n * q.dC_dstate_stride + t, r);
-            }
-            // ---- reverse sweep -------------------------------------------------------------------------------------
-#pragma unroll
-            for (int j = kBT / 4 - 1; j >= 0; --j) {
-                const f32x4 u4 = *reinterpret_cast<const f32x4 *>(&tU[btile_off(lane, j)]);
-                const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&tD[btile_off(lane, j)]);
-                const f32x4 y4 = *reinterpret_cast<const f32x4 *>(&tY[btile_off(lane, j)]);
-                float dnext[4];       // dt * log2e of step t+1
-#pragma unroll
-                for (int s = 0; s < 3; ++s) dnext[s] = d4.v[s + 1] * kLog2e;
-                if (j == kBT / 4 - 1) dnext[3] = dtl_next;
-                else dnext[3] = (*reinterpret_cast<const f32x4 *>(&tD[btile_off(lane, j + 1)])).v[0] * kLog2e;
-                if (j == 0) dtl_first = d4.v[0] * kLog2e;
-#pragma unroll
-                for (int k = 0; k < kBG; ++k) {
-                    const int n = min(n0 + k, kN - 1);
-                    const bool nlive = n0 + k < kN;
-                    const f32x4 bq = *reinterpret_cast<const f32x4 *>(&tB[n * kBT + j * 4]);
-                    const f32x4 cq = *reinterpret_cast<const f32x4 *>(&tC[n * kBT + j * 4]);
-#pragma unroll
-                    for (int s = 3; s >= 0; --s) {
-                        const int t = j * 4 + s;
-                        const float du = d4.v[s] * u4.v[s];
-                        const float a_next = fast_exp2(dnext[s] * Ak[k]);
-                        const float dhn = nlive ? fmaf(a_next, dhk[k], cq.v[s] * y4.v[s]) : 0.f;
-                        dhk[k] = dhn;
-                        const float ah = H[t * kBG + k] - bq.v[s] * du;           // a_t h_{t-1}
-                        const float gterm = dhn * ah;
-                        dAk[k] = fmaf(gterm, d4.v[s], dAk[k]);
-                        s2[t] = fmaf(gterm, Ak[k], s2[t]);
-                        s1[t] = fmaf(dhn, bq.v[s], s1[t]);
-                        H[t * kBG + k] = dhn * du;                                 // dB term
-                    }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < kBG; ++k)
-                if (n0 + k < kN) { sdA[(n0 + k) * kWave + lane] = dAk[k]; sdh[(n0 + k) * kWave + lane] = dhk[k]; }
-            // ---- dB[n, t] = sum_d dh_t[n] dt_t u_t -----------------------------------------------------------------
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                float v[32];
-#pragma unroll
-                for (int t = 0; t < kBT; ++t)
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) v[kk * 16 + t] = live ? H[t * kBG + half * 2 + kk] : 0.f;
-                const float r = transposed_reduce<32>(v, lane);
-                const int n = n0 + half * 2 + ((lane >> 4) & 1), t = t0 + (lane & 15);
-                if (lane < 32 && n < kN && t < L) atomicAdd(dBp + (int64_t)n * q.dB_dstate_stride + t, r);
-            }
-        }
-        dtl_next = dtl_first;
+            for (int t = 0; t < kBS; ++t) { s1[t] = 0.f; s2[t] = 0.f; }
 
-        // ---- per-(d, t) results: du, ddelta (softplus chain), dD, ddelta_bias; through LDS for coalesced stores ----
+#pragma unroll 1
+            for (int n0 = 0; n0 < kN; n0 += kBG) {
+                float H[kBG * kBS];       // [k][t]: h_t of state n0+k, later overwritten by the dB terms
+                float hk[kBG], Ak[kBG], dAk[kBG], dhk[kBG];
 #pragma unroll
-        for (int j = 0; j < kBT / 4; ++j) {
-            const f32x4 u4 = *reinterpret_cast<const f32x4 *>(&tU[btile_off(lane, j)]);
-            const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&tD[btile_off(lane, j)]);
-            const f32x4 y4 = *reinterpret_cast<const f32x4 *>(&tY[btile_off(lane, j)]);
-            f32x4 du4, dd4;
+                for (int k = 0; k < kBG; ++k) {
+                    hk[k] = h_pre[k];
+                    Ak[k] = sA[(n0 + k) * kWave + lane]; dAk[k] = sdA[(n0 + k) * kWave + lane]; dhk[k] = sdh[(n0 + k) * kWave + lane];
+                }
+                {   // prefetch the saved states of the next group (next kBG states of this half, or the previous half's first)
+                    const bool wrap = n0 + kBG >= kN;
+                    const int nh = wrap ? max(hidx - 1, 0) : hidx, nn = wrap ? 0 : n0 + kBG;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int t = j * 4 + s;
-                du4.v[s] = fmaf(d4.v[s], s1[t], Dval * y4.v[s]);
-                dD = fmaf(y4.v[s], u4.v[s], dD);
-                dd4.v[s] = fmaf(u4.v[s], s1[t], s2[t]);
+                    for (int k = 0; k < kBG; ++k) h_pre[k] = ck_lane[((int64_t)nh * kN + nn + k) * ck_ns];
+                }
+                // ---- forward sweep: h_t for the 8 steps of the half -------------------------------------------------------
+#pragma unroll
+                for (int jj = 0; jj < kBS / 4; ++jj) {
+                    const f32x4 u4 = *reinterpret_cast<const f32x4 *>(&tU[btile_off(lane, jb + jj)]);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&tD[btile_off(lane, jb + jj)]);
+                    float du[4];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) du[s] = d4.v[s] * u4.v[s];
+#pragma unroll
+                    for (int k = 0; k < kBG; ++k) {
+                        const f32x4 bq = *reinterpret_cast<const f32x4 *>(&tB[(n0 + k) * kBT + (jb + jj) * 4]);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            hk[k] = fmaf(fast_exp2(d4.v[s] * Ak[k]), hk[k], bq.v[s] * du[s]);
+                            H[k * kBS + jj * 4 + s] = hk[k];
+                        }
+                    }
+                }
+                // ---- dC[n, t] = sum_d dy_t h_t[n]: transposed reduction of the (k, t) products -----------------------------
+                {
+                    float y8[kBS];
+#pragma unroll
+                    for (int jj = 0; jj < kBS / 4; ++jj) {
+                        const f32x4 y4 = *reinterpret_cast<const f32x4 *>(&tY[btile_off(lane, jb + jj)]);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) y8[jj * 4 + s] = live ? y4.v[s] : 0.f;
+                    }
+                    const float r = transposed_reduce<NV>([&](int i) { return y8[i & (kBS - 1)] * H[i]; }, lane);
+                    const int vi = lane & (NV - 1), n = n0 + (vi >> 3), t = t0 + half * kBS + (vi & 7);
+                    if (lane < NV && t < L) atomicAdd(dCp + (unsigned)(n * dCns + t), r);
+                }
+                // ---- reverse sweep -------------------------------------------------------------------------------------------
+#pragma unroll
+                for (int jj = kBS / 4 - 1; jj >= 0; --jj) {
+                    const f32x4 u4 = *reinterpret_cast<const f32x4 *>(&tU[btile_off(lane, jb + jj)]);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&tD[btile_off(lane, jb + jj)]);
+                    const f32x4 y4 = *reinterpret_cast<const f32x4 *>(&tY[btile_off(lane, jb + jj)]);
+                    float dnext[4], du[4];       // dt of step t+1; dt u
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) dnext[s] = d4.v[s + 1];
+                    if (jj == kBS / 4 - 1) dnext[3] = dt_after;
+                    else dnext[3] = (*reinterpret_cast<const f32x4 *>(&tD[btile_off(lane, jb + jj + 1)])).v[0];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) du[s] = d4.v[s] * u4.v[s];
+#pragma unroll
+                    for (int k = 0; k < kBG; ++k) {
+                        const f32x4 bq = *reinterpret_cast<const f32x4 *>(&tB[(n0 + k) * kBT + (jb + jj) * 4]);
+                        const f32x4 cq = *reinterpret_cast<const f32x4 *>(&tC[(n0 + k) * kBT + (jb + jj) * 4]);
+#pragma unroll
+                        for (int s = 3; s >= 0; --s) {
+                            const int t = jj * 4 + s;
+                            const float a_next = fast_exp2(dnext[s] * Ak[k]);
+                            const float dhn = fmaf(a_next, dhk[k], cq.v[s] * y4.v[s]);
+                            dhk[k] = dhn;
+                            const float ah = fmaf(-bq.v[s], du[s], H[k * kBS + t]);     // a_t h_{t-1} = h_t - b_t
+                            const float gterm = dhn * ah;
+                            dAk[k] = fmaf(gterm, d4.v[s], dAk[k]);
+                            s2[t] = fmaf(gterm, Ak[k], s2[t]);
+                            s1[t] = fmaf(dhn, bq.v[s], s1[t]);
+                            H[k * kBS + t] = dhn * du[s];                               // dB term
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < kBG; ++k) { sdA[(n0 + k) * kWave + lane] = dAk[k]; sdh[(n0 + k) * kWave + lane] = dhk[k]; }
+                // ---- dB[n, t] = sum_d dh_t[n] dt_t u_t -----------------------------------------------------------------------
+                {
+                    const float r = transposed_reduce<NV>([&](int i) { return live ? H[i] : 0.f; }, lane);
+                    const int vi = lane & (NV - 1), n = n0 + (vi >> 3), t = t0 + half * kBS + (vi & 7);
+                    if (lane < NV && t < L) atomicAdd(dBp + (unsigned)(n * dBns + t), r);
+                }
             }
-            *reinterpret_cast<f32x4 *>(&tU[btile_off(lane, j)]) = du4;
-            *reinterpret_cast<f32x4 *>(&tY[btile_off(lane, j)]) = dd4;
-        }
-        // softplus derivative needs the raw delta again: re-stage it (bwd_kernel.cuh:439-452 reloads it too)
-        stage(dl_base, dl_ds, t0, tD);
+
+            // ---- per-(d, t) results of the half: du, ddelta (softplus chain), dD, ddelta_bias; parked in LDS over u / dy
+            //      (s2 was accumulated with A * log2 e) ----------------------------------------------------------------------
 #pragma unroll
-        for (int j = 0; j < kBT / 4; ++j) {
-            const f32x4 r4 = *reinterpret_cast<const f32x4 *>(&tD[btile_off(lane, j)]);
-            f32x4 dd4 = *reinterpret_cast<const f32x4 *>(&tY[btile_off(lane, j)]);
+            for (int jj = 0; jj < kBS / 4; ++jj) {
+                const f32x4 u4 = *reinterpret_cast<const f32x4 *>(&tU[btile_off(lane, jb + jj)]);
+                const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&tD[btile_off(lane, jb + jj)]);
+                const f32x4 y4 = *reinterpret_cast<const f32x4 *>(&tY[btile_off(lane, jb + jj)]);
+                f32x4 du4, dd4;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const float raw = r4.v[s] + bias;
-                if (softplus && raw <= 20.0f) dd4.v[s] *= sigmoidf_fast(raw);
-                if (t0 + j * 4 + s < L) dbias += dd4.v[s];
+                for (int s = 0; s < 4; ++s) {
+                    const int t = jj * 4 + s;
+                    du4.v[s] = fmaf(d4.v[s], s1[t], Dval * y4.v[s]);
+                    dD = fmaf(y4.v[s], u4.v[s], dD);
+                    const float ddt = fmaf(u4.v[s], s1[t], s2[t] * kLn2);
+                    // dead steps (t >= L) have dt = 0 -> factor 0 with softplus; without it they carry u = dy = 0 -> ddt = 0
+                    dd4.v[s] = softplus ? ddt * dsoftplus_from_dt(d4.v[s]) : ddt;
+                    dbias += dd4.v[s];
+                }
+                *reinterpret_cast<f32x4 *>(&tU[btile_off(lane, jb + jj)]) = du4;
+                *reinterpret_cast<f32x4 *>(&tY[btile_off(lane, jb + jj)]) = dd4;
             }
-            *reinterpret_cast<f32x4 *>(&tY[btile_off(lane, j)]) = dd4;
         }
+        dt_next = dt_first;
+
+        // ---- coalesced stores of du, ddelta -------------------------------------------------------------------------------
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = i * 16 + lrow;
             const f32x4 a = *reinterpret_cast<const f32x4 *>(&tU[btile_off(row, lc4)]);
             const f32x4 c = *reinterpret_cast<const f32x4 *>(&tY[btile_off(row, lc4)]);
+            if constexpr (kVec) {
+                if ((kFull || row < nd) && t0 + lcol < L) {
+                    st4<T>(at(du_base + i * 16 * du_ds, (unsigned)(lrow * du_ds + t0 + lcol)), a);
+                    st4<T>(at(dd_base + i * 16 * dd_ds, (unsigned)(lrow * dd_ds + t0 + lcol)), c);
+                }
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int t = t0 + lcol + e;
-                if (row < nd && t < L) {
-                    du_base[(int64_t)row * du_ds + t] = from_f32<T>(a.v[e]);
-                    dd_base[(int64_t)row * dd_ds + t] = from_f32<T>(c.v[e]);
+                for (int e = 0; e < 4; ++e) {
+                    const int t = t0 + lcol + e;
+                    if (row < nd && t < L) {
+                        du_base[(unsigned)(row * du_ds + t)] = from_f32<T>(a.v[e]);
+                        dd_base[(unsigned)(row * dd_ds + t)] = from_f32<T>(c.v[e]);
+                    }
                 }
             }
         }
@@ -410,33 +435,58 @@ __global__ __launch_bounds__(kWave, 1) void ssm_scan_bwd_kernel(const dimsum_ssm
 }
 
 template <typename T, int kN>
-static int launch_bwd(const dimsum_ssm_bwd_params_t &q, float *ws, hipStream_t stream) {
+static int launch_bwd(const dimsum_ssm_bwd_params_t &q, const float *ckpt, hipStream_t stream) {
     const dimsum_ssm_params_t &p = q.fwd;
     const int dpg = p.dim / p.n_groups;
     const int tiles = p.batch * p.n_groups * ((dpg + kWave - 1) / kWave);
     const size_t va = 4 * sizeof(T);
-    const bool vec = (p.seqlen % 4 == 0) && aligned_to<T>(p.u_ptr, va) && aligned_to<T>(p.delta_ptr, va) && aligned_to<T>(p.B_ptr, va) &&
-                     aligned_to<T>(p.C_ptr, va) && p.u_batch_stride % 4 == 0 && p.u_d_stride % 4 == 0 && p.delta_batch_stride % 4 == 0 &&
-                     p.delta_d_stride % 4 == 0 && p.B_batch_stride % 4 == 0 && p.B_group_stride % 4 == 0 && p.B_dstate_stride % 4 == 0 &&
-                     p.C_batch_stride % 4 == 0 && p.C_group_stride % 4 == 0 && p.C_dstate_stride % 4 == 0;
-    dim3 grid(tiles), block(kWave);
+    auto ok4 = [&](const void *ptr, int64_t bs, int64_t ds) { return aligned_to<T>(ptr, va) && bs % 4 == 0 && ds % 4 == 0; };
+    bool vec = (p.seqlen % 4 == 0) && ok4(p.u_ptr, p.u_batch_stride, p.u_d_stride) && ok4(p.delta_ptr, p.delta_batch_stride, p.delta_d_stride) &&
+               ok4(q.dout_ptr, q.dout_batch_stride, q.dout_d_stride) && ok4(q.du_ptr, q.du_batch_stride, q.du_d_stride) &&
+               ok4(q.ddelta_ptr, q.ddelta_batch_stride, q.ddelta_d_stride) &&
+               ok4(p.B_ptr, p.B_batch_stride, p.B_dstate_stride) && ok4(p.C_ptr, p.C_batch_stride, p.C_dstate_stride) &&
+               p.B_group_stride % 4 == 0 && p.C_group_stride % 4 == 0;
     if (p.z_ptr) {
-        if (vec) hipLaunchKernelGGL((ssm_scan_bwd_kernel<T, kN, true, true>), grid, block, 0, stream, q, ws);
-        else hipLaunchKernelGGL((ssm_scan_bwd_kernel<T, kN, true, false>), grid, block, 0, stream, q, ws);
-    } else {
-        if (vec) hipLaunchKernelGGL((ssm_scan_bwd_kernel<T, kN, false, true>), grid, block, 0, stream, q, ws);
-        else hipLaunchKernelGGL((ssm_scan_bwd_kernel<T, kN, false, false>), grid, block, 0, stream, q, ws);
+        vec = vec && ok4(p.z_ptr, p.z_batch_stride, p.z_d_stride) && ok4(p.out_ptr, p.out_batch_stride, p.out_d_stride) &&
+              ok4(q.dz_ptr, q.dz_batch_stride, q.dz_d_stride);
+        if (p.out_z_ptr) vec = vec && ok4(p.out_z_ptr, p.out_z_batch_stride, p.out_z_d_stride);
     }
+    // 32-bit in-tile offsets
+    const int64_t lim = (int64_t)1 << 31, Ls = p.seqlen;
+    const int64_t dss[] = {p.u_d_stride, p.delta_d_stride, q.dout_d_stride, q.du_d_stride, q.ddelta_d_stride,
+                           p.z_ptr ? p.z_d_stride : 0, p.z_ptr ? p.out_d_stride : 0, p.z_ptr ? q.dz_d_stride : 0,
+                           (p.z_ptr && p.out_z_ptr) ? p.out_z_d_stride : 0};
+    for (int64_t ds : dss)
+        if (ds < 0 || 64 * ds + Ls >= lim) return DIMSUM_ERR_STRIDE;
+    const int64_t nss[] = {p.B_dstate_stride, p.C_dstate_stride, q.dB_dstate_stride, q.dC_dstate_stride};
+    for (int64_t ns : nss)
+        if (ns < 0 || (int64_t)p.dstate * ns + Ls >= lim) return DIMSUM_ERR_STRIDE;
+    const bool full = vec && (dpg % kWave == 0);
+    dim3 grid(tiles), block(kWave);
+#define DIMSUM_LAUNCH(HASZ, VEC, FULL) \
+    hipLaunchKernelGGL((ssm_scan_bwd_kernel<T, kN, HASZ, VEC, FULL>), grid, block, 0, stream, q, ckpt)
+    if (p.z_ptr) {
+        if (full) DIMSUM_LAUNCH(true, true, true);
+        else if (vec) DIMSUM_LAUNCH(true, true, false);
+        else DIMSUM_LAUNCH(true, false, false);
+    } else {
+        if (full) DIMSUM_LAUNCH(false, true, true);
+        else if (vec) DIMSUM_LAUNCH(false, true, false);
+        else DIMSUM_LAUNCH(false, false, false);
+    }
+#undef DIMSUM_LAUNCH
     return launch_status();
 }
 
 template <typename T>
-static int dispatch_bwd(const dimsum_ssm_bwd_params_t &q, float *ws, hipStream_t stream) {
+static int dispatch_bwd(const dimsum_ssm_bwd_params_t &q, const float *ckpt, hipStream_t stream) {
     switch (q.fwd.dstate) {
-        case 4: return launch_bwd<T, 4>(q, ws, stream);
-        case 8: return launch_bwd<T, 8>(q, ws, stream);
-        case 16: return launch_bwd<T, 16>(q, ws, stream);
-        case 32: return launch_bwd<T, 32>(q, ws, stream);
+#ifndef DIMSUM_DEV_ONE      // development builds instantiate the headline variant only
+        case 4: return launch_bwd<T, 4>(q, ckpt, stream);
+        case 8: return launch_bwd<T, 8>(q, ckpt, stream);
+        case 32: return launch_bwd<T, 32>(q, ckpt, stream);
+#endif
+        case 16: return launch_bwd<T, 16>(q, ckpt, stream);
         default: return DIMSUM_ERR_SHAPE;
     }
 }
@@ -447,10 +497,8 @@ int ssm_check(const dimsum_ssm_params_t *p, bool forward);
 
 extern "C" int64_t dimsum_ssm_scan_bwd_workspace_bytes(int32_t batch, int32_t dim, int32_t seqlen, int32_t dstate, int32_t n_groups) {
     if (batch <= 0 || dim <= 0 || seqlen <= 0 || dstate <= 0 || n_groups <= 0 || dim % n_groups != 0) return 0;
-    const int64_t dpg = dim / n_groups;
-    const int64_t waves = (int64_t)batch * n_groups * ((dpg + dimsum::kWave - 1) / dimsum::kWave);
-    const int64_t n_tiles = (seqlen + dimsum::kBT - 1) / dimsum::kBT;
-    return waves * n_tiles * dstate * dimsum::kWave * (int64_t)sizeof(float);
+    const int64_t n_halves = (seqlen + dimsum::kBS - 1) / dimsum::kBS;
+    return (int64_t)batch * n_halves * dstate * dim * (int64_t)sizeof(float);      // (batch, half tiles, dstate, dim)
 }
 
 extern "C" int dimsum_ssm_scan_bwd(const dimsum_ssm_bwd_params_t *q, void *stream) {
@@ -458,16 +506,28 @@ extern "C" int dimsum_ssm_scan_bwd(const dimsum_ssm_bwd_params_t *q, void *strea
     if (!q) return DIMSUM_ERR_NULL;
     const int rc = ssm_check(&q->fwd, false);
     if (rc != DIMSUM_OK) return rc;
-    if (!q->dout_ptr || !q->dA_ptr || !q->dB_ptr || !q->dC_ptr || !q->du_ptr || !q->ddelta_ptr || !q->workspace_ptr) return DIMSUM_ERR_NULL;
+    if (!q->dout_ptr || !q->dA_ptr || !q->dB_ptr || !q->dC_ptr || !q->du_ptr || !q->ddelta_ptr) return DIMSUM_ERR_NULL;
     if (q->fwd.z_ptr && (!q->dz_ptr || !q->fwd.out_ptr)) return DIMSUM_ERR_NULL;
     const dimsum_ssm_params_t &p = q->fwd;
-    if (q->workspace_bytes < dimsum_ssm_scan_bwd_workspace_bytes(p.batch, p.dim, p.seqlen, p.dstate, p.n_groups)) return DIMSUM_ERR_SHAPE;
+    const float *ckpt = reinterpret_cast<const float *>(p.ckpt_ptr);
+    if (!ckpt) {
+        // reference-shaped call (no saved tile states): one state-only forward sweep rebuilds them in the workspace
+        if (!q->workspace_ptr) return DIMSUM_ERR_NULL;
+        if (q->workspace_bytes < dimsum_ssm_scan_bwd_workspace_bytes(p.batch, p.dim, p.seqlen, p.dstate, p.n_groups)) return DIMSUM_ERR_SHAPE;
+        dimsum_ssm_params_t f = p;
+        f.z_ptr = nullptr; f.out_ptr = nullptr; f.out_z_ptr = nullptr; f.x_ptr = nullptr; f.D_ptr = nullptr;
+        f.ckpt_ptr = q->workspace_ptr;
+        const int frc = dimsum_ssm_scan_fwd(&f, stream);
+        if (frc != DIMSUM_OK) return frc;
+        ckpt = reinterpret_cast<const float *>(q->workspace_ptr);
+    }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    float *ws = reinterpret_cast<float *>(q->workspace_ptr);
     switch (p.dtype) {
-        case DIMSUM_F32: return dispatch_bwd<float>(*q, ws, s);
-        case DIMSUM_F16: return dispatch_bwd<__half>(*q, ws, s);
-        case DIMSUM_BF16: return dispatch_bwd<__hip_bfloat16>(*q, ws, s);
+        case DIMSUM_F32: return dispatch_bwd<float>(*q, ckpt, s);
+#ifndef DIMSUM_DEV_ONE
+        case DIMSUM_F16: return dispatch_bwd<__half>(*q, ckpt, s);
+        case DIMSUM_BF16: return dispatch_bwd<__hip_bfloat16>(*q, ckpt, s);
+#endif
         default: return DIMSUM_ERR_DTYPE;
     }
 }

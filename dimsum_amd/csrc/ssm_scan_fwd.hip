@@ -1,354 +1,9 @@
-// ssm_scan_fwd.hip -- selective scan (Mamba S6) forward for gfx950.
-//
-// Replaces selective_scan_cuda.fwd (mamba/csrc/selective_scan/selective_scan.cpp:226-336; kernel
-// selective_scan_fwd_kernel.cuh:67-303). Math per (batch b, channel d) row:
-//     dt_t = softplus(delta_t + delta_bias_d)            a_t[n] = exp(dt_t * A[d,n])
-//     h_t[n] = a_t[n] h_{t-1}[n] + dt_t B_t[n] u_t       out_t = sum_n C_t[n] h_t[n] + D_d u_t
-//     out_z_t = out_t * silu(z_t)                        x[chunk] = (prod a, h) at each 2048 boundary
-//
-// MI355X design (not the reference's one-row-per-block parallel scan):
-//   * lane = channel. One wave64 owns 64 channels of ONE batch element and walks the sequence sequentially with the
-//     dstate states of its channel in registers: 5 VALU ops per (t, n) -- the minimum -- instead of the ~3x of a
-//     cross-lane parallel scan, and no cross-lane traffic at all.
-//   * B_t[n], C_t[n] depend on (batch, group, n, t) only, i.e. they are WAVE-UNIFORM here: they are fetched with scalar
-//     loads (s_load_dwordx4 = 4 time steps of one state) into SGPRs and used as the scalar operand of the FMAs.
-//     The reference re-reads the 32 KB (N,L) B/C tile per channel through L2; here it costs no vector memory
-//     traffic and no VGPRs.
-//   * u, delta are streamed HBM -> registers (coalesced 16 B/lane along L: a 64x32 fp32 tile is 64 full 128-B
-//     lines) -> LDS transposing tile (row stride 36 dwords: conflict-free ds_write_b128 in load layout and
-//     ds_read_b128 in lane=channel layout). The next tile's global loads are issued before the current tile is
-//     computed, so they fly under ~4k cycles of VALU work (register-staged double buffering; LDS single-buffered:
-//     18 KB per wave -> 8 waves per CU).
-//   * out is written back into the u tile in place, re-read in the coalesced layout, gated with silu(z) there
-//     (z never goes through LDS) and stored with 16 B/lane.
-//   * blockIdx -> tile map keeps the 16 waves of one batch element on one XCD so B/C are fetched into one L2 only.
-//
-// Algorithmic HBM bytes: 5*B*D*L*s + 2*B*G*N*L*s + B*D*ceil(L/2048)*2N*4 (+ A, D, bias).
+// ssm_scan_fwd.hip -- C entry point of the selective-scan forward (kernel: ssm_scan_fwd_kernel.hpp).
 #include "common.hpp"
 
 namespace dimsum {
 
-// Wave-uniform 4-element load. Going through the constant address space tells the compiler the data is invariant for
-// the kernel's lifetime, so a uniform address selects SMEM (s_load_dwordx4 / x2) instead of a broadcast vector load:
-// the values land in SGPRs and feed the FMAs as their scalar operand.
-template <typename T> struct UniformLd;
-template <> struct UniformLd<float> {
-    typedef float v4 __attribute__((ext_vector_type(4)));
-    static __device__ __forceinline__ f32x4 ld(const float *p) {
-        const v4 r = *(const __attribute__((address_space(4))) v4 *)(p);
-        return {{r.x, r.y, r.z, r.w}};
-    }
-    static __device__ __forceinline__ float ld1(const float *p) { return *(const __attribute__((address_space(4))) float *)(p); }
-};
-template <> struct UniformLd<__half> {
-    typedef unsigned v2 __attribute__((ext_vector_type(2)));
-    static __device__ __forceinline__ f32x4 ld(const __half *p) {
-        const v2 r = *(const __attribute__((address_space(4))) v2 *)(p);
-        Raw4<__half> w; w.r.x = r.x; w.r.y = r.y;
-        return widen(w);
-    }
-    static __device__ __forceinline__ float ld1(const __half *p) {
-        const unsigned short r = *(const __attribute__((address_space(4))) unsigned short *)(p);
-        return __half2float(__ushort_as_half(r));
-    }
-};
-template <> struct UniformLd<__hip_bfloat16> {
-    typedef unsigned v2 __attribute__((ext_vector_type(2)));
-    static __device__ __forceinline__ f32x4 ld(const __hip_bfloat16 *p) {
-        const v2 r = *(const __attribute__((address_space(4))) v2 *)(p);
-        Raw4<__hip_bfloat16> w; w.r.x = r.x; w.r.y = r.y;
-        return widen(w);
-    }
-    static __device__ __forceinline__ float ld1(const __hip_bfloat16 *p) {
-        const unsigned short r = *(const __attribute__((address_space(4))) unsigned short *)(p);
-        return __uint_as_float((unsigned)r << 16);
-    }
-};
-
-constexpr int kTC = 32;       // time steps per LDS tile (128-B segments per row in fp32)
-constexpr int kLdsStride = 32;  // dwords per tile row (unpadded; 16-byte slots are XOR-swizzled instead)
-
-// LDS image of a 64-row x 32-column fp32 tile: row r keeps its eight 16-byte slots permuted by (r >> 1) & 7.
-// ds_write_b128 in load layout (8 lanes = one row) and ds_read_b128 in lane = row layout (16-lane groups
-// {0-3,12-15,20-27}, ...) are both bank-conflict free, with no padding: 8 KB per tile, so that
-// 2 tiles + the B/C tiles = 20 KB per wave = exactly 8 waves per CU (160 KB).
-__device__ __forceinline__ int tile_off(int row, int col4) { return row * kLdsStride + ((col4 ^ ((row >> 1) & 7)) << 2); }
-
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-// base (wave-uniform, SGPR pair) + 32-bit BYTE offset held in one VGPR: selects the saddr + voffset addressing form.
-template <typename T> __device__ __forceinline__ const T *at(const T *base, unsigned elem_off) {
-    return reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (unsigned)(elem_off * (unsigned)sizeof(T)));
-}
-template <typename T> __device__ __forceinline__ T *at(T *base, unsigned elem_off) {
-    return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + (unsigned)(elem_off * (unsigned)sizeof(T)));
-}
-
-// kVec : every row base is 4-element aligned and L % 4 == 0 -> 16-byte (fp32) vector I/O, register-staged prefetch.
-// kFull: dim/n_groups % 64 == 0 -> all 64 lanes own a live channel, no row masks anywhere (needs kVec).
-template <typename T, int kN, bool kHasZ, bool kVec, bool kFull>
-__global__ __launch_bounds__(kWave, 2) void ssm_scan_fwd_kernel(const dimsum_ssm_params_t p) {
-    static_assert(!kFull || kVec, "kFull implies kVec");
-    __shared__ __attribute__((aligned(16))) float tileU[kWave * kLdsStride];
-    __shared__ __attribute__((aligned(16))) float tileD[kWave * kLdsStride];
-    __shared__ __attribute__((aligned(16))) float tileB[kN * kTC];   // [n][t] of the current 32 steps (wave-uniform data,
-    __shared__ __attribute__((aligned(16))) float tileC[kN * kTC];   //  read back as broadcast ds_read_b128)
-
-    const int lane = threadIdx.x;
-    const int L = p.seqlen;
-    const int dpg = p.dim / p.n_groups;                    // channels per B/C group
-    const int tiles_per_group = (dpg + kWave - 1) / kWave;
-    const int tiles_per_batch = p.n_groups * tiles_per_group;
-    // XCD-aware remap: consecutive tile ids (same batch element) land on the same XCD (blockIdx % 8).
-    int wg = blockIdx.x;
-    const int nwg = gridDim.x;
-    if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
-    const int b = wg / tiles_per_batch;
-    const int rem = wg - b * tiles_per_batch;
-    const int g = rem / tiles_per_group;
-    const int d0 = g * dpg + (rem - g * tiles_per_group) * kWave;
-    const int nd = kFull ? kWave : min(kWave, (g + 1) * dpg - d0);   // live channels in this tile
-    const int d = d0 + (kFull ? lane : min(lane, nd - 1));           // dead lanes shadow the last live channel
-
-    // Wave-uniform tile bases. In-tile offsets are 32-bit (the host checks 64 * d_stride + L < 2^31).
-    const T *u_base = reinterpret_cast<const T *>(p.u_ptr) + (int64_t)b * p.u_batch_stride + (int64_t)d0 * p.u_d_stride;
-    const T *dl_base = reinterpret_cast<const T *>(p.delta_ptr) + (int64_t)b * p.delta_batch_stride + (int64_t)d0 * p.delta_d_stride;
-    const T *z_base = kHasZ ? reinterpret_cast<const T *>(p.z_ptr) + (int64_t)b * p.z_batch_stride + (int64_t)d0 * p.z_d_stride : nullptr;
-    T *out_base = p.out_ptr ? reinterpret_cast<T *>(p.out_ptr) + (int64_t)b * p.out_batch_stride + (int64_t)d0 * p.out_d_stride : nullptr;
-    T *oz_base = kHasZ ? reinterpret_cast<T *>(p.out_z_ptr) + (int64_t)b * p.out_z_batch_stride + (int64_t)d0 * p.out_z_d_stride : nullptr;
-    const int u_ds = (int)p.u_d_stride, dl_ds = (int)p.delta_d_stride, z_ds = (int)p.z_d_stride;
-    const int out_ds = (int)p.out_d_stride, oz_ds = (int)p.out_z_d_stride;
-    // wave-uniform B/C rows of this (batch, group)
-    const T *Bp = reinterpret_cast<const T *>(p.B_ptr) + (int64_t)b * p.B_batch_stride + (int64_t)g * p.B_group_stride;
-    const T *Cp = reinterpret_cast<const T *>(p.C_ptr) + (int64_t)b * p.C_batch_stride + (int64_t)g * p.C_group_stride;
-    const int Bns = (int)p.B_dstate_stride, Cns = (int)p.C_dstate_stride;
-
-    // per-channel constants. A is pre-multiplied by log2(e) so that exp() is a bare v_exp_f32
-    // (same trick as selective_scan_fwd_kernel.cuh:169-171).
-    float A2[kN], h[kN];
-    const float *Ap = reinterpret_cast<const float *>(p.A_ptr) + (int64_t)d * p.A_d_stride;
-#pragma unroll
-    for (int n = 0; n < kN; ++n) { A2[n] = Ap[n * p.A_dstate_stride] * kLog2e; h[n] = 0.f; }
-    const float Dval = p.D_ptr ? reinterpret_cast<const float *>(p.D_ptr)[d] : 0.f;
-    const float bias = p.delta_bias_ptr ? reinterpret_cast<const float *>(p.delta_bias_ptr)[d] : 0.f;
-    const bool softplus = p.delta_softplus != 0;
-    const bool has_out = out_base != nullptr;
-    float sum_dt = 0.f;   // prod_t a_t[n] = exp2(A2[n] * sum_t dt_t)
-
-    const int n_tiles = (L + kTC - 1) / kTC;
-    // load layout: piece i of the tile, lane -> (row = i*8 + lane/8, 4 columns at (lane%8)*4)
-    const int lrow = lane >> 3, lcol = (lane & 7) * 4;
-
-    constexpr int kBCPieces = (kN * 8 + kWave - 1) / kWave;   // 16-byte pieces per lane of a [kN][32] tile
-    Raw4<T> ru[8], rd[8], rz[8], rb[kBCPieces], rc[kBCPieces];
-    // Branch-free tile loads: rows beyond nd are clamped to the last live row, columns beyond L to the last
-    // 4-column group (L % 4 == 0 on this path); the duplicates are never stored.
-    // Address = wave-uniform (base + i * 8 * stride) + one per-lane 32-bit offset per tensor, so the 8 pieces of a tile
-    // share a single VGPR offset (saddr + voffset addressing) instead of 8 precomputed per-lane addresses.
-    auto col_of = [&](int t0) { return min(t0 + lcol, L - 4); };
-    auto piece = [&](const T *base, int ds, int i, int col) -> const T * {   // address of piece i of a tile
-        if constexpr (kFull) return at(base + i * 8 * ds, (unsigned)(lrow * ds + col));
-        else return at(base, (unsigned)(min(i * 8 + lrow, nd - 1) * ds + col));   // clamped row: never negative
-    };
-    auto issue_loads = [&](int t0) {
-        const int col = col_of(t0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            ru[i] = ld4<T>(piece(u_base, u_ds, i, col));
-            rd[i] = ld4<T>(piece(dl_base, dl_ds, i, col));
-        }
-#pragma unroll
-        for (int i = 0; i < kBCPieces; ++i) {
-            const int n = min(i * 8 + lrow, kN - 1);
-            rb[i] = ld4<T>(at(Bp, (unsigned)(n * Bns + col)));
-            rc[i] = ld4<T>(at(Cp, (unsigned)(n * Cns + col)));
-        }
-    };
-
-    if constexpr (kVec) issue_loads(0);
-
-#pragma unroll 1
-    for (int tile = 0; tile < n_tiles; ++tile) {
-        const int t0 = tile * kTC;
-        // ---- stage the tile into LDS (transposing layout) ------------------------------------------------------
-        if constexpr (kVec) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = i * 8 + lrow;
-                *reinterpret_cast<f32x4 *>(&tileU[tile_off(row, lane & 7)]) = widen(ru[i]);
-                *reinterpret_cast<f32x4 *>(&tileD[tile_off(row, lane & 7)]) = widen(rd[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < kBCPieces; ++i) {
-                const int n = i * 8 + lrow;
-                if (kN * 8 % kWave == 0 || n < kN) {
-                    *reinterpret_cast<f32x4 *>(&tileB[n * kTC + lcol]) = widen(rb[i]);
-                    *reinterpret_cast<f32x4 *>(&tileC[n * kTC + lcol]) = widen(rc[i]);
-                }
-            }
-            if (tile + 1 < n_tiles) issue_loads(t0 + kTC);   // flies under the compute below
-            if constexpr (kHasZ) {
-                const int col = col_of(t0);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) rz[i] = ld4<T>(piece(z_base, z_ds, i, col));
-            }
-        } else {
-            // generic path (unaligned rows or L % 4 != 0): element-wise, still coalesced along L
-            for (int i = 0; i < kTC; ++i) {
-                const int idx = i * kWave + lane, row = idx >> 5, col = idx & 31;
-                const bool ok = row < nd && t0 + col < L;
-                tileU[tile_off(row, col >> 2) + (col & 3)] = ok ? to_f32<T>(u_base[(unsigned)(row * u_ds + t0 + col)]) : 0.f;
-                tileD[tile_off(row, col >> 2) + (col & 3)] = ok ? to_f32<T>(dl_base[(unsigned)(row * dl_ds + t0 + col)]) : 0.f;
-            }
-            for (int idx = lane; idx < kN * kTC; idx += kWave) {
-                const int n = idx >> 5, tc = min(t0 + (idx & 31), L - 1);
-                tileB[idx] = to_f32<T>(Bp[(unsigned)(n * Bns + tc)]);
-                tileC[idx] = to_f32<T>(Cp[(unsigned)(n * Cns + tc)]);
-            }
-        }
-
-        // ---- 32 sequential steps, 4 at a time ------------------------------------------------------------------
-        // 5 VALU ops per (t, n): mul, v_exp_f32, mul, fma, fma. Measured issue costs on gfx950 (tools/ubench/valu_rates):
-        // plain fp32 op 2 cycles per wave64, v_exp_f32 / v_rcp_f32 8, v_pk_*_f32 4 (= two plain ops, so packing buys
-        // nothing and its operand shuffles cost extra: the file is built with -fno-slp-vectorize).
-#pragma unroll 1
-        for (int j = 0; j < kTC / 4; ++j) {
-            const int tj = t0 + j * 4;
-            if (tj >= L) break;
-            const f32x4 u4 = *reinterpret_cast<const f32x4 *>(&tileU[tile_off(lane, j)]);
-            const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&tileD[tile_off(lane, j)]);
-            // software-pipelined broadcast reads: B/C of state n+1 are in flight while state n is computed
-            f32x4 bq_nxt = *reinterpret_cast<const f32x4 *>(&tileB[j * 4]);
-            f32x4 cq_nxt = *reinterpret_cast<const f32x4 *>(&tileC[j * 4]);
-            float dt[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                float v = d4.v[s] + bias;
-                if (softplus) v = softplus_ref(v);
-                const bool live = kVec || (tj + s < L);       // dead steps: a = 1, b = 0 -> state untouched
-                dt[s] = live ? v : 0.f;
-                sum_dt += dt[s];
-            }
-            float du[4], y[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) { du[s] = dt[s] * u4.v[s]; y[s] = Dval * u4.v[s]; }
-            __builtin_amdgcn_sched_barrier(0);   // region below = exactly 2*(kN-1) ds_read + 20*kN VALU
-#pragma unroll
-            for (int n = 0; n < kN; ++n) {
-                const f32x4 bq = bq_nxt, cq = cq_nxt;
-                if (n + 1 < kN) {
-                    bq_nxt = *reinterpret_cast<const f32x4 *>(&tileB[(n + 1) * kTC + j * 4]);
-                    cq_nxt = *reinterpret_cast<const f32x4 *>(&tileC[(n + 1) * kTC + j * 4]);
-                }
-                float hn = h[n];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    hn = fmaf(fast_exp2(dt[s] * A2[n]), hn, bq.v[s] * du[s]);
-                    y[s] = fmaf(hn, cq.v[s], y[s]);
-                }
-                h[n] = hn;
-                // keep the issue order: [2 ds_read for n+1] then [20 VALU of n]
-                if (n + 1 < kN) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x2, 20, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const f32x4 y4 = {{y[0], y[1], y[2], y[3]}};
-            *reinterpret_cast<f32x4 *>(&tileU[tile_off(lane, j)]) = y4;
-        }
-
-        // ---- chunk-state store at every 2048 boundary and at the end (selective_scan_fwd_kernel.cuh:251-254) ---
-        const int t_end = min(t0 + kTC, L);
-        if (p.x_ptr && ((t_end & 2047) == 0 || t_end == L) && (kFull || lane < nd)) {
-            float *xr = reinterpret_cast<float *>(p.x_ptr) + (((int64_t)b * p.dim + d) * p.n_chunks + (t_end - 1) / 2048) * (2 * kN);
-#pragma unroll
-            for (int n = 0; n < kN; n += 2) {
-                const f32x4 v = {{fast_exp2(A2[n] * sum_dt), h[n], fast_exp2(A2[n + 1] * sum_dt), h[n + 1]}};
-                *reinterpret_cast<f32x4 *>(xr + 2 * n) = v;
-            }
-        }
-
-        // ---- epilogue: re-read y in the coalesced layout, gate, store -------------------------------------------
-        if constexpr (kVec) {
-            if (t0 + lcol < L) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int row = i * 8 + lrow;
-                    if (kFull || row < nd) {
-                        f32x4 y4 = *reinterpret_cast<const f32x4 *>(&tileU[tile_off(row, lane & 7)]);
-                        if (has_out) st4<T>(at(out_base + i * 8 * out_ds, (unsigned)(lrow * out_ds + t0 + lcol)), y4);
-                        if constexpr (kHasZ) {
-                            const f32x4 z4 = widen(rz[i]);
-#pragma unroll
-                            for (int s = 0; s < 4; ++s) y4.v[s] *= z4.v[s] * sigmoidf_fast(z4.v[s]);
-                            st4<T>(at(oz_base + i * 8 * oz_ds, (unsigned)(lrow * oz_ds + t0 + lcol)), y4);
-                        }
-                    }
-                }
-            }
-        } else {
-            for (int i = 0; i < kTC; ++i) {
-                const int idx = i * kWave + lane, row = idx >> 5, col = idx & 31;
-                if (row < nd && t0 + col < L) {
-                    const float yv = tileU[tile_off(row, col >> 2) + (col & 3)];
-                    if (out_base) out_base[(unsigned)(row * out_ds + t0 + col)] = from_f32<T>(yv);
-                    if constexpr (kHasZ) {
-                        const float zv = to_f32<T>(z_base[(unsigned)(row * z_ds + t0 + col)]);
-                        oz_base[(unsigned)(row * oz_ds + t0 + col)] = from_f32<T>(yv * zv * sigmoidf_fast(zv));
-                    }
-                }
-            }
-        }
-    }
-}
-
-template <typename T, int kN>
-static int launch_fwd(const dimsum_ssm_params_t &p, hipStream_t stream) {
-    const int dpg = p.dim / p.n_groups;
-    const int tiles = p.batch * p.n_groups * ((dpg + kWave - 1) / kWave);
-    const size_t va = 4 * sizeof(T);  // vector path: every row base 4-element aligned
-    bool vec = (p.seqlen % 4 == 0) && aligned_to<T>(p.u_ptr, va) && aligned_to<T>(p.delta_ptr, va) &&
-               aligned_to<T>(p.B_ptr, va) && aligned_to<T>(p.C_ptr, va) && (p.u_batch_stride % 4 == 0) &&
-               (p.u_d_stride % 4 == 0) && (p.delta_batch_stride % 4 == 0) && (p.delta_d_stride % 4 == 0) &&
-               (p.B_batch_stride % 4 == 0) && (p.B_group_stride % 4 == 0) && (p.B_dstate_stride % 4 == 0) &&
-               (p.C_batch_stride % 4 == 0) && (p.C_group_stride % 4 == 0) && (p.C_dstate_stride % 4 == 0);
-    if (p.out_ptr) vec = vec && aligned_to<T>(p.out_ptr, va) && (p.out_batch_stride % 4 == 0) && (p.out_d_stride % 4 == 0);
-    if (p.z_ptr)
-        vec = vec && aligned_to<T>(p.z_ptr, va) && aligned_to<T>(p.out_z_ptr, va) && (p.z_batch_stride % 4 == 0) &&
-              (p.z_d_stride % 4 == 0) && (p.out_z_batch_stride % 4 == 0) && (p.out_z_d_stride % 4 == 0);
-    if (p.x_ptr && !aligned_to<float>(p.x_ptr, 16)) return DIMSUM_ERR_STRIDE;
-    // 32-bit in-tile offsets
-    const int64_t lim = (int64_t)1 << 31;
-    if (64 * p.u_d_stride + p.seqlen >= lim || 64 * p.delta_d_stride + p.seqlen >= lim || 64 * p.out_d_stride + p.seqlen >= lim ||
-        64 * p.z_d_stride + p.seqlen >= lim || 64 * p.out_z_d_stride + p.seqlen >= lim ||
-        (int64_t)p.dstate * p.B_dstate_stride + p.seqlen >= lim || (int64_t)p.dstate * p.C_dstate_stride + p.seqlen >= lim)
-        return DIMSUM_ERR_STRIDE;
-    const bool full = vec && (dpg % kWave == 0);
-    dim3 grid(tiles), block(kWave);
-#define DIMSUM_LAUNCH(HASZ, VEC, FULL) \
-    hipLaunchKernelGGL((ssm_scan_fwd_kernel<T, kN, HASZ, VEC, FULL>), grid, block, 0, stream, p)
-    if (p.z_ptr) {
-        if (full) DIMSUM_LAUNCH(true, true, true);
-        else if (vec) DIMSUM_LAUNCH(true, true, false);
-        else DIMSUM_LAUNCH(true, false, false);
-    } else {
-        if (full) DIMSUM_LAUNCH(false, true, true);
-        else if (vec) DIMSUM_LAUNCH(false, true, false);
-        else DIMSUM_LAUNCH(false, false, false);
-    }
-#undef DIMSUM_LAUNCH
-    return launch_status();
-}
-
-template <typename T>
-static int dispatch_n(const dimsum_ssm_params_t &p, hipStream_t stream) {
-    switch (p.dstate) {
-        case 4: return launch_fwd<T, 4>(p, stream);
-        case 8: return launch_fwd<T, 8>(p, stream);
-        case 16: return launch_fwd<T, 16>(p, stream);
-        case 32: return launch_fwd<T, 32>(p, stream);
-        default: return DIMSUM_ERR_SHAPE;
-    }
-}
+template <typename T> int ssm_scan_fwd_dispatch(const dimsum_ssm_params_t &p, hipStream_t stream);   // ssm_scan_fwd_{f32,f16,bf16}.hip
 
 int ssm_check(const dimsum_ssm_params_t *p, bool forward) {
     if (!p || !p->A_ptr || !p->B_ptr || !p->C_ptr || !p->u_ptr || !p->delta_ptr) return DIMSUM_ERR_NULL;
@@ -361,13 +16,6 @@ int ssm_check(const dimsum_ssm_params_t *p, bool forward) {
 
 }  // namespace dimsum
 
-// diagnostics (not part of the public header): resident workgroups per CU the runtime reports for the headline variant
-extern "C" int dimsum_debug_scan_fwd_occupancy(void) {
-    int n = -1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, dimsum::ssm_scan_fwd_kernel<float, 16, true, true, true>, dimsum::kWave, 0) != hipSuccess) return -1;
-    return n;
-}
-
 extern "C" int dimsum_ssm_scan_fwd(const dimsum_ssm_params_t *p, void *stream) {
     using namespace dimsum;
     const int rc = ssm_check(p, true);
@@ -375,9 +23,9 @@ extern "C" int dimsum_ssm_scan_fwd(const dimsum_ssm_params_t *p, void *stream) {
     if (p->batch == 0) return DIMSUM_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (p->dtype) {
-        case DIMSUM_F32: return dispatch_n<float>(*p, s);
-        case DIMSUM_F16: return dispatch_n<__half>(*p, s);
-        case DIMSUM_BF16: return dispatch_n<__hip_bfloat16>(*p, s);
+        case DIMSUM_F32: return ssm_scan_fwd_dispatch<float>(*p, s);
+        case DIMSUM_F16: return ssm_scan_fwd_dispatch<__half>(*p, s);
+        case DIMSUM_BF16: return ssm_scan_fwd_dispatch<__hip_bfloat16>(*p, s);
         default: return DIMSUM_ERR_DTYPE;
     }
 }

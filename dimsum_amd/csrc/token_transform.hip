@@ -114,11 +114,26 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
         for (int k = 0; k < 16; ++k) s_of[k] = (bh * 4 + (k >> 2)) * G + bw * 4 + (k & 3);
     }
     const float *xb = reinterpret_cast<const float *>(p.x_ptr) + (int64_t)b * p.x_batch_stride;
-    float *yb = reinterpret_cast<float *>(p.y_ptr) + (int64_t)b * p.y_batch_stride;
+    float *yb = p.y_ptr ? reinterpret_cast<float *>(p.y_ptr) + (int64_t)b * p.y_batch_stride : nullptr;
     const float *rb = p.residual_ptr ? reinterpret_cast<const float *>(p.residual_ptr) + (int64_t)b * p.res_batch_stride : nullptr;
     const float *gate = p.gate_ptr ? reinterpret_cast<const float *>(p.gate_ptr) + (int64_t)b * p.mod_batch_stride : nullptr;
     const float *scale = p.scale_ptr ? reinterpret_cast<const float *>(p.scale_ptr) + (int64_t)b * p.mod_batch_stride : nullptr;
     const float *shift = p.shift_ptr ? reinterpret_cast<const float *>(p.shift_ptr) + (int64_t)b * p.mod_batch_stride : nullptr;
+
+    const float *wb = p.w_ptr ? reinterpret_cast<const float *>(p.w_ptr) + (int64_t)b * p.w_batch_stride : nullptr;
+    float wdot[VEC], wsum[VEC];       // this thread's partial reductions for the channel group it is storing
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { wdot[e] = 0.f; wsum[e] = 0.f; }
+    auto flush_red = [&](int c) {     // one atomic per channel per workgroup; resets the partials
+        if (wb) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                if (p.wdot_ptr) atomicAdd(reinterpret_cast<float *>(p.wdot_ptr) + (int64_t)b * p.red_batch_stride + c + e, wdot[e]);
+                if (p.wsum_ptr) atomicAdd(reinterpret_cast<float *>(p.wsum_ptr) + (int64_t)b * p.red_batch_stride + c + e, wsum[e]);
+                wdot[e] = 0.f; wsum[e] = 0.f;
+            }
+        }
+    };
 
     auto load_vec = [&](const float *ptr, float *dst) {
         if constexpr (VEC == 4) { const float4 t = *reinterpret_cast<const float4 *>(ptr); dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w; }
@@ -130,6 +145,10 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
         float o[VEC], t[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) o[e] = val[e];
+        if (wb) { load_vec(wb + (int64_t)tok * p.w_token_stride + c, t);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { wdot[e] = fmaf(o[e], t[e], wdot[e]); wsum[e] += t[e]; } }
+        if (!yb) return;
         if (scale) { load_vec(scale + c, t);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) o[e] *= 1.0f + t[e]; }
@@ -184,6 +203,7 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) o[e] = X[e][k];
                 store_out(k, c, o); }
+            flush_red(c);
         } else {
 #pragma unroll
             for (int k = 0; k < 16; ++k) { float v[VEC]; load_in(k, c, v);
@@ -206,6 +226,7 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) o[e] = (KIND == DIMSUM_TT_NONE) ? X[e][k] : Y[e][k];
                     store_out(k, c, o); }
+                flush_red(c);
             }
         }
     }
@@ -225,6 +246,7 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
                 }
                 store_out(k, c, o);
             }
+            flush_red(c);
         }
     }
 }
@@ -289,16 +311,19 @@ __global__ __launch_bounds__(256) void gated_gelu_bwd_kernel(const float *x12, c
 
 extern "C" int dimsum_token_transform(const dimsum_tt_params_t *p, void *stream) {
     using namespace dimsum;
-    if (!p || !p->x_ptr || !p->y_ptr) return DIMSUM_ERR_NULL;
+    if (!p || !p->x_ptr) return DIMSUM_ERR_NULL;
+    if (!p->y_ptr && !(p->w_ptr && (p->wdot_ptr || p->wsum_ptr))) return DIMSUM_ERR_NULL;   // nothing to produce
+    if ((p->wdot_ptr || p->wsum_ptr) && !p->w_ptr) return DIMSUM_ERR_NULL;
     if (p->batch < 0 || p->tokens <= 0 || p->channels <= 0) return DIMSUM_ERR_SHAPE;
     if (p->kind != DIMSUM_TT_NONE && (p->grid % 4 != 0 || p->grid * p->grid != p->tokens)) return DIMSUM_ERR_SHAPE;
     if (p->batch == 0) return DIMSUM_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    bool vec = p->channels % 4 == 0 && aligned_to<float>(p->x_ptr, 16) && aligned_to<float>(p->y_ptr, 16) &&
+    bool vec = p->channels % 4 == 0 && aligned_to<float>(p->x_ptr, 16) && (!p->y_ptr || aligned_to<float>(p->y_ptr, 16)) &&
                p->x_batch_stride % 4 == 0 && p->x_token_stride % 4 == 0 && p->y_batch_stride % 4 == 0 && p->y_token_stride % 4 == 0 &&
                p->mod_batch_stride % 4 == 0 && (!p->gate_ptr || aligned_to<float>(p->gate_ptr, 16)) &&
                (!p->scale_ptr || aligned_to<float>(p->scale_ptr, 16)) && (!p->shift_ptr || aligned_to<float>(p->shift_ptr, 16));
     if (p->residual_ptr) vec = vec && aligned_to<float>(p->residual_ptr, 16) && p->res_batch_stride % 4 == 0 && p->res_token_stride % 4 == 0;
+    if (p->w_ptr) vec = vec && aligned_to<float>(p->w_ptr, 16) && p->w_batch_stride % 4 == 0 && p->w_token_stride % 4 == 0;
     return vec ? launch_tt<4>(*p, s) : launch_tt<1>(*p, s);
 }
 

@@ -39,7 +39,7 @@ def _ptr(t):
 # ---------------------------------------------------------------------------------------------------------------------
 # selective_scan_cuda.fwd / .bwd   (mamba/csrc/selective_scan/selective_scan.cpp:226-492)
 # ---------------------------------------------------------------------------------------------------------------------
-def _fill_ssm(P, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, x, out_z):
+def _fill_ssm(P, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, x, out_z, ckpt=None):
     batch, dim, seqlen = u.shape
     P.batch, P.dim, P.seqlen, P.dstate = batch, dim, seqlen, A.shape[1]
     P.n_groups, P.n_chunks = B.shape[1], (seqlen + 2047) // 2048
@@ -57,7 +57,7 @@ def _fill_ssm(P, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, x, ou
         P.out_z_batch_stride, P.out_z_d_stride = out_z.stride(0), out_z.stride(1)
     P.A_ptr, P.B_ptr, P.C_ptr, P.D_ptr = _ptr(A), _ptr(B), _ptr(C), _ptr(D)
     P.u_ptr, P.delta_ptr, P.delta_bias_ptr, P.z_ptr = _ptr(u), _ptr(delta), _ptr(delta_bias), _ptr(z)
-    P.out_ptr, P.x_ptr, P.out_z_ptr = _ptr(out), _ptr(x), _ptr(out_z)
+    P.out_ptr, P.x_ptr, P.out_z_ptr, P.ckpt_ptr = _ptr(out), _ptr(x), _ptr(out_z), _ptr(ckpt)
 
 
 def _check_ssm(u, delta, A, B, C, D, z, delta_bias):
@@ -87,9 +87,15 @@ def _check_ssm(u, delta, A, B, C, D, z, delta_bias):
         _check(z.dtype == u.dtype and tuple(z.shape) == (batch, dim, seqlen), "selective_scan: bad z")
 
 
-def selective_scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus, need_out=True, need_x=True):
+def scan_ckpt_shape(batch, dim, seqlen, dstate):
+    """states kept for the backward: h before every 8th step, (batch, ceil(L/8), dstate, dim) fp32"""
+    return (batch, (seqlen + 7) // 8, dstate, dim)
+
+
+def selective_scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus, need_out=True, need_x=True, need_ckpt=False):
     """-> [out, x, (out_z)]   exactly like selective_scan_cuda.fwd.
-    `need_out=False` / `need_x=False` are inference extras: the corresponding store is skipped and None returned."""
+    `need_out=False` / `need_x=False` are inference extras: the corresponding store is skipped and None returned.
+    `need_ckpt=True` (training extra) appends the tile-boundary states the backward kernel consumes."""
     _check_ssm(u, delta, A, B, C, D, z, delta_bias)
     batch, dim, seqlen = u.shape
     dstate = A.shape[1]
@@ -97,14 +103,17 @@ def selective_scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus, need
     out = torch.empty_like(delta) if need_out else None          # HBL layout like delta (selective_scan.cpp:310-311)
     x = torch.empty((batch, dim, n_chunks, dstate * 2), device=u.device, dtype=torch.float32) if need_x else None
     out_z = torch.empty_like(z) if z is not None else None
+    ckpt = torch.empty(scan_ckpt_shape(batch, dim, seqlen, dstate), device=u.device, dtype=torch.float32) if need_ckpt else None
     if u.numel() > 0:
         P = _lib.SsmParams()
-        _fill_ssm(P, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, x, out_z)
+        _fill_ssm(P, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, x, out_z, ckpt)
         with torch.cuda.device(u.device):
             _lib.check(_lib.load().dimsum_ssm_scan_fwd(P, _stream(u)), "selective_scan_fwd")
     res = [out, x]
     if z is not None:
         res.append(out_z)
+    if need_ckpt:
+        res.append(ckpt)
     return res
 
 
@@ -247,9 +256,11 @@ def layer_norm_bwd(dy, x, weight, bias, eps, mean, rstd, dresidual=None, has_res
     return dx, dw.to(weight.dtype), db.to(bias.dtype) if bias is not None else None, dresidual_in
 
 
-def selective_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, dz, delta_softplus, recompute_out_z):
+def selective_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, dz, delta_softplus, recompute_out_z, ckpt=None):
     """-> [du, ddelta, dA, dB, dC, dD, ddelta_bias, (dz), (out_z)] exactly like selective_scan_cuda.bwd
-    (selective_scan.cpp:338-492). dz may be a caller-provided view (fused chunk backward, :433-441)."""
+    (selective_scan.cpp:338-492). dz may be a caller-provided view (fused chunk backward, :433-441).
+    `ckpt` (extra): the tile-boundary states of selective_scan_fwd(need_ckpt=True); without it they are rebuilt by one
+    state-only sweep into a scratch buffer."""
     _check_ssm(u, delta, A, B, C, D, z, delta_bias)
     _gpu(dout, x, out, dz)
     batch, dim, seqlen = u.shape
@@ -272,7 +283,11 @@ def selective_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, dz, de
     ddelta_bias = torch.zeros_like(delta_bias) if delta_bias is not None else None
     if u.numel() > 0:
         Q = _lib.SsmBwdParams()
-        _fill_ssm(Q.fwd, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, x, out_z)
+        if ckpt is not None:
+            _gpu(ckpt)
+            _check(tuple(ckpt.shape) == scan_ckpt_shape(batch, dim, seqlen, A.shape[1]) and ckpt.dtype == torch.float32
+                   and ckpt.is_contiguous(), "selective_scan_bwd: bad ckpt")
+        _fill_ssm(Q.fwd, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, x, out_z, ckpt)
         Q.dout_batch_stride, Q.dout_d_stride = dout.stride(0), dout.stride(1)
         Q.dA_d_stride, Q.dA_dstate_stride = dA.stride(0), dA.stride(1)
         Q.dB_batch_stride, Q.dB_group_stride, Q.dB_dstate_stride = dB.stride(0), dB.stride(1), dB.stride(2)
@@ -284,9 +299,10 @@ def selective_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, dz, de
         Q.dout_ptr, Q.dA_ptr, Q.dB_ptr, Q.dC_ptr, Q.dD_ptr = _ptr(dout), _ptr(dA), _ptr(dB), _ptr(dC), _ptr(dD)
         Q.du_ptr, Q.dz_ptr, Q.ddelta_ptr, Q.ddelta_bias_ptr = _ptr(du), _ptr(dz), _ptr(ddelta), _ptr(ddelta_bias)
         lib = _lib.load()
-        nbytes = lib.dimsum_ssm_scan_bwd_workspace_bytes(batch, dim, seqlen, A.shape[1], B.shape[1])
-        ws = torch.empty((nbytes + 3) // 4, device=u.device, dtype=torch.float32)       # tile-boundary states
-        Q.workspace_ptr, Q.workspace_bytes = _ptr(ws), nbytes
+        if ckpt is None:
+            nbytes = lib.dimsum_ssm_scan_bwd_workspace_bytes(batch, dim, seqlen, A.shape[1], B.shape[1])
+            ws = torch.empty((nbytes + 3) // 4, device=u.device, dtype=torch.float32)       # tile-boundary states
+            Q.workspace_ptr, Q.workspace_bytes = _ptr(ws), nbytes
         with torch.cuda.device(u.device):
             _lib.check(lib.dimsum_ssm_scan_bwd(Q, _stream(u)), "selective_scan_bwd")
     res = [du, ddelta, dA, dB.to(B.dtype), dC.to(C.dtype), dD, ddelta_bias]
@@ -303,16 +319,21 @@ def selective_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, dz, de
 _TT_KIND = {("none", True): 0, ("none", False): 0, ("haar", True): 1, ("haar", False): 2, ("dct", True): 3, ("dct", False): 4}
 
 
-def token_transform(x, kind, forward, in_index=None, out_index=None, gate=None, scale=None, shift=None, residual=None):
+def token_transform(x, kind, forward, in_index=None, out_index=None, gate=None, scale=None, shift=None, residual=None,
+                    w=None, want_y=True, want_wsum=False):
     """y[b, out_index[s], c] = T(x[b, in_index[s], c] * gate[b, c])[s] * (1 + scale[b, c]) + shift[b, c] + residual[b, out_index[s], c]
-    x: (B, L, C) fp32 with unit channel stride (may be a channel slice of a wider tensor); index tables int32 (L,)."""
-    _gpu(x, in_index, out_index, gate, scale, shift, residual)
+    x: (B, L, C) fp32 with unit channel stride (may be a channel slice of a wider tensor); index tables int32 (L,).
+    With a weight tensor `w` (indexed like y) the same pass also reduces, per (batch, channel),
+        wdot = sum_s T(.)[s, c] * w[b, out_index[s], c]     and (want_wsum)  wsum = sum_s w[b, out_index[s], c]
+    and returns (y or None, wdot, wsum or None) -- the adaLN-modulation gradients of the block backward."""
+    _gpu(x, in_index, out_index, gate, scale, shift, residual, w)
     _check(x.dim() == 3 and x.dtype == torch.float32 and x.stride(2) == 1, "token_transform: x must be (B, L, C) float32, channel-contiguous")
     B, L, C = x.shape
     grid = int(round(L ** 0.5))
     if kind != "none":
         _check(grid * grid == L and grid % 4 == 0, "token_transform: the token grid must be square with side % 4 == 0")
-    y = torch.empty((B, L, C), device=x.device, dtype=torch.float32)
+    _check(want_y or w is not None, "token_transform: nothing to compute")
+    y = torch.empty((B, L, C), device=x.device, dtype=torch.float32) if want_y else None
     mods = [m for m in (gate, scale, shift) if m is not None]
     mstride = 0
     for m in mods:
@@ -324,19 +345,28 @@ def token_transform(x, kind, forward, in_index=None, out_index=None, gate=None, 
             _check(t.dtype == torch.int32 and t.numel() == L and t.is_contiguous(), "token_transform: index tables must be int32 (L,)")
     if residual is not None:
         _check(residual.shape == x.shape and residual.dtype == torch.float32 and residual.stride(2) == 1, "token_transform: bad residual")
+    wdot = wsum = None
+    if w is not None:
+        _check(w.shape == x.shape and w.dtype == torch.float32 and w.stride(2) == 1, "token_transform: bad w")
+        red = torch.zeros((2 if want_wsum else 1, B, C), device=x.device, dtype=torch.float32)
+        wdot, wsum = red[0], (red[1] if want_wsum else None)
     if B > 0:
         P = _lib.TtParams()
         P.batch, P.tokens, P.channels, P.grid, P.kind = B, L, C, grid, _TT_KIND[(kind, bool(forward))]
         P.x_batch_stride, P.x_token_stride = x.stride(0), x.stride(1)
-        P.y_batch_stride, P.y_token_stride = y.stride(0), y.stride(1)
+        if y is not None:
+            P.y_batch_stride, P.y_token_stride = y.stride(0), y.stride(1)
         if residual is not None:
             P.res_batch_stride, P.res_token_stride = residual.stride(0), residual.stride(1)
+        if w is not None:
+            P.w_batch_stride, P.w_token_stride, P.red_batch_stride = w.stride(0), w.stride(1), C
         P.mod_batch_stride = mstride
         P.x_ptr, P.in_index_ptr, P.out_index_ptr = _ptr(x), _ptr(in_index), _ptr(out_index)
         P.gate_ptr, P.scale_ptr, P.shift_ptr, P.residual_ptr, P.y_ptr = _ptr(gate), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(y)
+        P.w_ptr, P.wdot_ptr, P.wsum_ptr = _ptr(w), _ptr(wdot), _ptr(wsum)
         with torch.cuda.device(x.device):
             _lib.check(_lib.load().dimsum_token_transform(P, _stream(x)), "token_transform")
-    return y
+    return y if w is None else (y, wdot, wsum)
 
 
 def gated_gelu_fwd(x12):

@@ -35,21 +35,23 @@ class SelectiveScanFn(torch.autograd.Function):
             B = B.unsqueeze(1)
         if ctx.squeeze_C:
             C = C.unsqueeze(1)
-        out, x, *rest = native.selective_scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus)
+        need = any(ctx.needs_input_grad)      # training extra: tile-boundary states for the backward kernel
+        out, x, *rest = native.selective_scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus, need_ckpt=need)
+        ckpt = rest.pop() if need else None
         ctx.delta_softplus = delta_softplus
         ctx.has_z = z is not None
         ctx.has_D, ctx.has_bias = D is not None, delta_bias is not None
         last_state = x[:, :, -1, 1::2]                     # (batch, dim, dstate)   (:39)
-        ctx.save_for_backward(u, delta, A, B, C, D, z, delta_bias, x, out if ctx.has_z else None)
+        ctx.save_for_backward(u, delta, A, B, C, D, z, delta_bias, x, out if ctx.has_z else None, ckpt)
         res = rest[0] if ctx.has_z else out
         return res if not return_last_state else (res, last_state)
 
     @staticmethod
     def backward(ctx, dout, *args):
-        u, delta, A, B, C, D, z, delta_bias, x, out = ctx.saved_tensors
+        u, delta, A, B, C, D, z, delta_bias, x, out, ckpt = ctx.saved_tensors
         dout = _last_contig(dout)
         du, ddelta, dA, dB, dC, dD, ddelta_bias, *rest = native.selective_scan_bwd(
-            u, delta, A, B, C, D, z, delta_bias, dout, x, out, None, ctx.delta_softplus, False)
+            u, delta, A, B, C, D, z, delta_bias, dout, x, out, None, ctx.delta_softplus, False, ckpt=ckpt)
         dz = rest[0] if ctx.has_z else None
         dB = dB.squeeze(1) if ctx.squeeze_B else dB
         dC = dC.squeeze(1) if ctx.squeeze_C else dC
@@ -111,14 +113,19 @@ class _MambaInner(torch.autograd.Function):
         Bm = Bm.reshape(bsz, L, N).permute(0, 2, 1).unsqueeze(1).contiguous()                           # (b, 1, N, l)
         Cm = Cm.reshape(bsz, L, N).permute(0, 2, 1).unsqueeze(1).contiguous()
         D = D.contiguous() if D is not None else None
-        out, scan_x, out_z = native.selective_scan_fwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus)
+        # the tile-boundary states ride along to the backward (one activation tensor): it then needs no sweep of
+        # its own to rebuild them. They depend on (conv_out, delta, A, B) only, which the backward recomputes identically.
+        need = any(ctx.needs_input_grad)
+        out, scan_x, out_z, *rest = native.selective_scan_fwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus,
+                                                              need_ckpt=need)
+        ckpt = rest[0] if need else None
         ctx.delta_softplus, ctx.has_out_proj, ctx.checkpoint_lvl = delta_softplus, has_out_proj, checkpoint_lvl
         ctx.flags = (conv1d_bias is not None, D is not None, delta_bias is not None, B_proj_bias is not None,
                      C_proj_bias is not None, has_out_proj and out_proj_bias is not None)
         if checkpoint_lvl >= 1:
             conv_out, delta = None, None            # recomputed in the backward (:663-664)
         ctx.save_for_backward(xz, conv_w, conv_b, x_dbl, x_proj_weight, delta_proj_weight,
-                              out_proj_weight if has_out_proj else None, conv_out, delta, A, Bm, Cm, D, delta_bias, scan_x, out)
+                              out_proj_weight if has_out_proj else None, conv_out, delta, A, Bm, Cm, D, delta_bias, scan_x, out, ckpt)
         if not has_out_proj:
             return out_z                                                                                # (b, d, l)
         return F.linear(out_z.transpose(1, 2), out_proj_weight, out_proj_bias)                          # (b, l, d_model)
@@ -127,7 +134,7 @@ class _MambaInner(torch.autograd.Function):
     @custom_bwd(device_type="cuda")
     def backward(ctx, dout):
         (xz, conv_w, conv_b, x_dbl, x_proj_weight, delta_proj_weight, out_proj_weight, conv_out, delta, A, Bm, Cm, D,
-         delta_bias, scan_x, out) = ctx.saved_tensors
+         delta_bias, scan_x, out, ckpt) = ctx.saved_tensors
         has_conv_b, has_D, has_dbias, has_Bb, has_Cb, has_ob = ctx.flags
         L = xz.shape[-1]
         R = delta_proj_weight.shape[1]
@@ -146,7 +153,7 @@ class _MambaInner(torch.autograd.Function):
         else:
             dout_y = dout
         dconv_out, ddelta, dA, dB, dC, dD, ddelta_bias, dz, out_z = native.selective_scan_bwd(
-            conv_out, delta, A, Bm, Cm, D, z, delta_bias, dout_y, scan_x, out, dz, ctx.delta_softplus, True)
+            conv_out, delta, A, Bm, Cm, D, z, delta_bias, dout_y, scan_x, out, dz, ctx.delta_softplus, True, ckpt=ckpt)
         dout_proj_weight = dout_proj_bias = None
         if ctx.has_out_proj:
             dout_proj_weight = dout2 @ _rows(out_z).t()                                                 # "eB,dB->ed"

@@ -9,10 +9,14 @@
                (the reference computes T^-1(P^-1(P(T(x)) + gate*m)); T and P are linear/orthogonal, so the two agree to
                fp32 roundoff and the pre-mixer intermediate need not be kept)
 
-Two execution paths with identical results:
-  * inference (no autograd): ONE fused HIP kernel per call (csrc/token_transform.hip) through dimsum_amd.native;
-  * under autograd: the same math expressed with differentiable torch ops on the GPU (reshape/sum butterflies and
-    index_select), so gradients need no hand-written adjoint. Neither path touches the CPU.
+Both run as ONE fused HIP kernel per call (csrc/token_transform.hip) through dimsum_amd.native, forward and backward:
+T is orthogonal up to a constant (Haar: T T^t = I/16, DCT: orthonormal) and P a permutation, so the adjoint of each
+fusion is the OTHER fusion with a rescaled gate,
+        d pre / dx   = post-form(dy, gate = k (1 + scale)),   k = 1/16 (Haar) | 1
+        d post / dm  = pre-form(dy,  scale = gate / k - 1)
+and the adaLN gradients (d shift, d scale, d gate) are per-(batch, channel) reductions produced by the same pass.
+The plain torch expressions of the transforms below (haar_dwt_tokens, dct_tokens, ...) document the math and serve the
+tests; the blocks never call them.
 """
 import math
 
@@ -117,21 +121,63 @@ _FWD = {"none": None, "haar": haar_dwt_tokens, "dct": dct_tokens}
 _INV = {"none": None, "haar": haar_idwt_tokens, "dct": idct_tokens}
 
 
+_ADJ = {"none": 1.0, "haar": 1.0 / 16.0, "dct": 1.0}      # T^t = _ADJ * T^-1
+
+
+def _cc(t):     # channel-contiguous view for the kernel
+    return t if t.stride(-1) == 1 else t.contiguous()
+
+
+class _PreMixer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, shift, scale, kind, inv32):
+        from .. import native
+        x = _cc(x)
+        ctx.kind, ctx.inv32 = kind, inv32
+        ctx.save_for_backward(x, scale)
+        return native.token_transform(x, kind, True, out_index=inv32, scale=scale, shift=shift)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import native
+        x, scale = ctx.saved_tensors
+        dy = _cc(dy)
+        dx = dshift = dscale = None
+        if ctx.needs_input_grad[0]:
+            dx = native.token_transform(dy, ctx.kind, False, in_index=ctx.inv32, gate=(1.0 + scale) * _ADJ[ctx.kind])
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            # d scale = sum_tokens dy * P(T(x)), d shift = sum_tokens dy: one read-only pass over (x, dy)
+            _, dscale, dshift = native.token_transform(x, ctx.kind, True, out_index=ctx.inv32, w=dy, want_y=False, want_wsum=True)
+        return dx, dshift, dscale, None, None
+
+
+class _PostMixer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, m, gate, kind, inv32):
+        from .. import native
+        x, m = _cc(x), _cc(m)
+        ctx.kind, ctx.inv32 = kind, inv32
+        ctx.save_for_backward(m, gate)
+        return native.token_transform(m, kind, False, in_index=inv32, gate=gate, residual=x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import native
+        m, gate = ctx.saved_tensors
+        dy = _cc(dy)
+        k = 1.0 / _ADJ[ctx.kind]
+        # dm = gate * P(k T(dy));  d gate = sum_tokens m * P(k T(dy)) -- the same pass reduces T(dy) against m
+        dm, dot, _ = native.token_transform(dy, ctx.kind, True, out_index=ctx.inv32, scale=gate * k - 1.0, w=m)
+        return dy, dm, dot * k, None, None
+
+
 def pre_mixer(x, kind, table, shift, scale):
     """y = modulate(P(T(x)))."""
-    from .. import native
     _require_gpu(x)
-    if not torch.is_grad_enabled() and x.is_cuda:
-        return native.token_transform(x, kind, True, out_index=None if table is None else table["inv32"], scale=scale, shift=shift)
-    t = _FWD[kind](x) if _FWD[kind] is not None else x
-    return modulate(reorder(t, None if table is None else table["fwd"]), shift, scale)
+    return _PreMixer.apply(x, shift, scale, kind, None if table is None else table["inv32"])
 
 
 def post_mixer(x, m, gate, kind, table):
     """y = x + T^-1(P^-1(gate * m))."""
-    from .. import native
     _require_gpu(x)
-    if not torch.is_grad_enabled() and x.is_cuda:
-        return native.token_transform(m, kind, False, in_index=None if table is None else table["inv32"], gate=gate, residual=x)
-    t = reorder(gate.unsqueeze(1) * m, None if table is None else table["inv"])
-    return x + (_INV[kind](t) if _INV[kind] is not None else t)
+    return _PostMixer.apply(x, m, gate, kind, None if table is None else table["inv32"])

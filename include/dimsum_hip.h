@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DIMSUM_ABI_VERSION 1
+#define DIMSUM_ABI_VERSION 2
 
 typedef enum {
     DIMSUM_OK = 0,
@@ -78,6 +78,10 @@ typedef struct {
     void *out_ptr;    /* may be NULL: inference-only callers that need just out_z skip the store */
     void *x_ptr;      /* may be NULL: skip the chunk-state store */
     void *out_z_ptr;  /* required iff z_ptr != NULL */
+    void *ckpt_ptr;   /* optional (batch, ceil(seqlen/8), dstate, dim) f32: the state h BEFORE every 8th step.
+                         forward: written when non-NULL (training callers keep it for the backward);
+                         backward: read when non-NULL, otherwise rebuilt into workspace_ptr by one extra sweep.
+                         Not part of the reference interface (its backward re-scans whole rows instead). */
 } dimsum_ssm_params_t;
 
 typedef struct {
@@ -96,14 +100,16 @@ typedef struct {
     void *dD_ptr;          /* (dim) f32 zero-filled, or NULL */
     void *du_ptr, *dz_ptr, *ddelta_ptr;
     void *ddelta_bias_ptr; /* (dim) f32 zero-filled, or NULL */
-    void *workspace_ptr;   /* scratch for the tile-boundary states, >= dimsum_ssm_scan_bwd_workspace_bytes(...) bytes,
-                              16-byte aligned, contents undefined on entry and exit (the reference keeps the equivalent
-                              in shared memory because it re-scans a whole row per block) */
+    void *workspace_ptr;   /* needed iff fwd.ckpt_ptr == NULL: scratch for the tile-boundary states,
+                              >= dimsum_ssm_scan_bwd_workspace_bytes(...) bytes, 16-byte aligned, contents undefined on
+                              entry and exit (the reference keeps the equivalent in shared memory because it re-scans a
+                              whole row per block) */
     int64_t workspace_bytes;
 } dimsum_ssm_bwd_params_t;
 
 int dimsum_ssm_scan_fwd(const dimsum_ssm_params_t *p, void *stream);
 int dimsum_ssm_scan_bwd(const dimsum_ssm_bwd_params_t *p, void *stream);
+/* bytes of the tile-boundary state array (= size of ckpt_ptr's tensor = the backward's workspace) */
 int64_t dimsum_ssm_scan_bwd_workspace_bytes(int32_t batch, int32_t dim, int32_t seqlen, int32_t dstate, int32_t n_groups);
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -180,7 +186,12 @@ int dimsum_norm_bwd(const dimsum_norm_bwd_params_t *p, void *stream);
  *     transpose / continuity / flip / window-scan / zigzag orders (dimsum/scanning_orders.py, models_dim.py:1496-1524)
  *   - the adaLN affine and a residual at store:
  *       y[b, out_index[s], c] = T(v)[s, c] * (1 + scale[b, c]) + shift[b, c] + residual[b, out_index[s], c]
- * Every optional pointer may be NULL (identity / 0). Streaming op: 2*B*L*C*4 bytes (+ residual).
+ *   - for the backward passes (the adjoint of an orthogonal T is its inverse up to a constant, so the adjoints of
+ *     both block-side fusions are again this kernel), two per-(batch, channel) reductions against a weight tensor w
+ *     indexed like y:   wdot[b, c] += sum_s T(v)[s, c] * w[b, out_index[s], c]      wsum[b, c] += sum_s w[b, out_index[s], c]
+ *     (f32 atomics into caller-zeroed (batch, channels) arrays: d scale / d gate and d shift of the adaLN modulation).
+ *     With y_ptr == NULL only the reductions are produced.
+ * Every optional pointer may be NULL (identity / 0). Streaming op: 2*B*L*C*4 bytes (+ residual / + w).
  * ------------------------------------------------------------------------------------------------------------- */
 typedef enum {
     DIMSUM_TT_NONE = 0, DIMSUM_TT_HAAR_FWD = 1, DIMSUM_TT_HAAR_INV = 2, DIMSUM_TT_DCT_FWD = 3, DIMSUM_TT_DCT_INV = 4
@@ -194,10 +205,14 @@ typedef struct {
     int64_t res_batch_stride, res_token_stride;
     int64_t y_batch_stride, y_token_stride;
     int64_t mod_batch_stride;                         /* row stride of gate / scale / shift, each (batch, channels) */
+    int64_t w_batch_stride, w_token_stride;
+    int64_t red_batch_stride;                         /* row stride of wdot / wsum, each (batch, channels) */
     const void *x_ptr;
     const int32_t *in_index_ptr, *out_index_ptr;      /* (tokens) or NULL */
     const void *gate_ptr, *scale_ptr, *shift_ptr, *residual_ptr;
-    void *y_ptr;
+    void *y_ptr;                                      /* may be NULL when only the reductions are wanted */
+    const void *w_ptr;                                /* (batch, tokens, channels) f32 or NULL */
+    void *wdot_ptr, *wsum_ptr;                        /* (batch, channels) f32 accumulators (atomicAdd) or NULL */
 } dimsum_tt_params_t;
 
 int dimsum_token_transform(const dimsum_tt_params_t *p, void *stream);

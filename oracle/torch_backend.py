@@ -1,7 +1,7 @@
 """CPU stand-in for dimsum_amd.native built on oracle/ -- TEST INFRASTRUCTURE (tests/, smoke(), bench.py cpu_baseline).
 
 `with cpu_oracle_backend():` monkeypatches the tensor-level native entry points (same signatures) with implementations
-that run the CPU oracle, and lifts the GPU-only guard of the differentiable torch path of ops/token_ops.py. This lets
+that run the CPU oracle, and lifts the GPU-only guard of ops/token_ops.py. This lets
 the `-m "not gpu"` suite exercise the host logic of dimsum_amd (autograd Functions, layouts, module composition,
 state_dict keys) against the reference goldens. The product never enables this itself."""
 import contextlib
@@ -20,7 +20,7 @@ def _like(a, ref, dtype=None):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dtype or ref.dtype)
 
 
-def selective_scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus, need_out=True, need_x=True):
+def selective_scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus, need_out=True, need_x=True, need_ckpt=False):
     y, oz, x = c_ops.selective_scan_fwd(_np(u), _np(delta), _np(A), _np(B), _np(C), _np(D), _np(z), _np(delta_bias), delta_softplus)
     out = torch.empty_like(delta)
     out.copy_(_like(y, u))
@@ -29,10 +29,12 @@ def selective_scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus, need
         out_z = torch.empty_like(z)
         out_z.copy_(_like(oz, u))
         res.append(out_z)
+    if need_ckpt:
+        res.append(None)        # the CPU oracle's backward re-derives everything from its inputs
     return res
 
 
-def selective_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, dz, delta_softplus, recompute_out_z):
+def selective_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, dz, delta_softplus, recompute_out_z, ckpt=None):
     r = c_ops.selective_scan_bwd(_np(u), _np(delta), _np(A), _np(B), _np(C), _np(D), _np(z), _np(delta_bias), delta_softplus, _np(dout))
     du = torch.empty_like(u).copy_(_like(r["du"], u))
     ddelta = torch.empty_like(delta).copy_(_like(r["ddelta"], u))
@@ -96,7 +98,8 @@ def gated_gelu_bwd(x12, dh):
     return xr.grad
 
 
-def token_transform(x, kind, forward, in_index=None, out_index=None, gate=None, scale=None, shift=None, residual=None):
+def token_transform(x, kind, forward, in_index=None, out_index=None, gate=None, scale=None, shift=None, residual=None,
+                    w=None, want_y=True, want_wsum=False):
     v = _np(x)
     if gate is not None:
         v = v * _np(gate)[:, None]
@@ -105,6 +108,12 @@ def token_transform(x, kind, forward, in_index=None, out_index=None, gate=None, 
     T = {("haar", True): np_ops.haar_dwt_tokens, ("haar", False): np_ops.haar_idwt_tokens, ("dct", True): np_ops.dct_tokens,
          ("dct", False): np_ops.idct_tokens}.get((kind, bool(forward)), lambda a: a)
     t = T(np.ascontiguousarray(v))
+    wdot = wsum = None
+    if w is not None:       # reductions against w indexed like y: w[b, out_index[s], c] pairs with t[b, s, c]
+        wn = _np(w).astype(np.float64)
+        ws = wn if out_index is None else wn[:, out_index.cpu().numpy()]
+        wdot = torch.from_numpy((t.astype(np.float64) * ws).sum(1).astype(np.float32))
+        wsum = torch.from_numpy(ws.sum(1).astype(np.float32)) if want_wsum else None
     if scale is not None:
         t = t * (1 + _np(scale)[:, None])
     if shift is not None:
@@ -116,7 +125,8 @@ def token_transform(x, kind, forward, in_index=None, out_index=None, gate=None, 
         y = t
     if residual is not None:
         y = y + _np(residual)
-    return torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32))
+    y = torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32)) if want_y else None
+    return y if w is None else (y, wdot, wsum)
 
 
 def xattn_supported(qkv, head_dim):

@@ -87,3 +87,44 @@ def test_gated_gelu():
     dh = torch.randn(ref.shape, generator=torch.Generator().manual_seed(1)).cuda()
     ref.backward(dh)
     assert_close(native.gated_gelu_bwd(x, dh).cpu().numpy(), xr.grad.cpu().numpy(), 1e-4, 0, "bwd", scale_atol=1e-5)
+
+
+@pytest.mark.parametrize("C,H,kind", [(512, 16, "haar"), (576, 32, "haar"), (64, 16, "dct"), (512, 16, "none"), (20, 8, "haar")])
+def test_pre_post_autograd_vs_torch_expression(C, H, kind):
+    """backward of the fused pre/post passes (adjoint = the other fusion with a rescaled gate + in-kernel adaLN
+    reductions) vs torch autograd through the plain expression of the same math (token_ops.haar_dwt_tokens, ...).
+    fp32 tolerance: rtol 2e-5 + 2e-6 max|ref| on tensors, 1e-4 + 1e-5 max|ref| on the L-token reductions."""
+    from dimsum_amd import scanning_orders as so
+    from dimsum_amd.ops import token_ops as to
+    torch.manual_seed(C + H)
+    B, L = 3, H * H
+    table = so.compose(so.local_scan_table(H, H // 4, True), so.block_order_table(H, True, False, True))
+    inv = so.reverse_permut_np(table)
+    tab = {"fwd": torch.from_numpy(table).cuda(), "inv": torch.from_numpy(inv).cuda(), "inv32": torch.from_numpy(inv.astype(np.int32)).cuda()}
+    Tf = {"haar": to.haar_dwt_tokens, "dct": to.dct_tokens, "none": lambda a: a}[kind]
+    Ti = {"haar": to.haar_idwt_tokens, "dct": to.idct_tokens, "none": lambda a: a}[kind]
+
+    def leafs():
+        torch.manual_seed(C + H)
+        full = torch.randn(B, L, 2 * C, device="cuda", requires_grad=True)
+        mods = torch.randn(B, 3 * C, device="cuda", requires_grad=True)
+        m = torch.randn(B, L, C, device="cuda", requires_grad=True)
+        return full, mods, m
+
+    dy1, dy2 = torch.randn(B, L, C, device="cuda"), torch.randn(B, L, C, device="cuda")
+    grads = []
+    for fused in (True, False):
+        full, mods, m = leafs()
+        x = full[:, :, C:]
+        shift, scale, gate = mods.chunk(3, dim=1)
+        if fused:
+            y1 = to.pre_mixer(x, kind, tab, shift, scale)
+            y2 = to.post_mixer(x, m, gate, kind, tab)
+        else:
+            y1 = to.modulate(Tf(x).index_select(1, tab["fwd"]), shift, scale)
+            y2 = x + Ti((gate.unsqueeze(1) * m).index_select(1, tab["inv"]))
+        torch.autograd.backward((y1, y2), (dy1, dy2))
+        grads.append((y1.detach(), y2.detach(), full.grad, mods.grad, m.grad))
+    for name, a, b, (rt, sa) in zip(("pre", "post", "dx", "dmods", "dm"), grads[0], grads[1],
+                                    ((2e-5, 2e-6), (2e-5, 2e-6), (2e-5, 2e-6), (1e-4, 1e-5), (2e-5, 2e-6))):
+        assert_close(a.cpu().numpy(), b.cpu().numpy(), rt, 0, name, scale_atol=sa)

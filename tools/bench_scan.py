@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of the selective-scan forward kernel at the BASELINE config-2 shape (GPU box)."""
+"""Micro-benchmark of the selective-scan forward (default) or backward (--bwd) kernel at the BASELINE config-2/3 shape
+(GPU box). The operands have the layouts MambaInnerFn produces (d-major delta / out / dout, z = half of xz)."""
 import argparse
 import json
 import os
@@ -24,6 +25,8 @@ def main():
     ap.add_argument("--N", type=int, default=16)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dtype", default="float32")
+    ap.add_argument("--bwd", action="store_true", help="time selective_scan_bwd (with the saved states of the forward)")
+    ap.add_argument("--no-ckpt", action="store_true", help="--bwd without saved states: the kernel pair of the reference-shaped call")
     a = ap.parse_args()
     dt = getattr(torch, a.dtype)
     B, D, L, N = a.B, a.D, a.L, a.N
@@ -35,19 +38,33 @@ def main():
     Bm, Cm = torch.randn(B, 1, N, L, device=dev, dtype=dt), torch.randn(B, 1, N, L, device=dev, dtype=dt)
     Dv, bias = torch.randn(D, device=dev), 0.5 * torch.rand(D, device=dev)
     z = xz.chunk(2, 1)[1]
+    if a.bwd:
+        out, x, out_z, ckpt = native.selective_scan_fwd(u, delta, A, Bm, Cm, Dv, z, bias, True, need_ckpt=True)
+        dout = torch.randn(D, B, L, device=dev).to(dt).permute(1, 0, 2)
+        dxz = torch.empty_like(xz)
+        dz = dxz.chunk(2, 1)[1]
+        ck = None if a.no_ckpt else ckpt
+
+        def call():
+            return native.selective_scan_bwd(u, delta, A, Bm, Cm, Dv, z, bias, dout, x, out, dz, True, True, ckpt=ck)
+        s_ = u.element_size()       # SURVEY 8(d) with the out_z recompute: 9 B D L s + 2 B N L (s + 4) + x
+        nbytes = 9 * B * D * L * s_ + 2 * B * N * L * (s_ + 4) + B * D * ((L + 2047) // 2048) * 2 * N * 4 + (D * N + 2 * D) * 4
+    else:
+        def call():
+            return native.selective_scan_fwd(u, delta, A, Bm, Cm, Dv, z, bias, True)
+        nbytes = scan_bytes(B, D, L, N, 1, u.element_size())
     for _ in range(3):
-        native.selective_scan_fwd(u, delta, A, Bm, Cm, Dv, z, bias, True)
+        call()
     torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.iters)]
     for s, e in evs:
         s.record()
-        native.selective_scan_fwd(u, delta, A, Bm, Cm, Dv, z, bias, True)
+        call()
         e.record()
     torch.cuda.synchronize()
     ms = sorted(s.elapsed_time(e) for s, e in evs)
     med = ms[len(ms) // 2]
-    nbytes = scan_bytes(B, D, L, N, 1, u.element_size())
-    print(json.dumps({"shape": [B, D, L, N], "dtype": a.dtype, "ms_median": med, "ms_min": ms[0], "algorithmic_GB": nbytes / 1e9,
+    print(json.dumps({"kernel": "bwd" if a.bwd else "fwd", "shape": [B, D, L, N], "dtype": a.dtype, "ms_median": med, "ms_min": ms[0], "algorithmic_GB": nbytes / 1e9,
                       "GBps": nbytes / med / 1e6, "frac_of_8TBps": nbytes / med / 1e6 / 8000}))
 
 
