@@ -22,9 +22,10 @@
 //     algorithmic minimum + the states.
 //   * dB / dC are sums over the wave's 64 channels of per-lane values: a TRANSPOSED butterfly -- 64 values per lane go
 //     in, one fully reduced value per lane comes out, in 6 levels of v_permlane32_swap / v_permlane16_swap / DPP adds
-//     (~2.2 VALU ops per value instead of ~12 for 64 independent wave reductions) -- then ONE coalesced atomicAdd per
-//     (n, t) per wave (16 waves contend per address instead of the reference's 1024 rows,
-//     selective_scan_bwd_kernel.cuh:297-316).
+//     (~2.5 VALU ops per value instead of ~12 for independent wave reductions). The wave's (n, t) sums of a tile are
+//     collected in LDS and stored once, 16 B per lane, as this wave's PARTIAL dB / dC; a second small kernel adds the
+//     partials of the dim/64 waves of a (batch, group) in a fixed order. No atomics on dB / dC at all (the reference
+//     does 1024-way contended atomicAdds per address, selective_scan_bwd_kernel.cuh:297-316) -> bitwise reproducible.
 //   * u, delta, dy tiles go through an XOR-swizzled LDS transpose like in the forward; dz / out_z are computed in the
 //     coalesced load layout (16 B per lane in and out) and never touch LDS.
 //   * register budget <= 256 VGPRs (2 waves per SIMD cover each other's tile-staging latency).
@@ -107,16 +108,22 @@ __device__ __forceinline__ float dsoftplus_from_dt(float dt) {
 
 // kVec : every row base 4-element aligned and L % 4 == 0 -> 16-byte vector I/O.   kFull: all 64 lanes own a live channel.
 template <typename T, int kN, bool kHasZ, bool kVec, bool kFull>
-__global__ __launch_bounds__(kWave, 2) void ssm_scan_bwd_kernel(const dimsum_ssm_bwd_params_t q, const float *__restrict__ ckpt) {
+__global__ __launch_bounds__(kWave, 2) void ssm_scan_bwd_kernel(const dimsum_ssm_bwd_params_t q, const float *__restrict__ ckpt, float *__restrict__ part) {
     constexpr int kBG = 4;                        // states processed together
     constexpr int NV = kBG * kBS;                 // (state, step) values per transposed reduction
     static_assert(kN % kBG == 0 && (NV == 64 || NV == 32), "dstate must be a multiple of 4");
     const dimsum_ssm_params_t &p = q.fwd;
     __shared__ __attribute__((aligned(16))) float tU[kWave * kBT], tD[kWave * kBT], tY[kWave * kBT];   // u, dt (softplus'ed), dy
     __shared__ __attribute__((aligned(16))) float tB[kN * kBT], tC[kN * kBT];
-    // per-(state, lane) persistent values live in LDS ([n][lane], conflict-free) so that the 4-state group loop can stay
-    // rolled: A, the running dA sum and the reverse-recurrence carry dh
-    __shared__ float sA[kN * kWave], sdA[kN * kWave], sdh[kN * kWave];
+    __shared__ __attribute__((aligned(16))) float tdB[kN * kBT], tdC[kN * kBT];      // this wave's dB / dC sums of the tile
+    // Per-(state, lane) values that persist over the whole walk: the running dA sum lives in LDS ([n][lane], conflict
+    // free); the reverse-recurrence carry dh in registers for dstate <= 16 (-> 20 KB of LDS per wave = 8 waves per CU),
+    // in LDS otherwise; A is re-read from L1/L2 one group ahead. The state-group loop stays rolled (one copy of the body;
+    // real control flow between groups keeps the scheduler from interleaving them and blowing the register budget);
+    // a uniform switch moves the group's dh in and out of the static register array.
+    constexpr bool kRegState = kN <= 16;
+    __shared__ float sdA[kN * kWave], sdh[kRegState ? 1 : kN * kWave];
+    float rdh[kRegState ? kN : 1];
 
     const int lane = threadIdx.x;
     const int L = p.seqlen;
@@ -145,21 +152,20 @@ __global__ __launch_bounds__(kWave, 2) void ssm_scan_bwd_kernel(const dimsum_ssm
     T *dd_base = reinterpret_cast<T *>(q.ddelta_ptr) + (int64_t)b * q.ddelta_batch_stride + (int64_t)d0 * q.ddelta_d_stride;
     const T *Bp = reinterpret_cast<const T *>(p.B_ptr) + (int64_t)b * p.B_batch_stride + (int64_t)g * p.B_group_stride;
     const T *Cp = reinterpret_cast<const T *>(p.C_ptr) + (int64_t)b * p.C_batch_stride + (int64_t)g * p.C_group_stride;
-    float *dBp = reinterpret_cast<float *>(q.dB_ptr) + (int64_t)b * q.dB_batch_stride + (int64_t)g * q.dB_group_stride;
-    float *dCp = reinterpret_cast<float *>(q.dC_ptr) + (int64_t)b * q.dC_batch_stride + (int64_t)g * q.dC_group_stride;
+    // partial sums of this wave: part[wave][dB | dC][n][L]
+    float *pB = part + (int64_t)wg * 2 * kN * L, *pC = pB + (int64_t)kN * L;
     const int u_ds = (int)p.u_d_stride, dl_ds = (int)p.delta_d_stride, do_ds = (int)q.dout_d_stride, z_ds = (int)p.z_d_stride;
     const int y_ds = (int)p.out_d_stride, oz_ds = (int)p.out_z_d_stride, dz_ds = (int)q.dz_d_stride, du_ds = (int)q.du_d_stride;
     const int dd_ds = (int)q.ddelta_d_stride;
     const int Bns = (int)p.B_dstate_stride, Cns = (int)p.C_dstate_stride;
-    const int dBns = (int)q.dB_dstate_stride, dCns = (int)q.dC_dstate_stride;
 
-    {
-        const float *Ap = reinterpret_cast<const float *>(p.A_ptr) + (int64_t)d * p.A_d_stride;
+    const float *Ap = reinterpret_cast<const float *>(p.A_ptr) + (int64_t)d * p.A_d_stride;
+    const int A_ns = (int)p.A_dstate_stride;
 #pragma unroll
-        for (int n = 0; n < kN; ++n) {
-            sA[n * kWave + lane] = Ap[n * p.A_dstate_stride] * kLog2e;    // exp(dt A) = exp2(dt A log2 e)
-            sdA[n * kWave + lane] = 0.f; sdh[n * kWave + lane] = 0.f;
-        }
+    for (int n = 0; n < kN; ++n) {
+        sdA[n * kWave + lane] = 0.f;
+        if constexpr (kRegState) rdh[n] = 0.f;
+        else sdh[n * kWave + lane] = 0.f;
     }
     const float Dval = p.D_ptr ? reinterpret_cast<const float *>(p.D_ptr)[d] : 0.f;
     const float bias = p.delta_bias_ptr ? reinterpret_cast<const float *>(p.delta_bias_ptr)[d] : 0.f;
@@ -208,9 +214,9 @@ __global__ __launch_bounds__(kWave, 2) void ssm_scan_bwd_kernel(const dimsum_ssm
     };
 
     // states of the first group to be processed (last half tile, first kBG states); later groups are prefetched one ahead
-    float h_pre[kBG];
+    float h_pre[kBG], a_pre[kBG];
 #pragma unroll
-    for (int k = 0; k < kBG; ++k) h_pre[k] = ck_lane[((int64_t)(n_halves - 1) * kN + k) * ck_ns];
+    for (int k = 0; k < kBG; ++k) { h_pre[k] = ck_lane[((int64_t)(n_halves - 1) * kN + k) * ck_ns]; a_pre[k] = Ap[k * A_ns]; }
 
 #pragma unroll 1
     for (int tile = n_tiles - 1; tile >= 0; --tile) {
@@ -289,20 +295,26 @@ __global__ __launch_bounds__(kWave, 2) void ssm_scan_bwd_kernel(const dimsum_ssm
 #pragma unroll
             for (int t = 0; t < kBS; ++t) { s1[t] = 0.f; s2[t] = 0.f; }
 
-#pragma unroll 1
-            for (int n0 = 0; n0 < kN; n0 += kBG) {
+            auto group = [&](const int n0) {
                 float H[kBG * kBS];       // [k][t]: h_t of state n0+k, later overwritten by the dB terms
                 float hk[kBG], Ak[kBG], dAk[kBG], dhk[kBG];
 #pragma unroll
                 for (int k = 0; k < kBG; ++k) {
                     hk[k] = h_pre[k];
-                    Ak[k] = sA[(n0 + k) * kWave + lane]; dAk[k] = sdA[(n0 + k) * kWave + lane]; dhk[k] = sdh[(n0 + k) * kWave + lane];
+                    Ak[k] = a_pre[k] * kLog2e;            // exp(dt A) = exp2(dt A log2 e)
+                    dAk[k] = sdA[(n0 + k) * kWave + lane];
+                    if constexpr (!kRegState) dhk[k] = sdh[(n0 + k) * kWave + lane];
+                }
+                if constexpr (kRegState) {
+#define DIMSUM_GET(G) case G * kBG: _Pragma("unroll") for (int k = 0; k < kBG; ++k) { if (G * kBG + k < kN) dhk[k] = rdh[G * kBG + k]; } break;
+                    switch (n0) { DIMSUM_GET(0) DIMSUM_GET(1) DIMSUM_GET(2) default: DIMSUM_GET(3) }
+#undef DIMSUM_GET
                 }
                 {   // prefetch the saved states of the next group (next kBG states of this half, or the previous half's first)
                     const bool wrap = n0 + kBG >= kN;
                     const int nh = wrap ? max(hidx - 1, 0) : hidx, nn = wrap ? 0 : n0 + kBG;
 #pragma unroll
-                    for (int k = 0; k < kBG; ++k) h_pre[k] = ck_lane[((int64_t)nh * kN + nn + k) * ck_ns];
+                    for (int k = 0; k < kBG; ++k) { h_pre[k] = ck_lane[((int64_t)nh * kN + nn + k) * ck_ns]; a_pre[k] = Ap[(nn + k) * A_ns]; }
                 }
                 // ---- forward sweep: h_t for the 8 steps of the half -------------------------------------------------------
 #pragma unroll
@@ -332,8 +344,8 @@ __global__ __launch_bounds__(kWave, 2) void ssm_scan_bwd_kernel(const dimsum_ssm
                         for (int s = 0; s < 4; ++s) y8[jj * 4 + s] = live ? y4.v[s] : 0.f;
                     }
                     const float r = transposed_reduce<NV>([&](int i) { return y8[i & (kBS - 1)] * H[i]; }, lane);
-                    const int vi = lane & (NV - 1), n = n0 + (vi >> 3), t = t0 + half * kBS + (vi & 7);
-                    if (lane < NV && t < L) atomicAdd(dCp + (unsigned)(n * dCns + t), r);
+                    const int vi = lane & (NV - 1);
+                    if (lane < NV) tdC[(n0 + (vi >> 3)) * kBT + half * kBS + (vi & 7)] = r;
                 }
                 // ---- reverse sweep -------------------------------------------------------------------------------------------
 #pragma unroll
@@ -368,14 +380,24 @@ __global__ __launch_bounds__(kWave, 2) void ssm_scan_bwd_kernel(const dimsum_ssm
                     }
                 }
 #pragma unroll
-                for (int k = 0; k < kBG; ++k) { sdA[(n0 + k) * kWave + lane] = dAk[k]; sdh[(n0 + k) * kWave + lane] = dhk[k]; }
+                for (int k = 0; k < kBG; ++k) {
+                    sdA[(n0 + k) * kWave + lane] = dAk[k];
+                    if constexpr (!kRegState) sdh[(n0 + k) * kWave + lane] = dhk[k];
+                }
+                if constexpr (kRegState) {
+#define DIMSUM_PUT(G) case G * kBG: _Pragma("unroll") for (int k = 0; k < kBG; ++k) { if (G * kBG + k < kN) rdh[G * kBG + k] = dhk[k]; } break;
+                    switch (n0) { DIMSUM_PUT(0) DIMSUM_PUT(1) DIMSUM_PUT(2) default: DIMSUM_PUT(3) }
+#undef DIMSUM_PUT
+                }
                 // ---- dB[n, t] = sum_d dh_t[n] dt_t u_t -----------------------------------------------------------------------
                 {
                     const float r = transposed_reduce<NV>([&](int i) { return live ? H[i] : 0.f; }, lane);
-                    const int vi = lane & (NV - 1), n = n0 + (vi >> 3), t = t0 + half * kBS + (vi & 7);
-                    if (lane < NV && t < L) atomicAdd(dBp + (unsigned)(n * dBns + t), r);
+                    const int vi = lane & (NV - 1);
+                    if (lane < NV) tdB[(n0 + (vi >> 3)) * kBT + half * kBS + (vi & 7)] = r;
                 }
-            }
+            };
+#pragma unroll 1
+            for (int n0 = 0; n0 < kN; n0 += kBG) group(n0);
 
             // ---- per-(d, t) results of the half: du, ddelta (softplus chain), dD, ddelta_bias; parked in LDS over u / dy
             //      (s2 was accumulated with A * log2 e) ----------------------------------------------------------------------
@@ -401,6 +423,20 @@ __global__ __launch_bounds__(kWave, 2) void ssm_scan_bwd_kernel(const dimsum_ssm
         }
         dt_next = dt_first;
 
+        // ---- this wave's partial dB / dC of the tile: 16 B per lane, rows of 64 B ------------------------------------------
+        for (int idx = lane; idx < kN * 4; idx += kWave) {
+            const int n = idx >> 2, c = (idx & 3) * 4, t = t0 + c;
+            const f32x4 vb = *reinterpret_cast<const f32x4 *>(&tdB[n * kBT + c]);
+            const f32x4 vc = *reinterpret_cast<const f32x4 *>(&tdC[n * kBT + c]);
+            if (t + 3 < L) {
+                st4<float>(pB + (int64_t)n * L + t, vb);
+                st4<float>(pC + (int64_t)n * L + t, vc);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (t + e < L) { pB[(int64_t)n * L + t + e] = vb.v[e]; pC[(int64_t)n * L + t + e] = vc.v[e]; }
+            }
+        }
         // ---- coalesced stores of du, ddelta -------------------------------------------------------------------------------
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -434,8 +470,28 @@ __global__ __launch_bounds__(kWave, 2) void ssm_scan_bwd_kernel(const dimsum_ssm
     }
 }
 
+// dB[b, g, n, t] = sum over the waves w of (b, g), in index order, of part[b, g, w][0][n][t]  (same for dC)
+__global__ __launch_bounds__(256) void ssm_scan_bwd_reduce_kernel(const float *__restrict__ part, const dimsum_ssm_bwd_params_t q, int waves_per_group) {
+    const dimsum_ssm_params_t &p = q.fwd;
+    const int L = p.seqlen, N = p.dstate;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // over (b, g, which, n, t)
+    const int64_t total = (int64_t)p.batch * p.n_groups * 2 * N * L;
+    if (i >= total) return;
+    const int t = (int)(i % L);
+    int64_t r = i / L;
+    const int n = (int)(r % N); r /= N;
+    const int which = (int)(r & 1); r >>= 1;
+    const int g = (int)(r % p.n_groups);
+    const int b = (int)(r / p.n_groups);
+    const float *src = part + (((int64_t)(b * p.n_groups + g) * waves_per_group) * 2 + which) * N * L + (int64_t)n * L + t;
+    float acc = 0.f;
+    for (int w = 0; w < waves_per_group; ++w) acc += src[(int64_t)w * 2 * N * L];
+    if (which == 0) reinterpret_cast<float *>(q.dB_ptr)[(int64_t)b * q.dB_batch_stride + (int64_t)g * q.dB_group_stride + (int64_t)n * q.dB_dstate_stride + t] = acc;
+    else reinterpret_cast<float *>(q.dC_ptr)[(int64_t)b * q.dC_batch_stride + (int64_t)g * q.dC_group_stride + (int64_t)n * q.dC_dstate_stride + t] = acc;
+}
+
 template <typename T, int kN>
-static int launch_bwd(const dimsum_ssm_bwd_params_t &q, const float *ckpt, hipStream_t stream) {
+static int launch_bwd(const dimsum_ssm_bwd_params_t &q, const float *ckpt, float *part, hipStream_t stream) {
     const dimsum_ssm_params_t &p = q.fwd;
     const int dpg = p.dim / p.n_groups;
     const int tiles = p.batch * p.n_groups * ((dpg + kWave - 1) / kWave);
@@ -458,13 +514,13 @@ static int launch_bwd(const dimsum_ssm_bwd_params_t &q, const float *ckpt, hipSt
                            (p.z_ptr && p.out_z_ptr) ? p.out_z_d_stride : 0};
     for (int64_t ds : dss)
         if (ds < 0 || 64 * ds + Ls >= lim) return DIMSUM_ERR_STRIDE;
-    const int64_t nss[] = {p.B_dstate_stride, p.C_dstate_stride, q.dB_dstate_stride, q.dC_dstate_stride};
+    const int64_t nss[] = {p.B_dstate_stride, p.C_dstate_stride};
     for (int64_t ns : nss)
         if (ns < 0 || (int64_t)p.dstate * ns + Ls >= lim) return DIMSUM_ERR_STRIDE;
     const bool full = vec && (dpg % kWave == 0);
     dim3 grid(tiles), block(kWave);
 #define DIMSUM_LAUNCH(HASZ, VEC, FULL) \
-    hipLaunchKernelGGL((ssm_scan_bwd_kernel<T, kN, HASZ, VEC, FULL>), grid, block, 0, stream, q, ckpt)
+    hipLaunchKernelGGL((ssm_scan_bwd_kernel<T, kN, HASZ, VEC, FULL>), grid, block, 0, stream, q, ckpt, part)
     if (p.z_ptr) {
         if (full) DIMSUM_LAUNCH(true, true, true);
         else if (vec) DIMSUM_LAUNCH(true, true, false);
@@ -475,18 +531,21 @@ static int launch_bwd(const dimsum_ssm_bwd_params_t &q, const float *ckpt, hipSt
         else DIMSUM_LAUNCH(false, false, false);
     }
 #undef DIMSUM_LAUNCH
+    if (launch_status() != DIMSUM_OK) return DIMSUM_ERR_LAUNCH;
+    const int64_t total = (int64_t)p.batch * p.n_groups * 2 * kN * p.seqlen;
+    hipLaunchKernelGGL(ssm_scan_bwd_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, part, q, (dpg + kWave - 1) / kWave);
     return launch_status();
 }
 
 template <typename T>
-static int dispatch_bwd(const dimsum_ssm_bwd_params_t &q, const float *ckpt, hipStream_t stream) {
+static int dispatch_bwd(const dimsum_ssm_bwd_params_t &q, const float *ckpt, float *part, hipStream_t stream) {
     switch (q.fwd.dstate) {
 #ifndef DIMSUM_DEV_ONE      // development builds instantiate the headline variant only
-        case 4: return launch_bwd<T, 4>(q, ckpt, stream);
-        case 8: return launch_bwd<T, 8>(q, ckpt, stream);
-        case 32: return launch_bwd<T, 32>(q, ckpt, stream);
+        case 4: return launch_bwd<T, 4>(q, ckpt, part, stream);
+        case 8: return launch_bwd<T, 8>(q, ckpt, part, stream);
+        case 32: return launch_bwd<T, 32>(q, ckpt, part, stream);
 #endif
-        case 16: return launch_bwd<T, 16>(q, ckpt, stream);
+        case 16: return launch_bwd<T, 16>(q, ckpt, part, stream);
         default: return DIMSUM_ERR_SHAPE;
     }
 }
@@ -495,10 +554,19 @@ int ssm_check(const dimsum_ssm_params_t *p, bool forward);
 
 }  // namespace dimsum
 
+static int64_t partial_bytes(int32_t batch, int32_t dim, int32_t seqlen, int32_t dstate, int32_t n_groups) {
+    const int64_t dpg = dim / n_groups;
+    const int64_t waves = (int64_t)batch * n_groups * ((dpg + dimsum::kWave - 1) / dimsum::kWave);
+    return waves * 2 * dstate * seqlen * (int64_t)sizeof(float);                    // (waves, dB | dC, dstate, seqlen)
+}
+static int64_t ckpt_bytes(int32_t batch, int32_t dim, int32_t seqlen, int32_t dstate) {
+    const int64_t n_halves = (seqlen + dimsum::kBS - 1) / dimsum::kBS;
+    return (int64_t)batch * n_halves * dstate * dim * (int64_t)sizeof(float);       // (batch, half tiles, dstate, dim)
+}
+
 extern "C" int64_t dimsum_ssm_scan_bwd_workspace_bytes(int32_t batch, int32_t dim, int32_t seqlen, int32_t dstate, int32_t n_groups) {
     if (batch <= 0 || dim <= 0 || seqlen <= 0 || dstate <= 0 || n_groups <= 0 || dim % n_groups != 0) return 0;
-    const int64_t n_halves = (seqlen + dimsum::kBS - 1) / dimsum::kBS;
-    return (int64_t)batch * n_halves * dstate * dim * (int64_t)sizeof(float);      // (batch, half tiles, dstate, dim)
+    return partial_bytes(batch, dim, seqlen, dstate, n_groups) + ckpt_bytes(batch, dim, seqlen, dstate);
 }
 
 extern "C" int dimsum_ssm_scan_bwd(const dimsum_ssm_bwd_params_t *q, void *stream) {
@@ -506,27 +574,30 @@ extern "C" int dimsum_ssm_scan_bwd(const dimsum_ssm_bwd_params_t *q, void *strea
     if (!q) return DIMSUM_ERR_NULL;
     const int rc = ssm_check(&q->fwd, false);
     if (rc != DIMSUM_OK) return rc;
-    if (!q->dout_ptr || !q->dA_ptr || !q->dB_ptr || !q->dC_ptr || !q->du_ptr || !q->ddelta_ptr) return DIMSUM_ERR_NULL;
+    if (!q->dout_ptr || !q->dA_ptr || !q->dB_ptr || !q->dC_ptr || !q->du_ptr || !q->ddelta_ptr || !q->workspace_ptr) return DIMSUM_ERR_NULL;
     if (q->fwd.z_ptr && (!q->dz_ptr || !q->fwd.out_ptr)) return DIMSUM_ERR_NULL;
     const dimsum_ssm_params_t &p = q->fwd;
+    if (!aligned_to<float>(q->workspace_ptr, 16)) return DIMSUM_ERR_STRIDE;
+    // workspace = [per-wave partial dB / dC | saved states (only when the caller did not keep the forward's)]
+    const int64_t pbytes = partial_bytes(p.batch, p.dim, p.seqlen, p.dstate, p.n_groups);
     const float *ckpt = reinterpret_cast<const float *>(p.ckpt_ptr);
+    if (q->workspace_bytes < pbytes + (ckpt ? 0 : ckpt_bytes(p.batch, p.dim, p.seqlen, p.dstate))) return DIMSUM_ERR_SHAPE;
+    float *part = reinterpret_cast<float *>(q->workspace_ptr);
     if (!ckpt) {
-        // reference-shaped call (no saved tile states): one state-only forward sweep rebuilds them in the workspace
-        if (!q->workspace_ptr) return DIMSUM_ERR_NULL;
-        if (q->workspace_bytes < dimsum_ssm_scan_bwd_workspace_bytes(p.batch, p.dim, p.seqlen, p.dstate, p.n_groups)) return DIMSUM_ERR_SHAPE;
+        // reference-shaped call (no saved states): one state-only forward sweep rebuilds them in the workspace
         dimsum_ssm_params_t f = p;
         f.z_ptr = nullptr; f.out_ptr = nullptr; f.out_z_ptr = nullptr; f.x_ptr = nullptr; f.D_ptr = nullptr;
-        f.ckpt_ptr = q->workspace_ptr;
+        f.ckpt_ptr = reinterpret_cast<char *>(q->workspace_ptr) + pbytes;
         const int frc = dimsum_ssm_scan_fwd(&f, stream);
         if (frc != DIMSUM_OK) return frc;
-        ckpt = reinterpret_cast<const float *>(q->workspace_ptr);
+        ckpt = reinterpret_cast<const float *>(f.ckpt_ptr);
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (p.dtype) {
-        case DIMSUM_F32: return dispatch_bwd<float>(*q, ckpt, s);
+        case DIMSUM_F32: return dispatch_bwd<float>(*q, ckpt, part, s);
 #ifndef DIMSUM_DEV_ONE
-        case DIMSUM_F16: return dispatch_bwd<__half>(*q, ckpt, s);
-        case DIMSUM_BF16: return dispatch_bwd<__hip_bfloat16>(*q, ckpt, s);
+        case DIMSUM_F16: return dispatch_bwd<__half>(*q, ckpt, part, s);
+        case DIMSUM_BF16: return dispatch_bwd<__hip_bfloat16>(*q, ckpt, part, s);
 #endif
         default: return DIMSUM_ERR_DTYPE;
     }

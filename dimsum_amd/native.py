@@ -277,8 +277,8 @@ def selective_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, dz, de
     du = torch.empty_like(u)
     ddelta = torch.empty_like(delta)
     dA = torch.zeros_like(A)
-    dB = torch.zeros(B.shape, device=u.device, dtype=torch.float32)      # fp32 accumulate then cast (cpp:461-462,488)
-    dC = torch.zeros(C.shape, device=u.device, dtype=torch.float32)
+    dB = torch.empty(B.shape, device=u.device, dtype=torch.float32)      # fp32 then cast (cpp:461-462,488)
+    dC = torch.empty(C.shape, device=u.device, dtype=torch.float32)
     dD = torch.zeros_like(D) if D is not None else None
     ddelta_bias = torch.zeros_like(delta_bias) if delta_bias is not None else None
     if u.numel() > 0:
@@ -299,10 +299,11 @@ def selective_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, dz, de
         Q.dout_ptr, Q.dA_ptr, Q.dB_ptr, Q.dC_ptr, Q.dD_ptr = _ptr(dout), _ptr(dA), _ptr(dB), _ptr(dC), _ptr(dD)
         Q.du_ptr, Q.dz_ptr, Q.ddelta_ptr, Q.ddelta_bias_ptr = _ptr(du), _ptr(dz), _ptr(ddelta), _ptr(ddelta_bias)
         lib = _lib.load()
-        if ckpt is None:
-            nbytes = lib.dimsum_ssm_scan_bwd_workspace_bytes(batch, dim, seqlen, A.shape[1], B.shape[1])
-            ws = torch.empty((nbytes + 3) // 4, device=u.device, dtype=torch.float32)       # tile-boundary states
-            Q.workspace_ptr, Q.workspace_bytes = _ptr(ws), nbytes
+        nbytes = lib.dimsum_ssm_scan_bwd_workspace_bytes(batch, dim, seqlen, A.shape[1], B.shape[1])
+        if ckpt is not None:
+            nbytes -= ckpt.numel() * 4          # the states part is only needed when they must be rebuilt
+        ws = torch.empty((nbytes + 3) // 4, device=u.device, dtype=torch.float32)       # per-wave partial dB / dC (+ states)
+        Q.workspace_ptr, Q.workspace_bytes = _ptr(ws), nbytes
         with torch.cuda.device(u.device):
             _lib.check(lib.dimsum_ssm_scan_bwd(Q, _stream(u)), "selective_scan_bwd")
     res = [du, ddelta, dA, dB.to(B.dtype), dC.to(C.dtype), dD, ddelta_bias]

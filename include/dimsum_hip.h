@@ -96,20 +96,21 @@ typedef struct {
     int64_t ddelta_batch_stride, ddelta_d_stride;
     const void *dout_ptr;
     void *dA_ptr;          /* (dim, dstate) f32, zero-filled by the caller, accumulated with atomics */
-    void *dB_ptr, *dC_ptr; /* (batch, n_groups, dstate, seqlen) F32 always, zero-filled by the caller */
+    void *dB_ptr, *dC_ptr; /* (batch, n_groups, dstate, seqlen) F32 always; fully overwritten (no zero-fill needed): the
+                              per-wave partial sums go through the workspace and are added in a fixed order */
     void *dD_ptr;          /* (dim) f32 zero-filled, or NULL */
     void *du_ptr, *dz_ptr, *ddelta_ptr;
     void *ddelta_bias_ptr; /* (dim) f32 zero-filled, or NULL */
-    void *workspace_ptr;   /* needed iff fwd.ckpt_ptr == NULL: scratch for the tile-boundary states,
-                              >= dimsum_ssm_scan_bwd_workspace_bytes(...) bytes, 16-byte aligned, contents undefined on
-                              entry and exit (the reference keeps the equivalent in shared memory because it re-scans a
-                              whole row per block) */
+    void *workspace_ptr;   /* scratch, 16-byte aligned, contents undefined on entry and exit:
+                              per-wave partial dB / dC (2 * dim/64 * batch * dstate * seqlen f32) and, iff
+                              fwd.ckpt_ptr == NULL, the rebuilt states. dimsum_ssm_scan_bwd_workspace_bytes(...) bytes
+                              always suffice. */
     int64_t workspace_bytes;
 } dimsum_ssm_bwd_params_t;
 
 int dimsum_ssm_scan_fwd(const dimsum_ssm_params_t *p, void *stream);
 int dimsum_ssm_scan_bwd(const dimsum_ssm_bwd_params_t *p, void *stream);
-/* bytes of the tile-boundary state array (= size of ckpt_ptr's tensor = the backward's workspace) */
+/* upper bound of the backward's workspace (partial dB / dC + rebuilt states) */
 int64_t dimsum_ssm_scan_bwd_workspace_bytes(int32_t batch, int32_t dim, int32_t seqlen, int32_t dstate, int32_t n_groups);
 
 /* ---------------------------------------------------------------------------------------------------------------
