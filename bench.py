@@ -165,6 +165,10 @@ def main():
                          "(configs[3]); block: ONE DiMBlockCombined forward+backward (configs[2])")
     ap.add_argument("--nfe", type=int, default=250)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--matmul", choices=["tf32", "fp32"], default="tf32",
+                    help="library-GEMM policy. tf32 = the reference's own setting (torch.backends.cuda.matmul.allow_tf32 = "
+                         "True, dimsum/train.py:20-21, sample_ddp.py:56); on gfx950 hipBLASLt serves it with a split-bf16 "
+                         "MFMA path measured at 4e-6 rms relative error (real TF32: ~5e-4). fp32 = exact fp32 MFMA.")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -177,6 +181,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     torch.set_num_threads(max(1, usable_cores() // max(1, world)))
+
+    def set_matmul(policy):
+        torch.backends.cuda.matmul.allow_tf32 = policy == "tf32"
+        torch.backends.cudnn.allow_tf32 = policy == "tf32"
+    set_matmul(args.matmul)
 
     from dimsum_amd import _lib
     _lib.load()                                   # fail loudly if the HIP library is missing
@@ -252,7 +261,9 @@ def main():
             "config": {"workload": f"{args.model} {what}, "
                                    f"{args.image_size}px (4x{r}x{r} latents, {(r // 2) ** 2} tokens), {args.batch} latents per GPU, "
                                    "random-init weights (reference init, zero tensors re-drawn N(0, 0.02^2))",
-                       "global_batch": args.batch * world, "parallelism": f"dp{world} (replicas, independent latents)"},
+                       "global_batch": args.batch * world, "parallelism": f"dp{world} (replicas, independent latents)",
+                       "matmul_policy": ("allow_tf32=True like the reference (train.py:20-21); gfx950 split-bf16 path, 4e-6 rms rel err"
+                                         if args.matmul == "tf32" else "exact fp32")},
         }
         if fwd_mode:
             line["samples_per_sec_at_250_nfe"] = value / 250.0
@@ -277,6 +288,20 @@ def main():
         rb = roof("bwd", "ssm_scan_bwd_kernel<float,16>", "scan_bwd_pmc.json")
         if rb is not None:
             line["roofline_bwd"] = rb
+        if args.matmul == "tf32" and args.mode != "sample":
+            # the same step with exact-fp32 library GEMMs, for reference (2 untimed + 2 timed steps)
+            set_matmul("fp32")
+            timer.enabled = False
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / 2
+            line["fp32_exact_matmul"] = {"value_per_gpu": units_per_step / dt, "ms_per_step": 1e3 * dt}
+            set_matmul("tf32")
         if world == 1 and not args.no_cpu_baseline and args.mode != "block":
             line["cpu_baseline"] = cpu_baseline(args.model, 8, args.image_size)
         print(json.dumps(line), flush=True)

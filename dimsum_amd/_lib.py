@@ -66,13 +66,13 @@ class TtParams(C.Structure):
                                       "y_batch_stride", "y_token_stride", "mod_batch_stride", "w_batch_stride",
                                       "w_token_stride", "red_batch_stride")]
                 + [(n, vp) for n in ("x_ptr", "in_index_ptr", "out_index_ptr", "gate_ptr", "scale_ptr", "shift_ptr",
-                                     "residual_ptr", "y_ptr", "w_ptr", "wdot_ptr", "wsum_ptr")])
+                                     "residual_ptr", "y_ptr", "w_ptr", "wdot_ptr", "wsum_ptr", "tsum_ptr")])
 
 
 class XattnParams(C.Structure):
     _fields_ = ([(n, i32) for n in ("batch", "seqlen", "heads", "head_dim")] + [("scale", f32)]
                 + [(n, i64) for n in ("qkv_batch_stride", "qkv_token_stride", "out_batch_stride", "out_token_stride")]
-                + [(n, vp) for n in ("qkv1_ptr", "qkv2_ptr", "out_ptr", "lse_ptr")])
+                + [(n, vp) for n in ("qkv1_ptr", "qkv2_ptr", "out_ptr", "lse_ptr", "bias1_ptr", "bias2_ptr")])
 
 
 # every symbol include/dimsum_hip.h declares (tests check the library exports all of them)
@@ -107,7 +107,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = C.c_int
             fn.argtypes = [C.POINTER(ptype), vp]
-    for name, nptr in (("dimsum_gated_gelu_fwd", 2), ("dimsum_gated_gelu_bwd", 3)):
+    for name, nptr in (("dimsum_gated_gelu_fwd", 3), ("dimsum_gated_gelu_bwd", 5)):
         if hasattr(lib, name):
             fn = getattr(lib, name)
             fn.restype = C.c_int
@@ -115,7 +115,7 @@ def load():
     if hasattr(lib, "dimsum_ssm_scan_bwd_workspace_bytes"):
         lib.dimsum_ssm_scan_bwd_workspace_bytes.restype = i64
         lib.dimsum_ssm_scan_bwd_workspace_bytes.argtypes = [i32] * 5
-    if lib.dimsum_abi_version() != 2:
+    if lib.dimsum_abi_version() != 3:
         raise RuntimeError("dimsum_amd: libdimsum_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -33,12 +33,22 @@ class CrossAttentionFusion(nn.Module):
         return qkv.reshape(B, N, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4).unbind(0)
 
     def forward(self, x1, x2):
+        y, b = self.forward_deferred(x1, x2)
+        return y if b is None else y + b
+
+    def forward_deferred(self, x1, x2):
+        """-> (y, b): the module's output is y + b; b (proj's bias) is left to the caller's fused residual pass."""
         B, N, C = x1.shape
-        qkv1, qkv2 = self.qkv1(x1), self.qkv2(x2)
         drop = self.attn_drop.p if self.training else 0.0
-        if self._plain and drop == 0.0 and not torch.is_grad_enabled() and native.xattn_supported(qkv1, self.head_dim):
-            fused = native.xattn_fusion_fwd(qkv1, qkv2, self.num_heads)          # (B, N, 2C) = cat(x12, x21)
+        if self._plain and drop == 0.0 and not torch.is_grad_enabled() and native.xattn_supported(x1, self.head_dim):
+            # bias-free qkv GEMMs (fast hipBLASLt path); the biases are added inside the attention kernel
+            b1, b2 = self.qkv1.bias, self.qkv2.bias
+            fused = native.xattn_fusion_fwd(F.linear(x1, self.qkv1.weight), F.linear(x2, self.qkv2.weight), self.num_heads,
+                                            bias1=None if b1 is None else b1.float(), bias2=None if b2 is None else b2.float())
+            if b1 is None and b2 is not None or b2 is None and b1 is not None:
+                raise RuntimeError("CrossAttentionFusion: qkv1 / qkv2 must both have a bias or none")
         else:
+            qkv1, qkv2 = self.qkv1(x1), self.qkv2(x2)
             q1, k1, v1 = self._split(qkv1, B, N)
             q2, k2, v2 = self._split(qkv2, B, N)
             q1, k1, q2, k2 = self.q_norm1(q1), self.k_norm1(k1), self.q_norm2(q2), self.k_norm2(k2)
@@ -49,4 +59,6 @@ class CrossAttentionFusion(nn.Module):
                 x12 = F.scaled_dot_product_attention(q2, k1, v2, dropout_p=drop)
                 x21 = F.scaled_dot_product_attention(q1, k2, v1, dropout_p=drop)
             fused = torch.cat((x12.transpose(1, 2).reshape(B, N, C), x21.transpose(1, 2).reshape(B, N, C)), dim=-1)
-        return self.proj_drop(self.proj(fused))
+        if isinstance(self.proj_drop, nn.Dropout) and self.proj_drop.p > 0.0 and self.training:
+            return self.proj_drop(self.proj(fused)), None
+        return F.linear(fused, self.proj.weight), self.proj.bias

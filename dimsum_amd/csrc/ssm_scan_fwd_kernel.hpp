@@ -92,7 +92,7 @@ template <typename T> __device__ __forceinline__ T *at(T *base, unsigned elem_of
 
 // kVec : every row base is 4-element aligned and L % 4 == 0 -> 16-byte (fp32) vector I/O, register-staged prefetch.
 // kFull: dim/n_groups % 64 == 0 -> all 64 lanes own a live channel, no row masks anywhere (needs kVec).
-template <typename T, int kN, bool kHasZ, bool kVec, bool kFull>
+template <typename T, int kN, bool kHasZ, bool kVec, bool kFull, bool kCkpt = false>
 __global__ __launch_bounds__(kWave, 2) void ssm_scan_fwd_kernel(const dimsum_ssm_params_t p) {
     static_assert(!kFull || kVec, "kFull implies kVec");
     __shared__ __attribute__((aligned(16))) float tileU[kWave * kLdsStride];
@@ -141,7 +141,8 @@ __global__ __launch_bounds__(kWave, 2) void ssm_scan_fwd_kernel(const dimsum_ssm
     const bool has_out = out_base != nullptr;
     float sum_dt = 0.f;   // prod_t a_t[n] = exp2(A2[n] * sum_t dt_t)
     // optional saved states for the backward: ckpt[b][t/8][n][d] = h_n before step t, t % 8 == 0
-    float *ck_base = (p.ckpt_ptr && (kFull || lane < nd))
+    // (kCkpt is a template parameter: the inference variant carries none of this)
+    float *ck_base = (kCkpt && p.ckpt_ptr && (kFull || lane < nd))
                          ? reinterpret_cast<float *>(p.ckpt_ptr) + (int64_t)b * ((L + 7) / 8) * kN * p.dim + d : nullptr;
 
     const int n_tiles = (L + kTC - 1) / kTC;
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(kWave, 2) void ssm_scan_fwd_kernel(const dimsum_ssm
         for (int j = 0; j < kTC / 4; ++j) {
             const int tj = t0 + j * 4;
             if (tj >= L) break;
-            if (ck_base && (j & 1) == 0) {
+            if (kCkpt && ck_base && (j & 1) == 0) {
                 float *ck = ck_base + (int64_t)(tj >> 3) * kN * p.dim;
 #pragma unroll
                 for (int n = 0; n < kN; ++n) ck[(int64_t)n * p.dim] = h[n];
@@ -338,8 +339,11 @@ static int launch_fwd(const dimsum_ssm_params_t &p, hipStream_t stream) {
         return DIMSUM_ERR_STRIDE;
     const bool full = vec && (dpg % kWave == 0);
     dim3 grid(tiles), block(kWave);
-#define DIMSUM_LAUNCH(HASZ, VEC, FULL) \
-    hipLaunchKernelGGL((ssm_scan_fwd_kernel<T, kN, HASZ, VEC, FULL>), grid, block, 0, stream, p)
+#define DIMSUM_LAUNCH(HASZ, VEC, FULL)                                                                                   \
+    do {                                                                                                                  \
+        if (p.ckpt_ptr) hipLaunchKernelGGL((ssm_scan_fwd_kernel<T, kN, HASZ, VEC, FULL, true>), grid, block, 0, stream, p);  \
+        else hipLaunchKernelGGL((ssm_scan_fwd_kernel<T, kN, HASZ, VEC, FULL, false>), grid, block, 0, stream, p);            \
+    } while (0)
     if (p.z_ptr) {
         if (full) DIMSUM_LAUNCH(true, true, true);
         else if (vec) DIMSUM_LAUNCH(true, true, false);

@@ -121,16 +121,17 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
     const float *shift = p.shift_ptr ? reinterpret_cast<const float *>(p.shift_ptr) + (int64_t)b * p.mod_batch_stride : nullptr;
 
     const float *wb = p.w_ptr ? reinterpret_cast<const float *>(p.w_ptr) + (int64_t)b * p.w_batch_stride : nullptr;
-    float wdot[VEC], wsum[VEC];       // this thread's partial reductions for the channel group it is storing
+    float wdot[VEC], wsum[VEC], tsum[VEC];       // this thread's partial reductions for the channel group it is storing
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) { wdot[e] = 0.f; wsum[e] = 0.f; }
+    for (int e = 0; e < VEC; ++e) { wdot[e] = 0.f; wsum[e] = 0.f; tsum[e] = 0.f; }
     auto flush_red = [&](int c) {     // one atomic per channel per workgroup; resets the partials
-        if (wb) {
+        if (wb || p.tsum_ptr) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 if (p.wdot_ptr) atomicAdd(reinterpret_cast<float *>(p.wdot_ptr) + (int64_t)b * p.red_batch_stride + c + e, wdot[e]);
                 if (p.wsum_ptr) atomicAdd(reinterpret_cast<float *>(p.wsum_ptr) + (int64_t)b * p.red_batch_stride + c + e, wsum[e]);
-                wdot[e] = 0.f; wsum[e] = 0.f;
+                if (p.tsum_ptr) atomicAdd(reinterpret_cast<float *>(p.tsum_ptr) + (int64_t)b * p.red_batch_stride + c + e, tsum[e]);
+                wdot[e] = 0.f; wsum[e] = 0.f; tsum[e] = 0.f;
             }
         }
     };
@@ -148,6 +149,9 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
         if (wb) { load_vec(wb + (int64_t)tok * p.w_token_stride + c, t);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) { wdot[e] = fmaf(o[e], t[e], wdot[e]); wsum[e] += t[e]; } }
+        if (p.tsum_ptr) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) tsum[e] += o[e]; }
         if (!yb) return;
         if (scale) { load_vec(scale + c, t);
 #pragma unroll
@@ -285,25 +289,47 @@ __device__ __forceinline__ float gelu_tanh_grad(float a) {
     return 0.5f * (1.0f + t) + 0.5f * a * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * a * a);
 }
 
-__global__ __launch_bounds__(256) void gated_gelu_fwd_kernel(const float *x12, float *h, int64_t rows, int64_t H) {
-    const int64_t n4 = rows * (H / 4);
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        const int64_t r = i / (H / 4), c = (i - r * (H / 4)) * 4;
-        const float4 a = *reinterpret_cast<const float4 *>(x12 + r * 2 * H + c);
-        const float4 g = *reinterpret_cast<const float4 *>(x12 + r * 2 * H + H + c);
+// One workgroup = a strip of 1024 columns (4 per thread, 16 B) x a chunk of kGGRows rows: bias in registers, fully
+// coalesced rows, and in the backward the column sums of dx12 (= d bias) accumulate in registers: one atomic per column
+// per workgroup.
+constexpr int kGGRows = 64;
+__global__ __launch_bounds__(256) void gated_gelu_fwd_kernel(const float *x12, const float *bias, float *h, int64_t rows, int64_t H) {
+    const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= H) return;
+    float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bg = ba;
+    if (bias) { ba = *reinterpret_cast<const float4 *>(bias + c); bg = *reinterpret_cast<const float4 *>(bias + H + c); }
+    const int64_t r0 = (int64_t)blockIdx.y * kGGRows, r1 = min(rows, r0 + kGGRows);
+    for (int64_t r = r0; r < r1; ++r) {
+        float4 a = *reinterpret_cast<const float4 *>(x12 + r * 2 * H + c);
+        float4 g = *reinterpret_cast<const float4 *>(x12 + r * 2 * H + H + c);
+        a.x += ba.x; a.y += ba.y; a.z += ba.z; a.w += ba.w;
+        g.x += bg.x; g.y += bg.y; g.z += bg.z; g.w += bg.w;
         *reinterpret_cast<float4 *>(h + r * H + c) = make_float4(gelu_tanh(a.x) * g.x, gelu_tanh(a.y) * g.y, gelu_tanh(a.z) * g.z, gelu_tanh(a.w) * g.w);
     }
 }
-__global__ __launch_bounds__(256) void gated_gelu_bwd_kernel(const float *x12, const float *dh, float *dx12, int64_t rows, int64_t H) {
-    const int64_t n4 = rows * (H / 4);
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        const int64_t r = i / (H / 4), c = (i - r * (H / 4)) * 4;
-        const float4 a = *reinterpret_cast<const float4 *>(x12 + r * 2 * H + c);
-        const float4 g = *reinterpret_cast<const float4 *>(x12 + r * 2 * H + H + c);
+__global__ __launch_bounds__(256) void gated_gelu_bwd_kernel(const float *x12, const float *bias, const float *dh, float *dx12, float *dbias,
+                                                             int64_t rows, int64_t H) {
+    const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= H) return;
+    float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bg = ba, sa = ba, sg = ba;
+    if (bias) { ba = *reinterpret_cast<const float4 *>(bias + c); bg = *reinterpret_cast<const float4 *>(bias + H + c); }
+    const int64_t r0 = (int64_t)blockIdx.y * kGGRows, r1 = min(rows, r0 + kGGRows);
+    for (int64_t r = r0; r < r1; ++r) {
+        float4 a = *reinterpret_cast<const float4 *>(x12 + r * 2 * H + c);
+        float4 g = *reinterpret_cast<const float4 *>(x12 + r * 2 * H + H + c);
         const float4 d = *reinterpret_cast<const float4 *>(dh + r * H + c);
-        *reinterpret_cast<float4 *>(dx12 + r * 2 * H + c) = make_float4(d.x * g.x * gelu_tanh_grad(a.x), d.y * g.y * gelu_tanh_grad(a.y),
-                                                                       d.z * g.z * gelu_tanh_grad(a.z), d.w * g.w * gelu_tanh_grad(a.w));
-        *reinterpret_cast<float4 *>(dx12 + r * 2 * H + H + c) = make_float4(d.x * gelu_tanh(a.x), d.y * gelu_tanh(a.y), d.z * gelu_tanh(a.z), d.w * gelu_tanh(a.w));
+        a.x += ba.x; a.y += ba.y; a.z += ba.z; a.w += ba.w;
+        g.x += bg.x; g.y += bg.y; g.z += bg.z; g.w += bg.w;
+        const float4 da = make_float4(d.x * g.x * gelu_tanh_grad(a.x), d.y * g.y * gelu_tanh_grad(a.y), d.z * g.z * gelu_tanh_grad(a.z), d.w * g.w * gelu_tanh_grad(a.w));
+        const float4 dg = make_float4(d.x * gelu_tanh(a.x), d.y * gelu_tanh(a.y), d.z * gelu_tanh(a.z), d.w * gelu_tanh(a.w));
+        *reinterpret_cast<float4 *>(dx12 + r * 2 * H + c) = da;
+        *reinterpret_cast<float4 *>(dx12 + r * 2 * H + H + c) = dg;
+        sa.x += da.x; sa.y += da.y; sa.z += da.z; sa.w += da.w;
+        sg.x += dg.x; sg.y += dg.y; sg.z += dg.z; sg.w += dg.w;
+    }
+    if (dbias) {
+        atomicAdd(dbias + c, sa.x); atomicAdd(dbias + c + 1, sa.y); atomicAdd(dbias + c + 2, sa.z); atomicAdd(dbias + c + 3, sa.w);
+        atomicAdd(dbias + H + c, sg.x); atomicAdd(dbias + H + c + 1, sg.y); atomicAdd(dbias + H + c + 2, sg.z); atomicAdd(dbias + H + c + 3, sg.w);
     }
 }
 
@@ -312,7 +338,7 @@ __global__ __launch_bounds__(256) void gated_gelu_bwd_kernel(const float *x12, c
 extern "C" int dimsum_token_transform(const dimsum_tt_params_t *p, void *stream) {
     using namespace dimsum;
     if (!p || !p->x_ptr) return DIMSUM_ERR_NULL;
-    if (!p->y_ptr && !(p->w_ptr && (p->wdot_ptr || p->wsum_ptr))) return DIMSUM_ERR_NULL;   // nothing to produce
+    if (!p->y_ptr && !p->tsum_ptr && !(p->w_ptr && (p->wdot_ptr || p->wsum_ptr))) return DIMSUM_ERR_NULL;   // nothing to produce
     if ((p->wdot_ptr || p->wsum_ptr) && !p->w_ptr) return DIMSUM_ERR_NULL;
     if (p->batch < 0 || p->tokens <= 0 || p->channels <= 0) return DIMSUM_ERR_SHAPE;
     if (p->kind != DIMSUM_TT_NONE && (p->grid % 4 != 0 || p->grid * p->grid != p->tokens)) return DIMSUM_ERR_SHAPE;
@@ -327,28 +353,29 @@ extern "C" int dimsum_token_transform(const dimsum_tt_params_t *p, void *stream)
     return vec ? launch_tt<4>(*p, s) : launch_tt<1>(*p, s);
 }
 
-extern "C" int dimsum_gated_gelu_fwd(const void *x12, void *h, int64_t rows, int64_t hidden, void *stream) {
+extern "C" int dimsum_gated_gelu_fwd(const void *x12, const void *bias, void *h, int64_t rows, int64_t hidden, void *stream) {
     using namespace dimsum;
     if (!x12 || !h) return DIMSUM_ERR_NULL;
     if (rows < 0 || hidden <= 0 || hidden % 4 != 0) return DIMSUM_ERR_SHAPE;
-    if (!aligned_to<float>(x12, 16) || !aligned_to<float>(h, 16)) return DIMSUM_ERR_STRIDE;
+    if (!aligned_to<float>(x12, 16) || !aligned_to<float>(h, 16) || (bias && !aligned_to<float>(bias, 16))) return DIMSUM_ERR_STRIDE;
     if (rows == 0) return DIMSUM_OK;
-    const int64_t n4 = rows * (hidden / 4);
-    const int grid = (int)((n4 + 255) / 256 < 256 * 16 ? (n4 + 255) / 256 : 256 * 16);
-    hipLaunchKernelGGL(gated_gelu_fwd_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       reinterpret_cast<const float *>(x12), reinterpret_cast<float *>(h), rows, hidden);
+    const dim3 grid((unsigned)((hidden / 4 + 255) / 256), (unsigned)((rows + kGGRows - 1) / kGGRows));
+    hipLaunchKernelGGL(gated_gelu_fwd_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float *>(x12), reinterpret_cast<const float *>(bias), reinterpret_cast<float *>(h), rows, hidden);
     return launch_status();
 }
 
-extern "C" int dimsum_gated_gelu_bwd(const void *x12, const void *dh, void *dx12, int64_t rows, int64_t hidden, void *stream) {
+extern "C" int dimsum_gated_gelu_bwd(const void *x12, const void *bias, const void *dh, void *dx12, void *dbias, int64_t rows,
+                                     int64_t hidden, void *stream) {
     using namespace dimsum;
     if (!x12 || !dh || !dx12) return DIMSUM_ERR_NULL;
     if (rows < 0 || hidden <= 0 || hidden % 4 != 0) return DIMSUM_ERR_SHAPE;
-    if (!aligned_to<float>(x12, 16) || !aligned_to<float>(dh, 16) || !aligned_to<float>(dx12, 16)) return DIMSUM_ERR_STRIDE;
+    if (!aligned_to<float>(x12, 16) || !aligned_to<float>(dh, 16) || !aligned_to<float>(dx12, 16) || (bias && !aligned_to<float>(bias, 16)))
+        return DIMSUM_ERR_STRIDE;
     if (rows == 0) return DIMSUM_OK;
-    const int64_t n4 = rows * (hidden / 4);
-    const int grid = (int)((n4 + 255) / 256 < 256 * 16 ? (n4 + 255) / 256 : 256 * 16);
-    hipLaunchKernelGGL(gated_gelu_bwd_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       reinterpret_cast<const float *>(x12), reinterpret_cast<const float *>(dh), reinterpret_cast<float *>(dx12), rows, hidden);
+    const dim3 grid((unsigned)((hidden / 4 + 255) / 256), (unsigned)((rows + kGGRows - 1) / kGGRows));
+    hipLaunchKernelGGL(gated_gelu_bwd_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float *>(x12), reinterpret_cast<const float *>(bias), reinterpret_cast<const float *>(dh),
+                       reinterpret_cast<float *>(dx12), reinterpret_cast<float *>(dbias), rows, hidden);
     return launch_status();
 }

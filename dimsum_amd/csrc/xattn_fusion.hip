@@ -52,6 +52,11 @@ __global__ __launch_bounds__(256) void xattn_fusion_fwd_kernel(const dimsum_xatt
     const float *kvsrc = reinterpret_cast<const float *>(dir == 0 ? p.qkv2_ptr : p.qkv1_ptr) + (int64_t)b * p.qkv_batch_stride + h * HD;
     const float *ksrc = kvsrc + C, *vsrc = kvsrc + 2 * C;
     const int64_t ts = p.qkv_token_stride;
+    // optional qkv Linear biases (the GEMMs then run without a bias epilogue): same [q | k | v], head-major layout
+    const float *qbv = reinterpret_cast<const float *>(dir == 0 ? p.bias1_ptr : p.bias2_ptr);
+    const float *kvb = reinterpret_cast<const float *>(dir == 0 ? p.bias2_ptr : p.bias1_ptr);
+    const float *qbias = qbv ? qbv + h * HD : nullptr;
+    const float *kbias = kvb ? kvb + C + h * HD : nullptr, *vbias = kvb ? kvb + 2 * C + h * HD : nullptr;
 
     const int qi = lane & 15, kg = lane >> 4;                 // this lane's query (within the wave) and k-index group
     const int q_tok = qb * 64 + wave * kQW + qi;
@@ -61,11 +66,13 @@ __global__ __launch_bounds__(256) void xattn_fusion_fwd_kernel(const dimsum_xatt
     f4 qf[EC + (kTail8 ? 1 : 0)];
 #pragma unroll
     for (int c = 0; c < EC; ++c) {
-        const float4 t = *reinterpret_cast<const float4 *>(qsrc + (int64_t)q_ld * ts + 16 * c + 4 * kg);
+        float4 t = *reinterpret_cast<const float4 *>(qsrc + (int64_t)q_ld * ts + 16 * c + 4 * kg);
+        if (qbias) { const float4 bq = *reinterpret_cast<const float4 *>(qbias + 16 * c + 4 * kg); t.x += bq.x; t.y += bq.y; t.z += bq.z; t.w += bq.w; }
         qf[c] = f4{t.x * qscale, t.y * qscale, t.z * qscale, t.w * qscale};
     }
     if constexpr (kTail8) {                                   // 8-wide tail: k-groups 0,1 -> e = 16*EC + 4*(kg&1) ..; groups 2,3 idle
-        const float4 t = *reinterpret_cast<const float4 *>(qsrc + (int64_t)q_ld * ts + 16 * EC + 4 * (kg & 1));
+        float4 t = *reinterpret_cast<const float4 *>(qsrc + (int64_t)q_ld * ts + 16 * EC + 4 * (kg & 1));
+        if (qbias) { const float4 bq = *reinterpret_cast<const float4 *>(qbias + 16 * EC + 4 * (kg & 1)); t.x += bq.x; t.y += bq.y; t.z += bq.z; t.w += bq.w; }
         const float m = (kg < 2) ? qscale : 0.f;
         qf[EC] = f4{t.x * m, t.y * m, t.z * m, t.w * m};
     }
@@ -81,8 +88,13 @@ __global__ __launch_bounds__(256) void xattn_fusion_fwd_kernel(const dimsum_xatt
         for (int i = tid; i < kKT * (HD / 4); i += 256) {
             const int key = i / (HD / 4), e4 = i - key * (HD / 4);
             const int tok = min(k0 + key, L - 1);
-            const float4 kv = *reinterpret_cast<const float4 *>(ksrc + (int64_t)tok * ts + e4 * 4);
-            const float4 vv = *reinterpret_cast<const float4 *>(vsrc + (int64_t)tok * ts + e4 * 4);
+            float4 kv = *reinterpret_cast<const float4 *>(ksrc + (int64_t)tok * ts + e4 * 4);
+            float4 vv = *reinterpret_cast<const float4 *>(vsrc + (int64_t)tok * ts + e4 * 4);
+            if (kbias) {
+                const float4 bk = *reinterpret_cast<const float4 *>(kbias + e4 * 4), bv = *reinterpret_cast<const float4 *>(vbias + e4 * 4);
+                kv.x += bk.x; kv.y += bk.y; kv.z += bk.z; kv.w += bk.w;
+                vv.x += bv.x; vv.y += bv.y; vv.z += bv.z; vv.w += bv.w;
+            }
             *reinterpret_cast<float4 *>(&Ks[key * KS + e4 * 4]) = kv;
             Vt[(e4 * 4 + 0) * VS + key] = vv.x; Vt[(e4 * 4 + 1) * VS + key] = vv.y;
             Vt[(e4 * 4 + 2) * VS + key] = vv.z; Vt[(e4 * 4 + 3) * VS + key] = vv.w;
@@ -174,6 +186,8 @@ extern "C" int dimsum_xattn_fusion_fwd(const dimsum_xattn_params_t *p, void *str
     using namespace dimsum;
     if (!p || !p->qkv1_ptr || !p->qkv2_ptr || !p->out_ptr) return DIMSUM_ERR_NULL;
     if (p->batch < 0 || p->seqlen <= 0 || p->heads <= 0) return DIMSUM_ERR_SHAPE;
+    if ((p->bias1_ptr == nullptr) != (p->bias2_ptr == nullptr)) return DIMSUM_ERR_NULL;
+    if (p->bias1_ptr && (!aligned_to<float>(p->bias1_ptr, 16) || !aligned_to<float>(p->bias2_ptr, 16))) return DIMSUM_ERR_STRIDE;
     if (!aligned_to<float>(p->qkv1_ptr, 16) || !aligned_to<float>(p->qkv2_ptr, 16) || !aligned_to<float>(p->out_ptr, 16) ||
         p->qkv_batch_stride % 4 != 0 || p->qkv_token_stride % 4 != 0 || p->out_batch_stride % 4 != 0 || p->out_token_stride % 4 != 0)
         return DIMSUM_ERR_STRIDE;

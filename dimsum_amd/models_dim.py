@@ -140,11 +140,19 @@ class Attention(nn.Module):
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
         self.proj = nn.Linear(dim, dim)
 
-    def forward(self, x):
+    def forward_deferred(self, x):
+        """-> (y, b): the module's output is y + b (proj's bias is left to the caller's fused residual pass)."""
         B, N, C = x.shape
-        q, k, v = self.qkv(x).reshape(B, N, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4).unbind(0)
+        qkv = torch.nn.functional.linear(x, self.qkv.weight)          # bias-free GEMM (fast hipBLASLt path) ...
+        if self.qkv.bias is not None:
+            qkv = qkv.add_(self.qkv.bias) if not torch.is_grad_enabled() else qkv + self.qkv.bias      # ... + one add pass
+        q, k, v = qkv.reshape(B, N, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4).unbind(0)
         x = torch.nn.functional.scaled_dot_product_attention(q, k, v)
-        return self.proj(x.transpose(1, 2).reshape(B, N, C))
+        return torch.nn.functional.linear(x.transpose(1, 2).reshape(B, N, C), self.proj.weight), self.proj.bias
+
+    def forward(self, x):
+        y, b = self.forward_deferred(x)
+        return y if b is None else y + b
 
 
 class Mlp(nn.Module):
@@ -183,6 +191,15 @@ _approx_gelu = lambda: nn.GELU(approximate="tanh")  # noqa: E731
 def _make_mlp(dim, use_gated_mlp=True):
     cls = GatedMLP if use_gated_mlp else Mlp
     return cls(in_features=dim, hidden_features=int(dim * 4), act_layer=_approx_gelu, drop=0)
+
+
+def _mlp_tail(mlp, x, normed, shift, scale, gate):
+    """x + gate * mlp(modulate(normed, shift, scale))  (models_dim.py:1111-1115, 1551-1553)"""
+    h = token_ops.pre_mixer(normed, "none", None, shift, scale)               # modulate, one pass
+    if hasattr(mlp, "forward_deferred"):
+        m, mb = mlp.forward_deferred(h)
+        return token_ops.gate_residual(x, m, gate, mb)
+    return token_ops.gate_residual(x, mlp(h), gate, None)
 
 
 # ---- shared block plumbing ----------------------------------------------------------------------------------------------
@@ -341,10 +358,11 @@ class _CombinedBase(_BlockBase):
         x1, x2 = hidden_states.chunk(2, dim=2)
         x1, _ = self.spatial_mamba(x1, None, c, inference_params)
         x2, _ = self.freq_mamba(x2, None, c, inference_params)
-        hidden_states = hidden_states + self.proj(x1, x2)
+        # residual tails as single fused passes; the Linear biases ride along (mlp.py / attention_fusion.py docstrings)
+        fused, pb = self.proj.forward_deferred(x1, x2)
+        hidden_states = token_ops.gate_residual(hidden_states, fused, None, pb)
         shift, scale, gate = self.adaLN_modulation(c).chunk(3, dim=1)
-        hidden_states = hidden_states + gate.unsqueeze(1) * self.mlp(modulate(self.norm_2(hidden_states), shift, scale))
-        return hidden_states, residual
+        return _mlp_tail(self.mlp, hidden_states, self.norm_2(hidden_states), shift, scale, gate), residual
 
 
 class DiMBlockCombined(_CombinedBase):
@@ -393,8 +411,9 @@ class DiTBlock(nn.Module):
 
     def forward(self, x, c=None, **kwargs):
         sa, ca, ga, sm, cm, gm = self.adaLN_modulation(c).chunk(6, dim=1)
-        x = x + ga.unsqueeze(1) * self.attn(modulate(self.norm1(x), sa, ca))
-        return x + gm.unsqueeze(1) * self.mlp(modulate(self.norm2(x), sm, cm))
+        a, ab = self.attn.forward_deferred(token_ops.pre_mixer(self.norm1(x), "none", None, sa, ca))
+        x = token_ops.gate_residual(x, a, ga, ab)
+        return _mlp_tail(self.mlp, x, self.norm2(x), sm, cm, gm)
 
 
 def _init_weights(module, n_layer, initializer_range=0.02, rescale_prenorm_residual=True, n_residuals_per_layer=1):

@@ -321,19 +321,20 @@ _TT_KIND = {("none", True): 0, ("none", False): 0, ("haar", True): 1, ("haar", F
 
 
 def token_transform(x, kind, forward, in_index=None, out_index=None, gate=None, scale=None, shift=None, residual=None,
-                    w=None, want_y=True, want_wsum=False):
+                    w=None, want_y=True, want_wsum=False, want_tsum=False):
     """y[b, out_index[s], c] = T(x[b, in_index[s], c] * gate[b, c])[s] * (1 + scale[b, c]) + shift[b, c] + residual[b, out_index[s], c]
     x: (B, L, C) fp32 with unit channel stride (may be a channel slice of a wider tensor); index tables int32 (L,).
     With a weight tensor `w` (indexed like y) the same pass also reduces, per (batch, channel),
         wdot = sum_s T(.)[s, c] * w[b, out_index[s], c]     and (want_wsum)  wsum = sum_s w[b, out_index[s], c]
-    and returns (y or None, wdot, wsum or None) -- the adaLN-modulation gradients of the block backward."""
+    and returns (y or None, wdot, wsum or None) -- the adaLN-modulation gradients of the block backward.
+    `want_tsum` appends tsum = sum_s T(.)[s, c] (the plain token sum) to the returned tuple."""
     _gpu(x, in_index, out_index, gate, scale, shift, residual, w)
     _check(x.dim() == 3 and x.dtype == torch.float32 and x.stride(2) == 1, "token_transform: x must be (B, L, C) float32, channel-contiguous")
     B, L, C = x.shape
     grid = int(round(L ** 0.5))
     if kind != "none":
         _check(grid * grid == L and grid % 4 == 0, "token_transform: the token grid must be square with side % 4 == 0")
-    _check(want_y or w is not None, "token_transform: nothing to compute")
+    _check(want_y or w is not None or want_tsum, "token_transform: nothing to compute")
     y = torch.empty((B, L, C), device=x.device, dtype=torch.float32) if want_y else None
     mods = [m for m in (gate, scale, shift) if m is not None]
     mstride = 0
@@ -346,11 +347,13 @@ def token_transform(x, kind, forward, in_index=None, out_index=None, gate=None, 
             _check(t.dtype == torch.int32 and t.numel() == L and t.is_contiguous(), "token_transform: index tables must be int32 (L,)")
     if residual is not None:
         _check(residual.shape == x.shape and residual.dtype == torch.float32 and residual.stride(2) == 1, "token_transform: bad residual")
-    wdot = wsum = None
+    wdot = wsum = tsum = None
     if w is not None:
         _check(w.shape == x.shape and w.dtype == torch.float32 and w.stride(2) == 1, "token_transform: bad w")
-        red = torch.zeros((2 if want_wsum else 1, B, C), device=x.device, dtype=torch.float32)
-        wdot, wsum = red[0], (red[1] if want_wsum else None)
+    if w is not None or want_tsum:
+        red = torch.zeros((3, B, C), device=x.device, dtype=torch.float32)
+        wdot, wsum = (red[0] if w is not None else None), (red[1] if (w is not None and want_wsum) else None)
+        tsum = red[2] if want_tsum else None
     if B > 0:
         P = _lib.TtParams()
         P.batch, P.tokens, P.channels, P.grid, P.kind = B, L, C, grid, _TT_KIND[(kind, bool(forward))]
@@ -359,38 +362,46 @@ def token_transform(x, kind, forward, in_index=None, out_index=None, gate=None, 
             P.y_batch_stride, P.y_token_stride = y.stride(0), y.stride(1)
         if residual is not None:
             P.res_batch_stride, P.res_token_stride = residual.stride(0), residual.stride(1)
+        P.red_batch_stride = C
         if w is not None:
-            P.w_batch_stride, P.w_token_stride, P.red_batch_stride = w.stride(0), w.stride(1), C
+            P.w_batch_stride, P.w_token_stride = w.stride(0), w.stride(1)
         P.mod_batch_stride = mstride
         P.x_ptr, P.in_index_ptr, P.out_index_ptr = _ptr(x), _ptr(in_index), _ptr(out_index)
         P.gate_ptr, P.scale_ptr, P.shift_ptr, P.residual_ptr, P.y_ptr = _ptr(gate), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(y)
-        P.w_ptr, P.wdot_ptr, P.wsum_ptr = _ptr(w), _ptr(wdot), _ptr(wsum)
+        P.w_ptr, P.wdot_ptr, P.wsum_ptr, P.tsum_ptr = _ptr(w), _ptr(wdot), _ptr(wsum), _ptr(tsum)
         with torch.cuda.device(x.device):
             _lib.check(_lib.load().dimsum_token_transform(P, _stream(x)), "token_transform")
+    if want_tsum:
+        return (y, wdot, wsum, tsum)
     return y if w is None else (y, wdot, wsum)
 
 
-def gated_gelu_fwd(x12):
-    """x12: (..., 2H) fp32 contiguous -> gelu_tanh(x12[..., :H]) * x12[..., H:]   (mlp.py:66-70)"""
-    _gpu(x12)
+def gated_gelu_fwd(x12, bias=None):
+    """x12: (..., 2H) fp32 contiguous (w12 GEMM output WITHOUT bias), bias (2H) or None
+    -> gelu_tanh(x12[..., :H] + bias[:H]) * (x12[..., H:] + bias[H:])   (mlp.py:66-70)"""
+    _gpu(x12, bias)
     _check(x12.dtype == torch.float32 and x12.is_contiguous() and x12.shape[-1] % 8 == 0, "gated_gelu: x12 must be contiguous float32 with 2H % 8 == 0")
     H = x12.shape[-1] // 2
+    if bias is not None:
+        _check(bias.dtype == torch.float32 and tuple(bias.shape) == (2 * H,) and bias.is_contiguous(), "gated_gelu: bias must be (2H,) float32")
     h = torch.empty(x12.shape[:-1] + (H,), device=x12.device, dtype=torch.float32)
     rows = x12.numel() // (2 * H)
     with torch.cuda.device(x12.device):
-        _lib.check(_lib.load().dimsum_gated_gelu_fwd(_ptr(x12), _ptr(h), rows, H, _stream(x12)), "gated_gelu_fwd")
+        _lib.check(_lib.load().dimsum_gated_gelu_fwd(_ptr(x12), _ptr(bias), _ptr(h), rows, H, _stream(x12)), "gated_gelu_fwd")
     return h
 
 
-def gated_gelu_bwd(x12, dh):
-    _gpu(x12, dh)
+def gated_gelu_bwd(x12, bias, dh, need_dbias=True):
+    """-> (dx12, dbias or None)"""
+    _gpu(x12, bias, dh)
     dh = dh.contiguous()
     H = x12.shape[-1] // 2
     dx12 = torch.empty_like(x12)
+    dbias = torch.zeros(2 * H, device=x12.device, dtype=torch.float32) if (bias is not None and need_dbias) else None
     rows = x12.numel() // (2 * H)
     with torch.cuda.device(x12.device):
-        _lib.check(_lib.load().dimsum_gated_gelu_bwd(_ptr(x12), _ptr(dh), _ptr(dx12), rows, H, _stream(x12)), "gated_gelu_bwd")
-    return dx12
+        _lib.check(_lib.load().dimsum_gated_gelu_bwd(_ptr(x12), _ptr(bias), _ptr(dh), _ptr(dx12), _ptr(dbias), rows, H, _stream(x12)), "gated_gelu_bwd")
+    return dx12, dbias
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -401,9 +412,14 @@ def xattn_supported(qkv, head_dim):
     return qkv.is_cuda and qkv.dtype == torch.float32 and qkv.stride(-1) == 1 and head_dim in (24, 32, 48, 64, 72)
 
 
-def xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=False):
-    """qkv*: (B, L, 3*heads*hd) -> (B, L, 2*heads*hd) = cat(softmax(q1 k2^T/sqrt(hd)) v2, softmax(q2 k1^T/sqrt(hd)) v1)."""
-    _gpu(qkv1, qkv2)
+def xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=False, bias1=None, bias2=None):
+    """qkv*: (B, L, 3*heads*hd) -> (B, L, 2*heads*hd) = cat(softmax(q1 k2^T/sqrt(hd)) v2, softmax(q2 k1^T/sqrt(hd)) v1).
+    bias1/bias2 (3*heads*hd): the qkv Linear biases when qkv* are bias-free GEMM outputs (added inside the kernel)."""
+    _gpu(qkv1, qkv2, bias1, bias2)
+    _check((bias1 is None) == (bias2 is None), "xattn_fusion: pass both biases or none")
+    if bias1 is not None:
+        for bb in (bias1, bias2):
+            _check(bb.dtype == torch.float32 and bb.numel() == qkv1.shape[2] and bb.is_contiguous(), "xattn_fusion: bad bias")
     B, L, W = qkv1.shape
     hd = W // (3 * heads)
     _check(qkv1.shape == qkv2.shape and qkv1.dtype == torch.float32 and qkv2.dtype == torch.float32, "xattn_fusion: bad qkv")
@@ -416,6 +432,7 @@ def xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=False):
         P.qkv_batch_stride, P.qkv_token_stride = qkv1.stride(0), qkv1.stride(1)
         P.out_batch_stride, P.out_token_stride = out.stride(0), out.stride(1)
         P.qkv1_ptr, P.qkv2_ptr, P.out_ptr, P.lse_ptr = _ptr(qkv1), _ptr(qkv2), _ptr(out), _ptr(lse)
+        P.bias1_ptr, P.bias2_ptr = _ptr(bias1), _ptr(bias2)
         with torch.cuda.device(qkv1.device):
             _lib.check(_lib.load().dimsum_xattn_fusion_fwd(P, _stream(qkv1)), "xattn_fusion_fwd")
     return (out, lse) if need_lse else out

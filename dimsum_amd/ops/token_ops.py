@@ -171,6 +171,52 @@ class _PostMixer(torch.autograd.Function):
         return dy, dm, dot * k, None, None
 
 
+class _GateResidual(torch.autograd.Function):
+    """y = res + gate * (m + bias): the tail of every residual branch (gate (B, C) or None, bias (C,) or None), one pass."""
+
+    @staticmethod
+    def forward(ctx, res, m, gate, bias):
+        from .. import native
+        res, m = _cc(res), _cc(m)
+        B, _, C = m.shape
+        shift, g = None, gate
+        if bias is not None and gate is None:
+            shift = bias.float().expand(B, C)
+        elif bias is not None:
+            gs = torch.cat((gate, gate * bias.float()), dim=1)        # (B, 2C): gate | gate * bias share one row stride
+            g, shift = gs[:, :C], gs[:, C:]
+        ctx.save_for_backward(m, gate, bias)
+        return native.token_transform(m, "none", False, gate=g, shift=shift, residual=res)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import native
+        m, gate, bias = ctx.saved_tensors
+        dy = _cc(dy)
+        need_m, need_gate, need_bias = ctx.needs_input_grad[1], gate is not None and ctx.needs_input_grad[2], bias is not None and ctx.needs_input_grad[3]
+        dm = dgate = dbias = None
+        if gate is None:
+            dm = dy if need_m else None
+            if need_bias:
+                dbias = native.token_transform(dy, "none", True, want_y=False, want_tsum=True)[3].sum(0)
+        else:
+            # dm = gate * dy;  d gate = sum_t dy (m + bias);  d bias = sum_b gate sum_t dy -- one pass over (dy, m)
+            dm, dot, _, tsum = native.token_transform(dy, "none", True, scale=gate - 1.0, w=m, want_y=need_m, want_tsum=True)
+            if need_gate:
+                dgate = dot if bias is None else dot + tsum * bias.float()
+            if need_bias:
+                dbias = (gate * tsum).sum(0)
+        if dbias is not None:
+            dbias = dbias.to(bias.dtype)
+        return dy, dm, dgate, dbias
+
+
+def gate_residual(res, m, gate=None, bias=None):
+    """y = res + gate * (m + bias)."""
+    _require_gpu(res)
+    return _GateResidual.apply(res, m, gate, bias)
+
+
 def pre_mixer(x, kind, table, shift, scale):
     """y = modulate(P(T(x)))."""
     _require_gpu(x)

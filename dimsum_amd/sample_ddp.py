@@ -63,7 +63,11 @@ def main(argv=None):
     ap.add_argument("--global-seed", type=int, default=0)
     ap.add_argument("--ckpt", default=None)
     ap.add_argument("--out", default=None, help="rank 0 writes the gathered latents here (.pt)")
+    ap.add_argument("--tf32", action=argparse.BooleanOptionalAction, default=True,
+                    help="library-GEMM policy of the reference (sample_ddp.py:56,267-272); exact fp32 with --no-tf32")
     args, _ = ap.parse_known_args(argv)          # unknown flags are ignored like sample_ddp.py:369
+    torch.backends.cuda.matmul.allow_tf32 = args.tf32
+    torch.backends.cudnn.allow_tf32 = args.tf32
 
     dist.init_process_group("nccl")
     rank, world = dist.get_rank(), dist.get_world_size()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DIMSUM_ABI_VERSION 2
+#define DIMSUM_ABI_VERSION 3
 
 typedef enum {
     DIMSUM_OK = 0,
@@ -190,6 +190,7 @@ int dimsum_norm_bwd(const dimsum_norm_bwd_params_t *p, void *stream);
  *   - for the backward passes (the adjoint of an orthogonal T is its inverse up to a constant, so the adjoints of
  *     both block-side fusions are again this kernel), two per-(batch, channel) reductions against a weight tensor w
  *     indexed like y:   wdot[b, c] += sum_s T(v)[s, c] * w[b, out_index[s], c]      wsum[b, c] += sum_s w[b, out_index[s], c]
+ *     and the plain token sum   tsum[b, c] += sum_s T(v)[s, c]
  *     (f32 atomics into caller-zeroed (batch, channels) arrays: d scale / d gate and d shift of the adaLN modulation).
  *     With y_ptr == NULL only the reductions are produced.
  * Every optional pointer may be NULL (identity / 0). Streaming op: 2*B*L*C*4 bytes (+ residual / + w).
@@ -214,6 +215,7 @@ typedef struct {
     void *y_ptr;                                      /* may be NULL when only the reductions are wanted */
     const void *w_ptr;                                /* (batch, tokens, channels) f32 or NULL */
     void *wdot_ptr, *wsum_ptr;                        /* (batch, channels) f32 accumulators (atomicAdd) or NULL */
+    void *tsum_ptr;                                   /* (batch, channels) f32: tsum[b, c] += sum_s T(v)[s, c], or NULL */
 } dimsum_tt_params_t;
 
 int dimsum_token_transform(const dimsum_tt_params_t *p, void *stream);
@@ -232,15 +234,20 @@ typedef struct {
     int64_t out_batch_stride, out_token_stride;
     const void *qkv1_ptr, *qkv2_ptr;
     void *out_ptr, *lse_ptr;
+    const void *bias1_ptr, *bias2_ptr;   /* optional (3*heads*hd) f32: the qkv Linear biases, added while q / k / v are
+                                            fetched, so that the qkv GEMMs can run without a bias epilogue */
 } dimsum_xattn_params_t;
 
 int dimsum_xattn_fusion_fwd(const dimsum_xattn_params_t *p, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
- * GatedMLP epilogue (mlp.py:66-70, GELU tanh):  h[m, j] = gelu_tanh(x12[m, j]) * x12[m, H + j],  x12 : (M, 2H) f32
+ * GatedMLP epilogue (mlp.py:66-70, GELU tanh), x12 : (M, 2H) f32 = output of the w12 GEMM WITHOUT its bias:
+ *   h[m, j] = gelu_tanh(x12[m, j] + bias[j]) * (x12[m, H + j] + bias[H + j])          bias (2H) f32 or NULL
+ * bwd: dx12 (M, 2H); dbias (2H) f32 zero-filled by the caller (column sums of dx12, f32 atomics) or NULL.
  * ------------------------------------------------------------------------------------------------------------- */
-int dimsum_gated_gelu_fwd(const void *x12, void *h, int64_t rows, int64_t hidden, void *stream);
-int dimsum_gated_gelu_bwd(const void *x12, const void *dh, void *dx12, int64_t rows, int64_t hidden, void *stream);
+int dimsum_gated_gelu_fwd(const void *x12, const void *bias, void *h, int64_t rows, int64_t hidden, void *stream);
+int dimsum_gated_gelu_bwd(const void *x12, const void *bias, const void *dh, void *dx12, void *dbias, int64_t rows,
+                          int64_t hidden, void *stream);
 
 #ifdef __cplusplus
 }

@@ -86,20 +86,22 @@ def layer_norm_bwd(dy, x, weight, bias, eps, mean, rstd, dresidual=None, has_res
     return dx, _like(dw, weight), _like(db, bias) if bias is not None else None, (torch.from_numpy(dr).to(x.dtype) if has_residual else None)
 
 
-def gated_gelu_fwd(x12):
-    return torch.from_numpy(np_ops.gated_gelu(_np(x12)))
+def gated_gelu_fwd(x12, bias=None):
+    x = _np(x12) if bias is None else _np(x12) + _np(bias)
+    return torch.from_numpy(np_ops.gated_gelu(np.ascontiguousarray(x, dtype=np.float32)))
 
 
-def gated_gelu_bwd(x12, dh):
-    xr = x12.detach().clone().requires_grad_()
+def gated_gelu_bwd(x12, bias, dh, need_dbias=True):
+    xr = (x12.detach() if bias is None else x12.detach() + bias.detach()).clone().requires_grad_()
     H = xr.shape[-1] // 2
     with torch.enable_grad():
         (torch.nn.functional.gelu(xr[..., :H], approximate="tanh") * xr[..., H:]).backward(dh)
-    return xr.grad
+    dbias = xr.grad.reshape(-1, 2 * H).sum(0) if (bias is not None and need_dbias) else None
+    return xr.grad, dbias
 
 
 def token_transform(x, kind, forward, in_index=None, out_index=None, gate=None, scale=None, shift=None, residual=None,
-                    w=None, want_y=True, want_wsum=False):
+                    w=None, want_y=True, want_wsum=False, want_tsum=False):
     v = _np(x)
     if gate is not None:
         v = v * _np(gate)[:, None]
@@ -109,6 +111,7 @@ def token_transform(x, kind, forward, in_index=None, out_index=None, gate=None, 
          ("dct", False): np_ops.idct_tokens}.get((kind, bool(forward)), lambda a: a)
     t = T(np.ascontiguousarray(v))
     wdot = wsum = None
+    tsum = torch.from_numpy(t.astype(np.float64).sum(1).astype(np.float32)) if want_tsum else None
     if w is not None:       # reductions against w indexed like y: w[b, out_index[s], c] pairs with t[b, s, c]
         wn = _np(w).astype(np.float64)
         ws = wn if out_index is None else wn[:, out_index.cpu().numpy()]
@@ -126,6 +129,8 @@ def token_transform(x, kind, forward, in_index=None, out_index=None, gate=None, 
     if residual is not None:
         y = y + _np(residual)
     y = torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32)) if want_y else None
+    if want_tsum:
+        return (y, wdot, wsum, tsum)
     return y if w is None else (y, wdot, wsum)
 
 

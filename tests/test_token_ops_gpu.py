@@ -76,17 +76,55 @@ def test_pure_permutation_is_bit_exact():
                 assert torch.equal(back, x)
 
 
-def test_gated_gelu():
+@pytest.mark.parametrize("rows,H,with_bias", [(37, 96, False), (37, 96, True), (300, 4096, True), (65, 1032, True)])
+def test_gated_gelu(rows, H, with_bias):
+    """fused bias + tanh-GELU + gate epilogue of the w12 GEMM, forward and backward (dx12 and the in-kernel d bias column
+    sums) vs torch autograd. fp32: rtol 1e-5 + 1e-6 max (fwd), 1e-4 + 1e-5 max (bwd), d bias 2e-4 + 2e-5 max."""
     from dimsum_amd import native
-    from oracle import np_ops
-    x = (torch.randn(37, 2 * 96, generator=torch.Generator().manual_seed(0)) * 2).cuda()
-    h = native.gated_gelu_fwd(x)
-    assert_close(h.cpu().numpy(), np_ops.gated_gelu(x.cpu().numpy()), 1e-5, 0, "fwd", scale_atol=1e-6)
-    xr = x.detach().clone().requires_grad_()
-    ref = torch.nn.functional.gelu(xr[:, :96], approximate="tanh") * xr[:, 96:]
-    dh = torch.randn(ref.shape, generator=torch.Generator().manual_seed(1)).cuda()
+    g = torch.Generator().manual_seed(rows + H)
+    x = (torch.randn(rows, 2 * H, generator=g) * 2).cuda()
+    bias = torch.randn(2 * H, generator=g).cuda() if with_bias else None
+    xr, br = x.detach().clone().requires_grad_(), (bias.detach().clone().requires_grad_() if with_bias else None)
+    xb = xr + br if with_bias else xr
+    ref = torch.nn.functional.gelu(xb[:, :H], approximate="tanh") * xb[:, H:]
+    h = native.gated_gelu_fwd(x, bias)
+    assert_close(h.cpu().numpy(), ref.detach().cpu().numpy(), 1e-5, 0, "fwd", scale_atol=1e-6)
+    dh = torch.randn(ref.shape, generator=g).cuda()
     ref.backward(dh)
-    assert_close(native.gated_gelu_bwd(x, dh).cpu().numpy(), xr.grad.cpu().numpy(), 1e-4, 0, "bwd", scale_atol=1e-5)
+    dx, db = native.gated_gelu_bwd(x, bias, dh)
+    assert_close(dx.cpu().numpy(), xr.grad.cpu().numpy(), 1e-4, 0, "bwd", scale_atol=1e-5)
+    if with_bias:
+        assert_close(db.cpu().numpy(), br.grad.cpu().numpy(), 2e-4, 0, "dbias", scale_atol=2e-5)
+    else:
+        assert db is None
+
+
+@pytest.mark.parametrize("with_gate,with_bias", [(True, True), (True, False), (False, True), (False, False)])
+def test_gate_residual_autograd(with_gate, with_bias):
+    """y = res + gate * (m + bias) as one fused pass, forward and backward, vs the torch expression."""
+    from dimsum_amd.ops import token_ops as to
+    B, L, C = 3, 64, 512
+    torch.manual_seed(5)
+    dy = torch.randn(B, L, C, device="cuda")
+    outs = []
+    for fused in (True, False):
+        torch.manual_seed(6)
+        res = torch.randn(B, L, C, device="cuda", requires_grad=True)
+        m = torch.randn(B, L, C, device="cuda", requires_grad=True)
+        mods = torch.randn(B, 3 * C, device="cuda", requires_grad=True)
+        bias = torch.randn(C, device="cuda", requires_grad=True)
+        gate = mods.chunk(3, dim=1)[2] if with_gate else None
+        bb = bias if with_bias else None
+        if fused:
+            y = to.gate_residual(res, m, gate, bb)
+        else:
+            t = m if bb is None else m + bb
+            y = res + (t if gate is None else gate.unsqueeze(1) * t)
+        y.backward(dy)
+        outs.append((y.detach(), res.grad, m.grad, mods.grad if with_gate else torch.zeros(1), bias.grad if with_bias else torch.zeros(1)))
+    for name, a, b, (rt, sa) in zip(("y", "dres", "dm", "dmods", "dbias"), outs[0], outs[1],
+                                    ((2e-6, 2e-6), (0, 0), (2e-6, 2e-6), (1e-4, 1e-5), (1e-4, 1e-5))):
+        assert_close(a.cpu().numpy(), b.cpu().numpy(), rt, 0, name, scale_atol=sa)
 
 
 @pytest.mark.parametrize("C,H,kind", [(512, 16, "haar"), (576, 32, "haar"), (64, 16, "dct"), (512, 16, "none"), (20, 8, "haar")])

@@ -46,3 +46,17 @@ def test_module_vs_golden(name, dim):
     assert_close(y2.detach().cpu().numpy(), g["y"], 1e-4, 0, "y (autograd path)", scale_atol=1e-5)
     assert_close(x1r.grad.cpu().numpy(), g["dx1"], 5e-4, 0, "dx1", scale_atol=5e-5)
     assert_close(x2r.grad.cpu().numpy(), g["dx2"], 5e-4, 0, "dx2", scale_atol=5e-5)
+
+
+@pytest.mark.parametrize("L,heads,hd", [(256, 8, 64), (100, 4, 24), (64, 8, 72)])
+def test_in_kernel_qkv_bias(L, heads, hd):
+    """the qkv Linear biases added inside the kernel == attention on (qkv + bias): the adds are the same fp32 operations,
+    so the two results must agree to the last bit."""
+    from dimsum_amd import native
+    gen = torch.Generator().manual_seed(L * hd)
+    W = 3 * heads * hd
+    qkv1, qkv2 = torch.randn(2, L, W, generator=gen).cuda(), torch.randn(2, L, W, generator=gen).cuda()
+    b1, b2 = torch.randn(W, generator=gen).cuda(), torch.randn(W, generator=gen).cuda()
+    a = native.xattn_fusion_fwd(qkv1, qkv2, heads, bias1=b1, bias2=b2)
+    b = native.xattn_fusion_fwd(qkv1 + b1, qkv2 + b2, heads)
+    assert torch.equal(a, b)

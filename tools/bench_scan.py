@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--N", type=int, default=16)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dtype", default="float32")
+    ap.add_argument("--dmajor", action="store_true", help="u and z d-major too, exactly like inside MambaInnerFn (xz = in_proj GEMM view)")
     ap.add_argument("--bwd", action="store_true", help="time selective_scan_bwd (with the saved states of the forward)")
     ap.add_argument("--no-ckpt", action="store_true", help="--bwd without saved states: the kernel pair of the reference-shaped call")
     a = ap.parse_args()
@@ -38,6 +39,10 @@ def main():
     Bm, Cm = torch.randn(B, 1, N, L, device=dev, dtype=dt), torch.randn(B, 1, N, L, device=dev, dtype=dt)
     Dv, bias = torch.randn(D, device=dev), 0.5 * torch.rand(D, device=dev)
     z = xz.chunk(2, 1)[1]
+    if a.dmajor:
+        xz = torch.randn(2 * D, B, L, device=dev, dtype=dt).permute(1, 0, 2)        # strides (L, B L, 1)
+        z = xz.chunk(2, 1)[1]
+        u = torch.empty_like(xz.chunk(2, 1)[0]).copy_(u)                             # conv_out = empty_like(x): d-major
     if a.bwd:
         out, x, out_z, ckpt = native.selective_scan_fwd(u, delta, A, Bm, Cm, Dv, z, bias, True, need_ckpt=True)
         dout = torch.randn(D, B, L, device=dev).to(dt).permute(1, 0, 2)
