@@ -165,6 +165,7 @@ def main():
                          "(configs[3]); block: ONE DiMBlockCombined forward+backward (configs[2])")
     ap.add_argument("--nfe", type=int, default=250)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the extra exact-fp32 timing (for profiling runs)")
     ap.add_argument("--matmul", choices=["tf32", "fp32"], default="tf32",
                     help="library-GEMM policy. tf32 = the reference's own setting (torch.backends.cuda.matmul.allow_tf32 = "
                          "True, dimsum/train.py:20-21, sample_ddp.py:56); on gfx950 hipBLASLt serves it with a split-bf16 "
@@ -288,7 +289,7 @@ def main():
         rb = roof("bwd", "ssm_scan_bwd_kernel<float,16>", "scan_bwd_pmc.json")
         if rb is not None:
             line["roofline_bwd"] = rb
-        if args.matmul == "tf32" and args.mode != "sample":
+        if args.matmul == "tf32" and args.mode != "sample" and not args.no_fp32_leg:
             # the same step with exact-fp32 library GEMMs, for reference (2 untimed + 2 timed steps)
             set_matmul("fp32")
             timer.enabled = False

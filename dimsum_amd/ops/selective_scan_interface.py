@@ -25,7 +25,8 @@ def _last_contig(t):
 
 class SelectiveScanFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, return_last_state=False):
+    def forward(ctx, u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, return_last_state=False,
+                need_ckpt=False):
         u, delta, B, C, z = (_last_contig(t) for t in (u, delta, B, C, z))
         D = D.contiguous() if D is not None else None
         if B.dim() < 3 or C.dim() < 3:
@@ -35,9 +36,10 @@ class SelectiveScanFn(torch.autograd.Function):
             B = B.unsqueeze(1)
         if ctx.squeeze_C:
             C = C.unsqueeze(1)
-        need = any(ctx.needs_input_grad)      # training extra: tile-boundary states for the backward kernel
-        out, x, *rest = native.selective_scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus, need_ckpt=need)
-        ckpt = rest.pop() if need else None
+        # training extra: saved states for the backward kernel (`need_ckpt` is decided by the caller: inside forward()
+        # grad mode is off and ctx.needs_input_grad ignores torch.no_grad())
+        out, x, *rest = native.selective_scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus, need_ckpt=need_ckpt)
+        ckpt = rest.pop() if need_ckpt else None
         ctx.delta_softplus = delta_softplus
         ctx.has_z = z is not None
         ctx.has_D, ctx.has_bias = D is not None, delta_bias is not None
@@ -55,12 +57,18 @@ class SelectiveScanFn(torch.autograd.Function):
         dz = rest[0] if ctx.has_z else None
         dB = dB.squeeze(1) if ctx.squeeze_B else dB
         dC = dC.squeeze(1) if ctx.squeeze_C else dC
-        return (du, ddelta, dA, dB, dC, dD if ctx.has_D else None, dz, ddelta_bias if ctx.has_bias else None, None, None)
+        return (du, ddelta, dA, dB, dC, dD if ctx.has_D else None, dz, ddelta_bias if ctx.has_bias else None, None, None, None)
 
 
 def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, return_last_state=False):
     """out (or (out, last_state)); the gradient of last_state is not propagated (as in the reference)."""
-    return SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
+    return SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state,
+                                 _will_backprop(u, delta, A, B, C, D, z, delta_bias))
+
+
+def _will_backprop(*tensors):
+    """True when autograd will record this call: only then is it worth storing the scan's saved states"""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
 def _rows(t):   # "b d l -> d (b l)" as a view-friendly reshape
@@ -74,7 +82,8 @@ class _MambaInner(torch.autograd.Function):
     @staticmethod
     @custom_fwd(device_type="cuda")
     def forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
-                A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, init_states, has_out_proj, checkpoint_lvl):
+                A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, init_states, has_out_proj, checkpoint_lvl,
+                need_ckpt=False):
         assert checkpoint_lvl in (0, 1)
         if A.is_complex():
             raise NotImplementedError("mamba_inner_fn: complex A is outside this build's scope")
@@ -115,7 +124,7 @@ class _MambaInner(torch.autograd.Function):
         D = D.contiguous() if D is not None else None
         # the tile-boundary states ride along to the backward (one activation tensor): it then needs no sweep of
         # its own to rebuild them. They depend on (conv_out, delta, A, B) only, which the backward recomputes identically.
-        need = any(ctx.needs_input_grad)
+        need = need_ckpt        # decided by the caller (grad mode is off in here)
         out, scan_x, out_z, *rest = native.selective_scan_fwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus,
                                                               need_ckpt=need)
         ckpt = rest[0] if need else None
@@ -175,13 +184,14 @@ class _MambaInner(torch.autograd.Function):
         _, dconv_w, dconv_b = native.causal_conv1d_bwd(x, conv_w, conv_b, dconv_out, dx, True)
         return (dxz, dconv_w.unsqueeze(1), dconv_b if has_conv_b else None, dx_proj_weight, ddelta_proj_weight,
                 dout_proj_weight, dout_proj_bias, dA, None, None, dD if has_D else None,
-                ddelta_bias if has_dbias else None, dB_proj_bias, dC_proj_bias, None, None, None, None)
+                ddelta_bias if has_dbias else None, dB_proj_bias, dC_proj_bias, None, None, None, None, None)
 
 
 def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias, A,
                    B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True):
     return _MambaInner.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
-                             out_proj_bias, A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, None, True, 1)
+                             out_proj_bias, A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, None, True, 1,
+                             _will_backprop(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias, A, D, delta_bias))
 
 
 def mamba_inner_fn_cond(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
@@ -189,20 +199,22 @@ def mamba_inner_fn_cond(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
                         delta_softplus=True, init_states=None):
     return _MambaInner.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
                              out_proj_bias, A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, init_states,
-                             True, 1)
+                             True, 1, _will_backprop(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias, A, D, delta_bias))
 
 
 def mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B=None, C=None,
                                D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True):
     return _MambaInner.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, None, None, A, B, C, D,
-                             delta_bias, B_proj_bias, C_proj_bias, delta_softplus, None, False, 1)
+                             delta_bias, B_proj_bias, C_proj_bias, delta_softplus, None, False, 1,
+                             _will_backprop(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias))
 
 
 def mamba_inner_fn_no_out_proj_cond(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B=None, C=None,
                                     D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True,
                                     init_states=None):
     return _MambaInner.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, None, None, A, B, C, D,
-                             delta_bias, B_proj_bias, C_proj_bias, delta_softplus, init_states, False, 1)
+                             delta_bias, B_proj_bias, C_proj_bias, delta_softplus, init_states, False, 1,
+                             _will_backprop(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias))
 
 
 def bimamba_inner_fn(*args, **kwargs):
