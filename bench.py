@@ -109,11 +109,11 @@ class ScanTimer:
         return avg_ms, avg_bytes, len(ms)
 
 
-def build_model(name, device, image_size=256):
+def build_model(name, device, image_size=256, scan_type="none"):
     from dimsum_amd.create_model import create_model, published_config
     from dimsum_amd.utils import rerandomize_zeros
     torch.manual_seed(0)
-    model = create_model(published_config(model=name, image_size=image_size))
+    model = create_model(published_config(model=name, image_size=image_size, bimamba_type=scan_type))
     rerandomize_zeros(model, std=0.02, seed=0)       # reference init is adaLN-zero (SURVEY finding 5)
     return model.to(device).eval()
 
@@ -160,6 +160,8 @@ def main():
     ap.add_argument("--model", default="DiM-L/2")
     ap.add_argument("--batch", type=int, default=256, help="latents per GPU per step")
     ap.add_argument("--image-size", type=int, default=256)
+    ap.add_argument("--scan-type", default="none", help="none (published configs) | zigma_8 | sweep_8 | jpeg_8: zigzag token "
+                                                         "orders inside the mixers (BASELINE configs[4])")
     ap.add_argument("--mode", choices=["fwd", "sample", "block"], default="fwd",
                     help="fwd: denoiser forward (headline, BASELINE configs[1]); sample: --nfe Euler steps + all-gather "
                          "(configs[3]); block: ONE DiMBlockCombined forward+backward (configs[2])")
@@ -194,7 +196,7 @@ def main():
     if args.mode == "block":
         model, hidden = build_block(args.model, dev)
     else:
-        model = build_model(args.model, dev, args.image_size)
+        model = build_model(args.model, dev, args.image_size, args.scan_type)
     gen = torch.Generator(device=dev).manual_seed(0 * world + rank)      # sample_ddp.py:64 seeding rule
     x = torch.randn(args.batch, 4, r, r, device=dev, generator=gen)
     t = torch.rand(args.batch, device=dev, generator=gen)
@@ -261,7 +263,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.model} {what}, "
                                    f"{args.image_size}px (4x{r}x{r} latents, {(r // 2) ** 2} tokens), {args.batch} latents per GPU, "
-                                   "random-init weights (reference init, zero tensors re-drawn N(0, 0.02^2))",
+                                   "random-init weights (reference init, zero tensors re-drawn N(0, 0.02^2))"
+                                   + (f", scan_type={args.scan_type}" if args.scan_type != "none" else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world} (replicas, independent latents)",
                        "matmul_policy": ("allow_tf32=True like the reference (train.py:20-21); gfx950 split-bf16 path, 4e-6 rms rel err"
                                          if args.matmul == "tf32" else "exact fp32")},

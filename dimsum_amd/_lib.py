@@ -75,11 +75,16 @@ class XattnParams(C.Structure):
                 + [(n, vp) for n in ("qkv1_ptr", "qkv2_ptr", "out_ptr", "lse_ptr", "bias1_ptr", "bias2_ptr")])
 
 
+class XattnBwdParams(C.Structure):
+    _fields_ = ([("fwd", XattnParams)] + [(n, i64) for n in ("dqkv_batch_stride", "dqkv_token_stride")]
+                + [(n, vp) for n in ("dout_ptr", "dqkv1_ptr", "dqkv2_ptr", "delta_ptr")])
+
+
 # every symbol include/dimsum_hip.h declares (tests check the library exports all of them)
 EXPORTS = (
     "dimsum_status_string", "dimsum_abi_version", "dimsum_target_arch",
     "dimsum_ssm_scan_fwd", "dimsum_ssm_scan_bwd", "dimsum_ssm_scan_bwd_workspace_bytes", "dimsum_causal_conv1d_fwd", "dimsum_causal_conv1d_bwd",
-    "dimsum_norm_fwd", "dimsum_norm_bwd", "dimsum_token_transform", "dimsum_xattn_fusion_fwd",
+    "dimsum_norm_fwd", "dimsum_norm_bwd", "dimsum_token_transform", "dimsum_xattn_fusion_fwd", "dimsum_xattn_fusion_bwd",
     "dimsum_gated_gelu_fwd", "dimsum_gated_gelu_bwd",
 )
 
@@ -102,7 +107,8 @@ def load():
     for name, ptype in (("dimsum_ssm_scan_fwd", SsmParams), ("dimsum_ssm_scan_bwd", SsmBwdParams),
                         ("dimsum_causal_conv1d_fwd", ConvParams), ("dimsum_causal_conv1d_bwd", ConvBwdParams),
                         ("dimsum_norm_fwd", NormParams), ("dimsum_norm_bwd", NormBwdParams),
-                        ("dimsum_token_transform", TtParams), ("dimsum_xattn_fusion_fwd", XattnParams)):
+                        ("dimsum_token_transform", TtParams), ("dimsum_xattn_fusion_fwd", XattnParams),
+                        ("dimsum_xattn_fusion_bwd", XattnBwdParams)):
         if hasattr(lib, name):
             fn = getattr(lib, name)
             fn.restype = C.c_int
@@ -115,7 +121,7 @@ def load():
     if hasattr(lib, "dimsum_ssm_scan_bwd_workspace_bytes"):
         lib.dimsum_ssm_scan_bwd_workspace_bytes.restype = i64
         lib.dimsum_ssm_scan_bwd_workspace_bytes.argtypes = [i32] * 5
-    if lib.dimsum_abi_version() != 3:
+    if lib.dimsum_abi_version() != 4:
         raise RuntimeError("dimsum_amd: libdimsum_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -1,12 +1,35 @@
 """CrossAttentionFusion -- dimsum/attention_fusion.py:9-84: two qkv projections, swapped-KV attention
 (x12 = softmax(q1 k2^T / sqrt(hd)) v2, x21 = softmax(q2 k1^T / sqrt(hd)) v1), concat, proj.
-The attention core (both directions, straight from the qkv GEMM outputs to the concatenated proj input) is one HIP
-kernel with MFMA QK^T / PV (csrc/xattn_fusion.hip) under inference; under autograd it is torch SDPA on the GPU."""
+The attention core (both directions, straight from the bias-free qkv GEMM outputs to the concatenated proj input) is one
+HIP kernel with MFMA QK^T / PV (csrc/xattn_fusion.hip); its backward is two more (csrc/xattn_fusion_bwd.hip). Variants
+the published configs never enable (qk_norm, swap_k, attention dropout) run on torch SDPA on the GPU."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import native
+
+
+class _XattnCoreFn(torch.autograd.Function):
+    """fused (B, N, 2C) = cat(x12, x21) from bias-free qkv GEMM outputs + the qkv biases"""
+
+    @staticmethod
+    def forward(ctx, qkv1, qkv2, bias1, bias2, heads):
+        b1 = None if bias1 is None else bias1.float().contiguous()
+        b2 = None if bias2 is None else bias2.float().contiguous()
+        out, lse = native.xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=True, bias1=b1, bias2=b2)
+        ctx.heads = heads
+        ctx.save_for_backward(qkv1, qkv2, b1, b2, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv1, qkv2, b1, b2, out, lse = ctx.saved_tensors
+        dqkv1, dqkv2 = native.xattn_fusion_bwd(qkv1, qkv2, out, lse, dout, ctx.heads, bias1=b1, bias2=b2)
+        W = dqkv1.shape[-1]
+        db1 = dqkv1.reshape(-1, W).sum(0) if (b1 is not None and ctx.needs_input_grad[2]) else None
+        db2 = dqkv2.reshape(-1, W).sum(0) if (b2 is not None and ctx.needs_input_grad[3]) else None
+        return dqkv1, dqkv2, db1, db2, None
 
 
 class CrossAttentionFusion(nn.Module):
@@ -40,13 +63,12 @@ class CrossAttentionFusion(nn.Module):
         """-> (y, b): the module's output is y + b; b (proj's bias) is left to the caller's fused residual pass."""
         B, N, C = x1.shape
         drop = self.attn_drop.p if self.training else 0.0
-        if self._plain and drop == 0.0 and not torch.is_grad_enabled() and native.xattn_supported(x1, self.head_dim):
-            # bias-free qkv GEMMs (fast hipBLASLt path); the biases are added inside the attention kernel
+        if self._plain and drop == 0.0 and native.xattn_supported(x1, self.head_dim):
+            # bias-free qkv GEMMs (fast hipBLASLt path); the biases are added inside the attention kernels
             b1, b2 = self.qkv1.bias, self.qkv2.bias
-            fused = native.xattn_fusion_fwd(F.linear(x1, self.qkv1.weight), F.linear(x2, self.qkv2.weight), self.num_heads,
-                                            bias1=None if b1 is None else b1.float(), bias2=None if b2 is None else b2.float())
-            if b1 is None and b2 is not None or b2 is None and b1 is not None:
+            if (b1 is None) != (b2 is None):
                 raise RuntimeError("CrossAttentionFusion: qkv1 / qkv2 must both have a bias or none")
+            fused = _XattnCoreFn.apply(F.linear(x1, self.qkv1.weight), F.linear(x2, self.qkv2.weight), b1, b2, self.num_heads)
         else:
             qkv1, qkv2 = self.qkv1(x1), self.qkv2(x2)
             q1, k1, v1 = self._split(qkv1, B, N)

@@ -1,0 +1,332 @@
+// xattn_fusion_bwd.hip -- backward of the cross-attention fusion core on the matrix cores (gfx950), fp32.
+//
+// Forward (xattn_fusion.hip; dimsum/attention_fusion.py:64-79): per (batch, head, direction), with (q, k, v) =
+// (q1, k2, v2) for direction 0 and (q2, k1, v1) for direction 1:  S = scale q k^T,  P = softmax(S),  o = P v.
+// Backward, with do = d(out) and the saved log-sum-exp rows:
+//     D_i = sum_e do_ie o_ie        dP = do v^T        dS = P o (dP - D)        P = exp(S - lse)
+//     dq = scale dS k               dk = scale dS^T q  dv = P^T do
+// Two kernels, no atomics, every output element written exactly once (direction 0 owns dq1, dk2, dv2; direction 1 owns
+// dq2, dk1, dv1 -- the six slices of dqkv1 / dqkv2):
+//   xattn_bwd_dq_kernel   one wave = 16 queries, walks key tiles (the forward's structure): S^T = K Q^T and
+//                         dP^T = V dO^T in the TRANSPOSED form so that the C-layout registers of dS^T are directly the B
+//                         operand of dQ^T = K^T dS^T; also emits D (needed by the second kernel).
+//   xattn_bwd_dkv_kernel  one wave = 16 keys, walks query tiles: S = Q K^T and dP = dO V^T NON-transposed, so that the C
+//                         registers of P / dS are the B operands of dV^T = dO^T P and dK^T = Q^T dS.
+// S and dP are recomputed in both (7 GEMM-equivalents instead of 5): cheaper on fp32 MFMA than contended fp32 atomics
+// on dq, and bitwise reproducible. All products are v_mfma_f32_16x16x4_f32 (exact fp32).
+// Optional qkv Linear biases are added while q / k / v are fetched, like in the forward.
+#include "common.hpp"
+
+namespace dimsum {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+constexpr int kBKT = 64;         // keys per tile (dq kernel)
+constexpr int kBQT = 32;         // queries per tile (dkv kernel)
+
+#define MFMA4(ACC, A4, B4)                                                       \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A4).x, (B4).x, ACC, 0, 0, 0);     \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A4).y, (B4).y, ACC, 0, 0, 0);     \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A4).z, (B4).z, ACC, 0, 0, 0);     \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A4).w, (B4).w, ACC, 0, 0, 0)
+
+struct XSrc {
+    const float *q, *k, *v, *qb, *kb, *vb;     // rows of this (batch, head): token stride ts; biases or nullptr
+    float *dq, *dk, *dv;
+};
+__device__ __forceinline__ XSrc xattn_src(const dimsum_xattn_bwd_params_t &p, int b, int h, int dir, int HD) {
+    const int C = p.fwd.heads * HD;
+    const int64_t off = (int64_t)b * p.fwd.qkv_batch_stride + h * HD, doff = (int64_t)b * p.dqkv_batch_stride + h * HD;
+    const float *qs = reinterpret_cast<const float *>(dir == 0 ? p.fwd.qkv1_ptr : p.fwd.qkv2_ptr) + off;
+    const float *kvs = reinterpret_cast<const float *>(dir == 0 ? p.fwd.qkv2_ptr : p.fwd.qkv1_ptr) + off;
+    const float *qbias = reinterpret_cast<const float *>(dir == 0 ? p.fwd.bias1_ptr : p.fwd.bias2_ptr);
+    const float *kvbias = reinterpret_cast<const float *>(dir == 0 ? p.fwd.bias2_ptr : p.fwd.bias1_ptr);
+    float *dqs = reinterpret_cast<float *>(dir == 0 ? p.dqkv1_ptr : p.dqkv2_ptr) + doff;
+    float *dkvs = reinterpret_cast<float *>(dir == 0 ? p.dqkv2_ptr : p.dqkv1_ptr) + doff;
+    XSrc s;
+    s.q = qs; s.k = kvs + C; s.v = kvs + 2 * C;
+    s.qb = qbias ? qbias + h * HD : nullptr;
+    s.kb = kvbias ? kvbias + C + h * HD : nullptr;
+    s.vb = kvbias ? kvbias + 2 * C + h * HD : nullptr;
+    s.dq = dqs; s.dk = dkvs + C; s.dv = dkvs + 2 * C;
+    return s;
+}
+__device__ __forceinline__ float4 ld_bias4(const float *row, const float *bias, int e) {
+    float4 t = *reinterpret_cast<const float4 *>(row + e);
+    if (bias) { const float4 bb = *reinterpret_cast<const float4 *>(bias + e); t.x += bb.x; t.y += bb.y; t.z += bb.z; t.w += bb.w; }
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dq (+ D): workgroup = 4 waves = 64 queries of one (batch, head, direction)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void xattn_bwd_dq_kernel(const dimsum_xattn_bwd_params_t p) {
+    constexpr int KS = HD + 4;               // [key][e] tiles (K and V): 16-B aligned rows, conflict-free b128 reads
+    constexpr int TS = kBKT + 4;             // [e][key] tile (K^T)
+    constexpr int ET = (HD + 15) / 16;
+    constexpr int EC = HD / 16;
+    constexpr bool kTail8 = (HD % 16) == 8;
+    constexpr int NC = EC + (kTail8 ? 1 : 0);
+    __shared__ __attribute__((aligned(16))) float Ks[kBKT * KS];
+    __shared__ __attribute__((aligned(16))) float Vs[kBKT * KS];
+    __shared__ __attribute__((aligned(16))) float Kt[ET * 16 * TS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int L = p.fwd.seqlen, H = p.fwd.heads;
+    const int qblocks = (L + 63) / 64;
+    int idx = blockIdx.x;
+    const int qblk = idx % qblocks; idx /= qblocks;
+    const int dir = idx & 1; idx >>= 1;
+    const int h = idx % H;
+    const int b = idx / H;
+    const int C = H * HD;
+    const XSrc s = xattn_src(p, b, h, dir, HD);
+    const int64_t ts = p.fwd.qkv_token_stride, dts = p.dqkv_token_stride;
+
+    const int qi = lane & 15, kg = lane >> 4;
+    const int q_tok = qblk * 64 + wave * 16 + qi;
+    const int q_ld = min(q_tok, L - 1);
+    const float qscale = p.fwd.scale * kLog2e;
+    const float *dorow = reinterpret_cast<const float *>(p.dout_ptr) + (int64_t)b * p.fwd.out_batch_stride + (int64_t)q_ld * p.fwd.out_token_stride + dir * C + h * HD;
+    const float *orow = reinterpret_cast<const float *>(p.fwd.out_ptr) + (int64_t)b * p.fwd.out_batch_stride + (int64_t)q_ld * p.fwd.out_token_stride + dir * C + h * HD;
+    // Q^T (scaled into the log2 domain) and dO^T fragments: chunk c holds e = 16c + 4 kg .. +3 of this lane's query
+    f4 qf[NC], dof[NC];
+    float dpart = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const bool tail = kTail8 && c == EC;
+        const int e = tail ? 16 * EC + 4 * (kg & 1) : 16 * c + 4 * kg;
+        const float m = (tail && kg >= 2) ? 0.f : 1.f;        // 8-wide tail: k-groups 2, 3 idle
+        const float4 t = ld_bias4(s.q + (int64_t)q_ld * ts, s.qb, e);
+        const float4 g = *reinterpret_cast<const float4 *>(dorow + e), o = *reinterpret_cast<const float4 *>(orow + e);
+        qf[c] = f4{t.x * qscale * m, t.y * qscale * m, t.z * qscale * m, t.w * qscale * m};
+        dof[c] = f4{g.x * m, g.y * m, g.z * m, g.w * m};
+        dpart += m * (g.x * o.x + g.y * o.y + g.z * o.z + g.w * o.w);
+    }
+    dpart += __shfl_xor(dpart, 16, kWave);
+    dpart += __shfl_xor(dpart, 32, kWave);                    // D of this lane's query
+    const int64_t stat = (((int64_t)b * 2 + dir) * H + h) * L + q_ld;
+    const float lse2 = reinterpret_cast<const float *>(p.fwd.lse_ptr)[stat] * kLog2e;
+    if (q_tok < L && kg == 0) reinterpret_cast<float *>(p.delta_ptr)[stat] = dpart;
+
+    f4 acc[ET];
+#pragma unroll
+    for (int e = 0; e < ET; ++e) acc[e] = f4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < L; k0 += kBKT) {
+        __syncthreads();
+        for (int i = tid; i < kBKT * (HD / 4); i += 256) {
+            const int key = i / (HD / 4), e4 = i - key * (HD / 4);
+            const int tok = min(k0 + key, L - 1);
+            const float4 kv = ld_bias4(s.k + (int64_t)tok * ts, s.kb, e4 * 4);
+            const float4 vv = ld_bias4(s.v + (int64_t)tok * ts, s.vb, e4 * 4);
+            *reinterpret_cast<float4 *>(&Ks[key * KS + e4 * 4]) = kv;
+            *reinterpret_cast<float4 *>(&Vs[key * KS + e4 * 4]) = vv;
+            Kt[(e4 * 4 + 0) * TS + key] = kv.x; Kt[(e4 * 4 + 1) * TS + key] = kv.y;
+            Kt[(e4 * 4 + 2) * TS + key] = kv.z; Kt[(e4 * 4 + 3) * TS + key] = kv.w;
+        }
+        if constexpr (ET * 16 > HD) {
+            for (int i = tid; i < (ET * 16 - HD) * kBKT; i += 256) Kt[(HD + i / kBKT) * TS + (i % kBKT)] = 0.f;
+        }
+        __syncthreads();
+
+        f4 ds[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            f4 sacc = f4{0.f, 0.f, 0.f, 0.f}, pacc = f4{0.f, 0.f, 0.f, 0.f};
+            const float *krow = &Ks[(kt * 16 + qi) * KS], *vrow = &Vs[(kt * 16 + qi) * KS];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int e = (kTail8 && c == EC) ? 16 * EC + 4 * (kg & 1) : 16 * c + 4 * kg;
+                const float4 kf = *reinterpret_cast<const float4 *>(krow + e);
+                const float4 vf = *reinterpret_cast<const float4 *>(vrow + e);
+                MFMA4(sacc, kf, qf[c]);          // S^T  (log2 domain)
+                MFMA4(pacc, vf, dof[c]);         // dP^T
+            }
+            // dS^T = P^T o (dP^T - D); keys beyond L contribute nothing
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pr = (k0 + kt * 16 + kg * 4 + r < L) ? fast_exp2(sacc[r] - lse2) : 0.f;
+                ds[kt][r] = pr * (pacc[r] - dpart);
+            }
+        }
+        // dQ^T += K^T dS^T: K-step (kt, r) covers keys kt*16 + {r, 4+r, 8+r, 12+r}; its B operand is ds[kt][r]
+#pragma unroll
+        for (int e = 0; e < ET; ++e) {
+            const float *trow = &Kt[(e * 16 + qi) * TS];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const float4 kf = *reinterpret_cast<const float4 *>(trow + kt * 16 + kg * 4);
+                MFMA4(acc[e], kf, ds[kt]);
+            }
+        }
+    }
+    if (q_tok < L) {
+        float *dst = s.dq + (int64_t)q_tok * dts;
+        const float sc = p.fwd.scale;
+#pragma unroll
+        for (int e = 0; e < ET; ++e) {
+            const int e0 = e * 16 + kg * 4;
+            if (e0 < HD) *reinterpret_cast<float4 *>(dst + e0) = make_float4(acc[e][0] * sc, acc[e][1] * sc, acc[e][2] * sc, acc[e][3] * sc);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dk, dv: workgroup = 4 waves = 64 keys of one (batch, head, direction), walks query tiles of 32
+// ---------------------------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void xattn_bwd_dkv_kernel(const dimsum_xattn_bwd_params_t p) {
+    constexpr int RS = HD + 4;               // [query][e] tiles (Q and dO)
+    constexpr int TS = kBQT + 4;             // [e][query] tiles (Q^T and dO^T)
+    constexpr int ET = (HD + 15) / 16;
+    constexpr int EC = HD / 16;
+    constexpr bool kTail8 = (HD % 16) == 8;
+    constexpr int NC = EC + (kTail8 ? 1 : 0);
+    __shared__ __attribute__((aligned(16))) float Qs[kBQT * RS];
+    __shared__ __attribute__((aligned(16))) float Gs[kBQT * RS];
+    __shared__ __attribute__((aligned(16))) float Qt[ET * 16 * TS];
+    __shared__ __attribute__((aligned(16))) float Gt[ET * 16 * TS];
+    __shared__ __attribute__((aligned(16))) float sL[kBQT], sD[kBQT];      // lse (log2 domain) and D of the tile's queries
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int L = p.fwd.seqlen, H = p.fwd.heads;
+    const int kblocks = (L + 63) / 64;
+    int idx = blockIdx.x;
+    const int kblk = idx % kblocks; idx /= kblocks;
+    const int dir = idx & 1; idx >>= 1;
+    const int h = idx % H;
+    const int b = idx / H;
+    const int C = H * HD;
+    const XSrc s = xattn_src(p, b, h, dir, HD);
+    const int64_t ts = p.fwd.qkv_token_stride, dts = p.dqkv_token_stride;
+    const float *dobase = reinterpret_cast<const float *>(p.dout_ptr) + (int64_t)b * p.fwd.out_batch_stride + dir * C + h * HD;
+    const int64_t stat0 = (((int64_t)b * 2 + dir) * H + h) * L;
+    const float *lse = reinterpret_cast<const float *>(p.fwd.lse_ptr) + stat0;
+    const float *dlt = reinterpret_cast<const float *>(p.delta_ptr) + stat0;
+
+    const int ki = lane & 15, kg = lane >> 4;
+    const int k_tok = kblk * 64 + wave * 16 + ki;
+    const int k_ld = min(k_tok, L - 1);
+    const float kscale = p.fwd.scale * kLog2e;
+    // K^T (scaled) and V^T fragments of this lane's key: chunk c holds e = 16c + 4 kg .. +3   (B operands)
+    f4 kf[NC], vf[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const bool tail = kTail8 && c == EC;
+        const int e = tail ? 16 * EC + 4 * (kg & 1) : 16 * c + 4 * kg;
+        const float m = (tail && kg >= 2) ? 0.f : 1.f;
+        const float4 kk = ld_bias4(s.k + (int64_t)k_ld * ts, s.kb, e);
+        const float4 vv = ld_bias4(s.v + (int64_t)k_ld * ts, s.vb, e);
+        kf[c] = f4{kk.x * kscale * m, kk.y * kscale * m, kk.z * kscale * m, kk.w * kscale * m};
+        vf[c] = f4{vv.x * m, vv.y * m, vv.z * m, vv.w * m};
+    }
+    f4 dk[ET], dv[ET];
+#pragma unroll
+    for (int e = 0; e < ET; ++e) { dk[e] = f4{0.f, 0.f, 0.f, 0.f}; dv[e] = f4{0.f, 0.f, 0.f, 0.f}; }
+    const bool key_live = k_tok < L;
+
+    for (int q0 = 0; q0 < L; q0 += kBQT) {
+        __syncthreads();
+        for (int i = tid; i < kBQT * (HD / 4); i += 256) {
+            const int q = i / (HD / 4), e4 = i - q * (HD / 4);
+            const int tok = min(q0 + q, L - 1);
+            const float4 qv = ld_bias4(s.q + (int64_t)tok * ts, s.qb, e4 * 4);
+            const float4 gv = *reinterpret_cast<const float4 *>(dobase + (int64_t)tok * p.fwd.out_token_stride + e4 * 4);
+            *reinterpret_cast<float4 *>(&Qs[q * RS + e4 * 4]) = qv;
+            *reinterpret_cast<float4 *>(&Gs[q * RS + e4 * 4]) = gv;
+            Qt[(e4 * 4 + 0) * TS + q] = qv.x; Qt[(e4 * 4 + 1) * TS + q] = qv.y; Qt[(e4 * 4 + 2) * TS + q] = qv.z; Qt[(e4 * 4 + 3) * TS + q] = qv.w;
+            Gt[(e4 * 4 + 0) * TS + q] = gv.x; Gt[(e4 * 4 + 1) * TS + q] = gv.y; Gt[(e4 * 4 + 2) * TS + q] = gv.z; Gt[(e4 * 4 + 3) * TS + q] = gv.w;
+        }
+        if constexpr (ET * 16 > HD) {
+            for (int i = tid; i < (ET * 16 - HD) * kBQT; i += 256) { Qt[(HD + i / kBQT) * TS + (i % kBQT)] = 0.f; Gt[(HD + i / kBQT) * TS + (i % kBQT)] = 0.f; }
+        }
+        if (tid < kBQT) {
+            const int tok = q0 + tid;
+            sL[tid] = tok < L ? lse[tok] * kLog2e : 1e30f;       // queries beyond L: P = exp2(S - inf) = 0
+            sD[tid] = tok < L ? dlt[tok] : 0.f;
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int qt = 0; qt < kBQT / 16; ++qt) {
+            // S (queries x keys) = Q K^T, dP = dO V^T: A rows = this tile's query (lane & 15)
+            f4 sacc = f4{0.f, 0.f, 0.f, 0.f}, pacc = f4{0.f, 0.f, 0.f, 0.f};
+            const float *qrow = &Qs[(qt * 16 + ki) * RS], *grow = &Gs[(qt * 16 + ki) * RS];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int e = (kTail8 && c == EC) ? 16 * EC + 4 * (kg & 1) : 16 * c + 4 * kg;
+                const float4 qa = *reinterpret_cast<const float4 *>(qrow + e);
+                const float4 ga = *reinterpret_cast<const float4 *>(grow + e);
+                MFMA4(sacc, qa, kf[c]);
+                MFMA4(pacc, ga, vf[c]);
+            }
+            // C layout: key = lane & 15 (column), queries qt*16 + kg*4 + r (rows)
+            const float4 l4 = *reinterpret_cast<const float4 *>(&sL[qt * 16 + kg * 4]);
+            const float4 d4 = *reinterpret_cast<const float4 *>(&sD[qt * 16 + kg * 4]);
+            f4 pp, dsv;
+            pp[0] = key_live ? fast_exp2(sacc[0] - l4.x) : 0.f; pp[1] = key_live ? fast_exp2(sacc[1] - l4.y) : 0.f;
+            pp[2] = key_live ? fast_exp2(sacc[2] - l4.z) : 0.f; pp[3] = key_live ? fast_exp2(sacc[3] - l4.w) : 0.f;
+            dsv[0] = pp[0] * (pacc[0] - d4.x); dsv[1] = pp[1] * (pacc[1] - d4.y);
+            dsv[2] = pp[2] * (pacc[2] - d4.z); dsv[3] = pp[3] * (pacc[3] - d4.w);
+            // dV^T += dO^T P, dK^T += Q^T dS: K-step r covers queries qt*16 + {r, 4+r, 8+r, 12+r} = C register r
+#pragma unroll
+            for (int e = 0; e < ET; ++e) {
+                const float4 ga = *reinterpret_cast<const float4 *>(&Gt[(e * 16 + ki) * TS + qt * 16 + kg * 4]);
+                const float4 qa = *reinterpret_cast<const float4 *>(&Qt[(e * 16 + ki) * TS + qt * 16 + kg * 4]);
+                MFMA4(dv[e], ga, pp);
+                MFMA4(dk[e], qa, dsv);
+            }
+        }
+    }
+    if (key_live) {
+        float *dkd = s.dk + (int64_t)k_tok * dts, *dvd = s.dv + (int64_t)k_tok * dts;
+        const float sc = p.fwd.scale;
+#pragma unroll
+        for (int e = 0; e < ET; ++e) {
+            const int e0 = e * 16 + kg * 4;
+            if (e0 < HD) {
+                *reinterpret_cast<float4 *>(dkd + e0) = make_float4(dk[e][0] * sc, dk[e][1] * sc, dk[e][2] * sc, dk[e][3] * sc);
+                *reinterpret_cast<float4 *>(dvd + e0) = make_float4(dv[e][0], dv[e][1], dv[e][2], dv[e][3]);
+            }
+        }
+    }
+}
+
+template <int HD>
+static int launch_xbwd(const dimsum_xattn_bwd_params_t &p, hipStream_t s) {
+    const int64_t nblk = (int64_t)p.fwd.batch * p.fwd.heads * 2 * ((p.fwd.seqlen + 63) / 64);
+    if (nblk > 0x7fffffff) return DIMSUM_ERR_SHAPE;
+    hipLaunchKernelGGL(xattn_bwd_dq_kernel<HD>, dim3((unsigned)nblk), dim3(256), 0, s, p);
+    if (launch_status() != DIMSUM_OK) return DIMSUM_ERR_LAUNCH;
+    hipLaunchKernelGGL(xattn_bwd_dkv_kernel<HD>, dim3((unsigned)nblk), dim3(256), 0, s, p);
+    return launch_status();
+}
+
+}  // namespace dimsum
+
+extern "C" int dimsum_xattn_fusion_bwd(const dimsum_xattn_bwd_params_t *p, void *stream) {
+    using namespace dimsum;
+    if (!p || !p->fwd.qkv1_ptr || !p->fwd.qkv2_ptr || !p->fwd.out_ptr || !p->fwd.lse_ptr || !p->dout_ptr || !p->dqkv1_ptr ||
+        !p->dqkv2_ptr || !p->delta_ptr)
+        return DIMSUM_ERR_NULL;
+    const dimsum_xattn_params_t &f = p->fwd;
+    if (f.batch < 0 || f.seqlen <= 0 || f.heads <= 0) return DIMSUM_ERR_SHAPE;
+    if ((f.bias1_ptr == nullptr) != (f.bias2_ptr == nullptr)) return DIMSUM_ERR_NULL;
+    const void *ptrs[] = {f.qkv1_ptr, f.qkv2_ptr, f.out_ptr, p->dout_ptr, p->dqkv1_ptr, p->dqkv2_ptr, f.bias1_ptr, f.bias2_ptr};
+    for (const void *q : ptrs)
+        if (q && !aligned_to<float>(q, 16)) return DIMSUM_ERR_STRIDE;
+    if (f.qkv_batch_stride % 4 || f.qkv_token_stride % 4 || f.out_batch_stride % 4 || f.out_token_stride % 4 || p->dqkv_batch_stride % 4 ||
+        p->dqkv_token_stride % 4)
+        return DIMSUM_ERR_STRIDE;
+    if (f.batch == 0) return DIMSUM_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (f.head_dim) {
+        case 24: return launch_xbwd<24>(*p, s);
+        case 32: return launch_xbwd<32>(*p, s);
+        case 48: return launch_xbwd<48>(*p, s);
+        case 64: return launch_xbwd<64>(*p, s);
+        case 72: return launch_xbwd<72>(*p, s);
+        default: return DIMSUM_ERR_SHAPE;
+    }
+}

@@ -436,3 +436,32 @@ def xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=False, bias1=None, bias2=None):
         with torch.cuda.device(qkv1.device):
             _lib.check(_lib.load().dimsum_xattn_fusion_fwd(P, _stream(qkv1)), "xattn_fusion_fwd")
     return (out, lse) if need_lse else out
+
+
+def xattn_fusion_bwd(qkv1, qkv2, out, lse, dout, heads, bias1=None, bias2=None):
+    """backward of xattn_fusion_fwd -> (dqkv1, dqkv2), each (B, L, 3*heads*hd); `out`, `lse` are the forward's results."""
+    _gpu(qkv1, qkv2, out, lse, dout, bias1, bias2)
+    B, L, W = qkv1.shape
+    hd = W // (3 * heads)
+    _check(qkv1.shape == qkv2.shape and qkv1.dtype == torch.float32 and qkv1.stride() == qkv2.stride() and qkv1.stride(2) == 1, "xattn_fusion_bwd: bad qkv")
+    _check(tuple(out.shape) == (B, L, 2 * heads * hd) and out.stride(2) == 1 and tuple(lse.shape) == (B, 2, heads, L) and lse.is_contiguous(), "xattn_fusion_bwd: bad out / lse")
+    dout = dout if (dout.stride() == out.stride()) else dout.contiguous()
+    if dout.stride() != out.stride():
+        out = out.contiguous()
+    _check((bias1 is None) == (bias2 is None), "xattn_fusion_bwd: pass both biases or none")
+    dqkv1 = torch.empty((B, L, W), device=qkv1.device, dtype=torch.float32)
+    dqkv2 = torch.empty((B, L, W), device=qkv1.device, dtype=torch.float32)
+    delta = torch.empty((B, 2, heads, L), device=qkv1.device, dtype=torch.float32)
+    if B > 0:
+        Q = _lib.XattnBwdParams()
+        P = Q.fwd
+        P.batch, P.seqlen, P.heads, P.head_dim, P.scale = B, L, heads, hd, hd ** -0.5
+        P.qkv_batch_stride, P.qkv_token_stride = qkv1.stride(0), qkv1.stride(1)
+        P.out_batch_stride, P.out_token_stride = out.stride(0), out.stride(1)
+        P.qkv1_ptr, P.qkv2_ptr, P.out_ptr, P.lse_ptr = _ptr(qkv1), _ptr(qkv2), _ptr(out), _ptr(lse)
+        P.bias1_ptr, P.bias2_ptr = _ptr(bias1), _ptr(bias2)
+        Q.dqkv_batch_stride, Q.dqkv_token_stride = dqkv1.stride(0), dqkv1.stride(1)
+        Q.dout_ptr, Q.dqkv1_ptr, Q.dqkv2_ptr, Q.delta_ptr = _ptr(dout), _ptr(dqkv1), _ptr(dqkv2), _ptr(delta)
+        with torch.cuda.device(qkv1.device):
+            _lib.check(_lib.load().dimsum_xattn_fusion_bwd(Q, _stream(qkv1)), "xattn_fusion_bwd")
+    return dqkv1, dqkv2

@@ -10,7 +10,7 @@
  *   dimsum_causal_conv1d_bwd   <- causal_conv1d_cuda.causal_conv1d_bwd[_cond]   causal-conv1d/csrc/causal_conv1d.cpp:338-509
  *   dimsum_norm_fwd / _bwd     <- _layer_norm_fwd / _layer_norm_bwd (Triton)     mamba/mamba_ssm/ops/triton/layernorm.py:120-364
  *   dimsum_token_transform     <- einops/flip/local_scan/DWT/DCT chains          dimsum/models_dim.py:572-604,656-705,876-928,1496-1524
- *   dimsum_xattn_fusion_fwd    <- F.scaled_dot_product_attention x2              dimsum/attention_fusion.py:44-75
+ *   dimsum_xattn_fusion_fwd/_bwd <- F.scaled_dot_product_attention x2 (+ autograd)  dimsum/attention_fusion.py:44-75
  *   dimsum_gated_gelu_fwd/_bwd <- gelu_tanh(x1) * x2                             dimsum/mlp.py:66-70
  *
  * Conventions (same as the reference's host wrappers, minus ATen):
@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DIMSUM_ABI_VERSION 3
+#define DIMSUM_ABI_VERSION 4
 
 typedef enum {
     DIMSUM_OK = 0,
@@ -239,6 +239,20 @@ typedef struct {
 } dimsum_xattn_params_t;
 
 int dimsum_xattn_fusion_fwd(const dimsum_xattn_params_t *p, void *stream);
+
+/* Backward of the core (replaces the autograd of the two F.scaled_dot_product_attention calls).
+ *   fwd      : the forward's operands; out_ptr = the forward's `out`, lse_ptr = its saved log-sum-exp (both required)
+ *   dout     : (batch, L, 2*heads*hd) f32, strides like `out`
+ *   dqkv1/2  : (batch, L, 3*heads*hd) f32, fully overwritten (direction 0 -> dq1, dk2, dv2; direction 1 -> dq2, dk1, dv1)
+ *   delta    : (batch, 2, heads, L) f32 scratch (row sums of dout o out) */
+typedef struct {
+    dimsum_xattn_params_t fwd;
+    int64_t dqkv_batch_stride, dqkv_token_stride;
+    const void *dout_ptr;
+    void *dqkv1_ptr, *dqkv2_ptr, *delta_ptr;
+} dimsum_xattn_bwd_params_t;
+
+int dimsum_xattn_fusion_bwd(const dimsum_xattn_bwd_params_t *p, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * GatedMLP epilogue (mlp.py:66-70, GELU tanh), x12 : (M, 2H) f32 = output of the w12 GEMM WITHOUT its bias:
