@@ -32,6 +32,27 @@ class ICPlan:
         sigma_t, d_sigma_t = self.compute_sigma_t(t)
         return -(ratio * x), ratio * (sigma_t ** 2) - sigma_t * d_sigma_t
 
+    def compute_diffusion(self, x, t, form="constant", norm=1.0):
+        """diffusion coefficient w(t) of the sampling SDE (path.py:52-76); only the requested form is evaluated"""
+        t = expand_t_like_x(t, x)
+        if form == "none":
+            return th.zeros((1,), device=t.device)
+        if form == "constant":
+            return th.full((1,), norm, device=t.device)
+        if form == "SBDM":
+            return norm * 2.0 * self.compute_drift(x, t.reshape(t.shape[0]))[1]
+        if form == "sigma":
+            return norm * self.compute_sigma_t(t)[0]
+        if form == "linear":
+            return norm * (1 - t)
+        if form == "decreasing":
+            return 0.25 * (norm * th.cos(math.pi * t) + 1) ** 2
+        if form == "increasing-decreasing":
+            return norm * th.sin(math.pi * t) ** 2
+        if form == "log":
+            return norm * th.log(t - t ** 2 + 1)
+        raise NotImplementedError(f"Diffusion form {form} not implemented")
+
     def get_score_from_velocity(self, velocity, x, t):
         t = expand_t_like_x(t, x)
         alpha_t, d_alpha_t = self.compute_alpha_t(t)

@@ -1,12 +1,11 @@
-"""Flow-matching transport: training loss and ODE sampler around the denoiser (dimsum/transport/transport.py).
-Velocity prediction (the published configs); the SDE samplers, likelihood ODE and blurring are not part of the
-denoiser hot path and are left out."""
+"""Flow-matching transport: training loss, ODE and SDE samplers around the denoiser (dimsum/transport/transport.py).
+The likelihood ODE and the DCT blurring of the path are not part of the denoiser hot path and are left out."""
 import enum
 
 import torch as th
 
 from . import path
-from .integrators import ode
+from .integrators import ode, sde
 
 
 class ModelType(enum.Enum):
@@ -104,10 +103,21 @@ class Transport:
         return body_fn
 
 
+    def get_score(self):
+        """score of x_t = alpha_t x + sigma_t eps from the model's prediction (transport.py:199-219)"""
+        ps = self.path_sampler
+        if self.model_type == ModelType.NOISE:
+            return lambda x, t, model, **kw: model(x, t, **kw) / -ps.compute_sigma_t(path.expand_t_like_x(t, x))[0]
+        if self.model_type == ModelType.SCORE:
+            return lambda x, t, model, **kw: model(x, t, **kw)
+        return lambda x, t, model, **kw: ps.get_score_from_velocity(model(x, t, **kw), x, t)
+
+
 class Sampler:
     def __init__(self, transport):
         self.transport = transport
         self.drift = transport.get_drift()
+        self.score = transport.get_score()
 
     def sample_ode(self, *, sampling_method="euler", num_steps=50, atol=1e-6, rtol=1e-3, reverse=False):
         """-> sample_fn(x, model, **model_kwargs) returning the trajectory (transport.py:343-386)"""
@@ -119,5 +129,49 @@ class Sampler:
                                                reverse=reverse, last_step_size=0.0)
         return ode(drift=drift, t0=t0, t1=t1, sampler_type=sampling_method, num_steps=num_steps, atol=atol, rtol=rtol).sample
 
-    def sample_sde(self, *a, **k):
-        raise NotImplementedError("SDE sampling is outside the denoiser hot path (SURVEY.md 8 f1)")
+    def sample_sde(self, *, sampling_method="Euler", diffusion_form="SBDM", diffusion_norm=1.0, last_step="Mean",
+                   last_step_size=0.04, num_steps=250):
+        """-> sample_fn(x, model, **model_kwargs) returning the list of states (transport.py:286-341).
+        SDE: dx = [v + w(t) s] dt + sqrt(2 w(t)) dW, followed by one deterministic last step of `last_step_size`:
+        None | "Mean" (drift only) | "Tweedie" (posterior mean) | "Euler" (probability-flow step).
+        Note: one model call per drift evaluation would do; like the reference this evaluates the model twice (velocity
+        and score) per drift."""
+        num_steps = num_steps if sampling_method == "Euler" else num_steps // 2
+        if last_step is None:
+            last_step_size = 0.0
+        elif last_step_size == -1:
+            last_step_size = 1.0 / num_steps
+        ps = self.transport.path_sampler
+
+        def diffusion_fn(x, t):
+            return ps.compute_diffusion(x, t, form=diffusion_form, norm=diffusion_norm)
+
+        def sde_drift(x, t, model, **kw):
+            return self.drift(x, t, model, **kw) + diffusion_fn(x, t) * self.score(x, t, model, **kw)
+
+        t0, t1 = self.transport.check_interval(self.transport.train_eps, self.transport.sample_eps, diffusion_form=diffusion_form,
+                                               sde=True, eval=True, reverse=False, last_step_size=last_step_size)
+        solver = sde(sde_drift, diffusion_fn, t0=t0, t1=t1, num_steps=num_steps, sampler_type=sampling_method)
+
+        if last_step is None:
+            last = lambda x, t, model, **kw: x  # noqa: E731
+        elif last_step == "Mean":
+            last = lambda x, t, model, **kw: x + sde_drift(x, t, model, **kw) * last_step_size  # noqa: E731
+        elif last_step == "Tweedie":
+            def last(x, t, model, **kw):
+                a, sg = ps.compute_alpha_t(t)[0][0], ps.compute_sigma_t(t)[0][0]
+                return x / a + (sg ** 2) / a * self.score(x, t, model, **kw)
+        elif last_step == "Euler":
+            last = lambda x, t, model, **kw: x + self.drift(x, t, model, **kw) * last_step_size  # noqa: E731
+        else:
+            raise NotImplementedError(f"last_step={last_step!r}")
+
+        def _sample(init, model, **model_kwargs):
+            xs = solver.sample(init, model, **model_kwargs)
+            ts = th.ones(init.size(0), device=init.device, dtype=init.dtype) * t1
+            with th.no_grad():
+                xs.append(last(xs[-1], ts, model, **model_kwargs))
+            assert len(xs) == num_steps, "Samples does not match the number of steps"
+            return xs
+
+        return _sample

@@ -112,3 +112,53 @@ def test_two_rank_sharding_and_all_gather():
     assert torch.equal(full0, full1) and full0.shape == (8, 2, 4, 4)      # every rank holds the same gathered tensor
     assert torch.equal(full0[:4], loc0) and torch.equal(full0[4:], loc1)  # rank-major order
     assert not torch.equal(loc0, loc1)                                    # rank-dependent seeds / labels
+
+
+def test_dopri5_adaptive():
+    """dx/dt = -x from 1: the dense output on the grid matches e^-t within the tolerances; tighter tolerances cost more
+    function evaluations; every call passes t as ones(B) * t."""
+    nfes = []
+    for rtol, atol, bound in ((1e-3, 1e-6, 2e-3), (1e-7, 1e-9, 1e-6)):
+        def model(x, t, y=None):
+            assert t.shape == (x.shape[0],)
+            return -x
+        sampler = Sampler(create_transport("Linear", "velocity"))
+        fn_owner = sampler.sample_ode(sampling_method="dopri5", num_steps=11, atol=atol, rtol=rtol)
+        x0 = torch.ones(3, 2, dtype=torch.float64)
+        traj = fn_owner(x0, model, y=None)
+        assert traj.shape == (11, 3, 2)
+        ts = torch.linspace(0, 1, 11, dtype=torch.float64)
+        err = (traj[:, 0, 0] - torch.exp(-ts)).abs().max().item()
+        assert err < bound, err
+        nfes.append(fn_owner.__self__.last_nfe)
+    assert nfes[0] < nfes[1] and nfes[0] >= 8            # 2 for the initial step + 6 per step
+
+
+def test_dopri5_matches_rk4_on_a_nonlinear_field():
+    def model(x, t, y=None):
+        return torch.sin(3 * t).view(-1, 1) * x - 0.5 * x ** 3
+    sampler = Sampler(create_transport("GVP", "velocity"))
+    x0 = torch.linspace(-1, 1, 8, dtype=torch.float64).view(4, 2)
+    ref = sampler.sample_ode(sampling_method="rk4", num_steps=2001)(x0, model, return_trajectory=False)
+    got = sampler.sample_ode(sampling_method="dopri5", num_steps=2, atol=1e-9, rtol=1e-8)(x0, model, return_trajectory=False)
+    assert torch.allclose(got, ref, atol=1e-7)
+
+
+@pytest.mark.parametrize("method,last_step", [("Euler", "Mean"), ("Heun", "Mean"), ("Euler", "Tweedie"), ("Euler", "Euler")])
+def test_sde_sampler_shapes_and_zero_noise_limit(method, last_step):
+    """structure of sample_sde (transport.py:286-341): number of returned states, Heun halves the grid, and with the
+    diffusion switched off (form 'none') the Euler-Maruyama path equals the fixed-grid Euler ODE path."""
+    torch.manual_seed(0)
+    sampler = Sampler(create_transport("Linear", "velocity"))
+
+    def model(x, t, y=None):
+        return -x
+
+    x0 = torch.randn(5, 3)
+    n = 20
+    xs = sampler.sample_sde(sampling_method=method, diffusion_form="sigma", last_step=last_step, last_step_size=0.04, num_steps=n)(x0, model)
+    assert len(xs) == (n if method == "Euler" else n // 2) and xs[-1].shape == x0.shape and torch.isfinite(xs[-1]).all()
+    if method == "Euler" and last_step == "Euler":
+        det = sampler.sample_sde(sampling_method="Euler", diffusion_form="none", last_step=None, num_steps=n)(x0, model)
+        ode_traj = sampler.sample_ode(sampling_method="euler", num_steps=n)(x0, model)
+        assert torch.allclose(det[-2], ode_traj[-1], atol=1e-6)
