@@ -162,9 +162,10 @@ def main():
     ap.add_argument("--image-size", type=int, default=256)
     ap.add_argument("--scan-type", default="none", help="none (published configs) | zigma_8 | sweep_8 | jpeg_8: zigzag token "
                                                          "orders inside the mixers (BASELINE configs[4])")
-    ap.add_argument("--mode", choices=["fwd", "sample", "block"], default="fwd",
+    ap.add_argument("--mode", choices=["fwd", "sample", "block", "train"], default="fwd",
                     help="fwd: denoiser forward (headline, BASELINE configs[1]); sample: --nfe Euler steps + all-gather "
-                         "(configs[3]); block: ONE DiMBlockCombined forward+backward (configs[2])")
+                         "(configs[3]); block: ONE DiMBlockCombined forward+backward (configs[2]); train: one whole "
+                         "flow-matching training step (loss, backward, DDP all-reduce over RCCL, clip, AdamW, EMA)")
     ap.add_argument("--nfe", type=int, default=250)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the extra exact-fp32 timing (for profiling runs)")
@@ -205,7 +206,16 @@ def main():
     timer = ScanTimer()
     timer.install()
 
-    if args.mode == "block":
+    if args.mode == "train":
+        from dimsum_amd.train import build_training, train_step
+        from dimsum_amd.transport import create_transport
+        ddp, ema, opt = build_training(model.train(), dev, 1e-4, world, [local_rank])
+        transport = create_transport("GVP", "velocity")
+
+        def step():
+            return train_step(ddp, ema, opt, transport, x, y)
+        units_per_step = args.batch
+    elif args.mode == "block":
         ntok = (r // 2) ** 2
         hs = torch.randn(args.batch, ntok, hidden, device=dev, generator=gen).requires_grad_()
         res = torch.randn(args.batch, ntok, hidden, device=dev, generator=gen).requires_grad_()
@@ -254,10 +264,11 @@ def main():
         value = units_per_step * world * args.steps / elapsed
         fwd_mode = args.mode == "fwd"
         what = {"fwd": "denoiser forward", "sample": f"denoiser {args.nfe}-NFE Euler sampling",
-                "block": "ONE DiMBlockCombined (scan + Haar + attention fusion + gated MLP) forward+backward"}[args.mode]
+                "block": "ONE DiMBlockCombined (scan + Haar + attention fusion + gated MLP) forward+backward",
+                "train": "flow-matching training step (GVP velocity loss, backward, grad all-reduce, clip, AdamW, EMA)"}[args.mode]
         line = {
             "metric": {"fwd": "denoiser-fwd latents/sec", "sample": f"{args.nfe}-NFE samples/sec",
-                       "block": "block fwd+bwd latents/sec"}[args.mode],
+                       "block": "block fwd+bwd latents/sec", "train": "training latents/sec"}[args.mode],
             "value": value, "unit": "samples/s" if args.mode == "sample" else "latents/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -292,7 +303,7 @@ def main():
         rb = roof("bwd", "ssm_scan_bwd_kernel<float,16>", "scan_bwd_pmc.json")
         if rb is not None:
             line["roofline_bwd"] = rb
-        if args.matmul == "tf32" and args.mode != "sample" and not args.no_fp32_leg:
+        if args.matmul == "tf32" and args.mode in ("fwd", "block") and not args.no_fp32_leg:
             # the same step with exact-fp32 library GEMMs, for reference (2 untimed + 2 timed steps)
             set_matmul("fp32")
             timer.enabled = False
@@ -306,7 +317,7 @@ def main():
             dt = (time.perf_counter() - t1) / 2
             line["fp32_exact_matmul"] = {"value_per_gpu": units_per_step / dt, "ms_per_step": 1e3 * dt}
             set_matmul("tf32")
-        if world == 1 and not args.no_cpu_baseline and args.mode != "block":
+        if world == 1 and not args.no_cpu_baseline and args.mode in ("fwd", "sample"):
             line["cpu_baseline"] = cpu_baseline(args.model, 8, args.image_size)
         print(json.dumps(line), flush=True)
     if world > 1:
