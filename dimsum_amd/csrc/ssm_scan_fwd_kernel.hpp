@@ -71,14 +71,28 @@ template <> struct UniformLd<__hip_bfloat16> {
     }
 };
 
-constexpr int kTC = 32;       // time steps per LDS tile (128-B segments per row in fp32)
-constexpr int kLdsStride = 32;  // dwords per tile row (unpadded; 16-byte slots are XOR-swizzled instead)
+#ifndef DIMSUM_SCAN_TC
+#define DIMSUM_SCAN_TC 32
+#endif
+#ifndef DIMSUM_SCAN_WAVES
+#define DIMSUM_SCAN_WAVES (DIMSUM_SCAN_TC == 16 ? 3 : 2)      // waves per SIMD the register allocation aims at
+#endif
+constexpr int kTC = DIMSUM_SCAN_TC;   // time steps per LDS tile: 32 (128-B row segments, 20 KB of LDS per wave = 2 waves per SIMD).
+                                      // 16 (64-B segments, 10 KB, 143 VGPRs = 3 waves per SIMD) was measured SLOWER at the
+                                      // config-2 shape (0.40-0.43 ms vs 0.36 ms): twice the per-tile work (staging, softplus,
+                                      // epilogue) outweighs the extra occupancy; the knob stays for other shapes.
+constexpr int kLdsStride = kTC;       // dwords per tile row (unpadded; 16-byte slots are XOR-swizzled instead)
+constexpr int kLPR = kTC / 4;         // lanes per tile row in the coalesced load layout (16 B each)
+constexpr int kRPP = kWave / kLPR;    // rows per load piece
+constexpr int kNP = kWave / kRPP;     // pieces per 64-row tile
+static_assert(kTC == 32 || kTC == 16, "tile width");
 
-// LDS image of a 64-row x 32-column fp32 tile: row r keeps its eight 16-byte slots permuted by (r >> 1) & 7.
-// ds_write_b128 in load layout (8 lanes = one row) and ds_read_b128 in lane = row layout (16-lane groups
-// {0-3,12-15,20-27}, ...) are both bank-conflict free, with no padding: 8 KB per tile, so that
-// 2 tiles + the B/C tiles = 20 KB per wave = exactly 8 waves per CU (160 KB).
-__device__ __forceinline__ int tile_off(int row, int col4) { return row * kLdsStride + ((col4 ^ ((row >> 1) & 7)) << 2); }
+// LDS image of a 64-row x kTC-column fp32 tile: row r keeps its 16-byte slots XOR-permuted -- 8 slots by (r >> 1) & 7
+// (kTC = 32), 4 slots by (r >> 2) & 3 (kTC = 16). ds_write_b128 in load layout (kLPR lanes = one row) and ds_read_b128 in
+// lane = row layout are both bank-conflict free, with no padding.
+__device__ __forceinline__ int tile_off(int row, int col4) {
+    return kTC == 32 ? row * kLdsStride + ((col4 ^ ((row >> 1) & 7)) << 2) : row * kLdsStride + ((col4 ^ ((row >> 2) & 3)) << 2);
+}
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -93,7 +107,7 @@ template <typename T> __device__ __forceinline__ T *at(T *base, unsigned elem_of
 // kVec : every row base is 4-element aligned and L % 4 == 0 -> 16-byte (fp32) vector I/O, register-staged prefetch.
 // kFull: dim/n_groups % 64 == 0 -> all 64 lanes own a live channel, no row masks anywhere (needs kVec).
 template <typename T, int kN, bool kHasZ, bool kVec, bool kFull, bool kCkpt = false>
-__global__ __launch_bounds__(kWave, 2) void ssm_scan_fwd_kernel(const dimsum_ssm_params_t p) {
+__global__ __launch_bounds__(kWave, DIMSUM_SCAN_WAVES) void ssm_scan_fwd_kernel(const dimsum_ssm_params_t p) {
     static_assert(!kFull || kVec, "kFull implies kVec");
     __shared__ __attribute__((aligned(16))) float tileU[kWave * kLdsStride];
     __shared__ __attribute__((aligned(16))) float tileD[kWave * kLdsStride];
@@ -146,30 +160,30 @@ __global__ __launch_bounds__(kWave, 2) void ssm_scan_fwd_kernel(const dimsum_ssm
                          ? reinterpret_cast<float *>(p.ckpt_ptr) + (int64_t)b * ((L + 7) / 8) * kN * p.dim + d : nullptr;
 
     const int n_tiles = (L + kTC - 1) / kTC;
-    // load layout: piece i of the tile, lane -> (row = i*8 + lane/8, 4 columns at (lane%8)*4)
-    const int lrow = lane >> 3, lcol = (lane & 7) * 4;
+    // load layout: piece i of the tile, lane -> (row = i*kRPP + lane/kLPR, 4 columns at (lane%kLPR)*4)
+    const int lrow = lane / kLPR, lc4 = lane & (kLPR - 1), lcol = lc4 * 4;
 
-    constexpr int kBCPieces = (kN * 8 + kWave - 1) / kWave;   // 16-byte pieces per lane of a [kN][32] tile
-    Raw4<T> ru[8], rd[8], rz[8], rb[kBCPieces], rc[kBCPieces];
+    constexpr int kBCPieces = (kN * kLPR + kWave - 1) / kWave;   // 16-byte pieces per lane of a [kN][kTC] tile
+    Raw4<T> ru[kNP], rd[kNP], rz[kNP], rb[kBCPieces], rc[kBCPieces];
     // Branch-free tile loads: rows beyond nd are clamped to the last live row, columns beyond L to the last
     // 4-column group (L % 4 == 0 on this path); the duplicates are never stored.
     // Address = wave-uniform (base + i * 8 * stride) + one per-lane 32-bit offset per tensor, so the 8 pieces of a tile
     // share a single VGPR offset (saddr + voffset addressing) instead of 8 precomputed per-lane addresses.
     auto col_of = [&](int t0) { return min(t0 + lcol, L - 4); };
     auto piece = [&](const T *base, int ds, int i, int col) -> const T * {   // address of piece i of a tile
-        if constexpr (kFull) return at(base + i * 8 * ds, (unsigned)(lrow * ds + col));
-        else return at(base, (unsigned)(min(i * 8 + lrow, nd - 1) * ds + col));   // clamped row: never negative
+        if constexpr (kFull) return at(base + i * kRPP * ds, (unsigned)(lrow * ds + col));
+        else return at(base, (unsigned)(min(i * kRPP + lrow, nd - 1) * ds + col));   // clamped row: never negative
     };
     auto issue_loads = [&](int t0) {
         const int col = col_of(t0);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < kNP; ++i) {
             ru[i] = ld4<T>(piece(u_base, u_ds, i, col));
             rd[i] = ld4<T>(piece(dl_base, dl_ds, i, col));
         }
 #pragma unroll
         for (int i = 0; i < kBCPieces; ++i) {
-            const int n = min(i * 8 + lrow, kN - 1);
+            const int n = min(i * kRPP + lrow, kN - 1);
             rb[i] = ld4<T>(at(Bp, (unsigned)(n * Bns + col)));
             rc[i] = ld4<T>(at(Cp, (unsigned)(n * Cns + col)));
         }
@@ -183,15 +197,15 @@ __global__ __launch_bounds__(kWave, 2) void ssm_scan_fwd_kernel(const dimsum_ssm
         // ---- stage the tile into LDS (transposing layout) ------------------------------------------------------
         if constexpr (kVec) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = i * 8 + lrow;
-                *reinterpret_cast<f32x4 *>(&tileU[tile_off(row, lane & 7)]) = widen(ru[i]);
-                *reinterpret_cast<f32x4 *>(&tileD[tile_off(row, lane & 7)]) = widen(rd[i]);
+            for (int i = 0; i < kNP; ++i) {
+                const int row = i * kRPP + lrow;
+                *reinterpret_cast<f32x4 *>(&tileU[tile_off(row, lc4)]) = widen(ru[i]);
+                *reinterpret_cast<f32x4 *>(&tileD[tile_off(row, lc4)]) = widen(rd[i]);
             }
 #pragma unroll
             for (int i = 0; i < kBCPieces; ++i) {
-                const int n = i * 8 + lrow;
-                if (kN * 8 % kWave == 0 || n < kN) {
+                const int n = i * kRPP + lrow;
+                if (kN * kLPR % kWave == 0 || n < kN) {
                     *reinterpret_cast<f32x4 *>(&tileB[n * kTC + lcol]) = widen(rb[i]);
                     *reinterpret_cast<f32x4 *>(&tileC[n * kTC + lcol]) = widen(rc[i]);
                 }
@@ -200,18 +214,18 @@ __global__ __launch_bounds__(kWave, 2) void ssm_scan_fwd_kernel(const dimsum_ssm
             if constexpr (kHasZ) {
                 const int col = col_of(t0);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) rz[i] = ld4<T>(piece(z_base, z_ds, i, col));
+                for (int i = 0; i < kNP; ++i) rz[i] = ld4<T>(piece(z_base, z_ds, i, col));
             }
         } else {
             // generic path (unaligned rows or L % 4 != 0): element-wise, still coalesced along L
             for (int i = 0; i < kTC; ++i) {
-                const int idx = i * kWave + lane, row = idx >> 5, col = idx & 31;
+                const int idx = i * kWave + lane, row = idx / kTC, col = idx & (kTC - 1);
                 const bool ok = row < nd && t0 + col < L;
                 tileU[tile_off(row, col >> 2) + (col & 3)] = ok ? to_f32<T>(u_base[(unsigned)(row * u_ds + t0 + col)]) : 0.f;
                 tileD[tile_off(row, col >> 2) + (col & 3)] = ok ? to_f32<T>(dl_base[(unsigned)(row * dl_ds + t0 + col)]) : 0.f;
             }
             for (int idx = lane; idx < kN * kTC; idx += kWave) {
-                const int n = idx >> 5, tc = min(t0 + (idx & 31), L - 1);
+                const int n = idx / kTC, tc = min(t0 + (idx & (kTC - 1)), L - 1);
                 tileB[idx] = to_f32<T>(Bp[(unsigned)(n * Bns + tc)]);
                 tileC[idx] = to_f32<T>(Cp[(unsigned)(n * Cns + tc)]);
             }
@@ -286,23 +300,23 @@ __global__ __launch_bounds__(kWave, 2) void ssm_scan_fwd_kernel(const dimsum_ssm
         if constexpr (kVec) {
             if (t0 + lcol < L) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int row = i * 8 + lrow;
+                for (int i = 0; i < kNP; ++i) {
+                    const int row = i * kRPP + lrow;
                     if (kFull || row < nd) {
-                        f32x4 y4 = *reinterpret_cast<const f32x4 *>(&tileU[tile_off(row, lane & 7)]);
-                        if (has_out) st4<T>(at(out_base + i * 8 * out_ds, (unsigned)(lrow * out_ds + t0 + lcol)), y4);
+                        f32x4 y4 = *reinterpret_cast<const f32x4 *>(&tileU[tile_off(row, lc4)]);
+                        if (has_out) st4<T>(at(out_base + i * kRPP * out_ds, (unsigned)(lrow * out_ds + t0 + lcol)), y4);
                         if constexpr (kHasZ) {
                             const f32x4 z4 = widen(rz[i]);
 #pragma unroll
                             for (int s = 0; s < 4; ++s) y4.v[s] *= z4.v[s] * sigmoidf_fast(z4.v[s]);
-                            st4<T>(at(oz_base + i * 8 * oz_ds, (unsigned)(lrow * oz_ds + t0 + lcol)), y4);
+                            st4<T>(at(oz_base + i * kRPP * oz_ds, (unsigned)(lrow * oz_ds + t0 + lcol)), y4);
                         }
                     }
                 }
             }
         } else {
             for (int i = 0; i < kTC; ++i) {
-                const int idx = i * kWave + lane, row = idx >> 5, col = idx & 31;
+                const int idx = i * kWave + lane, row = idx / kTC, col = idx & (kTC - 1);
                 if (row < nd && t0 + col < L) {
                     const float yv = tileU[tile_off(row, col >> 2) + (col & 3)];
                     if (out_base) out_base[(unsigned)(row * out_ds + t0 + col)] = from_f32<T>(yv);
@@ -360,10 +374,12 @@ static int launch_fwd(const dimsum_ssm_params_t &p, hipStream_t stream) {
 template <typename T>
 int ssm_scan_fwd_dispatch(const dimsum_ssm_params_t &p, hipStream_t stream) {
     switch (p.dstate) {
+#ifndef DIMSUM_DEV_ONE      // development builds instantiate the headline variant only
         case 4: return launch_fwd<T, 4>(p, stream);
         case 8: return launch_fwd<T, 8>(p, stream);
-        case 16: return launch_fwd<T, 16>(p, stream);
         case 32: return launch_fwd<T, 32>(p, stream);
+#endif
+        case 16: return launch_fwd<T, 16>(p, stream);
         default: return DIMSUM_ERR_SHAPE;
     }
 }
