@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kWave, 2) void ssm_scan_bwd_kernel(const dimsum_ssm
     // a uniform switch moves the group's dh in and out of the static register array.
     constexpr bool kRegState = kN <= 16;
     __shared__ float sdA[kN * kWave], sdh[kRegState ? 1 : kN * kWave];
-    float rdh[kRegState ? kN : 1];
+    float rdh[kRegState ? kN : 1];      // only ever indexed with compile-time constants (see the group loop)
 
     const int lane = threadIdx.x;
     const int L = p.seqlen;
@@ -295,7 +295,8 @@ __global__ __launch_bounds__(kWave, 2) void ssm_scan_bwd_kernel(const dimsum_ssm
 #pragma unroll
             for (int t = 0; t < kBS; ++t) { s1[t] = 0.f; s2[t] = 0.f; }
 
-            auto group = [&](const int n0) {
+#pragma unroll 1
+            for (int n0 = 0; n0 < kN; n0 += kBG) {
                 float H[kBG * kBS];       // [k][t]: h_t of state n0+k, later overwritten by the dB terms
                 float hk[kBG], Ak[kBG], dAk[kBG], dhk[kBG];
 #pragma unroll
@@ -306,9 +307,15 @@ __global__ __launch_bounds__(kWave, 2) void ssm_scan_bwd_kernel(const dimsum_ssm
                     if constexpr (!kRegState) dhk[k] = sdh[(n0 + k) * kWave + lane];
                 }
                 if constexpr (kRegState) {
-#define DIMSUM_GET(G) case G * kBG: _Pragma("unroll") for (int k = 0; k < kBG; ++k) { if (G * kBG + k < kN) dhk[k] = rdh[G * kBG + k]; } break;
-                    switch (n0) { DIMSUM_GET(0) DIMSUM_GET(1) DIMSUM_GET(2) default: DIMSUM_GET(3) }
-#undef DIMSUM_GET
+                    // uniform selects on static indices (a `switch` gets merged into a dynamically indexed private array,
+                    // i.e. scratch memory = HBM round trips in the hot loop)
+#pragma unroll
+                    for (int k = 0; k < kBG; ++k) {
+                        float v = rdh[k];
+#pragma unroll
+                        for (int gq = 1; gq < kN / kBG; ++gq) v = (n0 == gq * kBG) ? rdh[gq * kBG + k] : v;
+                        dhk[k] = v;
+                    }
                 }
                 {   // prefetch the saved states of the next group (next kBG states of this half, or the previous half's first)
                     const bool wrap = n0 + kBG >= kN;
@@ -316,21 +323,26 @@ __global__ __launch_bounds__(kWave, 2) void ssm_scan_bwd_kernel(const dimsum_ssm
 #pragma unroll
                     for (int k = 0; k < kBG; ++k) { h_pre[k] = ck_lane[((int64_t)nh * kN + nn + k) * ck_ns]; a_pre[k] = Ap[(nn + k) * A_ns]; }
                 }
-                // ---- forward sweep: h_t for the 8 steps of the half -------------------------------------------------------
+                // ---- forward sweep: h_t for the 8 steps of the half (B row of the next (slot, state) fetched one ahead) --------
+                {
+                    f32x4 bq_nxt = *reinterpret_cast<const f32x4 *>(&tB[n0 * kBT + jb * 4]);
 #pragma unroll
-                for (int jj = 0; jj < kBS / 4; ++jj) {
-                    const f32x4 u4 = *reinterpret_cast<const f32x4 *>(&tU[btile_off(lane, jb + jj)]);
-                    const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&tD[btile_off(lane, jb + jj)]);
-                    float du[4];
+                    for (int jj = 0; jj < kBS / 4; ++jj) {
+                        const f32x4 u4 = *reinterpret_cast<const f32x4 *>(&tU[btile_off(lane, jb + jj)]);
+                        const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&tD[btile_off(lane, jb + jj)]);
+                        float du[4];
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) du[s] = d4.v[s] * u4.v[s];
+                        for (int s = 0; s < 4; ++s) du[s] = d4.v[s] * u4.v[s];
 #pragma unroll
-                    for (int k = 0; k < kBG; ++k) {
-                        const f32x4 bq = *reinterpret_cast<const f32x4 *>(&tB[(n0 + k) * kBT + (jb + jj) * 4]);
+                        for (int k = 0; k < kBG; ++k) {
+                            const f32x4 bq = bq_nxt;
+                            if (k + 1 < kBG) bq_nxt = *reinterpret_cast<const f32x4 *>(&tB[(n0 + k + 1) * kBT + (jb + jj) * 4]);
+                            else if (jj + 1 < kBS / 4) bq_nxt = *reinterpret_cast<const f32x4 *>(&tB[n0 * kBT + (jb + jj + 1) * 4]);
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) {
-                            hk[k] = fmaf(fast_exp2(d4.v[s] * Ak[k]), hk[k], bq.v[s] * du[s]);
-                            H[k * kBS + jj * 4 + s] = hk[k];
+                            for (int s = 0; s < 4; ++s) {
+                                hk[k] = fmaf(fast_exp2(d4.v[s] * Ak[k]), hk[k], bq.v[s] * du[s]);
+                                H[k * kBS + jj * 4 + s] = hk[k];
+                            }
                         }
                     }
                 }
@@ -347,35 +359,46 @@ __global__ __launch_bounds__(kWave, 2) void ssm_scan_bwd_kernel(const dimsum_ssm
                     const int vi = lane & (NV - 1);
                     if (lane < NV) tdC[(n0 + (vi >> 3)) * kBT + half * kBS + (vi & 7)] = r;
                 }
-                // ---- reverse sweep -------------------------------------------------------------------------------------------
+                // ---- reverse sweep (B / C rows of the next (slot, state) are fetched one iteration ahead) -------------------
+                {
+                    f32x4 bq_nxt = *reinterpret_cast<const f32x4 *>(&tB[n0 * kBT + (jb + kBS / 4 - 1) * 4]);
+                    f32x4 cq_nxt = *reinterpret_cast<const f32x4 *>(&tC[n0 * kBT + (jb + kBS / 4 - 1) * 4]);
+                    float dt_succ = dt_after;       // dt of the step after the current slot
 #pragma unroll
-                for (int jj = kBS / 4 - 1; jj >= 0; --jj) {
-                    const f32x4 u4 = *reinterpret_cast<const f32x4 *>(&tU[btile_off(lane, jb + jj)]);
-                    const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&tD[btile_off(lane, jb + jj)]);
-                    const f32x4 y4 = *reinterpret_cast<const f32x4 *>(&tY[btile_off(lane, jb + jj)]);
-                    float dnext[4], du[4];       // dt of step t+1; dt u
+                    for (int jj = kBS / 4 - 1; jj >= 0; --jj) {
+                        const f32x4 u4 = *reinterpret_cast<const f32x4 *>(&tU[btile_off(lane, jb + jj)]);
+                        const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&tD[btile_off(lane, jb + jj)]);
+                        const f32x4 y4 = *reinterpret_cast<const f32x4 *>(&tY[btile_off(lane, jb + jj)]);
+                        float dnext[4], du[4];       // dt of step t+1; dt u
 #pragma unroll
-                    for (int s = 0; s < 3; ++s) dnext[s] = d4.v[s + 1];
-                    if (jj == kBS / 4 - 1) dnext[3] = dt_after;
-                    else dnext[3] = (*reinterpret_cast<const f32x4 *>(&tD[btile_off(lane, jb + jj + 1)])).v[0];
+                        for (int s = 0; s < 3; ++s) dnext[s] = d4.v[s + 1];
+                        dnext[3] = dt_succ;
+                        dt_succ = d4.v[0];
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) du[s] = d4.v[s] * u4.v[s];
+                        for (int s = 0; s < 4; ++s) du[s] = d4.v[s] * u4.v[s];
 #pragma unroll
-                    for (int k = 0; k < kBG; ++k) {
-                        const f32x4 bq = *reinterpret_cast<const f32x4 *>(&tB[(n0 + k) * kBT + (jb + jj) * 4]);
-                        const f32x4 cq = *reinterpret_cast<const f32x4 *>(&tC[(n0 + k) * kBT + (jb + jj) * 4]);
+                        for (int k = 0; k < kBG; ++k) {
+                            const f32x4 bq = bq_nxt, cq = cq_nxt;
+                            if (k + 1 < kBG) {
+                                bq_nxt = *reinterpret_cast<const f32x4 *>(&tB[(n0 + k + 1) * kBT + (jb + jj) * 4]);
+                                cq_nxt = *reinterpret_cast<const f32x4 *>(&tC[(n0 + k + 1) * kBT + (jb + jj) * 4]);
+                            } else if (jj > 0) {
+                                bq_nxt = *reinterpret_cast<const f32x4 *>(&tB[n0 * kBT + (jb + jj - 1) * 4]);
+                                cq_nxt = *reinterpret_cast<const f32x4 *>(&tC[n0 * kBT + (jb + jj - 1) * 4]);
+                            }
 #pragma unroll
-                        for (int s = 3; s >= 0; --s) {
-                            const int t = jj * 4 + s;
-                            const float a_next = fast_exp2(dnext[s] * Ak[k]);
-                            const float dhn = fmaf(a_next, dhk[k], cq.v[s] * y4.v[s]);
-                            dhk[k] = dhn;
-                            const float ah = fmaf(-bq.v[s], du[s], H[k * kBS + t]);     // a_t h_{t-1} = h_t - b_t
-                            const float gterm = dhn * ah;
-                            dAk[k] = fmaf(gterm, d4.v[s], dAk[k]);
-                            s2[t] = fmaf(gterm, Ak[k], s2[t]);
-                            s1[t] = fmaf(dhn, bq.v[s], s1[t]);
-                            H[k * kBS + t] = dhn * du[s];                               // dB term
+                            for (int s = 3; s >= 0; --s) {
+                                const int t = jj * 4 + s;
+                                const float a_next = fast_exp2(dnext[s] * Ak[k]);
+                                const float dhn = fmaf(a_next, dhk[k], cq.v[s] * y4.v[s]);
+                                dhk[k] = dhn;
+                                const float ah = fmaf(-bq.v[s], du[s], H[k * kBS + t]);     // a_t h_{t-1} = h_t - b_t
+                                const float gterm = dhn * ah;
+                                dAk[k] = fmaf(gterm, d4.v[s], dAk[k]);
+                                s2[t] = fmaf(gterm, Ak[k], s2[t]);
+                                s1[t] = fmaf(dhn, bq.v[s], s1[t]);
+                                H[k * kBS + t] = dhn * du[s];                               // dB term
+                            }
                         }
                     }
                 }
@@ -385,9 +408,10 @@ __global__ __launch_bounds__(kWave, 2) void ssm_scan_bwd_kernel(const dimsum_ssm
                     if constexpr (!kRegState) sdh[(n0 + k) * kWave + lane] = dhk[k];
                 }
                 if constexpr (kRegState) {
-#define DIMSUM_PUT(G) case G * kBG: _Pragma("unroll") for (int k = 0; k < kBG; ++k) { if (G * kBG + k < kN) rdh[G * kBG + k] = dhk[k]; } break;
-                    switch (n0) { DIMSUM_PUT(0) DIMSUM_PUT(1) DIMSUM_PUT(2) default: DIMSUM_PUT(3) }
-#undef DIMSUM_PUT
+#pragma unroll
+                    for (int gq = 0; gq < kN / kBG; ++gq)
+#pragma unroll
+                        for (int k = 0; k < kBG; ++k) rdh[gq * kBG + k] = (n0 == gq * kBG) ? dhk[k] : rdh[gq * kBG + k];
                 }
                 // ---- dB[n, t] = sum_d dh_t[n] dt_t u_t -----------------------------------------------------------------------
                 {
@@ -395,9 +419,7 @@ __global__ __launch_bounds__(kWave, 2) void ssm_scan_bwd_kernel(const dimsum_ssm
                     const int vi = lane & (NV - 1);
                     if (lane < NV) tdB[(n0 + (vi >> 3)) * kBT + half * kBS + (vi & 7)] = r;
                 }
-            };
-#pragma unroll 1
-            for (int n0 = 0; n0 < kN; n0 += kBG) group(n0);
+            }
 
             // ---- per-(d, t) results of the half: du, ddelta (softplus chain), dD, ddelta_bias; parked in LDS over u / dy
             //      (s2 was accumulated with A * log2 e) ----------------------------------------------------------------------

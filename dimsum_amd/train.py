@@ -99,11 +99,13 @@ def main(argv=None):
     torch.backends.cuda.matmul.allow_tf32 = args.tf32          # train.py:20-21
     torch.backends.cudnn.allow_tf32 = args.tf32
 
-    dist.init_process_group("nccl")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)            # before the process group: every rank binds its own GPU
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     rank, world = dist.get_rank(), dist.get_world_size()
     assert args.global_batch_size % world == 0, "Batch size must be divisible by world size."
-    device = rank % torch.cuda.device_count()
-    torch.cuda.set_device(device)
+    device = local_rank
     torch.manual_seed(args.global_seed * world + rank)
     model = create_model(published_config(args.model, args.image_size, args.num_classes)).to(device)
     model, ema, opt = build_training(model, device, args.lr, world, [device])
