@@ -11,7 +11,8 @@ from . import native
 
 
 class _XattnCoreFn(torch.autograd.Function):
-    """fused (B, N, 2C) = cat(x12, x21) from bias-free qkv GEMM outputs + the qkv biases"""
+    """fused (B, N, 2C) = cat(x12, x21) from bias-free qkv GEMM outputs + the qkv biases; with qkv2 = None plain
+    self-attention (B, N, C) of qkv1 (the shared DiTBlock)"""
 
     @staticmethod
     def forward(ctx, qkv1, qkv2, bias1, bias2, heads):
@@ -28,7 +29,7 @@ class _XattnCoreFn(torch.autograd.Function):
         dqkv1, dqkv2 = native.xattn_fusion_bwd(qkv1, qkv2, out, lse, dout, ctx.heads, bias1=b1, bias2=b2)
         W = dqkv1.shape[-1]
         db1 = dqkv1.reshape(-1, W).sum(0) if (b1 is not None and ctx.needs_input_grad[2]) else None
-        db2 = dqkv2.reshape(-1, W).sum(0) if (b2 is not None and ctx.needs_input_grad[3]) else None
+        db2 = dqkv2.reshape(-1, W).sum(0) if (b2 is not None and dqkv2 is not None and ctx.needs_input_grad[3]) else None
         return dqkv1, dqkv2, db1, db2, None
 
 

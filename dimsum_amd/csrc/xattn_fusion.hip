@@ -43,18 +43,20 @@ __global__ __launch_bounds__(256) void xattn_fusion_fwd_kernel(const dimsum_xatt
     const int qblocks = (L + 63) / 64;
     int idx = blockIdx.x;
     const int qb = idx % qblocks; idx /= qblocks;
-    const int dir = idx & 1; idx >>= 1;
+    const int ndir = p.n_dirs == 1 ? 1 : 2;
+    const int dir = idx % ndir; idx /= ndir;
     const int h = idx % H;
     const int b = idx / H;
     const int C = H * HD;
-    // direction 0: q1, k2, v2   direction 1: q2, k1, v1
+    // direction 0: q1, k2, v2   direction 1: q2, k1, v1   (self-attention, n_dirs = 1: q1, k1, v1)
+    const bool kv_from_1 = dir == 1 || ndir == 1;
     const float *qsrc = reinterpret_cast<const float *>(dir == 0 ? p.qkv1_ptr : p.qkv2_ptr) + (int64_t)b * p.qkv_batch_stride + h * HD;
-    const float *kvsrc = reinterpret_cast<const float *>(dir == 0 ? p.qkv2_ptr : p.qkv1_ptr) + (int64_t)b * p.qkv_batch_stride + h * HD;
+    const float *kvsrc = reinterpret_cast<const float *>(kv_from_1 ? p.qkv1_ptr : p.qkv2_ptr) + (int64_t)b * p.qkv_batch_stride + h * HD;
     const float *ksrc = kvsrc + C, *vsrc = kvsrc + 2 * C;
     const int64_t ts = p.qkv_token_stride;
     // optional qkv Linear biases (the GEMMs then run without a bias epilogue): same [q | k | v], head-major layout
     const float *qbv = reinterpret_cast<const float *>(dir == 0 ? p.bias1_ptr : p.bias2_ptr);
-    const float *kvb = reinterpret_cast<const float *>(dir == 0 ? p.bias2_ptr : p.bias1_ptr);
+    const float *kvb = reinterpret_cast<const float *>(kv_from_1 ? p.bias1_ptr : p.bias2_ptr);
     const float *qbias = qbv ? qbv + h * HD : nullptr;
     const float *kbias = kvb ? kvb + C + h * HD : nullptr, *vbias = kvb ? kvb + 2 * C + h * HD : nullptr;
 
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256) void xattn_fusion_fwd_kernel(const dimsum_xatt
             if (e0 < HD) *reinterpret_cast<float4 *>(dst + e0) = make_float4(o[e][0] * inv, o[e][1] * inv, o[e][2] * inv, o[e][3] * inv);
         }
         if (p.lse_ptr && kg == 0)
-            reinterpret_cast<float *>(p.lse_ptr)[(((int64_t)b * 2 + dir) * H + h) * L + q_tok] = (m_run + __builtin_amdgcn_logf(l_run)) * kLn2;
+            reinterpret_cast<float *>(p.lse_ptr)[(((int64_t)b * ndir + dir) * H + h) * L + q_tok] = (m_run + __builtin_amdgcn_logf(l_run)) * kLn2;
     }
 }
 
@@ -184,16 +186,18 @@ __global__ __launch_bounds__(256) void xattn_fusion_fwd_kernel(const dimsum_xatt
 
 extern "C" int dimsum_xattn_fusion_fwd(const dimsum_xattn_params_t *p, void *stream) {
     using namespace dimsum;
-    if (!p || !p->qkv1_ptr || !p->qkv2_ptr || !p->out_ptr) return DIMSUM_ERR_NULL;
+    const bool self_attn = p && p->n_dirs == 1;
+    if (!p || !p->qkv1_ptr || (!self_attn && !p->qkv2_ptr) || !p->out_ptr) return DIMSUM_ERR_NULL;
+    if (p->n_dirs != 0 && p->n_dirs != 1 && p->n_dirs != 2) return DIMSUM_ERR_SHAPE;
     if (p->batch < 0 || p->seqlen <= 0 || p->heads <= 0) return DIMSUM_ERR_SHAPE;
-    if ((p->bias1_ptr == nullptr) != (p->bias2_ptr == nullptr)) return DIMSUM_ERR_NULL;
-    if (p->bias1_ptr && (!aligned_to<float>(p->bias1_ptr, 16) || !aligned_to<float>(p->bias2_ptr, 16))) return DIMSUM_ERR_STRIDE;
-    if (!aligned_to<float>(p->qkv1_ptr, 16) || !aligned_to<float>(p->qkv2_ptr, 16) || !aligned_to<float>(p->out_ptr, 16) ||
+    if (!self_attn && (p->bias1_ptr == nullptr) != (p->bias2_ptr == nullptr)) return DIMSUM_ERR_NULL;
+    if ((p->bias1_ptr && !aligned_to<float>(p->bias1_ptr, 16)) || (!self_attn && p->bias2_ptr && !aligned_to<float>(p->bias2_ptr, 16))) return DIMSUM_ERR_STRIDE;
+    if (!aligned_to<float>(p->qkv1_ptr, 16) || (!self_attn && !aligned_to<float>(p->qkv2_ptr, 16)) || !aligned_to<float>(p->out_ptr, 16) ||
         p->qkv_batch_stride % 4 != 0 || p->qkv_token_stride % 4 != 0 || p->out_batch_stride % 4 != 0 || p->out_token_stride % 4 != 0)
         return DIMSUM_ERR_STRIDE;
     if (p->batch == 0) return DIMSUM_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int64_t nblk = (int64_t)p->batch * p->heads * 2 * ((p->seqlen + 63) / 64);
+    const int64_t nblk = (int64_t)p->batch * p->heads * (self_attn ? 1 : 2) * ((p->seqlen + 63) / 64);
     if (nblk > 0x7fffffff) return DIMSUM_ERR_SHAPE;
     const dim3 grid((unsigned)nblk), block(256);
     switch (p->head_dim) {

@@ -35,13 +35,14 @@ struct XSrc {
 };
 __device__ __forceinline__ XSrc xattn_src(const dimsum_xattn_bwd_params_t &p, int b, int h, int dir, int HD) {
     const int C = p.fwd.heads * HD;
+    const bool kv1 = dir == 1 || p.fwd.n_dirs == 1;        // k, v (and dk, dv) live in tensor 1: direction 1, or self-attention
     const int64_t off = (int64_t)b * p.fwd.qkv_batch_stride + h * HD, doff = (int64_t)b * p.dqkv_batch_stride + h * HD;
     const float *qs = reinterpret_cast<const float *>(dir == 0 ? p.fwd.qkv1_ptr : p.fwd.qkv2_ptr) + off;
-    const float *kvs = reinterpret_cast<const float *>(dir == 0 ? p.fwd.qkv2_ptr : p.fwd.qkv1_ptr) + off;
+    const float *kvs = reinterpret_cast<const float *>(kv1 ? p.fwd.qkv1_ptr : p.fwd.qkv2_ptr) + off;
     const float *qbias = reinterpret_cast<const float *>(dir == 0 ? p.fwd.bias1_ptr : p.fwd.bias2_ptr);
-    const float *kvbias = reinterpret_cast<const float *>(dir == 0 ? p.fwd.bias2_ptr : p.fwd.bias1_ptr);
+    const float *kvbias = reinterpret_cast<const float *>(kv1 ? p.fwd.bias1_ptr : p.fwd.bias2_ptr);
     float *dqs = reinterpret_cast<float *>(dir == 0 ? p.dqkv1_ptr : p.dqkv2_ptr) + doff;
-    float *dkvs = reinterpret_cast<float *>(dir == 0 ? p.dqkv2_ptr : p.dqkv1_ptr) + doff;
+    float *dkvs = reinterpret_cast<float *>(kv1 ? p.dqkv1_ptr : p.dqkv2_ptr) + doff;
     XSrc s;
     s.q = qs; s.k = kvs + C; s.v = kvs + 2 * C;
     s.qb = qbias ? qbias + h * HD : nullptr;
@@ -76,7 +77,8 @@ __global__ __launch_bounds__(256) void xattn_bwd_dq_kernel(const dimsum_xattn_bw
     const int qblocks = (L + 63) / 64;
     int idx = blockIdx.x;
     const int qblk = idx % qblocks; idx /= qblocks;
-    const int dir = idx & 1; idx >>= 1;
+    const int ndir = p.fwd.n_dirs == 1 ? 1 : 2;
+    const int dir = idx % ndir; idx /= ndir;
     const int h = idx % H;
     const int b = idx / H;
     const int C = H * HD;
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void xattn_bwd_dq_kernel(const dimsum_xattn_bw
     }
     dpart += __shfl_xor(dpart, 16, kWave);
     dpart += __shfl_xor(dpart, 32, kWave);                    // D of this lane's query
-    const int64_t stat = (((int64_t)b * 2 + dir) * H + h) * L + q_ld;
+    const int64_t stat = (((int64_t)b * ndir + dir) * H + h) * L + q_ld;
     const float lse2 = reinterpret_cast<const float *>(p.fwd.lse_ptr)[stat] * kLog2e;
     if (q_tok < L && kg == 0) reinterpret_cast<float *>(p.delta_ptr)[stat] = dpart;
 
@@ -194,14 +196,15 @@ __global__ __launch_bounds__(256) void xattn_bwd_dkv_kernel(const dimsum_xattn_b
     const int kblocks = (L + 63) / 64;
     int idx = blockIdx.x;
     const int kblk = idx % kblocks; idx /= kblocks;
-    const int dir = idx & 1; idx >>= 1;
+    const int ndir = p.fwd.n_dirs == 1 ? 1 : 2;
+    const int dir = idx % ndir; idx /= ndir;
     const int h = idx % H;
     const int b = idx / H;
     const int C = H * HD;
     const XSrc s = xattn_src(p, b, h, dir, HD);
     const int64_t ts = p.fwd.qkv_token_stride, dts = p.dqkv_token_stride;
     const float *dobase = reinterpret_cast<const float *>(p.dout_ptr) + (int64_t)b * p.fwd.out_batch_stride + dir * C + h * HD;
-    const int64_t stat0 = (((int64_t)b * 2 + dir) * H + h) * L;
+    const int64_t stat0 = (((int64_t)b * ndir + dir) * H + h) * L;
     const float *lse = reinterpret_cast<const float *>(p.fwd.lse_ptr) + stat0;
     const float *dlt = reinterpret_cast<const float *>(p.delta_ptr) + stat0;
 
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(256) void xattn_bwd_dkv_kernel(const dimsum_xattn_b
 
 template <int HD>
 static int launch_xbwd(const dimsum_xattn_bwd_params_t &p, hipStream_t s) {
-    const int64_t nblk = (int64_t)p.fwd.batch * p.fwd.heads * 2 * ((p.fwd.seqlen + 63) / 64);
+    const int64_t nblk = (int64_t)p.fwd.batch * p.fwd.heads * (p.fwd.n_dirs == 1 ? 1 : 2) * ((p.fwd.seqlen + 63) / 64);
     if (nblk > 0x7fffffff) return DIMSUM_ERR_SHAPE;
     hipLaunchKernelGGL(xattn_bwd_dq_kernel<HD>, dim3((unsigned)nblk), dim3(256), 0, s, p);
     if (launch_status() != DIMSUM_OK) return DIMSUM_ERR_LAUNCH;
@@ -307,13 +310,15 @@ static int launch_xbwd(const dimsum_xattn_bwd_params_t &p, hipStream_t s) {
 
 extern "C" int dimsum_xattn_fusion_bwd(const dimsum_xattn_bwd_params_t *p, void *stream) {
     using namespace dimsum;
-    if (!p || !p->fwd.qkv1_ptr || !p->fwd.qkv2_ptr || !p->fwd.out_ptr || !p->fwd.lse_ptr || !p->dout_ptr || !p->dqkv1_ptr ||
-        !p->dqkv2_ptr || !p->delta_ptr)
+    const bool self_attn = p && p->fwd.n_dirs == 1;
+    if (!p || !p->fwd.qkv1_ptr || (!self_attn && !p->fwd.qkv2_ptr) || !p->fwd.out_ptr || !p->fwd.lse_ptr || !p->dout_ptr || !p->dqkv1_ptr ||
+        (!self_attn && !p->dqkv2_ptr) || !p->delta_ptr)
         return DIMSUM_ERR_NULL;
     const dimsum_xattn_params_t &f = p->fwd;
-    if (f.batch < 0 || f.seqlen <= 0 || f.heads <= 0) return DIMSUM_ERR_SHAPE;
-    if ((f.bias1_ptr == nullptr) != (f.bias2_ptr == nullptr)) return DIMSUM_ERR_NULL;
-    const void *ptrs[] = {f.qkv1_ptr, f.qkv2_ptr, f.out_ptr, p->dout_ptr, p->dqkv1_ptr, p->dqkv2_ptr, f.bias1_ptr, f.bias2_ptr};
+    if (f.batch < 0 || f.seqlen <= 0 || f.heads <= 0 || (f.n_dirs != 0 && f.n_dirs != 1 && f.n_dirs != 2)) return DIMSUM_ERR_SHAPE;
+    if (!self_attn && (f.bias1_ptr == nullptr) != (f.bias2_ptr == nullptr)) return DIMSUM_ERR_NULL;
+    const void *ptrs[] = {f.qkv1_ptr, self_attn ? nullptr : f.qkv2_ptr, f.out_ptr, p->dout_ptr, p->dqkv1_ptr, self_attn ? nullptr : p->dqkv2_ptr,
+                          f.bias1_ptr, self_attn ? nullptr : f.bias2_ptr};
     for (const void *q : ptrs)
         if (q && !aligned_to<float>(q, 16)) return DIMSUM_ERR_STRIDE;
     if (f.qkv_batch_stride % 4 || f.qkv_token_stride % 4 || f.out_batch_stride % 4 || f.out_token_stride % 4 || p->dqkv_batch_stride % 4 ||

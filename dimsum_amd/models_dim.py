@@ -142,13 +142,19 @@ class Attention(nn.Module):
 
     def forward_deferred(self, x):
         """-> (y, b): the module's output is y + b (proj's bias is left to the caller's fused residual pass)."""
+        from . import native
+        from .attention_fusion import _XattnCoreFn
         B, N, C = x.shape
-        qkv = torch.nn.functional.linear(x, self.qkv.weight)          # bias-free GEMM (fast hipBLASLt path) ...
-        if self.qkv.bias is not None:
-            qkv = qkv.add_(self.qkv.bias) if not torch.is_grad_enabled() else qkv + self.qkv.bias      # ... + one add pass
-        q, k, v = qkv.reshape(B, N, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4).unbind(0)
-        x = torch.nn.functional.scaled_dot_product_attention(q, k, v)
-        return torch.nn.functional.linear(x.transpose(1, 2).reshape(B, N, C), self.proj.weight), self.proj.bias
+        qkv = torch.nn.functional.linear(x, self.qkv.weight)          # bias-free GEMM (fast hipBLASLt path)
+        if native.xattn_supported(qkv, self.head_dim):
+            # MFMA self-attention core (csrc/xattn_fusion*.hip, n_dirs = 1); the qkv bias is added inside the kernels
+            o = _XattnCoreFn.apply(qkv, None, self.qkv.bias, None, self.num_heads)
+        else:
+            if self.qkv.bias is not None:
+                qkv = qkv + self.qkv.bias
+            q, k, v = qkv.reshape(B, N, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4).unbind(0)
+            o = torch.nn.functional.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, N, C)
+        return torch.nn.functional.linear(o, self.proj.weight), self.proj.bias
 
     def forward(self, x):
         y, b = self.forward_deferred(x)

@@ -414,21 +414,25 @@ def xattn_supported(qkv, head_dim):
 
 def xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=False, bias1=None, bias2=None):
     """qkv*: (B, L, 3*heads*hd) -> (B, L, 2*heads*hd) = cat(softmax(q1 k2^T/sqrt(hd)) v2, softmax(q2 k1^T/sqrt(hd)) v1).
+    qkv2 = None: plain self-attention softmax(q1 k1^T/sqrt(hd)) v1 -> (B, L, heads*hd).
     bias1/bias2 (3*heads*hd): the qkv Linear biases when qkv* are bias-free GEMM outputs (added inside the kernel)."""
+    self_attn = qkv2 is None
     _gpu(qkv1, qkv2, bias1, bias2)
-    _check((bias1 is None) == (bias2 is None), "xattn_fusion: pass both biases or none")
-    if bias1 is not None:
-        for bb in (bias1, bias2):
+    _check(self_attn or (bias1 is None) == (bias2 is None), "xattn_fusion: pass both biases or none")
+    for bb in (bias1, bias2):
+        if bb is not None:
             _check(bb.dtype == torch.float32 and bb.numel() == qkv1.shape[2] and bb.is_contiguous(), "xattn_fusion: bad bias")
     B, L, W = qkv1.shape
     hd = W // (3 * heads)
-    _check(qkv1.shape == qkv2.shape and qkv1.dtype == torch.float32 and qkv2.dtype == torch.float32, "xattn_fusion: bad qkv")
-    _check(qkv1.stride(2) == 1 and qkv2.stride(2) == 1 and qkv1.stride() == qkv2.stride(), "xattn_fusion: qkv1/qkv2 must share strides")
-    out = torch.empty((B, L, 2 * heads * hd), device=qkv1.device, dtype=torch.float32)
-    lse = torch.empty((B, 2, heads, L), device=qkv1.device, dtype=torch.float32) if need_lse else None
+    _check(qkv1.dtype == torch.float32 and qkv1.stride(2) == 1, "xattn_fusion: bad qkv")
+    if not self_attn:
+        _check(qkv1.shape == qkv2.shape and qkv2.dtype == torch.float32 and qkv1.stride() == qkv2.stride(), "xattn_fusion: qkv1/qkv2 must share shape and strides")
+    nd = 1 if self_attn else 2
+    out = torch.empty((B, L, nd * heads * hd), device=qkv1.device, dtype=torch.float32)
+    lse = torch.empty((B, nd, heads, L), device=qkv1.device, dtype=torch.float32) if need_lse else None
     if B > 0:
         P = _lib.XattnParams()
-        P.batch, P.seqlen, P.heads, P.head_dim, P.scale = B, L, heads, hd, hd ** -0.5
+        P.batch, P.seqlen, P.heads, P.head_dim, P.scale, P.n_dirs = B, L, heads, hd, hd ** -0.5, nd
         P.qkv_batch_stride, P.qkv_token_stride = qkv1.stride(0), qkv1.stride(1)
         P.out_batch_stride, P.out_token_stride = out.stride(0), out.stride(1)
         P.qkv1_ptr, P.qkv2_ptr, P.out_ptr, P.lse_ptr = _ptr(qkv1), _ptr(qkv2), _ptr(out), _ptr(lse)
@@ -439,23 +443,27 @@ def xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=False, bias1=None, bias2=None):
 
 
 def xattn_fusion_bwd(qkv1, qkv2, out, lse, dout, heads, bias1=None, bias2=None):
-    """backward of xattn_fusion_fwd -> (dqkv1, dqkv2), each (B, L, 3*heads*hd); `out`, `lse` are the forward's results."""
+    """backward of xattn_fusion_fwd -> (dqkv1, dqkv2), each (B, L, 3*heads*hd); `out`, `lse` are the forward's results.
+    qkv2 = None (self-attention): -> (dqkv1, None)."""
+    self_attn = qkv2 is None
     _gpu(qkv1, qkv2, out, lse, dout, bias1, bias2)
     B, L, W = qkv1.shape
     hd = W // (3 * heads)
-    _check(qkv1.shape == qkv2.shape and qkv1.dtype == torch.float32 and qkv1.stride() == qkv2.stride() and qkv1.stride(2) == 1, "xattn_fusion_bwd: bad qkv")
-    _check(tuple(out.shape) == (B, L, 2 * heads * hd) and out.stride(2) == 1 and tuple(lse.shape) == (B, 2, heads, L) and lse.is_contiguous(), "xattn_fusion_bwd: bad out / lse")
-    dout = dout if (dout.stride() == out.stride()) else dout.contiguous()
+    nd = 1 if self_attn else 2
+    _check(qkv1.dtype == torch.float32 and qkv1.stride(2) == 1, "xattn_fusion_bwd: bad qkv")
+    if not self_attn:
+        _check(qkv1.shape == qkv2.shape and qkv1.stride() == qkv2.stride(), "xattn_fusion_bwd: bad qkv2")
+    _check(tuple(out.shape) == (B, L, nd * heads * hd) and out.stride(2) == 1 and tuple(lse.shape) == (B, nd, heads, L) and lse.is_contiguous(), "xattn_fusion_bwd: bad out / lse")
     if dout.stride() != out.stride():
-        out = out.contiguous()
-    _check((bias1 is None) == (bias2 is None), "xattn_fusion_bwd: pass both biases or none")
+        dout, out = dout.contiguous(), out.contiguous()
+    _check(self_attn or (bias1 is None) == (bias2 is None), "xattn_fusion_bwd: pass both biases or none")
     dqkv1 = torch.empty((B, L, W), device=qkv1.device, dtype=torch.float32)
-    dqkv2 = torch.empty((B, L, W), device=qkv1.device, dtype=torch.float32)
-    delta = torch.empty((B, 2, heads, L), device=qkv1.device, dtype=torch.float32)
+    dqkv2 = None if self_attn else torch.empty((B, L, W), device=qkv1.device, dtype=torch.float32)
+    delta = torch.empty((B, nd, heads, L), device=qkv1.device, dtype=torch.float32)
     if B > 0:
         Q = _lib.XattnBwdParams()
         P = Q.fwd
-        P.batch, P.seqlen, P.heads, P.head_dim, P.scale = B, L, heads, hd, hd ** -0.5
+        P.batch, P.seqlen, P.heads, P.head_dim, P.scale, P.n_dirs = B, L, heads, hd, hd ** -0.5, nd
         P.qkv_batch_stride, P.qkv_token_stride = qkv1.stride(0), qkv1.stride(1)
         P.out_batch_stride, P.out_token_stride = out.stride(0), out.stride(1)
         P.qkv1_ptr, P.qkv2_ptr, P.out_ptr, P.lse_ptr = _ptr(qkv1), _ptr(qkv2), _ptr(out), _ptr(lse)

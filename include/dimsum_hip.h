@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DIMSUM_ABI_VERSION 4
+#define DIMSUM_ABI_VERSION 5
 
 typedef enum {
     DIMSUM_OK = 0,
@@ -230,6 +230,9 @@ int dimsum_token_transform(const dimsum_tt_params_t *p, void *stream);
 typedef struct {
     int32_t batch, seqlen, heads, head_dim;
     float scale;
+    int32_t n_dirs;   /* 0 or 2: the two swapped-KV directions above. 1: plain self-attention out = softmax(q1 k1^T) v1
+                         (DiTBlock's attention, models_dim.py:1540): qkv2 / bias2 unused, out (batch, L, heads*hd),
+                         lse (batch, 1, heads, L); in the backward dqkv2_ptr is unused and dqkv1 receives dq, dk, dv */
     int64_t qkv_batch_stride, qkv_token_stride;
     int64_t out_batch_stride, out_token_stride;
     const void *qkv1_ptr, *qkv2_ptr;

@@ -93,3 +93,27 @@ def test_core_backward_vs_torch_sdpa(B, L, heads, hd, bias):
         res.append([out.detach(), q1.grad, q2.grad] + ([b1.grad, b2.grad] if bias else []))
     for name, a, b in zip(("out", "dqkv1", "dqkv2", "dbias1", "dbias2"), res[0], res[1]):
         assert_close(a.cpu().numpy(), b.cpu().numpy(), 1e-4, 0, name, scale_atol=1e-5 if not name.startswith("dbias") else 5e-5)
+
+
+@pytest.mark.parametrize("B,L,heads,hd", [(2, 256, 16, 64), (1, 100, 4, 24), (2, 64, 6, 48)])
+def test_self_attention_mode_fwd_bwd(B, L, heads, hd):
+    """n_dirs = 1 (the shared DiTBlock's attention): forward and backward vs fp32 SDPA math incl. the in-kernel qkv bias."""
+    from dimsum_amd.attention_fusion import _XattnCoreFn
+    from torch.nn.attention import SDPBackend, sdpa_kernel
+    W = 3 * heads * hd
+    gen = torch.Generator().manual_seed(L + heads)
+    base, bias0 = torch.randn(B, L, W, generator=gen), torch.randn(W, generator=gen)
+    dout = torch.randn(B, L, heads * hd, generator=gen).cuda()
+    res = []
+    for fused in (True, False):
+        qkv, bias = base.clone().cuda().requires_grad_(), bias0.clone().cuda().requires_grad_()
+        if fused:
+            out = _XattnCoreFn.apply(qkv, None, bias, None, heads)
+        else:
+            q, k, v = (qkv + bias).reshape(B, L, 3, heads, hd).permute(2, 0, 3, 1, 4).unbind(0)
+            with sdpa_kernel(SDPBackend.MATH):
+                out = torch.nn.functional.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, L, -1)
+        out.backward(dout)
+        res.append((out.detach(), qkv.grad, bias.grad))
+    for name, a, b in zip(("out", "dqkv", "dbias"), res[0], res[1]):
+        assert_close(a.cpu().numpy(), b.cpu().numpy(), 1e-4, 0, name, scale_atol=1e-5 if name != "dbias" else 5e-5)
