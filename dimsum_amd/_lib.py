@@ -50,7 +50,8 @@ class NormParams(C.Structure):
                 + [("eps", f32)]
                 + [(n, i64) for n in ("x_row_stride", "residual_row_stride", "y_row_stride", "residual_out_row_stride")]
                 + [(n, vp) for n in ("x_ptr", "residual_ptr", "weight_ptr", "bias_ptr", "y_ptr", "residual_out_ptr",
-                                     "mean_ptr", "rstd_ptr")])
+                                     "mean_ptr", "rstd_ptr", "xbias_ptr", "mod_scale_ptr", "mod_shift_ptr")]
+                + [("mod_row_stride", i64), ("rows_per_batch", i32), ("reserved", i32)])
 
 
 class NormBwdParams(C.Structure):
@@ -121,7 +122,7 @@ def load():
     if hasattr(lib, "dimsum_ssm_scan_bwd_workspace_bytes"):
         lib.dimsum_ssm_scan_bwd_workspace_bytes.restype = i64
         lib.dimsum_ssm_scan_bwd_workspace_bytes.argtypes = [i32] * 5
-    if lib.dimsum_abi_version() != 5:
+    if lib.dimsum_abi_version() != 6:
         raise RuntimeError("dimsum_amd: libdimsum_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -45,8 +45,15 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const dimsum_norm_params_
     const float inv_n = 1.0f / (float)N;
     const float *w = reinterpret_cast<const float *>(p.weight_ptr);
     const float *bb = reinterpret_cast<const float *>(p.bias_ptr);
+    const float *xb = reinterpret_cast<const float *>(p.xbias_ptr);
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < p.rows; row += (int64_t)gridDim.x * 4) {
         const TX *x = reinterpret_cast<const TX *>(p.x_ptr) + row * p.x_row_stride;
+        const float *msc = nullptr, *msh = nullptr;
+        if (p.mod_scale_ptr) {
+            const int64_t bi = row / p.rows_per_batch;
+            msc = reinterpret_cast<const float *>(p.mod_scale_ptr) + bi * p.mod_row_stride;
+            msh = reinterpret_cast<const float *>(p.mod_shift_ptr) + bi * p.mod_row_stride;
+        }
         const TR *res = p.residual_ptr ? reinterpret_cast<const TR *>(p.residual_ptr) + row * p.residual_row_stride : nullptr;
         TR *ro = p.residual_out_ptr ? reinterpret_cast<TR *>(p.residual_out_ptr) + row * p.residual_out_row_stride : nullptr;
         TY *y = reinterpret_cast<TY *>(p.y_ptr) + row * p.y_row_stride;
@@ -56,6 +63,11 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const dimsum_norm_params_
         for (int i = 0; i < kPieces; ++i) {
             const int c = (i * kWave + lane) * 4;
             r[i] = ld_cols<TX>(x, c, N, vec);
+            if (xb) {
+                const f32x4 q = ld_cols<float>(xb, c, N, vec);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[i].v[e] += q.v[e];
+            }
             if (res) {
                 const f32x4 q = ld_cols<TR>(res, c, N, vec);
 #pragma unroll
@@ -94,6 +106,11 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const dimsum_norm_params_
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o.v[e] = (r[i].v[e] - mean) * rstd * wv.v[e] + bv.v[e];
+                if (msc) {
+                    const f32x4 sc = ld_cols<float>(msc, c, N, vec), sh = ld_cols<float>(msh, c, N, vec);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o.v[e] = fmaf(o.v[e], 1.0f + sc.v[e], sh.v[e]);
+                }
                 st_cols<TY>(y, c, N, vec, o);
             }
         }
@@ -174,6 +191,8 @@ static int launch_norm_fwd(const dimsum_norm_params_t &p, hipStream_t s) {
                (!p.bias_ptr || aligned_to<float>(p.bias_ptr, 16));
     if (p.residual_ptr) vec = vec && aligned_to<TR>(p.residual_ptr, 4 * sizeof(TR)) && p.residual_row_stride % 4 == 0;
     if (p.residual_out_ptr) vec = vec && aligned_to<TR>(p.residual_out_ptr, 4 * sizeof(TR)) && p.residual_out_row_stride % 4 == 0;
+    if (p.xbias_ptr) vec = vec && aligned_to<float>(p.xbias_ptr, 16);
+    if (p.mod_scale_ptr) vec = vec && aligned_to<float>(p.mod_scale_ptr, 16) && aligned_to<float>(p.mod_shift_ptr, 16) && p.mod_row_stride % 4 == 0;
     const int pieces = (N + 255) / 256;
     const int64_t blocks = (p.rows + 3) / 4;
     const dim3 grid((unsigned)(blocks < 256 * 16 ? blocks : 256 * 16)), block(256);
@@ -213,6 +232,8 @@ extern "C" int dimsum_norm_fwd(const dimsum_norm_params_t *p, void *stream) {
     using namespace dimsum;
     if (!p || !p->x_ptr || !p->weight_ptr || !p->y_ptr) return DIMSUM_ERR_NULL;
     if (p->rows < 0 || p->cols <= 0) return DIMSUM_ERR_SHAPE;
+    if ((p->mod_scale_ptr == nullptr) != (p->mod_shift_ptr == nullptr)) return DIMSUM_ERR_NULL;
+    if (p->mod_scale_ptr && p->rows_per_batch <= 0) return DIMSUM_ERR_SHAPE;
     if (p->rows == 0) return DIMSUM_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (p->x_dtype) {

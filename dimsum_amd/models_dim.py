@@ -366,8 +366,17 @@ class _CombinedBase(_BlockBase):
         x2, _ = self.freq_mamba(x2, None, c, inference_params)
         # residual tails as single fused passes; the Linear biases ride along (mlp.py / attention_fusion.py docstrings)
         fused, pb = self.proj.forward_deferred(x1, x2)
-        hidden_states = token_ops.gate_residual(hidden_states, fused, None, pb)
         shift, scale, gate = self.adaLN_modulation(c).chunk(3, dim=1)
+        if not torch.is_grad_enabled() and isinstance(self.norm_2, RMSNorm) and hasattr(self.mlp, "forward_deferred") and hidden_states.dtype == torch.float32:
+            # inference: h' = h + proj(..) + b, RMSNorm(h'), modulate -- ONE pass (csrc/norm.hip with x_bias + modulation)
+            from . import native
+            B, L, H = hidden_states.shape
+            y, _, _, hnew = native.layer_norm_fwd(fused.reshape(B * L, H), self.norm_2.weight, self.norm_2.bias, self.norm_2.eps,
+                                                  residual=hidden_states.reshape(B * L, H), is_rms_norm=True, x_bias=pb,
+                                                  mod_scale=scale, mod_shift=shift, rows_per_batch=L)
+            m, mb = self.mlp.forward_deferred(y.view(B, L, H))
+            return token_ops.gate_residual(hnew.view(B, L, H), m, gate, mb), residual
+        hidden_states = token_ops.gate_residual(hidden_states, fused, None, pb)
         return _mlp_tail(self.mlp, hidden_states, self.norm_2(hidden_states), shift, scale, gate), residual
 
 

@@ -193,9 +193,12 @@ def causal_conv1d_bwd(x, weight, bias, dout, dx, silu_activation):
 # ---------------------------------------------------------------------------------------------------------------------
 # fused add + RMSNorm / LayerNorm   (Triton _layer_norm_fwd / _layer_norm_bwd, ops/triton/layernorm.py:120-364)
 # ---------------------------------------------------------------------------------------------------------------------
-def layer_norm_fwd(x, weight, bias, eps, residual=None, out_dtype=None, residual_dtype=None, is_rms_norm=False):
+def layer_norm_fwd(x, weight, bias, eps, residual=None, out_dtype=None, residual_dtype=None, is_rms_norm=False,
+                   x_bias=None, mod_scale=None, mod_shift=None, rows_per_batch=0):
     """x: (M, N) -> (y, mean, rstd, residual_out), like _layer_norm_fwd (layernorm.py:120-187).
-    residual_out is x itself when no residual is added and no dtype change is requested."""
+    residual_out is x itself when no residual is added and no dtype change is requested.
+    Extras: `x_bias` (N) is added to x first (the bias of the Linear that produced x); `mod_scale/mod_shift`
+    ((M / rows_per_batch, N), sharing a row stride) apply y * (1 + scale) + shift per batch element after the norm."""
     _gpu(x, weight, bias, residual)
     _check(x.dim() == 2 and x.stride(-1) == 1, "layer_norm_fwd: x must be (M, N) with contiguous rows")
     M, N = x.shape
@@ -204,7 +207,9 @@ def layer_norm_fwd(x, weight, bias, eps, residual=None, out_dtype=None, residual
         _check(residual.shape == x.shape and residual.stride(-1) == 1, "layer_norm_fwd: bad residual")
         residual_dtype = residual.dtype
     y = torch.empty((M, N), device=x.device, dtype=x.dtype if out_dtype is None else out_dtype)
-    need_res_out = residual is not None or (residual_dtype is not None and residual_dtype != x.dtype)
+    need_res_out = residual is not None or x_bias is not None or (residual_dtype is not None and residual_dtype != x.dtype)
+    if residual_dtype is None:
+        residual_dtype = x.dtype
     residual_out = torch.empty((M, N), device=x.device, dtype=residual_dtype) if need_res_out else None
     mean = torch.empty((M,), device=x.device, dtype=torch.float32) if not is_rms_norm else None
     rstd = torch.empty((M,), device=x.device, dtype=torch.float32)
@@ -222,6 +227,18 @@ def layer_norm_fwd(x, weight, bias, eps, residual=None, out_dtype=None, residual
         b32 = bias.float().contiguous() if bias is not None else None
         P.x_ptr, P.residual_ptr, P.weight_ptr, P.bias_ptr = _ptr(x), _ptr(residual), _ptr(w32), _ptr(b32)
         P.y_ptr, P.residual_out_ptr, P.mean_ptr, P.rstd_ptr = _ptr(y), _ptr(residual_out), _ptr(mean), _ptr(rstd)
+        if x_bias is not None:
+            xb32 = x_bias.float().contiguous()
+            _check(tuple(xb32.shape) == (N,), "layer_norm_fwd: x_bias must be (N,)")
+            P.xbias_ptr = _ptr(xb32)
+        if mod_scale is not None:
+            _gpu(mod_scale, mod_shift)
+            _check(mod_shift is not None and rows_per_batch > 0 and M % rows_per_batch == 0, "layer_norm_fwd: bad modulation arguments")
+            nb = M // rows_per_batch
+            _check(tuple(mod_scale.shape) == (nb, N) and tuple(mod_shift.shape) == (nb, N) and mod_scale.dtype == torch.float32
+                   and mod_shift.dtype == torch.float32 and mod_scale.stride(1) == 1 and mod_shift.stride(1) == 1
+                   and mod_scale.stride(0) == mod_shift.stride(0), "layer_norm_fwd: mod_scale / mod_shift must be (M / rows_per_batch, N) float32 sharing a row stride")
+            P.mod_scale_ptr, P.mod_shift_ptr, P.mod_row_stride, P.rows_per_batch = _ptr(mod_scale), _ptr(mod_shift), mod_scale.stride(0), rows_per_batch
         with torch.cuda.device(x.device):
             _lib.check(_lib.load().dimsum_norm_fwd(P, _stream(x)), "layer_norm_fwd")
     return y, mean, rstd, residual_out if residual_out is not None else x

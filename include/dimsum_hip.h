@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DIMSUM_ABI_VERSION 5
+#define DIMSUM_ABI_VERSION 6
 
 typedef enum {
     DIMSUM_OK = 0,
@@ -145,7 +145,11 @@ int dimsum_causal_conv1d_bwd(const dimsum_conv_bwd_params_t *p, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Fused residual-add + RMSNorm / LayerNorm over rows (M, N), f32 statistics.
- *   r = x (+ residual) ; residual_out = r (if residual_out_ptr) ; y = norm(r) * weight (+ bias)
+ *   r = x (+ x_bias) (+ residual) ; residual_out = r (if residual_out_ptr) ; y = norm(r) * weight (+ bias)
+ *   optionally followed by the adaLN modulation of the row's batch element (rows_per_batch consecutive rows each):
+ *       y = y * (1 + mod_scale[row / rows_per_batch, :]) + mod_shift[row / rows_per_batch, :]
+ *   (x_bias = the bias of the Linear that produced x, so that the GEMM runs without a bias epilogue; with it and the
+ *   modulation, "h + proj(x) -> RMSNorm -> modulate" of a DiM block is ONE pass instead of three.)
  *   rstd (M) f32 always written; mean (M) f32 written for LayerNorm.
  * bwd: dx = d(norm)/dr . dy (+ dresidual_out) ; dweight/dbias (N) f32 accumulated with atomics into zero-filled
  * buffers (the Triton reference reduces per-SM partials on the host, layernorm.py:324-359).
@@ -158,6 +162,10 @@ typedef struct {
     int64_t x_row_stride, residual_row_stride, y_row_stride, residual_out_row_stride;
     const void *x_ptr, *residual_ptr, *weight_ptr, *bias_ptr;
     void *y_ptr, *residual_out_ptr, *mean_ptr, *rstd_ptr;
+    const void *xbias_ptr;                      /* (N) f32 or NULL */
+    const void *mod_scale_ptr, *mod_shift_ptr;  /* (M / rows_per_batch, N) f32, both or none */
+    int64_t mod_row_stride;
+    int32_t rows_per_batch, reserved;
 } dimsum_norm_params_t;
 
 typedef struct {

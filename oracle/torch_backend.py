@@ -71,11 +71,17 @@ def causal_conv1d_bwd(x, weight, bias, dout, dx, silu_activation):
     return [dx, _like(rdw, weight), _like(rdb, bias) if bias is not None else None]
 
 
-def layer_norm_fwd(x, weight, bias, eps, residual=None, out_dtype=None, residual_dtype=None, is_rms_norm=False):
-    y, ro, mean, rstd = c_ops.norm_fwd(_np(x), _np(weight), _np(bias), _np(residual), eps, is_rms_norm)
+def layer_norm_fwd(x, weight, bias, eps, residual=None, out_dtype=None, residual_dtype=None, is_rms_norm=False,
+                   x_bias=None, mod_scale=None, mod_shift=None, rows_per_batch=0):
+    xin = _np(x) if x_bias is None else _np(x) + _np(x_bias)
+    y, ro, mean, rstd = c_ops.norm_fwd(np.ascontiguousarray(xin, dtype=np.float32), _np(weight), _np(bias), _np(residual), eps, is_rms_norm)
+    if mod_scale is not None:
+        y = (y.reshape(-1, rows_per_batch, y.shape[-1]) * (1 + _np(mod_scale)[:, None]) + _np(mod_shift)[:, None]).reshape(y.shape).astype(np.float32)
     if residual is not None:
         residual_dtype = residual.dtype
-    need = residual is not None or (residual_dtype is not None and residual_dtype != x.dtype)
+    need = residual is not None or x_bias is not None or (residual_dtype is not None and residual_dtype != x.dtype)
+    if residual_dtype is None:
+        residual_dtype = x.dtype
     res_out = torch.from_numpy(ro).to(residual_dtype) if need else x
     return (torch.from_numpy(y).to(out_dtype or x.dtype), None if is_rms_norm else torch.from_numpy(mean), torch.from_numpy(rstd), res_out)
 

@@ -135,3 +135,22 @@ def test_norm_vs_oracle(M, N):
     dr_ref, dw_ref, _ = c_ops.norm_bwd(ro_ref, w.numpy(), dy.numpy(), dro.numpy(), 1e-5, True)
     assert_close(dx.cpu().numpy(), dr_ref, 1e-4, 1e-5, "dx")
     assert_close(dw.cpu().numpy(), dw_ref, 1e-4, 0, "dw", scale_atol=1e-5)
+
+
+@pytest.mark.parametrize("M,N,L", [(6 * 64, 1024, 64), (4 * 16, 384, 16), (3 * 8, 72, 8)])
+def test_fused_bias_add_rmsnorm_modulate(M, N, L):
+    """h' = x + x_bias + residual; y = RMSNorm(h') * w * (1 + scale[b]) + shift[b] in ONE pass vs the composition.
+    The residual stream must be bit-identical to the separate adds; y within fp32 roundoff (rtol 2e-6 + 2e-6 max)."""
+    from dimsum_amd import native
+    g = torch.Generator().manual_seed(M + N)
+    x, res = torch.randn(M, N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
+    w, xb = (1 + 0.1 * torch.randn(N, generator=g)).cuda(), torch.randn(N, generator=g).cuda()
+    mods = torch.randn(M // L, 3 * N, generator=g).cuda()
+    shift, scale = mods[:, :N], mods[:, N:2 * N]
+    y, _, rstd, hnew = native.layer_norm_fwd(x, w, None, 1e-5, residual=res, is_rms_norm=True, x_bias=xb, mod_scale=scale, mod_shift=shift,
+                                             rows_per_batch=L)
+    h_ref = (x + xb) + res
+    assert torch.equal(hnew, h_ref)
+    n_ref = h_ref * torch.rsqrt(h_ref.pow(2).mean(-1, keepdim=True) + 1e-5) * w
+    y_ref = (n_ref.view(M // L, L, N) * (1 + scale.unsqueeze(1)) + shift.unsqueeze(1)).view(M, N)
+    assert_close(y.cpu().numpy(), y_ref.cpu().numpy(), 2e-6, 0, "y", scale_atol=2e-6)
