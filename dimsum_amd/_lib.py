@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdimsum_hip.so")
+LIB_PATH = os.environ.get("DIMSUM_HIP_LIB") or os.path.join(_HERE, "lib", "libdimsum_hip.so")   # override: kernel-variant experiments
 
 F32, F16, BF16 = 0, 1, 2
 i32, i64, vp, f32 = C.c_int32, C.c_int64, C.c_void_p, C.c_float

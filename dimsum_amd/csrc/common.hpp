@@ -82,6 +82,15 @@ __device__ __forceinline__ float softplus_ref(float x) {
     return x <= 20.0f ? r : x;
 }
 
+// `flag ? softplus_ref(x) : x` for a wave-uniform runtime flag WITHOUT a branch: the empty asm pins the evaluation into
+// the straight-line code, so that the exp/log chains of neighbouring elements interleave (a uniform branch around each
+// element ends the basic block and serialises four ~80-cycle dependent chains per 4 time steps).
+__device__ __forceinline__ float softplus_if(float x, bool flag) {
+    float sp = softplus_ref(x);
+    asm volatile("" : "+v"(sp));
+    return flag ? sp : x;
+}
+
 // ---- host ----------------------------------------------------------------------------------------------------------
 inline int launch_status() { return hipGetLastError() == hipSuccess ? DIMSUM_OK : DIMSUM_ERR_LAUNCH; }
 

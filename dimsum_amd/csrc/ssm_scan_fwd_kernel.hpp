@@ -252,8 +252,7 @@ __global__ __launch_bounds__(kWave, DIMSUM_SCAN_WAVES) void ssm_scan_fwd_kernel(
             float dt[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                float v = d4.v[s] + bias;
-                if (softplus) v = softplus_ref(v);
+                const float v = softplus_if(d4.v[s] + bias, softplus);
                 const bool live = kVec || (tj + s < L);       // dead steps: a = 1, b = 0 -> state untouched
                 dt[s] = live ? v : 0.f;
                 sum_dt += dt[s];
