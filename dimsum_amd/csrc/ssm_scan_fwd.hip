@@ -1,4 +1,6 @@
 // ssm_scan_fwd.hip -- C entry point of the selective-scan forward (kernel: ssm_scan_fwd_kernel.hpp).
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace dimsum {
@@ -12,6 +14,18 @@ int ssm_check(const dimsum_ssm_params_t *p, bool forward) {
     if (p->dstate > 256) return DIMSUM_ERR_SHAPE;  // selective_scan.cpp:262
     if (p->n_chunks != (p->seqlen + 2047) / 2048) return DIMSUM_ERR_SHAPE;
     return DIMSUM_OK;
+}
+
+// Which forward kernel serves a shape. DIMSUM_SCAN_SPLIT=0/1 forces one (experiments).
+bool ssm_scan_fwd_use_split(const dimsum_ssm_params_t &p) {
+    static const char *env = getenv("DIMSUM_SCAN_SPLIT");
+    if (env && (env[0] == '0' || env[0] == '1')) return env[0] == '1';
+    // The 64-channel kernel keeps 8 waves per CU resident (2048 on the chip). A launch that does not even fill those slots
+    // once is latency-bound per wave: the split kernel gives it twice the waves, each with half the sequential work
+    // (measured: (64, 1152, 1024) 534 -> 475 us, (16, 1152, 4096) 1225 -> 785 us; (256, 1024, 256) equal).
+    const int64_t dpg = p.dim / p.n_groups;
+    const int64_t waves = (int64_t)p.batch * p.n_groups * ((dpg + kWave - 1) / kWave);
+    return p.dstate % 4 == 0 && waves < 2048;
 }
 
 }  // namespace dimsum

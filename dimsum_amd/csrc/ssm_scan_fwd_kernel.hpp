@@ -104,6 +104,15 @@ template <typename T> __device__ __forceinline__ T *at(T *base, unsigned elem_of
     return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + (unsigned)(elem_off * (unsigned)sizeof(T)));
 }
 
+// timing experiments (tools/scratch): DIMSUM_SCAN_X_NOMEM drops the tile loads / stores, DIMSUM_SCAN_X_NOCOMP the recurrence
+#ifdef DIMSUM_SCAN_X_NOMEM
+#define FXLD(T, ptr) (Raw4<T>{})
+#define FXST_ON (L < 0)
+#else
+#define FXLD(T, ptr) ld4<T>(ptr)
+#define FXST_ON true
+#endif
+
 // kVec : every row base is 4-element aligned and L % 4 == 0 -> 16-byte (fp32) vector I/O, register-staged prefetch.
 // kFull: dim/n_groups % 64 == 0 -> all 64 lanes own a live channel, no row masks anywhere (needs kVec).
 template <typename T, int kN, bool kHasZ, bool kVec, bool kFull, bool kCkpt = false>
@@ -178,8 +187,8 @@ __global__ __launch_bounds__(kWave, DIMSUM_SCAN_WAVES) void ssm_scan_fwd_kernel(
         const int col = col_of(t0);
 #pragma unroll
         for (int i = 0; i < kNP; ++i) {
-            ru[i] = ld4<T>(piece(u_base, u_ds, i, col));
-            rd[i] = ld4<T>(piece(dl_base, dl_ds, i, col));
+            ru[i] = FXLD(T, piece(u_base, u_ds, i, col));
+            rd[i] = FXLD(T, piece(dl_base, dl_ds, i, col));
         }
 #pragma unroll
         for (int i = 0; i < kBCPieces; ++i) {
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(kWave, DIMSUM_SCAN_WAVES) void ssm_scan_fwd_kernel(
             if constexpr (kHasZ) {
                 const int col = col_of(t0);
 #pragma unroll
-                for (int i = 0; i < kNP; ++i) rz[i] = ld4<T>(piece(z_base, z_ds, i, col));
+                for (int i = 0; i < kNP; ++i) rz[i] = FXLD(T, piece(z_base, z_ds, i, col));
             }
         } else {
             // generic path (unaligned rows or L % 4 != 0): element-wise, still coalesced along L
@@ -246,9 +255,17 @@ __global__ __launch_bounds__(kWave, DIMSUM_SCAN_WAVES) void ssm_scan_fwd_kernel(
             }
             const f32x4 u4 = *reinterpret_cast<const f32x4 *>(&tileU[tile_off(lane, j)]);
             const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&tileD[tile_off(lane, j)]);
-            // software-pipelined broadcast reads: B/C of state n+1 are in flight while state n is computed
-            f32x4 bq_nxt = *reinterpret_cast<const f32x4 *>(&tileB[j * 4]);
-            f32x4 cq_nxt = *reinterpret_cast<const f32x4 *>(&tileC[j * 4]);
+            // software-pipelined broadcast reads: B/C of states n+1 .. n+kPD are in flight while state n is computed
+#ifndef DIMSUM_SCAN_PD
+#define DIMSUM_SCAN_PD 1
+#endif
+            constexpr int kPD = DIMSUM_SCAN_PD < kN ? DIMSUM_SCAN_PD : kN - 1;
+            f32x4 bq_pipe[kPD], cq_pipe[kPD];
+#pragma unroll
+            for (int i = 0; i < kPD; ++i) {
+                bq_pipe[i] = *reinterpret_cast<const f32x4 *>(&tileB[i * kTC + j * 4]);
+                cq_pipe[i] = *reinterpret_cast<const f32x4 *>(&tileC[i * kTC + j * 4]);
+            }
             float dt[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -260,13 +277,23 @@ __global__ __launch_bounds__(kWave, DIMSUM_SCAN_WAVES) void ssm_scan_fwd_kernel(
             float du[4], y[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) { du[s] = dt[s] * u4.v[s]; y[s] = Dval * u4.v[s]; }
-            __builtin_amdgcn_sched_barrier(0);   // region below = exactly 2*(kN-1) ds_read + 20*kN VALU
+            __builtin_amdgcn_sched_barrier(0);   // region below = exactly 2*(kN-kPD) ds_read + 20*kN VALU
+#ifdef DIMSUM_SCAN_X_NOCOMP
+#pragma unroll
+            for (int n = 0; n < 1; ++n) {
+#else
 #pragma unroll
             for (int n = 0; n < kN; ++n) {
-                const f32x4 bq = bq_nxt, cq = cq_nxt;
-                if (n + 1 < kN) {
-                    bq_nxt = *reinterpret_cast<const f32x4 *>(&tileB[(n + 1) * kTC + j * 4]);
-                    cq_nxt = *reinterpret_cast<const f32x4 *>(&tileC[(n + 1) * kTC + j * 4]);
+#endif
+#ifdef DIMSUM_SCAN_X_NOBC       // timing experiment: no broadcast LDS reads in the inner block
+                const f32x4 bq = u4, cq = d4;
+                if (false) {
+#else
+                const f32x4 bq = bq_pipe[n % kPD], cq = cq_pipe[n % kPD];
+                if (n + kPD < kN) {
+#endif
+                    bq_pipe[n % kPD] = *reinterpret_cast<const f32x4 *>(&tileB[(n + kPD) * kTC + j * 4]);
+                    cq_pipe[n % kPD] = *reinterpret_cast<const f32x4 *>(&tileC[(n + kPD) * kTC + j * 4]);
                 }
                 float hn = h[n];
 #pragma unroll
@@ -275,8 +302,8 @@ __global__ __launch_bounds__(kWave, DIMSUM_SCAN_WAVES) void ssm_scan_fwd_kernel(
                     y[s] = fmaf(hn, cq.v[s], y[s]);
                 }
                 h[n] = hn;
-                // keep the issue order: [2 ds_read for n+1] then [20 VALU of n]
-                if (n + 1 < kN) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                // keep the issue order: [2 ds_read for n+kPD] then [20 VALU of n]
+                if (n + kPD < kN) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x2, 20, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -303,12 +330,12 @@ __global__ __launch_bounds__(kWave, DIMSUM_SCAN_WAVES) void ssm_scan_fwd_kernel(
                     const int row = i * kRPP + lrow;
                     if (kFull || row < nd) {
                         f32x4 y4 = *reinterpret_cast<const f32x4 *>(&tileU[tile_off(row, lc4)]);
-                        if (has_out) st4<T>(at(out_base + i * kRPP * out_ds, (unsigned)(lrow * out_ds + t0 + lcol)), y4);
+                        if (FXST_ON && has_out) st4<T>(at(out_base + i * kRPP * out_ds, (unsigned)(lrow * out_ds + t0 + lcol)), y4);
                         if constexpr (kHasZ) {
                             const f32x4 z4 = widen(rz[i]);
 #pragma unroll
                             for (int s = 0; s < 4; ++s) y4.v[s] *= z4.v[s] * sigmoidf_fast(z4.v[s]);
-                            st4<T>(at(oz_base + i * kRPP * oz_ds, (unsigned)(lrow * oz_ds + t0 + lcol)), y4);
+                            if (FXST_ON) st4<T>(at(oz_base + i * kRPP * oz_ds, (unsigned)(lrow * oz_ds + t0 + lcol)), y4);
                         }
                     }
                 }
@@ -329,10 +356,20 @@ __global__ __launch_bounds__(kWave, DIMSUM_SCAN_WAVES) void ssm_scan_fwd_kernel(
     }
 }
 
+}  // namespace dimsum
+
+#include "ssm_scan_fwd_split.hpp"   // the state-split variant (32 channels per wave, lane = (channel, state half))
+
+namespace dimsum {
+
+bool ssm_scan_fwd_use_split(const dimsum_ssm_params_t &p);   // ssm_scan_fwd.hip
+
 template <typename T, int kN>
 static int launch_fwd(const dimsum_ssm_params_t &p, hipStream_t stream) {
     const int dpg = p.dim / p.n_groups;
-    const int tiles = p.batch * p.n_groups * ((dpg + kWave - 1) / kWave);
+    const bool split = ssm_scan_fwd_use_split(p);
+    const int cpw = split ? 32 : kWave;                    // channels per wave
+    const int tiles = p.batch * p.n_groups * ((dpg + cpw - 1) / cpw);
     const size_t va = 4 * sizeof(T);  // vector path: every row base 4-element aligned
     bool vec = (p.seqlen % 4 == 0) && aligned_to<T>(p.u_ptr, va) && aligned_to<T>(p.delta_ptr, va) &&
                aligned_to<T>(p.B_ptr, va) && aligned_to<T>(p.C_ptr, va) && (p.u_batch_stride % 4 == 0) &&
@@ -350,11 +387,14 @@ static int launch_fwd(const dimsum_ssm_params_t &p, hipStream_t stream) {
         64 * p.z_d_stride + p.seqlen >= lim || 64 * p.out_z_d_stride + p.seqlen >= lim ||
         (int64_t)p.dstate * p.B_dstate_stride + p.seqlen >= lim || (int64_t)p.dstate * p.C_dstate_stride + p.seqlen >= lim)
         return DIMSUM_ERR_STRIDE;
-    const bool full = vec && (dpg % kWave == 0);
+    const bool full = vec && (dpg % cpw == 0);
     dim3 grid(tiles), block(kWave);
 #define DIMSUM_LAUNCH(HASZ, VEC, FULL)                                                                                   \
     do {                                                                                                                  \
-        if (p.ckpt_ptr) hipLaunchKernelGGL((ssm_scan_fwd_kernel<T, kN, HASZ, VEC, FULL, true>), grid, block, 0, stream, p);  \
+        if (split) {                                                                                                      \
+            if (p.ckpt_ptr) hipLaunchKernelGGL((ssm_scan_fwd_split_kernel<T, kN, HASZ, VEC, FULL, true>), grid, block, 0, stream, p);  \
+            else hipLaunchKernelGGL((ssm_scan_fwd_split_kernel<T, kN, HASZ, VEC, FULL, false>), grid, block, 0, stream, p);            \
+        } else if (p.ckpt_ptr) hipLaunchKernelGGL((ssm_scan_fwd_kernel<T, kN, HASZ, VEC, FULL, true>), grid, block, 0, stream, p);  \
         else hipLaunchKernelGGL((ssm_scan_fwd_kernel<T, kN, HASZ, VEC, FULL, false>), grid, block, 0, stream, p);            \
     } while (0)
     if (p.z_ptr) {

@@ -1,0 +1,244 @@
+// ssm_scan_fwd_split.hpp -- selective scan forward, state-split variant: lane = (channel, state half).
+//
+// Same math and interface as ssm_scan_fwd_kernel (ssm_scan_fwd_kernel.hpp; reference selective_scan_fwd_kernel.cuh:67-303).
+// One wave64 owns 32 channels of one batch element; lanes 0-31 carry the first dstate/2 states of their channel, lanes
+// 32-63 the second half. Per wave that is half the sequential work, half the registers (A, h: dstate/2 each; 4 instead
+// of 8 staged 16-byte pieces per tensor) and 12 KB instead of 20 KB of LDS, i.e. 3 waves per SIMD instead of 2 and twice
+// as many waves per launch: shapes whose batch * dim / 64 does not fill the 2048 wave slots of the chip
+// (DiM-XL/2 at 512 px: 64 x 1152 channels x 1024 steps = 1152 waves) get 2304 waves that are all resident at once.
+//   * tiles are 32 channels x 32 steps: 128-B row segments, whole HBM lines, XOR-swizzled LDS image (no padding);
+//   * dt = softplus(delta + bias) is evaluated once per element in the coalesced load layout (not once per half);
+//   * y_t = sum over the lane's states; the two halves are joined with ONE v_permlane32_swap + add per pair of steps:
+//     the low lane ends up with steps 0 and 2 of a 4-step group, the high lane with steps 1 and 3.
+#pragma once   // included by ssm_scan_fwd_kernel.hpp (uses its helpers: at(), Raw4, softplus_if, ...)
+
+namespace dimsum {
+
+constexpr int kSC = 32;   // channels per wave
+constexpr int kST = 32;   // time steps per tile
+
+__device__ __forceinline__ int stile_off(int row, int col4) { return row * kST + ((col4 ^ ((row >> 1) & 7)) << 2); }
+
+__device__ __forceinline__ void swap_halves(float &x, float &y) {      // x.hi <-> y.lo (v_permlane32_swap)
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    x = __uint_as_float(r[0]); y = __uint_as_float(r[1]);
+}
+
+template <typename T, int kN, bool kHasZ, bool kVec, bool kFull, bool kCkpt = false>
+__global__ __launch_bounds__(kWave, 3) void ssm_scan_fwd_split_kernel(const dimsum_ssm_params_t p) {
+    static_assert(!kFull || kVec, "kFull implies kVec");
+    static_assert(kN % 4 == 0, "dstate must be a multiple of 4");
+    constexpr int kNL = kN / 2;                    // states per lane
+    __shared__ __attribute__((aligned(16))) float tileU[kSC * kST];
+    __shared__ __attribute__((aligned(16))) float tileD[kSC * kST];
+    __shared__ __attribute__((aligned(16))) float tileB[kN * kST];   // [n][t]: uniform per half wave, read back as broadcast ds_read_b128
+    __shared__ __attribute__((aligned(16))) float tileC[kN * kST];
+
+    const int lane = threadIdx.x, c = lane & (kSC - 1), sh = lane >> 5;
+    const int ns0 = sh * kNL;
+    const int L = p.seqlen;
+    const int dpg = p.dim / p.n_groups;
+    const int tiles_per_group = (dpg + kSC - 1) / kSC;
+    const int tiles_per_batch = p.n_groups * tiles_per_group;
+    int wg = blockIdx.x;
+    const int nwg = gridDim.x;
+    if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);   // a batch element's waves share an XCD (one L2 for B / C)
+    const int b = wg / tiles_per_batch;
+    const int rem = wg - b * tiles_per_batch;
+    const int g = rem / tiles_per_group;
+    const int d0 = g * dpg + (rem - g * tiles_per_group) * kSC;
+    const int nd = kFull ? kSC : min(kSC, (g + 1) * dpg - d0);
+    const bool live = kFull || c < nd;
+    const int d = d0 + (kFull ? c : min(c, nd - 1));
+
+    const T *u_base = reinterpret_cast<const T *>(p.u_ptr) + (int64_t)b * p.u_batch_stride + (int64_t)d0 * p.u_d_stride;
+    const T *dl_base = reinterpret_cast<const T *>(p.delta_ptr) + (int64_t)b * p.delta_batch_stride + (int64_t)d0 * p.delta_d_stride;
+    const T *z_base = kHasZ ? reinterpret_cast<const T *>(p.z_ptr) + (int64_t)b * p.z_batch_stride + (int64_t)d0 * p.z_d_stride : nullptr;
+    T *out_base = p.out_ptr ? reinterpret_cast<T *>(p.out_ptr) + (int64_t)b * p.out_batch_stride + (int64_t)d0 * p.out_d_stride : nullptr;
+    T *oz_base = kHasZ ? reinterpret_cast<T *>(p.out_z_ptr) + (int64_t)b * p.out_z_batch_stride + (int64_t)d0 * p.out_z_d_stride : nullptr;
+    const int u_ds = (int)p.u_d_stride, dl_ds = (int)p.delta_d_stride, z_ds = (int)p.z_d_stride;
+    const int out_ds = (int)p.out_d_stride, oz_ds = (int)p.out_z_d_stride;
+    const T *Bp = reinterpret_cast<const T *>(p.B_ptr) + (int64_t)b * p.B_batch_stride + (int64_t)g * p.B_group_stride;
+    const T *Cp = reinterpret_cast<const T *>(p.C_ptr) + (int64_t)b * p.C_batch_stride + (int64_t)g * p.C_group_stride;
+    const int Bns = (int)p.B_dstate_stride, Cns = (int)p.C_dstate_stride;
+
+    float A2[kNL], h[kNL];
+    {
+        const float *Ap = reinterpret_cast<const float *>(p.A_ptr) + (int64_t)d * p.A_d_stride;
+#pragma unroll
+        for (int k = 0; k < kNL; ++k) { A2[k] = Ap[(ns0 + k) * p.A_dstate_stride] * kLog2e; h[k] = 0.f; }
+    }
+    const float Dval = (p.D_ptr && sh == 0) ? reinterpret_cast<const float *>(p.D_ptr)[d] : 0.f;   // D u is added by the low half only
+    const float *bias_p = reinterpret_cast<const float *>(p.delta_bias_ptr);
+    const bool softplus = p.delta_softplus != 0;
+    const bool has_out = out_base != nullptr;
+    float sum_dt = 0.f;   // prod_t a_t[n] = exp2(A2[n] * sum_t dt_t)
+    float *ck_base = (kCkpt && p.ckpt_ptr && live) ? reinterpret_cast<float *>(p.ckpt_ptr) + (int64_t)b * ((L + 7) / 8) * kN * p.dim + (int64_t)ns0 * p.dim + d : nullptr;
+
+    const int n_tiles = (L + kST - 1) / kST;
+    // load layout: piece i of the tile, lane -> (row = i*8 + lane/8, 4 columns at (lane%8)*4)
+    const int lrow = lane >> 3, lc4 = lane & 7, lcol = lc4 * 4;
+    float brow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) brow[i] = bias_p ? bias_p[d0 + min(i * 8 + lrow, nd - 1)] : 0.f;
+
+    constexpr int kBCPieces = (kN * 8 + kWave - 1) / kWave;
+    Raw4<T> ru[4], rd[4], rz[4], rb[kBCPieces], rc[kBCPieces];
+    auto col_of = [&](int t0) { return min(t0 + lcol, L - 4); };
+    auto piece = [&](const T *base, int ds, int i, int col) -> const T * {
+        if constexpr (kFull) return at(base + i * 8 * ds, (unsigned)(lrow * ds + col));
+        else return at(base, (unsigned)(min(i * 8 + lrow, nd - 1) * ds + col));
+    };
+    auto issue_loads = [&](int t0) {
+        const int col = col_of(t0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ru[i] = ld4<T>(piece(u_base, u_ds, i, col));
+            rd[i] = ld4<T>(piece(dl_base, dl_ds, i, col));
+        }
+#pragma unroll
+        for (int i = 0; i < kBCPieces; ++i) {
+            const int n = min(i * 8 + lrow, kN - 1);
+            rb[i] = ld4<T>(at(Bp, (unsigned)(n * Bns + col)));
+            rc[i] = ld4<T>(at(Cp, (unsigned)(n * Cns + col)));
+        }
+    };
+
+    if constexpr (kVec) issue_loads(0);
+
+#pragma unroll 1
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        const int t0 = tile * kST;
+        // ---- stage the tile into LDS: u, dt = softplus(delta + bias) (0 beyond L: a = 1, b = 0, the state is untouched) ----
+        if constexpr (kVec) {
+            const bool col_ok = t0 + lcol < L;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = i * 8 + lrow;
+                f32x4 vd = widen(rd[i]);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) vd.v[s] = col_ok ? softplus_if(vd.v[s] + brow[i], softplus) : 0.f;
+                *reinterpret_cast<f32x4 *>(&tileU[stile_off(row, lc4)]) = widen(ru[i]);
+                *reinterpret_cast<f32x4 *>(&tileD[stile_off(row, lc4)]) = vd;
+            }
+#pragma unroll
+            for (int i = 0; i < kBCPieces; ++i) {
+                const int n = i * 8 + lrow;
+                if (kN * 8 % kWave == 0 || n < kN) {
+                    *reinterpret_cast<f32x4 *>(&tileB[n * kST + lcol]) = widen(rb[i]);
+                    *reinterpret_cast<f32x4 *>(&tileC[n * kST + lcol]) = widen(rc[i]);
+                }
+            }
+            if (tile + 1 < n_tiles) issue_loads(t0 + kST);   // flies under the compute below
+            if constexpr (kHasZ) {
+                const int col = col_of(t0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rz[i] = ld4<T>(piece(z_base, z_ds, i, col));
+            }
+        } else {
+            for (int i = 0; i < kSC * kST / kWave; ++i) {
+                const int idx = i * kWave + lane, row = idx / kST, col = idx & (kST - 1);
+                const bool ok = row < nd && t0 + col < L;
+                float vu = 0.f, vd = 0.f;
+                if (ok) {
+                    vu = to_f32<T>(u_base[(unsigned)(row * u_ds + t0 + col)]);
+                    vd = softplus_if(to_f32<T>(dl_base[(unsigned)(row * dl_ds + t0 + col)]) + (bias_p ? bias_p[d0 + row] : 0.f), softplus);
+                }
+                tileU[stile_off(row, col >> 2) + (col & 3)] = vu;
+                tileD[stile_off(row, col >> 2) + (col & 3)] = vd;
+            }
+            for (int idx = lane; idx < kN * kST; idx += kWave) {
+                const int n = idx / kST, tc = min(t0 + (idx & (kST - 1)), L - 1);
+                tileB[idx] = to_f32<T>(Bp[(unsigned)(n * Bns + tc)]);
+                tileC[idx] = to_f32<T>(Cp[(unsigned)(n * Cns + tc)]);
+            }
+        }
+
+        // ---- 32 sequential steps, 4 at a time; 5 VALU ops per (t, n): mul, v_exp_f32, mul, fma, fma ---------------------
+#pragma unroll 1
+        for (int j = 0; j < kST / 4; ++j) {
+            const int tj = t0 + j * 4;
+            if (tj >= L) break;
+            if (kCkpt && ck_base && (j & 1) == 0) {
+                float *ck = ck_base + (int64_t)(tj >> 3) * kN * p.dim;
+#pragma unroll
+                for (int k = 0; k < kNL; ++k) ck[(int64_t)k * p.dim] = h[k];
+            }
+            const f32x4 u4 = *reinterpret_cast<const f32x4 *>(&tileU[stile_off(c, j)]);
+            const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&tileD[stile_off(c, j)]);
+            const int brow0 = ns0 * kST + j * 4;
+            f32x4 bq_nxt = *reinterpret_cast<const f32x4 *>(&tileB[brow0]);
+            f32x4 cq_nxt = *reinterpret_cast<const f32x4 *>(&tileC[brow0]);
+            float du[4], y[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { sum_dt += d4.v[s]; du[s] = d4.v[s] * u4.v[s]; y[s] = Dval * u4.v[s]; }
+#pragma unroll
+            for (int k = 0; k < kNL; ++k) {
+                const f32x4 bq = bq_nxt, cq = cq_nxt;
+                if (k + 1 < kNL) {
+                    bq_nxt = *reinterpret_cast<const f32x4 *>(&tileB[brow0 + (k + 1) * kST]);
+                    cq_nxt = *reinterpret_cast<const f32x4 *>(&tileC[brow0 + (k + 1) * kST]);
+                }
+                float hn = h[k];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    hn = fmaf(fast_exp2(d4.v[s] * A2[k]), hn, bq.v[s] * du[s]);
+                    y[s] = fmaf(hn, cq.v[s], y[s]);
+                }
+                h[k] = hn;
+            }
+            // join the halves: low lane <- totals of steps 0 and 2, high lane <- totals of steps 1 and 3
+            swap_halves(y[0], y[1]);
+            swap_halves(y[2], y[3]);
+            const float ya = y[0] + y[1], yb = y[2] + y[3];
+            float *slot = &tileU[stile_off(c, j)] + sh;
+            slot[0] = ya;
+            slot[2] = yb;
+        }
+
+        // ---- chunk-state store at every 2048 boundary and at the end (selective_scan_fwd_kernel.cuh:251-254) ---
+        const int t_end = min(t0 + kST, L);
+        if (p.x_ptr && ((t_end & 2047) == 0 || t_end == L) && live) {
+            float *xr = reinterpret_cast<float *>(p.x_ptr) + (((int64_t)b * p.dim + d) * p.n_chunks + (t_end - 1) / 2048) * (2 * kN) + 2 * ns0;
+#pragma unroll
+            for (int k = 0; k < kNL; k += 2) {
+                const f32x4 v = {{fast_exp2(A2[k] * sum_dt), h[k], fast_exp2(A2[k + 1] * sum_dt), h[k + 1]}};
+                *reinterpret_cast<f32x4 *>(xr + 2 * k) = v;
+            }
+        }
+
+        // ---- epilogue: re-read y in the coalesced layout, gate, store -------------------------------------------
+        if constexpr (kVec) {
+            if (t0 + lcol < L) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = i * 8 + lrow;
+                    if (kFull || row < nd) {
+                        f32x4 y4 = *reinterpret_cast<const f32x4 *>(&tileU[stile_off(row, lc4)]);
+                        if (has_out) st4<T>(at(out_base + i * 8 * out_ds, (unsigned)(lrow * out_ds + t0 + lcol)), y4);
+                        if constexpr (kHasZ) {
+                            const f32x4 z4 = widen(rz[i]);
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) y4.v[s] *= z4.v[s] * sigmoidf_fast(z4.v[s]);
+                            st4<T>(at(oz_base + i * 8 * oz_ds, (unsigned)(lrow * oz_ds + t0 + lcol)), y4);
+                        }
+                    }
+                }
+            }
+        } else {
+            for (int i = 0; i < kSC * kST / kWave; ++i) {
+                const int idx = i * kWave + lane, row = idx / kST, col = idx & (kST - 1);
+                if (row < nd && t0 + col < L) {
+                    const float yv = tileU[stile_off(row, col >> 2) + (col & 3)];
+                    if (out_base) out_base[(unsigned)(row * out_ds + t0 + col)] = from_f32<T>(yv);
+                    if constexpr (kHasZ) {
+                        const float zv = to_f32<T>(z_base[(unsigned)(row * z_ds + t0 + col)]);
+                        oz_base[(unsigned)(row * oz_ds + t0 + col)] = from_f32<T>(yv * zv * sigmoidf_fast(zv));
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace dimsum

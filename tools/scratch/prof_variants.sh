@@ -13,7 +13,7 @@ rows=list(csv.DictReader(open(f)))
 out=[]
 for r in rows:
     n=r['Name']
-    if 'ssm_scan' in n:
+    if "ssm_scan" in n:
         out.append(f"{n.split('(')[0].replace('void dimsum::','')[:48]} avg {float(r['AverageNs'])/1e3:.1f}us min {int(r['MinNs'])/1e3:.1f} x{r['Calls']}")
 print(v+': '+' | '.join(out))
 P
