@@ -73,7 +73,8 @@ class TtParams(C.Structure):
 class XattnParams(C.Structure):
     _fields_ = ([(n, i32) for n in ("batch", "seqlen", "heads", "head_dim")] + [("scale", f32), ("n_dirs", i32)]
                 + [(n, i64) for n in ("qkv_batch_stride", "qkv_token_stride", "out_batch_stride", "out_token_stride")]
-                + [(n, vp) for n in ("qkv1_ptr", "qkv2_ptr", "out_ptr", "lse_ptr", "bias1_ptr", "bias2_ptr")])
+                + [(n, vp) for n in ("qkv1_ptr", "qkv2_ptr", "out_ptr", "lse_ptr", "bias1_ptr", "bias2_ptr")]
+                + [("precision", i32), ("reserved", i32)])
 
 
 class XattnBwdParams(C.Structure):
@@ -122,7 +123,7 @@ def load():
     if hasattr(lib, "dimsum_ssm_scan_bwd_workspace_bytes"):
         lib.dimsum_ssm_scan_bwd_workspace_bytes.restype = i64
         lib.dimsum_ssm_scan_bwd_workspace_bytes.argtypes = [i32] * 5
-    if lib.dimsum_abi_version() != 6:
+    if lib.dimsum_abi_version() != 7:
         raise RuntimeError("dimsum_amd: libdimsum_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

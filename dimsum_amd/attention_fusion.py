@@ -18,6 +18,8 @@ class _XattnCoreFn(torch.autograd.Function):
     def forward(ctx, qkv1, qkv2, bias1, bias2, heads):
         b1 = None if bias1 is None else bias1.float().contiguous()
         b2 = None if bias2 is None else bias2.float().contiguous()
+        if not any(ctx.needs_input_grad[:4]):        # inference: no log-sum-exp to save
+            return native.xattn_fusion_fwd(qkv1, qkv2, heads, bias1=b1, bias2=b2)
         out, lse = native.xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=True, bias1=b1, bias2=b2)
         ctx.heads = heads
         ctx.save_for_backward(qkv1, qkv2, b1, b2, out, lse)

@@ -182,6 +182,206 @@ __global__ __launch_bounds__(256) void xattn_fusion_fwd_kernel(const dimsum_xatt
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Split-bf16 variant (precision = 1). Same transposed formulation, on v_mfma_f32_16x16x32_bf16 (2.5 PFLOP/s dense peak,
+// 16x the fp32 MFMA rate): every fp32 operand x is split into hi = bf16(x), lo = bf16(x - hi) and a product a.b becomes
+// hi.hi + hi.lo + lo.hi with fp32 accumulation (the dropped lo.lo term is ~2^-16 relative) -- the arithmetic hipBLASLt uses
+// for the library GEMMs under the reference's allow_tf32 policy on gfx950, so attention and GEMMs share one precision
+// policy. 3 bf16 MFMAs of K = 32 replace 8 fp32 MFMAs of K = 4: 5.3x fewer matrix-core cycles per tile.
+//   * K-slot j of lane group g (= lane >> 4) of a 32-deep chunk is reduction index 8g + j. For QK^T that is e = 32c + 8g + j
+//     (one ds_read_b128 of the bf16 K tile); for PV the slots of chunk c are the keys the lane ALREADY holds in its two S^T
+//     C-register quadruples: j < 4 -> key 32c + 4g + j (tile 2c), j >= 4 -> key 32c + 16 + 4g + (j - 4) (tile 2c + 1).
+//     V^T is staged with exactly that key permutation inside each 32-key chunk, so its A operand is one ds_read_b128 too
+//     and P^T never changes layout.
+//   * K, V^T tiles are split once per workgroup while they are staged (hi and lo images, bf16, rows padded by 16 B).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct alignas(16) u4v { unsigned w[4]; };
+
+// (hi, lo) bf16 pair images of two fp32 values, packed [x0 | x1 << 16] (v_cvt_pk_bf16_f32: round to nearest even)
+__device__ __forceinline__ void split2(float x0, float x1, unsigned &hi, unsigned &lo) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const bf16x2 h = __builtin_convertvector(f2{x0, x1}, bf16x2);
+    hi = *reinterpret_cast<const unsigned *>(&h);
+    const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+    const bf16x2 l = __builtin_convertvector(f2{r0, r1}, bf16x2);
+    lo = *reinterpret_cast<const unsigned *>(&l);
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(const u4v &v) { return __builtin_bit_cast(bf16x8, v); }
+
+template <int HD>
+__global__ __launch_bounds__(256) void xattn_fusion_fwd_split_kernel(const dimsum_xattn_params_t p) {
+    constexpr int EP = (HD + 31) / 32 * 32;  // reduction length of QK^T, padded with zeros to whole 32-deep chunks
+    constexpr int EC = EP / 32;
+    constexpr int ET = (HD + 15) / 16;       // 16-row output tiles along e
+    constexpr int KS = EP + 8;               // K tile row stride in bf16 elements (16 B of padding)
+    constexpr int VS = kKT + 8;              // V^T tile row stride
+    static_assert(HD % 8 == 0, "head_dim must be a multiple of 8");
+    __shared__ __attribute__((aligned(16))) unsigned short Kh[kKT * KS], Kl[kKT * KS];
+    __shared__ __attribute__((aligned(16))) unsigned short Vh[ET * 16 * VS], Vl[ET * 16 * VS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int L = p.seqlen, H = p.heads;
+    const int qblocks = (L + 63) / 64;
+    int idx = blockIdx.x;
+    const int qb = idx % qblocks; idx /= qblocks;
+    const int ndir = p.n_dirs == 1 ? 1 : 2;
+    const int dir = idx % ndir; idx /= ndir;
+    const int h = idx % H;
+    const int b = idx / H;
+    const int C = H * HD;
+    const bool kv_from_1 = dir == 1 || ndir == 1;
+    const float *qsrc = reinterpret_cast<const float *>(dir == 0 ? p.qkv1_ptr : p.qkv2_ptr) + (int64_t)b * p.qkv_batch_stride + h * HD;
+    const float *kvsrc = reinterpret_cast<const float *>(kv_from_1 ? p.qkv1_ptr : p.qkv2_ptr) + (int64_t)b * p.qkv_batch_stride + h * HD;
+    const float *ksrc = kvsrc + C, *vsrc = kvsrc + 2 * C;
+    const int64_t ts = p.qkv_token_stride;
+    const float *qbv = reinterpret_cast<const float *>(dir == 0 ? p.bias1_ptr : p.bias2_ptr);
+    const float *kvb = reinterpret_cast<const float *>(kv_from_1 ? p.bias1_ptr : p.bias2_ptr);
+    const float *qbias = qbv ? qbv + h * HD : nullptr;
+    const float *kbias = kvb ? kvb + C + h * HD : nullptr, *vbias = kvb ? kvb + 2 * C + h * HD : nullptr;
+
+    const int qi = lane & 15, kg = lane >> 4;
+    const int q_tok = qb * 64 + wave * kQW + qi;
+    const int q_ld = min(q_tok, L - 1);
+    const float qscale = p.scale * kLog2e;                    // scores live in the log2 domain
+    // Q^T fragments (B operand): chunk c, slots j = 0..7 <-> e = 32c + 8 kg + j; zeros beyond hd
+    u4v qh[EC], ql[EC];
+#pragma unroll
+    for (int c = 0; c < EC; ++c) {
+        float v[8];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int e0 = 32 * c + 8 * kg + 4 * half;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e0 < HD) {
+                t = *reinterpret_cast<const float4 *>(qsrc + (int64_t)q_ld * ts + e0);
+                if (qbias) { const float4 bq = *reinterpret_cast<const float4 *>(qbias + e0); t.x += bq.x; t.y += bq.y; t.z += bq.z; t.w += bq.w; }
+            }
+            v[4 * half + 0] = t.x * qscale; v[4 * half + 1] = t.y * qscale; v[4 * half + 2] = t.z * qscale; v[4 * half + 3] = t.w * qscale;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) split2(v[2 * i], v[2 * i + 1], qh[c].w[i], ql[c].w[i]);
+    }
+    // zero the padding that is never rewritten: K columns e in [hd, EP), V^T rows e in [hd, ET*16)
+    if constexpr (EP > HD) {
+        for (int i = tid; i < kKT * (EP - HD); i += 256) { const int key = i / (EP - HD), e = HD + i % (EP - HD); Kh[key * KS + e] = 0; Kl[key * KS + e] = 0; }
+    }
+    if constexpr (ET * 16 > HD) {
+        for (int i = tid; i < (ET * 16 - HD) * kKT; i += 256) { const int e = HD + i / kKT, k = i % kKT; Vh[e * VS + k] = 0; Vl[e * VS + k] = 0; }
+    }
+
+    f4 o[ET];
+#pragma unroll
+    for (int e = 0; e < ET; ++e) o[e] = f4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -1e30f, l_run = 0.f;
+
+    for (int k0 = 0; k0 < L; k0 += kKT) {
+        __syncthreads();
+        // ---- stage K [key][e] and V^T [e][pi(key)] (hi / lo bf16 images) for keys k0 .. k0+63; one thread = 2 keys x 4 e -----
+        for (int i = tid; i < (kKT / 2) * (HD / 4); i += 256) {
+            const int kp = i / (HD / 4), e4 = i - kp * (HD / 4), key = 2 * kp;
+            const int tok0 = min(k0 + key, L - 1), tok1 = min(k0 + key + 1, L - 1);
+            float4 ka = *reinterpret_cast<const float4 *>(ksrc + (int64_t)tok0 * ts + e4 * 4), kb = *reinterpret_cast<const float4 *>(ksrc + (int64_t)tok1 * ts + e4 * 4);
+            float4 va = *reinterpret_cast<const float4 *>(vsrc + (int64_t)tok0 * ts + e4 * 4), vb = *reinterpret_cast<const float4 *>(vsrc + (int64_t)tok1 * ts + e4 * 4);
+            if (kbias) {
+                const float4 bk = *reinterpret_cast<const float4 *>(kbias + e4 * 4), bv = *reinterpret_cast<const float4 *>(vbias + e4 * 4);
+                ka.x += bk.x; ka.y += bk.y; ka.z += bk.z; ka.w += bk.w; kb.x += bk.x; kb.y += bk.y; kb.z += bk.z; kb.w += bk.w;
+                va.x += bv.x; va.y += bv.y; va.z += bv.z; va.w += bv.w; vb.x += bv.x; vb.y += bv.y; vb.z += bv.z; vb.w += bv.w;
+            }
+            unsigned h0, l0, h1, l1;
+            split2(ka.x, ka.y, h0, l0); split2(ka.z, ka.w, h1, l1);
+            *reinterpret_cast<uint2 *>(&Kh[key * KS + e4 * 4]) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2 *>(&Kl[key * KS + e4 * 4]) = make_uint2(l0, l1);
+            split2(kb.x, kb.y, h0, l0); split2(kb.z, kb.w, h1, l1);
+            *reinterpret_cast<uint2 *>(&Kh[(key + 1) * KS + e4 * 4]) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2 *>(&Kl[(key + 1) * KS + e4 * 4]) = make_uint2(l0, l1);
+            // position of key kappa inside its 32-key chunk: 8 * ((kappa & 15) >> 2) + (kappa & 3) + 4 * ((kappa >> 4) & 1)
+            const int kap = key & 31, pos = (key & ~31) + 8 * ((kap & 15) >> 2) + (kap & 3) + 4 * (kap >> 4);   // key even -> pos, pos + 1 = keys key, key + 1
+            const float a4[4] = {va.x, va.y, va.z, va.w}, b4[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                split2(a4[e], b4[e], h0, l0);
+                *reinterpret_cast<unsigned *>(&Vh[(e4 * 4 + e) * VS + pos]) = h0;
+                *reinterpret_cast<unsigned *>(&Vl[(e4 * 4 + e) * VS + pos]) = l0;
+            }
+        }
+        __syncthreads();
+
+        // ---- S^T = K Q^T for the 4 key tiles of 16: 3 bf16 MFMAs per 32-deep chunk ----------------------------------------
+        f4 s[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+            const int krow = (kt * 16 + qi) * KS + 8 * kg;         // A operand row: key = kt*16 + (lane&15), slots e = 32c + 8 kg + j
+#pragma unroll
+            for (int c = 0; c < EC; ++c) {
+                const u4v kh = *reinterpret_cast<const u4v *>(&Kh[krow + 32 * c]), kl = *reinterpret_cast<const u4v *>(&Kl[krow + 32 * c]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(kl), as_bf16x8(qh[c]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(kh), as_bf16x8(ql[c]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(kh), as_bf16x8(qh[c]), acc, 0, 0, 0);
+            }
+            s[kt] = acc;                                       // s[kt][r]: key k0 + kt*16 + kg*4 + r, query qi
+        }
+        // ---- online softmax for this lane's query (fp32) ------------------------------------------------------------------
+        float mx = -1e30f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (k0 + kt * 16 + kg * 4 + r >= L) s[kt][r] = -1e30f;
+                mx = fmaxf(mx, s[kt][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, kWave));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = fast_exp2(m_run - m_new);
+        float rs = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[kt][r] = fast_exp2(s[kt][r] - m_new); rs += s[kt][r]; }
+        rs += __shfl_xor(rs, 16, kWave);
+        rs += __shfl_xor(rs, 32, kWave);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int e = 0; e < ET; ++e) o[e] *= alpha;
+        // ---- P^T (B operand) of the two 32-key chunks: slots j < 4 = s[2c][j], j >= 4 = s[2c+1][j-4], split hi / lo -----------
+        u4v ph[2], pl[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            split2(s[2 * c][0], s[2 * c][1], ph[c].w[0], pl[c].w[0]);
+            split2(s[2 * c][2], s[2 * c][3], ph[c].w[1], pl[c].w[1]);
+            split2(s[2 * c + 1][0], s[2 * c + 1][1], ph[c].w[2], pl[c].w[2]);
+            split2(s[2 * c + 1][2], s[2 * c + 1][3], ph[c].w[3], pl[c].w[3]);
+        }
+        // ---- O^T += V^T P^T ---------------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int e = 0; e < ET; ++e) {
+            const int vrow = (e * 16 + qi) * VS + 8 * kg;          // A operand row: e = e*16 + (lane&15), slots = permuted keys
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const u4v vh = *reinterpret_cast<const u4v *>(&Vh[vrow + 32 * c]), vl = *reinterpret_cast<const u4v *>(&Vl[vrow + 32 * c]);
+                o[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(vl), as_bf16x8(ph[c]), o[e], 0, 0, 0);
+                o[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(vh), as_bf16x8(pl[c]), o[e], 0, 0, 0);
+                o[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(vh), as_bf16x8(ph[c]), o[e], 0, 0, 0);
+            }
+        }
+    }
+
+    if (q_tok < L) {
+        const float inv = 1.0f / l_run;
+        float *dst = reinterpret_cast<float *>(p.out_ptr) + (int64_t)b * p.out_batch_stride + (int64_t)q_tok * p.out_token_stride + dir * C + h * HD;
+#pragma unroll
+        for (int e = 0; e < ET; ++e) {
+            const int e0 = e * 16 + kg * 4;
+            if (e0 < HD) *reinterpret_cast<float4 *>(dst + e0) = make_float4(o[e][0] * inv, o[e][1] * inv, o[e][2] * inv, o[e][3] * inv);
+        }
+        if (p.lse_ptr && kg == 0)
+            reinterpret_cast<float *>(p.lse_ptr)[(((int64_t)b * ndir + dir) * H + h) * L + q_tok] = (m_run + __builtin_amdgcn_logf(l_run)) * kLn2;
+    }
+}
+
 }  // namespace dimsum
 
 extern "C" int dimsum_xattn_fusion_fwd(const dimsum_xattn_params_t *p, void *stream) {
@@ -200,6 +400,18 @@ extern "C" int dimsum_xattn_fusion_fwd(const dimsum_xattn_params_t *p, void *str
     const int64_t nblk = (int64_t)p->batch * p->heads * (self_attn ? 1 : 2) * ((p->seqlen + 63) / 64);
     if (nblk > 0x7fffffff) return DIMSUM_ERR_SHAPE;
     const dim3 grid((unsigned)nblk), block(256);
+    if (p->precision != 0 && p->precision != 1) return DIMSUM_ERR_SHAPE;
+    if (p->precision == 1) {
+        switch (p->head_dim) {
+            case 24: hipLaunchKernelGGL(xattn_fusion_fwd_split_kernel<24>, grid, block, 0, s, *p); break;
+            case 32: hipLaunchKernelGGL(xattn_fusion_fwd_split_kernel<32>, grid, block, 0, s, *p); break;
+            case 48: hipLaunchKernelGGL(xattn_fusion_fwd_split_kernel<48>, grid, block, 0, s, *p); break;
+            case 64: hipLaunchKernelGGL(xattn_fusion_fwd_split_kernel<64>, grid, block, 0, s, *p); break;
+            case 72: hipLaunchKernelGGL(xattn_fusion_fwd_split_kernel<72>, grid, block, 0, s, *p); break;
+            default: return DIMSUM_ERR_SHAPE;
+        }
+        return launch_status();
+    }
     switch (p->head_dim) {
         case 24: hipLaunchKernelGGL(xattn_fusion_fwd_kernel<24>, grid, block, 0, s, *p); break;
         case 32: hipLaunchKernelGGL(xattn_fusion_fwd_kernel<32>, grid, block, 0, s, *p); break;

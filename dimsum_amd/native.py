@@ -429,11 +429,15 @@ def xattn_supported(qkv, head_dim):
     return qkv.is_cuda and qkv.dtype == torch.float32 and qkv.stride(-1) == 1 and head_dim in (24, 32, 48, 64, 72)
 
 
-def xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=False, bias1=None, bias2=None):
+def xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=False, bias1=None, bias2=None, split_bf16=None):
     """qkv*: (B, L, 3*heads*hd) -> (B, L, 2*heads*hd) = cat(softmax(q1 k2^T/sqrt(hd)) v2, softmax(q2 k1^T/sqrt(hd)) v1).
     qkv2 = None: plain self-attention softmax(q1 k1^T/sqrt(hd)) v1 -> (B, L, heads*hd).
-    bias1/bias2 (3*heads*hd): the qkv Linear biases when qkv* are bias-free GEMM outputs (added inside the kernel)."""
+    bias1/bias2 (3*heads*hd): the qkv Linear biases when qkv* are bias-free GEMM outputs (added inside the kernel).
+    split_bf16: None follows torch.backends.cuda.matmul.allow_tf32 (the reference's GEMM policy, train.py:20-21: the
+    QK^T / PV contractions then run as split-bf16 MFMA like the library GEMMs do); False = exact fp32 MFMA."""
     self_attn = qkv2 is None
+    if split_bf16 is None:
+        split_bf16 = bool(torch.backends.cuda.matmul.allow_tf32)
     _gpu(qkv1, qkv2, bias1, bias2)
     _check(self_attn or (bias1 is None) == (bias2 is None), "xattn_fusion: pass both biases or none")
     for bb in (bias1, bias2):
@@ -454,6 +458,7 @@ def xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=False, bias1=None, bias2=None):
         P.out_batch_stride, P.out_token_stride = out.stride(0), out.stride(1)
         P.qkv1_ptr, P.qkv2_ptr, P.out_ptr, P.lse_ptr = _ptr(qkv1), _ptr(qkv2), _ptr(out), _ptr(lse)
         P.bias1_ptr, P.bias2_ptr = _ptr(bias1), _ptr(bias2)
+        P.precision = 1 if split_bf16 else 0
         with torch.cuda.device(qkv1.device):
             _lib.check(_lib.load().dimsum_xattn_fusion_fwd(P, _stream(qkv1)), "xattn_fusion_fwd")
     return (out, lse) if need_lse else out

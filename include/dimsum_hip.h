@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DIMSUM_ABI_VERSION 6
+#define DIMSUM_ABI_VERSION 7
 
 typedef enum {
     DIMSUM_OK = 0,
@@ -247,6 +247,11 @@ typedef struct {
     void *out_ptr, *lse_ptr;
     const void *bias1_ptr, *bias2_ptr;   /* optional (3*heads*hd) f32: the qkv Linear biases, added while q / k / v are
                                             fetched, so that the qkv GEMMs can run without a bias epilogue */
+    int32_t precision;  /* forward only. 0: exact fp32 MFMA (v_mfma_f32_16x16x4_f32). 1: split-bf16 -- every fp32 operand
+                           x = hi + lo (two bf16), products hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_bf16 with fp32
+                           accumulation, ~1e-5 relative: the same arithmetic hipBLASLt uses for the reference's
+                           torch.backends.cuda.matmul.allow_tf32 = True policy (train.py:20-21) on gfx950 */
+    int32_t reserved;
 } dimsum_xattn_params_t;
 
 int dimsum_xattn_fusion_fwd(const dimsum_xattn_params_t *p, void *stream);

@@ -117,3 +117,44 @@ def test_self_attention_mode_fwd_bwd(B, L, heads, hd):
         res.append((out.detach(), qkv.grad, bias.grad))
     for name, a, b in zip(("out", "dqkv", "dbias"), res[0], res[1]):
         assert_close(a.cpu().numpy(), b.cpu().numpy(), 1e-4, 0, name, scale_atol=1e-5 if name != "dbias" else 5e-5)
+
+
+@pytest.mark.parametrize("B,L,heads,hd", [(2, 256, 8, 64), (1, 1024, 8, 72), (3, 256, 8, 24), (2, 256, 8, 48), (2, 100, 4, 32), (1, 64, 8, 64)])
+def test_split_bf16_core_vs_oracle(B, L, heads, hd):
+    """precision = 1: the QK^T / PV contractions on bf16 MFMA with every fp32 operand split into hi + lo (3 products,
+    fp32 accumulation). Tolerance rtol 5e-5 + 2e-5 * max|ref| -- the dropped lo.lo terms are 2^-16 relative per product;
+    20x tighter than real TF32 (the reference's own matmul policy) would need, and far inside the north star's 1e-3."""
+    from dimsum_amd import native
+    from oracle import np_ops
+    gen = torch.Generator().manual_seed(L + hd)
+    qkv1, qkv2 = torch.randn(B, L, 3 * heads * hd, generator=gen), torch.randn(B, L, 3 * heads * hd, generator=gen)
+    ref = np_ops.xattn_fusion_core(qkv1.numpy(), qkv2.numpy(), heads)
+    out = native.xattn_fusion_fwd(qkv1.cuda(), qkv2.cuda(), heads, split_bf16=True)
+    assert_close(out.cpu().numpy(), ref, 5e-5, 0, "out (split-bf16)", scale_atol=2e-5)
+    exact = native.xattn_fusion_fwd(qkv1.cuda(), qkv2.cuda(), heads, split_bf16=False)
+    rms = ((out - exact).pow(2).mean().sqrt() / exact.pow(2).mean().sqrt()).item()
+    assert rms < 1e-5, rms
+    # biases ride along the same way, and the self-attention mode shares the kernel
+    W = 3 * heads * hd
+    b1, b2 = torch.randn(W, generator=gen).cuda(), torch.randn(W, generator=gen).cuda()
+    a = native.xattn_fusion_fwd(qkv1.cuda(), qkv2.cuda(), heads, bias1=b1, bias2=b2, split_bf16=True)
+    r = native.xattn_fusion_fwd(qkv1.cuda() + b1, qkv2.cuda() + b2, heads, split_bf16=False)
+    assert_close(a.cpu().numpy(), r.cpu().numpy(), 5e-5, 0, "out (split-bf16, in-kernel bias)", scale_atol=2e-5)
+    sa = native.xattn_fusion_fwd(qkv1.cuda(), None, heads, split_bf16=True)
+    sr = native.xattn_fusion_fwd(qkv1.cuda(), None, heads, split_bf16=False)
+    assert_close(sa.cpu().numpy(), sr.cpu().numpy(), 5e-5, 0, "self-attention (split-bf16)", scale_atol=2e-5)
+
+
+def test_split_bf16_follows_matmul_policy():
+    """the default precision follows torch.backends.cuda.matmul.allow_tf32 (the reference's policy switch, train.py:20-21)"""
+    from dimsum_amd import native
+    gen = torch.Generator().manual_seed(1)
+    qkv1, qkv2 = torch.randn(1, 128, 3 * 8 * 64, generator=gen).cuda(), torch.randn(1, 128, 3 * 8 * 64, generator=gen).cuda()
+    old = torch.backends.cuda.matmul.allow_tf32
+    try:
+        torch.backends.cuda.matmul.allow_tf32 = False
+        assert torch.equal(native.xattn_fusion_fwd(qkv1, qkv2, 8), native.xattn_fusion_fwd(qkv1, qkv2, 8, split_bf16=False))
+        torch.backends.cuda.matmul.allow_tf32 = True
+        assert torch.equal(native.xattn_fusion_fwd(qkv1, qkv2, 8), native.xattn_fusion_fwd(qkv1, qkv2, 8, split_bf16=True))
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = old
