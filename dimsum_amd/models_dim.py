@@ -17,6 +17,7 @@ from functools import partial
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import scanning_orders as so
 from .attention_fusion import CrossAttentionFusion
@@ -73,7 +74,13 @@ class PatchEmbed(nn.Module):
         self.norm = nn.Identity()
 
     def forward(self, x):
-        return self.proj(x).flatten(2).transpose(1, 2)
+        # Conv2d with kernel = stride = patch is a Linear over the flattened (c, i, j) patch: run it as ONE GEMM (MIOpen
+        # serves this conv with a per-image im2col + GEMM pair, 2 x batch launches). `proj` stays a Conv2d for the
+        # reference's state_dict layout (x_embedder.proj.weight (D, C, p, p)).
+        B, C, H, W = x.shape
+        ph, pw = self.patch_size
+        patches = x.reshape(B, C, H // ph, ph, W // pw, pw).permute(0, 2, 4, 1, 3, 5).reshape(B, (H // ph) * (W // pw), C * ph * pw)
+        return F.linear(patches, self.proj.weight.reshape(self.proj.weight.shape[0], -1), self.proj.bias)
 
 
 class TimestepEmbedder(nn.Module):
