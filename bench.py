@@ -167,6 +167,8 @@ def main():
                          "(configs[3]); block: ONE DiMBlockCombined forward+backward (configs[2]); train: one whole "
                          "flow-matching training step (loss, backward, DDP all-reduce over RCCL, clip, AdamW, EMA)")
     ap.add_argument("--nfe", type=int, default=250)
+    ap.add_argument("--hip-graph", action="store_true", help="fwd / sample: replay the denoiser forward from a captured hipGraph "
+                                                             "(dimsum_amd/hip_graph.py): for per-GPU batches below ~32, where eager is launch-bound")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the extra exact-fp32 timing (for profiling runs)")
     ap.add_argument("--matmul", choices=["tf32", "fp32"], default="tf32",
@@ -230,14 +232,23 @@ def main():
             torch.autograd.backward((out, res_out), (dy, dy))
         units_per_step = args.batch
     elif args.mode == "fwd":
-        def step():
-            with torch.no_grad():
-                return model(x, t, y)
+        if args.hip_graph:
+            from dimsum_amd.hip_graph import GraphedForward
+            graphed = GraphedForward(model)
+
+            def step():
+                return graphed(x, t, y)
+        else:
+            def step():
+                with torch.no_grad():
+                    return model(x, t, y)
         units_per_step = args.batch
     else:
         from dimsum_amd.sample_ddp import sample_batch
+        graphs = {} if args.hip_graph else None
+
         def step():
-            return sample_batch(model, x, y, num_steps=args.nfe, world_size=world)
+            return sample_batch(model, x, y, num_steps=args.nfe, world_size=world, hip_graph=graphs)
         units_per_step = args.batch
 
     def fence():
@@ -277,6 +288,7 @@ def main():
                                    "random-init weights (reference init, zero tensors re-drawn N(0, 0.02^2))"
                                    + (f", scan_type={args.scan_type}" if args.scan_type != "none" else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world} (replicas, independent latents)",
+                       "launch": "hipGraph replay" if args.hip_graph else "eager",
                        "matmul_policy": ("allow_tf32=True like the reference (train.py:20-21); gfx950 split-bf16 path, 4e-6 rms rel err"
                                          if args.matmul == "tf32" else "exact fp32")},
         }

@@ -93,7 +93,7 @@ class TimestepEmbedder(nn.Module):
     @staticmethod
     def timestep_embedding(t, dim, max_period=10000):
         half = dim // 2
-        freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32) / half).to(t.device)
+        freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / half)   # on the device: HIP-graph capturable
         args = t[:, None].float() * freqs[None]
         emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
         if dim % 2:

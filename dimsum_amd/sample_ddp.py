@@ -19,19 +19,27 @@ def _dist_ready():
 
 
 @torch.no_grad()
-def sample_batch(model, z, y, num_steps=250, sampling_method="euler", cfg_scale=None, path_type="GVP", world_size=None, gather=True):
+def sample_batch(model, z, y, num_steps=250, sampling_method="euler", cfg_scale=None, path_type="GVP", world_size=None, gather=True,
+                 hip_graph=None):
     """Integrates dx/dt = model(x, t, y) from t = 0 (noise z) to t = 1 on linspace(0, 1, num_steps + 1): exactly
     `num_steps` function evaluations with Euler. With cfg_scale the batch is doubled like sample_ddp.py:168-173.
     Returns this rank's samples, or the all-gathered (world * B, C, H, W) tensor when a process group is up."""
+    fwd = model.forward if hasattr(model, "forward") else model
+    fwd_cfg = getattr(model, "forward_with_cfg", None)
+    if hip_graph is not None:                     # a dict owned by the caller: the captured graphs live across batches
+        from .hip_graph import GraphedForward
+        fwd = hip_graph.setdefault("fwd", GraphedForward(fwd))
+        if fwd_cfg is not None:
+            fwd_cfg = hip_graph.setdefault("cfg", GraphedForward(fwd_cfg))
     sampler = Sampler(create_transport(path_type, "velocity"))
     fn = sampler.sample_ode(sampling_method=sampling_method, num_steps=num_steps + 1)
     if cfg_scale is not None and cfg_scale > 1.0:
         n = z.shape[0]
         zz = torch.cat([z, z], 0)
         y_null = torch.full_like(y, getattr(model, "num_classes", 1000))
-        out = fn(zz, model.forward_with_cfg, return_trajectory=False, y=torch.cat([y, y_null], 0), cfg_scale=cfg_scale)[:n]
+        out = fn(zz, fwd_cfg, return_trajectory=False, y=torch.cat([y, y_null], 0), cfg_scale=cfg_scale)[:n]
     else:
-        out = fn(z, model.forward if hasattr(model, "forward") else model, return_trajectory=False, y=y)
+        out = fn(z, fwd, return_trajectory=False, y=y)
     ws = world_size if world_size is not None else (dist.get_world_size() if _dist_ready() else 1)
     if gather and ws > 1 and _dist_ready():
         out = out.contiguous()
@@ -63,6 +71,7 @@ def main(argv=None):
     ap.add_argument("--global-seed", type=int, default=0)
     ap.add_argument("--ckpt", default=None)
     ap.add_argument("--out", default=None, help="rank 0 writes the gathered latents here (.pt)")
+    ap.add_argument("--hip-graph", action="store_true", help="replay the denoiser forward from a captured hipGraph (small per-GPU batches)")
     ap.add_argument("--tf32", action=argparse.BooleanOptionalAction, default=True,
                     help="library-GEMM policy of the reference (sample_ddp.py:56,267-272); exact fp32 with --no-tf32")
     args, _ = ap.parse_known_args(argv)          # unknown flags are ignored like sample_ddp.py:369
@@ -83,11 +92,12 @@ def main(argv=None):
     r = args.image_size // 8
     n_iter = -(-args.num_fid_samples // (args.per_proc_batch_size * world))
     chunks = []
+    graphs = {} if args.hip_graph else None
     for _ in range(n_iter):
         z = torch.randn(args.per_proc_batch_size, model.in_channels, r, r, device=device)
         y = torch.randint(0, args.num_classes, (args.per_proc_batch_size,), device=device)
         chunks.append(sample_batch(model, z, y, args.num_sampling_steps, args.sampling_method,
-                                   args.cfg_scale if args.cfg_scale > 1.0 else None, args.path_type))
+                                   args.cfg_scale if args.cfg_scale > 1.0 else None, args.path_type, hip_graph=graphs))
     dist.barrier()
     if rank == 0 and args.out:
         torch.save(torch.cat(chunks)[: args.num_fid_samples].cpu(), args.out)

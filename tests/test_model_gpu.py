@@ -123,3 +123,33 @@ def test_tiny_model_fwd_bwd():
     out.backward(T(g["dout"]).cuda())
     assert_close(out.detach().cpu().numpy(), g["out"], 2e-4, 0, "out", scale_atol=2e-5)
     assert_close(x.grad.cpu().numpy(), g["dx"], 1e-3, 0, "dx", scale_atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_hip_graph_replay_is_bit_identical():
+    """GraphedForward: the denoiser forward replayed from a captured hipGraph (every libdimsum_hip.so launch recorded on
+    the capture stream) returns exactly the eager result, also for new input values and through the Euler sampler."""
+    import torch
+    from dimsum_amd.hip_graph import GraphedForward
+    from dimsum_amd.models_dim import DiM
+    from dimsum_amd.sample_ddp import sample_batch
+    from procedural import procedural_fill
+    kw = dict(img_resolution=32, in_channels=4, label_dropout=0.15, num_classes=1000, scan_type="none", pe_type="ape",
+              block_type="combined", cond_mamba=True, rms_norm=True, fused_add_norm=True, learnable_pe=True,
+              use_attn_every_k_layers=4)
+    m = DiM(depth=4, hidden_size=64, patch_size=2, **kw).eval()
+    procedural_fill(m, seed=3)
+    m = m.cuda()
+    g = GraphedForward(m)
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    for _ in range(3):
+        x, t = torch.randn(4, 4, 32, 32, device="cuda", generator=gen), torch.rand(4, device="cuda", generator=gen)
+        y = torch.randint(0, 1000, (4,), device="cuda", generator=gen)
+        with torch.no_grad():
+            ref = m(x, t, y)
+        assert torch.equal(g(x, t, y), ref)
+    assert len(g.graphs) == 1
+    z, y = torch.randn(4, 4, 32, 32, device="cuda", generator=gen), torch.randint(0, 1000, (4,), device="cuda", generator=gen)
+    a = sample_batch(m, z, y, num_steps=5, gather=False)
+    b = sample_batch(m, z, y, num_steps=5, gather=False, hip_graph={})
+    assert torch.equal(a, b)
