@@ -209,8 +209,10 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned &hi, unsigne
 }
 __device__ __forceinline__ bf16x8 as_bf16x8(const u4v &v) { return __builtin_bit_cast(bf16x8, v); }
 
-template <int HD>
-__global__ __launch_bounds__(256) void xattn_fusion_fwd_split_kernel(const dimsum_xattn_params_t p) {
+// QT = 16-query tiles per wave: a workgroup covers 64 * QT queries, so the K / V^T staging (load, bias, hi / lo split, LDS
+// writes: more VALU work than the softmax itself) and every A-operand ds_read_b128 are shared by QT query tiles.
+template <int HD, int QT>
+__global__ __launch_bounds__(256, (QT == 2 && HD <= 64) ? 3 : (QT == 2 ? 2 : 1)) void xattn_fusion_fwd_split_kernel(const dimsum_xattn_params_t p) {
     constexpr int EP = (HD + 31) / 32 * 32;  // reduction length of QK^T, padded with zeros to whole 32-deep chunks
     constexpr int EC = EP / 32;
     constexpr int ET = (HD + 15) / 16;       // 16-row output tiles along e
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(256) void xattn_fusion_fwd_split_kernel(const dimsu
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = p.seqlen, H = p.heads;
-    const int qblocks = (L + 63) / 64;
+    const int qblocks = (L + 64 * QT - 1) / (64 * QT);
     int idx = blockIdx.x;
     const int qb = idx % qblocks; idx /= qblocks;
     const int ndir = p.n_dirs == 1 ? 1 : 2;
@@ -241,26 +243,30 @@ __global__ __launch_bounds__(256) void xattn_fusion_fwd_split_kernel(const dimsu
     const float *kbias = kvb ? kvb + C + h * HD : nullptr, *vbias = kvb ? kvb + 2 * C + h * HD : nullptr;
 
     const int qi = lane & 15, kg = lane >> 4;
-    const int q_tok = qb * 64 + wave * kQW + qi;
-    const int q_ld = min(q_tok, L - 1);
     const float qscale = p.scale * kLog2e;                    // scores live in the log2 domain
-    // Q^T fragments (B operand): chunk c, slots j = 0..7 <-> e = 32c + 8 kg + j; zeros beyond hd
-    u4v qh[EC], ql[EC];
+    // Q^T fragments (B operand) of the wave's QT query tiles: chunk c, slots j = 0..7 <-> e = 32c + 8 kg + j; zeros beyond hd
+    int q_tok[QT];
+    u4v qh[QT][EC], ql[QT][EC];
 #pragma unroll
-    for (int c = 0; c < EC; ++c) {
-        float v[8];
+    for (int t = 0; t < QT; ++t) {
+        q_tok[t] = qb * (64 * QT) + (wave * QT + t) * kQW + qi;
+        const int q_ld = min(q_tok[t], L - 1);
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int e0 = 32 * c + 8 * kg + 4 * half;
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e0 < HD) {
-                t = *reinterpret_cast<const float4 *>(qsrc + (int64_t)q_ld * ts + e0);
-                if (qbias) { const float4 bq = *reinterpret_cast<const float4 *>(qbias + e0); t.x += bq.x; t.y += bq.y; t.z += bq.z; t.w += bq.w; }
+        for (int c = 0; c < EC; ++c) {
+            float v[8];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int e0 = 32 * c + 8 * kg + 4 * half;
+                float4 tq = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e0 < HD) {
+                    tq = *reinterpret_cast<const float4 *>(qsrc + (int64_t)q_ld * ts + e0);
+                    if (qbias) { const float4 bq = *reinterpret_cast<const float4 *>(qbias + e0); tq.x += bq.x; tq.y += bq.y; tq.z += bq.z; tq.w += bq.w; }
+                }
+                v[4 * half + 0] = tq.x * qscale; v[4 * half + 1] = tq.y * qscale; v[4 * half + 2] = tq.z * qscale; v[4 * half + 3] = tq.w * qscale;
             }
-            v[4 * half + 0] = t.x * qscale; v[4 * half + 1] = t.y * qscale; v[4 * half + 2] = t.z * qscale; v[4 * half + 3] = t.w * qscale;
-        }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) split2(v[2 * i], v[2 * i + 1], qh[c].w[i], ql[c].w[i]);
+            for (int i = 0; i < 4; ++i) split2(v[2 * i], v[2 * i + 1], qh[t][c].w[i], ql[t][c].w[i]);
+        }
     }
     // zero the padding that is never rewritten: K columns e in [hd, EP), V^T rows e in [hd, ET*16)
     if constexpr (EP > HD) {
@@ -270,10 +276,14 @@ __global__ __launch_bounds__(256) void xattn_fusion_fwd_split_kernel(const dimsu
         for (int i = tid; i < (ET * 16 - HD) * kKT; i += 256) { const int e = HD + i / kKT, k = i % kKT; Vh[e * VS + k] = 0; Vl[e * VS + k] = 0; }
     }
 
-    f4 o[ET];
+    f4 o[QT][ET];
+    float m_run[QT], l_run[QT];
 #pragma unroll
-    for (int e = 0; e < ET; ++e) o[e] = f4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -1e30f, l_run = 0.f;
+    for (int t = 0; t < QT; ++t) {
+        m_run[t] = -1e30f; l_run[t] = 0.f;
+#pragma unroll
+        for (int e = 0; e < ET; ++e) o[t][e] = f4{0.f, 0.f, 0.f, 0.f};
+    }
 
     for (int k0 = 0; k0 < L; k0 += kKT) {
         __syncthreads();
@@ -307,53 +317,59 @@ __global__ __launch_bounds__(256) void xattn_fusion_fwd_split_kernel(const dimsu
         }
         __syncthreads();
 
-        // ---- S^T = K Q^T for the 4 key tiles of 16: 3 bf16 MFMAs per 32-deep chunk ----------------------------------------
-        f4 s[4];
+        // ---- S^T = K Q^T for the 4 key tiles of 16: 3 bf16 MFMAs per 32-deep chunk and query tile ------------------------
+        f4 s[QT][4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            f4 acc = f4{0.f, 0.f, 0.f, 0.f};
             const int krow = (kt * 16 + qi) * KS + 8 * kg;         // A operand row: key = kt*16 + (lane&15), slots e = 32c + 8 kg + j
+#pragma unroll
+            for (int t = 0; t < QT; ++t) s[t][kt] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < EC; ++c) {
                 const u4v kh = *reinterpret_cast<const u4v *>(&Kh[krow + 32 * c]), kl = *reinterpret_cast<const u4v *>(&Kl[krow + 32 * c]);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(kl), as_bf16x8(qh[c]), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(kh), as_bf16x8(ql[c]), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(kh), as_bf16x8(qh[c]), acc, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    s[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(kl), as_bf16x8(qh[t][c]), s[t][kt], 0, 0, 0);
+                    s[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(kh), as_bf16x8(ql[t][c]), s[t][kt], 0, 0, 0);
+                    s[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(kh), as_bf16x8(qh[t][c]), s[t][kt], 0, 0, 0);
+                }
             }
-            s[kt] = acc;                                       // s[kt][r]: key k0 + kt*16 + kg*4 + r, query qi
-        }
-        // ---- online softmax for this lane's query (fp32) ------------------------------------------------------------------
-        float mx = -1e30f;
+        }                                                      // s[t][kt][r]: key k0 + kt*16 + kg*4 + r, query qi of tile t
+        // ---- online softmax for this lane's queries (fp32), then P^T (B operand) of the two 32-key chunks: slots j < 4 =
+        //      s[2c][j], j >= 4 = s[2c+1][j-4], split hi / lo -----------------------------------------------------------------
+        u4v ph[QT][2], pl[QT][2];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int t = 0; t < QT; ++t) {
+            float mx = -1e30f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (k0 + kt * 16 + kg * 4 + r >= L) s[kt][r] = -1e30f;
-                mx = fmaxf(mx, s[kt][r]);
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (k0 + kt * 16 + kg * 4 + r >= L) s[t][kt][r] = -1e30f;
+                    mx = fmaxf(mx, s[t][kt][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, kWave));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
+            const float m_new = fmaxf(m_run[t], mx);
+            const float alpha = fast_exp2(m_run[t] - m_new);
+            float rs = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s[t][kt][r] = fast_exp2(s[t][kt][r] - m_new); rs += s[t][kt][r]; }
+            rs += __shfl_xor(rs, 16, kWave);
+            rs += __shfl_xor(rs, 32, kWave);
+            l_run[t] = l_run[t] * alpha + rs;
+            m_run[t] = m_new;
+#pragma unroll
+            for (int e = 0; e < ET; ++e) o[t][e] *= alpha;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                split2(s[t][2 * c][0], s[t][2 * c][1], ph[t][c].w[0], pl[t][c].w[0]);
+                split2(s[t][2 * c][2], s[t][2 * c][3], ph[t][c].w[1], pl[t][c].w[1]);
+                split2(s[t][2 * c + 1][0], s[t][2 * c + 1][1], ph[t][c].w[2], pl[t][c].w[2]);
+                split2(s[t][2 * c + 1][2], s[t][2 * c + 1][3], ph[t][c].w[3], pl[t][c].w[3]);
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, kWave));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = fast_exp2(m_run - m_new);
-        float rs = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { s[kt][r] = fast_exp2(s[kt][r] - m_new); rs += s[kt][r]; }
-        rs += __shfl_xor(rs, 16, kWave);
-        rs += __shfl_xor(rs, 32, kWave);
-        l_run = l_run * alpha + rs;
-        m_run = m_new;
-#pragma unroll
-        for (int e = 0; e < ET; ++e) o[e] *= alpha;
-        // ---- P^T (B operand) of the two 32-key chunks: slots j < 4 = s[2c][j], j >= 4 = s[2c+1][j-4], split hi / lo -----------
-        u4v ph[2], pl[2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            split2(s[2 * c][0], s[2 * c][1], ph[c].w[0], pl[c].w[0]);
-            split2(s[2 * c][2], s[2 * c][3], ph[c].w[1], pl[c].w[1]);
-            split2(s[2 * c + 1][0], s[2 * c + 1][1], ph[c].w[2], pl[c].w[2]);
-            split2(s[2 * c + 1][2], s[2 * c + 1][3], ph[c].w[3], pl[c].w[3]);
         }
         // ---- O^T += V^T P^T ---------------------------------------------------------------------------------------------------
 #pragma unroll
@@ -362,23 +378,29 @@ __global__ __launch_bounds__(256) void xattn_fusion_fwd_split_kernel(const dimsu
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const u4v vh = *reinterpret_cast<const u4v *>(&Vh[vrow + 32 * c]), vl = *reinterpret_cast<const u4v *>(&Vl[vrow + 32 * c]);
-                o[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(vl), as_bf16x8(ph[c]), o[e], 0, 0, 0);
-                o[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(vh), as_bf16x8(pl[c]), o[e], 0, 0, 0);
-                o[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(vh), as_bf16x8(ph[c]), o[e], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    o[t][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(vl), as_bf16x8(ph[t][c]), o[t][e], 0, 0, 0);
+                    o[t][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(vh), as_bf16x8(pl[t][c]), o[t][e], 0, 0, 0);
+                    o[t][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(vh), as_bf16x8(ph[t][c]), o[t][e], 0, 0, 0);
+                }
             }
         }
     }
 
-    if (q_tok < L) {
-        const float inv = 1.0f / l_run;
-        float *dst = reinterpret_cast<float *>(p.out_ptr) + (int64_t)b * p.out_batch_stride + (int64_t)q_tok * p.out_token_stride + dir * C + h * HD;
 #pragma unroll
-        for (int e = 0; e < ET; ++e) {
-            const int e0 = e * 16 + kg * 4;
-            if (e0 < HD) *reinterpret_cast<float4 *>(dst + e0) = make_float4(o[e][0] * inv, o[e][1] * inv, o[e][2] * inv, o[e][3] * inv);
+    for (int t = 0; t < QT; ++t) {
+        if (q_tok[t] < L) {
+            const float inv = 1.0f / l_run[t];
+            float *dst = reinterpret_cast<float *>(p.out_ptr) + (int64_t)b * p.out_batch_stride + (int64_t)q_tok[t] * p.out_token_stride + dir * C + h * HD;
+#pragma unroll
+            for (int e = 0; e < ET; ++e) {
+                const int e0 = e * 16 + kg * 4;
+                if (e0 < HD) *reinterpret_cast<float4 *>(dst + e0) = make_float4(o[t][e][0] * inv, o[t][e][1] * inv, o[t][e][2] * inv, o[t][e][3] * inv);
+            }
+            if (p.lse_ptr && kg == 0)
+                reinterpret_cast<float *>(p.lse_ptr)[(((int64_t)b * ndir + dir) * H + h) * L + q_tok[t]] = (m_run[t] + __builtin_amdgcn_logf(l_run[t])) * kLn2;
         }
-        if (p.lse_ptr && kg == 0)
-            reinterpret_cast<float *>(p.lse_ptr)[(((int64_t)b * ndir + dir) * H + h) * L + q_tok] = (m_run + __builtin_amdgcn_logf(l_run)) * kLn2;
     }
 }
 
@@ -402,14 +424,22 @@ extern "C" int dimsum_xattn_fusion_fwd(const dimsum_xattn_params_t *p, void *str
     const dim3 grid((unsigned)nblk), block(256);
     if (p->precision != 0 && p->precision != 1) return DIMSUM_ERR_SHAPE;
     if (p->precision == 1) {
+        // 2 query tiles per wave (128 queries per workgroup) halve the per-query staging work; short sequences keep 1
+        const bool two = p->seqlen >= 128;
+        const int64_t nblk2 = (int64_t)p->batch * p->heads * (self_attn ? 1 : 2) * ((p->seqlen + 127) / 128);
+        const dim3 grid2((unsigned)nblk2);
+#define DIMSUM_XSPLIT(HDV)                                                                                       \
+        if (two) hipLaunchKernelGGL((xattn_fusion_fwd_split_kernel<HDV, 2>), grid2, block, 0, s, *p);          \
+        else hipLaunchKernelGGL((xattn_fusion_fwd_split_kernel<HDV, 1>), grid, block, 0, s, *p)
         switch (p->head_dim) {
-            case 24: hipLaunchKernelGGL(xattn_fusion_fwd_split_kernel<24>, grid, block, 0, s, *p); break;
-            case 32: hipLaunchKernelGGL(xattn_fusion_fwd_split_kernel<32>, grid, block, 0, s, *p); break;
-            case 48: hipLaunchKernelGGL(xattn_fusion_fwd_split_kernel<48>, grid, block, 0, s, *p); break;
-            case 64: hipLaunchKernelGGL(xattn_fusion_fwd_split_kernel<64>, grid, block, 0, s, *p); break;
-            case 72: hipLaunchKernelGGL(xattn_fusion_fwd_split_kernel<72>, grid, block, 0, s, *p); break;
+            case 24: DIMSUM_XSPLIT(24); break;
+            case 32: DIMSUM_XSPLIT(32); break;
+            case 48: DIMSUM_XSPLIT(48); break;
+            case 64: DIMSUM_XSPLIT(64); break;
+            case 72: DIMSUM_XSPLIT(72); break;
             default: return DIMSUM_ERR_SHAPE;
         }
+#undef DIMSUM_XSPLIT
         return launch_status();
     }
     switch (p->head_dim) {
