@@ -1,0 +1,46 @@
+// xattn_common.hpp -- split-bf16 helpers shared by the attention forward and backward kernels (gfx950).
+// A fp32 value x is carried as hi = bf16(x), lo = bf16(x - hi); a product a.b is evaluated as hi.hi + hi.lo + lo.hi on
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation (the dropped lo.lo term is ~2^-16 relative).
+#pragma once
+#include "common.hpp"
+
+namespace dimsum {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct alignas(16) u4v { unsigned w[4]; };       // 8 bf16 = the A / B operand of one lane for a 32-deep K chunk
+
+// (hi, lo) bf16 pair images of two fp32 values, packed [x0 | x1 << 16] (v_cvt_pk_bf16_f32: round to nearest even)
+__device__ __forceinline__ void split2(float x0, float x1, unsigned &hi, unsigned &lo) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const bf16x2 h = __builtin_convertvector(f2{x0, x1}, bf16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+    const bf16x2 l = __builtin_convertvector(f2{r0, r1}, bf16x2);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(const u4v &v) { return __builtin_bit_cast(bf16x8, v); }
+
+// acc += a . b with a = (ah, al), b = (bh, bl): the small cross terms first
+__device__ __forceinline__ f4 mfma_split(const u4v &ah, const u4v &al, const u4v &bh, const u4v &bl, f4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(al), as_bf16x8(bh), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah), as_bf16x8(bl), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah), as_bf16x8(bh), acc, 0, 0, 0);
+    return acc;
+}
+
+// Position of index kappa (0..31) inside a 32-deep chunk whose K-slots follow the C layout of two stacked 16-row MFMA
+// results: slot 8g + j holds row 4g + j of the first tile (j < 4) or row 4g + j - 4 of the second (j >= 4). An even kappa
+// and kappa + 1 land on adjacent positions.
+__device__ __forceinline__ int cslot(int kappa) { return 8 * ((kappa & 15) >> 2) + (kappa & 3) + 4 * (kappa >> 4); }
+
+// the 8 slot values of one lane (C registers of two stacked tiles) -> hi / lo B (or A) operand
+__device__ __forceinline__ void split_c2(const f4 &t0, const f4 &t1, u4v &hi, u4v &lo) {
+    split2(t0[0], t0[1], hi.w[0], lo.w[0]);
+    split2(t0[2], t0[3], hi.w[1], lo.w[1]);
+    split2(t1[0], t1[1], hi.w[2], lo.w[2]);
+    split2(t1[2], t1[3], hi.w[3], lo.w[3]);
+}
+
+}  // namespace dimsum

@@ -19,11 +19,10 @@
 //
 // Workgroup = 4 waves = 64 queries of one (batch, head, direction); K and V^T tiles of 64 keys are staged through LDS
 // once per workgroup (34 KB -> 4 workgroups per CU). 2 * (QK^T + PV) = 4*L*L*hd FLOP per (b, h, direction).
-#include "common.hpp"
+#include "xattn_common.hpp"
 
 namespace dimsum {
 
-typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int kKT = 64;          // keys per tile
 constexpr int kQW = 16;          // queries per wave
 
@@ -194,21 +193,6 @@ __global__ __launch_bounds__(256) void xattn_fusion_fwd_kernel(const dimsum_xatt
 //     V^T is staged with exactly that key permutation inside each 32-key chunk, so its A operand is one ds_read_b128 too
 //     and P^T never changes layout.
 //   * K, V^T tiles are split once per workgroup while they are staged (hi and lo images, bf16, rows padded by 16 B).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-struct alignas(16) u4v { unsigned w[4]; };
-
-// (hi, lo) bf16 pair images of two fp32 values, packed [x0 | x1 << 16] (v_cvt_pk_bf16_f32: round to nearest even)
-__device__ __forceinline__ void split2(float x0, float x1, unsigned &hi, unsigned &lo) {
-    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    const bf16x2 h = __builtin_convertvector(f2{x0, x1}, bf16x2);
-    hi = *reinterpret_cast<const unsigned *>(&h);
-    const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
-    const bf16x2 l = __builtin_convertvector(f2{r0, r1}, bf16x2);
-    lo = *reinterpret_cast<const unsigned *>(&l);
-}
-__device__ __forceinline__ bf16x8 as_bf16x8(const u4v &v) { return __builtin_bit_cast(bf16x8, v); }
-
 // QT = 16-query tiles per wave: a workgroup covers 64 * QT queries, so the K / V^T staging (load, bias, hi / lo split, LDS
 // writes: more VALU work than the softmax itself) and every A-operand ds_read_b128 are shared by QT query tiles.
 template <int HD, int QT>

@@ -15,11 +15,10 @@
 // S and dP are recomputed in both (7 GEMM-equivalents instead of 5): cheaper on fp32 MFMA than contended fp32 atomics
 // on dq, and bitwise reproducible. All products are v_mfma_f32_16x16x4_f32 (exact fp32).
 // Optional qkv Linear biases are added while q / k / v are fetched, like in the forward.
-#include "common.hpp"
+#include "xattn_common.hpp"
 
 namespace dimsum {
 
-typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int kBKT = 64;         // keys per tile (dq kernel)
 constexpr int kBQT = 32;         // queries per tile (dkv kernel)
 
@@ -296,10 +295,338 @@ __global__ __launch_bounds__(256) void xattn_bwd_dkv_kernel(const dimsum_xattn_b
     }
 }
 
+// =====================================================================================================================
+// Split-bf16 variants (fwd.precision = 1): the same two kernels on v_mfma_f32_16x16x32_bf16 with every fp32 operand carried
+// as hi + lo bf16 (xattn_common.hpp). The register-resident C results (dS^T; P and dS) become the B operand of the next
+// product through the slot convention of xattn_fusion.hip: K-slot 8g + j of a 32-deep chunk is the row the lane already
+// holds in the C registers of two stacked 16-row tiles, and the transposed LDS images (K^T; Q^T, dO^T) are staged with
+// that permutation (cslot), so no operand changes layout. Softmax probabilities, D and all accumulators stay fp32.
+// =====================================================================================================================
+constexpr int kSQW = 128;        // queries per workgroup of the split dq kernel (8 waves)
+
+template <int HD>
+__global__ __launch_bounds__(512, 4) void xattn_bwd_dq_split_kernel(const dimsum_xattn_bwd_params_t p) {
+    constexpr int EP = (HD + 31) / 32 * 32, EC = EP / 32, ET = (HD + 15) / 16;
+    constexpr int KS = EP + 8;               // [key][e] rows of K and V (bf16 elements, 16 B of padding)
+    constexpr int TS = kBKT + 8;             // [e][key slot] rows of K^T
+    __shared__ __attribute__((aligned(16))) unsigned short Kh[kBKT * KS], Kl[kBKT * KS], Vh[kBKT * KS], Vl[kBKT * KS];
+    __shared__ __attribute__((aligned(16))) unsigned short Th[ET * 16 * TS], Tl[ET * 16 * TS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int L = p.fwd.seqlen, H = p.fwd.heads;
+    const int qblocks = (L + kSQW - 1) / kSQW;
+    int idx = blockIdx.x;
+    const int qblk = idx % qblocks; idx /= qblocks;
+    const int ndir = p.fwd.n_dirs == 1 ? 1 : 2;
+    const int dir = idx % ndir; idx /= ndir;
+    const int h = idx % H;
+    const int b = idx / H;
+    const int C = H * HD;
+    const XSrc s = xattn_src(p, b, h, dir, HD);
+    const int64_t ts = p.fwd.qkv_token_stride, dts = p.dqkv_token_stride;
+
+    const int qi = lane & 15, kg = lane >> 4;
+    const int q_tok = qblk * kSQW + wave * 16 + qi;
+    const int q_ld = min(q_tok, L - 1);
+    const float qscale = p.fwd.scale * kLog2e;
+    const float *dorow = reinterpret_cast<const float *>(p.dout_ptr) + (int64_t)b * p.fwd.out_batch_stride + (int64_t)q_ld * p.fwd.out_token_stride + dir * C + h * HD;
+    const float *orow = reinterpret_cast<const float *>(p.fwd.out_ptr) + (int64_t)b * p.fwd.out_batch_stride + (int64_t)q_ld * p.fwd.out_token_stride + dir * C + h * HD;
+    // Q^T (scaled into the log2 domain) and dO^T fragments (B operands): chunk c, slots j <-> e = 32c + 8 kg + j
+    u4v qh[EC], ql[EC], gh[EC], gl[EC];
+    float dpart = 0.f;
+#pragma unroll
+    for (int c = 0; c < EC; ++c) {
+        float qv[8], gv[8];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int e0 = 32 * c + 8 * kg + 4 * half;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f), g = t;
+            if (e0 < HD) {
+                t = ld_bias4(s.q + (int64_t)q_ld * ts, s.qb, e0);
+                g = *reinterpret_cast<const float4 *>(dorow + e0);
+                const float4 o = *reinterpret_cast<const float4 *>(orow + e0);
+                dpart += g.x * o.x + g.y * o.y + g.z * o.z + g.w * o.w;
+            }
+            qv[4 * half + 0] = t.x * qscale; qv[4 * half + 1] = t.y * qscale; qv[4 * half + 2] = t.z * qscale; qv[4 * half + 3] = t.w * qscale;
+            gv[4 * half + 0] = g.x; gv[4 * half + 1] = g.y; gv[4 * half + 2] = g.z; gv[4 * half + 3] = g.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { split2(qv[2 * i], qv[2 * i + 1], qh[c].w[i], ql[c].w[i]); split2(gv[2 * i], gv[2 * i + 1], gh[c].w[i], gl[c].w[i]); }
+    }
+    dpart += __shfl_xor(dpart, 16, kWave);
+    dpart += __shfl_xor(dpart, 32, kWave);                    // D of this lane's query
+    const int64_t stat = (((int64_t)b * ndir + dir) * H + h) * L + q_ld;
+    const float lse2 = reinterpret_cast<const float *>(p.fwd.lse_ptr)[stat] * kLog2e;
+    if (q_tok < L && kg == 0) reinterpret_cast<float *>(p.delta_ptr)[stat] = dpart;
+
+    f4 acc[ET];
+#pragma unroll
+    for (int e = 0; e < ET; ++e) acc[e] = f4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (EP > HD) {      // padding that is never rewritten: columns e in [hd, EP) of K and V
+        for (int i = tid; i < kBKT * (EP - HD); i += 512) { const int key = i / (EP - HD), e = HD + i % (EP - HD); Kh[key * KS + e] = 0; Kl[key * KS + e] = 0; Vh[key * KS + e] = 0; Vl[key * KS + e] = 0; }
+    }
+    if constexpr (ET * 16 > HD) {  // rows e in [hd, ET*16) of K^T
+        for (int i = tid; i < (ET * 16 - HD) * kBKT; i += 512) { const int e = HD + i / kBKT, k = i % kBKT; Th[e * TS + k] = 0; Tl[e * TS + k] = 0; }
+    }
+
+    // The K / V rows of the NEXT key tile are requested right after the current tile has been staged (register-staged
+    // prefetch: one thread = 2 keys x 4 e, kIt items per tile), so their HBM latency hides under the tile's MFMA work.
+    constexpr int kItems = (kBKT / 2) * (HD / 4), kIt = (kItems + 511) / 512;
+    float4 pka[kIt], pkb[kIt], pva[kIt], pvb[kIt];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int i = min(tid + it * 512, kItems - 1);
+            const int kp = i / (HD / 4), e4 = i - kp * (HD / 4), key = 2 * kp;
+            const int tok0 = min(k0 + key, L - 1), tok1 = min(k0 + key + 1, L - 1);
+            pka[it] = ld_bias4(s.k + (int64_t)tok0 * ts, s.kb, e4 * 4); pkb[it] = ld_bias4(s.k + (int64_t)tok1 * ts, s.kb, e4 * 4);
+            pva[it] = ld_bias4(s.v + (int64_t)tok0 * ts, s.vb, e4 * 4); pvb[it] = ld_bias4(s.v + (int64_t)tok1 * ts, s.vb, e4 * 4);
+        }
+    };
+    fetch(0);
+
+    for (int k0 = 0; k0 < L; k0 += kBKT) {
+        __syncthreads();
+        // ---- stage K, V [key][e] and K^T [e][slot(key)] as hi / lo bf16 images; one thread = 2 keys x 4 e -----------------
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int i = tid + it * 512;
+            if (i >= kItems) break;
+            const int kp = i / (HD / 4), e4 = i - kp * (HD / 4), key = 2 * kp;
+            const float4 ka = pka[it], kb = pkb[it], va = pva[it], vb = pvb[it];
+            unsigned h0, l0, h1, l1;
+            split2(ka.x, ka.y, h0, l0); split2(ka.z, ka.w, h1, l1);
+            *reinterpret_cast<uint2 *>(&Kh[key * KS + e4 * 4]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Kl[key * KS + e4 * 4]) = make_uint2(l0, l1);
+            split2(kb.x, kb.y, h0, l0); split2(kb.z, kb.w, h1, l1);
+            *reinterpret_cast<uint2 *>(&Kh[(key + 1) * KS + e4 * 4]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Kl[(key + 1) * KS + e4 * 4]) = make_uint2(l0, l1);
+            split2(va.x, va.y, h0, l0); split2(va.z, va.w, h1, l1);
+            *reinterpret_cast<uint2 *>(&Vh[key * KS + e4 * 4]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Vl[key * KS + e4 * 4]) = make_uint2(l0, l1);
+            split2(vb.x, vb.y, h0, l0); split2(vb.z, vb.w, h1, l1);
+            *reinterpret_cast<uint2 *>(&Vh[(key + 1) * KS + e4 * 4]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Vl[(key + 1) * KS + e4 * 4]) = make_uint2(l0, l1);
+            const int pos = (key & ~31) + cslot(key & 31);
+            const float a4[4] = {ka.x, ka.y, ka.z, ka.w}, b4[4] = {kb.x, kb.y, kb.z, kb.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                split2(a4[e], b4[e], h0, l0);
+                *reinterpret_cast<unsigned *>(&Th[(e4 * 4 + e) * TS + pos]) = h0;
+                *reinterpret_cast<unsigned *>(&Tl[(e4 * 4 + e) * TS + pos]) = l0;
+            }
+        }
+        __syncthreads();
+        if (k0 + kBKT < L) fetch(k0 + kBKT);
+
+        f4 ds[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            f4 sacc = f4{0.f, 0.f, 0.f, 0.f}, pacc = f4{0.f, 0.f, 0.f, 0.f};
+            const int krow = (kt * 16 + qi) * KS + 8 * kg;
+#pragma unroll
+            for (int c = 0; c < EC; ++c) {
+                const u4v kh = *reinterpret_cast<const u4v *>(&Kh[krow + 32 * c]), kl = *reinterpret_cast<const u4v *>(&Kl[krow + 32 * c]);
+                const u4v vh = *reinterpret_cast<const u4v *>(&Vh[krow + 32 * c]), vl = *reinterpret_cast<const u4v *>(&Vl[krow + 32 * c]);
+                sacc = mfma_split(kh, kl, qh[c], ql[c], sacc);      // S^T  (log2 domain)
+                pacc = mfma_split(vh, vl, gh[c], gl[c], pacc);      // dP^T
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {     // dS^T = P^T o (dP^T - D); keys beyond L contribute nothing
+                const float pr = (k0 + kt * 16 + kg * 4 + r < L) ? fast_exp2(sacc[r] - lse2) : 0.f;
+                ds[kt][r] = pr * (pacc[r] - dpart);
+            }
+        }
+        // ---- dQ^T += K^T dS^T: chunk c = key tiles 2c, 2c + 1 -----------------------------------------------------------------
+        u4v dh[2], dl[2];
+        split_c2(ds[0], ds[1], dh[0], dl[0]);
+        split_c2(ds[2], ds[3], dh[1], dl[1]);
+#pragma unroll
+        for (int e = 0; e < ET; ++e) {
+            const int trow = (e * 16 + qi) * TS + 8 * kg;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const u4v th = *reinterpret_cast<const u4v *>(&Th[trow + 32 * c]), tl = *reinterpret_cast<const u4v *>(&Tl[trow + 32 * c]);
+                acc[e] = mfma_split(th, tl, dh[c], dl[c], acc[e]);
+            }
+        }
+    }
+    if (q_tok < L) {
+        float *dst = s.dq + (int64_t)q_tok * dts;
+        const float sc = p.fwd.scale;
+#pragma unroll
+        for (int e = 0; e < ET; ++e) {
+            const int e0 = e * 16 + kg * 4;
+            if (e0 < HD) *reinterpret_cast<float4 *>(dst + e0) = make_float4(acc[e][0] * sc, acc[e][1] * sc, acc[e][2] * sc, acc[e][3] * sc);
+        }
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256, 3) void xattn_bwd_dkv_split_kernel(const dimsum_xattn_bwd_params_t p) {
+    constexpr int EP = (HD + 31) / 32 * 32, EC = EP / 32, ET = (HD + 15) / 16;
+    constexpr int RS = EP + 8;               // [query][e] rows of Q and dO
+    constexpr int TS = kBQT + 8;             // [e][query slot] rows of Q^T and dO^T
+    __shared__ __attribute__((aligned(16))) unsigned short Qh[kBQT * RS], Ql[kBQT * RS], Gh[kBQT * RS], Gl[kBQT * RS];
+    __shared__ __attribute__((aligned(16))) unsigned short QTh[ET * 16 * TS], QTl[ET * 16 * TS], GTh[ET * 16 * TS], GTl[ET * 16 * TS];
+    __shared__ __attribute__((aligned(16))) float sL[kBQT], sD[kBQT];      // lse (log2 domain) and D of the tile's queries
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int L = p.fwd.seqlen, H = p.fwd.heads;
+    const int kblocks = (L + 63) / 64;
+    int idx = blockIdx.x;
+    const int kblk = idx % kblocks; idx /= kblocks;
+    const int ndir = p.fwd.n_dirs == 1 ? 1 : 2;
+    const int dir = idx % ndir; idx /= ndir;
+    const int h = idx % H;
+    const int b = idx / H;
+    const int C = H * HD;
+    const XSrc s = xattn_src(p, b, h, dir, HD);
+    const int64_t ts = p.fwd.qkv_token_stride, dts = p.dqkv_token_stride;
+    const float *dobase = reinterpret_cast<const float *>(p.dout_ptr) + (int64_t)b * p.fwd.out_batch_stride + dir * C + h * HD;
+    const int64_t stat0 = (((int64_t)b * ndir + dir) * H + h) * L;
+    const float *lse = reinterpret_cast<const float *>(p.fwd.lse_ptr) + stat0;
+    const float *dlt = reinterpret_cast<const float *>(p.delta_ptr) + stat0;
+
+    const int ki = lane & 15, kg = lane >> 4;
+    const int k_tok = kblk * 64 + wave * 16 + ki;
+    const int k_ld = min(k_tok, L - 1);
+    const float kscale = p.fwd.scale * kLog2e;
+    // K^T (scaled) and V^T fragments of this lane's key (B operands): chunk c, slots j <-> e = 32c + 8 kg + j
+    u4v kh[EC], kl[EC], vh[EC], vl[EC];
+#pragma unroll
+    for (int c = 0; c < EC; ++c) {
+        float kv[8], vv[8];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int e0 = 32 * c + 8 * kg + 4 * half;
+            float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), v4 = kk;
+            if (e0 < HD) { kk = ld_bias4(s.k + (int64_t)k_ld * ts, s.kb, e0); v4 = ld_bias4(s.v + (int64_t)k_ld * ts, s.vb, e0); }
+            kv[4 * half + 0] = kk.x * kscale; kv[4 * half + 1] = kk.y * kscale; kv[4 * half + 2] = kk.z * kscale; kv[4 * half + 3] = kk.w * kscale;
+            vv[4 * half + 0] = v4.x; vv[4 * half + 1] = v4.y; vv[4 * half + 2] = v4.z; vv[4 * half + 3] = v4.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { split2(kv[2 * i], kv[2 * i + 1], kh[c].w[i], kl[c].w[i]); split2(vv[2 * i], vv[2 * i + 1], vh[c].w[i], vl[c].w[i]); }
+    }
+    f4 dk[ET], dv[ET];
+#pragma unroll
+    for (int e = 0; e < ET; ++e) { dk[e] = f4{0.f, 0.f, 0.f, 0.f}; dv[e] = f4{0.f, 0.f, 0.f, 0.f}; }
+    const bool key_live = k_tok < L;
+    if constexpr (EP > HD) {
+        for (int i = tid; i < kBQT * (EP - HD); i += 256) { const int q = i / (EP - HD), e = HD + i % (EP - HD); Qh[q * RS + e] = 0; Ql[q * RS + e] = 0; Gh[q * RS + e] = 0; Gl[q * RS + e] = 0; }
+    }
+    if constexpr (ET * 16 > HD) {
+        for (int i = tid; i < (ET * 16 - HD) * kBQT; i += 256) { const int e = HD + i / kBQT, q = i % kBQT; QTh[e * TS + q] = 0; QTl[e * TS + q] = 0; GTh[e * TS + q] = 0; GTl[e * TS + q] = 0; }
+    }
+
+    // The Q / dO rows of the NEXT query tile are requested right after the current tile has been staged, so their HBM
+    // latency hides under the tile's MFMA work (register-staged prefetch: one thread = 2 queries x 4 e, kIt items per tile).
+    constexpr int kItems = (kBQT / 2) * (HD / 4), kIt = (kItems + 255) / 256;
+    float4 pqa[kIt], pqb[kIt], pga[kIt], pgb[kIt];
+    auto fetch = [&](int q0) {
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int i = min(tid + it * 256, kItems - 1);
+            const int qp = i / (HD / 4), e4 = i - qp * (HD / 4), q = 2 * qp;
+            const int tok0 = min(q0 + q, L - 1), tok1 = min(q0 + q + 1, L - 1);
+            pqa[it] = ld_bias4(s.q + (int64_t)tok0 * ts, s.qb, e4 * 4); pqb[it] = ld_bias4(s.q + (int64_t)tok1 * ts, s.qb, e4 * 4);
+            pga[it] = *reinterpret_cast<const float4 *>(dobase + (int64_t)tok0 * p.fwd.out_token_stride + e4 * 4);
+            pgb[it] = *reinterpret_cast<const float4 *>(dobase + (int64_t)tok1 * p.fwd.out_token_stride + e4 * 4);
+        }
+    };
+    fetch(0);
+
+    for (int q0 = 0; q0 < L; q0 += kBQT) {
+        __syncthreads();
+        // ---- stage Q, dO [query][e] and Q^T, dO^T [e][slot(query)] as hi / lo bf16 images; one thread = 2 queries x 4 e --------
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int i = tid + it * 256;
+            if (i >= kItems) break;
+            const int qp = i / (HD / 4), e4 = i - qp * (HD / 4), q = 2 * qp;
+            const float4 qa = pqa[it], qb = pqb[it], ga = pga[it], gb = pgb[it];
+            unsigned h0, l0, h1, l1;
+            split2(qa.x, qa.y, h0, l0); split2(qa.z, qa.w, h1, l1);
+            *reinterpret_cast<uint2 *>(&Qh[q * RS + e4 * 4]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Ql[q * RS + e4 * 4]) = make_uint2(l0, l1);
+            split2(qb.x, qb.y, h0, l0); split2(qb.z, qb.w, h1, l1);
+            *reinterpret_cast<uint2 *>(&Qh[(q + 1) * RS + e4 * 4]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Ql[(q + 1) * RS + e4 * 4]) = make_uint2(l0, l1);
+            split2(ga.x, ga.y, h0, l0); split2(ga.z, ga.w, h1, l1);
+            *reinterpret_cast<uint2 *>(&Gh[q * RS + e4 * 4]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Gl[q * RS + e4 * 4]) = make_uint2(l0, l1);
+            split2(gb.x, gb.y, h0, l0); split2(gb.z, gb.w, h1, l1);
+            *reinterpret_cast<uint2 *>(&Gh[(q + 1) * RS + e4 * 4]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Gl[(q + 1) * RS + e4 * 4]) = make_uint2(l0, l1);
+            const int pos = cslot(q);
+            const float qa4[4] = {qa.x, qa.y, qa.z, qa.w}, qb4[4] = {qb.x, qb.y, qb.z, qb.w};
+            const float ga4[4] = {ga.x, ga.y, ga.z, ga.w}, gb4[4] = {gb.x, gb.y, gb.z, gb.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                split2(qa4[e], qb4[e], h0, l0);
+                *reinterpret_cast<unsigned *>(&QTh[(e4 * 4 + e) * TS + pos]) = h0; *reinterpret_cast<unsigned *>(&QTl[(e4 * 4 + e) * TS + pos]) = l0;
+                split2(ga4[e], gb4[e], h0, l0);
+                *reinterpret_cast<unsigned *>(&GTh[(e4 * 4 + e) * TS + pos]) = h0; *reinterpret_cast<unsigned *>(&GTl[(e4 * 4 + e) * TS + pos]) = l0;
+            }
+        }
+        if (tid < kBQT) {
+            const int tok = q0 + tid;
+            sL[tid] = tok < L ? lse[tok] * kLog2e : 1e30f;       // queries beyond L: P = exp2(S - inf) = 0
+            sD[tid] = tok < L ? dlt[tok] : 0.f;
+        }
+        __syncthreads();
+        if (q0 + kBQT < L) fetch(q0 + kBQT);
+
+        // ---- S = Q K^T, dP = dO V^T for the two 16-query tiles: C layout key = lane & 15 (column), queries qt*16 + kg*4 + r ----
+        f4 pp[2], dsv[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            f4 sacc = f4{0.f, 0.f, 0.f, 0.f}, pacc = f4{0.f, 0.f, 0.f, 0.f};
+            const int qrow = (qt * 16 + ki) * RS + 8 * kg;
+#pragma unroll
+            for (int c = 0; c < EC; ++c) {
+                const u4v qh_ = *reinterpret_cast<const u4v *>(&Qh[qrow + 32 * c]), ql_ = *reinterpret_cast<const u4v *>(&Ql[qrow + 32 * c]);
+                const u4v gh_ = *reinterpret_cast<const u4v *>(&Gh[qrow + 32 * c]), gl_ = *reinterpret_cast<const u4v *>(&Gl[qrow + 32 * c]);
+                sacc = mfma_split(qh_, ql_, kh[c], kl[c], sacc);
+                pacc = mfma_split(gh_, gl_, vh[c], vl[c], pacc);
+            }
+            const float4 l4 = *reinterpret_cast<const float4 *>(&sL[qt * 16 + kg * 4]);
+            const float4 d4 = *reinterpret_cast<const float4 *>(&sD[qt * 16 + kg * 4]);
+            pp[qt][0] = key_live ? fast_exp2(sacc[0] - l4.x) : 0.f; pp[qt][1] = key_live ? fast_exp2(sacc[1] - l4.y) : 0.f;
+            pp[qt][2] = key_live ? fast_exp2(sacc[2] - l4.z) : 0.f; pp[qt][3] = key_live ? fast_exp2(sacc[3] - l4.w) : 0.f;
+            dsv[qt][0] = pp[qt][0] * (pacc[0] - d4.x); dsv[qt][1] = pp[qt][1] * (pacc[1] - d4.y);
+            dsv[qt][2] = pp[qt][2] * (pacc[2] - d4.z); dsv[qt][3] = pp[qt][3] * (pacc[3] - d4.w);
+        }
+        // ---- dV^T += dO^T P, dK^T += Q^T dS: ONE 32-deep chunk whose slots are the tile's queries --------------------------------
+        u4v ph, pl, sh_, sl_;
+        split_c2(pp[0], pp[1], ph, pl);
+        split_c2(dsv[0], dsv[1], sh_, sl_);
+#pragma unroll
+        for (int e = 0; e < ET; ++e) {
+            const int row = (e * 16 + ki) * TS + 8 * kg;
+            const u4v gth = *reinterpret_cast<const u4v *>(&GTh[row]), gtl = *reinterpret_cast<const u4v *>(&GTl[row]);
+            const u4v qth = *reinterpret_cast<const u4v *>(&QTh[row]), qtl = *reinterpret_cast<const u4v *>(&QTl[row]);
+            dv[e] = mfma_split(gth, gtl, ph, pl, dv[e]);
+            dk[e] = mfma_split(qth, qtl, sh_, sl_, dk[e]);
+        }
+    }
+    if (key_live) {
+        float *dkd = s.dk + (int64_t)k_tok * dts, *dvd = s.dv + (int64_t)k_tok * dts;
+        const float sc = p.fwd.scale;
+#pragma unroll
+        for (int e = 0; e < ET; ++e) {
+            const int e0 = e * 16 + kg * 4;
+            if (e0 < HD) {
+                *reinterpret_cast<float4 *>(dkd + e0) = make_float4(dk[e][0] * sc, dk[e][1] * sc, dk[e][2] * sc, dk[e][3] * sc);
+                *reinterpret_cast<float4 *>(dvd + e0) = make_float4(dv[e][0], dv[e][1], dv[e][2], dv[e][3]);
+            }
+        }
+    }
+}
+
 template <int HD>
 static int launch_xbwd(const dimsum_xattn_bwd_params_t &p, hipStream_t s) {
     const int64_t nblk = (int64_t)p.fwd.batch * p.fwd.heads * (p.fwd.n_dirs == 1 ? 1 : 2) * ((p.fwd.seqlen + 63) / 64);
     if (nblk > 0x7fffffff) return DIMSUM_ERR_SHAPE;
+    if (p.fwd.precision == 1) {
+        const int64_t nq = (int64_t)p.fwd.batch * p.fwd.heads * (p.fwd.n_dirs == 1 ? 1 : 2) * ((p.fwd.seqlen + kSQW - 1) / kSQW);
+        hipLaunchKernelGGL(xattn_bwd_dq_split_kernel<HD>, dim3((unsigned)nq), dim3(512), 0, s, p);
+        if (launch_status() != DIMSUM_OK) return DIMSUM_ERR_LAUNCH;
+        hipLaunchKernelGGL(xattn_bwd_dkv_split_kernel<HD>, dim3((unsigned)nblk), dim3(256), 0, s, p);
+        return launch_status();
+    }
     hipLaunchKernelGGL(xattn_bwd_dq_kernel<HD>, dim3((unsigned)nblk), dim3(256), 0, s, p);
     if (launch_status() != DIMSUM_OK) return DIMSUM_ERR_LAUNCH;
     hipLaunchKernelGGL(xattn_bwd_dkv_kernel<HD>, dim3((unsigned)nblk), dim3(256), 0, s, p);
@@ -316,6 +643,7 @@ extern "C" int dimsum_xattn_fusion_bwd(const dimsum_xattn_bwd_params_t *p, void 
         return DIMSUM_ERR_NULL;
     const dimsum_xattn_params_t &f = p->fwd;
     if (f.batch < 0 || f.seqlen <= 0 || f.heads <= 0 || (f.n_dirs != 0 && f.n_dirs != 1 && f.n_dirs != 2)) return DIMSUM_ERR_SHAPE;
+    if (f.precision != 0 && f.precision != 1) return DIMSUM_ERR_SHAPE;
     if (!self_attn && (f.bias1_ptr == nullptr) != (f.bias2_ptr == nullptr)) return DIMSUM_ERR_NULL;
     const void *ptrs[] = {f.qkv1_ptr, self_attn ? nullptr : f.qkv2_ptr, f.out_ptr, p->dout_ptr, p->dqkv1_ptr, self_attn ? nullptr : p->dqkv2_ptr,
                           f.bias1_ptr, self_attn ? nullptr : f.bias2_ptr};

@@ -464,7 +464,7 @@ def xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=False, bias1=None, bias2=None, 
     return (out, lse) if need_lse else out
 
 
-def xattn_fusion_bwd(qkv1, qkv2, out, lse, dout, heads, bias1=None, bias2=None):
+def xattn_fusion_bwd(qkv1, qkv2, out, lse, dout, heads, bias1=None, bias2=None, split_bf16=None):
     """backward of xattn_fusion_fwd -> (dqkv1, dqkv2), each (B, L, 3*heads*hd); `out`, `lse` are the forward's results.
     qkv2 = None (self-attention): -> (dqkv1, None)."""
     self_attn = qkv2 is None
@@ -490,6 +490,9 @@ def xattn_fusion_bwd(qkv1, qkv2, out, lse, dout, heads, bias1=None, bias2=None):
         P.out_batch_stride, P.out_token_stride = out.stride(0), out.stride(1)
         P.qkv1_ptr, P.qkv2_ptr, P.out_ptr, P.lse_ptr = _ptr(qkv1), _ptr(qkv2), _ptr(out), _ptr(lse)
         P.bias1_ptr, P.bias2_ptr = _ptr(bias1), _ptr(bias2)
+        if split_bf16 is None:                    # same policy switch as the forward and the library GEMMs
+            split_bf16 = bool(torch.backends.cuda.matmul.allow_tf32)
+        P.precision = 1 if split_bf16 else 0
         Q.dqkv_batch_stride, Q.dqkv_token_stride = dqkv1.stride(0), dqkv1.stride(1)
         Q.dout_ptr, Q.dqkv1_ptr, Q.dqkv2_ptr, Q.delta_ptr = _ptr(dout), _ptr(dqkv1), _ptr(dqkv2), _ptr(delta)
         with torch.cuda.device(qkv1.device):

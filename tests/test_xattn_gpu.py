@@ -158,3 +158,29 @@ def test_split_bf16_follows_matmul_policy():
         assert torch.equal(native.xattn_fusion_fwd(qkv1, qkv2, 8), native.xattn_fusion_fwd(qkv1, qkv2, 8, split_bf16=True))
     finally:
         torch.backends.cuda.matmul.allow_tf32 = old
+
+
+@pytest.mark.parametrize("B,L,heads,hd,self_attn", [(2, 256, 8, 64, False), (1, 1024, 8, 72, False), (2, 100, 4, 24, False), (1, 64, 8, 48, False),
+                                                    (2, 72, 2, 32, False), (2, 256, 16, 64, True), (1, 100, 4, 24, True)])
+def test_split_bf16_backward_vs_exact(B, L, heads, hd, self_attn):
+    """precision = 1 in the two backward kernels: dqkv of the split-bf16 MFMA kernels vs the exact-fp32 MFMA kernels (which
+    test_core_backward_vs_torch_sdpa pins to torch autograd). rtol 1e-4 + 3e-5 * max|ref|, rms deviation < 2e-5."""
+    from dimsum_amd import native
+    W = 3 * heads * hd
+    gen = torch.Generator().manual_seed(L + hd)
+    qkv1 = torch.randn(B, L, W, generator=gen).cuda()
+    qkv2 = None if self_attn else torch.randn(B, L, W, generator=gen).cuda()
+    b1 = torch.randn(W, generator=gen).cuda()
+    b2 = None if self_attn else torch.randn(W, generator=gen).cuda()
+    nd = 1 if self_attn else 2
+    dout = torch.randn(B, L, nd * heads * hd, generator=gen).cuda()
+    out, lse = native.xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=True, bias1=b1, bias2=b2, split_bf16=False)
+    ref = native.xattn_fusion_bwd(qkv1, qkv2, out, lse, dout, heads, bias1=b1, bias2=b2, split_bf16=False)
+    got = native.xattn_fusion_bwd(qkv1, qkv2, out, lse, dout, heads, bias1=b1, bias2=b2, split_bf16=True)
+    for name, a, b in zip(("dqkv1", "dqkv2"), got, ref):
+        if b is None:
+            assert a is None
+            continue
+        assert_close(a.cpu().numpy(), b.cpu().numpy(), 1e-4, 0, name, scale_atol=3e-5)
+        rms = ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
+        assert rms < 2e-5, (name, rms)
