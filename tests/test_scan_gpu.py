@@ -89,11 +89,12 @@ def test_fwd_half_dtypes(dtype, rtol, atol):
     assert_close(out_z.float().cpu().numpy(), oz_ref, rtol, atol, "out_z")
 
 
-def test_linearity_in_u_at_full_size():
-    """Size-independent property at the BASELINE config-2 shape (256, 1024, 256, 16): with D = 0 and no gate the scan is
-    linear in u for fixed (delta, A, B, C): scan(2u1 - 3u2) == 2 scan(u1) - 3 scan(u2)."""
+@pytest.mark.parametrize("B,D,L,N", [(256, 1024, 256, 16), (64, 1152, 1024, 16)])
+def test_linearity_in_u_at_full_size(B, D, L, N):
+    """Size-independent property at the BASELINE config-2 shape (256, 1024, 256, 16) and at the config-5 shape
+    (64, 1152, 1024, 16: served by the state-split kernel): with D = 0 and no gate the scan is linear in u for fixed
+    (delta, A, B, C): scan(2u1 - 3u2) == 2 scan(u1) - 3 scan(u2)."""
     from dimsum_amd import native
-    B, D, L, N = 256, 1024, 256, 16
     g = torch.Generator(device="cuda").manual_seed(0)
     u1, u2 = torch.randn(B, D, L, device="cuda", generator=g), torch.randn(B, D, L, device="cuda", generator=g)
     delta = 0.5 * torch.rand(B, D, L, device="cuda", generator=g)
@@ -105,6 +106,60 @@ def test_linearity_in_u_at_full_size():
     err = (lhs - rhs).abs().max().item()
     scale = rhs.abs().max().item()
     assert err <= 1e-4 * scale, (err, scale)
+
+
+def test_split_and_64_channel_kernels_agree():
+    """the two forward kernels (64 channels per wave / lane = (channel, state half)) on the same operands: same fp32
+    operations per state, only the order of the final sum over states differs -> rtol 2e-5 + 2e-6 max|ref|."""
+    import os
+    import subprocess
+    import sys
+    code = ("import torch, sys; sys.path.insert(0, %r); from dimsum_amd import native; g = torch.Generator(device='cuda').manual_seed(1); "
+            "B, D, L, N = 8, 192, 320, 16; u = torch.randn(B, D, L, device='cuda', generator=g); z = torch.randn(B, D, L, device='cuda', generator=g); "
+            "dl = 0.5 * torch.rand(B, D, L, device='cuda', generator=g); A = -0.5 * torch.rand(D, N, device='cuda', generator=g); "
+            "Bm = torch.randn(B, 1, N, L, device='cuda', generator=g); Cm = torch.randn(B, 1, N, L, device='cuda', generator=g); "
+            "Dv = torch.randn(D, device='cuda', generator=g); bias = 0.5 * torch.rand(D, device='cuda', generator=g); "
+            "out, x, oz = native.selective_scan_fwd(u, dl, A, Bm, Cm, Dv, z, bias, True); torch.save((out.cpu(), x.cpu(), oz.cpu()), sys.argv[1])")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for split in ("0", "1"):                       # the env switch is read once per process
+        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"dimsum_split_{split}_{os.getpid()}.pt")
+        subprocess.run([sys.executable, "-c", code % root, path], check=True, env=dict(os.environ, DIMSUM_SCAN_SPLIT=split))
+        res.append(torch.load(path))
+        os.remove(path)
+    for name, a, b in zip(("out", "x", "out_z"), res[0], res[1]):
+        assert_close(a.numpy(), b.numpy(), 2e-5, 0, name, scale_atol=2e-6)
+
+
+def test_bwd_adjoint_identity_at_full_size():
+    """Size-independent property of the backward at the BASELINE config-3 shape (256, 1024, 256, 16), MambaInnerFn layouts.
+    For fixed (delta, A, B, C, z) the forward is linear in u and in D:  out_z(u) = M u + diag(D) (silu(z) u). So for any
+    probe w:  <dout, M w + D silu(z) w> == <du, w>  and  <dout, silu(z) u e_d> == dD[d]  -- the kernel's du / dD against the
+    forward kernel itself, in float64 accumulation, with no oracle. rtol 2e-4 of the scale of the sums."""
+    from dimsum_amd import native
+    B, D, L, N = 256, 1024, 256, 16
+    g = torch.Generator(device="cuda").manual_seed(3)
+    dm = lambda: torch.randn(D, B, L, device="cuda", generator=g).permute(1, 0, 2)          # d-major like MambaInnerFn
+    u, z, dout, w = dm(), dm(), dm(), dm()
+    delta = (0.5 * torch.rand(D, B, L, device="cuda", generator=g)).permute(1, 0, 2)
+    A = -0.5 * torch.rand(D, N, device="cuda", generator=g)
+    Bm, Cm = torch.randn(B, 1, N, L, device="cuda", generator=g), torch.randn(B, 1, N, L, device="cuda", generator=g)
+    Dv, bias = torch.randn(D, device="cuda", generator=g), 0.5 * torch.rand(D, device="cuda", generator=g)
+    out, x, out_z, ckpt = native.selective_scan_fwd(u, delta, A, Bm, Cm, Dv, z, bias, True, need_ckpt=True)
+    dz = torch.empty_like(z)
+    res = native.selective_scan_bwd(u, delta, A, Bm, Cm, Dv, z, bias, dout, x, out, dz, True, True, ckpt=ckpt)
+    du, ddelta, dA, dB, dC, dD, dbias = res[:7]
+    fw = native.selective_scan_fwd(w, delta, A, Bm, Cm, Dv, z, bias, True)[2]             # out_z for the probe input
+    lhs, rhs = (dout.double() * fw.double()).sum().item(), (du.double() * w.double()).sum().item()
+    scale = (dout.double() * fw.double()).abs().sum().sqrt().item() * 16                   # ~ the statistical size of the sum
+    assert abs(lhs - rhs) <= 2e-4 * max(abs(lhs), scale), (lhs, rhs, scale)
+    silu = z.double() * torch.sigmoid(z.double())
+    dD_ref = (dout.double() * silu * u.double()).sum(dim=(0, 2))
+    assert torch.allclose(dD.double(), dD_ref, rtol=2e-4, atol=2e-4 * dD_ref.abs().max().item())
+    # ddelta_bias is the row sum of ddelta (both produced by the kernel through different paths: LDS tile vs register sums)
+    assert torch.allclose(dbias.double(), ddelta.double().sum(dim=(0, 2)), rtol=2e-4, atol=2e-4 * dbias.abs().max().item())
+    # the out_z the backward recomputes from the saved y (selective_scan_interface.py:952) equals the forward's
+    assert torch.allclose(res[-1], out_z, rtol=1e-6, atol=0)
 
 
 def test_errors_are_loud():

@@ -184,3 +184,24 @@ def test_split_bf16_backward_vs_exact(B, L, heads, hd, self_attn):
         assert_close(a.cpu().numpy(), b.cpu().numpy(), 1e-4, 0, name, scale_atol=3e-5)
         rms = ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
         assert rms < 2e-5, (name, rms)
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_linearity_in_v_at_full_size(split):
+    """Size-independent property at the BASELINE config-2 shape (batch 256, 256 tokens, 8 heads x 64): for fixed q, k the
+    fusion core is linear in v:  core(q, k, 2 v1 - 3 v2) == 2 core(q, k, v1) - 3 core(q, k, v2). Exact-fp32 MFMA: 2e-5 of
+    the scale; split-bf16 (hi + lo of a sum is not the sum of the parts): 5e-5."""
+    from dimsum_amd import native
+    B, L, heads, hd = 256, 256, 8, 64
+    C = heads * hd
+    g = torch.Generator(device="cuda").manual_seed(5)
+    mk = lambda: torch.randn(B, L, 3 * C, device="cuda", generator=g)
+    a1, a2, b1, b2 = mk(), mk(), mk(), mk()
+    a2[:, :, :2 * C], b2[:, :, :2 * C] = a1[:, :, :2 * C], b1[:, :, :2 * C]          # same q, k; different v
+    f = lambda x, y: native.xattn_fusion_fwd(x, y, heads, split_bf16=split)
+    mix1, mix2 = a1.clone(), b1.clone()
+    mix1[:, :, 2 * C:], mix2[:, :, 2 * C:] = 2 * a1[:, :, 2 * C:] - 3 * a2[:, :, 2 * C:], 2 * b1[:, :, 2 * C:] - 3 * b2[:, :, 2 * C:]
+    lhs = f(mix1, mix2)
+    rhs = 2 * f(a1, b1) - 3 * f(a2, b2)
+    err, scale = (lhs - rhs).abs().max().item(), rhs.abs().max().item()
+    assert err <= (5e-5 if split else 2e-5) * scale, (err, scale)
