@@ -171,10 +171,12 @@ def main():
                                                              "(dimsum_amd/hip_graph.py): for per-GPU batches below ~32, where eager is launch-bound")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the extra exact-fp32 timing (for profiling runs)")
-    ap.add_argument("--matmul", choices=["tf32", "fp32"], default="tf32",
+    ap.add_argument("--matmul", choices=["tf32", "fp32", "fp16"], default="tf32",
                     help="library-GEMM policy. tf32 = the reference's own setting (torch.backends.cuda.matmul.allow_tf32 = "
                          "True, dimsum/train.py:20-21, sample_ddp.py:56); on gfx950 hipBLASLt serves it with a split-bf16 "
-                         "MFMA path measured at 4e-6 rms relative error (real TF32: ~5e-4). fp32 = exact fp32 MFMA.")
+                         "MFMA path measured at 4e-6 rms relative error (real TF32: ~5e-4). fp32 = exact fp32 MFMA. "
+                         "fp16 = opt-in, inference only: fp16 operands (TF32's 10 mantissa bits, NOT its exponent range) with "
+                         "fp32 accumulation for the large Linears (dimsum_amd/gemm.py); never the headline.")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -189,8 +191,10 @@ def main():
     torch.set_num_threads(max(1, usable_cores() // max(1, world)))
 
     def set_matmul(policy):
-        torch.backends.cuda.matmul.allow_tf32 = policy == "tf32"
-        torch.backends.cudnn.allow_tf32 = policy == "tf32"
+        from dimsum_amd import gemm
+        torch.backends.cuda.matmul.allow_tf32 = policy in ("tf32", "fp16")
+        torch.backends.cudnn.allow_tf32 = policy in ("tf32", "fp16")
+        gemm.set_policy("fp16" if policy == "fp16" else "default")
     set_matmul(args.matmul)
 
     from dimsum_amd import _lib
@@ -289,8 +293,10 @@ def main():
                                    + (f", scan_type={args.scan_type}" if args.scan_type != "none" else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world} (replicas, independent latents)",
                        "launch": "hipGraph replay" if args.hip_graph else "eager",
-                       "matmul_policy": ("allow_tf32=True like the reference (train.py:20-21); gfx950 split-bf16 path, 4e-6 rms rel err"
-                                         if args.matmul == "tf32" else "exact fp32")},
+                       "matmul_policy": {"tf32": "allow_tf32=True like the reference (train.py:20-21); gfx950 split-bf16 path, 4e-6 rms rel err",
+                                         "fp32": "exact fp32",
+                                         "fp16": "OPT-IN: fp16 operands (TF32 mantissa, fp16 exponent range) + fp32 accumulation for the large "
+                                                 "Linears, split-bf16 elsewhere"}[args.matmul]},
         }
         if fwd_mode:
             line["samples_per_sec_at_250_nfe"] = value / 250.0
@@ -328,6 +334,20 @@ def main():
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t1) / 2
             line["fp32_exact_matmul"] = {"value_per_gpu": units_per_step / dt, "ms_per_step": 1e3 * dt}
+            if args.mode == "fwd":
+                # opt-in fp16-operand policy of dimsum_amd/gemm.py, for reference only (never the headline)
+                ref = step()
+                set_matmul("fp16")
+                for _ in range(2):
+                    got = step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t1) / 3
+                line["fp16_operand_matmul_optin"] = {"value_per_gpu": units_per_step / dt, "ms_per_step": 1e3 * dt,
+                                                     "max_abs_dev_over_max_abs_vs_exact_fp32": ((got - ref).abs().max() / ref.abs().max()).item()}
             set_matmul("tf32")
         if world == 1 and not args.no_cpu_baseline and args.mode in ("fwd", "sample"):
             line["cpu_baseline"] = cpu_baseline(args.model, 8, args.image_size)

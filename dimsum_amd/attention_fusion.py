@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import native
+from . import gemm, native
 
 
 class _XattnCoreFn(torch.autograd.Function):
@@ -71,7 +71,7 @@ class CrossAttentionFusion(nn.Module):
             b1, b2 = self.qkv1.bias, self.qkv2.bias
             if (b1 is None) != (b2 is None):
                 raise RuntimeError("CrossAttentionFusion: qkv1 / qkv2 must both have a bias or none")
-            fused = _XattnCoreFn.apply(F.linear(x1, self.qkv1.weight), F.linear(x2, self.qkv2.weight), b1, b2, self.num_heads)
+            fused = _XattnCoreFn.apply(gemm.linear(x1, self.qkv1.weight), gemm.linear(x2, self.qkv2.weight), b1, b2, self.num_heads)
         else:
             qkv1, qkv2 = self.qkv1(x1), self.qkv2(x2)
             q1, k1, v1 = self._split(qkv1, B, N)
@@ -86,4 +86,4 @@ class CrossAttentionFusion(nn.Module):
             fused = torch.cat((x12.transpose(1, 2).reshape(B, N, C), x21.transpose(1, 2).reshape(B, N, C)), dim=-1)
         if isinstance(self.proj_drop, nn.Dropout) and self.proj_drop.p > 0.0 and self.training:
             return self.proj_drop(self.proj(fused)), None
-        return F.linear(fused, self.proj.weight), self.proj.bias
+        return gemm.linear(fused, self.proj.weight), self.proj.bias

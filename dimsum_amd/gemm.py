@@ -1,0 +1,62 @@
+"""Library-GEMM precision policy of the host layer (the large bias-free Linears of the denoiser: in_proj, out_proj, qkv,
+proj, w12, w3 -- everything else is small).
+
+  "default"  whatever torch is set to: torch.backends.cuda.matmul.allow_tf32 = True (the reference's own setting,
+             dimsum/train.py:20-21) makes hipBLASLt run its split-bf16 path on gfx950 (3 bf16 products per fp32 product,
+             ~4e-6 rms relative error, ~380-420 TFLOP/s-equivalent); False = exact fp32 MFMA (~144 TFLOP/s).
+  "fp16"     OPT-IN, inference only. TF32 keeps 10 mantissa bits of each operand and accumulates in fp32; gfx950 has no
+             TF32 MFMA, but an fp16-input / fp32-accumulate GEMM has exactly that mantissa (10 bits) and ONE product per
+             element instead of three. What it does NOT have is TF32's 8-bit exponent: operands above 65504 overflow and
+             operands below 6e-5 lose bits (below 6e-8 they vanish). The DiM activations that feed these GEMMs are
+             RMS-normalised / gated O(1..1e2) values and the weights O(1e-2), so the model's outputs stay within the
+             TF32-class error (~5e-4 relative; tests/test_model_gpu.py::test_fp16_product_gemm_policy) -- but this is a
+             weaker guarantee than the default and is therefore never the default nor bench.py's headline.
+The operands are converted by a torch cast (weights: cached per parameter version); outputs stay fp32."""
+import torch
+import torch.nn.functional as F
+
+_policy = "default"
+_wcache = {}
+
+
+def set_policy(policy):
+    global _policy
+    if policy not in ("default", "fp16"):
+        raise ValueError(f"unknown GEMM policy {policy!r}")
+    _policy = policy
+    _wcache.clear()
+
+
+def get_policy():
+    return _policy
+
+
+def _use_fp16(x, weight):
+    return (_policy == "fp16" and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)))
+
+
+def _w16(weight):
+    key = id(weight)
+    hit = _wcache.get(key)
+    if hit is None or hit[0] != weight._version or hit[1].device != weight.device:
+        hit = _wcache[key] = (weight._version, weight.detach().to(torch.float16))
+    return hit[1]
+
+
+def linear(x, weight):
+    """x (..., K) @ weight (N, K)^T -> (..., N), no bias (the bias rides in the consumer kernel)"""
+    if not _use_fp16(x, weight):
+        return F.linear(x, weight)
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K)
+    # (a row-major cast of out_proj's d-major input was tried: torch's transposing copy costs more than the slower GEMM kernel)
+    y = torch.mm(x2.to(torch.float16), _w16(weight).t(), out_dtype=torch.float32)
+    return y.view(*x.shape[:-1], weight.shape[0])
+
+
+def matmul_wx(weight, xt):
+    """weight (N, K) @ xt (K, M) -> (N, M): the in_proj site, whose output is consumed d-major without a copy"""
+    if not _use_fp16(xt, weight):
+        return weight @ xt
+    return torch.mm(_w16(weight), xt.to(torch.float16), out_dtype=torch.float32)

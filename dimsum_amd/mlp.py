@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import native
+from . import gemm, native
 
 
 class _GatedGeluFn(torch.autograd.Function):
@@ -44,11 +44,11 @@ class GatedMLP(nn.Module):
         """-> (y, b): the module's output is y + b; b (w3's bias or None) is left to the caller's fused residual pass."""
         if self._fused and x.dtype == torch.float32:
             b12 = self.w12.bias
-            h = gated_gelu(F.linear(x, self.w12.weight), None if b12 is None else b12.float())
+            h = gated_gelu(gemm.linear(x, self.w12.weight), None if b12 is None else b12.float())
         else:
             x1, x2 = self.w12(x).chunk(2, dim=-1)
             h = self.act_layer(x1) * x2
-        return F.linear(h, self.w3.weight), self.w3.bias
+        return gemm.linear(h, self.w3.weight), self.w3.bias
 
     def forward(self, x):
         y, b = self.forward_deferred(x)

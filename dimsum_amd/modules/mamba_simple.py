@@ -16,6 +16,7 @@ import math
 import torch
 import torch.nn as nn
 
+from .. import gemm
 from ..ops.selective_scan_interface import (mamba_inner_fn_cond, mamba_inner_fn_no_out_proj_cond)
 
 _ZIGZAG = ("zigma", "sweep", "jpeg")
@@ -90,7 +91,7 @@ class _MambaBase(nn.Module):
             # xz[..., j] = xz[..., perm[j]]: permuting the columns of xz == permuting the tokens before in_proj
             hidden_states = hidden_states.index_select(1, self.zigzag_paths[self.layer_idx])
         # in_proj with the transpose fused: (2D, d_model) @ (d_model, B*L) viewed as (B, 2D, L) -- d-major, no copy
-        xz = (self.in_proj.weight @ hidden_states.reshape(bsz * L, -1).t()).view(2 * self.d_inner, bsz, L).permute(1, 0, 2)
+        xz = gemm.matmul_wx(self.in_proj.weight, hidden_states.reshape(bsz * L, -1).t()).view(2 * self.d_inner, bsz, L).permute(1, 0, 2)
         if self.in_proj.bias is not None:
             xz = xz + self.in_proj.bias.to(xz.dtype).view(1, -1, 1)
         A = -torch.exp(self.A_log.float())

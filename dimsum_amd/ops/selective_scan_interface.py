@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 from torch.amp import custom_bwd, custom_fwd
 
-from .. import native
+from .. import gemm, native
 
 
 def _last_contig(t):
@@ -137,7 +137,9 @@ class _MambaInner(torch.autograd.Function):
                               out_proj_weight if has_out_proj else None, conv_out, delta, A, Bm, Cm, D, delta_bias, scan_x, out, ckpt)
         if not has_out_proj:
             return out_z                                                                                # (b, d, l)
-        return F.linear(out_z.transpose(1, 2), out_proj_weight, out_proj_bias)                          # (b, l, d_model)
+        if out_proj_bias is None:
+            return gemm.linear(out_z.transpose(1, 2), out_proj_weight)                                   # (b, l, d_model)
+        return F.linear(out_z.transpose(1, 2), out_proj_weight, out_proj_bias)
 
     @staticmethod
     @custom_bwd(device_type="cuda")

@@ -153,3 +153,31 @@ def test_hip_graph_replay_is_bit_identical():
     a = sample_batch(m, z, y, num_steps=5, gather=False)
     b = sample_batch(m, z, y, num_steps=5, gather=False, hip_graph={})
     assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_fp16_product_gemm_policy():
+    """dimsum_amd.gemm "fp16" (opt-in, inference): fp16 operands + fp32 accumulation in the large Linears. DiM-L/2 on the
+    bench inputs (reference init, zero tensors re-drawn): the deviation from the exact-fp32 forward must stay in the TF32 class (the reference's own
+    matmul policy has 10 mantissa bits: ~5e-4 per product): max|dev| <= 2e-3 max|ref|, rms <= 5e-4."""
+    from dimsum_amd import gemm
+    from dimsum_amd.create_model import create_model, published_config
+    torch.manual_seed(0)
+    m = create_model(published_config(model="DiM-L/2", image_size=256))
+    from dimsum_amd.utils import rerandomize_zeros
+    rerandomize_zeros(m, std=0.02, seed=0)
+    m = m.cuda().eval()
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    x, t = torch.randn(4, 4, 32, 32, device="cuda", generator=gen), torch.rand(4, device="cuda", generator=gen)
+    y = torch.randint(0, 1000, (4,), device="cuda", generator=gen)
+    try:
+        with torch.no_grad():
+            ref = m(x, t, y)
+            gemm.set_policy("fp16")
+            got = m(x, t, y)
+    finally:
+        gemm.set_policy("default")
+    dev = (got - ref)
+    assert dev.abs().max().item() <= 2e-3 * ref.abs().max().item(), (dev.abs().max().item(), ref.abs().max().item())
+    assert (dev.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item() <= 5e-4
+    assert not torch.equal(got, ref)            # the policy really took another path
