@@ -77,6 +77,26 @@ def test_zoo_forward(name, tag, B, R):
     assert_close(out.cpu().numpy(), g["out"], 1e-3, 0, "out", scale_atol=1e-4)
 
 
+@pytest.mark.parametrize("name,tag,B,R", [("DiM-L/2", "model_L2", 2, 32), ("DiM-XL/2", "model_XL2_512", 1, 64)])
+def test_zoo_forward_under_the_reference_matmul_policy(name, tag, B, R):
+    """the configuration bench.py times: torch.backends.cuda.matmul.allow_tf32 = True (dimsum/train.py:20-21), i.e. hipBLASLt's
+    split-bf16 GEMMs AND the split-bf16 MFMA attention kernels -- against the same reference goldens with the same tolerance
+    as the exact-fp32 run (north star: 1e-3)."""
+    from dimsum_amd.models_dim import DiM_models
+    g = golden(tag)
+    m = DiM_models[name](**_published(img_resolution=R))
+    procedural_fill(m, seed=3)
+    m = m.cuda().eval()
+    old = torch.backends.cuda.matmul.allow_tf32
+    try:
+        torch.backends.cuda.matmul.allow_tf32 = True
+        with torch.no_grad():
+            out = m(T(seeded((B, 4, R, R), 71)).cuda(), T(g["t"]).cuda(), T(g["y"]).cuda())
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = old
+    assert_close(out.cpu().numpy(), g["out"], 1e-3, 0, "out (allow_tf32 policy)", scale_atol=1e-4)
+
+
 # ---- forward + backward through autograd on the GPU (BASELINE config 3 path) ---------------------------------------------
 def test_mamba_inner_fn_fwd_bwd_gpu():
     from dimsum_amd.ops import mamba_inner_fn
