@@ -289,22 +289,33 @@ __device__ __forceinline__ float gelu_tanh_grad(float a) {
     return 0.5f * (1.0f + t) + 0.5f * a * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * a * a);
 }
 
-// One workgroup = a strip of 1024 columns (4 per thread, 16 B) x a chunk of kGGRows rows: bias in registers, fully
-// coalesced rows, and in the backward the column sums of dx12 (= d bias) accumulate in registers: one atomic per column
-// per workgroup.
+// backward: one workgroup = a strip of 1024 columns (4 per thread, 16 B) x a chunk of kGGRows rows: bias in registers,
+// fully coalesced rows, the column sums of dx12 (= d bias) accumulate in registers: one atomic per column per workgroup.
 constexpr int kGGRows = 64;
+// forward: one thread = 4 columns of one row, consecutive threads = consecutive 16-byte pieces of h (and of each half of
+// x12); 4 independent pieces in flight per thread, a grid stride apart
 __global__ __launch_bounds__(256) void gated_gelu_fwd_kernel(const float *x12, const float *bias, float *h, int64_t rows, int64_t H) {
-    const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (c >= H) return;
-    float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bg = ba;
-    if (bias) { ba = *reinterpret_cast<const float4 *>(bias + c); bg = *reinterpret_cast<const float4 *>(bias + H + c); }
-    const int64_t r0 = (int64_t)blockIdx.y * kGGRows, r1 = min(rows, r0 + kGGRows);
-    for (int64_t r = r0; r < r1; ++r) {
-        float4 a = *reinterpret_cast<const float4 *>(x12 + r * 2 * H + c);
-        float4 g = *reinterpret_cast<const float4 *>(x12 + r * 2 * H + H + c);
-        a.x += ba.x; a.y += ba.y; a.z += ba.z; a.w += ba.w;
-        g.x += bg.x; g.y += bg.y; g.z += bg.z; g.w += bg.w;
-        *reinterpret_cast<float4 *>(h + r * H + c) = make_float4(gelu_tanh(a.x) * g.x, gelu_tanh(a.y) * g.y, gelu_tanh(a.z) * g.z, gelu_tanh(a.w) * g.w);
+    const int64_t q = H / 4, total = rows * q;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += 4 * stride) {
+        float4 a[4], g[4];
+        int64_t rr[4], cc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t i = min(i0 + k * stride, total - 1);
+            rr[k] = i / q; cc[k] = (i - rr[k] * q) * 4;
+            a[k] = *reinterpret_cast<const float4 *>(x12 + rr[k] * 2 * H + cc[k]);
+            g[k] = *reinterpret_cast<const float4 *>(x12 + rr[k] * 2 * H + H + cc[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i0 + k * stride >= total) break;
+            float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bg = ba;
+            if (bias) { ba = *reinterpret_cast<const float4 *>(bias + cc[k]); bg = *reinterpret_cast<const float4 *>(bias + H + cc[k]); }
+            const float4 av = make_float4(a[k].x + ba.x, a[k].y + ba.y, a[k].z + ba.z, a[k].w + ba.w);
+            const float4 gv = make_float4(g[k].x + bg.x, g[k].y + bg.y, g[k].z + bg.z, g[k].w + bg.w);
+            *reinterpret_cast<float4 *>(h + rr[k] * H + cc[k]) = make_float4(gelu_tanh(av.x) * gv.x, gelu_tanh(av.y) * gv.y, gelu_tanh(av.z) * gv.z, gelu_tanh(av.w) * gv.w);
+        }
     }
 }
 __global__ __launch_bounds__(256) void gated_gelu_bwd_kernel(const float *x12, const float *bias, const float *dh, float *dx12, float *dbias,
@@ -359,8 +370,12 @@ extern "C" int dimsum_gated_gelu_fwd(const void *x12, const void *bias, void *h,
     if (rows < 0 || hidden <= 0 || hidden % 4 != 0) return DIMSUM_ERR_SHAPE;
     if (!aligned_to<float>(x12, 16) || !aligned_to<float>(h, 16) || (bias && !aligned_to<float>(bias, 16))) return DIMSUM_ERR_STRIDE;
     if (rows == 0) return DIMSUM_OK;
-    const dim3 grid((unsigned)((hidden / 4 + 255) / 256), (unsigned)((rows + kGGRows - 1) / kGGRows));
-    hipLaunchKernelGGL(gated_gelu_fwd_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+    // flat mapping: 4 pieces per thread a quarter of the tensor apart, no row loop: 0.60 ms at (65536, 2 x 4096) against 0.67 ms
+    // for the strip-per-workgroup form the backward keeps (it needs the row loop for the d bias column sums)
+    const int64_t total = rows * (hidden / 4);
+    const int64_t blocks = (total + 256 * 4 - 1) / (256 * 4);
+    if (blocks > 0x7fffffff) return DIMSUM_ERR_SHAPE;
+    hipLaunchKernelGGL(gated_gelu_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        reinterpret_cast<const float *>(x12), reinterpret_cast<const float *>(bias), reinterpret_cast<float *>(h), rows, hidden);
     return launch_status();
 }
