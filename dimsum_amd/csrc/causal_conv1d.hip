@@ -5,7 +5,8 @@
 //     out[b,d,t] = act(bias[d] + sum_k W[d,k] * x[b,d,t-(width-1-k)]),   x[.., t<0] = 0,   act = SiLU or identity
 // Pure streaming: 2*B*D*L*s bytes forward, 3*B*D*L*s backward.
 //
-// MI355X design: one wave64 walks one (b,d) row, 256 elements per step (16 B per lane, fully coalesced 1-KiB requests);
+// MI355X design: one wave64 walks (b,d) rows, four at a time with their loads issued back to back, 256 elements per step
+// and row (16 B per lane, fully coalesced 1-KiB requests);
 // the 3-element halo comes from the neighbouring lane (one cross-lane move per value) and, across 256-element steps,
 // from registers -- no LDS, no block barrier (the reference stages a 128-thread block through shared memory and idles
 // half of it at L = 256). Weights and bias are wave-uniform (scalar loads). The backward walks the row from the end
@@ -63,34 +64,49 @@ __global__ __launch_bounds__(256) void causal_conv1d_fwd_kernel(const dimsum_con
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t rows = (int64_t)p.batch * p.dim;
     const int L = p.seqlen, W = p.width;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
-        const int b = (int)(row / p.dim), d = (int)(row - (int64_t)b * p.dim);
-        const T *x = reinterpret_cast<const T *>(p.x_ptr) + (int64_t)b * p.x_batch_stride + (int64_t)d * p.x_c_stride;
-        T *o = reinterpret_cast<T *>(p.out_ptr) + (int64_t)b * p.out_batch_stride + (int64_t)d * p.out_c_stride;
-        const float *wp = reinterpret_cast<const float *>(p.weight_ptr) + (int64_t)d * p.weight_c_stride;
-        // taps right-aligned into 4 slots: w4[3] multiplies x[t], w4[2] x[t-1], ...
-        float w4[4];
+    // kR rows per wave and iteration, a grid stride apart: their loads are issued back to back (kR x 1 KiB in flight per wave)
+    constexpr int kR = 4;
+    const int64_t gstride = (int64_t)gridDim.x * 4;
+    for (int64_t row0 = (int64_t)blockIdx.x * 4 + wave; row0 < rows; row0 += kR * gstride) {
+        const T *x[kR];
+        T *o[kR];
+        float w4[kR][4], bias[kR], c1[kR], c2[kR], c3[kR];   // taps right-aligned into 4 slots: w4[3] multiplies x[t], w4[2] x[t-1], ...
+        bool ok[kR];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) w4[k] = (k >= 4 - W) ? wp[(k - (4 - W)) * p.weight_width_stride] : 0.f;
-        const float bias = p.bias_ptr ? reinterpret_cast<const float *>(p.bias_ptr)[d] : 0.f;
-        float c1 = 0.f, c2 = 0.f, c3 = 0.f;   // x[t0-1], x[t0-2], x[t0-3] carried across 256-element steps
+        for (int r = 0; r < kR; ++r) {
+            const int64_t row = min(row0 + r * gstride, rows - 1);
+            ok[r] = row0 + r * gstride < rows;
+            const int b = (int)(row / p.dim), d = (int)(row - (int64_t)b * p.dim);
+            x[r] = reinterpret_cast<const T *>(p.x_ptr) + (int64_t)b * p.x_batch_stride + (int64_t)d * p.x_c_stride;
+            o[r] = reinterpret_cast<T *>(p.out_ptr) + (int64_t)b * p.out_batch_stride + (int64_t)d * p.out_c_stride;
+            const float *wp = reinterpret_cast<const float *>(p.weight_ptr) + (int64_t)d * p.weight_c_stride;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w4[r][k] = (k >= 4 - W) ? wp[(k - (4 - W)) * p.weight_width_stride] : 0.f;
+            bias[r] = p.bias_ptr ? reinterpret_cast<const float *>(p.bias_ptr)[d] : 0.f;
+            c1[r] = c2[r] = c3[r] = 0.f;                     // x[t0-1], x[t0-2], x[t0-3] carried across 256-element steps
+        }
         for (int t0 = 0; t0 < L; t0 += 4 * kWave) {
             const int t = t0 + lane * 4;
-            const f32x4 v = load_row4<T, kVec>(x, t, L);
-            const float m1 = lane_up(v.v[3], c1), m2 = lane_up(v.v[2], c2), m3 = lane_up(v.v[1], c3);
-            f32x4 r;
-            r.v[0] = bias + w4[0] * m3 + w4[1] * m2 + w4[2] * m1 + w4[3] * v.v[0];
-            r.v[1] = bias + w4[0] * m2 + w4[1] * m1 + w4[2] * v.v[0] + w4[3] * v.v[1];
-            r.v[2] = bias + w4[0] * m1 + w4[1] * v.v[0] + w4[2] * v.v[1] + w4[3] * v.v[2];
-            r.v[3] = bias + w4[0] * v.v[0] + w4[1] * v.v[1] + w4[2] * v.v[2] + w4[3] * v.v[3];
-            if (p.silu_activation) {
+            f32x4 v[kR];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) r.v[e] *= sigmoidf_fast(r.v[e]);   // out / (1 + exp(-out)), causal_conv1d_fwd.cu:113-118
+            for (int r = 0; r < kR; ++r) v[r] = load_row4<T, kVec>(x[r], t, L);
+#pragma unroll
+            for (int r = 0; r < kR; ++r) {
+                const float m1 = lane_up(v[r].v[3], c1[r]), m2 = lane_up(v[r].v[2], c2[r]), m3 = lane_up(v[r].v[1], c3[r]);
+                f32x4 q;
+                q.v[0] = bias[r] + w4[r][0] * m3 + w4[r][1] * m2 + w4[r][2] * m1 + w4[r][3] * v[r].v[0];
+                q.v[1] = bias[r] + w4[r][0] * m2 + w4[r][1] * m1 + w4[r][2] * v[r].v[0] + w4[r][3] * v[r].v[1];
+                q.v[2] = bias[r] + w4[r][0] * m1 + w4[r][1] * v[r].v[0] + w4[r][2] * v[r].v[1] + w4[r][3] * v[r].v[2];
+                q.v[3] = bias[r] + w4[r][0] * v[r].v[0] + w4[r][1] * v[r].v[1] + w4[r][2] * v[r].v[2] + w4[r][3] * v[r].v[3];
+                if (p.silu_activation) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) q.v[e] *= sigmoidf_fast(q.v[e]);   // out / (1 + exp(-out)), causal_conv1d_fwd.cu:113-118
+                }
+                if (ok[r]) store_row4<T, kVec>(o[r], t, L, q);
+                c1[r] = __shfl(v[r].v[3], kWave - 1, kWave);
+                c2[r] = __shfl(v[r].v[2], kWave - 1, kWave);
+                c3[r] = __shfl(v[r].v[1], kWave - 1, kWave);
             }
-            store_row4<T, kVec>(o, t, L, r);
-            c1 = __shfl(v.v[3], kWave - 1, kWave);
-            c2 = __shfl(v.v[2], kWave - 1, kWave);
-            c3 = __shfl(v.v[1], kWave - 1, kWave);
         }
     }
 }
@@ -179,7 +195,7 @@ template <typename T> static int launch_conv_fwd(const dimsum_conv_params_t &p, 
     const bool vec = vec_ok<T>(p.x_ptr, p.x_batch_stride, p.x_c_stride, p.seqlen) &&
                      vec_ok<T>(p.out_ptr, p.out_batch_stride, p.out_c_stride, p.seqlen);
     const int64_t rows = (int64_t)p.batch * p.dim;
-    const int grid = (int)((rows + 3) / 4 < 256 * 32 ? (rows + 3) / 4 : 256 * 32);
+    const int grid = (int)((rows + 15) / 16 < 256 * 32 ? (rows + 15) / 16 : 256 * 32);   // 4 waves x 4 rows per workgroup and pass (a 2x larger grid measured slower)
     if (vec) hipLaunchKernelGGL((causal_conv1d_fwd_kernel<T, true>), dim3(grid), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((causal_conv1d_fwd_kernel<T, false>), dim3(grid), dim3(256), 0, s, p);
     return launch_status();
