@@ -140,8 +140,15 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const dimsum_norm_bwd_par
         float *dx = reinterpret_cast<float *>(p.dx_ptr) + row * p.dx_row_stride;
         const float rstd = reinterpret_cast<const float *>(p.rstd_ptr)[row];
         const float mean = (p.is_rms_norm || !p.mean_ptr) ? 0.f : reinterpret_cast<const float *>(p.mean_ptr)[row];
-        f32x4 xh[kPieces], wdy[kPieces];
+        f32x4 xh[kPieces], wdy[kPieces], dr[kPieces];
         float c1 = 0.f, c2 = 0.f;
+        // all three row streams are requested up front (dres is only needed after the row reduction: loading it there would
+        // expose its latency once per row)
+#pragma unroll
+        for (int i = 0; i < kPieces; ++i) {
+            const int c = (i * kWave + lane) * 4;
+            dr[i] = (dres && c < N) ? ld_cols<float>(dres, c, N, vec) : f32x4{{0.f, 0.f, 0.f, 0.f}};
+        }
 #pragma unroll
         for (int i = 0; i < kPieces; ++i) {
             const int c = (i * kWave + lane) * 4;
@@ -163,23 +170,36 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const dimsum_norm_bwd_par
         for (int i = 0; i < kPieces; ++i) {
             const int c = (i * kWave + lane) * 4;
             if (c < N) {
-                f32x4 o = dres ? ld_cols<float>(dres, c, N, vec) : f32x4{{0.f, 0.f, 0.f, 0.f}};
+                f32x4 o = dr[i];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o.v[e] += (wdy[i].v[e] - (xh[i].v[e] * c1 + c2)) * rstd;
                 st_cols<float>(dx, c, N, vec, o);
             }
         }
     }
+    // The 4 waves of the workgroup add their column sums in LDS first: one atomic per column per WORKGROUP (the atomics were
+    // ~40 % of the kernel's time with one per wave), which also leaves room for twice the waves in flight.
+    __shared__ __attribute__((aligned(16))) float sred[4 * kPieces * kWave * 4];
     float *dwp = reinterpret_cast<float *>(p.dweight_ptr), *dbp = reinterpret_cast<float *>(p.dbias_ptr);
+    for (int pass = 0; pass < (dbp ? 2 : 1); ++pass) {
+        if (pass) __syncthreads();
 #pragma unroll
-    for (int i = 0; i < kPieces; ++i) {
-        const int c = (i * kWave + lane) * 4;
+        for (int i = 0; i < kPieces; ++i)
+            *reinterpret_cast<f32x4 *>(&sred[(wave * kPieces * kWave + i * kWave + lane) * 4]) = pass ? db[i] : dw[i];
+        __syncthreads();
+        float *dst = pass ? dbp : dwp;
+        for (int i = threadIdx.x; i < kPieces * kWave; i += 256) {          // 16-byte column group i
+            f32x4 acc = *reinterpret_cast<const f32x4 *>(&sred[i * 4]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (c + e < N) {
-                atomicAdd(dwp + c + e, dw[i].v[e]);
-                if (dbp) atomicAdd(dbp + c + e, db[i].v[e]);
+            for (int wv = 1; wv < 4; ++wv) {
+                const f32x4 t = *reinterpret_cast<const f32x4 *>(&sred[(wv * kPieces * kWave + i) * 4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc.v[e] += t.v[e];
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (i * 4 + e < N) atomicAdd(dst + i * 4 + e, acc.v[e]);
+        }
     }
 }
 
@@ -255,9 +275,9 @@ extern "C" int dimsum_norm_bwd(const dimsum_norm_bwd_params_t *p, void *stream) 
                aligned_to<float>(p->weight_ptr, 16) && p->r_row_stride % 4 == 0 && p->dy_row_stride % 4 == 0 && p->dx_row_stride % 4 == 0;
     if (p->dres_ptr) vec = vec && aligned_to<float>(p->dres_ptr, 16) && p->dres_row_stride % 4 == 0;
     const int pieces = (N + 255) / 256;
-    // few, fat waves: every wave ends with N atomics, so cap the grid at ~2 waves per SIMD
+    // few, fat workgroups: every workgroup ends with N atomics, so cap the grid at ~2 waves per SIMD
     const int64_t blocks = (p->rows + 3) / 4;
-    const dim3 grid((unsigned)(blocks < 512 ? blocks : 512)), block(256);
+    const dim3 grid((unsigned)(blocks < 512 ? blocks : 512)), block(256);    // measured: 256 -> 370 us, 512 -> 256 us, 1024 -> 308 us
 #define DIMSUM_NB(K) hipLaunchKernelGGL((norm_bwd_kernel<K>), grid, block, 0, s, *p, vec)
     if (pieces <= 1) DIMSUM_NB(1);
     else if (pieces <= 2) DIMSUM_NB(2);
