@@ -17,8 +17,11 @@ int ssm_check(const dimsum_ssm_params_t *p, bool forward) {
 }
 
 // Which forward kernel serves a shape. DIMSUM_SCAN_SPLIT=0/1 forces one (experiments).
+static int g_force_split = -1;      // -1: automatic; 0 / 1: forced (tests, experiments)
+
 bool ssm_scan_fwd_use_split(const dimsum_ssm_params_t &p) {
     static const char *env = getenv("DIMSUM_SCAN_SPLIT");
+    if (g_force_split == 0 || g_force_split == 1) return g_force_split == 1 && p.dstate % 4 == 0;
     if (env && (env[0] == '0' || env[0] == '1')) return env[0] == '1';
     // The 64-channel kernel keeps 8 waves per CU resident (2048 on the chip). A launch that does not even fill those slots
     // once is latency-bound per wave: the split kernel gives it twice the waves, each with half the sequential work
@@ -29,6 +32,9 @@ bool ssm_scan_fwd_use_split(const dimsum_ssm_params_t &p) {
 }
 
 }  // namespace dimsum
+
+// diagnostics (not part of the public header): force one of the two forward kernels (-1 = automatic choice)
+extern "C" void dimsum_debug_scan_fwd_force_split(int mode) { dimsum::g_force_split = mode; }
 
 extern "C" int dimsum_ssm_scan_fwd(const dimsum_ssm_params_t *p, void *stream) {
     using namespace dimsum;

@@ -20,6 +20,17 @@ pytestmark = pytest.mark.gpu
 CASES = ["scan_main", "scan_long", "scan_odd", "scan_plain", "scan_nosoftplus_z", "scan_groups2"]
 
 
+@pytest.fixture(params=["auto", "64ch", "split"])
+def fwd_kernel(request):
+    """runs a forward test under the automatic kernel choice and with each of the two forward kernels forced
+    (64 channels per wave / lane = (channel, state half)): small test shapes would otherwise all take the split kernel"""
+    from dimsum_amd import _lib
+    lib = _lib.load()
+    lib.dimsum_debug_scan_fwd_force_split({"auto": -1, "64ch": 0, "split": 1}[request.param])
+    yield request.param
+    lib.dimsum_debug_scan_fwd_force_split(-1)
+
+
 def _t(a, dev="cuda"):
     return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
@@ -29,7 +40,7 @@ def _opt(g, k):
 
 
 @pytest.mark.parametrize("name", CASES)
-def test_fwd_vs_golden(name):
+def test_fwd_vs_golden(name, fwd_kernel):
     from dimsum_amd import native
     g = golden(name)
     args = [_t(g[k]) for k in ("u", "delta", "A", "B", "C")] + [_t(_opt(g, k)) for k in ("D", "z", "delta_bias")]
@@ -43,7 +54,7 @@ def test_fwd_vs_golden(name):
 
 
 @pytest.mark.parametrize("B,D,L,N", [(3, 192, 256, 16), (2, 64, 1024, 16), (1, 130, 96, 16), (2, 4, 4100, 8), (1, 64, 32, 4), (2, 70, 36, 32)])
-def test_fwd_vs_oracle_mamba_layout(B, D, L, N):
+def test_fwd_vs_oracle_mamba_layout(B, D, L, N, fwd_kernel):
     """Layouts exactly as MambaInnerFn produces them: u contiguous, z = half of xz (batch stride 2DL),
     delta d-major (strides (L, B*L, 1)), out inherits delta's layout, B/C (B,1,N,L) contiguous."""
     from dimsum_amd import native
@@ -71,7 +82,7 @@ def test_fwd_vs_oracle_mamba_layout(B, D, L, N):
 
 
 @pytest.mark.parametrize("dtype,rtol,atol", [(torch.bfloat16, 3e-2, 5e-2), (torch.float16, 3e-3, 5e-3)])
-def test_fwd_half_dtypes(dtype, rtol, atol):
+def test_fwd_half_dtypes(dtype, rtol, atol, fwd_kernel):
     """16-bit I/O, fp32 state (tolerances of mamba/tests/ops/test_selective_scan.py:49-53)."""
     from dimsum_amd import native
     from oracle import c_ops
@@ -206,7 +217,7 @@ def test_bwd_vs_golden(name):
         assert_close(res[8].cpu().numpy(), g["out"], what="recomputed out_z", **tol(L))
 
 
-@pytest.mark.parametrize("B,D,L,N", [(3, 192, 256, 16), (2, 70, 100, 16), (1, 64, 1024, 8)])
+@pytest.mark.parametrize("B,D,L,N", [(3, 192, 256, 16), (2, 70, 100, 16), (1, 64, 1024, 8), (2, 40, 72, 4), (1, 96, 64, 32), (2, 33, 44, 32)])
 def test_bwd_vs_oracle_mamba_layout(B, D, L, N):
     """d-major delta / dout / ddelta and a caller-provided dz view into dxz, as in MambaInnerFn.backward (:933-953)."""
     from dimsum_amd import native
