@@ -17,6 +17,8 @@
 // output token p of the block, channel c' holds band q of input channel c with  q*C + c = c'*16 + p.  That regrouping
 // mixes channels across threads, so the coefficients go through an LDS image indexed by the flat j = q*C + c, stored
 // as [c'/4][p][c'%4] with 68-dword rows: 16-B reads by the storing thread (4 channels of one token) are conflict free.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace dimsum {
@@ -113,6 +115,7 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
 #pragma unroll
         for (int k = 0; k < 16; ++k) s_of[k] = (bh * 4 + (k >> 2)) * G + bw * 4 + (k & 3);
     }
+    auto pos_of = [&](int k) { return KIND == DIMSUM_TT_NONE ? (int)blockIdx.x * 16 + k : s_of[k]; };   // NONE: k may be dynamic
     const float *xb = reinterpret_cast<const float *>(p.x_ptr) + (int64_t)b * p.x_batch_stride;
     float *yb = p.y_ptr ? reinterpret_cast<float *>(p.y_ptr) + (int64_t)b * p.y_batch_stride : nullptr;
     const float *rb = p.residual_ptr ? reinterpret_cast<const float *>(p.residual_ptr) + (int64_t)b * p.res_batch_stride : nullptr;
@@ -141,8 +144,8 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
         else dst[0] = *ptr;
     };
     auto store_out = [&](int k, int c, const float *val) {       // position k of the block, channels c..c+VEC-1
-        if (s_of[k] >= p.tokens) return;
-        const int tok = p.out_index_ptr ? p.out_index_ptr[s_of[k]] : s_of[k];
+        if (pos_of(k) >= p.tokens) return;
+        const int tok = p.out_index_ptr ? p.out_index_ptr[pos_of(k)] : pos_of(k);
         float o[VEC], t[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) o[e] = val[e];
@@ -167,17 +170,42 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
         else dst[0] = o[0];
     };
     auto load_in = [&](int k, int c, float *dst) {               // gated input of position k
-        if (s_of[k] >= p.tokens) {
+        if (pos_of(k) >= p.tokens) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) dst[e] = 0.f;
             return;
         }
-        const int tok = p.in_index_ptr ? p.in_index_ptr[s_of[k]] : s_of[k];
+        const int tok = p.in_index_ptr ? p.in_index_ptr[pos_of(k)] : pos_of(k);
         load_vec(xb + (int64_t)tok * p.x_token_stride + c, dst);
         if (gate) { float t[VEC]; load_vec(gate + c, t);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) dst[e] *= t[e]; }
     };
+
+    if constexpr (KIND == DIMSUM_TT_NONE) {
+        // No transform ties the 16 positions together: when the channel groups do not fill the workgroup (the half-width
+        // x1 / x2 slices: 128 groups for 256 threads), split the 16 tokens over the idle threads as well -- every thread
+        // active, 8 (or 4) tokens with all their loads in flight per thread.
+        const int cg = (C + VEC - 1) / VEC;
+        const int nsub = cg <= kTTThreads / 4 ? 4 : (cg <= kTTThreads / 2 ? 2 : 1);
+        if (nsub > 1 && C % VEC == 0) {
+            const int sub = tid / cg, c = (tid - sub * cg) * VEC;
+            if (sub < nsub) {
+                auto pass = [&](auto perc) {
+                    constexpr int PER = decltype(perc)::value;
+                    float v[PER][VEC];
+#pragma unroll
+                    for (int k = 0; k < PER; ++k) load_in(sub * PER + k, c, v[k]);
+#pragma unroll
+                    for (int k = 0; k < PER; ++k) store_out(sub * PER + k, c, v[k]);
+                    flush_red(c);
+                };
+                if (nsub == 2) pass(std::integral_constant<int, 8>{});
+                else pass(std::integral_constant<int, 4>{});
+            }
+            return;
+        }
+    }
 
     if constexpr (KIND == DIMSUM_TT_HAAR_INV) {
         // phase 1: the (token p, channel c') image goes to LDS at flat j = c'*16 + p
