@@ -325,13 +325,17 @@ __global__ __launch_bounds__(256, (QT == 2 && HD <= 64) ? 3 : (QT == 2 ? 2 : 1))
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             float mx = -1e30f;
+            if (k0 + kKT > L) {                        // only the last, ragged key tile needs the mask (wave-uniform branch)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (k0 + kt * 16 + kg * 4 + r >= L) s[t][kt][r] = -1e30f;
+            }
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (k0 + kt * 16 + kg * 4 + r >= L) s[t][kt][r] = -1e30f;
-                    mx = fmaxf(mx, s[t][kt][r]);
-                }
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][kt][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 16, kWave));
             mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
             const float m_new = fmaxf(m_run[t], mx);
