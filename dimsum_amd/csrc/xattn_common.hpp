@@ -22,6 +22,23 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned &hi, unsigne
 }
 __device__ __forceinline__ bf16x8 as_bf16x8(const u4v &v) { return __builtin_bit_cast(bf16x8, v); }
 
+// max / sum over the 4 lanes {l, l^16, l^32, l^48} that share a query (or key) column of a 16x16 MFMA C tile, on the VALU:
+// v_permlane16_swap / v_permlane32_swap exchange half of (x, x) so that op(a, b) is the pair result in every lane. The
+// ds_bpermute form of __shfl_xor makes each of these steps an LDS round trip (~100+ cycles of latency, 4 per query tile
+// and key tile, in a dependent chain).
+__device__ __forceinline__ float quad_max(float x) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float quad_sum(float x) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // acc += a . b with a = (ah, al), b = (bh, bl): the small cross terms first
 __device__ __forceinline__ f4 mfma_split(const u4v &ah, const u4v &al, const u4v &bh, const u4v &bl, f4 acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(al), as_bf16x8(bh), acc, 0, 0, 0);

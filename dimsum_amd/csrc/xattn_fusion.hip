@@ -137,8 +137,7 @@ __global__ __launch_bounds__(256) void xattn_fusion_fwd_kernel(const dimsum_xatt
                 if (k0 + kt * 16 + kg * 4 + r >= L) s[kt][r] = -1e30f;
                 mx = fmaxf(mx, s[kt][r]);
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, kWave));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
+        mx = quad_max(mx);
         const float m_new = fmaxf(m_run, mx);
         const float alpha = fast_exp2(m_run - m_new);
         float rs = 0.f;
@@ -146,8 +145,7 @@ __global__ __launch_bounds__(256) void xattn_fusion_fwd_kernel(const dimsum_xatt
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { s[kt][r] = fast_exp2(s[kt][r] - m_new); rs += s[kt][r]; }
-        rs += __shfl_xor(rs, 16, kWave);
-        rs += __shfl_xor(rs, 32, kWave);
+        rs = quad_sum(rs);
         l_run = l_run * alpha + rs;
         m_run = m_new;
 #pragma unroll
@@ -336,8 +334,7 @@ __global__ __launch_bounds__(256, (QT == 2 && HD <= 64) ? 3 : (QT == 2 ? 2 : 1))
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][kt][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, kWave));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
+            mx = quad_max(mx);
             const float m_new = fmaxf(m_run[t], mx);
             const float alpha = fast_exp2(m_run[t] - m_new);
             float rs = 0.f;
@@ -345,8 +342,7 @@ __global__ __launch_bounds__(256, (QT == 2 && HD <= 64) ? 3 : (QT == 2 ? 2 : 1))
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { s[t][kt][r] = fast_exp2(s[t][kt][r] - m_new); rs += s[t][kt][r]; }
-            rs += __shfl_xor(rs, 16, kWave);
-            rs += __shfl_xor(rs, 32, kWave);
+            rs = quad_sum(rs);
             l_run[t] = l_run[t] * alpha + rs;
             m_run[t] = m_new;
 #pragma unroll

@@ -104,8 +104,7 @@ __global__ __launch_bounds__(256) void xattn_bwd_dq_kernel(const dimsum_xattn_bw
         dof[c] = f4{g.x * m, g.y * m, g.z * m, g.w * m};
         dpart += m * (g.x * o.x + g.y * o.y + g.z * o.z + g.w * o.w);
     }
-    dpart += __shfl_xor(dpart, 16, kWave);
-    dpart += __shfl_xor(dpart, 32, kWave);                    // D of this lane's query
+    dpart = quad_sum(dpart);                                  // D of this lane's query
     const int64_t stat = (((int64_t)b * ndir + dir) * H + h) * L + q_ld;
     const float lse2 = reinterpret_cast<const float *>(p.fwd.lse_ptr)[stat] * kLog2e;
     if (q_tok < L && kg == 0) reinterpret_cast<float *>(p.delta_ptr)[stat] = dpart;
@@ -353,8 +352,7 @@ __global__ __launch_bounds__(512, 4) void xattn_bwd_dq_split_kernel(const dimsum
 #pragma unroll
         for (int i = 0; i < 4; ++i) { split2(qv[2 * i], qv[2 * i + 1], qh[c].w[i], ql[c].w[i]); split2(gv[2 * i], gv[2 * i + 1], gh[c].w[i], gl[c].w[i]); }
     }
-    dpart += __shfl_xor(dpart, 16, kWave);
-    dpart += __shfl_xor(dpart, 32, kWave);                    // D of this lane's query
+    dpart = quad_sum(dpart);                                  // D of this lane's query
     const int64_t stat = (((int64_t)b * ndir + dir) * H + h) * L + q_ld;
     const float lse2 = reinterpret_cast<const float *>(p.fwd.lse_ptr)[stat] * kLog2e;
     if (q_tok < L && kg == 0) reinterpret_cast<float *>(p.delta_ptr)[stat] = dpart;
