@@ -72,7 +72,8 @@ def build_training(model, device, lr=1e-4, world_size=1, device_ids=None):
     requires_grad(ema, False)
     if world_size > 1:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=device_ids, find_unused_parameters=False)
-    opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=0)
+    fused = os.environ.get("DIMSUM_FUSED_ADAMW", "1") != "0" and torch.device(device).type == "cuda"
+    opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=0, fused=fused)      # one multi-tensor kernel for the whole step
     update_ema(ema, model.module if hasattr(model, "module") else model, decay=0)
     ema.eval()
     return model, ema, opt
