@@ -263,3 +263,29 @@ def test_selective_scan_fn_autograd():
         assert_close(leaves[k].grad.cpu().numpy(), g[gk], what=gk, **_bwd_tol(256))
     for k, gk in (("A", "dA"), ("D", "dD"), ("delta_bias", "ddelta_bias")):
         assert_close(leaves[k].grad.cpu().numpy(), g[gk], what=gk, **_bwd_tol(256, True))
+
+
+@pytest.mark.parametrize("dtype,tol_rel", [(torch.bfloat16, 4e-2), (torch.float16, 6e-3)])
+def test_bwd_half_dtypes(dtype, tol_rel):
+    """bf16 / fp16 I/O of the backward (fp32 state and accumulators inside, like selective_scan_bwd_kernel.cuh): the gradients
+    on half-precision operands vs the fp32 kernel on the same (rounded) values, within the output rounding of the dtype."""
+    from dimsum_amd import native
+    B, D, L, N = 2, 96, 160, 16
+    g = torch.Generator(device="cuda").manual_seed(11)
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    u, z, dout = rnd(B, D, L).to(dtype), rnd(B, D, L).to(dtype), rnd(B, D, L).to(dtype)
+    delta = (0.5 * torch.rand(B, D, L, device="cuda", generator=g)).to(dtype)
+    A = -0.5 * torch.rand(D, N, device="cuda", generator=g)
+    Bm, Cm = rnd(B, 1, N, L).to(dtype), rnd(B, 1, N, L).to(dtype)
+    Dv, bias = rnd(D), 0.5 * torch.rand(D, device="cuda", generator=g)
+
+    def run(cast):
+        args = [t.to(cast) for t in (u, delta)] + [A] + [t.to(cast) for t in (Bm, Cm)] + [Dv, z.to(cast), bias]
+        out, x, out_z = native.selective_scan_fwd(*args, True)
+        res = native.selective_scan_bwd(*args, dout.to(cast), x, out, None, True, True)
+        return res[:8]
+    ref, got = run(torch.float32), run(dtype)
+    for name, a, b in zip(("du", "ddelta", "dA", "dB", "dC", "dD", "ddelta_bias", "dz"), got, ref):
+        a, b = a.float(), b.float()
+        err, scale = (a - b).abs().max().item(), b.abs().max().item()
+        assert err <= tol_rel * scale, (name, err, scale)
