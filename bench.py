@@ -321,7 +321,7 @@ def main():
         rb = roof("bwd", "ssm_scan_bwd_kernel<float,16>", "scan_bwd_pmc.json")
         if rb is not None:
             line["roofline_bwd"] = rb
-        if args.matmul == "tf32" and args.mode in ("fwd", "block") and not args.no_fp32_leg:
+        if world == 1 and args.matmul == "tf32" and args.mode in ("fwd", "block") and not args.no_fp32_leg:
             # the same step with exact-fp32 library GEMMs, for reference (2 untimed + 2 timed steps)
             set_matmul("fp32")
             timer.enabled = False
@@ -353,6 +353,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.model, 8, args.image_size)
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier(device_ids=[local_rank])     # nobody tears the communicator down while rank 0 is still reporting
         dist.destroy_process_group()
 
 
