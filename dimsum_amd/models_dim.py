@@ -12,6 +12,7 @@ Out of scope (constructor raises): block types linear/window/combined_einfft, Mo
 `enable_fourier_layers` -- unused by every published config.
 """
 import math
+import os
 from functools import partial
 
 import numpy as np
@@ -238,6 +239,15 @@ class _BlockBase(nn.Module):
         key = (L, str(device))
         if key not in cache:
             fwd = build(math.isqrt(L))
+            # a zigzag mixer (scan_type zigma_N / sweep_N / jpeg_N) gathers its tokens once more by its layer's path
+            # (mamba_simple.py:627-657): composed into this block's table, the mixer then skips its two gathers
+            mixer = getattr(self, "mixer", None)
+            if mixer is not None and getattr(mixer, "_is_zigzag", lambda: False)() and getattr(mixer, "zigzag_paths", None) is not None \
+                    and os.environ.get("DIMSUM_FOLD_ZIGZAG", "1") != "0":
+                perm = mixer.zigzag_paths[mixer.layer_idx].detach().cpu().numpy().astype(np.int64)
+                assert perm.shape[0] == L, "zigzag path length != sequence length"
+                fwd = perm if fwd is None else so.compose(fwd, perm)
+                mixer._zigzag_folded = True
             if fwd is None:
                 cache[key] = None
             else:

@@ -87,7 +87,8 @@ class _MambaBase(nn.Module):
 
     def _mix(self, hidden_states, cond):
         bsz, L, _ = hidden_states.shape
-        if self._is_zigzag():
+        own_gather = self._is_zigzag() and not getattr(self, "_zigzag_folded", False)   # folded: the enclosing block's token
+        if own_gather:                                                                  # tables already include the path
             # xz[..., j] = xz[..., perm[j]]: permuting the columns of xz == permuting the tokens before in_proj
             hidden_states = hidden_states.index_select(1, self.zigzag_paths[self.layer_idx])
         # in_proj with the transpose fused: (2D, d_model) @ (d_model, B*L) viewed as (B, 2D, L) -- d-major, no copy
@@ -115,7 +116,7 @@ class _MambaBase(nn.Module):
         out = mamba_inner_fn_cond(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight, self.dt_proj.weight,
                                   self.out_proj.weight, self.out_proj.bias, A, None, None, self.D.float(),
                                   delta_bias=self.dt_proj.bias.float(), delta_softplus=True, init_states=cond)
-        if self._is_zigzag():
+        if own_gather:
             out = out.index_select(1, self.zigzag_paths_reverse[self.layer_idx])
         return out
 

@@ -201,3 +201,32 @@ def test_fp16_product_gemm_policy():
     assert dev.abs().max().item() <= 2e-3 * ref.abs().max().item(), (dev.abs().max().item(), ref.abs().max().item())
     assert (dev.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item() <= 5e-4
     assert not torch.equal(got, ref)            # the policy really took another path
+
+
+@pytest.mark.gpu
+def test_zigzag_paths_folded_into_block_tables():
+    """scan_type zigma_8: the mixers' token gathers (mamba_simple.py:627-657) composed into the blocks' permutation tables
+    give bit-identical outputs to the mixers gathering by themselves (tokens only move; every per-token op is unchanged)."""
+    import os
+    import subprocess
+    import sys
+    code = ("import torch, sys; sys.path.insert(0, %r); sys.path.insert(0, %r); from dimsum_amd.models_dim import DiM; from procedural import procedural_fill; "
+            "kw = dict(img_resolution=32, in_channels=4, label_dropout=0.15, num_classes=1000, scan_type='zigma_8', pe_type='ape', block_type='combined', "
+            "cond_mamba=True, rms_norm=True, fused_add_norm=True, learnable_pe=True, use_attn_every_k_layers=4); "
+            "m = DiM(depth=4, hidden_size=64, patch_size=2, **kw).eval(); procedural_fill(m, seed=3); m = m.cuda(); "
+            "g = torch.Generator(device='cuda').manual_seed(0); x = torch.randn(3, 4, 32, 32, device='cuda', generator=g); "
+            "t = torch.rand(3, device='cuda', generator=g); y = torch.tensor([1, 2, 3], device='cuda'); "
+            "folded = [getattr(mm, '_zigzag_folded', False) for mm in m.modules() if hasattr(mm, 'zigzag_paths')]; "
+            "out = m(x, t, y).detach(); folded = [getattr(mm, '_zigzag_folded', False) for mm in m.modules() if hasattr(mm, 'zigzag_paths') and mm.zigzag_paths is not None]; "
+            "torch.save((out.cpu(), folded), sys.argv[1])")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for fold in ("1", "0"):
+        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"dimsum_zz_{fold}_{os.getpid()}.pt")
+        subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "tests", "golden")), path], check=True,
+                       env=dict(os.environ, DIMSUM_FOLD_ZIGZAG=fold))
+        res.append(torch.load(path))
+        os.remove(path)
+    (a, fa), (b, fb) = res
+    assert len(fa) > 0 and all(fa) and not any(fb)
+    assert torch.equal(a, b)
