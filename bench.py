@@ -1,24 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py -- DiM-L/2 (256 px: 4x32x32 latents, L = 256 tokens) denoiser-forward throughput on MI355X.
+"""bench.py -- the DiMSUM denoiser hot path on MI355X: every BASELINE.json config on one JSON line.
 
   python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A step = one forward of the denoiser hot path (every Mamba / frequency / fusion op through libdimsum_hip.so, GEMMs in
-hipBLASLt fp32) over one batch of 256 synthetic latents per GPU -- BASELINE.json configs[1]. The batch is resident in
-HBM before the timed region. Weak scaling: every rank owns a replica and its own batch, no data-path collective
-(the path shards by independent latents); timing is barrier + synchronize on both sides, max over ranks.
+Headline (`value`, configs[1]): DiM-L/2 (256 px: 4x32x32 latents, 256 tokens) denoiser-forward throughput. A step = one
+forward of the denoiser (every Mamba / frequency / fusion op through libdimsum_hip.so, GEMMs in hipBLASLt) over one batch
+of 256 synthetic latents per GPU, resident in HBM before the timed region. Weak scaling: every rank owns a replica and
+its own batch, no data-path collective (the path shards by independent latents); timing is barrier +
+synchronize on both sides, max over ranks.
 
-Extra objects on the JSON line:
-  roofline      selective-scan forward kernel (the path's dominant hand-written kernel): algorithmic bytes per launch
-                (SURVEY.md 8d formula) / its average launch duration measured live with HIP events on the launch
-                stream during the timed steps; peak = 8 TB/s HBM3E (MI355X_MICROARCH.md)
-  cpu_baseline  the same denoiser forward on the host cores through the CPU oracle ("port"), bounded sample
-`--mode sample` times 250-NFE fixed-step Euler flow-matching sampling instead (samples/s; one RCCL all-gather of the
-final latents per batch).
+Further legs on the same line (default `--mode all`; each is also a `--mode` of its own for profiling runs):
+  sample_250nfe  configs[3]: REAL 250-NFE fixed-step Euler flow-matching sampling of 128 latents per GPU, one RCCL
+                 all-gather of the final latents -- at every N (so the scaling runs exercise the collective)
+  block_fwdbwd   configs[2]: one DiMBlockCombined(1024) forward+backward at batch 256, with `roofline_bwd`   (N = 1)
+  xl512_zigzag   configs[4]: DiM-XL/2 at 512 px (1024 tokens), batch 64, 8-way zigzag scanning orders       (N = 1)
+  cpu_baseline   the same forward on the host cores through the CPU oracle ("port"): 1 warm-up + 3 runs, median (N = 1)
+Every `roofline*` object: algorithmic bytes per launch (SURVEY.md 8d formula) / average launch duration of the scan
+kernel measured live with HIP events on the launch stream during that leg's timed steps; the kernel name comes from the
+library's own dispatch (dimsum_ssm_scan_fwd_variant); `traffic` (HBM bytes from rocprofv3 --pmc, profiles/*.json) is
+attached only when the timed launches have exactly the profiled shape and kernel, otherwise null.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -29,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0
+WEIGHTS = "random-init weights (reference init, zero tensors re-drawn N(0, 0.02^2))"
 
 
 def usable_cores():
@@ -60,11 +66,15 @@ def scan_bwd_bytes(B, D, L, N, G=1, s=4):
 
 class ScanTimer:
     """HIP-event pairs around every selective-scan launch (recorded on torch's current stream = the launch stream).
-    The events bracket exactly one kernel launch: native.selective_scan_fwd/_bwd allocate (caching allocator, no
-    device work) and launch; the bwd's accumulator memsets are issued before the first event."""
+    The events bracket exactly one C-ABI call: native.selective_scan_fwd/_bwd allocate (caching allocator, no device
+    work) and launch; the bwd's accumulator memsets are issued before the first event. Every record keeps the launch
+    shape and the kernel the library's dispatch picks for it."""
 
     def __init__(self):
-        self.events, self.bytes, self.enabled = {"fwd": [], "bwd": []}, {"fwd": [], "bwd": []}, False
+        self.records, self.enabled = {"fwd": [], "bwd": []}, False
+
+    def reset(self):
+        self.records = {"fwd": [], "bwd": []}
 
     def install(self):
         from dimsum_amd import _lib
@@ -80,15 +90,19 @@ class ScanTimer:
             def _timed(self, which, fn, P, stream):
                 if not timer.enabled:
                     return fn(P, stream)
+                p = P.fwd if which == "bwd" else P
+                if which == "fwd":
+                    kernel = _lib.SCAN_FWD_KERNELS[lib.dimsum_ssm_scan_fwd_variant(p)] + (" (+ saved states)" if p.ckpt_ptr else "")
+                else:
+                    kernel = "ssm_scan_bwd_kernel (+ ssm_scan_bwd_reduce_kernel)"
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 rc = fn(P, stream)
                 e1.record()
-                p = P.fwd if which == "bwd" else P
                 f = scan_bwd_bytes if which == "bwd" else scan_bytes
                 s = {_lib.F32: 4}.get(p.dtype, 2)
-                timer.events[which].append((e0, e1))
-                timer.bytes[which].append(f(p.batch, p.dim, p.seqlen, p.dstate, p.n_groups, s))
+                shape = (p.batch, p.dim, p.seqlen, p.dstate)
+                timer.records[which].append((e0, e1, f(p.batch, p.dim, p.seqlen, p.dstate, p.n_groups, s), shape, kernel))
                 return rc
 
             def dimsum_ssm_scan_fwd(self, P, stream):
@@ -100,13 +114,27 @@ class ScanTimer:
         proxy = Timed()
         _lib.load = lambda: proxy
 
-    def summary(self, which="fwd"):
-        if not self.events[which]:
+    def roofline(self, which, pmc_json):
+        """roofline object of the dominant (shape, kernel) class among the timed launches of `which`, or None"""
+        recs = self.records[which]
+        if not recs:
             return None
-        ms = [a.elapsed_time(b) for a, b in self.events[which]]
-        avg_ms = sum(ms) / len(ms)
-        avg_bytes = sum(self.bytes[which]) / len(self.bytes[which])
-        return avg_ms, avg_bytes, len(ms)
+        classes = {}
+        for r in recs:
+            classes.setdefault((r[3], r[4]), []).append(r)
+        (shape, kernel), rs = max(classes.items(), key=lambda kv: len(kv[1]))
+        avg_ms = sum(a.elapsed_time(b) for a, b, *_ in rs) / len(rs)
+        nbytes = rs[0][2]
+        achieved = nbytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", pmc_json)        # HBM bytes per launch from rocprofv3 --pmc
+        if os.path.exists(prof):
+            j = json.load(open(prof))
+            if tuple(j.get("shape_BDLN", ())) == shape and j.get("bench_kernel") == kernel:
+                traffic = j.get("hbm_bytes_per_launch")
+        return {"kernel": kernel, "shape_BDLN": list(shape), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": avg_ms,
+                "launches_timed": len(rs)}
 
 
 def build_model(name, device, image_size=256, scan_type="none"):
@@ -132,9 +160,10 @@ def build_block(name, device):
     return blk.to(device).train(), hidden
 
 
-def cpu_baseline(name, latents=2, image_size=256):
-    """Bounded CPU sample of the same workload: one DiM forward of `latents` latents through the CPU oracle ("port" of
-    the reference's pure-PyTorch path: GEMMs in torch-CPU, scan/conv/norm in oracle/ssm_oracle.c with OpenMP)."""
+def cpu_baseline(name, latents=4, image_size=256, runs=3):
+    """Bounded CPU sample of the headline workload: DiM forwards of `latents` latents through the CPU oracle
+    ("port" of the reference's pure-PyTorch path: GEMMs in torch-CPU, scan / conv / norm in oracle/ssm_oracle.c with OpenMP),
+    1 warm-up + `runs` timed runs, median."""
     from oracle import c_ops
     from oracle.torch_backend import cpu_oracle_backend
     cores = usable_cores()
@@ -143,100 +172,87 @@ def cpu_baseline(name, latents=2, image_size=256):
     model = build_model(name, "cpu", image_size)
     r = image_size // 8
     x, t, y = torch.randn(latents, 4, r, r), torch.rand(latents), torch.randint(0, 1000, (latents,))
+    times = []
     with torch.no_grad(), cpu_oracle_backend():
-        model(x[:1], t[:1], y[:1])                   # warm-up (allocator, oracle build/load)
-        t0 = time.perf_counter()
-        model(x, t, y)
-        dt = time.perf_counter() - t0
-    return {"value": latents / dt, "unit": "latents/s", "cores": cores, "kind": "port",
-            "sample": f"1 forward of {name} on {latents} latents (fp32, torch-CPU GEMMs + OpenMP C oracle), {dt:.1f} s"}
+        model(x, t, y)                               # warm-up (allocator, oracle build/load, page-in of the weights)
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            model(x, t, y)
+            times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return {"value": latents / med, "unit": "latents/s", "cores": cores, "kind": "port",
+            "sample": f"{name} forward on {latents} latents (fp32, torch-CPU GEMMs + OpenMP C oracle): 1 warm-up + {runs} runs, "
+                      f"median {med:.2f} s (runs: {', '.join(f'{v:.2f}' for v in times)})"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--model", default="DiM-L/2")
-    ap.add_argument("--batch", type=int, default=256, help="latents per GPU per step")
-    ap.add_argument("--image-size", type=int, default=256)
-    ap.add_argument("--scan-type", default="none", help="none (published configs) | zigma_8 | sweep_8 | jpeg_8: zigzag token "
-                                                         "orders inside the mixers (BASELINE configs[4])")
-    ap.add_argument("--mode", choices=["fwd", "sample", "block", "train"], default="fwd",
-                    help="fwd: denoiser forward (headline, BASELINE configs[1]); sample: --nfe Euler steps + all-gather "
-                         "(configs[3]); block: ONE DiMBlockCombined forward+backward (configs[2]); train: one whole "
-                         "flow-matching training step (loss, backward, DDP all-reduce over RCCL, clip, AdamW, EMA)")
-    ap.add_argument("--nfe", type=int, default=250)
-    ap.add_argument("--hip-graph", action="store_true", help="fwd / sample: replay the denoiser forward from a captured hipGraph "
-                                                             "(dimsum_amd/hip_graph.py): for per-GPU batches below ~32, where eager is launch-bound")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the extra exact-fp32 timing (for profiling runs)")
-    ap.add_argument("--matmul", choices=["tf32", "fp32", "fp16"], default="tf32",
-                    help="library-GEMM policy. tf32 = the reference's own setting (torch.backends.cuda.matmul.allow_tf32 = "
-                         "True, dimsum/train.py:20-21, sample_ddp.py:56); on gfx950 hipBLASLt serves it with a split-bf16 "
-                         "MFMA path measured at 4e-6 rms relative error (real TF32: ~5e-4). fp32 = exact fp32 MFMA. "
-                         "fp16 = opt-in, inference only: fp16 operands (TF32's 10 mantissa bits, NOT its exponent range) with "
-                         "fp32 accumulation for the large Linears (dimsum_amd/gemm.py); never the headline.")
-    args = ap.parse_args()
+class Bench:
+    def __init__(self, args):
+        self.args = args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        assert self.world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={self.world}: launch with torch.distributed.run"
+        torch.cuda.set_device(self.local_rank)            # before the process group: every rank binds its own GPU
+        self.dev = torch.device("cuda", self.local_rank)
+        if self.world > 1:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", device_id=self.dev)          # RCCL on ROCm
+        torch.set_num_threads(max(1, usable_cores() // max(1, self.world)))
+        self.set_matmul(args.matmul)
+        from dimsum_amd import _lib
+        _lib.load()                                   # fail loudly if the HIP library is missing
+        self.timer = ScanTimer()
+        self.timer.install()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    torch.cuda.set_device(local_rank)            # before the process group: every rank binds its own GPU
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)          # RCCL on ROCm
-    torch.set_num_threads(max(1, usable_cores() // max(1, world)))
-
+    @staticmethod
     def set_matmul(policy):
         from dimsum_amd import gemm
         torch.backends.cuda.matmul.allow_tf32 = policy in ("tf32", "fp16")
         torch.backends.cudnn.allow_tf32 = policy in ("tf32", "fp16")
         gemm.set_policy("fp16" if policy == "fp16" else "default")
-    set_matmul(args.matmul)
 
-    from dimsum_amd import _lib
-    _lib.load()                                   # fail loudly if the HIP library is missing
-    r = args.image_size // 8
-    if args.mode == "block":
-        model, hidden = build_block(args.model, dev)
-    else:
-        model = build_model(args.model, dev, args.image_size, args.scan_type)
-    gen = torch.Generator(device=dev).manual_seed(0 * world + rank)      # sample_ddp.py:64 seeding rule
-    x = torch.randn(args.batch, 4, r, r, device=dev, generator=gen)
-    t = torch.rand(args.batch, device=dev, generator=gen)
-    y = torch.randint(0, 1000, (args.batch,), device=dev, generator=gen)
+    def fence(self):
+        if self.world > 1:
+            dist.barrier(device_ids=[self.local_rank])
+        torch.cuda.synchronize()
 
-    timer = ScanTimer()
-    timer.install()
+    def timed(self, step, steps, warmup):
+        """`warmup` untimed steps, then exactly `steps` steps between two fences; max over ranks. -> seconds"""
+        for _ in range(warmup):
+            step()
+        self.fence()
+        self.timer.reset()
+        self.timer.enabled = True
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.fence()
+        elapsed = time.perf_counter() - t0
+        self.timer.enabled = False
+        if self.world > 1:
+            tmax = torch.tensor([elapsed], device=self.dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = tmax.item()
+        return elapsed
 
-    if args.mode == "train":
-        from dimsum_amd.train import build_training, train_step
-        from dimsum_amd.transport import create_transport
-        ddp, ema, opt = build_training(model.train(), dev, 1e-4, world, [local_rank])
-        transport = create_transport("GVP", "velocity")
+    def inputs(self, batch, r):
+        gen = torch.Generator(device=self.dev).manual_seed(0 * self.world + self.rank)      # sample_ddp.py:64 seeding rule
+        x = torch.randn(batch, 4, r, r, device=self.dev, generator=gen)
+        t = torch.rand(batch, device=self.dev, generator=gen)
+        y = torch.randint(0, 1000, (batch,), device=self.dev, generator=gen)
+        return x, t, y, gen
 
-        def step():
-            return train_step(ddp, ema, opt, transport, x, y)
-        units_per_step = args.batch
-    elif args.mode == "block":
-        ntok = (r // 2) ** 2
-        hs = torch.randn(args.batch, ntok, hidden, device=dev, generator=gen).requires_grad_()
-        res = torch.randn(args.batch, ntok, hidden, device=dev, generator=gen).requires_grad_()
-        cond = torch.randn(args.batch, hidden, device=dev, generator=gen).requires_grad_()
-        dy = torch.randn(args.batch, ntok, hidden, device=dev, generator=gen)
+    def free(self):
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
 
-        def step():
-            for p_ in model.parameters():
-                p_.grad = None
-            hs.grad = res.grad = cond.grad = None
-            out, res_out = model(hs, res, cond)
-            torch.autograd.backward((out, res_out), (dy, dy))
-        units_per_step = args.batch
-    elif args.mode == "fwd":
-        if args.hip_graph:
+    # ---- legs -----------------------------------------------------------------------------------------------------------
+    def leg_fwd(self, model_name, image_size, batch, scan_type, steps, warmup, extra_precisions):
+        a, r = self.args, image_size // 8
+        model = build_model(model_name, self.dev, image_size, scan_type)
+        x, t, y, _ = self.inputs(batch, r)
+        if a.hip_graph:
             from dimsum_amd.hip_graph import GraphedForward
             graphed = GraphedForward(model)
 
@@ -246,114 +262,178 @@ def main():
             def step():
                 with torch.no_grad():
                     return model(x, t, y)
-        units_per_step = args.batch
-    else:
-        from dimsum_amd.sample_ddp import sample_batch
-        graphs = {} if args.hip_graph else None
+        elapsed = self.timed(step, steps, warmup)
+        out = {"workload": f"{model_name} denoiser forward, {image_size}px (4x{r}x{r} latents, {(r // 2) ** 2} tokens), {batch} latents per GPU, "
+                           + WEIGHTS + (f", scan_type={scan_type}" if scan_type != "none" else ""),
+               "value": batch * self.world * steps / elapsed, "unit": "latents/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
+               "warmup": warmup, "launch": "hipGraph replay" if a.hip_graph else "eager"}
+        rf = self.timer.roofline("fwd", "scan_fwd_pmc.json")
+        if rf is not None:
+            out["roofline"] = rf
+        if extra_precisions and self.world == 1 and a.matmul == "tf32" and not a.hip_graph:
+            # the same step with exact-fp32 library GEMMs, and with the opt-in fp16-operand policy (never the headline).
+            # (skipped under --hip-graph: a captured graph has the policy of its capture baked in)
+            self.set_matmul("fp32")
+            dt = self.timed(step, 2, 2) / 2
+            out["fp32_exact_matmul"] = {"value_per_gpu": batch / dt, "ms_per_step": 1e3 * dt}
+            ref = step()
+            self.set_matmul("fp16")
+            got = step()
+            dt = self.timed(step, 3, 1) / 3
+            out["fp16_operand_matmul_optin"] = {"value_per_gpu": batch / dt, "ms_per_step": 1e3 * dt,
+                                                "max_abs_dev_over_max_abs_vs_exact_fp32": ((got - ref).abs().max() / ref.abs().max()).item()}
+            self.set_matmul("tf32")
+        del model
+        self.free()
+        return out
+
+    def leg_block(self, model_name, image_size, batch, steps, warmup):
+        r = image_size // 8
+        model, hidden = build_block(model_name, self.dev)
+        _, _, _, gen = self.inputs(1, r)
+        ntok = (r // 2) ** 2
+        hs = torch.randn(batch, ntok, hidden, device=self.dev, generator=gen).requires_grad_()
+        res = torch.randn(batch, ntok, hidden, device=self.dev, generator=gen).requires_grad_()
+        cond = torch.randn(batch, hidden, device=self.dev, generator=gen).requires_grad_()
+        dy = torch.randn(batch, ntok, hidden, device=self.dev, generator=gen)
 
         def step():
-            return sample_batch(model, x, y, num_steps=args.nfe, world_size=world, hip_graph=graphs)
-        units_per_step = args.batch
+            for p_ in model.parameters():
+                p_.grad = None
+            hs.grad = res.grad = cond.grad = None
+            out, res_out = model(hs, res, cond)
+            torch.autograd.backward((out, res_out), (dy, dy))
+        elapsed = self.timed(step, steps, warmup)
+        out = {"workload": f"ONE DiMBlockCombined({hidden}) of {model_name} (scan + Haar + attention fusion + gated MLP) forward+backward, "
+                           f"{ntok} tokens, batch {batch}, " + WEIGHTS,
+               "value": batch * self.world * steps / elapsed, "unit": "latents/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup}
+        for key, which, pmc in (("roofline", "fwd", "scan_fwd_train_pmc.json"), ("roofline_bwd", "bwd", "scan_bwd_pmc.json")):
+            rf = self.timer.roofline(which, pmc)
+            if rf is not None:
+                out[key] = rf
+        del model, hs, res, cond, dy
+        self.free()
+        return out
 
-    def fence():
-        if world > 1:
-            dist.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize()
+    def leg_sample(self, model_name, image_size, batch, nfe):
+        """configs[3]: `nfe` Euler evaluations of dx/dt = model(x, t, y) on `batch` latents per GPU + ONE all-gather"""
+        from dimsum_amd.sample_ddp import sample_batch
+        a, r = self.args, image_size // 8
+        model = build_model(model_name, self.dev, image_size)
+        x, _, y, _ = self.inputs(batch, r)
+        graphs = {} if a.hip_graph else None
+        sample_batch(model, x[:8], y[:8], num_steps=2, world_size=1, gather=False)       # warm-up: allocator, GEMM heuristics
+        res = {}
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    timer.enabled = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    timer.enabled = False
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = tmax.item()
+        def step():
+            res["out"] = sample_batch(model, x, y, num_steps=nfe, world_size=self.world, hip_graph=graphs)
+        elapsed = self.timed(step, 1, 0)
+        out = {"workload": f"{model_name} {nfe}-NFE fixed-step Euler flow-matching sampling, {image_size}px, {batch} latents per GPU "
+                           f"(global batch {batch * self.world}), one all_gather_into_tensor of the final latents, " + WEIGHTS,
+               "value": batch * self.world / elapsed, "unit": "samples/s", "nfe": nfe, "s_per_batch": elapsed,
+               "ms_per_nfe": 1e3 * elapsed / nfe, "gathered_shape": list(res["out"].shape), "finite": bool(torch.isfinite(res["out"]).all().item()),
+               "launch": "hipGraph replay" if a.hip_graph else "eager"}
+        rf = self.timer.roofline("fwd", "scan_fwd_pmc.json")
+        if rf is not None:
+            out["roofline"] = rf
+        del model
+        self.free()
+        return out
+
+    def leg_train(self, model_name, image_size, batch, steps, warmup):
+        from dimsum_amd.train import build_training, train_step
+        from dimsum_amd.transport import create_transport
+        r = image_size // 8
+        model = build_model(model_name, self.dev, image_size)
+        x, _, y, _ = self.inputs(batch, r)
+        ddp, ema, opt = build_training(model.train(), self.dev, 1e-4, self.world, [self.local_rank])
+        transport = create_transport("GVP", "velocity")
+        elapsed = self.timed(lambda: train_step(ddp, ema, opt, transport, x, y), steps, warmup)
+        out = {"workload": f"{model_name} flow-matching training step (GVP velocity loss, backward, grad all-reduce, clip, AdamW, EMA), "
+                           f"{batch} latents per GPU, " + WEIGHTS,
+               "value": batch * self.world * steps / elapsed, "unit": "latents/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup}
+        rb = self.timer.roofline("bwd", "scan_bwd_pmc.json")
+        if rb is not None:
+            out["roofline_bwd"] = rb
+        return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--model", default="DiM-L/2")
+    ap.add_argument("--batch", type=int, default=256, help="latents per GPU per step (headline / single-mode runs)")
+    ap.add_argument("--image-size", type=int, default=256)
+    ap.add_argument("--scan-type", default="none", help="none (published configs) | zigma_8 | sweep_8 | jpeg_8: zigzag token "
+                                                         "orders inside the mixers (BASELINE configs[4])")
+    ap.add_argument("--mode", choices=["all", "fwd", "sample", "block", "train", "xl512"], default="all",
+                    help="all (default): headline forward (configs[1]) + every other BASELINE config as an extra leg; fwd / "
+                         "sample / block / xl512 / train: that leg alone on the headline keys (profiling runs)")
+    ap.add_argument("--nfe", type=int, default=250)
+    ap.add_argument("--sample-batch", type=int, default=128, help="latents per GPU of the sampling leg (configs[3]: 1024 over 8 GPUs)")
+    ap.add_argument("--hip-graph", action="store_true", help="fwd / sample: replay the denoiser forward from a captured hipGraph "
+                                                             "(dimsum_amd/hip_graph.py): for per-GPU batches below ~32, where eager is launch-bound")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the extra exact-fp32 / fp16-operand timings (for profiling runs)")
+    ap.add_argument("--matmul", choices=["tf32", "fp32", "fp16"], default="tf32",
+                    help="library-GEMM policy. tf32 = the reference's own setting (torch.backends.cuda.matmul.allow_tf32 = "
+                         "True, dimsum/train.py:20-21, sample_ddp.py:56); on gfx950 hipBLASLt serves it with a split-bf16 "
+                         "MFMA path measured at 4e-6 rms relative error (real TF32: ~5e-4). fp32 = exact fp32 MFMA. "
+                         "fp16 = opt-in, inference only: fp16 operands (TF32's 10 mantissa bits, NOT its exponent range) with "
+                         "fp32 accumulation for the large Linears (dimsum_amd/gemm.py); never the headline.")
+    args = ap.parse_args()
+    b = Bench(args)
+    world, rank = b.world, b.rank
+    policy = {"tf32": "allow_tf32=True like the reference (train.py:20-21); gfx950 split-bf16 path, 4e-6 rms rel err",
+              "fp32": "exact fp32",
+              "fp16": "OPT-IN: fp16 operands (TF32 mantissa, fp16 exponent range) + fp32 accumulation for the large Linears, split-bf16 elsewhere"}[args.matmul]
+
+    extras = {}
+    if args.mode in ("all", "fwd"):
+        head = b.leg_fwd(args.model, args.image_size, args.batch, args.scan_type, args.steps, args.warmup, extra_precisions=not args.no_fp32_leg)
+        metric = "denoiser-fwd latents/sec"
+    elif args.mode == "xl512":
+        head = b.leg_fwd("DiM-XL/2", 512, 64 if args.batch == 256 else args.batch, "zigma_8" if args.scan_type == "none" else args.scan_type,
+                         args.steps, args.warmup, extra_precisions=False)
+        metric = "denoiser-fwd latents/sec (DiM-XL/2 512px, 8-way zigzag)"
+    elif args.mode == "block":
+        head = b.leg_block(args.model, args.image_size, args.batch, args.steps, args.warmup)
+        metric = "block fwd+bwd latents/sec"
+    elif args.mode == "train":
+        head = b.leg_train(args.model, args.image_size, args.batch, args.steps, args.warmup)
+        metric = "training latents/sec"
+    else:
+        head = b.leg_sample(args.model, args.image_size, args.batch if args.batch != 256 else args.sample_batch, args.nfe)
+        head.update(steps=1, warmup=0, ms_per_step=1e3 * head["s_per_batch"])
+        metric = f"{args.nfe}-NFE samples/sec"
+    if args.mode == "all":
+        # configs[3] at every N: the scaling runs then exercise the sampler and its one RCCL collective
+        extras["sample_250nfe"] = b.leg_sample(args.model, args.image_size, args.sample_batch, args.nfe)
+        if world == 1:
+            extras["block_fwdbwd"] = b.leg_block(args.model, args.image_size, 256, 5, 2)                      # configs[2]
+            extras["xl512_zigzag"] = b.leg_fwd("DiM-XL/2", 512, 64, "zigma_8", 5, 2, extra_precisions=False)   # configs[4]
 
     if rank == 0:
-        value = units_per_step * world * args.steps / elapsed
-        fwd_mode = args.mode == "fwd"
-        what = {"fwd": "denoiser forward", "sample": f"denoiser {args.nfe}-NFE Euler sampling",
-                "block": "ONE DiMBlockCombined (scan + Haar + attention fusion + gated MLP) forward+backward",
-                "train": "flow-matching training step (GVP velocity loss, backward, grad all-reduce, clip, AdamW, EMA)"}[args.mode]
-        line = {
-            "metric": {"fwd": "denoiser-fwd latents/sec", "sample": f"{args.nfe}-NFE samples/sec",
-                       "block": "block fwd+bwd latents/sec", "train": "training latents/sec"}[args.mode],
-            "value": value, "unit": "samples/s" if args.mode == "sample" else "latents/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.model} {what}, "
-                                   f"{args.image_size}px (4x{r}x{r} latents, {(r // 2) ** 2} tokens), {args.batch} latents per GPU, "
-                                   "random-init weights (reference init, zero tensors re-drawn N(0, 0.02^2))"
-                                   + (f", scan_type={args.scan_type}" if args.scan_type != "none" else ""),
-                       "global_batch": args.batch * world, "parallelism": f"dp{world} (replicas, independent latents)",
-                       "launch": "hipGraph replay" if args.hip_graph else "eager",
-                       "matmul_policy": {"tf32": "allow_tf32=True like the reference (train.py:20-21); gfx950 split-bf16 path, 4e-6 rms rel err",
-                                         "fp32": "exact fp32",
-                                         "fp16": "OPT-IN: fp16 operands (TF32 mantissa, fp16 exponent range) + fp32 accumulation for the large "
-                                                 "Linears, split-bf16 elsewhere"}[args.matmul]},
-        }
-        if fwd_mode:
-            line["samples_per_sec_at_250_nfe"] = value / 250.0
-
-        def roof(which, kernel, pmc):
-            s = timer.summary(which)
-            if s is None:
-                return None
-            avg_ms, avg_bytes, n = s
-            achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
-            traffic = None
-            prof = os.path.join(ROOT, "profiles", pmc)    # HBM bytes per launch from rocprofv3 --pmc
-            if os.path.exists(prof):
-                traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
-            return {"kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "algorithmic_bytes_per_launch": avg_bytes,
-                    "avg_launch_ms": avg_ms, "launches_timed": n}
-
-        rf = roof("fwd", "ssm_scan_fwd_kernel<float,16>", "scan_fwd_pmc.json")
-        if rf is not None:
-            line["roofline"] = rf
-        rb = roof("bwd", "ssm_scan_bwd_kernel<float,16>", "scan_bwd_pmc.json")
-        if rb is not None:
-            line["roofline_bwd"] = rb
-        if world == 1 and args.matmul == "tf32" and args.mode in ("fwd", "block") and not args.no_fp32_leg:
-            # the same step with exact-fp32 library GEMMs, for reference (2 untimed + 2 timed steps)
-            set_matmul("fp32")
-            timer.enabled = False
-            for _ in range(2):
-                step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(2):
-                step()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t1) / 2
-            line["fp32_exact_matmul"] = {"value_per_gpu": units_per_step / dt, "ms_per_step": 1e3 * dt}
-            if args.mode == "fwd":
-                # opt-in fp16-operand policy of dimsum_amd/gemm.py, for reference only (never the headline)
-                ref = step()
-                set_matmul("fp16")
-                for _ in range(2):
-                    got = step()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(3):
-                    step()
-                torch.cuda.synchronize()
-                dt = (time.perf_counter() - t1) / 3
-                line["fp16_operand_matmul_optin"] = {"value_per_gpu": units_per_step / dt, "ms_per_step": 1e3 * dt,
-                                                     "max_abs_dev_over_max_abs_vs_exact_fp32": ((got - ref).abs().max() / ref.abs().max()).item()}
-            set_matmul("tf32")
-        if world == 1 and not args.no_cpu_baseline and args.mode in ("fwd", "sample"):
-            line["cpu_baseline"] = cpu_baseline(args.model, 8, args.image_size)
+        line = {"metric": metric, "value": head["value"], "unit": head["unit"], "n_gpus": world, "steps": head["steps"], "warmup": head["warmup"],
+                "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                "data": "synthetic",
+                "config": {"workload": head["workload"], "global_batch": (args.batch if args.mode != "sample" else args.sample_batch) * world,
+                           "parallelism": f"dp{world} (replicas, independent latents)", "launch": head.get("launch", "eager"), "matmul_policy": policy},
+                "dist": {"world_size": dist.get_world_size() if world > 1 else 1,
+                         "backend": (dist.get_backend() + " (RCCL)") if world > 1 else "none (single process)"}}
+        for k in ("roofline", "roofline_bwd", "fp32_exact_matmul", "fp16_operand_matmul_optin", "nfe", "s_per_batch", "gathered_shape", "finite"):
+            if k in head:
+                line[k] = head[k]
+        if "sample_250nfe" in extras:
+            line["samples_per_sec_250nfe_measured"] = extras["sample_250nfe"]["value"]
+        line.update(extras)
+        if world == 1 and not args.no_cpu_baseline and args.mode in ("all", "fwd", "sample"):
+            line["cpu_baseline"] = cpu_baseline(args.model, 4, args.image_size)
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.barrier(device_ids=[local_rank])     # nobody tears the communicator down while rank 0 is still reporting
+        dist.barrier(device_ids=[b.local_rank])     # nobody tears the communicator down while rank 0 is still reporting
         dist.destroy_process_group()
 
 

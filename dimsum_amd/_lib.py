@@ -85,7 +85,8 @@ class XattnBwdParams(C.Structure):
 # every symbol include/dimsum_hip.h declares (tests check the library exports all of them)
 EXPORTS = (
     "dimsum_status_string", "dimsum_abi_version", "dimsum_target_arch",
-    "dimsum_ssm_scan_fwd", "dimsum_ssm_scan_bwd", "dimsum_ssm_scan_bwd_workspace_bytes", "dimsum_causal_conv1d_fwd", "dimsum_causal_conv1d_bwd",
+    "dimsum_ssm_scan_fwd", "dimsum_ssm_scan_bwd", "dimsum_ssm_scan_bwd_workspace_bytes", "dimsum_ssm_scan_fwd_variant",
+    "dimsum_ssm_scan_fwd_force_variant", "dimsum_causal_conv1d_fwd", "dimsum_causal_conv1d_bwd",
     "dimsum_norm_fwd", "dimsum_norm_bwd", "dimsum_token_transform", "dimsum_xattn_fusion_fwd", "dimsum_xattn_fusion_bwd",
     "dimsum_gated_gelu_fwd", "dimsum_gated_gelu_bwd",
 )
@@ -123,10 +124,19 @@ def load():
     if hasattr(lib, "dimsum_ssm_scan_bwd_workspace_bytes"):
         lib.dimsum_ssm_scan_bwd_workspace_bytes.restype = i64
         lib.dimsum_ssm_scan_bwd_workspace_bytes.argtypes = [i32] * 5
-    if lib.dimsum_abi_version() != 7:
+    if hasattr(lib, "dimsum_ssm_scan_fwd_variant"):
+        lib.dimsum_ssm_scan_fwd_variant.restype = C.c_int
+        lib.dimsum_ssm_scan_fwd_variant.argtypes = [C.POINTER(SsmParams)]
+        lib.dimsum_ssm_scan_fwd_force_variant.restype = None
+        lib.dimsum_ssm_scan_fwd_force_variant.argtypes = [C.c_int]
+    if lib.dimsum_abi_version() != 8:
         raise RuntimeError("dimsum_amd: libdimsum_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib
+
+
+SCAN_FWD_KERNELS = {0: "ssm_scan_fwd_kernel", 2: "ssm_scan_fwd_split_kernel<2 lanes per channel>",
+                    4: "ssm_scan_fwd_split_kernel<4 lanes per channel>"}      # dimsum_ssm_scan_fwd_variant() -> kernel
 
 
 def check(status, what):

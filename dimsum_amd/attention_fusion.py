@@ -2,12 +2,15 @@
 (x12 = softmax(q1 k2^T / sqrt(hd)) v2, x21 = softmax(q2 k1^T / sqrt(hd)) v1), concat, proj.
 The attention core (both directions, straight from the bias-free qkv GEMM outputs to the concatenated proj input) is one
 HIP kernel with MFMA QK^T / PV (csrc/xattn_fusion.hip); its backward is two more (csrc/xattn_fusion_bwd.hip). Variants
-the published configs never enable (qk_norm, swap_k, attention dropout) run on torch SDPA on the GPU."""
+the published configs never enable (qk_norm, swap_k, attention dropout) run on torch SDPA on the GPU -- announced once and
+counted (dimsum_amd.utils.note_torch_path); the plain variant on a shape without a HIP kernel is an error unless
+DIMSUM_ALLOW_TORCH_SDPA=1."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import gemm, native
+from .utils import note_torch_path
 
 
 class _XattnCoreFn(torch.autograd.Function):
@@ -73,6 +76,12 @@ class CrossAttentionFusion(nn.Module):
                 raise RuntimeError("CrossAttentionFusion: qkv1 / qkv2 must both have a bias or none")
             fused = _XattnCoreFn.apply(gemm.linear(x1, self.qkv1.weight), gemm.linear(x2, self.qkv2.weight), b1, b2, self.num_heads)
         else:
+            if not x1.is_cuda:
+                pass        # only reachable with the CPU oracle backend of the tests installed (every other op raises on CPU)
+            elif self._plain and drop == 0.0:
+                note_torch_path(f"CrossAttentionFusion core for head_dim {self.head_dim} / {x1.dtype}", required_opt_in=True)
+            else:
+                note_torch_path("CrossAttentionFusion variant (qk_norm / swap_k / attention dropout: unused by the published configs)")
             qkv1, qkv2 = self.qkv1(x1), self.qkv2(x2)
             q1, k1, v1 = self._split(qkv1, B, N)
             q2, k2, v2 = self._split(qkv2, B, N)

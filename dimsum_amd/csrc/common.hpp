@@ -5,6 +5,8 @@
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 
+#include <initializer_list>
+
 #include "../../include/dimsum_hip.h"
 
 namespace dimsum {
@@ -95,5 +97,14 @@ __device__ __forceinline__ float softplus_if(float x, bool flag) {
 inline int launch_status() { return hipGetLastError() == hipSuccess ? DIMSUM_OK : DIMSUM_ERR_LAUNCH; }
 
 template <typename T> inline bool aligned_to(const void *p, size_t bytes) { return (reinterpret_cast<uintptr_t>(p) % bytes) == 0; }
+
+// The kernels address inside a tile with ONE 32-bit byte offset per lane (base in SGPRs + voffset). A tile spans `rows`
+// rows of `row_stride` elements plus `seqlen` along the row: every such offset must stay below 2^32 bytes (and below
+// 2^31 elements: the row * stride products are formed in int). Negative strides are not supported.
+template <typename T> inline bool offsets_fit_32bit(int64_t seqlen, int64_t rows, std::initializer_list<int64_t> row_strides) {
+    for (int64_t rs : row_strides)
+        if (rs < 0 || (rows * rs + seqlen) * (int64_t)sizeof(T) >= ((int64_t)1 << 32) || rows * rs + seqlen >= ((int64_t)1 << 31)) return false;
+    return true;
+}
 
 }  // namespace dimsum

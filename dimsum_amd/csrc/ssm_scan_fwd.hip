@@ -16,25 +16,35 @@ int ssm_check(const dimsum_ssm_params_t *p, bool forward) {
     return DIMSUM_OK;
 }
 
-// Which forward kernel serves a shape. DIMSUM_SCAN_SPLIT=0/1 forces one (experiments).
-static int g_force_split = -1;      // -1: automatic; 0 / 1: forced (tests, experiments)
+// Which forward kernel serves a shape: 0 = lane = channel (64 channels per wave), 2 / 4 = lanes per channel of the
+// state-split kernel (32 / 16 channels per wave). dimsum_ssm_scan_fwd_force_variant() overrides the choice (tests, tuning).
+static int g_force_variant = -1;
 
-bool ssm_scan_fwd_use_split(const dimsum_ssm_params_t &p) {
-    static const char *env = getenv("DIMSUM_SCAN_SPLIT");
-    if (g_force_split == 0 || g_force_split == 1) return g_force_split == 1 && p.dstate % 4 == 0;
-    if (env && (env[0] == '0' || env[0] == '1')) return env[0] == '1';
-    // The 64-channel kernel keeps 8 waves per CU resident (2048 on the chip). A launch that does not even fill those slots
-    // once is latency-bound per wave: the split kernel gives it twice the waves, each with half the sequential work
-    // (measured: (64, 1152, 1024) 534 -> 475 us, (16, 1152, 4096) 1225 -> 785 us; (256, 1024, 256) equal).
+static bool variant_ok(const dimsum_ssm_params_t &p, int v) {
+    return v == 0 || (v == 2 && p.dstate % 4 == 0) || (v == 4 && p.dstate % 8 == 0);
+}
+
+int ssm_scan_fwd_variant(const dimsum_ssm_params_t &p) {
+    if (g_force_variant >= 0) return variant_ok(p, g_force_variant) ? g_force_variant : 0;
+    // The 64-channel kernel keeps 8 waves per CU resident (2048 on the chip) and is HBM-bound when they are all there.
+    // A launch that does not fill those slots is latency-bound per wave: splitting the states over 2 or 4 lanes gives it
+    // 2x / 4x the waves, each with 1/2 / 1/4 of the sequential work per step. Measured (fp32, dstate 16):
+    //   (256, 1024, 256): 64-channel 0.33 ms, kSP = 2 equal;   (64, 1152, 1024): 0.534 / 0.475 / see DESIGN.md section 3.1
     const int64_t dpg = p.dim / p.n_groups;
     const int64_t waves = (int64_t)p.batch * p.n_groups * ((dpg + kWave - 1) / kWave);
-    return p.dstate % 4 == 0 && waves < 2048;
+    if (waves >= 2048) return 0;
+    if (variant_ok(p, 4)) return 4;
+    return variant_ok(p, 2) ? 2 : 0;
 }
 
 }  // namespace dimsum
 
-// diagnostics (not part of the public header): force one of the two forward kernels (-1 = automatic choice)
-extern "C" void dimsum_debug_scan_fwd_force_split(int mode) { dimsum::g_force_split = mode; }
+extern "C" int dimsum_ssm_scan_fwd_variant(const dimsum_ssm_params_t *p) {
+    if (!p || p->n_groups <= 0) return -1;
+    return dimsum::ssm_scan_fwd_variant(*p);
+}
+
+extern "C" void dimsum_ssm_scan_fwd_force_variant(int variant) { dimsum::g_force_variant = variant; }
 
 extern "C" int dimsum_ssm_scan_fwd(const dimsum_ssm_params_t *p, void *stream) {
     using namespace dimsum;

@@ -12,15 +12,15 @@
 //   * lane = channel. One wave64 owns 64 channels of ONE batch element and walks the sequence sequentially with the
 //     dstate states of its channel in registers: 5 VALU ops per (t, n) -- the minimum -- instead of the ~3x of a
 //     cross-lane parallel scan, and no cross-lane traffic at all.
-//   * B_t[n], C_t[n] depend on (batch, group, n, t) only, i.e. they are WAVE-UNIFORM here: they are fetched with scalar
-//     loads (s_load_dwordx4 = 4 time steps of one state) into SGPRs and used as the scalar operand of the FMAs.
-//     The reference re-reads the 32 KB (N,L) B/C tile per channel through L2; here it costs no vector memory
-//     traffic and no VGPRs.
+//   * B_t[n], C_t[n] depend on (batch, group, n, t) only, i.e. they are WAVE-UNIFORM here: staged once per wave and tile
+//     in LDS as [n][t] and read back as broadcast ds_read_b128 (4 time steps of one state per read), software-pipelined
+//     two states ahead of the FMAs. The reference re-reads the 32 KB (N, L) B/C tile per channel through L2.
+//     (Scalar loads were tried: out-of-order SMEM return forces lgkmcnt(0) after every pair -- 0.70 ms, rejected.)
 //   * u, delta are streamed HBM -> registers (coalesced 16 B/lane along L: a 64x32 fp32 tile is 64 full 128-B
-//     lines) -> LDS transposing tile (row stride 36 dwords: conflict-free ds_write_b128 in load layout and
-//     ds_read_b128 in lane=channel layout). The next tile's global loads are issued before the current tile is
-//     computed, so they fly under ~4k cycles of VALU work (register-staged double buffering; LDS single-buffered:
-//     18 KB per wave -> 8 waves per CU).
+//     lines) -> LDS transposing tile whose 16-byte slots are XOR-swizzled per row (no padding): conflict-free both as
+//     ds_write_b128 in the load layout and as ds_read_b128 in the lane = channel layout. The next tile's global loads are
+//     issued before the current tile is computed, so they fly under its ~7k cycles of VALU work (register-staged double
+//     buffering; LDS single-buffered: 2 x 8 KB + 2 x 2 KB of B/C = 20 KB per wave -> 8 waves per CU).
 //   * out is written back into the u tile in place, re-read in the coalesced layout, gated with silu(z) there
 //     (z never goes through LDS) and stored with 16 B/lane.
 //   * blockIdx -> tile map keeps the 16 waves of one batch element on one XCD so B/C are fetched into one L2 only.
@@ -104,15 +104,6 @@ template <typename T> __device__ __forceinline__ T *at(T *base, unsigned elem_of
     return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + (unsigned)(elem_off * (unsigned)sizeof(T)));
 }
 
-// timing experiments (tools/scratch): DIMSUM_SCAN_X_NOMEM drops the tile loads / stores, DIMSUM_SCAN_X_NOCOMP the recurrence
-#ifdef DIMSUM_SCAN_X_NOMEM
-#define FXLD(T, ptr) (Raw4<T>{})
-#define FXST_ON (L < 0)
-#else
-#define FXLD(T, ptr) ld4<T>(ptr)
-#define FXST_ON true
-#endif
-
 // kVec : every row base is 4-element aligned and L % 4 == 0 -> 16-byte (fp32) vector I/O, register-staged prefetch.
 // kFull: dim/n_groups % 64 == 0 -> all 64 lanes own a live channel, no row masks anywhere (needs kVec).
 template <typename T, int kN, bool kHasZ, bool kVec, bool kFull, bool kCkpt = false>
@@ -187,8 +178,8 @@ __global__ __launch_bounds__(kWave, DIMSUM_SCAN_WAVES) void ssm_scan_fwd_kernel(
         const int col = col_of(t0);
 #pragma unroll
         for (int i = 0; i < kNP; ++i) {
-            ru[i] = FXLD(T, piece(u_base, u_ds, i, col));
-            rd[i] = FXLD(T, piece(dl_base, dl_ds, i, col));
+            ru[i] = ld4<T>(piece(u_base, u_ds, i, col));
+            rd[i] = ld4<T>(piece(dl_base, dl_ds, i, col));
         }
 #pragma unroll
         for (int i = 0; i < kBCPieces; ++i) {
@@ -223,7 +214,7 @@ __global__ __launch_bounds__(kWave, DIMSUM_SCAN_WAVES) void ssm_scan_fwd_kernel(
             if constexpr (kHasZ) {
                 const int col = col_of(t0);
 #pragma unroll
-                for (int i = 0; i < kNP; ++i) rz[i] = FXLD(T, piece(z_base, z_ds, i, col));
+                for (int i = 0; i < kNP; ++i) rz[i] = ld4<T>(piece(z_base, z_ds, i, col));
             }
         } else {
             // generic path (unaligned rows or L % 4 != 0): element-wise, still coalesced along L
@@ -279,20 +270,10 @@ __global__ __launch_bounds__(kWave, DIMSUM_SCAN_WAVES) void ssm_scan_fwd_kernel(
 #pragma unroll
             for (int s = 0; s < 4; ++s) { du[s] = dt[s] * u4.v[s]; y[s] = Dval * u4.v[s]; }
             __builtin_amdgcn_sched_barrier(0);   // region below = exactly 2*(kN-kPD) ds_read + 20*kN VALU
-#ifdef DIMSUM_SCAN_X_NOCOMP
-#pragma unroll
-            for (int n = 0; n < 1; ++n) {
-#else
 #pragma unroll
             for (int n = 0; n < kN; ++n) {
-#endif
-#ifdef DIMSUM_SCAN_X_NOBC       // timing experiment: no broadcast LDS reads in the inner block
-                const f32x4 bq = u4, cq = d4;
-                if (false) {
-#else
                 const f32x4 bq = bq_pipe[n % kPD], cq = cq_pipe[n % kPD];
                 if (n + kPD < kN) {
-#endif
                     bq_pipe[n % kPD] = *reinterpret_cast<const f32x4 *>(&tileB[(n + kPD) * kTC + j * 4]);
                     cq_pipe[n % kPD] = *reinterpret_cast<const f32x4 *>(&tileC[(n + kPD) * kTC + j * 4]);
                 }
@@ -331,12 +312,12 @@ __global__ __launch_bounds__(kWave, DIMSUM_SCAN_WAVES) void ssm_scan_fwd_kernel(
                     const int row = i * kRPP + lrow;
                     if (kFull || row < nd) {
                         f32x4 y4 = *reinterpret_cast<const f32x4 *>(&tileU[tile_off(row, lc4)]);
-                        if (FXST_ON && has_out) st4<T>(at(out_base + i * kRPP * out_ds, (unsigned)(lrow * out_ds + t0 + lcol)), y4);
+                        if (has_out) st4<T>(at(out_base + i * kRPP * out_ds, (unsigned)(lrow * out_ds + t0 + lcol)), y4);
                         if constexpr (kHasZ) {
                             const f32x4 z4 = widen(rz[i]);
 #pragma unroll
                             for (int s = 0; s < 4; ++s) y4.v[s] *= z4.v[s] * sigmoidf_fast(z4.v[s]);
-                            if (FXST_ON) st4<T>(at(oz_base + i * kRPP * oz_ds, (unsigned)(lrow * oz_ds + t0 + lcol)), y4);
+                            st4<T>(at(oz_base + i * kRPP * oz_ds, (unsigned)(lrow * oz_ds + t0 + lcol)), y4);
                         }
                     }
                 }
@@ -363,13 +344,13 @@ __global__ __launch_bounds__(kWave, DIMSUM_SCAN_WAVES) void ssm_scan_fwd_kernel(
 
 namespace dimsum {
 
-bool ssm_scan_fwd_use_split(const dimsum_ssm_params_t &p);   // ssm_scan_fwd.hip
+int ssm_scan_fwd_variant(const dimsum_ssm_params_t &p);   // ssm_scan_fwd.hip: 0 = 64 channels per wave, 2 / 4 = lanes per channel
 
 template <typename T, int kN>
 static int launch_fwd(const dimsum_ssm_params_t &p, hipStream_t stream) {
     const int dpg = p.dim / p.n_groups;
-    const bool split = ssm_scan_fwd_use_split(p);
-    const int cpw = split ? 32 : kWave;                    // channels per wave
+    const int sp = ssm_scan_fwd_variant(p);                // 0, 2 or 4
+    const int cpw = sp == 0 ? kWave : kWave / sp;          // channels per wave
     const int tiles = p.batch * p.n_groups * ((dpg + cpw - 1) / cpw);
     const size_t va = 4 * sizeof(T);  // vector path: every row base 4-element aligned
     bool vec = (p.seqlen % 4 == 0) && aligned_to<T>(p.u_ptr, va) && aligned_to<T>(p.delta_ptr, va) &&
@@ -382,21 +363,27 @@ static int launch_fwd(const dimsum_ssm_params_t &p, hipStream_t stream) {
         vec = vec && aligned_to<T>(p.z_ptr, va) && aligned_to<T>(p.out_z_ptr, va) && (p.z_batch_stride % 4 == 0) &&
               (p.z_d_stride % 4 == 0) && (p.out_z_batch_stride % 4 == 0) && (p.out_z_d_stride % 4 == 0);
     if (p.x_ptr && !aligned_to<float>(p.x_ptr, 16)) return DIMSUM_ERR_STRIDE;
-    // 32-bit in-tile offsets
-    const int64_t lim = (int64_t)1 << 31;
-    if (64 * p.u_d_stride + p.seqlen >= lim || 64 * p.delta_d_stride + p.seqlen >= lim || 64 * p.out_d_stride + p.seqlen >= lim ||
-        64 * p.z_d_stride + p.seqlen >= lim || 64 * p.out_z_d_stride + p.seqlen >= lim ||
-        (int64_t)p.dstate * p.B_dstate_stride + p.seqlen >= lim || (int64_t)p.dstate * p.C_dstate_stride + p.seqlen >= lim)
+    // In-tile offsets are 32-bit BYTE offsets (saddr + voffset addressing): the farthest element of a tile is
+    // (channels_per_wave - 1) * d_stride + seqlen elements from the tile base.
+    if (!offsets_fit_32bit<T>(p.seqlen, kWave, {p.u_d_stride, p.delta_d_stride, p.out_ptr ? p.out_d_stride : 0, p.z_ptr ? p.z_d_stride : 0,
+                                                p.z_ptr ? p.out_z_d_stride : 0}) ||
+        !offsets_fit_32bit<T>(p.seqlen, p.dstate, {p.B_dstate_stride, p.C_dstate_stride}))
         return DIMSUM_ERR_STRIDE;
     const bool full = vec && (dpg % cpw == 0);
     dim3 grid(tiles), block(kWave);
-#define DIMSUM_LAUNCH(HASZ, VEC, FULL)                                                                                   \
-    do {                                                                                                                  \
-        if (split) {                                                                                                      \
-            if (p.ckpt_ptr) hipLaunchKernelGGL((ssm_scan_fwd_split_kernel<T, kN, HASZ, VEC, FULL, true>), grid, block, 0, stream, p);  \
-            else hipLaunchKernelGGL((ssm_scan_fwd_split_kernel<T, kN, HASZ, VEC, FULL, false>), grid, block, 0, stream, p);            \
-        } else if (p.ckpt_ptr) hipLaunchKernelGGL((ssm_scan_fwd_kernel<T, kN, HASZ, VEC, FULL, true>), grid, block, 0, stream, p);  \
-        else hipLaunchKernelGGL((ssm_scan_fwd_kernel<T, kN, HASZ, VEC, FULL, false>), grid, block, 0, stream, p);            \
+#define DIMSUM_LAUNCH_V(KERNEL, ...)                                                                       \
+    do {                                                                                                    \
+        if (p.ckpt_ptr) hipLaunchKernelGGL((KERNEL<T, kN, __VA_ARGS__, true>), grid, block, 0, stream, p);  \
+        else hipLaunchKernelGGL((KERNEL<T, kN, __VA_ARGS__, false>), grid, block, 0, stream, p);            \
+    } while (0)
+#define DIMSUM_LAUNCH(HASZ, VEC, FULL)                                                                      \
+    do {                                                                                                    \
+        if (sp == 4) {                                                                                      \
+            if constexpr (kN % 8 == 0) DIMSUM_LAUNCH_V(ssm_scan_fwd_split_kernel, 4, HASZ, VEC, FULL);      \
+        } else if (sp == 2) {                                                                               \
+            if constexpr (kN % 4 == 0) DIMSUM_LAUNCH_V(ssm_scan_fwd_split_kernel, 2, HASZ, VEC, FULL);      \
+        } else                                                                                              \
+            DIMSUM_LAUNCH_V(ssm_scan_fwd_kernel, HASZ, VEC, FULL);                                          \
     } while (0)
     if (p.z_ptr) {
         if (full) DIMSUM_LAUNCH(true, true, true);
@@ -408,17 +395,16 @@ static int launch_fwd(const dimsum_ssm_params_t &p, hipStream_t stream) {
         else DIMSUM_LAUNCH(false, false, false);
     }
 #undef DIMSUM_LAUNCH
+#undef DIMSUM_LAUNCH_V
     return launch_status();
 }
 
 template <typename T>
 int ssm_scan_fwd_dispatch(const dimsum_ssm_params_t &p, hipStream_t stream) {
     switch (p.dstate) {
-#ifndef DIMSUM_DEV_ONE      // development builds instantiate the headline variant only
         case 4: return launch_fwd<T, 4>(p, stream);
         case 8: return launch_fwd<T, 8>(p, stream);
         case 32: return launch_fwd<T, 32>(p, stream);
-#endif
         case 16: return launch_fwd<T, 16>(p, stream);
         default: return DIMSUM_ERR_SHAPE;
     }

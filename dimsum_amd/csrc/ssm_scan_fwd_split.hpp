@@ -1,20 +1,24 @@
-// ssm_scan_fwd_split.hpp -- selective scan forward, state-split variant: lane = (channel, state half).
+// ssm_scan_fwd_split.hpp -- selective scan forward, state-split variants: lane = (channel, state part), kSP parts.
 //
 // Same math and interface as ssm_scan_fwd_kernel (ssm_scan_fwd_kernel.hpp; reference selective_scan_fwd_kernel.cuh:67-303).
-// One wave64 owns 32 channels of one batch element; lanes 0-31 carry the first dstate/2 states of their channel, lanes
-// 32-63 the second half. Per wave that is half the sequential work, half the registers (A, h: dstate/2 each; 4 instead
-// of 8 staged 16-byte pieces per tensor) and 12 KB instead of 20 KB of LDS, i.e. 3 waves per SIMD instead of 2 and twice
-// as many waves per launch: shapes whose batch * dim / 64 does not fill the 2048 wave slots of the chip
-// (DiM-XL/2 at 512 px: 64 x 1152 channels x 1024 steps = 1152 waves) get 2304 waves that are all resident at once.
-//   * tiles are 32 channels x 32 steps: 128-B row segments, whole HBM lines, XOR-swizzled LDS image (no padding);
-//   * dt = softplus(delta + bias) is evaluated once per element in the coalesced load layout (not once per half);
-//   * y_t = sum over the lane's states; the two halves are joined with ONE v_permlane32_swap + add per pair of steps:
-//     the low lane ends up with steps 0 and 2 of a 4-step group, the high lane with steps 1 and 3.
+// The sequence axis cannot be shortened without re-doing the exponentials (a chunk carry costs another v_exp_f32 per
+// (t, n), and this kernel family is VALU- / latency-bound once the chip is not full), so launches with few channels are
+// widened along the STATE axis instead: a wave64 owns 64 / kSP channels of one batch element and lane (c, s) carries
+// dstate / kSP states of channel c.
+//   kSP = 2: 32 channels per wave, lanes 0-31 the first dstate/2 states, lanes 32-63 the rest. Half the sequential work
+//            per wave, 12 KB of LDS, 3 waves per SIMD, twice the waves per launch.
+//   kSP = 4: 16 channels per wave, one DPP row of 16 lanes per state quarter. A quarter of the sequential work per
+//            wave, 8.6 KB of LDS, 4 waves per SIMD, four times the waves: DiM-XL/2 at 512 px (64 x 1152 channels x 1024
+//            steps) is 1152 waves in the 64-channel kernel -- not even one per SIMD -- and 4608 here.
+//   * tiles are (64 / kSP) channels x 32 steps: 128-B row segments, whole HBM lines, XOR-swizzled LDS image (no padding);
+//   * dt = softplus(delta + bias) is evaluated once per element in the coalesced load layout (not once per part);
+//   * y_t = sum over the lane's states; the parts are joined by a transposed exchange per 4-step group:
+//     kSP = 2: one v_permlane32_swap + add per PAIR of steps (low lane keeps steps 0, 2, high lane steps 1, 3);
+//     kSP = 4: v_permlane32_swap then v_permlane16_swap, 3 swaps + 3 adds per 4 steps: quarter q ends up with step q.
 #pragma once   // included by ssm_scan_fwd_kernel.hpp (uses its helpers: at(), Raw4, softplus_if, ...)
 
 namespace dimsum {
 
-constexpr int kSC = 32;   // channels per wave
 constexpr int kST = 32;   // time steps per tile
 
 __device__ __forceinline__ int stile_off(int row, int col4) { return row * kST + ((col4 ^ ((row >> 1) & 7)) << 2); }
@@ -24,17 +28,28 @@ __device__ __forceinline__ void swap_halves(float &x, float &y) {      // x.hi <
     x = __uint_as_float(r[0]); y = __uint_as_float(r[1]);
 }
 
-template <typename T, int kN, bool kHasZ, bool kVec, bool kFull, bool kCkpt = false>
-__global__ __launch_bounds__(kWave, 3) void ssm_scan_fwd_split_kernel(const dimsum_ssm_params_t p) {
+__device__ __forceinline__ void swap_rows(float &x, float &y) {        // x.odd rows <-> y.even rows (v_permlane16_swap)
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    x = __uint_as_float(r[0]); y = __uint_as_float(r[1]);
+}
+
+template <typename T, int kN, int kSP, bool kHasZ, bool kVec, bool kFull, bool kCkpt = false>
+__global__ __launch_bounds__(kWave, (kSP == 4 && kN <= 16) ? 4 : 3) void ssm_scan_fwd_split_kernel(const dimsum_ssm_params_t p) {
     static_assert(!kFull || kVec, "kFull implies kVec");
-    static_assert(kN % 4 == 0, "dstate must be a multiple of 4");
-    constexpr int kNL = kN / 2;                    // states per lane
+    static_assert(kSP == 2 || kSP == 4, "2 or 4 lanes per channel");
+    static_assert(kN % (2 * kSP) == 0, "dstate must be a multiple of 2 * kSP");
+    constexpr int kSC = kWave / kSP;               // channels per wave
+    constexpr int kNL = kN / kSP;                  // states per lane
+    constexpr int kNPc = kSC / 8;                  // 16-byte pieces per lane of a kSC x 32 tile (a piece = 8 rows x 128 B)
+    // B / C as [n][t], read back as ds_read_b128 whose address is uniform per state part. With 4 parts a 16-lane service
+    // group of the read spans two parts: rows kNL apart must not share banks -> row stride 36 dwords (kNL * 36 % 64 = 16).
+    constexpr int kBS = kSP == 4 ? kST + 4 : kST;
     __shared__ __attribute__((aligned(16))) float tileU[kSC * kST];
     __shared__ __attribute__((aligned(16))) float tileD[kSC * kST];
-    __shared__ __attribute__((aligned(16))) float tileB[kN * kST];   // [n][t]: uniform per half wave, read back as broadcast ds_read_b128
-    __shared__ __attribute__((aligned(16))) float tileC[kN * kST];
+    __shared__ __attribute__((aligned(16))) float tileB[kN * kBS];
+    __shared__ __attribute__((aligned(16))) float tileC[kN * kBS];
 
-    const int lane = threadIdx.x, c = lane & (kSC - 1), sh = lane >> 5;
+    const int lane = threadIdx.x, c = lane & (kSC - 1), sh = lane / kSC;
     const int ns0 = sh * kNL;
     const int L = p.seqlen;
     const int dpg = p.dim / p.n_groups;
@@ -78,12 +93,12 @@ __global__ __launch_bounds__(kWave, 3) void ssm_scan_fwd_split_kernel(const dims
     const int n_tiles = (L + kST - 1) / kST;
     // load layout: piece i of the tile, lane -> (row = i*8 + lane/8, 4 columns at (lane%8)*4)
     const int lrow = lane >> 3, lc4 = lane & 7, lcol = lc4 * 4;
-    float brow[4];
+    float brow[kNPc];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) brow[i] = bias_p ? bias_p[d0 + min(i * 8 + lrow, nd - 1)] : 0.f;
+    for (int i = 0; i < kNPc; ++i) brow[i] = bias_p ? bias_p[d0 + min(i * 8 + lrow, nd - 1)] : 0.f;
 
     constexpr int kBCPieces = (kN * 8 + kWave - 1) / kWave;
-    Raw4<T> ru[4], rd[4], rz[4], rb[kBCPieces], rc[kBCPieces];
+    Raw4<T> ru[kNPc], rd[kNPc], rz[kNPc], rb[kBCPieces], rc[kBCPieces];
     auto col_of = [&](int t0) { return min(t0 + lcol, L - 4); };
     auto piece = [&](const T *base, int ds, int i, int col) -> const T * {
         if constexpr (kFull) return at(base + i * 8 * ds, (unsigned)(lrow * ds + col));
@@ -92,7 +107,7 @@ __global__ __launch_bounds__(kWave, 3) void ssm_scan_fwd_split_kernel(const dims
     auto issue_loads = [&](int t0) {
         const int col = col_of(t0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < kNPc; ++i) {
             ru[i] = ld4<T>(piece(u_base, u_ds, i, col));
             rd[i] = ld4<T>(piece(dl_base, dl_ds, i, col));
         }
@@ -113,7 +128,7 @@ __global__ __launch_bounds__(kWave, 3) void ssm_scan_fwd_split_kernel(const dims
         if constexpr (kVec) {
             const bool col_ok = t0 + lcol < L;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < kNPc; ++i) {
                 const int row = i * 8 + lrow;
                 f32x4 vd = widen(rd[i]);
 #pragma unroll
@@ -125,15 +140,15 @@ __global__ __launch_bounds__(kWave, 3) void ssm_scan_fwd_split_kernel(const dims
             for (int i = 0; i < kBCPieces; ++i) {
                 const int n = i * 8 + lrow;
                 if (kN * 8 % kWave == 0 || n < kN) {
-                    *reinterpret_cast<f32x4 *>(&tileB[n * kST + lcol]) = widen(rb[i]);
-                    *reinterpret_cast<f32x4 *>(&tileC[n * kST + lcol]) = widen(rc[i]);
+                    *reinterpret_cast<f32x4 *>(&tileB[n * kBS + lcol]) = widen(rb[i]);
+                    *reinterpret_cast<f32x4 *>(&tileC[n * kBS + lcol]) = widen(rc[i]);
                 }
             }
             if (tile + 1 < n_tiles) issue_loads(t0 + kST);   // flies under the compute below
             if constexpr (kHasZ) {
                 const int col = col_of(t0);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) rz[i] = ld4<T>(piece(z_base, z_ds, i, col));
+                for (int i = 0; i < kNPc; ++i) rz[i] = ld4<T>(piece(z_base, z_ds, i, col));
             }
         } else {
             for (int i = 0; i < kSC * kST / kWave; ++i) {
@@ -148,9 +163,9 @@ __global__ __launch_bounds__(kWave, 3) void ssm_scan_fwd_split_kernel(const dims
                 tileD[stile_off(row, col >> 2) + (col & 3)] = vd;
             }
             for (int idx = lane; idx < kN * kST; idx += kWave) {
-                const int n = idx / kST, tc = min(t0 + (idx & (kST - 1)), L - 1);
-                tileB[idx] = to_f32<T>(Bp[(unsigned)(n * Bns + tc)]);
-                tileC[idx] = to_f32<T>(Cp[(unsigned)(n * Cns + tc)]);
+                const int n = idx / kST, col = idx & (kST - 1), tc = min(t0 + col, L - 1);
+                tileB[n * kBS + col] = to_f32<T>(Bp[(unsigned)(n * Bns + tc)]);
+                tileC[n * kBS + col] = to_f32<T>(Cp[(unsigned)(n * Cns + tc)]);
             }
         }
 
@@ -166,7 +181,7 @@ __global__ __launch_bounds__(kWave, 3) void ssm_scan_fwd_split_kernel(const dims
             }
             const f32x4 u4 = *reinterpret_cast<const f32x4 *>(&tileU[stile_off(c, j)]);
             const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&tileD[stile_off(c, j)]);
-            const int brow0 = ns0 * kST + j * 4;
+            const int brow0 = ns0 * kBS + j * 4;
             f32x4 bq_nxt = *reinterpret_cast<const f32x4 *>(&tileB[brow0]);
             f32x4 cq_nxt = *reinterpret_cast<const f32x4 *>(&tileC[brow0]);
             float du[4], y[4];
@@ -176,8 +191,8 @@ __global__ __launch_bounds__(kWave, 3) void ssm_scan_fwd_split_kernel(const dims
             for (int k = 0; k < kNL; ++k) {
                 const f32x4 bq = bq_nxt, cq = cq_nxt;
                 if (k + 1 < kNL) {
-                    bq_nxt = *reinterpret_cast<const f32x4 *>(&tileB[brow0 + (k + 1) * kST]);
-                    cq_nxt = *reinterpret_cast<const f32x4 *>(&tileC[brow0 + (k + 1) * kST]);
+                    bq_nxt = *reinterpret_cast<const f32x4 *>(&tileB[brow0 + (k + 1) * kBS]);
+                    cq_nxt = *reinterpret_cast<const f32x4 *>(&tileC[brow0 + (k + 1) * kBS]);
                 }
                 float hn = h[k];
 #pragma unroll
@@ -187,13 +202,23 @@ __global__ __launch_bounds__(kWave, 3) void ssm_scan_fwd_split_kernel(const dims
                 }
                 h[k] = hn;
             }
-            // join the halves: low lane <- totals of steps 0 and 2, high lane <- totals of steps 1 and 3
-            swap_halves(y[0], y[1]);
-            swap_halves(y[2], y[3]);
-            const float ya = y[0] + y[1], yb = y[2] + y[3];
-            float *slot = &tileU[stile_off(c, j)] + sh;
-            slot[0] = ya;
-            slot[2] = yb;
+            if constexpr (kSP == 2) {
+                // join the halves: low lane <- totals of steps 0 and 2, high lane <- totals of steps 1 and 3
+                swap_halves(y[0], y[1]);
+                swap_halves(y[2], y[3]);
+                const float ya = y[0] + y[1], yb = y[2] + y[3];
+                float *slot = &tileU[stile_off(c, j)] + sh;
+                slot[0] = ya;
+                slot[2] = yb;
+            } else {
+                // join the quarters (rows of 16 lanes): rows 0, 1 <- sums over rows {r, r + 2} of steps 0 / 1, rows 2, 3 of
+                // steps 2 / 3; then the even row of each pair keeps the first, the odd row the second: quarter q <- step q
+                swap_halves(y[0], y[2]);
+                swap_halves(y[1], y[3]);
+                float w0 = y[0] + y[2], w1 = y[1] + y[3];
+                swap_rows(w0, w1);
+                tileU[stile_off(c, j) + sh] = w0 + w1;
+            }
         }
 
         // ---- chunk-state store at every 2048 boundary and at the end (selective_scan_fwd_kernel.cuh:251-254) ---
@@ -211,7 +236,7 @@ __global__ __launch_bounds__(kWave, 3) void ssm_scan_fwd_split_kernel(const dims
         if constexpr (kVec) {
             if (t0 + lcol < L) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < kNPc; ++i) {
                     const int row = i * 8 + lrow;
                     if (kFull || row < nd) {
                         f32x4 y4 = *reinterpret_cast<const f32x4 *>(&tileU[stile_off(row, lc4)]);

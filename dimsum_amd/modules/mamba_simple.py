@@ -95,13 +95,9 @@ class _MambaBase(nn.Module):
         xz = gemm.matmul_wx(self.in_proj.weight, hidden_states.reshape(bsz * L, -1).t()).view(2 * self.d_inner, bsz, L).permute(1, 0, 2)
         if self.in_proj.bias is not None:
             xz = xz + self.in_proj.bias.to(xz.dtype).view(1, -1, 1)
-        if torch.is_grad_enabled() and self.A_log.requires_grad:
-            A = -torch.exp(self.A_log.float())
-        else:                                    # inference: A only changes when the parameter does (2 tiny launches per mixer call saved)
-            key = (self.A_log._version, self.A_log.device, self.A_log.data_ptr())
-            if getattr(self, "_A_cache_key", None) != key:
-                self._A_cache_key, self._A_cache = key, -torch.exp(self.A_log.detach().float())
-            A = self._A_cache
+        # recomputed on every call (two tiny launches): a cached copy could not see in-place parameter updates made through
+        # `.data` (EMA, load_state_dict), which do not bump the version counter, and would be frozen into a captured hipGraph
+        A = -torch.exp(self.A_log.float())
         if self.scan_type == "v2":
             A_b = -torch.exp(self.A_b_log.float())
             out = mamba_inner_fn_no_out_proj_cond(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,

@@ -41,7 +41,7 @@ def sample_batch(model, z, y, num_steps=250, sampling_method="euler", cfg_scale=
     else:
         out = fn(z, fwd, return_trajectory=False, y=y)
     ws = world_size if world_size is not None else (dist.get_world_size() if _dist_ready() else 1)
-    if gather and ws > 1 and _dist_ready():
+    if gather and _dist_ready() and (ws > 1 or gather == "force"):      # "force": also with one rank (collective bring-up tests)
         out = out.contiguous()
         full = torch.empty((ws * out.shape[0],) + tuple(out.shape[1:]), device=out.device, dtype=out.dtype)
         dist.all_gather_into_tensor(full, out)
@@ -87,7 +87,9 @@ def main(argv=None):
     torch.manual_seed(args.global_seed * world + rank)
     model = create_model(published_config(args.model, args.image_size, args.num_classes)).to(device).eval()
     if args.ckpt:
-        sd = torch.load(args.ckpt, map_location="cpu")
+        # the reference's container stores "args" as an argparse.Namespace (train.py:355-373): not loadable under
+        # torch >= 2.6's weights_only default. Checkpoints are trusted input here, as in the reference (download.py:17-37).
+        sd = torch.load(args.ckpt, map_location="cpu", weights_only=False)
         model.load_state_dict(sd.get("ema", sd.get("model", sd)), strict=True)     # EMA preferred (download.py:26-27)
     r = args.image_size // 8
     n_iter = -(-args.num_fid_samples // (args.per_proc_batch_size * world))
@@ -96,7 +98,9 @@ def main(argv=None):
     for _ in range(n_iter):
         z = torch.randn(args.per_proc_batch_size, model.in_channels, r, r, device=device)
         y = torch.randint(0, args.num_classes, (args.per_proc_batch_size,), device=device)
-        chunks.append(sample_batch(model, z, y, args.num_sampling_steps, args.sampling_method,
+        # the reference integrates on t = linspace(0, 1, --num-sampling-steps) (transport.py:379-386, integrators.py:98-111):
+        # N grid points = N - 1 Euler evaluations; sample_batch counts evaluations
+        chunks.append(sample_batch(model, z, y, max(1, args.num_sampling_steps - 1), args.sampling_method,
                                    args.cfg_scale if args.cfg_scale > 1.0 else None, args.path_type, hip_graph=graphs))
     dist.barrier()
     if rank == 0 and args.out:

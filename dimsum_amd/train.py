@@ -54,8 +54,10 @@ def checkpoint_content(model, ema, opt, args, epoch, train_steps):
             "ema": ema.state_dict()}
 
 
-def load_checkpoint(path, model, ema=None, opt=None, map_location="cpu"):
-    """resume (train.py:238-252): -> (init_epoch, train_steps). Inference loaders prefer the "ema" weights (download.py:26-27)."""
+def load_checkpoint(path, model, ema=None, opt=None, map_location="cpu", lr=None):
+    """resume (train.py:238-252): -> (init_epoch, train_steps). Inference loaders prefer the "ema" weights (download.py:26-27).
+    `lr`: the run's --lr, written over the restored param groups like train.py:248-249 (a resumed run follows its own flag,
+    not the checkpoint's). The container holds an argparse.Namespace ("args"), hence weights_only=False: trusted files only."""
     ck = torch.load(path, map_location=map_location, weights_only=False)
     net = model.module if hasattr(model, "module") else model
     net.load_state_dict(ck["model"], strict=True)
@@ -63,6 +65,9 @@ def load_checkpoint(path, model, ema=None, opt=None, map_location="cpu"):
         ema.load_state_dict(ck["ema"], strict=True)
     if opt is not None and "opt" in ck:
         opt.load_state_dict(ck["opt"])
+        if lr is not None:
+            for g in opt.param_groups:
+                g["lr"] = lr
     return ck.get("epoch", 0), ck.get("train_steps", 0)
 
 
@@ -111,7 +116,7 @@ def main(argv=None):
     model = create_model(published_config(args.model, args.image_size, args.num_classes)).to(device)
     model, ema, opt = build_training(model, device, args.lr, world, [device])
     transport = create_transport(args.path_type, args.prediction)
-    init_epoch, train_steps = (load_checkpoint(args.resume, model, ema, opt) if args.resume else (0, 0))
+    init_epoch, train_steps = (load_checkpoint(args.resume, model, ema, opt, lr=args.lr) if args.resume else (0, 0))
     model.train()
     r, b = args.image_size // 8, args.global_batch_size // world
     running, t0 = 0.0, time.time()

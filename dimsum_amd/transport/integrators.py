@@ -119,11 +119,12 @@ class _Dopri5:
                     out.append(x1 if theta >= 1.0 else self._interp(x, x1, mid, f0, f1, h, theta))
                     nxt += 1
                 t, x, f0 = t + h, x1, f1
-            # torchdiffeq _optimal_step_size
+            # torchdiffeq 0.2.3 _optimal_step_size: an accepted step (ratio < 1) never shrinks h (its dfactor becomes 1)
             if ratio == 0.0:
                 factor = self.ifactor
             else:
-                factor = min(self.ifactor if ratio <= 1.0 else 1.0, max(self.dfactor, self.safety * ratio ** -0.2))
+                lo = 1.0 if ratio < 1.0 else self.dfactor
+                factor = min(self.ifactor, max(lo, self.safety * ratio ** -0.2))
             h = h * factor
         return th.stack(out) if return_trajectory else out[-1]
 

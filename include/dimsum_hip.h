@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DIMSUM_ABI_VERSION 7
+#define DIMSUM_ABI_VERSION 8
 
 typedef enum {
     DIMSUM_OK = 0,
@@ -112,6 +112,16 @@ int dimsum_ssm_scan_fwd(const dimsum_ssm_params_t *p, void *stream);
 int dimsum_ssm_scan_bwd(const dimsum_ssm_bwd_params_t *p, void *stream);
 /* upper bound of the backward's workspace (partial dB / dC + rebuilt states) */
 int64_t dimsum_ssm_scan_bwd_workspace_bytes(int32_t batch, int32_t dim, int32_t seqlen, int32_t dstate, int32_t n_groups);
+/* Which forward kernel dimsum_ssm_scan_fwd launches for these parameters (measurement / diagnostics; no reference
+ * counterpart: the reference has one kernel, selective_scan_fwd_kernel.cuh:67-303):
+ *   0 = ssm_scan_fwd_kernel        lane = channel, 64 channels per wave (launches that fill the chip)
+ *   2 = ssm_scan_fwd_split_kernel  lane = (channel, state half), 32 channels per wave
+ *   4 = ssm_scan_fwd_split_kernel  lane = (channel, state quarter), 16 channels per wave (few channels, long sequences)
+ * -1 on invalid parameters. */
+int dimsum_ssm_scan_fwd_variant(const dimsum_ssm_params_t *p);
+/* Process-global override of that choice for subsequent launches: 0 / 2 / 4, or -1 = automatic (the default). A variant
+ * the shape does not support (dstate % 4, % 8) falls back to 0. For tests and tuning; not thread-safe. */
+void dimsum_ssm_scan_fwd_force_variant(int variant);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Causal depthwise conv1d, width 2..4, optional bias, optional SiLU.  Mirrors ConvParamsBase / ConvParamsBwd

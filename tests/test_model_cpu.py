@@ -38,29 +38,49 @@ def test_mamba_inner_fn_fwd_bwd():
         assert_close(p[k].grad.numpy(), g["g_" + k], what="g_" + k, rtol=5e-4, atol=0, scale_atol=1e-4)
 
 
-@pytest.mark.parametrize("name", ["condmamba_none", "mamba_none", "condmamba_zigma8"])
-def test_mixer_modules(name):
+def build_mixer(name):
+    """the mixer of golden `name` (tools/gen_golden.py::gen_mixer) with its procedural weights"""
     from dimsum_amd.modules.mamba_simple import CondMamba, Mamba
     from dimsum_amd import scanning_orders as so
-    g = golden(name)
     kw = dict(layer_idx=3, scan_type="none")
     if name == "condmamba_zigma8":
         paths = so.SCAN_ZOO["zigma"](8)[:8]
         kw.update(scan_type="zigma_8", zigzag_paths=torch.stack([T(p) for p in paths]),
                   zigzag_paths_reverse=torch.stack([T(so.reverse_permut_np(p)) for p in paths]))
+    elif name == "condmamba_v2":
+        kw.update(scan_type="v2")
     m = Mamba(32, **kw) if name == "mamba_none" else CondMamba(32, d_cond=48, **kw)
     procedural_fill(m, seed=7)
-    x = T(g["x"]).clone().requires_grad_()
-    with cpu_oracle_backend():
-        y = m(x) if name == "mamba_none" else m(x, T(g["c"]))
-        y.backward(T(g["dy"]))
-    assert_close(y.detach().numpy(), g["y"], what="y", **TOL)
-    assert_close(x.grad.numpy(), g["dx"], what="dx", **TOL)
+    return m
+
+
+def check_mixer(name, m, g, dev, tol, gtol):
+    x = T(g["x"]).clone().to(dev).requires_grad_()
+    y = m(x) if name == "mamba_none" else m(x, T(g["c"]).to(dev))
+    y.backward(T(g["dy"]).to(dev))
+    assert_close(y.detach().cpu().numpy(), g["y"], what="y", **tol)
+    assert_close(x.grad.cpu().numpy(), g["dx"], what="dx", **tol)
+    checked = 0
     for k, v in m.named_parameters():
         if "g_" + k in g.files:
-            assert_close(v.grad.numpy(), g["g_" + k], what=k, rtol=5e-4, atol=0, scale_atol=1e-4)
+            assert_close(v.grad.cpu().numpy(), g["g_" + k], what=k, **gtol)
+            checked += 1
         else:
             assert k.startswith("cond_proj") and (v.grad is None or not v.grad.any()), k   # SURVEY finding 1: dead parameter
+    assert checked >= 9
+
+
+MIXERS = ["condmamba_none", "mamba_none", "condmamba_zigma8", "condmamba_v2"]
+
+
+@pytest.mark.parametrize("name", MIXERS)
+def test_mixer_modules(name):
+    """Mamba / CondMamba forward + dx + every parameter gradient vs the reference module (mamba_simple.py:42-297, 439-657;
+    v2 :593-625 over the reference's own *_ref ops)."""
+    g = golden(name)
+    m = build_mixer(name)
+    with cpu_oracle_backend():
+        check_mixer(name, m, g, "cpu", TOL, dict(rtol=5e-4, atol=0, scale_atol=1e-4))
 
 
 @pytest.mark.parametrize("r,t,c", [(0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0), (1, 1, 1), (0, 1, 1)])
@@ -85,7 +105,9 @@ def test_block_combined(r, t, c):
 
 @pytest.mark.parametrize("tag,over", [("tiny", {}), ("tiny_cont", dict(scanning_continuity=True)),
                                       ("tiny_fourier", dict(block_type="combined_fourier")),
-                                      ("tiny_final_norm", dict(use_final_norm=True, num_classes=10))])
+                                      ("tiny_final_norm", dict(use_final_norm=True, num_classes=10)),
+                                      ("tiny_zigma8", dict(scan_type="zigma_8")), ("tiny_jpeg8", dict(scan_type="jpeg_8")),
+                                      ("tiny_sweep8", dict(scan_type="sweep_8"))])
 def test_tiny_models(tag, over):
     from dimsum_amd.models_dim import DiM
     g = golden("model_" + tag)

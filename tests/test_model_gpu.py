@@ -45,11 +45,18 @@ def test_block_combined_forward(r, t, c):
     assert np.array_equal(ro.cpu().numpy(), g[f"{tag}_res_out"])
 
 
-@pytest.mark.parametrize("tag,over", [("tiny", {}), ("tiny_cont", dict(scanning_continuity=True)),
-                                      ("tiny_fourier", dict(block_type="combined_fourier")),
-                                      ("tiny_final_norm", dict(use_final_norm=True, num_classes=10))])
-def test_tiny_models_forward(tag, over):
+@pytest.mark.parametrize("tag,over,fold", [("tiny", {}, "1"), ("tiny_cont", dict(scanning_continuity=True), "1"),
+                                           ("tiny_fourier", dict(block_type="combined_fourier"), "1"),
+                                           ("tiny_fourier", dict(block_type="combined_fourier"), "0"),
+                                           ("tiny_final_norm", dict(use_final_norm=True, num_classes=10), "1"),
+                                           ("tiny_zigma8", dict(scan_type="zigma_8"), "1"), ("tiny_zigma8", dict(scan_type="zigma_8"), "0"),
+                                           ("tiny_jpeg8", dict(scan_type="jpeg_8"), "1"), ("tiny_jpeg8", dict(scan_type="jpeg_8"), "0"),
+                                           ("tiny_sweep8", dict(scan_type="sweep_8"), "1"), ("tiny_sweep8", dict(scan_type="sweep_8"), "0")])
+def test_tiny_models_forward(tag, over, fold, monkeypatch):
+    """`fold`: DIMSUM_FOLD_ZIGZAG -- 1 composes the mixers' zigzag gathers (mamba_simple.py:627-657) into the enclosing
+    block's token tables, 0 lets the mixers gather by themselves; both against the reference golden."""
     from dimsum_amd.models_dim import DiM
+    monkeypatch.setenv("DIMSUM_FOLD_ZIGZAG", fold)
     g = golden("model_" + tag)
     m = DiM(depth=4, hidden_size=64, patch_size=2, **_published(**over))
     procedural_fill(m, seed=3)
@@ -61,14 +68,24 @@ def test_tiny_models_forward(tag, over):
             x4, t4, y4 = T(g["cfg_x"]).cuda(), T(g["cfg_t"]).cuda(), T(g["cfg_y"]).cuda()
             assert_close(m.forward_with_cfg(x4, t4, y4, cfg_scale=1.4).cpu().numpy(), g["cfg_out"], 2e-4, 0, "cfg", scale_atol=2e-5)
             assert_close(m(x4, t4, None).cpu().numpy(), g["out_nolabel"], 2e-4, 0, "nolabel", scale_atol=2e-5)
+            assert_close(m.forward_with_adacfg(x4, t4, y4, cfg_scale=3.8, scale_pow=4.0).cpu().numpy(), g["adacfg_out"], 2e-4, 0,
+                         "adacfg", scale_atol=2e-5)     # models_dim.py:1904-1924
+    zz = [mm for mm in m.modules() if getattr(mm, "zigzag_paths", None) is not None and mm._is_zigzag()]
+    if "scan_type" in over or tag == "tiny_fourier":
+        assert len(zz) > 0 and all(getattr(mm, "_zigzag_folded", False) == (fold == "1") for mm in zz)
 
 
-@pytest.mark.parametrize("name,tag,B,R", [("DiM-S/2", "model_S2", 4, 32), ("DiM-L/2", "model_L2", 2, 32), ("DiM-XL/2", "model_XL2_512", 1, 64)])
-def test_zoo_forward(name, tag, B, R):
-    """BASELINE configs 1/2/5 shapes: S/2 (L=256), L/2 (L=256, the headline model), XL/2 at 512 px (L=1024)."""
+@pytest.mark.parametrize("name,tag,B,R,over,fold", [("DiM-S/2", "model_S2", 4, 32, {}, "1"), ("DiM-L/2", "model_L2", 2, 32, {}, "1"),
+                                                    ("DiM-XL/2", "model_XL2_512", 1, 64, {}, "1"),
+                                                    ("DiM-XL/2", "model_XL2_512_zigma8", 1, 64, dict(scan_type="zigma_8"), "1"),
+                                                    ("DiM-XL/2", "model_XL2_512_zigma8", 1, 64, dict(scan_type="zigma_8"), "0")])
+def test_zoo_forward(name, tag, B, R, over, fold, monkeypatch):
+    """BASELINE configs 1/2/5 shapes: S/2 (L=256), L/2 (L=256, the headline model), XL/2 at 512 px (L=1024), and
+    configs[4] proper: XL/2 at 512 px with the 8-way zigzag scanning orders inside the mixers (mamba_simple.py:627-657)."""
     from dimsum_amd.models_dim import DiM_models
+    monkeypatch.setenv("DIMSUM_FOLD_ZIGZAG", fold)
     g = golden(tag)
-    m = DiM_models[name](**_published(img_resolution=R))
+    m = DiM_models[name](**_published(img_resolution=R, **over))
     assert sorted(m.state_dict().keys()) == [str(k) for k in g["keys"]]
     procedural_fill(m, seed=3)
     m = m.cuda().eval()
@@ -77,14 +94,15 @@ def test_zoo_forward(name, tag, B, R):
     assert_close(out.cpu().numpy(), g["out"], 1e-3, 0, "out", scale_atol=1e-4)
 
 
-@pytest.mark.parametrize("name,tag,B,R", [("DiM-L/2", "model_L2", 2, 32), ("DiM-XL/2", "model_XL2_512", 1, 64)])
-def test_zoo_forward_under_the_reference_matmul_policy(name, tag, B, R):
+@pytest.mark.parametrize("name,tag,B,R,over", [("DiM-L/2", "model_L2", 2, 32, {}), ("DiM-XL/2", "model_XL2_512", 1, 64, {}),
+                                               ("DiM-XL/2", "model_XL2_512_zigma8", 1, 64, dict(scan_type="zigma_8"))])
+def test_zoo_forward_under_the_reference_matmul_policy(name, tag, B, R, over):
     """the configuration bench.py times: torch.backends.cuda.matmul.allow_tf32 = True (dimsum/train.py:20-21), i.e. hipBLASLt's
     split-bf16 GEMMs AND the split-bf16 MFMA attention kernels -- against the same reference goldens with the same tolerance
     as the exact-fp32 run (north star: 1e-3)."""
     from dimsum_amd.models_dim import DiM_models
     g = golden(tag)
-    m = DiM_models[name](**_published(img_resolution=R))
+    m = DiM_models[name](**_published(img_resolution=R, **over))
     procedural_fill(m, seed=3)
     m = m.cuda().eval()
     old = torch.backends.cuda.matmul.allow_tf32
@@ -111,6 +129,37 @@ def test_mamba_inner_fn_fwd_bwd_gpu():
     assert_close(xz.grad.cpu().numpy(), g["dxz"], 5e-4, 0, "dxz", scale_atol=5e-5)
     for k in names:
         assert_close(p[k].grad.cpu().numpy(), g["g_" + k], 1e-3, 0, "g_" + k, scale_atol=2e-4)
+
+
+def test_no_torch_library_attention_on_published_configs():
+    """"no silent fallback": a published-config forward + backward never touches torch's SDPA (dimsum_amd.utils counts every
+    such call), and a head size without an MFMA kernel raises instead of quietly running elsewhere"""
+    from dimsum_amd import utils
+    from dimsum_amd.attention_fusion import CrossAttentionFusion
+    from dimsum_amd.models_dim import DiM
+    before = utils.torch_path_counts()
+    m = DiM(depth=4, hidden_size=64, patch_size=2, **_published())
+    procedural_fill(m, seed=3)
+    m = m.cuda()
+    x = torch.randn(2, 4, 32, 32, device="cuda", requires_grad=True)
+    m(x, torch.rand(2, device="cuda"), torch.tensor([1, 2], device="cuda")).sum().backward()
+    assert utils.torch_path_counts() == before
+    odd = CrossAttentionFusion(2 * 8 * 40, num_heads=8, qkv_bias=True).cuda()        # head_dim 40: no kernel
+    with pytest.raises(RuntimeError, match="no HIP kernel"):
+        odd(torch.randn(1, 16, 320, device="cuda"), torch.randn(1, 16, 320, device="cuda"))
+
+
+@pytest.mark.parametrize("name", ["condmamba_none", "mamba_none", "condmamba_zigma8", "condmamba_v2"])
+def test_mixer_modules_gpu(name):
+    """Mamba / CondMamba on the HIP path: forward, dx and every parameter gradient vs the reference module goldens
+    (mamba_simple.py:42-297 Mamba, :439-657 CondMamba incl. the zigzag gather -> inner fn -> inverse gather of :627-657,
+    :593-625 the bidirectional v2 pair over mamba_inner_fn_no_out_proj_cond)."""
+    from test_model_cpu import build_mixer, check_mixer
+    g = golden(name)
+    m = build_mixer(name).cuda()
+    check_mixer(name, m, g, "cuda", dict(rtol=2e-4, atol=0.0, scale_atol=2e-5), dict(rtol=1e-3, atol=0, scale_atol=2e-4))
+    if name == "condmamba_zigma8":
+        assert not getattr(m, "_zigzag_folded", False)        # stand-alone mixer: gathers by itself
 
 
 @pytest.mark.parametrize("r,t,c", [(0, 0, 0), (1, 1, 1)])
@@ -169,6 +218,16 @@ def test_hip_graph_replay_is_bit_identical():
             ref = m(x, t, y)
         assert torch.equal(g(x, t, y), ref)
     assert len(g.graphs) == 1
+    # in-place parameter updates through .data (EMA, load_state_dict: no version bump) are seen by eager AND by the replay:
+    # nothing derived from a parameter is cached on the host or frozen into the graph (A = -exp(A_log) is part of it)
+    before = ref.clone()
+    for mm in m.modules():
+        if hasattr(mm, "A_log"):
+            mm.A_log.data.add_(0.3)
+            mm.in_proj.weight.data.mul_(1.01)
+    with torch.no_grad():
+        ref2 = m(x, t, y)
+    assert not torch.equal(ref2, before) and torch.equal(g(x, t, y), ref2)
     z, y = torch.randn(4, 4, 32, 32, device="cuda", generator=gen), torch.randint(0, 1000, (4,), device="cuda", generator=gen)
     a = sample_batch(m, z, y, num_steps=5, gather=False)
     b = sample_batch(m, z, y, num_steps=5, gather=False, hip_graph={})

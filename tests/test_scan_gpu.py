@@ -20,15 +20,15 @@ pytestmark = pytest.mark.gpu
 CASES = ["scan_main", "scan_long", "scan_odd", "scan_plain", "scan_nosoftplus_z", "scan_groups2"]
 
 
-@pytest.fixture(params=["auto", "64ch", "split"])
+@pytest.fixture(params=["auto", "64ch", "split2", "split4"])
 def fwd_kernel(request):
-    """runs a forward test under the automatic kernel choice and with each of the two forward kernels forced
-    (64 channels per wave / lane = (channel, state half)): small test shapes would otherwise all take the split kernel"""
+    """runs a forward test under the automatic kernel choice and with each forward kernel forced (64 channels per wave /
+    lane = (channel, state half) / lane = (channel, state quarter)): small test shapes would otherwise all take one"""
     from dimsum_amd import _lib
     lib = _lib.load()
-    lib.dimsum_debug_scan_fwd_force_split({"auto": -1, "64ch": 0, "split": 1}[request.param])
+    lib.dimsum_ssm_scan_fwd_force_variant({"auto": -1, "64ch": 0, "split2": 2, "split4": 4}[request.param])
     yield request.param
-    lib.dimsum_debug_scan_fwd_force_split(-1)
+    lib.dimsum_ssm_scan_fwd_force_variant(-1)
 
 
 def _t(a, dev="cuda"):
@@ -119,27 +119,44 @@ def test_linearity_in_u_at_full_size(B, D, L, N):
     assert err <= 1e-4 * scale, (err, scale)
 
 
-def test_split_and_64_channel_kernels_agree():
-    """the two forward kernels (64 channels per wave / lane = (channel, state half)) on the same operands: same fp32
-    operations per state, only the order of the final sum over states differs -> rtol 2e-5 + 2e-6 max|ref|."""
-    import os
-    import subprocess
-    import sys
-    code = ("import torch, sys; sys.path.insert(0, %r); from dimsum_amd import native; g = torch.Generator(device='cuda').manual_seed(1); "
-            "B, D, L, N = 8, 192, 320, 16; u = torch.randn(B, D, L, device='cuda', generator=g); z = torch.randn(B, D, L, device='cuda', generator=g); "
-            "dl = 0.5 * torch.rand(B, D, L, device='cuda', generator=g); A = -0.5 * torch.rand(D, N, device='cuda', generator=g); "
-            "Bm = torch.randn(B, 1, N, L, device='cuda', generator=g); Cm = torch.randn(B, 1, N, L, device='cuda', generator=g); "
-            "Dv = torch.randn(D, device='cuda', generator=g); bias = 0.5 * torch.rand(D, device='cuda', generator=g); "
-            "out, x, oz = native.selective_scan_fwd(u, dl, A, Bm, Cm, Dv, z, bias, True); torch.save((out.cpu(), x.cpu(), oz.cpu()), sys.argv[1])")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = []
-    for split in ("0", "1"):                       # the env switch is read once per process
-        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"dimsum_split_{split}_{os.getpid()}.pt")
-        subprocess.run([sys.executable, "-c", code % root, path], check=True, env=dict(os.environ, DIMSUM_SCAN_SPLIT=split))
-        res.append(torch.load(path))
-        os.remove(path)
-    for name, a, b in zip(("out", "x", "out_z"), res[0], res[1]):
-        assert_close(a.numpy(), b.numpy(), 2e-5, 0, name, scale_atol=2e-6)
+def test_forward_kernel_variants_agree():
+    """the three forward kernels (64 channels per wave / 2 / 4 lanes per channel) on the same operands: same fp32 operations
+    per state, only the order of the final sum over states differs -> rtol 2e-5 + 2e-6 max|ref|; and the dispatch query
+    reports what was forced."""
+    from dimsum_amd import _lib, native
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    B, D, L, N = 8, 192, 320, 16
+    u, z = torch.randn(B, D, L, device="cuda", generator=g), torch.randn(B, D, L, device="cuda", generator=g)
+    dl = 0.5 * torch.rand(B, D, L, device="cuda", generator=g)
+    A = -0.5 * torch.rand(D, N, device="cuda", generator=g)
+    Bm, Cm = torch.randn(B, 1, N, L, device="cuda", generator=g), torch.randn(B, 1, N, L, device="cuda", generator=g)
+    Dv, bias = torch.randn(D, device="cuda", generator=g), 0.5 * torch.rand(D, device="cuda", generator=g)
+    res = {}
+    try:
+        for v in (0, 2, 4):
+            lib.dimsum_ssm_scan_fwd_force_variant(v)
+            out, x, oz, ck = native.selective_scan_fwd(u, dl, A, Bm, Cm, Dv, z, bias, True, need_ckpt=True)
+            res[v] = [t.cpu().numpy() for t in (out, x, oz, ck)]
+            P = _lib.SsmParams()
+            native._fill_ssm(P, u, dl, A, Bm, Cm, Dv, z, bias, True, out, x, oz)
+            assert lib.dimsum_ssm_scan_fwd_variant(P) == v
+    finally:
+        lib.dimsum_ssm_scan_fwd_force_variant(-1)
+    for v in (2, 4):
+        for name, a, b in zip(("out", "x", "out_z", "saved states"), res[v], res[0]):
+            assert_close(a, b, 2e-5, 0, f"{name} (variant {v})", scale_atol=2e-6)
+
+
+def test_forward_dispatch_by_shape():
+    """launches that fill the 2048 wave slots take the 64-channel kernel; smaller ones the widest state split their dstate allows"""
+    from dimsum_amd import _lib
+    lib = _lib.load()
+    for (B, D, N, G), want in {(256, 1024, 16, 1): 0, (64, 1152, 16, 1): 4, (16, 1152, 16, 1): 4, (4, 384, 4, 1): 2, (2, 70, 6, 1): 0,
+                               (2048, 64, 16, 1): 0}.items():
+        P = _lib.SsmParams()
+        P.batch, P.dim, P.seqlen, P.dstate, P.n_groups, P.n_chunks = B, D, 256, N, G, 1
+        assert lib.dimsum_ssm_scan_fwd_variant(P) == want, (B, D, N, G)
 
 
 def test_bwd_adjoint_identity_at_full_size():

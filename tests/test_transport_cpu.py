@@ -162,3 +162,23 @@ def test_sde_sampler_shapes_and_zero_noise_limit(method, last_step):
         det = sampler.sample_sde(sampling_method="Euler", diffusion_form="none", last_step=None, num_steps=n)(x0, model)
         ode_traj = sampler.sample_ode(sampling_method="euler", num_steps=n)(x0, model)
         assert torch.allclose(det[-2], ode_traj[-1], atol=1e-6)
+
+
+def test_dopri5_accepted_steps_never_shrink():
+    """torchdiffeq 0.2.3 `_optimal_step_size`: for an accepted step (error ratio < 1) dfactor becomes 1, so the factor is
+    min(ifactor, max(1, safety * ratio^-1/5)) -- h never shrinks after an acceptance. Hence every shrink in the sequence of
+    attempted step sizes comes from a rejection (ratio > 1), whose factor lies in [dfactor, safety) = [0.2, 0.9)."""
+    from dimsum_amd.transport.integrators import _Dopri5
+    hs = []
+
+    class Spy(_Dopri5):
+        def _step(self, t, h, x, f0):
+            hs.append(h)
+            return super()._step(t, h, x, f0)
+
+    f = lambda t, x: torch.stack([x[1], -25.0 * x[0]]) * (1 + 2 * t)       # oscillator speeding up: forces step changes
+    Spy(f, atol=1e-7, rtol=1e-5).integrate(torch.tensor([1.0, 0.0], dtype=torch.float64), [0.0, 1.0], False)
+    assert len(hs) > 10
+    shrank = [(a, b) for a, b in zip(hs[:-1], hs[1:]) if b < a]
+    assert all(0.2 - 1e-12 <= b / a < 0.9 for a, b in shrank), shrank
+    assert any(b >= a for a, b in zip(hs[:-1], hs[1:]))

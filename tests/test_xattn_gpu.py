@@ -186,6 +186,40 @@ def test_split_bf16_backward_vs_exact(B, L, heads, hd, self_attn):
         assert rms < 2e-5, (name, rms)
 
 
+@pytest.mark.parametrize("B,L,heads,hd,bias", [(2, 256, 8, 64, True), (1, 1024, 8, 72, False), (2, 100, 4, 24, True), (2, 256, 8, 48, True)])
+def test_split_bf16_backward_vs_sdpa_math_float64(B, L, heads, hd, bias):
+    """The backward that training and `bench.py --mode block` run under the reference's allow_tf32 policy (precision = 1,
+    split-bf16 MFMA in xattn_bwd_dq_split / xattn_bwd_dkv_split) against an independent oracle: torch autograd through
+    float64 SDPA math on the CPU (attention_fusion.py:72-79 written out). rtol 2e-4 + 4e-5 * max|ref| -- the split drops
+    the lo*lo terms (2^-16 relative per product) in each of the 7 GEMM-equivalents; real TF32 would need ~1e-3."""
+    from dimsum_amd import native
+    from torch.nn.attention import SDPBackend, sdpa_kernel
+    W = 3 * heads * hd
+    gen = torch.Generator().manual_seed(7 * L + hd)
+    q1, q2 = torch.randn(B, L, W, generator=gen), torch.randn(B, L, W, generator=gen)
+    b1, b2 = (torch.randn(W, generator=gen), torch.randn(W, generator=gen)) if bias else (None, None)
+    dout = torch.randn(B, L, 2 * heads * hd, generator=gen)
+    # oracle (float64, CPU)
+    r1, r2 = q1.double().requires_grad_(), q2.double().requires_grad_()
+
+    def split(t, bb):
+        t = t if bb is None else t + bb.double()
+        return t.reshape(B, L, 3, heads, hd).permute(2, 0, 3, 1, 4).unbind(0)
+    (qa, ka, va), (qb, kb, vb) = split(r1, b1), split(r2, b2)
+    with sdpa_kernel(SDPBackend.MATH):
+        x12 = torch.nn.functional.scaled_dot_product_attention(qa, kb, vb)
+        x21 = torch.nn.functional.scaled_dot_product_attention(qb, ka, va)
+    ref = torch.cat((x12.transpose(1, 2).reshape(B, L, -1), x21.transpose(1, 2).reshape(B, L, -1)), dim=-1)
+    ref.backward(dout.double())
+    # HIP, split-bf16 forward and backward
+    c = lambda t: None if t is None else t.cuda()
+    out, lse = native.xattn_fusion_fwd(c(q1), c(q2), heads, need_lse=True, bias1=c(b1), bias2=c(b2), split_bf16=True)
+    d1, d2 = native.xattn_fusion_bwd(c(q1), c(q2), out, lse, c(dout), heads, bias1=c(b1), bias2=c(b2), split_bf16=True)
+    assert_close(out.cpu().numpy(), ref.detach().numpy(), 5e-5, 0, "out", scale_atol=2e-5)
+    assert_close(d1.cpu().numpy(), r1.grad.numpy(), 2e-4, 0, "dqkv1", scale_atol=4e-5)
+    assert_close(d2.cpu().numpy(), r2.grad.numpy(), 2e-4, 0, "dqkv2", scale_atol=4e-5)
+
+
 @pytest.mark.parametrize("split", [False, True])
 def test_linearity_in_v_at_full_size(split):
     """Size-independent property at the BASELINE config-2 shape (batch 256, 256 tokens, 8 heads x 64): for fixed q, k the

@@ -28,7 +28,11 @@ def main():
     ap.add_argument("--dmajor", action="store_true", help="u and z d-major too, exactly like inside MambaInnerFn (xz = in_proj GEMM view)")
     ap.add_argument("--bwd", action="store_true", help="time selective_scan_bwd (with the saved states of the forward)")
     ap.add_argument("--no-ckpt", action="store_true", help="--bwd without saved states: the kernel pair of the reference-shaped call")
+    ap.add_argument("--variant", type=int, default=-1, help="force a forward kernel: 0 = 64 channels per wave, 2 / 4 = lanes per channel (-1: automatic)")
+    ap.add_argument("--train-fwd", action="store_true", help="time the forward's training variant (also stores the states the backward consumes)")
     a = ap.parse_args()
+    from dimsum_amd import _lib
+    _lib.load().dimsum_ssm_scan_fwd_force_variant(a.variant)
     dt = getattr(torch, a.dtype)
     B, D, L, N = a.B, a.D, a.L, a.N
     dev = "cuda"
@@ -56,7 +60,7 @@ def main():
         nbytes = 9 * B * D * L * s_ + 2 * B * N * L * (s_ + 4) + B * D * ((L + 2047) // 2048) * 2 * N * 4 + (D * N + 2 * D) * 4
     else:
         def call():
-            return native.selective_scan_fwd(u, delta, A, Bm, Cm, Dv, z, bias, True)
+            return native.selective_scan_fwd(u, delta, A, Bm, Cm, Dv, z, bias, True, need_ckpt=a.train_fwd)
         nbytes = scan_bytes(B, D, L, N, 1, u.element_size())
     for _ in range(3):
         call()
@@ -69,7 +73,9 @@ def main():
     torch.cuda.synchronize()
     ms = sorted(s.elapsed_time(e) for s, e in evs)
     med = ms[len(ms) // 2]
-    print(json.dumps({"kernel": "bwd" if a.bwd else "fwd", "shape": [B, D, L, N], "dtype": a.dtype, "ms_median": med, "ms_min": ms[0], "algorithmic_GB": nbytes / 1e9,
+    P = _lib.SsmParams()
+    P.batch, P.dim, P.seqlen, P.dstate, P.n_groups, P.n_chunks = B, D, L, N, 1, (L + 2047) // 2048
+    print(json.dumps({"kernel": "bwd" if a.bwd else "fwd", "fwd_variant": _lib.load().dimsum_ssm_scan_fwd_variant(P), "shape": [B, D, L, N], "dtype": a.dtype, "ms_median": med, "ms_min": ms[0], "algorithmic_GB": nbytes / 1e9,
                       "GBps": nbytes / med / 1e6, "frac_of_8TBps": nbytes / med / 1e6 / 8000}))
 
 

@@ -278,10 +278,11 @@ def gen_mixer(ns):
         "condmamba_none": dict(cls="CondMamba", scan_type="none"),
         "mamba_none": dict(cls="Mamba", scan_type="none"),
         "condmamba_zigma8": dict(cls="CondMamba", scan_type="zigma_8"),
+        "condmamba_v2": dict(cls="CondMamba", scan_type="v2"),
     }.items():
         d_model, L, B, H = 32, 64, 2, 8
         extra = {}
-        if kw["scan_type"] != "none":
+        if kw["scan_type"].startswith("zigma"):
             so = ns.scanning_orders
             paths = so.SCAN_ZOO["zigma"](H)[:8]
             extra["zigzag_paths"] = torch.stack([T(p) for p in paths])
@@ -291,11 +292,15 @@ def gen_mixer(ns):
         if kw["cls"] == "CondMamba":
             ckw["d_cond"] = 48
         m = cls(d_model, **ckw)
-        m.use_fast_path = False
         procedural_fill(m, seed=7)
         x = T(seeded((B, L, d_model), 41)).requires_grad_()
         c = T(seeded((B, 48), 42))
-        ref_shim.slow_path(m)          # wraps the zigzag gather around the slow path (mamba_simple.py:627-657)
+        if kw["scan_type"] == "v2":    # the reference's own fast-path code (:593-625) over its *_ref ops
+            ref_shim.route_no_out_proj_to_refs(ns)
+            assert m.use_fast_path
+        else:
+            m.use_fast_path = False
+            ref_shim.slow_path(m)      # wraps the zigzag gather around the slow path (mamba_simple.py:627-657)
         y = m(x, c) if kw["cls"] == "CondMamba" else m(x)
         g = T(seeded(tuple(y.shape), 43))
         y.backward(g)
@@ -361,11 +366,16 @@ def _mk_model(ns, name, **over):
     return ref_shim.slow_path(m).eval()
 
 
-def gen_models(ns, which):
+def gen_models(ns, which, only_tags=()):
     if "tiny" in which:
+        ref_shim.allow_zigzag_through_dim(ns)
         for tag, over in {"tiny": {}, "tiny_cont": dict(scanning_continuity=True),
                           "tiny_fourier": dict(block_type="combined_fourier"),
-                          "tiny_final_norm": dict(use_final_norm=True, num_classes=10)}.items():
+                          "tiny_final_norm": dict(use_final_norm=True, num_classes=10),
+                          "tiny_zigma8": dict(scan_type="zigma_8"), "tiny_jpeg8": dict(scan_type="jpeg_8"),
+                          "tiny_sweep8": dict(scan_type="sweep_8")}.items():
+            if only_tags and tag not in only_tags:
+                continue
             m = _mk_model(ns, "tiny", **over)
             procedural_fill(m, seed=3)
             x = T(seeded((2, 4, 32, 32), 61)).requires_grad_()
@@ -386,13 +396,17 @@ def gen_models(ns, which):
                                 out_nolabel=m(x4, t4, None))
             save("model_" + tag, "DiM.forward (dimsum/models_dim.py:1796-1884), depth 4 hidden 64, "
                  "published flags (scripts/train.sh), procedural weights seed 3", **arrs)
-    for name, tag, B in (("S/2", "model_S2", 4), ("DiM-L/2", "model_L2", 2), ("DiM-XL/2", "model_XL2_512", 1)):
+    for name, tag, B in (("S/2", "model_S2", 4), ("DiM-L/2", "model_L2", 2), ("DiM-XL/2", "model_XL2_512", 1),
+                         ("DiM-XL/2", "model_XL2_512_zigma8", 1)):
         if tag not in which:
             continue
-        over = dict(img_resolution=64) if tag.endswith("512") else {}
+        over = dict(img_resolution=64) if "512" in tag else {}
+        if tag.endswith("zigma8"):      # BASELINE configs[4]: 8-way zigzag scanning orders inside the mixers
+            ref_shim.allow_zigzag_through_dim(ns)
+            over["scan_type"] = "zigma_8"
         m = _mk_model(ns, name, **over)
         procedural_fill(m, seed=3)
-        R = 64 if tag.endswith("512") else 32
+        R = 64 if "512" in tag else 32
         x = T(seeded((B, 4, R, R), 71))
         t = T(seeded((B,), 72, kind="uniform"))
         y = torch.arange(B) * 37 % 1000
@@ -419,6 +433,8 @@ def main():
         "block": lambda: gen_block(ns), "tiny": lambda: gen_models(ns, {"tiny"}),
         "S2": lambda: gen_models(ns, {"model_S2"}), "L2": lambda: gen_models(ns, {"model_L2"}),
         "XL2": lambda: gen_models(ns, {"model_XL2_512"}),
+        "zigzag": lambda: gen_models(ns, {"tiny"}, only_tags=("tiny_zigma8", "tiny_jpeg8", "tiny_sweep8")),
+        "XL2zigzag": lambda: gen_models(ns, {"model_XL2_512_zigma8"}),
     }
     for k, fn in steps.items():
         if args.only is None or k in args.only:

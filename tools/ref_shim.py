@@ -188,6 +188,44 @@ def slow_path(model):
     return model
 
 
+def allow_zigzag_through_dim(ns):
+    """SURVEY finding 2: with cond_mamba=True the reference's create_block passes `scan_type` twice to
+    partial(CondMamba, ...) (models_dim.py:2035-2043: once by name, once inside **block_kwargs built at :1657) and raises
+    TypeError, so `DiM(scan_type="zigma_8")` cannot be constructed in this snapshot. Both values are the same string; this
+    wrapper drops the duplicate before delegating to the reference's own create_block, which is the intended semantics
+    (CondMamba.forward :627-657 with zigzag_paths / zigzag_paths_reverse of :1640-1658)."""
+    md = ns.models_dim
+    if getattr(md.create_block, "_dedup", False):
+        return
+    orig = md.create_block
+
+    def create_block(*a, scan_type="none", block_kwargs={}, **k):
+        bk = dict(block_kwargs)
+        st = bk.pop("scan_type", scan_type)
+        return orig(*a, scan_type=st, block_kwargs=bk, **k)
+
+    create_block._dedup = True
+    md.create_block = create_block
+
+
+def route_no_out_proj_to_refs(ns):
+    """scan_type="v2" (mamba_simple.py:593-625) only exists on the fast path, whose mamba_inner_fn_no_out_proj_cond is
+    CUDA-only (selective_scan_interface.py:375-576). Route it to the reference's own mamba_inner_ref (:1455-1500, i.e.
+    causal_conv1d_ref + selective_scan_ref) with an identity out-projection -- exact in fp32 (products by 1, sums with 0) --
+    so that the reference's v2 forward code runs unchanged on CPU."""
+    ssi, ms = ns.ssi, ns.ms
+
+    def no_out_proj(xz, conv_w, conv_b, x_proj_w, dt_proj_w, A, B=None, C=None, D=None, delta_bias=None,
+                    B_proj_bias=None, C_proj_bias=None, delta_softplus=True, init_states=None):
+        eye = torch.eye(A.shape[0], dtype=xz.dtype)
+        y = ssi.mamba_inner_ref(xz, conv_w, conv_b, x_proj_w, dt_proj_w, eye, None, A, B, C, D, delta_bias=delta_bias,
+                                B_proj_bias=B_proj_bias, C_proj_bias=C_proj_bias, delta_softplus=delta_softplus)
+        return y.transpose(1, 2)        # "b l d -> b d l"
+
+    ms.mamba_inner_fn_no_out_proj_cond = no_out_proj
+    ms.mamba_inner_fn_no_out_proj = no_out_proj
+
+
 def rerandomize_zeros(model, std=0.02, seed=1234):
     """SURVEY finding 5: adaLN-zero / zero final layer make the reference-initialised model output exactly 0.
     Every all-zero parameter <- N(0, std^2) so goldens are not vacuous."""
