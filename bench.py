@@ -58,10 +58,10 @@ def scan_bytes(B, D, L, N, G=1, s=4):
     return 5 * B * D * L * s + 2 * B * G * N * L * s + B * D * ((L + 2047) // 2048) * 2 * N * 4 + (D * N + 2 * D) * 4
 
 
-def scan_bwd_bytes(B, D, L, N, G=1, s=4):
-    """SURVEY.md 8(d), with the out_z recompute MambaInnerFn always requests: reads u, delta, z, out, dout, B, C, x;
-    writes du, ddelta, dz, out_z, dB, dC (fp32): 9 B D L s + 2 B G N L (s + 4) + x"""
-    return 9 * B * D * L * s + 2 * B * G * N * L * (s + 4) + B * D * ((L + 2047) // 2048) * 2 * N * 4 + (D * N + 2 * D) * 4
+def scan_bwd_bytes(B, D, L, N, G=1, s=4, recompute_out_z=True):
+    """reads u, delta, z, out, dout, B, C, x; writes du, ddelta, dz, dB, dC (fp32) (+ out_z when the caller
+    asks for its recompute, like the reference's MambaInnerFn): (8 [+ 1]) B D L s + 2 B G N L (s + 4) + x"""
+    return (9 if recompute_out_z else 8) * B * D * L * s + 2 * B * G * N * L * (s + 4) + B * D * ((L + 2047) // 2048) * 2 * N * 4 + (D * N + 2 * D) * 4
 
 
 class ScanTimer:
@@ -94,15 +94,16 @@ class ScanTimer:
                 if which == "fwd":
                     kernel = _lib.SCAN_FWD_KERNELS[lib.dimsum_ssm_scan_fwd_variant(p)] + (" (+ saved states)" if p.ckpt_ptr else "")
                 else:
-                    kernel = "ssm_scan_bwd_kernel (+ ssm_scan_bwd_reduce_kernel)"
+                    kernel = "ssm_scan_bwd_kernel (+ ssm_scan_bwd_reduce_kernel)" + ("" if p.out_z_ptr else ", no out_z recompute")
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 rc = fn(P, stream)
                 e1.record()
-                f = scan_bwd_bytes if which == "bwd" else scan_bytes
                 s = {_lib.F32: 4}.get(p.dtype, 2)
                 shape = (p.batch, p.dim, p.seqlen, p.dstate)
-                timer.records[which].append((e0, e1, f(p.batch, p.dim, p.seqlen, p.dstate, p.n_groups, s), shape, kernel))
+                nbytes = (scan_bwd_bytes(*shape, p.n_groups, s, recompute_out_z=bool(p.out_z_ptr)) if which == "bwd"
+                          else scan_bytes(*shape, p.n_groups, s))
+                timer.records[which].append((e0, e1, nbytes, shape, kernel))
                 return rc
 
             def dimsum_ssm_scan_fwd(self, P, stream):

@@ -34,7 +34,7 @@ __device__ __forceinline__ void swap_rows(float &x, float &y) {        // x.odd 
 }
 
 template <typename T, int kN, int kSP, bool kHasZ, bool kVec, bool kFull, bool kCkpt = false>
-__global__ __launch_bounds__(kWave, (kSP == 4 && kN <= 16) ? 4 : 3) void ssm_scan_fwd_split_kernel(const dimsum_ssm_params_t p) {
+__global__ __launch_bounds__(kWave, (kSP == 4 && kN <= 16) ? 5 : 3) void ssm_scan_fwd_split_kernel(const dimsum_ssm_params_t p) {
     static_assert(!kFull || kVec, "kFull implies kVec");
     static_assert(kSP == 2 || kSP == 4, "2 or 4 lanes per channel");
     static_assert(kN % (2 * kSP) == 0, "dstate must be a multiple of 2 * kSP");
@@ -42,8 +42,10 @@ __global__ __launch_bounds__(kWave, (kSP == 4 && kN <= 16) ? 4 : 3) void ssm_sca
     constexpr int kNL = kN / kSP;                  // states per lane
     constexpr int kNPc = kSC / 8;                  // 16-byte pieces per lane of a kSC x 32 tile (a piece = 8 rows x 128 B)
     // B / C as [n][t], read back as ds_read_b128 whose address is uniform per state part. With 4 parts a 16-lane service
-    // group of the read spans two parts: rows kNL apart must not share banks -> row stride 36 dwords (kNL * 36 % 64 = 16).
-    constexpr int kBS = kSP == 4 ? kST + 4 : kST;
+    // group of the read spans two parts, whose rows (kNL apart) start on the same bank: the 16-byte slots of row n are
+    // XOR-permuted by n / kNL, so the parts read different slots (no padding: 8 KB of LDS per wave = 20 waves per CU).
+    constexpr int kBS = kST;
+    auto bc_off = [](int n, int col4) { return n * kST + (((kSP == 4 ? col4 ^ (n / kNL) : col4)) << 2); };
     __shared__ __attribute__((aligned(16))) float tileU[kSC * kST];
     __shared__ __attribute__((aligned(16))) float tileD[kSC * kST];
     __shared__ __attribute__((aligned(16))) float tileB[kN * kBS];
@@ -104,6 +106,19 @@ __global__ __launch_bounds__(kWave, (kSP == 4 && kN <= 16) ? 4 : 3) void ssm_sca
         if constexpr (kFull) return at(base + i * 8 * ds, (unsigned)(lrow * ds + col));
         else return at(base, (unsigned)(min(i * 8 + lrow, nd - 1) * ds + col));
     };
+    // With 4 lanes per channel the kernel targets 5 waves per SIMD (<= 96 VGPRs): only the two HBM streams (u, delta) are
+    // prefetched a tile ahead in registers; B / C (L2-resident: shared by all waves of a batch element) and z are requested
+    // where they are used -- the other 4 waves of the SIMD cover that latency.
+    constexpr bool kLean = kSP == 4;
+    auto issue_bc = [&](int t0) {
+        const int col = col_of(t0);
+#pragma unroll
+        for (int i = 0; i < kBCPieces; ++i) {
+            const int n = min(i * 8 + lrow, kN - 1);
+            rb[i] = ld4<T>(at(Bp, (unsigned)(n * Bns + col)));
+            rc[i] = ld4<T>(at(Cp, (unsigned)(n * Cns + col)));
+        }
+    };
     auto issue_loads = [&](int t0) {
         const int col = col_of(t0);
 #pragma unroll
@@ -111,12 +126,7 @@ __global__ __launch_bounds__(kWave, (kSP == 4 && kN <= 16) ? 4 : 3) void ssm_sca
             ru[i] = ld4<T>(piece(u_base, u_ds, i, col));
             rd[i] = ld4<T>(piece(dl_base, dl_ds, i, col));
         }
-#pragma unroll
-        for (int i = 0; i < kBCPieces; ++i) {
-            const int n = min(i * 8 + lrow, kN - 1);
-            rb[i] = ld4<T>(at(Bp, (unsigned)(n * Bns + col)));
-            rc[i] = ld4<T>(at(Cp, (unsigned)(n * Cns + col)));
-        }
+        if constexpr (!kLean) issue_bc(t0);
     };
 
     if constexpr (kVec) issue_loads(0);
@@ -127,6 +137,7 @@ __global__ __launch_bounds__(kWave, (kSP == 4 && kN <= 16) ? 4 : 3) void ssm_sca
         // ---- stage the tile into LDS: u, dt = softplus(delta + bias) (0 beyond L: a = 1, b = 0, the state is untouched) ----
         if constexpr (kVec) {
             const bool col_ok = t0 + lcol < L;
+            if constexpr (kLean) issue_bc(t0);
 #pragma unroll
             for (int i = 0; i < kNPc; ++i) {
                 const int row = i * 8 + lrow;
@@ -140,12 +151,12 @@ __global__ __launch_bounds__(kWave, (kSP == 4 && kN <= 16) ? 4 : 3) void ssm_sca
             for (int i = 0; i < kBCPieces; ++i) {
                 const int n = i * 8 + lrow;
                 if (kN * 8 % kWave == 0 || n < kN) {
-                    *reinterpret_cast<f32x4 *>(&tileB[n * kBS + lcol]) = widen(rb[i]);
-                    *reinterpret_cast<f32x4 *>(&tileC[n * kBS + lcol]) = widen(rc[i]);
+                    *reinterpret_cast<f32x4 *>(&tileB[bc_off(n, lc4)]) = widen(rb[i]);
+                    *reinterpret_cast<f32x4 *>(&tileC[bc_off(n, lc4)]) = widen(rc[i]);
                 }
             }
             if (tile + 1 < n_tiles) issue_loads(t0 + kST);   // flies under the compute below
-            if constexpr (kHasZ) {
+            if constexpr (kHasZ && !kLean) {
                 const int col = col_of(t0);
 #pragma unroll
                 for (int i = 0; i < kNPc; ++i) rz[i] = ld4<T>(piece(z_base, z_ds, i, col));
@@ -164,8 +175,8 @@ __global__ __launch_bounds__(kWave, (kSP == 4 && kN <= 16) ? 4 : 3) void ssm_sca
             }
             for (int idx = lane; idx < kN * kST; idx += kWave) {
                 const int n = idx / kST, col = idx & (kST - 1), tc = min(t0 + col, L - 1);
-                tileB[n * kBS + col] = to_f32<T>(Bp[(unsigned)(n * Bns + tc)]);
-                tileC[n * kBS + col] = to_f32<T>(Cp[(unsigned)(n * Cns + tc)]);
+                tileB[bc_off(n, col >> 2) + (col & 3)] = to_f32<T>(Bp[(unsigned)(n * Bns + tc)]);
+                tileC[bc_off(n, col >> 2) + (col & 3)] = to_f32<T>(Cp[(unsigned)(n * Cns + tc)]);
             }
         }
 
@@ -181,7 +192,7 @@ __global__ __launch_bounds__(kWave, (kSP == 4 && kN <= 16) ? 4 : 3) void ssm_sca
             }
             const f32x4 u4 = *reinterpret_cast<const f32x4 *>(&tileU[stile_off(c, j)]);
             const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&tileD[stile_off(c, j)]);
-            const int brow0 = ns0 * kBS + j * 4;
+            const int brow0 = bc_off(ns0, j);        // rows ns0 .. ns0 + kNL - 1 share the slot permutation
             f32x4 bq_nxt = *reinterpret_cast<const f32x4 *>(&tileB[brow0]);
             f32x4 cq_nxt = *reinterpret_cast<const f32x4 *>(&tileC[brow0]);
             float du[4], y[4];
@@ -235,6 +246,11 @@ __global__ __launch_bounds__(kWave, (kSP == 4 && kN <= 16) ? 4 : 3) void ssm_sca
         // ---- epilogue: re-read y in the coalesced layout, gate, store -------------------------------------------
         if constexpr (kVec) {
             if (t0 + lcol < L) {
+                if constexpr (kHasZ && kLean) {
+                    const int col = col_of(t0);
+#pragma unroll
+                    for (int i = 0; i < kNPc; ++i) rz[i] = ld4<T>(piece(z_base, z_ds, i, col));
+                }
 #pragma unroll
                 for (int i = 0; i < kNPc; ++i) {
                     const int row = i * 8 + lrow;

@@ -9,9 +9,16 @@ The four fused variants of the reference are four near-identical 200-line classe
 switches (out-projection, conditional conv entry). Semantics kept: checkpoint_lvl=1 recomputation of conv1d_out and
 delta in the backward, dx/dz written side by side into one `dxz`, `dcond = None` (SURVEY finding 1), fp32 dB/dC
 accumulation cast back to the input dtype, autocast-aware weight casts.
+One deliberate difference in what is SAVED (not in what is computed): the reference drops `out_z` after the forward and has
+the backward kernel recompute and re-write it (selective_scan_interface.py:952, `recompute_out_z=True`) to save one
+activation tensor on 40-80 GB GPUs. With 288 GB of HBM the forward's `out_z` is simply kept for `d out_proj.weight`, and the
+backward kernel skips that store (0.27 GB less traffic per call at DiM-L/2, batch 256). DIMSUM_RECOMPUTE_OUT_Z=1 restores
+the reference's trade.
 
 Not implemented (raise): complex A, constant (non input-dependent) B/C -- unused by DiMSUM (mamba_simple.py:586,602-603).
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch.amp import custom_bwd, custom_fwd
@@ -133,8 +140,10 @@ class _MambaInner(torch.autograd.Function):
                      C_proj_bias is not None, has_out_proj and out_proj_bias is not None)
         if checkpoint_lvl >= 1:
             conv_out, delta = None, None            # recomputed in the backward (:663-664)
+        keep_out_z = has_out_proj and need and os.environ.get("DIMSUM_RECOMPUTE_OUT_Z", "0") != "1"
         ctx.save_for_backward(xz, conv_w, conv_b, x_dbl, x_proj_weight, delta_proj_weight,
-                              out_proj_weight if has_out_proj else None, conv_out, delta, A, Bm, Cm, D, delta_bias, scan_x, out, ckpt)
+                              out_proj_weight if has_out_proj else None, conv_out, delta, A, Bm, Cm, D, delta_bias, scan_x, out, ckpt,
+                              out_z if keep_out_z else None)
         if not has_out_proj:
             return out_z                                                                                # (b, d, l)
         if out_proj_bias is None:
@@ -145,7 +154,7 @@ class _MambaInner(torch.autograd.Function):
     @custom_bwd(device_type="cuda")
     def backward(ctx, dout):
         (xz, conv_w, conv_b, x_dbl, x_proj_weight, delta_proj_weight, out_proj_weight, conv_out, delta, A, Bm, Cm, D,
-         delta_bias, scan_x, out, ckpt) = ctx.saved_tensors
+         delta_bias, scan_x, out, ckpt, kept_out_z) = ctx.saved_tensors
         has_conv_b, has_D, has_dbias, has_Bb, has_Cb, has_ob = ctx.flags
         L = xz.shape[-1]
         R = delta_proj_weight.shape[1]
@@ -163,8 +172,10 @@ class _MambaInner(torch.autograd.Function):
             dout_y = (out_proj_weight.t() @ dout2).view(d_inner, bsz, L).permute(1, 0, 2)               # d-major like delta
         else:
             dout_y = dout
-        dconv_out, ddelta, dA, dB, dC, dD, ddelta_bias, dz, out_z = native.selective_scan_bwd(
-            conv_out, delta, A, Bm, Cm, D, z, delta_bias, dout_y, scan_x, out, dz, ctx.delta_softplus, True, ckpt=ckpt)
+        recompute = ctx.has_out_proj and kept_out_z is None      # only d out_proj.weight needs out_z
+        dconv_out, ddelta, dA, dB, dC, dD, ddelta_bias, dz, *rest = native.selective_scan_bwd(
+            conv_out, delta, A, Bm, Cm, D, z, delta_bias, dout_y, scan_x, out, dz, ctx.delta_softplus, recompute, ckpt=ckpt)
+        out_z = rest[0] if recompute else kept_out_z
         dout_proj_weight = dout_proj_bias = None
         if ctx.has_out_proj:
             dout_proj_weight = dout2 @ _rows(out_z).t()                                                 # "eB,dB->ed"

@@ -38,3 +38,10 @@ def assert_close(a, b, rtol, atol, what="", scale_atol=0.0):
         i = np.unravel_index(np.argmax(err - tol), err.shape)
         raise AssertionError(f"{what}: max violation at {i}: got {a[i]!r} want {b[i]!r} (|err|={err[i]:.3e}, "
                              f"tol={tol[i]:.3e}); max abs err {err.max():.3e}")
+
+
+@pytest.fixture
+def allow_torch_sdpa(monkeypatch):
+    """Tiny test models (hidden 64 / 128: head_dim 4 / 8) have no MFMA attention kernel (head_dim in {24, 32, 48, 64, 72});
+    their attention core runs on torch's SDPA, which the product only does when asked to (dimsum_amd.utils.note_torch_path)."""
+    monkeypatch.setenv("DIMSUM_ALLOW_TORCH_SDPA", "1")

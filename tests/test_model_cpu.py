@@ -103,6 +103,35 @@ def test_block_combined(r, t, c):
     assert_close(cc.grad.numpy(), g[f"{tag}_dc"], what="dc", rtol=5e-4, atol=0, scale_atol=1e-4)
 
 
+def check_block_384(dev, tol, gtol):
+    """DiMBlockCombined at DiM-S/2's width (hidden 384: attention head_dim 24), all three order flags on: y, res_out, input
+    gradients and three parameter gradients (qkv1 of the fusion, A_log of the spatial mixer, norm_2) vs the reference block"""
+    from dimsum_amd.models_dim import create_block
+    g = golden("block_combined_384")
+    blk = create_block(384, norm_epsilon=1e-5, rms_norm=True, residual_in_fp32=True, fused_add_norm=True, layer_idx=1,
+                       scan_type="none", block_type="combined", reverse=True, transpose=True, cond_mamba=True,
+                       scanning_continuity=True, use_gated_mlp=True)
+    procedural_fill(blk, seed=9)
+    blk = blk.to(dev)
+    x, res, cc = (T(seeded(sh, sd)).to(dev).requires_grad_() for sh, sd in (((1, 256, 384), 56), ((1, 256, 384), 57), ((1, 384), 58)))
+    y, ro = blk(x, res, cc)
+    ((y * T(seeded((1, 256, 384), 59)).to(dev)).sum() + (ro * T(seeded((1, 256, 384), 60)).to(dev)).sum()).backward()
+    n = lambda t: t.detach().cpu().numpy()
+    assert_close(n(y), g["y"], what="y", **tol)
+    assert np.array_equal(n(ro), g["res_out"])
+    assert_close(n(x.grad), g["dx"], what="dx", **gtol)
+    assert_close(n(res.grad), g["dres"], what="dres", **gtol)
+    assert_close(n(cc.grad), g["dc"], what="dc", rtol=1e-3, atol=0, scale_atol=2e-4)
+    assert_close(n(blk.proj.qkv1.weight.grad), g["g_qkv1"], what="g qkv1", rtol=1e-3, atol=0, scale_atol=2e-4)
+    assert_close(n(blk.spatial_mamba.mixer.A_log.grad), g["g_A_log"], what="g A_log", rtol=1e-3, atol=0, scale_atol=2e-4)
+    assert_close(n(blk.norm_2.weight.grad), g["g_norm2"], what="g norm_2", rtol=1e-3, atol=0, scale_atol=2e-4)
+
+
+def test_block_combined_384():
+    with cpu_oracle_backend():
+        check_block_384("cpu", TOL, TOL)
+
+
 @pytest.mark.parametrize("tag,over", [("tiny", {}), ("tiny_cont", dict(scanning_continuity=True)),
                                       ("tiny_fourier", dict(block_type="combined_fourier")),
                                       ("tiny_final_norm", dict(use_final_norm=True, num_classes=10)),

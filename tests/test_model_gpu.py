@@ -29,6 +29,12 @@ def _fp32_matmul():
     torch.set_float32_matmul_precision("highest")
 
 
+# the hidden-64 / hidden-128 fixtures have head_dim 4 / 8: their attention core is torch SDPA by explicit opt-in (conftest);
+# everything else in them -- and ALL of the zoo-size tests -- runs on libdimsum_hip.so
+tiny = pytest.mark.usefixtures("allow_torch_sdpa")
+
+
+@tiny
 @pytest.mark.parametrize("r,t,c", [(0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0), (1, 1, 1), (0, 1, 1)])
 def test_block_combined_forward(r, t, c):
     from dimsum_amd.models_dim import create_block
@@ -45,6 +51,7 @@ def test_block_combined_forward(r, t, c):
     assert np.array_equal(ro.cpu().numpy(), g[f"{tag}_res_out"])
 
 
+@tiny
 @pytest.mark.parametrize("tag,over,fold", [("tiny", {}, "1"), ("tiny_cont", dict(scanning_continuity=True), "1"),
                                            ("tiny_fourier", dict(block_type="combined_fourier"), "1"),
                                            ("tiny_fourier", dict(block_type="combined_fourier"), "0"),
@@ -131,6 +138,23 @@ def test_mamba_inner_fn_fwd_bwd_gpu():
         assert_close(p[k].grad.cpu().numpy(), g["g_" + k], 1e-3, 0, "g_" + k, scale_atol=2e-4)
 
 
+@pytest.mark.parametrize("tf32", [False, True])
+def test_block_combined_384_fwd_bwd_all_hip(tf32):
+    """BASELINE configs[2]'s block at a width whose attention runs on the MFMA kernels (hidden 384, head_dim 24): forward,
+    input gradients and parameter gradients vs the reference block golden, nothing on a torch-library path -- in exact fp32
+    and under the reference's allow_tf32 policy (split-bf16 GEMMs + split-bf16 attention forward / backward kernels)."""
+    from dimsum_amd import utils
+    from test_model_cpu import check_block_384
+    before = utils.torch_path_counts()
+    old = torch.backends.cuda.matmul.allow_tf32
+    try:
+        torch.backends.cuda.matmul.allow_tf32 = tf32
+        check_block_384("cuda", dict(rtol=2e-4, atol=0.0, scale_atol=2e-5), dict(rtol=5e-4, atol=0.0, scale_atol=5e-5))
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = old
+    assert utils.torch_path_counts() == before
+
+
 def test_no_torch_library_attention_on_published_configs():
     """"no silent fallback": a published-config forward + backward never touches torch's SDPA (dimsum_amd.utils counts every
     such call), and a head size without an MFMA kernel raises instead of quietly running elsewhere"""
@@ -138,7 +162,7 @@ def test_no_torch_library_attention_on_published_configs():
     from dimsum_amd.attention_fusion import CrossAttentionFusion
     from dimsum_amd.models_dim import DiM
     before = utils.torch_path_counts()
-    m = DiM(depth=4, hidden_size=64, patch_size=2, **_published())
+    m = DiM(depth=4, hidden_size=384, patch_size=2, **_published())        # DiM-S/2's width: head_dim 24 in both attention flavours
     procedural_fill(m, seed=3)
     m = m.cuda()
     x = torch.randn(2, 4, 32, 32, device="cuda", requires_grad=True)
@@ -162,6 +186,7 @@ def test_mixer_modules_gpu(name):
         assert not getattr(m, "_zigzag_folded", False)        # stand-alone mixer: gathers by itself
 
 
+@tiny
 @pytest.mark.parametrize("r,t,c", [(0, 0, 0), (1, 1, 1)])
 def test_block_combined_fwd_bwd(r, t, c):
     from dimsum_amd.models_dim import create_block
@@ -181,6 +206,7 @@ def test_block_combined_fwd_bwd(r, t, c):
     assert_close(cc.grad.cpu().numpy(), g[f"{tag}_dc"], 1e-3, 0, "dc", scale_atol=2e-4)
 
 
+@tiny
 def test_tiny_model_fwd_bwd():
     from dimsum_amd.models_dim import DiM
     g = golden("model_tiny")
@@ -194,6 +220,7 @@ def test_tiny_model_fwd_bwd():
     assert_close(x.grad.cpu().numpy(), g["dx"], 1e-3, 0, "dx", scale_atol=1e-4)
 
 
+@tiny
 @pytest.mark.gpu
 def test_hip_graph_replay_is_bit_identical():
     """GraphedForward: the denoiser forward replayed from a captured hipGraph (every libdimsum_hip.so launch recorded on
@@ -283,7 +310,7 @@ def test_zigzag_paths_folded_into_block_tables():
     for fold in ("1", "0"):
         path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"dimsum_zz_{fold}_{os.getpid()}.pt")
         subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "tests", "golden")), path], check=True,
-                       env=dict(os.environ, DIMSUM_FOLD_ZIGZAG=fold))
+                       env=dict(os.environ, DIMSUM_FOLD_ZIGZAG=fold, DIMSUM_ALLOW_TORCH_SDPA="1"))
         res.append(torch.load(path))
         os.remove(path)
     (a, fa), (b, fb) = res

@@ -51,6 +51,7 @@ def _one_step(dev, lr, decay):
         {k: v.detach().cpu().numpy() for k, v in ema.named_parameters()}, (model, ema, opt)
 
 
+@pytest.mark.usefixtures("allow_torch_sdpa")      # hidden 64: head_dim 4 (conftest)
 def test_train_step_hip_vs_cpu_oracle():
     """loss rtol 1e-4; every clipped gradient rtol 1e-3 + 2e-4 * max|ref| (the tolerance of the block-level gradient goldens);
     updated parameters and EMA: AdamW's first update is -lr * g / (|g| + 1e-8) ~ -lr * sign(g), so the two runs agree to
@@ -81,6 +82,7 @@ def test_train_step_hip_vs_cpu_oracle():
     assert n_off <= 0.005 * n_tot, (n_off, n_tot)
 
 
+@pytest.mark.usefixtures("allow_torch_sdpa")
 def test_checkpoint_roundtrip_on_gpu(tmp_path):
     from dimsum_amd.train import build_training, checkpoint_content, load_checkpoint
     *_, (model, ema, opt) = _one_step("cuda", 1e-3, 0.9)
@@ -101,6 +103,7 @@ import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests", "golden"))
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2], RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ["DIMSUM_ALLOW_TORCH_SDPA"] = "1"      # hidden 64: head_dim 4 has no MFMA attention kernel
 from dimsum_amd.models_dim import DiM
 from dimsum_amd.sample_ddp import sample_batch
 from procedural import procedural_fill

@@ -28,16 +28,23 @@ def test_core_vs_oracle(B, L, heads, hd):
 
 
 @pytest.mark.parametrize("name,dim", [("fusion_128", 128), ("fusion_hd24", 384)])
-def test_module_vs_golden(name, dim):
-    """CrossAttentionFusion end to end (qkv GEMMs + MFMA core + proj) against the reference module's output."""
+def test_module_vs_golden(name, dim, monkeypatch):
+    """CrossAttentionFusion end to end (qkv GEMMs + MFMA core + proj) against the reference module's output.
+    fusion_hd24 (head_dim 24) runs the MFMA kernels; fusion_128 has head_dim 8, for which no kernel is built: it checks the
+    module's explicit torch-SDPA opt-in path (DIMSUM_ALLOW_TORCH_SDPA) and that the call is counted."""
     from dimsum_amd.attention_fusion import CrossAttentionFusion
     g = golden(name)
+    from dimsum_amd import utils
+    if name == "fusion_128":
+        monkeypatch.setenv("DIMSUM_ALLOW_TORCH_SDPA", "1")
     m = CrossAttentionFusion(dim, num_heads=8, qkv_bias=True, swap_k=False)
     procedural_fill(m, seed=5)
     m = m.cuda().eval()
     x1, x2 = torch.from_numpy(g["x1"]).cuda(), torch.from_numpy(g["x2"]).cuda()
+    before = sum(utils.torch_path_counts().values())
     with torch.no_grad():
         y = m(x1, x2)
+    assert sum(utils.torch_path_counts().values()) - before == (1 if name == "fusion_128" else 0)
     assert_close(y.cpu().numpy(), g["y"], 1e-4, 0, "y (fused MFMA path)", scale_atol=1e-5)
     # autograd path (MFMA forward + the two MFMA backward kernels) gives the same forward and the reference gradients
     x1r, x2r = x1.clone().requires_grad_(), x2.clone().requires_grad_()

@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--dmajor", action="store_true", help="u and z d-major too, exactly like inside MambaInnerFn (xz = in_proj GEMM view)")
     ap.add_argument("--bwd", action="store_true", help="time selective_scan_bwd (with the saved states of the forward)")
     ap.add_argument("--no-ckpt", action="store_true", help="--bwd without saved states: the kernel pair of the reference-shaped call")
+    ap.add_argument("--no-out-z", action="store_true", help="--bwd without the out_z recompute (what dimsum_amd.ops requests: it keeps the forward's out_z)")
+    ap.add_argument("--pad", type=int, default=0, help="--dmajor: extra elements in the channel stride (B*L + pad): probes L2 / HBM channel camping "
+                                                       "of power-of-two strides")
     ap.add_argument("--variant", type=int, default=-1, help="force a forward kernel: 0 = 64 channels per wave, 2 / 4 = lanes per channel (-1: automatic)")
     ap.add_argument("--train-fwd", action="store_true", help="time the forward's training variant (also stores the states the backward consumes)")
     a = ap.parse_args()
@@ -38,26 +41,33 @@ def main():
     dev = "cuda"
     xz = torch.randn(B, 2 * D, L, device=dev, dtype=dt)
     u = torch.randn(B, D, L, device=dev, dtype=dt)
-    delta = (0.5 * torch.rand(D, B, L, device=dev)).to(dt).permute(1, 0, 2)   # d-major like MambaInnerFn
+    def dm(t):          # (D, B, L) -> d-major (B, D, L) view with channel stride B * L + pad
+        if a.pad == 0:
+            return t.permute(1, 0, 2)
+        buf = torch.empty(t.shape[0], B * L + a.pad, device=dev, dtype=t.dtype)
+        v = buf[:, :B * L].view(t.shape[0], B, L)
+        v.copy_(t)
+        return v.permute(1, 0, 2)
+    delta = dm((0.5 * torch.rand(D, B, L, device=dev)).to(dt))   # d-major like MambaInnerFn
     A = -0.5 * torch.rand(D, N, device=dev)
     Bm, Cm = torch.randn(B, 1, N, L, device=dev, dtype=dt), torch.randn(B, 1, N, L, device=dev, dtype=dt)
     Dv, bias = torch.randn(D, device=dev), 0.5 * torch.rand(D, device=dev)
     z = xz.chunk(2, 1)[1]
     if a.dmajor:
-        xz = torch.randn(2 * D, B, L, device=dev, dtype=dt).permute(1, 0, 2)        # strides (L, B L, 1)
+        xz = dm(torch.randn(2 * D, B, L, device=dev, dtype=dt))                      # strides (L, B L, 1)
         z = xz.chunk(2, 1)[1]
-        u = torch.empty_like(xz.chunk(2, 1)[0]).copy_(u)                             # conv_out = empty_like(x): d-major
+        u = dm(u.permute(1, 0, 2).contiguous())                                      # conv_out = empty_like(x): d-major
     if a.bwd:
         out, x, out_z, ckpt = native.selective_scan_fwd(u, delta, A, Bm, Cm, Dv, z, bias, True, need_ckpt=True)
-        dout = torch.randn(D, B, L, device=dev).to(dt).permute(1, 0, 2)
+        dout = dm(torch.randn(D, B, L, device=dev).to(dt))
         dxz = torch.empty_like(xz)
         dz = dxz.chunk(2, 1)[1]
         ck = None if a.no_ckpt else ckpt
 
         def call():
-            return native.selective_scan_bwd(u, delta, A, Bm, Cm, Dv, z, bias, dout, x, out, dz, True, True, ckpt=ck)
-        s_ = u.element_size()       # SURVEY 8(d) with the out_z recompute: 9 B D L s + 2 B N L (s + 4) + x
-        nbytes = 9 * B * D * L * s_ + 2 * B * N * L * (s_ + 4) + B * D * ((L + 2047) // 2048) * 2 * N * 4 + (D * N + 2 * D) * 4
+            return native.selective_scan_bwd(u, delta, A, Bm, Cm, Dv, z, bias, dout, x, out, dz, True, not a.no_out_z, ckpt=ck)
+        s_ = u.element_size()       # (8 + out_z recompute) B D L s + 2 B N L (s + 4) + x
+        nbytes = (8 if a.no_out_z else 9) * B * D * L * s_ + 2 * B * N * L * (s_ + 4) + B * D * ((L + 2047) // 2048) * 2 * N * 4 + (D * N + 2 * D) * 4
     else:
         def call():
             return native.selective_scan_fwd(u, delta, A, Bm, Cm, Dv, z, bias, True, need_ckpt=a.train_fwd)

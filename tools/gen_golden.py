@@ -348,6 +348,21 @@ def gen_block(ns):
                      f"{tag}_dc": ci.grad})
     save("block_combined", "DiMBlockCombined.forward (dimsum/models_dim.py:1055-1117) via create_block(:2001-2160), "
          "hidden 128, procedural weights seed 9", **arrs)
+    # the same at DiM-S/2's width (hidden 384: fusion head_dim 24, the smallest the MFMA attention kernels are built for),
+    # one batch row, the richest flag combination -- so that a GPU block test runs every HIP kernel incl. attention
+    hidden, B = 384, 1
+    x, res, c = T(seeded((B, L, hidden), 56)), T(seeded((B, L, hidden), 57)), T(seeded((B, hidden), 58))
+    gy, gr = T(seeded((B, L, hidden), 59)), T(seeded((B, L, hidden), 60))
+    blk = _mk_block(ns, hidden, True, True, True)
+    procedural_fill(blk, seed=9)
+    xi, ri, ci = x.clone().requires_grad_(), res.clone().requires_grad_(), c.clone().requires_grad_()
+    y, ro = blk(xi, ri, ci)
+    ((y * gy).sum() + (ro * gr).sum()).backward()
+    f16 = lambda t: t.detach().numpy().astype(np.float32)
+    save("block_combined_384", "DiMBlockCombined.forward + input grads (dimsum/models_dim.py:1055-1117), hidden 384, reverse / transpose / "
+         "continuity all on, procedural weights seed 9; inputs = seeded(56..60)", y=f16(y), res_out=f16(ro), dx=f16(xi.grad), dres=f16(ri.grad),
+         dc=f16(ci.grad), g_qkv1=f16(blk.proj.qkv1.weight.grad), g_A_log=f16(blk.spatial_mamba.mixer.A_log.grad),
+         g_norm2=f16(blk.norm_2.weight.grad))
 
 
 def _mk_model(ns, name, **over):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 counter passes for one scan kernel in isolation (GPU box). usage: tools/pmc_scan.sh <outdir> [bench_scan.py args]
 # One run per counter set (SQ: 8 slots, TCC: FETCH_SIZE and WRITE_SIZE need separate passes); kernel-trace only.
-out=$1; shift
+out=$1; shift; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
