@@ -17,7 +17,7 @@ Further legs on the same line (default `--mode all`; each is also a `--mode` of 
   cpu_baseline   the same forward on the host cores through the CPU oracle ("port"): 1 warm-up + 3 runs, median (N = 1)
 Every `roofline*` object: algorithmic bytes per launch (SURVEY.md 8d formula) / average launch duration of the scan
 kernel measured live with HIP events on the launch stream during that leg's timed steps; the kernel name comes from the
-library's own dispatch (dimsum_ssm_scan_fwd_variant); `traffic` (HBM bytes from rocprofv3 --pmc, profiles/*.json) is
+library's own dispatch (dimsum_ssm_scan_fwd_variant); `traffic` (HBM bytes from rocprofv3 --pmc, profiles/scan_pmc.json) is
 attached only when the timed launches have exactly the profiled shape and kernel, otherwise null.
 """
 import argparse
@@ -115,7 +115,7 @@ class ScanTimer:
         proxy = Timed()
         _lib.load = lambda: proxy
 
-    def roofline(self, which, pmc_json):
+    def roofline(self, which):
         """roofline object of the dominant (shape, kernel) class among the timed launches of `which`, or None"""
         recs = self.records[which]
         if not recs:
@@ -128,11 +128,11 @@ class ScanTimer:
         nbytes = rs[0][2]
         achieved = nbytes / (avg_ms * 1e-3) / 1e9
         traffic = None
-        prof = os.path.join(ROOT, "profiles", pmc_json)        # HBM bytes per launch from rocprofv3 --pmc
+        prof = os.path.join(ROOT, "profiles", "scan_pmc.json")         # HBM bytes per launch from rocprofv3 --pmc
         if os.path.exists(prof):
-            j = json.load(open(prof))
-            if tuple(j.get("shape_BDLN", ())) == shape and j.get("bench_kernel") == kernel:
-                traffic = j.get("hbm_bytes_per_launch")
+            for e in json.load(open(prof)).get("entries", []):
+                if tuple(e.get("shape_BDLN", ())) == shape and e.get("bench_kernel") == kernel:
+                    traffic = e.get("hbm_bytes_per_launch")
         return {"kernel": kernel, "shape_BDLN": list(shape), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": avg_ms,
                 "launches_timed": len(rs)}
@@ -268,7 +268,7 @@ class Bench:
                            + WEIGHTS + (f", scan_type={scan_type}" if scan_type != "none" else ""),
                "value": batch * self.world * steps / elapsed, "unit": "latents/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
                "warmup": warmup, "launch": "hipGraph replay" if a.hip_graph else "eager"}
-        rf = self.timer.roofline("fwd", "scan_fwd_pmc.json")
+        rf = self.timer.roofline("fwd")
         if rf is not None:
             out["roofline"] = rf
         if extra_precisions and self.world == 1 and a.matmul == "tf32" and not a.hip_graph:
@@ -308,8 +308,8 @@ class Bench:
         out = {"workload": f"ONE DiMBlockCombined({hidden}) of {model_name} (scan + Haar + attention fusion + gated MLP) forward+backward, "
                            f"{ntok} tokens, batch {batch}, " + WEIGHTS,
                "value": batch * self.world * steps / elapsed, "unit": "latents/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup}
-        for key, which, pmc in (("roofline", "fwd", "scan_fwd_train_pmc.json"), ("roofline_bwd", "bwd", "scan_bwd_pmc.json")):
-            rf = self.timer.roofline(which, pmc)
+        for key, which in (("roofline", "fwd"), ("roofline_bwd", "bwd")):
+            rf = self.timer.roofline(which)
             if rf is not None:
                 out[key] = rf
         del model, hs, res, cond, dy
@@ -334,7 +334,7 @@ class Bench:
                "value": batch * self.world / elapsed, "unit": "samples/s", "nfe": nfe, "s_per_batch": elapsed,
                "ms_per_nfe": 1e3 * elapsed / nfe, "gathered_shape": list(res["out"].shape), "finite": bool(torch.isfinite(res["out"]).all().item()),
                "launch": "hipGraph replay" if a.hip_graph else "eager"}
-        rf = self.timer.roofline("fwd", "scan_fwd_pmc.json")
+        rf = self.timer.roofline("fwd")
         if rf is not None:
             out["roofline"] = rf
         del model
@@ -353,7 +353,7 @@ class Bench:
         out = {"workload": f"{model_name} flow-matching training step (GVP velocity loss, backward, grad all-reduce, clip, AdamW, EMA), "
                            f"{batch} latents per GPU, " + WEIGHTS,
                "value": batch * self.world * steps / elapsed, "unit": "latents/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup}
-        rb = self.timer.roofline("bwd", "scan_bwd_pmc.json")
+        rb = self.timer.roofline("bwd")
         if rb is not None:
             out["roofline_bwd"] = rb
         return out

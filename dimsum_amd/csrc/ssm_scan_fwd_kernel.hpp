@@ -71,27 +71,20 @@ template <> struct UniformLd<__hip_bfloat16> {
     }
 };
 
-#ifndef DIMSUM_SCAN_TC
-#define DIMSUM_SCAN_TC 32
-#endif
-#ifndef DIMSUM_SCAN_WAVES
-#define DIMSUM_SCAN_WAVES (DIMSUM_SCAN_TC == 16 ? 3 : 2)      // waves per SIMD the register allocation aims at
-#endif
-constexpr int kTC = DIMSUM_SCAN_TC;   // time steps per LDS tile: 32 (128-B row segments, 20 KB of LDS per wave = 2 waves per SIMD).
-                                      // 16 (64-B segments, 10 KB, 143 VGPRs = 3 waves per SIMD) was measured SLOWER at the
-                                      // config-2 shape (0.40-0.43 ms vs 0.36 ms): twice the per-tile work (staging, softplus,
-                                      // epilogue) outweighs the extra occupancy; the knob stays for other shapes.
+constexpr int kTC = 32;               // time steps per LDS tile: 128-B row segments, 20 KB of LDS per wave = 2 waves per SIMD.
+                                      // (16: 64-B segments, 10 KB, 143 VGPRs = 3 waves per SIMD, was measured SLOWER at the config-2
+                                      // shape, 0.40-0.43 ms vs 0.36 ms: twice the per-tile work outweighs the extra occupancy.)
+constexpr int kScanWaves = 2;         // waves per SIMD the register allocation aims at
 constexpr int kLdsStride = kTC;       // dwords per tile row (unpadded; 16-byte slots are XOR-swizzled instead)
 constexpr int kLPR = kTC / 4;         // lanes per tile row in the coalesced load layout (16 B each)
 constexpr int kRPP = kWave / kLPR;    // rows per load piece
 constexpr int kNP = kWave / kRPP;     // pieces per 64-row tile
-static_assert(kTC == 32 || kTC == 16, "tile width");
 
-// LDS image of a 64-row x kTC-column fp32 tile: row r keeps its 16-byte slots XOR-permuted -- 8 slots by (r >> 1) & 7
-// (kTC = 32), 4 slots by (r >> 2) & 3 (kTC = 16). ds_write_b128 in load layout (kLPR lanes = one row) and ds_read_b128 in
-// lane = row layout are both bank-conflict free, with no padding.
+// LDS image of a 64-row x 32-column fp32 tile: row r keeps its eight 16-byte slots XOR-permuted by (r >> 1) & 7.
+// ds_write_b128 in load layout (kLPR lanes = one row) and ds_read_b128 in lane = row layout are both bank-conflict
+// free, with no padding.
 __device__ __forceinline__ int tile_off(int row, int col4) {
-    return kTC == 32 ? row * kLdsStride + ((col4 ^ ((row >> 1) & 7)) << 2) : row * kLdsStride + ((col4 ^ ((row >> 2) & 3)) << 2);
+    return row * kLdsStride + ((col4 ^ ((row >> 1) & 7)) << 2);
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -107,7 +100,7 @@ template <typename T> __device__ __forceinline__ T *at(T *base, unsigned elem_of
 // kVec : every row base is 4-element aligned and L % 4 == 0 -> 16-byte (fp32) vector I/O, register-staged prefetch.
 // kFull: dim/n_groups % 64 == 0 -> all 64 lanes own a live channel, no row masks anywhere (needs kVec).
 template <typename T, int kN, bool kHasZ, bool kVec, bool kFull, bool kCkpt = false>
-__global__ __launch_bounds__(kWave, DIMSUM_SCAN_WAVES) void ssm_scan_fwd_kernel(const dimsum_ssm_params_t p) {
+__global__ __launch_bounds__(kWave, kScanWaves) void ssm_scan_fwd_kernel(const dimsum_ssm_params_t p) {
     static_assert(!kFull || kVec, "kFull implies kVec");
     __shared__ __attribute__((aligned(16))) float tileU[kWave * kLdsStride];
     __shared__ __attribute__((aligned(16))) float tileD[kWave * kLdsStride];
@@ -248,10 +241,7 @@ __global__ __launch_bounds__(kWave, DIMSUM_SCAN_WAVES) void ssm_scan_fwd_kernel(
             const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&tileD[tile_off(lane, j)]);
             // software-pipelined broadcast reads: B/C of states n+1 .. n+kPD are in flight while state n is computed (2 ahead
             // measured 0.306 ms in situ against 0.308-0.321 with 1)
-#ifndef DIMSUM_SCAN_PD
-#define DIMSUM_SCAN_PD 2
-#endif
-            constexpr int kPD = DIMSUM_SCAN_PD < kN ? DIMSUM_SCAN_PD : kN - 1;
+            constexpr int kPD = 2 < kN ? 2 : kN - 1;
             f32x4 bq_pipe[kPD], cq_pipe[kPD];
 #pragma unroll
             for (int i = 0; i < kPD; ++i) {

@@ -1,0 +1,34 @@
+#!/bin/bash
+# tools/profile_round.sh <tag>  (GPU box): the rocprofv3 evidence of one round, written under gpurun_out/profiles_<tag>/.
+#   kernel-trace + stats of the bench legs (per-kernel average durations), and --pmc passes (kernel-trace only, one
+#   counter set per run) of the scan kernels in isolation at the bench's launch shapes. Copy what should be judged
+#   into profiles/ (see profiles/README.md).
+tag=${1:-rXX}
+out=$GRAFT_REPO_ROOT/gpurun_out/profiles_$tag; mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+stats() {   # stats <name> <bench args...>
+  name=$1; shift
+  rm -rf /tmp/prof_$name
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python3 bench.py "$@" > $out/${name}.log 2>&1
+  f=$(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && python3 - "$f" "$out/${tag}_${name}_kernel_stats.csv" <<'P'
+import csv, sys
+rows = list(csv.reader(open(sys.argv[1])))
+w = csv.writer(open(sys.argv[2], "w"))
+for r in rows:
+    w.writerow([c[:200] for c in r])          # kernel names truncated to 200 chars
+P
+  tail -1 $out/${name}.log | cut -c1-300
+}
+stats fwd --mode fwd --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg
+stats block --mode block --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg
+stats xl512 --mode xl512 --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg
+stats all --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg --nfe 10
+# PMC: forward (inference), forward + saved states, backward (as dimsum_amd.ops calls it: no out_z recompute; and with it), config-5 forward
+bash tools/pmc_scan.sh $out/pmc_fwd --dmajor > $out/${tag}_scan_fwd_pmc.txt 2>&1
+bash tools/pmc_scan.sh $out/pmc_fwd_train --dmajor --train-fwd > $out/${tag}_scan_fwd_train_pmc.txt 2>&1
+bash tools/pmc_scan.sh $out/pmc_bwd --dmajor --bwd --no-out-z > $out/${tag}_scan_bwd_pmc.txt 2>&1
+bash tools/pmc_scan.sh $out/pmc_bwd_oz --dmajor --bwd > $out/${tag}_scan_bwd_outz_pmc.txt 2>&1
+bash tools/pmc_scan.sh $out/pmc_fwd_xl --dmajor --B 64 --D 1152 --L 1024 > $out/${tag}_scan_fwd_xl512_pmc.txt 2>&1
+rm -rf $out/pmc_fwd $out/pmc_fwd_train $out/pmc_bwd $out/pmc_bwd_oz $out/pmc_fwd_xl     # raw csv trees: only the summaries travel back
+ls -la $out
