@@ -5,7 +5,9 @@
 
 namespace dimsum {
 
-template <typename T> int ssm_scan_fwd_dispatch(const dimsum_ssm_params_t &p, hipStream_t stream);   // ssm_scan_fwd_{f32,f16,bf16}.hip
+// kernel launchers, instantiated in ssm_scan_fwd_{f32,f16,bf16}.hip / ssm_scan_fwd_split_{f32,f16,bf16}.hip
+template <typename T, int kN> void ssm_scan_fwd_launch_v0(const dimsum_ssm_params_t &p, hipStream_t stream, int tiles, bool vec, bool full);
+template <typename T, int kN, int kSP> void ssm_scan_fwd_launch_split(const dimsum_ssm_params_t &p, hipStream_t stream, int tiles, bool vec, bool full);
 
 int ssm_check(const dimsum_ssm_params_t *p, bool forward) {
     if (!p || !p->A_ptr || !p->B_ptr || !p->C_ptr || !p->u_ptr || !p->delta_ptr) return DIMSUM_ERR_NULL;
@@ -35,6 +37,51 @@ int ssm_scan_fwd_variant(const dimsum_ssm_params_t &p) {
     if (waves >= 2048) return 0;
     if (variant_ok(p, 4)) return 4;
     return variant_ok(p, 2) ? 2 : 0;
+}
+
+template <typename T, int kN>
+static int launch_fwd(const dimsum_ssm_params_t &p, hipStream_t stream) {
+    const int dpg = p.dim / p.n_groups;
+    const int sp = ssm_scan_fwd_variant(p);                // 0, 2 or 4
+    const int cpw = sp == 0 ? kWave : kWave / sp;          // channels per wave
+    const int tiles = p.batch * p.n_groups * ((dpg + cpw - 1) / cpw);
+    const size_t va = 4 * sizeof(T);  // vector path: every row base 4-element aligned
+    bool vec = (p.seqlen % 4 == 0) && aligned_to<T>(p.u_ptr, va) && aligned_to<T>(p.delta_ptr, va) &&
+               aligned_to<T>(p.B_ptr, va) && aligned_to<T>(p.C_ptr, va) && (p.u_batch_stride % 4 == 0) &&
+               (p.u_d_stride % 4 == 0) && (p.delta_batch_stride % 4 == 0) && (p.delta_d_stride % 4 == 0) &&
+               (p.B_batch_stride % 4 == 0) && (p.B_group_stride % 4 == 0) && (p.B_dstate_stride % 4 == 0) &&
+               (p.C_batch_stride % 4 == 0) && (p.C_group_stride % 4 == 0) && (p.C_dstate_stride % 4 == 0);
+    if (p.out_ptr) vec = vec && aligned_to<T>(p.out_ptr, va) && (p.out_batch_stride % 4 == 0) && (p.out_d_stride % 4 == 0);
+    if (p.z_ptr)
+        vec = vec && aligned_to<T>(p.z_ptr, va) && aligned_to<T>(p.out_z_ptr, va) && (p.z_batch_stride % 4 == 0) &&
+              (p.z_d_stride % 4 == 0) && (p.out_z_batch_stride % 4 == 0) && (p.out_z_d_stride % 4 == 0);
+    if (p.x_ptr && !aligned_to<float>(p.x_ptr, 16)) return DIMSUM_ERR_STRIDE;
+    // In-tile offsets are 32-bit BYTE offsets (saddr + voffset addressing): the farthest element of a tile is
+    // (channels_per_wave - 1) * d_stride + seqlen elements from the tile base.
+    if (!offsets_fit_32bit<T>(p.seqlen, kWave, {p.u_d_stride, p.delta_d_stride, p.out_ptr ? p.out_d_stride : 0, p.z_ptr ? p.z_d_stride : 0,
+                                                p.z_ptr ? p.out_z_d_stride : 0}) ||
+        !offsets_fit_32bit<T>(p.seqlen, p.dstate, {p.B_dstate_stride, p.C_dstate_stride}))
+        return DIMSUM_ERR_STRIDE;
+    const bool full = vec && (dpg % cpw == 0);
+    if (sp == 4) {
+        if constexpr (kN % 8 == 0) ssm_scan_fwd_launch_split<T, kN, 4>(p, stream, tiles, vec, full);
+    } else if (sp == 2) {
+        ssm_scan_fwd_launch_split<T, kN, 2>(p, stream, tiles, vec, full);
+    } else {
+        ssm_scan_fwd_launch_v0<T, kN>(p, stream, tiles, vec, full);
+    }
+    return launch_status();
+}
+
+template <typename T>
+static int ssm_scan_fwd_dispatch(const dimsum_ssm_params_t &p, hipStream_t stream) {
+    switch (p.dstate) {
+        case 4: return launch_fwd<T, 4>(p, stream);
+        case 8: return launch_fwd<T, 8>(p, stream);
+        case 32: return launch_fwd<T, 32>(p, stream);
+        case 16: return launch_fwd<T, 16>(p, stream);
+        default: return DIMSUM_ERR_SHAPE;
+    }
 }
 
 }  // namespace dimsum

@@ -1,7 +1,7 @@
-// selective-scan forward, f32 I/O instantiations (see ssm_scan_fwd_kernel.hpp)
+// selective-scan forward, f32 I/O: the 64-channels-per-wave kernel (ssm_scan_fwd_kernel.hpp). One translation unit per dtype
+// and kernel family: the scheduled inner blocks make every instantiation slow to compile.
 #include "ssm_scan_fwd_kernel.hpp"
 
 namespace dimsum {
-template int ssm_scan_fwd_dispatch<float>(const dimsum_ssm_params_t &, hipStream_t);
+DIMSUM_INSTANTIATE_FWD_V0(float)
 }  // namespace dimsum
-

@@ -1,6 +1,7 @@
-// ssm_scan_fwd_kernel.hpp -- selective scan (Mamba S6) forward for gfx950: the kernel template and its launcher.
+// ssm_scan_fwd_kernel.hpp -- selective scan (Mamba S6) forward for gfx950: the 64-channels-per-wave kernel and its launcher.
 // Instantiated per I/O dtype in ssm_scan_fwd_{f32,f16,bf16}.hip (separate translation units: the scheduled inner
-// block makes each instantiation slow to compile); C entry point in ssm_scan_fwd.hip.
+// block makes each instantiation slow to compile); the state-split kernels live in ssm_scan_fwd_split.hpp /
+// ssm_scan_fwd_split_{f32,f16,bf16}.hip; checks, kernel choice and the C entry point in ssm_scan_fwd.hip.
 //
 // Replaces selective_scan_cuda.fwd (mamba/csrc/selective_scan/selective_scan.cpp:226-336; kernel
 // selective_scan_fwd_kernel.cuh:67-303). Math per (batch b, channel d) row:
@@ -328,52 +329,15 @@ __global__ __launch_bounds__(kWave, kScanWaves) void ssm_scan_fwd_kernel(const d
     }
 }
 
-}  // namespace dimsum
-
-#include "ssm_scan_fwd_split.hpp"   // the state-split variant (32 channels per wave, lane = (channel, state half))
-
-namespace dimsum {
-
-int ssm_scan_fwd_variant(const dimsum_ssm_params_t &p);   // ssm_scan_fwd.hip: 0 = 64 channels per wave, 2 / 4 = lanes per channel
-
+// ---- launchers of this kernel: defined here, explicitly instantiated per I/O dtype in ssm_scan_fwd_{f32,f16,bf16}.hip, called
+// by the dispatch in ssm_scan_fwd.hip (the split kernels' launcher lives in ssm_scan_fwd_split.hpp the same way) -----------
 template <typename T, int kN>
-static int launch_fwd(const dimsum_ssm_params_t &p, hipStream_t stream) {
-    const int dpg = p.dim / p.n_groups;
-    const int sp = ssm_scan_fwd_variant(p);                // 0, 2 or 4
-    const int cpw = sp == 0 ? kWave : kWave / sp;          // channels per wave
-    const int tiles = p.batch * p.n_groups * ((dpg + cpw - 1) / cpw);
-    const size_t va = 4 * sizeof(T);  // vector path: every row base 4-element aligned
-    bool vec = (p.seqlen % 4 == 0) && aligned_to<T>(p.u_ptr, va) && aligned_to<T>(p.delta_ptr, va) &&
-               aligned_to<T>(p.B_ptr, va) && aligned_to<T>(p.C_ptr, va) && (p.u_batch_stride % 4 == 0) &&
-               (p.u_d_stride % 4 == 0) && (p.delta_batch_stride % 4 == 0) && (p.delta_d_stride % 4 == 0) &&
-               (p.B_batch_stride % 4 == 0) && (p.B_group_stride % 4 == 0) && (p.B_dstate_stride % 4 == 0) &&
-               (p.C_batch_stride % 4 == 0) && (p.C_group_stride % 4 == 0) && (p.C_dstate_stride % 4 == 0);
-    if (p.out_ptr) vec = vec && aligned_to<T>(p.out_ptr, va) && (p.out_batch_stride % 4 == 0) && (p.out_d_stride % 4 == 0);
-    if (p.z_ptr)
-        vec = vec && aligned_to<T>(p.z_ptr, va) && aligned_to<T>(p.out_z_ptr, va) && (p.z_batch_stride % 4 == 0) &&
-              (p.z_d_stride % 4 == 0) && (p.out_z_batch_stride % 4 == 0) && (p.out_z_d_stride % 4 == 0);
-    if (p.x_ptr && !aligned_to<float>(p.x_ptr, 16)) return DIMSUM_ERR_STRIDE;
-    // In-tile offsets are 32-bit BYTE offsets (saddr + voffset addressing): the farthest element of a tile is
-    // (channels_per_wave - 1) * d_stride + seqlen elements from the tile base.
-    if (!offsets_fit_32bit<T>(p.seqlen, kWave, {p.u_d_stride, p.delta_d_stride, p.out_ptr ? p.out_d_stride : 0, p.z_ptr ? p.z_d_stride : 0,
-                                                p.z_ptr ? p.out_z_d_stride : 0}) ||
-        !offsets_fit_32bit<T>(p.seqlen, p.dstate, {p.B_dstate_stride, p.C_dstate_stride}))
-        return DIMSUM_ERR_STRIDE;
-    const bool full = vec && (dpg % cpw == 0);
-    dim3 grid(tiles), block(kWave);
-#define DIMSUM_LAUNCH_V(KERNEL, ...)                                                                       \
-    do {                                                                                                    \
-        if (p.ckpt_ptr) hipLaunchKernelGGL((KERNEL<T, kN, __VA_ARGS__, true>), grid, block, 0, stream, p);  \
-        else hipLaunchKernelGGL((KERNEL<T, kN, __VA_ARGS__, false>), grid, block, 0, stream, p);            \
-    } while (0)
-#define DIMSUM_LAUNCH(HASZ, VEC, FULL)                                                                      \
-    do {                                                                                                    \
-        if (sp == 4) {                                                                                      \
-            if constexpr (kN % 8 == 0) DIMSUM_LAUNCH_V(ssm_scan_fwd_split_kernel, 4, HASZ, VEC, FULL);      \
-        } else if (sp == 2) {                                                                               \
-            if constexpr (kN % 4 == 0) DIMSUM_LAUNCH_V(ssm_scan_fwd_split_kernel, 2, HASZ, VEC, FULL);      \
-        } else                                                                                              \
-            DIMSUM_LAUNCH_V(ssm_scan_fwd_kernel, HASZ, VEC, FULL);                                          \
+void ssm_scan_fwd_launch_v0(const dimsum_ssm_params_t &p, hipStream_t stream, int tiles, bool vec, bool full) {
+    const dim3 grid(tiles), block(kWave);
+#define DIMSUM_LAUNCH(HASZ, VEC, FULL)                                                                                        \
+    do {                                                                                                                       \
+        if (p.ckpt_ptr) hipLaunchKernelGGL((ssm_scan_fwd_kernel<T, kN, HASZ, VEC, FULL, true>), grid, block, 0, stream, p);    \
+        else hipLaunchKernelGGL((ssm_scan_fwd_kernel<T, kN, HASZ, VEC, FULL, false>), grid, block, 0, stream, p);              \
     } while (0)
     if (p.z_ptr) {
         if (full) DIMSUM_LAUNCH(true, true, true);
@@ -385,20 +349,12 @@ static int launch_fwd(const dimsum_ssm_params_t &p, hipStream_t stream) {
         else DIMSUM_LAUNCH(false, false, false);
     }
 #undef DIMSUM_LAUNCH
-#undef DIMSUM_LAUNCH_V
-    return launch_status();
 }
 
-template <typename T>
-int ssm_scan_fwd_dispatch(const dimsum_ssm_params_t &p, hipStream_t stream) {
-    switch (p.dstate) {
-        case 4: return launch_fwd<T, 4>(p, stream);
-        case 8: return launch_fwd<T, 8>(p, stream);
-        case 32: return launch_fwd<T, 32>(p, stream);
-        case 16: return launch_fwd<T, 16>(p, stream);
-        default: return DIMSUM_ERR_SHAPE;
-    }
-}
-
+#define DIMSUM_INSTANTIATE_FWD_V0(T)                                                                                \
+    template void ssm_scan_fwd_launch_v0<T, 4>(const dimsum_ssm_params_t &, hipStream_t, int, bool, bool);           \
+    template void ssm_scan_fwd_launch_v0<T, 8>(const dimsum_ssm_params_t &, hipStream_t, int, bool, bool);           \
+    template void ssm_scan_fwd_launch_v0<T, 16>(const dimsum_ssm_params_t &, hipStream_t, int, bool, bool);          \
+    template void ssm_scan_fwd_launch_v0<T, 32>(const dimsum_ssm_params_t &, hipStream_t, int, bool, bool);
 
 }  // namespace dimsum

@@ -15,7 +15,8 @@
 //   * y_t = sum over the lane's states; the parts are joined by a transposed exchange per 4-step group:
 //     kSP = 2: one v_permlane32_swap + add per PAIR of steps (low lane keeps steps 0, 2, high lane steps 1, 3);
 //     kSP = 4: v_permlane32_swap then v_permlane16_swap, 3 swaps + 3 adds per 4 steps: quarter q ends up with step q.
-#pragma once   // included by ssm_scan_fwd_kernel.hpp (uses its helpers: at(), Raw4, softplus_if, ...)
+#pragma once
+#include "ssm_scan_fwd_kernel.hpp"   // helpers: at(), Raw4, softplus_if, ... (its kernel template is not instantiated by the split units)
 
 namespace dimsum {
 
@@ -281,5 +282,35 @@ __global__ __launch_bounds__(kWave, (kSP == 4 && kN <= 16) ? 5 : 3) void ssm_sca
         }
     }
 }
+
+// ---- launcher: explicitly instantiated per I/O dtype in ssm_scan_fwd_split_{f32,f16,bf16}.hip ---------------------------------
+template <typename T, int kN, int kSP>
+void ssm_scan_fwd_launch_split(const dimsum_ssm_params_t &p, hipStream_t stream, int tiles, bool vec, bool full) {
+    const dim3 grid(tiles), block(kWave);
+#define DIMSUM_LAUNCH(HASZ, VEC, FULL)                                                                                               \
+    do {                                                                                                                              \
+        if (p.ckpt_ptr) hipLaunchKernelGGL((ssm_scan_fwd_split_kernel<T, kN, kSP, HASZ, VEC, FULL, true>), grid, block, 0, stream, p); \
+        else hipLaunchKernelGGL((ssm_scan_fwd_split_kernel<T, kN, kSP, HASZ, VEC, FULL, false>), grid, block, 0, stream, p);           \
+    } while (0)
+    if (p.z_ptr) {
+        if (full) DIMSUM_LAUNCH(true, true, true);
+        else if (vec) DIMSUM_LAUNCH(true, true, false);
+        else DIMSUM_LAUNCH(true, false, false);
+    } else {
+        if (full) DIMSUM_LAUNCH(false, true, true);
+        else if (vec) DIMSUM_LAUNCH(false, true, false);
+        else DIMSUM_LAUNCH(false, false, false);
+    }
+#undef DIMSUM_LAUNCH
+}
+
+#define DIMSUM_INSTANTIATE_FWD_SPLIT(T)                                                                                   \
+    template void ssm_scan_fwd_launch_split<T, 4, 2>(const dimsum_ssm_params_t &, hipStream_t, int, bool, bool);           \
+    template void ssm_scan_fwd_launch_split<T, 8, 2>(const dimsum_ssm_params_t &, hipStream_t, int, bool, bool);           \
+    template void ssm_scan_fwd_launch_split<T, 16, 2>(const dimsum_ssm_params_t &, hipStream_t, int, bool, bool);          \
+    template void ssm_scan_fwd_launch_split<T, 32, 2>(const dimsum_ssm_params_t &, hipStream_t, int, bool, bool);          \
+    template void ssm_scan_fwd_launch_split<T, 8, 4>(const dimsum_ssm_params_t &, hipStream_t, int, bool, bool);           \
+    template void ssm_scan_fwd_launch_split<T, 16, 4>(const dimsum_ssm_params_t &, hipStream_t, int, bool, bool);          \
+    template void ssm_scan_fwd_launch_split<T, 32, 4>(const dimsum_ssm_params_t &, hipStream_t, int, bool, bool);
 
 }  // namespace dimsum

@@ -1,0 +1,6 @@
+// selective-scan forward, f32 I/O: the state-split kernels, 2 and 4 lanes per channel (ssm_scan_fwd_split.hpp)
+#include "ssm_scan_fwd_split.hpp"
+
+namespace dimsum {
+DIMSUM_INSTANTIATE_FWD_SPLIT(float)
+}  // namespace dimsum
