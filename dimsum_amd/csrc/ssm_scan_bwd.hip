@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
     const int nd = kFull ? kBC : max(0, min(kBC, (g + 1) * dpg - d0));              // live channels of this wave (0: idle wave)
     const bool wave_live = kFull || nd > 0;
     const bool live = kFull || c < nd;
-    const int d = d0 + (kFull ? c : max(0, min(c, nd - 1)));
+    const int d = kFull ? d0 + c : min(d0 + max(0, min(c, nd - 1)), p.dim - 1);      // (an idle wave's d0 may lie beyond dim: clamp its reads)
 
     const T *u_base = reinterpret_cast<const T *>(p.u_ptr) + (int64_t)b * p.u_batch_stride + (int64_t)d0 * p.u_d_stride;
     const T *dl_base = reinterpret_cast<const T *>(p.delta_ptr) + (int64_t)b * p.delta_batch_stride + (int64_t)d0 * p.delta_d_stride;
