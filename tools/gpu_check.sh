@@ -1,13 +1,13 @@
 #!/bin/bash
-# round-2 GPU pass F: whole gpu suite + smoke, then the default bench line
-out=gpurun_out/r2f; mkdir -p $out
+# tools/gpu_check.sh (GPU box, e.g. `gpurun -- bash tools/gpu_check.sh`): the whole -m gpu suite, smoke(), then the driver-run bench line
+out=gpurun_out/check; mkdir -p $out
 python -m pytest tests -q -m gpu --timeout 900 > $out/pytest.log 2>&1; echo "pytest rc=$?"
 tail -12 $out/pytest.log
 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; tail -2 $out/smoke.log
 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench.log 2> $out/bench.err; echo "bench rc=$?"
 python - <<'P'
 import json
-d=json.loads(open("gpurun_out/r2f/bench.log").read().strip().splitlines()[-1])
+d=json.loads(open("gpurun_out/check/bench.log").read().strip().splitlines()[-1])
 print("fwd", d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["avg_launch_ms"])
 print("sample", d["sample_250nfe"]["value"], d["sample_250nfe"]["s_per_batch"])
 b=d["block_fwdbwd"]; print("block", b["ms_per_step"], b["roofline"]["avg_launch_ms"], b["roofline_bwd"]["avg_launch_ms"], b["roofline_bwd"]["frac"], b["roofline_bwd"]["kernel"])
