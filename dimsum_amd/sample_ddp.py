@@ -49,6 +49,20 @@ def sample_batch(model, z, y, num_steps=250, sampling_method="euler", cfg_scale=
     return out
 
 
+def load_denoiser_weights(model, path):
+    """Loads a checkpoint the way the reference's samplers do (dimsum/download.py:17-37 `find_model`, sample_ddp.py:96-103):
+    either a bare state_dict or the training container of train.py:355-373 -- {"model", "ema", "opt", "args", "epoch",
+    "train_steps"} with "args" an argparse.Namespace -- from which the EMA weights are preferred. Strict key match: the
+    module tree has the reference's state_dict keys, incl. the numerically dead cond_proj tensors (SURVEY finding 1).
+    The container is a pickle (Namespace): not loadable under torch >= 2.6's weights_only default; checkpoints are trusted
+    input here, as in the reference."""
+    sd = torch.load(path, map_location="cpu", weights_only=False)
+    if isinstance(sd, dict) and ("ema" in sd or "model" in sd):
+        sd = sd.get("ema", sd.get("model"))
+    model.load_state_dict(sd, strict=True)
+    return model
+
+
 def shard_range(total, rank, world):
     """indices [lo, hi) of the global sample list owned by `rank` (contiguous, remainder to the first ranks)"""
     base, rem = divmod(total, world)
@@ -87,10 +101,7 @@ def main(argv=None):
     torch.manual_seed(args.global_seed * world + rank)
     model = create_model(published_config(args.model, args.image_size, args.num_classes)).to(device).eval()
     if args.ckpt:
-        # the reference's container stores "args" as an argparse.Namespace (train.py:355-373): not loadable under
-        # torch >= 2.6's weights_only default. Checkpoints are trusted input here, as in the reference (download.py:17-37).
-        sd = torch.load(args.ckpt, map_location="cpu", weights_only=False)
-        model.load_state_dict(sd.get("ema", sd.get("model", sd)), strict=True)     # EMA preferred (download.py:26-27)
+        load_denoiser_weights(model, args.ckpt)                  # EMA preferred (download.py:26-27)
     r = args.image_size // 8
     n_iter = -(-args.num_fid_samples // (args.per_proc_batch_size * world))
     chunks = []

@@ -99,3 +99,24 @@ def test_two_rank_ddp_step():
     (_, l0, w0, g0), (_, l1, w1, g1) = res
     assert l0 != l1                                   # different data per rank
     assert (g0 == g1).all() and (w0 == w1).all() and g0.any()      # all-reduced gradients -> identical replicas
+
+
+def test_sampler_loads_reference_style_container(tmp_path):
+    """the reference's training container (train.py:355-373) stores `args` as an argparse.Namespace and both "model" and
+    "ema"; its samplers take the EMA weights (download.py:26-27). A bare state_dict loads too; a wrong key set is refused."""
+    import argparse
+    from dimsum_amd.sample_ddp import load_denoiser_weights
+    m, e = _tiny(0), _tiny(1)
+    path = tmp_path / "content.pth"
+    torch.save({"epoch": 3, "train_steps": 10, "args": argparse.Namespace(model="tiny", lr=1e-4), "model": m.state_dict(),
+                "opt": {}, "ema": e.state_dict()}, path)
+    got = load_denoiser_weights(_tiny(2), str(path))
+    assert all(torch.equal(a, b) for a, b in zip(got.state_dict().values(), e.state_dict().values()))      # EMA, not "model"
+    torch.save(m.state_dict(), path)
+    got = load_denoiser_weights(_tiny(2), str(path))
+    assert all(torch.equal(a, b) for a, b in zip(got.state_dict().values(), m.state_dict().values()))
+    bad = dict(m.state_dict())
+    bad.pop(next(iter(bad)))
+    torch.save(bad, path)
+    with pytest.raises(RuntimeError):
+        load_denoiser_weights(_tiny(2), str(path))
