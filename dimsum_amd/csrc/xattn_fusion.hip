@@ -267,14 +267,39 @@ __global__ __launch_bounds__(256, (QT == 2 && HD <= 64) ? 3 : (QT == 2 ? 2 : 1))
         for (int e = 0; e < ET; ++e) o[t][e] = f4{0.f, 0.f, 0.f, 0.f};
     }
 
+    // K / V rows of a 64-key tile: one work item = 2 keys x 4 e of K and of V (4 float4 loads). With the 256-VGPR budget of
+    // the wide-head / two-tile variant the NEXT tile's rows are requested right after the current tile has been staged, so
+    // their HBM / L2 latency flies under the tile's MFMA + softmax work (register-staged double buffer, like the dk/dv
+    // backward kernel); the 168-VGPR variants (3 workgroups per CU cover the latency) load where they stage.
+    constexpr bool kPF = QT == 2 && HD > 64;
+    constexpr bool kPFK = false;                  // (K rows only for the 168-VGPR variants: 40-44 B of scratch per lane -- not worth it)
+    constexpr int kItems = (kKT / 2) * (HD / 4), kIters = (kItems + 255) / 256;
+    float4 rka[kIters], rkb[kIters], rva[kIters], rvb[kIters];
+    auto issue_one = [&](int k0, int it, bool want_k, bool want_v) {
+        const int i = tid + it * 256;
+        if (kItems % 256 == 0 || i < kItems) {
+            const int kp = i / (HD / 4), e4 = i - kp * (HD / 4), key = 2 * kp;
+            const int tok0 = min(k0 + key, L - 1), tok1 = min(k0 + key + 1, L - 1);
+            if (want_k) { rka[it] = *reinterpret_cast<const float4 *>(ksrc + (int64_t)tok0 * ts + e4 * 4); rkb[it] = *reinterpret_cast<const float4 *>(ksrc + (int64_t)tok1 * ts + e4 * 4); }
+            if (want_v) { rva[it] = *reinterpret_cast<const float4 *>(vsrc + (int64_t)tok0 * ts + e4 * 4); rvb[it] = *reinterpret_cast<const float4 *>(vsrc + (int64_t)tok1 * ts + e4 * 4); }
+        }
+    };
+    auto issue_kv = [&](int k0, bool want_v) {
+#pragma unroll
+        for (int it = 0; it < kIters; ++it) issue_one(k0, it, true, want_v);
+    };
+    if constexpr (kPF || kPFK) issue_kv(0, kPF);
+
     for (int k0 = 0; k0 < L; k0 += kKT) {
         __syncthreads();
         // ---- stage K [key][e] and V^T [e][pi(key)] (hi / lo bf16 images) for keys k0 .. k0+63; one thread = 2 keys x 4 e -----
-        for (int i = tid; i < (kKT / 2) * (HD / 4); i += 256) {
+#pragma unroll
+        for (int it = 0; it < kIters; ++it) {
+            const int i = tid + it * 256;
+            if (kItems % 256 != 0 && i >= kItems) continue;
+            if constexpr (!kPF) issue_one(k0, it, !kPFK, true);
             const int kp = i / (HD / 4), e4 = i - kp * (HD / 4), key = 2 * kp;
-            const int tok0 = min(k0 + key, L - 1), tok1 = min(k0 + key + 1, L - 1);
-            float4 ka = *reinterpret_cast<const float4 *>(ksrc + (int64_t)tok0 * ts + e4 * 4), kb = *reinterpret_cast<const float4 *>(ksrc + (int64_t)tok1 * ts + e4 * 4);
-            float4 va = *reinterpret_cast<const float4 *>(vsrc + (int64_t)tok0 * ts + e4 * 4), vb = *reinterpret_cast<const float4 *>(vsrc + (int64_t)tok1 * ts + e4 * 4);
+            float4 ka = rka[it], kb = rkb[it], va = rva[it], vb = rvb[it];
             if (kbias) {
                 const float4 bk = *reinterpret_cast<const float4 *>(kbias + e4 * 4), bv = *reinterpret_cast<const float4 *>(vbias + e4 * 4);
                 ka.x += bk.x; ka.y += bk.y; ka.z += bk.z; ka.w += bk.w; kb.x += bk.x; kb.y += bk.y; kb.z += bk.z; kb.w += bk.w;
@@ -298,6 +323,7 @@ __global__ __launch_bounds__(256, (QT == 2 && HD <= 64) ? 3 : (QT == 2 ? 2 : 1))
             }
         }
         __syncthreads();
+        if constexpr (kPF || kPFK) if (k0 + kKT < L) issue_kv(k0 + kKT, kPF);      // flies under the MFMA + softmax work below
 
         // ---- S^T = K Q^T for the 4 key tiles of 16: 3 bf16 MFMAs per 32-deep chunk and query tile ------------------------
         f4 s[QT][4];
