@@ -127,6 +127,21 @@ class LabelEmbedder(nn.Module):
         return self.in_channels
 
 
+def _ln_modulate(norm, x, shift, scale):
+    """modulate(LayerNorm(x), shift, scale) for the affine-free LayerNorms of DiTBlock / FinalLayer (models_dim.py:1536-1553,
+    214-219). Inference on the GPU: ONE pass of the fused norm kernel (csrc/norm.hip with the modulation folded in) instead of
+    torch's LayerNorm followed by a modulate pass; under autograd the two-step form, whose pieces have backward kernels."""
+    if torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32 or norm.weight is not None:
+        return None
+    from . import native
+    B, L, H = x.shape
+    ones = norm.__dict__.get("_dimsum_ones")
+    if ones is None or ones.device != x.device:
+        ones = norm.__dict__["_dimsum_ones"] = torch.ones(H, device=x.device, dtype=torch.float32)
+    y = native.layer_norm_fwd(x.reshape(B * L, H), ones, None, norm.eps, is_rms_norm=False, mod_scale=scale, mod_shift=shift, rows_per_batch=L)[0]
+    return y.view(B, L, H)
+
+
 class FinalLayer(nn.Module):
     def __init__(self, hidden_size, patch_size, out_channels):
         super().__init__()
@@ -136,7 +151,8 @@ class FinalLayer(nn.Module):
 
     def forward(self, x, c):
         shift, scale = self.adaLN_modulation(c).chunk(2, dim=1)
-        return self.linear(modulate(self.norm_final(x), shift, scale))
+        h = _ln_modulate(self.norm_final, x, shift, scale)
+        return self.linear(modulate(self.norm_final(x), shift, scale) if h is None else h)
 
 
 class Attention(nn.Module):
@@ -446,9 +462,16 @@ class DiTBlock(nn.Module):
 
     def forward(self, x, c=None, **kwargs):
         sa, ca, ga, sm, cm, gm = self.adaLN_modulation(c).chunk(6, dim=1)
-        a, ab = self.attn.forward_deferred(token_ops.pre_mixer(self.norm1(x), "none", None, sa, ca))
+        h = _ln_modulate(self.norm1, x, sa, ca)
+        a, ab = self.attn.forward_deferred(token_ops.pre_mixer(self.norm1(x), "none", None, sa, ca) if h is None else h)
         x = token_ops.gate_residual(x, a, ga, ab)
-        return _mlp_tail(self.mlp, x, self.norm2(x), sm, cm, gm)
+        h = _ln_modulate(self.norm2, x, sm, cm)
+        if h is None:
+            return _mlp_tail(self.mlp, x, self.norm2(x), sm, cm, gm)
+        if hasattr(self.mlp, "forward_deferred"):
+            m, mb = self.mlp.forward_deferred(h)
+            return token_ops.gate_residual(x, m, gm, mb)
+        return token_ops.gate_residual(x, self.mlp(h), gm, None)
 
 
 def _init_weights(module, n_layer, initializer_range=0.02, rescale_prenorm_residual=True, n_residuals_per_layer=1):
