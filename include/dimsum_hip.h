@@ -97,12 +97,12 @@ typedef struct {
     const void *dout_ptr;
     void *dA_ptr;          /* (dim, dstate) f32, zero-filled by the caller, accumulated with atomics */
     void *dB_ptr, *dC_ptr; /* (batch, n_groups, dstate, seqlen) F32 always; fully overwritten (no zero-fill needed): the
-                              per-wave partial sums go through the workspace and are added in a fixed order */
+                              per-workgroup (64-channel) partial sums go through the workspace and are added in a fixed order */
     void *dD_ptr;          /* (dim) f32 zero-filled, or NULL */
     void *du_ptr, *dz_ptr, *ddelta_ptr;
     void *ddelta_bias_ptr; /* (dim) f32 zero-filled, or NULL */
     void *workspace_ptr;   /* scratch, 16-byte aligned, contents undefined on entry and exit:
-                              per-wave partial dB / dC (2 * dim/64 * batch * dstate * seqlen f32) and, iff
+                              per-workgroup partial dB / dC (2 * ceil(dim/64) * batch * dstate * seqlen f32) and, iff
                               fwd.ckpt_ptr == NULL, the rebuilt states. dimsum_ssm_scan_bwd_workspace_bytes(...) bytes
                               always suffice. */
     int64_t workspace_bytes;
