@@ -14,6 +14,7 @@ Further legs on the same line (default `--mode all`; each is also a `--mode` of 
                  all-gather of the final latents -- at every N (so the scaling runs exercise the collective)
   block_fwdbwd   configs[2]: one DiMBlockCombined(1024) forward+backward at batch 256, with `roofline_bwd`   (N = 1)
   xl512_zigzag   configs[4]: DiM-XL/2 at 512 px (1024 tokens), batch 64, 8-way zigzag scanning orders       (N = 1)
+  train_step     SURVEY 8 f2: one whole flow-matching training step of DiM-L/2 (loss, backward, clip, fused AdamW, EMA), batch 64 (N = 1)
   cpu_baseline   the same forward on the host cores through the CPU oracle ("port"): 1 warm-up + 3 runs, median (N = 1)
 Every `roofline*` object: algorithmic bytes per launch (SURVEY.md 8d formula) / average launch duration of the scan
 kernel measured live with HIP events on the launch stream during that leg's timed steps; the kernel name comes from the
@@ -356,6 +357,8 @@ class Bench:
         rb = self.timer.roofline("bwd")
         if rb is not None:
             out["roofline_bwd"] = rb
+        del ddp, ema, opt, model
+        self.free()
         return out
 
 
@@ -415,6 +418,7 @@ def main():
         if world == 1:
             extras["block_fwdbwd"] = b.leg_block(args.model, args.image_size, 256, 5, 2)                      # configs[2]
             extras["xl512_zigzag"] = b.leg_fwd("DiM-XL/2", 512, 64, "zigma_8", 5, 2, extra_precisions=False)   # configs[4]
+            extras["train_step"] = b.leg_train(args.model, args.image_size, 64, 3, 2)
 
     if rank == 0:
         line = {"metric": metric, "value": head["value"], "unit": head["unit"], "n_gpus": world, "steps": head["steps"], "warmup": head["warmup"],
