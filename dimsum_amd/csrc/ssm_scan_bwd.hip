@@ -114,6 +114,22 @@ template <int NV, typename Gen> __device__ __forceinline__ void transposed_reduc
     r[1] = NV == 32 ? v[1] : 0.f;
 }
 
+// NV = 32 with the lanes' state slots permuted (kernel: slot j of row lane c holds state j ^ ((c >> 2) & 3)): at the two levels
+// that split on the STATE bits every lane keeps its slots 0, 1 (then 0) and sends slots 2, 3 (then 1) -- the partner's sent
+// slots hold exactly the states this lane keeps, because the partners' permutations differ in that bit. No selects at those
+// levels (24 of the 30 outputs); the two time-bit levels are as above. Same result layout: r[i] = value 2 l + i.
+template <typename Gen> __device__ __forceinline__ void transposed_reduce_row32_perm(Gen gen, int lane, float (&r)[2]) {
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = gen(i) + dpp<0x128>(gen(i + 16));           // slots {0, 1} += partner's slots {2, 3}   (l ^ 8)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += dpp<0x141>(v[i + 8]);                       // slot 0 += partner's slot 1               (7 - l)
+    reduce_level<0x4E, 8>(v, lane & 2);                                             // time bit 2
+    reduce_level<0xB1, 4>(v, lane & 1);                                             // time bit 1
+    r[0] = v[0];
+    r[1] = v[1];
+}
+
 // sigmoid(x) for dt = softplus(x) = log(1 + e^x):  sigmoid(x) = 1 - exp(-dt)  (for x > 20 the reference takes dt = x and
 // a derivative of 1: 1 - exp(-20) rounds to 1). Small dt: alternating series (the direct form cancels).
 __device__ __forceinline__ float dsoftplus_from_dt(float dt) {
@@ -175,12 +191,20 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
     const int dd_ds = (int)q.ddelta_d_stride;
     const int Bns = (int)p.B_dstate_stride, Cns = (int)p.C_dstate_stride;
 
+    // State slots: slot j of this lane holds state ns0 + (j ^ kperm). With one 4-state sweep per half (dstate 16) the slots are
+    // permuted by the row lane's bits 3, 2 so that the dB / dC butterflies need no selects at their two state levels
+    // (transposed_reduce_row32_perm); everything per-state below (A, saved states, B / C rows, dA) goes through `sidx`.
+    constexpr bool kPerm = kNG == 1 && kBG == 4;
+    const int kperm = kPerm ? ((c >> 2) & 3) : 0;
+    int sidx[kNL], brow[kNL];                     // state index of slot j (relative to ns0); its row offset in tB / tC
+#pragma unroll
+    for (int k = 0; k < kNL; ++k) { sidx[k] = k ^ kperm; brow[k] = (ns0 + sidx[k]) * kBCS; }
     // per-lane constants and carries, all in registers (only ever indexed with compile-time constants)
     float A2[kNL], re[kNL], rdA[kNL];             // A log2 e; e = a_{t+1} dh_{t+1} carried across halves; dA accumulators
     {
         const float *Ap = reinterpret_cast<const float *>(p.A_ptr) + (int64_t)d * p.A_d_stride;
 #pragma unroll
-        for (int k = 0; k < kNL; ++k) { A2[k] = Ap[(ns0 + k) * p.A_dstate_stride] * kLog2e; re[k] = 0.f; rdA[k] = 0.f; }   // exp(dt A) = exp2(dt A log2 e)
+        for (int k = 0; k < kNL; ++k) { A2[k] = Ap[(ns0 + sidx[k]) * p.A_dstate_stride] * kLog2e; re[k] = 0.f; rdA[k] = 0.f; }   // exp(dt A) = exp2(dt A log2 e)
     }
     const float Dval = p.D_ptr ? reinterpret_cast<const float *>(p.D_ptr)[d] : 0.f;
     const float *bias_p = reinterpret_cast<const float *>(p.delta_bias_ptr);
@@ -194,37 +218,40 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
     const int64_t ck_ns = p.dim;                                // stride between states
     // coalesced tile layout: 16 rows x 32 columns = 2 pieces of (8 rows x 8 lanes-per-row x 4 columns): whole 128-B lines
     const int lrow = lane >> 3, lc4 = lane & 7, lcol = lc4 * 4;
-    float brow[kNPc];                                            // delta_bias of the rows this lane stages
+    float bias_row[kNPc];                                        // delta_bias of the rows this lane stages
 #pragma unroll
-    for (int i = 0; i < kNPc; ++i) brow[i] = (bias_p && wave_live) ? bias_p[d0 + min(i * 8 + lrow, nd - 1)] : 0.f;
+    for (int i = 0; i < kNPc; ++i) bias_row[i] = (bias_p && wave_live) ? bias_p[d0 + min(i * 8 + lrow, nd - 1)] : 0.f;
 
     // states of the last half tile (the first one processed); later halves are prefetched one half ahead
     float hpre[kNL];
 #pragma unroll
-    for (int k = 0; k < kNL; ++k) hpre[k] = wave_live ? ck_lane[((int64_t)(n_halves - 1) * kN + k) * ck_ns] : 0.f;
+    for (int k = 0; k < kNL; ++k) hpre[k] = wave_live ? ck_lane[((int64_t)(n_halves - 1) * kN + sidx[k]) * ck_ns] : 0.f;
 
-    // Register-staged prefetch (vector path): the next tile's u / delta rows are requested right after the current tile
-    // has been staged, so they fly under the tile's sweeps. Branch-free: rows beyond nd are clamped to the last live row,
-    // columns beyond L to the last 4-column group; the masks are applied when the registers are staged.
+    // Register-staged prefetch (vector path): the next tile's delta rows -- the operand with the longest dependent chain behind
+    // it (softplus) -- are requested right after the current tile has been staged, so they fly under the tile's sweeps; the
+    // register budget (256 VGPRs at 2 waves per SIMD) has no room for more: also prefetching u costs 104 B of scratch per
+    // lane and 8 % (measured). Branch-free: rows beyond nd are clamped to the last live row, columns beyond L to the last
+    // 4-column group; the masks are applied when the registers are staged.
     Raw4<T> pu[kNPc], pd[kNPc], pg[kNPc], pz[kNPc], py[kNPc];
     auto tile_addr = [&](const T *base, int ds, int i, int col) -> const T * {
         if constexpr (kFull) return at(base + i * 8 * ds, (unsigned)(lrow * ds + col));
         else return at(base, (unsigned)(min(i * 8 + lrow, nd - 1) * ds + col));
     };
-    auto issue_ud = [&](int t0n) {
+    auto issue_d = [&](int t0n) {
         const int col = min(t0n + lcol, L - 4);
 #pragma unroll
-        for (int i = 0; i < kNPc; ++i) { pu[i] = ld4<T>(tile_addr(u_base, u_ds, i, col)); pd[i] = ld4<T>(tile_addr(dl_base, dl_ds, i, col)); }
+        for (int i = 0; i < kNPc; ++i) pd[i] = ld4<T>(tile_addr(dl_base, dl_ds, i, col));
     };
     auto issue_rest = [&](int t0n) {
         const int col = min(t0n + lcol, L - 4);
 #pragma unroll
         for (int i = 0; i < kNPc; ++i) {
+            pu[i] = ld4<T>(tile_addr(u_base, u_ds, i, col));
             pg[i] = ld4<T>(tile_addr(do_base, do_ds, i, col));
             if constexpr (kHasZ) { pz[i] = ld4<T>(tile_addr(z_base, z_ds, i, col)); py[i] = ld4<T>(tile_addr(y_base, y_ds, i, col)); }
         }
     };
-    if constexpr (kVec) if (wave_live) issue_ud((n_tiles - 1) * kBT);
+    if constexpr (kVec) if (wave_live) issue_d((n_tiles - 1) * kBT);
 
 #pragma unroll 1
     for (int tile = n_tiles - 1; tile >= 0; --tile) {
@@ -257,7 +284,7 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
                         vu = widen(pu[i]);
                         vd = widen(pd[i]);
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) vd.v[s] = softplus_if(vd.v[s] + brow[i], softplus);
+                        for (int s = 0; s < 4; ++s) vd.v[s] = softplus_if(vd.v[s] + bias_row[i], softplus);
                     }
                     *reinterpret_cast<f32x4 *>(&tU[btile_off(row, lc4)]) = vu;
                     *reinterpret_cast<f32x4 *>(&tD[btile_off(row, lc4)]) = vd;
@@ -289,7 +316,7 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
                     }
                     *reinterpret_cast<f32x4 *>(&tY[btile_off(row, lc4)]) = dy;
                 }
-                if (tile > 0) issue_ud(t0 - kBT);                // flies under the sweeps below
+                if (tile > 0) issue_d(t0 - kBT);                 // flies under the sweeps below
             } else {
                 for (int i = 0; i < kBC * kBT / kWave; ++i) {
                     const int idx = i * kWave + lane, row = idx / kBT, col = idx & (kBT - 1), t = t0 + col;
@@ -330,7 +357,7 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
                 {
                     const float *ck_next = ck_lane + (int64_t)max(hidx - 1, 0) * kN * ck_ns;
 #pragma unroll
-                    for (int k = 0; k < kNL; ++k) hnext[k] = ck_next[k * ck_ns];
+                    for (int k = 0; k < kNL; ++k) hnext[k] = ck_next[sidx[k] * ck_ns];
                 }
                 float s1[kBS], s2[kBS];
 #pragma unroll
@@ -367,7 +394,7 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
                         for (int s = 0; s < 4; ++s) du[s] = d4.v[s] * u4.v[s];
 #pragma unroll
                         for (int k = 0; k < kBG; ++k) {
-                            const f32x4 bq = *reinterpret_cast<const f32x4 *>(&tB[(nrow + k) * kBCS + (jb + jj) * 4]);
+                            const f32x4 bq = *reinterpret_cast<const f32x4 *>(&tB[(kPerm ? brow[k] : (nrow + k) * kBCS) + (jb + jj) * 4]);
 #pragma unroll
                             for (int s = 0; s < 4; ++s) {
                                 const float a = fast_exp2(d4.v[s] * Ak[k]);
@@ -387,7 +414,8 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
                             for (int s = 0; s < 4; ++s) y8[jj * 4 + s] = y4.v[s];
                         }
                         float r[2];
-                        transposed_reduce_row<NV>([&](int i) { return y8[i & (kBS - 1)] * H[i]; }, lane, r);
+                        if constexpr (kPerm) transposed_reduce_row32_perm([&](int i) { return y8[i & (kBS - 1)] * H[i]; }, lane, r);
+                        else transposed_reduce_row<NV>([&](int i) { return y8[i & (kBS - 1)] * H[i]; }, lane, r);
                         if constexpr (NV == 32) {
                             *reinterpret_cast<float2 *>(&tdC[(nrow + (c >> 2)) * kDS + half * kBS + 2 * (c & 3)]) = make_float2(r[0], r[1]);
                         } else if constexpr (NV == 16) {
@@ -407,8 +435,8 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
                         for (int s = 0; s < 4; ++s) du[s] = d4.v[s] * u4.v[s];
 #pragma unroll
                         for (int k = 0; k < kBG; ++k) {
-                            const f32x4 bq = *reinterpret_cast<const f32x4 *>(&tB[(nrow + k) * kBCS + (jb + jj) * 4]);
-                            const f32x4 cq = *reinterpret_cast<const f32x4 *>(&tC[(nrow + k) * kBCS + (jb + jj) * 4]);
+                            const f32x4 bq = *reinterpret_cast<const f32x4 *>(&tB[(kPerm ? brow[k] : (nrow + k) * kBCS) + (jb + jj) * 4]);
+                            const f32x4 cq = *reinterpret_cast<const f32x4 *>(&tC[(kPerm ? brow[k] : (nrow + k) * kBCS) + (jb + jj) * 4]);
 #pragma unroll
                             for (int s = 3; s >= 0; --s) {
                                 const int t = jj * 4 + s;
@@ -433,7 +461,8 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
                     // ---- dB[n, t] = sum_d dh_t[n] dt_t u_t ---------------------------------------------------------------------------
                     {
                         float r[2];
-                        transposed_reduce_row<NV>([&](int i) { return H[i]; }, lane, r);
+                        if constexpr (kPerm) transposed_reduce_row32_perm([&](int i) { return H[i]; }, lane, r);
+                        else transposed_reduce_row<NV>([&](int i) { return H[i]; }, lane, r);
                         if constexpr (NV == 32) {
                             *reinterpret_cast<float2 *>(&tdB[(nrow + (c >> 2)) * kDS + half * kBS + 2 * (c & 3)]) = make_float2(r[0], r[1]);
                         } else if constexpr (NV == 16) {
@@ -538,7 +567,7 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
     if (live) {
         float *dAp = reinterpret_cast<float *>(q.dA_ptr) + (int64_t)d * q.dA_d_stride;
 #pragma unroll
-        for (int k = 0; k < kNL; ++k) atomicAdd(dAp + (ns0 + k) * q.dA_dstate_stride, rdA[k]);
+        for (int k = 0; k < kNL; ++k) atomicAdd(dAp + (ns0 + sidx[k]) * q.dA_dstate_stride, rdA[k]);
         if (q.dD_ptr && sh == 0) atomicAdd(reinterpret_cast<float *>(q.dD_ptr) + d, dD);
         if (q.ddelta_bias_ptr && sh == 0) atomicAdd(reinterpret_cast<float *>(q.ddelta_bias_ptr) + d, dbias);
     }
