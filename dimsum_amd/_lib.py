@@ -136,7 +136,8 @@ def load():
 
 
 SCAN_FWD_KERNELS = {0: "ssm_scan_fwd_kernel", 2: "ssm_scan_fwd_split_kernel<2 lanes per channel>",
-                    4: "ssm_scan_fwd_split_kernel<4 lanes per channel>"}      # dimsum_ssm_scan_fwd_variant() -> kernel
+                    4: "ssm_scan_fwd_split_kernel<4 lanes per channel>",
+                    16: "ssm_scan_fwd_lanes_kernel<one lane per state>"}      # dimsum_ssm_scan_fwd_variant() -> kernel
 
 
 def check(status, what):

@@ -8,6 +8,7 @@ namespace dimsum {
 // kernel launchers, instantiated in ssm_scan_fwd_{f32,f16,bf16}.hip / ssm_scan_fwd_split_{f32,f16,bf16}.hip
 template <typename T, int kN> void ssm_scan_fwd_launch_v0(const dimsum_ssm_params_t &p, hipStream_t stream, int tiles, bool vec, bool full);
 template <typename T, int kN, int kSP> void ssm_scan_fwd_launch_split(const dimsum_ssm_params_t &p, hipStream_t stream, int tiles, bool vec, bool full);
+template <typename T> void ssm_scan_fwd_launch_lanes(const dimsum_ssm_params_t &p, hipStream_t stream, int tiles, bool vec, bool full);
 
 int ssm_check(const dimsum_ssm_params_t *p, bool forward) {
     if (!p || !p->A_ptr || !p->B_ptr || !p->C_ptr || !p->u_ptr || !p->delta_ptr) return DIMSUM_ERR_NULL;
@@ -19,11 +20,13 @@ int ssm_check(const dimsum_ssm_params_t *p, bool forward) {
 }
 
 // Which forward kernel serves a shape: 0 = lane = channel (64 channels per wave), 2 / 4 = lanes per channel of the
-// state-split kernel (32 / 16 channels per wave). dimsum_ssm_scan_fwd_force_variant() overrides the choice (tests, tuning).
+// state-split kernel (32 / 16 channels per wave), 16 = one lane per state (dstate 16: 4 channels per wave).
+// dimsum_ssm_scan_fwd_force_variant() overrides the choice (tests, tuning).
 static int g_force_variant = -1;
+constexpr int64_t kLanesBelowWaves = 2560;
 
 static bool variant_ok(const dimsum_ssm_params_t &p, int v) {
-    return v == 0 || (v == 2 && p.dstate % 4 == 0) || (v == 4 && p.dstate % 8 == 0);
+    return v == 0 || (v == 2 && p.dstate % 4 == 0) || (v == 4 && p.dstate % 8 == 0) || (v == 16 && p.dstate == 16);
 }
 
 int ssm_scan_fwd_variant(const dimsum_ssm_params_t &p) {
@@ -35,6 +38,9 @@ int ssm_scan_fwd_variant(const dimsum_ssm_params_t &p) {
     const int64_t dpg = p.dim / p.n_groups;
     const int64_t waves = (int64_t)p.batch * p.n_groups * ((dpg + kWave - 1) / kWave);
     if (waves >= 2048) return 0;
+    // fewer than ~2.5 waves per SIMD even at 16 channels per wave: one lane per state (4 channels per wave)
+    const int64_t waves4 = (int64_t)p.batch * p.n_groups * ((dpg + 15) / 16);
+    if (waves4 < kLanesBelowWaves && variant_ok(p, 16)) return 16;
     if (variant_ok(p, 4)) return 4;
     return variant_ok(p, 2) ? 2 : 0;
 }
@@ -42,7 +48,7 @@ int ssm_scan_fwd_variant(const dimsum_ssm_params_t &p) {
 template <typename T, int kN>
 static int launch_fwd(const dimsum_ssm_params_t &p, hipStream_t stream) {
     const int dpg = p.dim / p.n_groups;
-    const int sp = ssm_scan_fwd_variant(p);                // 0, 2 or 4
+    const int sp = ssm_scan_fwd_variant(p);                // 0, 2, 4 or 16
     const int cpw = sp == 0 ? kWave : kWave / sp;          // channels per wave
     const int tiles = p.batch * p.n_groups * ((dpg + cpw - 1) / cpw);
     const size_t va = 4 * sizeof(T);  // vector path: every row base 4-element aligned
@@ -63,7 +69,9 @@ static int launch_fwd(const dimsum_ssm_params_t &p, hipStream_t stream) {
         !offsets_fit_32bit<T>(p.seqlen, p.dstate, {p.B_dstate_stride, p.C_dstate_stride}))
         return DIMSUM_ERR_STRIDE;
     const bool full = vec && (dpg % cpw == 0);
-    if (sp == 4) {
+    if (sp == 16) {
+        if constexpr (kN == 16) ssm_scan_fwd_launch_lanes<T>(p, stream, tiles, vec, full);
+    } else if (sp == 4) {
         if constexpr (kN % 8 == 0) ssm_scan_fwd_launch_split<T, kN, 4>(p, stream, tiles, vec, full);
     } else if (sp == 2) {
         ssm_scan_fwd_launch_split<T, kN, 2>(p, stream, tiles, vec, full);

@@ -1,6 +1,8 @@
-// selective-scan forward, f16 I/O: the state-split kernels, 2 and 4 lanes per channel (ssm_scan_fwd_split.hpp)
-#include "ssm_scan_fwd_split.hpp"
+// selective-scan forward, f16 I/O: the state-split kernels -- 2 and 4 lanes per channel (ssm_scan_fwd_split.hpp), one lane
+// per state (ssm_scan_fwd_lanes.hpp)
+#include "ssm_scan_fwd_lanes.hpp"
 
 namespace dimsum {
 DIMSUM_INSTANTIATE_FWD_SPLIT(__half)
+DIMSUM_INSTANTIATE_FWD_LANES(__half)
 }  // namespace dimsum

@@ -117,10 +117,11 @@ int64_t dimsum_ssm_scan_bwd_workspace_bytes(int32_t batch, int32_t dim, int32_t 
  *   0 = ssm_scan_fwd_kernel        lane = channel, 64 channels per wave (launches that fill the chip)
  *   2 = ssm_scan_fwd_split_kernel  lane = (channel, state half), 32 channels per wave
  *   4 = ssm_scan_fwd_split_kernel  lane = (channel, state quarter), 16 channels per wave (few channels, long sequences)
+ *  16 = ssm_scan_fwd_lanes_kernel  lane = (channel, state), 4 channels per wave, dstate 16 (fewer channels still)
  * -1 on invalid parameters. */
 int dimsum_ssm_scan_fwd_variant(const dimsum_ssm_params_t *p);
-/* Process-global override of that choice for subsequent launches: 0 / 2 / 4, or -1 = automatic (the default). A variant
- * the shape does not support (dstate % 4, % 8) falls back to 0. For tests and tuning; not thread-safe. */
+/* Process-global override of that choice for subsequent launches: 0 / 2 / 4 / 16, or -1 = automatic (the default). A variant
+ * the shape does not support (dstate % 4, % 8, != 16) falls back to 0. For tests and tuning; not thread-safe. */
 void dimsum_ssm_scan_fwd_force_variant(int variant);
 
 /* ---------------------------------------------------------------------------------------------------------------

@@ -20,13 +20,14 @@ pytestmark = pytest.mark.gpu
 CASES = ["scan_main", "scan_long", "scan_odd", "scan_plain", "scan_nosoftplus_z", "scan_groups2"]
 
 
-@pytest.fixture(params=["auto", "64ch", "split2", "split4"])
+@pytest.fixture(params=["auto", "64ch", "split2", "split4", "lanes16"])
 def fwd_kernel(request):
     """runs a forward test under the automatic kernel choice and with each forward kernel forced (64 channels per wave /
-    lane = (channel, state half) / lane = (channel, state quarter)): small test shapes would otherwise all take one"""
+    lane = (channel, state half) / lane = (channel, state quarter) / lane = (channel, state), the last for dstate 16 only -- other
+    dstates fall back to the 64-channel kernel): small test shapes would otherwise all take one"""
     from dimsum_amd import _lib
     lib = _lib.load()
-    lib.dimsum_ssm_scan_fwd_force_variant({"auto": -1, "64ch": 0, "split2": 2, "split4": 4}[request.param])
+    lib.dimsum_ssm_scan_fwd_force_variant({"auto": -1, "64ch": 0, "split2": 2, "split4": 4, "lanes16": 16}[request.param])
     yield request.param
     lib.dimsum_ssm_scan_fwd_force_variant(-1)
 
@@ -120,8 +121,8 @@ def test_linearity_in_u_at_full_size(B, D, L, N):
 
 
 def test_forward_kernel_variants_agree():
-    """the three forward kernels (64 channels per wave / 2 / 4 lanes per channel) on the same operands: same fp32 operations
-    per state, only the order of the final sum over states differs -> rtol 2e-5 + 2e-6 max|ref|; and the dispatch query
+    """the four forward kernels (64 channels per wave / 2 / 4 / 16 lanes per channel) on the same operands: same fp32 operations
+    per state, only the order of the final sum over states (and, one lane per state, of sum(dt) behind x's prod a) differs -> rtol 2e-5 + 2e-6 max|ref|; and the dispatch query
     reports what was forced."""
     from dimsum_amd import _lib, native
     lib = _lib.load()
@@ -134,7 +135,7 @@ def test_forward_kernel_variants_agree():
     Dv, bias = torch.randn(D, device="cuda", generator=g), 0.5 * torch.rand(D, device="cuda", generator=g)
     res = {}
     try:
-        for v in (0, 2, 4):
+        for v in (0, 2, 4, 16):
             lib.dimsum_ssm_scan_fwd_force_variant(v)
             out, x, oz, ck = native.selective_scan_fwd(u, dl, A, Bm, Cm, Dv, z, bias, True, need_ckpt=True)
             res[v] = [t.cpu().numpy() for t in (out, x, oz, ck)]
@@ -143,16 +144,16 @@ def test_forward_kernel_variants_agree():
             assert lib.dimsum_ssm_scan_fwd_variant(P) == v
     finally:
         lib.dimsum_ssm_scan_fwd_force_variant(-1)
-    for v in (2, 4):
+    for v in (2, 4, 16):
         for name, a, b in zip(("out", "x", "out_z", "saved states"), res[v], res[0]):
             assert_close(a, b, 2e-5, 0, f"{name} (variant {v})", scale_atol=2e-6)
 
 
 def test_forward_dispatch_by_shape():
-    """launches that fill the 2048 wave slots take the 64-channel kernel; smaller ones the widest state split their dstate allows"""
+    """launches that fill the 2048 wave slots take the 64-channel kernel; smaller ones a state split: 4 lanes per channel, one lane per state (dstate 16) when even that leaves < 2.5 waves per SIMD"""
     from dimsum_amd import _lib
     lib = _lib.load()
-    for (B, D, N, G), want in {(256, 1024, 16, 1): 0, (64, 1152, 16, 1): 4, (16, 1152, 16, 1): 4, (4, 384, 4, 1): 2, (2, 70, 6, 1): 0,
+    for (B, D, N, G), want in {(256, 1024, 16, 1): 0, (64, 1152, 16, 1): 4, (16, 1152, 16, 1): 16, (32, 1152, 16, 1): 16, (16, 1152, 8, 1): 4, (4, 384, 4, 1): 2, (2, 70, 6, 1): 0,
                                (2048, 64, 16, 1): 0}.items():
         P = _lib.SsmParams()
         P.batch, P.dim, P.seqlen, P.dstate, P.n_groups, P.n_chunks = B, D, 256, N, G, 1

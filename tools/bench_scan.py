@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--no-out-z", action="store_true", help="--bwd without the out_z recompute (what dimsum_amd.ops requests: it keeps the forward's out_z)")
     ap.add_argument("--pad", type=int, default=0, help="--dmajor: extra elements in the channel stride (B*L + pad): probes L2 / HBM channel camping "
                                                        "of power-of-two strides")
-    ap.add_argument("--variant", type=int, default=-1, help="force a forward kernel: 0 = 64 channels per wave, 2 / 4 = lanes per channel (-1: automatic)")
+    ap.add_argument("--variant", type=int, default=-1, help="force a forward kernel: 0 = 64 channels per wave, 2 / 4 / 16 = lanes per channel (-1: automatic)")
     ap.add_argument("--train-fwd", action="store_true", help="time the forward's training variant (also stores the states the backward consumes)")
     a = ap.parse_args()
     from dimsum_amd import _lib
