@@ -23,7 +23,7 @@ int ssm_check(const dimsum_ssm_params_t *p, bool forward) {
 // state-split kernel (32 / 16 channels per wave), 16 = one lane per state (dstate 16: 4 channels per wave).
 // dimsum_ssm_scan_fwd_force_variant() overrides the choice (tests, tuning).
 static int g_force_variant = -1;
-constexpr int64_t kLanesBelowWaves = 2560;
+constexpr int64_t kLanesBelowWaves = 2048;
 
 static bool variant_ok(const dimsum_ssm_params_t &p, int v) {
     return v == 0 || (v == 2 && p.dstate % 4 == 0) || (v == 4 && p.dstate % 8 == 0) || (v == 16 && p.dstate == 16);
@@ -38,7 +38,8 @@ int ssm_scan_fwd_variant(const dimsum_ssm_params_t &p) {
     const int64_t dpg = p.dim / p.n_groups;
     const int64_t waves = (int64_t)p.batch * p.n_groups * ((dpg + kWave - 1) / kWave);
     if (waves >= 2048) return 0;
-    // fewer than ~2.5 waves per SIMD even at 16 channels per wave: one lane per state (4 channels per wave)
+    // fewer than 2 waves per SIMD even at 16 channels per wave: one lane per state (4 channels per wave). Measured (fp32):
+    //   (16, 1152, 4096): 0.71 -> 0.57 ms, (8, 1152, 4096): 0.54 -> 0.34 ms; (32, 1152, 1024), 2304 waves: equal
     const int64_t waves4 = (int64_t)p.batch * p.n_groups * ((dpg + 15) / 16);
     if (waves4 < kLanesBelowWaves && variant_ok(p, 16)) return 16;
     if (variant_ok(p, 4)) return 4;

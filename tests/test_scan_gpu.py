@@ -150,10 +150,10 @@ def test_forward_kernel_variants_agree():
 
 
 def test_forward_dispatch_by_shape():
-    """launches that fill the 2048 wave slots take the 64-channel kernel; smaller ones a state split: 4 lanes per channel, one lane per state (dstate 16) when even that leaves < 2.5 waves per SIMD"""
+    """launches that fill the 2048 wave slots take the 64-channel kernel; smaller ones a state split: 4 lanes per channel, one lane per state (dstate 16) when even that leaves < 2 waves per SIMD"""
     from dimsum_amd import _lib
     lib = _lib.load()
-    for (B, D, N, G), want in {(256, 1024, 16, 1): 0, (64, 1152, 16, 1): 4, (16, 1152, 16, 1): 16, (32, 1152, 16, 1): 16, (16, 1152, 8, 1): 4, (4, 384, 4, 1): 2, (2, 70, 6, 1): 0,
+    for (B, D, N, G), want in {(256, 1024, 16, 1): 0, (64, 1152, 16, 1): 4, (16, 1152, 16, 1): 16, (32, 1152, 16, 1): 4, (16, 1152, 8, 1): 4, (4, 384, 4, 1): 2, (2, 70, 6, 1): 0,
                                (2048, 64, 16, 1): 0}.items():
         P = _lib.SsmParams()
         P.batch, P.dim, P.seqlen, P.dstate, P.n_groups, P.n_chunks = B, D, 256, N, G, 1
