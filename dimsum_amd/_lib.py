@@ -51,7 +51,7 @@ class NormParams(C.Structure):
                 + [(n, i64) for n in ("x_row_stride", "residual_row_stride", "y_row_stride", "residual_out_row_stride")]
                 + [(n, vp) for n in ("x_ptr", "residual_ptr", "weight_ptr", "bias_ptr", "y_ptr", "residual_out_ptr",
                                      "mean_ptr", "rstd_ptr", "xbias_ptr", "mod_scale_ptr", "mod_shift_ptr")]
-                + [("mod_row_stride", i64), ("rows_per_batch", i32), ("reserved", i32)])
+                + [("mod_row_stride", i64), ("rows_per_batch", i32), ("y_split3", i32)])
 
 
 class NormBwdParams(C.Structure):
@@ -88,7 +88,7 @@ EXPORTS = (
     "dimsum_ssm_scan_fwd", "dimsum_ssm_scan_bwd", "dimsum_ssm_scan_bwd_workspace_bytes", "dimsum_ssm_scan_fwd_variant",
     "dimsum_ssm_scan_fwd_force_variant", "dimsum_causal_conv1d_fwd", "dimsum_causal_conv1d_bwd",
     "dimsum_norm_fwd", "dimsum_norm_bwd", "dimsum_token_transform", "dimsum_xattn_fusion_fwd", "dimsum_xattn_fusion_bwd",
-    "dimsum_gated_gelu_fwd", "dimsum_gated_gelu_bwd",
+    "dimsum_gated_gelu_fwd", "dimsum_gated_gelu_bwd", "dimsum_gated_gelu_fwd_split3", "dimsum_split3",
 )
 
 _lib = None
@@ -116,11 +116,14 @@ def load():
             fn = getattr(lib, name)
             fn.restype = C.c_int
             fn.argtypes = [C.POINTER(ptype), vp]
-    for name, nptr in (("dimsum_gated_gelu_fwd", 3), ("dimsum_gated_gelu_bwd", 5)):
+    for name, nptr in (("dimsum_gated_gelu_fwd", 3), ("dimsum_gated_gelu_bwd", 5), ("dimsum_gated_gelu_fwd_split3", 3)):
         if hasattr(lib, name):
             fn = getattr(lib, name)
             fn.restype = C.c_int
             fn.argtypes = [vp] * nptr + [i64, i64, vp]
+    if hasattr(lib, "dimsum_split3"):
+        lib.dimsum_split3.restype = C.c_int
+        lib.dimsum_split3.argtypes = [vp, i64, i64, i64, vp, i32, vp]
     if hasattr(lib, "dimsum_ssm_scan_bwd_workspace_bytes"):
         lib.dimsum_ssm_scan_bwd_workspace_bytes.restype = i64
         lib.dimsum_ssm_scan_bwd_workspace_bytes.argtypes = [i32] * 5
@@ -129,7 +132,7 @@ def load():
         lib.dimsum_ssm_scan_fwd_variant.argtypes = [C.POINTER(SsmParams)]
         lib.dimsum_ssm_scan_fwd_force_variant.restype = None
         lib.dimsum_ssm_scan_fwd_force_variant.argtypes = [C.c_int]
-    if lib.dimsum_abi_version() != 8:
+    if lib.dimsum_abi_version() != 9:
         raise RuntimeError("dimsum_amd: libdimsum_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

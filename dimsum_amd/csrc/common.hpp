@@ -66,6 +66,31 @@ template <> __device__ __forceinline__ void st4<__hip_bfloat16>(__hip_bfloat16 *
 }
 
 // ---- math --------------------------------------------------------------------------------------------------------
+// ---- split-bf16 operand images --------------------------------------------------------------------------------------
+// fp32 x = hi + lo (+ 2^-17 relative): hi = bf16(x), lo = bf16(x - hi), both round to nearest even (v_cvt_pk_bf16_f32).
+// Three bf16 MFMA products hi*hi + hi*lo + lo*hi reproduce the fp32 product to ~4e-6 -- what hipBLASLt does for fp32 operands
+// under the reference's allow_tf32 policy. A producer kernel can hand the library the operand already split ("split3" rows:
+// [hi | hi | lo] for the left operand, [hi | lo | hi] for the weights, 3 K bf16 per row), which turns the product into ONE
+// plain bf16 GEMM over 3 K -- the library's fastest kernels.
+__device__ __forceinline__ void split2(float x0, float x1, unsigned &hi, unsigned &lo) {   // packed [x0 | x1 << 16]
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const bf16x2 h = __builtin_convertvector(f2{x0, x1}, bf16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+    const bf16x2 l = __builtin_convertvector(f2{r0, r1}, bf16x2);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+// 4 consecutive columns c .. c + 3 of a split3 row of logical width N (row: 3 N bf16, 8-byte aligned pieces): kLeft = [hi | hi | lo]
+template <bool kLeft> __device__ __forceinline__ void st_split3(unsigned short *row, int64_t c, int64_t N, const f32x4 &v) {
+    unsigned h0, l0, h1, l1;
+    split2(v.v[0], v.v[1], h0, l0);
+    split2(v.v[2], v.v[3], h1, l1);
+    *reinterpret_cast<uint2 *>(row + c) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2 *>(row + N + c) = kLeft ? make_uint2(h0, h1) : make_uint2(l0, l1);
+    *reinterpret_cast<uint2 *>(row + 2 * N + c) = kLeft ? make_uint2(l0, l1) : make_uint2(h0, h1);
+}
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }        // v_exp_f32
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
 __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * kLn2; }   // v_log_f32

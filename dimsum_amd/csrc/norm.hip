@@ -111,7 +111,8 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const dimsum_norm_params_
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o.v[e] = fmaf(o.v[e], 1.0f + sc.v[e], sh.v[e]);
                 }
-                st_cols<TY>(y, c, N, vec, o);
+                if (p.y_split3) st_split3<true>(reinterpret_cast<unsigned short *>(p.y_ptr) + row * p.y_row_stride, c, N, o);
+                else st_cols<TY>(y, c, N, vec, o);
             }
         }
     }
@@ -254,6 +255,10 @@ extern "C" int dimsum_norm_fwd(const dimsum_norm_params_t *p, void *stream) {
     if (p->rows < 0 || p->cols <= 0) return DIMSUM_ERR_SHAPE;
     if ((p->mod_scale_ptr == nullptr) != (p->mod_shift_ptr == nullptr)) return DIMSUM_ERR_NULL;
     if (p->mod_scale_ptr && p->rows_per_batch <= 0) return DIMSUM_ERR_SHAPE;
+    // split3 output: bf16 rows of 3 N, written 8 bytes at a time
+    if (p->y_split3 && (p->out_dtype != DIMSUM_BF16 || p->cols % 4 != 0 || p->y_row_stride % 4 != 0 || p->y_row_stride < 3 * (int64_t)p->cols ||
+                        !dimsum::aligned_to<char>(p->y_ptr, 8)))
+        return DIMSUM_ERR_STRIDE;
     if (p->rows == 0) return DIMSUM_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (p->x_dtype) {

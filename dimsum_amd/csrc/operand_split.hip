@@ -1,0 +1,39 @@
+// operand_split.hip -- split-bf16 operand images for the library GEMMs (gfx950).
+//
+// No reference counterpart: the reference's Linears run as TF32 GEMMs (torch.backends.cuda.matmul.allow_tf32 = True,
+// dimsum/train.py:20-21, sample_ddp.py:56). gfx950 has no TF32 MFMA; hipBLASLt serves fp32 operands under that flag by splitting
+// them into hi + lo bf16 inside the GEMM (3 products, ~370 TFLOP/s-equivalent). Given the SAME three products as one plain bf16
+// GEMM over a 3 K reduction -- rows [hi | hi | lo] on the left, [hi | lo | hi] on the weights, fp32 accumulate and output -- the
+// library's bf16 kernels reach ~410-430 TFLOP/s-equivalent (tools/scratch/ksplit_probe.py). The left images are written by the
+// kernels that produce the activations (norm.hip y_split3, gated GeLU split3, ...); this file converts what has no producer
+// of its own: the weights (per call: a cached image could not see parameter updates made through .data) and plain fp32 rows.
+#include "common.hpp"
+
+namespace dimsum {
+
+template <bool kLeft>
+__global__ __launch_bounds__(256) void split3_kernel(const float *src, int64_t rows, int64_t cols, int64_t src_row_stride, unsigned short *dst) {
+    const int64_t q = cols / 4, total = rows * q;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / q, c = (i - r * q) * 4;
+        const float4 v = *reinterpret_cast<const float4 *>(src + r * src_row_stride + c);
+        st_split3<kLeft>(dst + r * 3 * cols, c, cols, f32x4{{v.x, v.y, v.z, v.w}});
+    }
+}
+
+}  // namespace dimsum
+
+extern "C" int dimsum_split3(const void *src, int64_t rows, int64_t cols, int64_t src_row_stride, void *dst, int32_t left, void *stream) {
+    using namespace dimsum;
+    if (!src || !dst) return DIMSUM_ERR_NULL;
+    if (rows < 0 || cols <= 0 || cols % 4 != 0) return DIMSUM_ERR_SHAPE;
+    if (src_row_stride % 4 != 0 || src_row_stride < cols || !aligned_to<float>(src, 16) || !aligned_to<char>(dst, 8)) return DIMSUM_ERR_STRIDE;
+    if (rows == 0) return DIMSUM_OK;
+    const int64_t total = rows * (cols / 4);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (left) hipLaunchKernelGGL(split3_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float *>(src), rows, cols, src_row_stride, reinterpret_cast<unsigned short *>(dst));
+    else hipLaunchKernelGGL(split3_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float *>(src), rows, cols, src_row_stride, reinterpret_cast<unsigned short *>(dst));
+    return launch_status();
+}

@@ -322,7 +322,10 @@ __device__ __forceinline__ float gelu_tanh_grad(float a) {
 constexpr int kGGRows = 64;
 // forward: one thread = 4 columns of one row, consecutive threads = consecutive 16-byte pieces of h (and of each half of
 // x12); 4 independent pieces in flight per thread, a grid stride apart
-__global__ __launch_bounds__(256) void gated_gelu_fwd_kernel(const float *x12, const float *bias, float *h, int64_t rows, int64_t H) {
+// kSplit: h is the split-bf16 left operand image of the w3 GEMM (rows of 3 H bf16 [hi | hi | lo], common.hpp) instead of fp32
+template <bool kSplit>
+__global__ __launch_bounds__(256) void gated_gelu_fwd_kernel(const float *x12, const float *bias, void *hv, int64_t rows, int64_t H) {
+    float *h = reinterpret_cast<float *>(hv);
     const int64_t q = H / 4, total = rows * q;
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += 4 * stride) {
@@ -342,7 +345,9 @@ __global__ __launch_bounds__(256) void gated_gelu_fwd_kernel(const float *x12, c
             if (bias) { ba = *reinterpret_cast<const float4 *>(bias + cc[k]); bg = *reinterpret_cast<const float4 *>(bias + H + cc[k]); }
             const float4 av = make_float4(a[k].x + ba.x, a[k].y + ba.y, a[k].z + ba.z, a[k].w + ba.w);
             const float4 gv = make_float4(g[k].x + bg.x, g[k].y + bg.y, g[k].z + bg.z, g[k].w + bg.w);
-            *reinterpret_cast<float4 *>(h + rr[k] * H + cc[k]) = make_float4(gelu_tanh(av.x) * gv.x, gelu_tanh(av.y) * gv.y, gelu_tanh(av.z) * gv.z, gelu_tanh(av.w) * gv.w);
+            const f32x4 o = {{gelu_tanh(av.x) * gv.x, gelu_tanh(av.y) * gv.y, gelu_tanh(av.z) * gv.z, gelu_tanh(av.w) * gv.w}};
+            if constexpr (kSplit) st_split3<true>(reinterpret_cast<unsigned short *>(hv) + rr[k] * 3 * H, cc[k], H, o);
+            else *reinterpret_cast<float4 *>(h + rr[k] * H + cc[k]) = make_float4(o.v[0], o.v[1], o.v[2], o.v[3]);
         }
     }
 }
@@ -392,7 +397,8 @@ extern "C" int dimsum_token_transform(const dimsum_tt_params_t *p, void *stream)
     return vec ? launch_tt<4>(*p, s) : launch_tt<1>(*p, s);
 }
 
-extern "C" int dimsum_gated_gelu_fwd(const void *x12, const void *bias, void *h, int64_t rows, int64_t hidden, void *stream) {
+template <bool kSplit>
+static int launch_gated_gelu_fwd(const void *x12, const void *bias, void *h, int64_t rows, int64_t hidden, void *stream) {
     using namespace dimsum;
     if (!x12 || !h) return DIMSUM_ERR_NULL;
     if (rows < 0 || hidden <= 0 || hidden % 4 != 0) return DIMSUM_ERR_SHAPE;
@@ -403,9 +409,17 @@ extern "C" int dimsum_gated_gelu_fwd(const void *x12, const void *bias, void *h,
     const int64_t total = rows * (hidden / 4);
     const int64_t blocks = (total + 256 * 4 - 1) / (256 * 4);
     if (blocks > 0x7fffffff) return DIMSUM_ERR_SHAPE;
-    hipLaunchKernelGGL(gated_gelu_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       reinterpret_cast<const float *>(x12), reinterpret_cast<const float *>(bias), reinterpret_cast<float *>(h), rows, hidden);
+    hipLaunchKernelGGL(gated_gelu_fwd_kernel<kSplit>, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float *>(x12), reinterpret_cast<const float *>(bias), h, rows, hidden);
     return launch_status();
+}
+
+extern "C" int dimsum_gated_gelu_fwd(const void *x12, const void *bias, void *h, int64_t rows, int64_t hidden, void *stream) {
+    return launch_gated_gelu_fwd<false>(x12, bias, h, rows, hidden, stream);
+}
+
+extern "C" int dimsum_gated_gelu_fwd_split3(const void *x12, const void *bias, void *h3, int64_t rows, int64_t hidden, void *stream) {
+    return launch_gated_gelu_fwd<true>(x12, bias, h3, rows, hidden, stream);
 }
 
 extern "C" int dimsum_gated_gelu_bwd(const void *x12, const void *bias, const void *dh, void *dx12, void *dbias, int64_t rows,

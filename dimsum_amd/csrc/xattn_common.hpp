@@ -10,16 +10,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct alignas(16) u4v { unsigned w[4]; };       // 8 bf16 = the A / B operand of one lane for a 32-deep K chunk
 
-// (hi, lo) bf16 pair images of two fp32 values, packed [x0 | x1 << 16] (v_cvt_pk_bf16_f32: round to nearest even)
-__device__ __forceinline__ void split2(float x0, float x1, unsigned &hi, unsigned &lo) {
-    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    const bf16x2 h = __builtin_convertvector(f2{x0, x1}, bf16x2);
-    hi = __builtin_bit_cast(unsigned, h);
-    const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
-    const bf16x2 l = __builtin_convertvector(f2{r0, r1}, bf16x2);
-    lo = __builtin_bit_cast(unsigned, l);
-}
+// split2 (hi / lo bf16 pair images of two fp32 values): common.hpp
 __device__ __forceinline__ bf16x8 as_bf16x8(const u4v &v) { return __builtin_bit_cast(bf16x8, v); }
 
 // max / sum over the 4 lanes {l, l^16, l^32, l^48} that share a query (or key) column of a 16x16 MFMA C tile, on the VALU:

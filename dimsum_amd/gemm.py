@@ -11,6 +11,12 @@ proj, w12, w3 -- everything else is small).
              RMS-normalised / gated O(1..1e2) values and the weights O(1e-2), so the model's outputs stay within the
              TF32-class error (~5e-4 relative; tests/test_model_gpu.py::test_fp16_product_gemm_policy) -- but this is a
              weaker guarantee than the default and is therefore never the default nor bench.py's headline.
+  split3     (not a policy: a faster carrier of the "default" policy, inference only) when allow_tf32 is set, a kernel of this
+             package that produces the left operand of a Linear can write it as a split-bf16 image (M, 3K) bfloat16
+             [hi | hi | lo] (csrc/operand_split.hip, native.split3_rows); `linear_split3` multiplies it with the weight image
+             [hi | lo | hi] in ONE plain bf16 GEMM with fp32 accumulation and output: the same three products the library
+             forms inside its fp32 kernels, on its faster bf16 kernels (w12: 2.99 -> 2.67 ms, w3: 1.45 -> 1.27 ms at 65536 rows).
+             `DIMSUM_SPLIT3=0` keeps the fp32 operands.
 The operands are converted by a torch cast on every call -- weights too: DiM-L/2's 460 M parameters cost ~0.5 ms per
 forward (< 1 %) to cast, and a cached copy could not see in-place updates made through `.data` (EMA updates,
 load_state_dict), which do not bump a tensor's version counter. Outputs stay fp32."""
@@ -56,3 +62,18 @@ def matmul_wx(weight, xt):
     if not _use_fp16(xt, weight):
         return weight @ xt
     return torch.mm(_w16(weight), xt.to(torch.float16), out_dtype=torch.float32)
+
+
+def split3_enabled(x, weight):
+    """the split3 carrier serves exactly the launches the library would run as split-bf16 fp32 GEMMs: inference, fp32, allow_tf32"""
+    import os
+    return (_policy == "default" and torch.backends.cuda.matmul.allow_tf32 and os.environ.get("DIMSUM_SPLIT3", "1") != "0"
+            and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.shape[-1] % 4 == 0
+            and not torch.is_grad_enabled())
+
+
+def linear_split3(x3, weight):
+    """x3 (M, 3K) bfloat16 left image [hi | hi | lo] @ weight (N, K)^T -> (M, N) float32"""
+    from . import native
+    w3 = native.split3_rows(weight.detach(), left=False)
+    return torch.mm(x3, w3.t(), out_dtype=torch.float32)

@@ -21,6 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import scanning_orders as so
+from . import gemm
 from .attention_fusion import CrossAttentionFusion
 from .dct_layer import init_dct_kernel, init_idct_kernel
 from .mlp import GatedMLP
@@ -127,10 +128,11 @@ class LabelEmbedder(nn.Module):
         return self.in_channels
 
 
-def _ln_modulate(norm, x, shift, scale):
+def _ln_modulate(norm, x, shift, scale, split3=False):
     """modulate(LayerNorm(x), shift, scale) for the affine-free LayerNorms of DiTBlock / FinalLayer (models_dim.py:1536-1553,
     214-219). Inference on the GPU: ONE pass of the fused norm kernel (csrc/norm.hip with the modulation folded in) instead of
-    torch's LayerNorm followed by a modulate pass; under autograd the two-step form, whose pieces have backward kernels."""
+    torch's LayerNorm followed by a modulate pass; under autograd the two-step form, whose pieces have backward kernels.
+    split3: the result as the split-bf16 operand image (B * L, 3H) of the Linear that consumes it (gemm.py)."""
     if torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32 or norm.weight is not None:
         return None
     from . import native
@@ -138,8 +140,9 @@ def _ln_modulate(norm, x, shift, scale):
     ones = norm.__dict__.get("_dimsum_ones")
     if ones is None or ones.device != x.device:
         ones = norm.__dict__["_dimsum_ones"] = torch.ones(H, device=x.device, dtype=torch.float32)
-    y = native.layer_norm_fwd(x.reshape(B * L, H), ones, None, norm.eps, is_rms_norm=False, mod_scale=scale, mod_shift=shift, rows_per_batch=L)[0]
-    return y.view(B, L, H)
+    y = native.layer_norm_fwd(x.reshape(B * L, H), ones, None, norm.eps, is_rms_norm=False, mod_scale=scale, mod_shift=shift, rows_per_batch=L,
+                              **({"split3": True} if split3 else {}))[0]
+    return y if split3 else y.view(B, L, H)
 
 
 class FinalLayer(nn.Module):
@@ -164,12 +167,16 @@ class Attention(nn.Module):
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
         self.proj = nn.Linear(dim, dim)
 
-    def forward_deferred(self, x):
-        """-> (y, b): the module's output is y + b (proj's bias is left to the caller's fused residual pass)."""
+    def forward_deferred(self, x, x3=None):
+        """-> (y, b): the module's output is y + b (proj's bias is left to the caller's fused residual pass).
+        x3: x as a split-bf16 operand image written by the caller's norm kernel (gemm.py, split3); x then only carries the shape."""
         from . import native
         from .attention_fusion import _XattnCoreFn
         B, N, C = x.shape
-        qkv = torch.nn.functional.linear(x, self.qkv.weight)          # bias-free GEMM (fast hipBLASLt path)
+        if x3 is not None:
+            qkv = gemm.linear_split3(x3, self.qkv.weight).view(B, N, 3 * C)
+        else:
+            qkv = torch.nn.functional.linear(x, self.qkv.weight)      # bias-free GEMM (fast hipBLASLt path)
         if native.xattn_supported(qkv, self.head_dim):
             # MFMA self-attention core (csrc/xattn_fusion*.hip, n_dirs = 1); the qkv bias is added inside the kernels
             o = _XattnCoreFn.apply(qkv, None, self.qkv.bias, None, self.num_heads)
@@ -407,10 +414,12 @@ class _CombinedBase(_BlockBase):
             # inference: h' = h + proj(..) + b, RMSNorm(h'), modulate -- ONE pass (csrc/norm.hip with x_bias + modulation)
             from . import native
             B, L, H = hidden_states.shape
+            # ... written directly as the split-bf16 operand image of the w12 GEMM when the library would split it anyway (gemm.py)
+            s3 = gemm.split3_enabled(hidden_states, self.mlp.w12.weight) and getattr(self.mlp, "_fused", False)
             y, _, _, hnew = native.layer_norm_fwd(fused.reshape(B * L, H), self.norm_2.weight, self.norm_2.bias, self.norm_2.eps,
                                                   residual=hidden_states.reshape(B * L, H), is_rms_norm=True, x_bias=pb,
-                                                  mod_scale=scale, mod_shift=shift, rows_per_batch=L)
-            m, mb = self.mlp.forward_deferred(y.view(B, L, H))
+                                                  mod_scale=scale, mod_shift=shift, rows_per_batch=L, **({"split3": True} if s3 else {}))
+            m, mb = self.mlp.forward_deferred(hidden_states, x3=y) if s3 else self.mlp.forward_deferred(y.view(B, L, H))
             return token_ops.gate_residual(hnew.view(B, L, H), m, gate, mb), residual
         hidden_states = token_ops.gate_residual(hidden_states, fused, None, pb)
         return _mlp_tail(self.mlp, hidden_states, self.norm_2(hidden_states), shift, scale, gate), residual
@@ -462,14 +471,19 @@ class DiTBlock(nn.Module):
 
     def forward(self, x, c=None, **kwargs):
         sa, ca, ga, sm, cm, gm = self.adaLN_modulation(c).chunk(6, dim=1)
-        h = _ln_modulate(self.norm1, x, sa, ca)
-        a, ab = self.attn.forward_deferred(token_ops.pre_mixer(self.norm1(x), "none", None, sa, ca) if h is None else h)
+        s3 = gemm.split3_enabled(x, self.attn.qkv.weight)      # inference under allow_tf32: the norm passes write operand images
+        h = _ln_modulate(self.norm1, x, sa, ca, split3=s3)
+        if h is not None and s3:
+            a, ab = self.attn.forward_deferred(x, x3=h)
+        else:
+            a, ab = self.attn.forward_deferred(token_ops.pre_mixer(self.norm1(x), "none", None, sa, ca) if h is None else h)
         x = token_ops.gate_residual(x, a, ga, ab)
-        h = _ln_modulate(self.norm2, x, sm, cm)
+        s3 = s3 and getattr(self.mlp, "_fused", False)
+        h = _ln_modulate(self.norm2, x, sm, cm, split3=s3)
         if h is None:
             return _mlp_tail(self.mlp, x, self.norm2(x), sm, cm, gm)
         if hasattr(self.mlp, "forward_deferred"):
-            m, mb = self.mlp.forward_deferred(h)
+            m, mb = self.mlp.forward_deferred(x, x3=h) if s3 else self.mlp.forward_deferred(h)
             return token_ops.gate_residual(x, m, gm, mb)
         return token_ops.gate_residual(x, self.mlp(h), gm, None)
 

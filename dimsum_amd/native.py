@@ -194,11 +194,12 @@ def causal_conv1d_bwd(x, weight, bias, dout, dx, silu_activation):
 # fused add + RMSNorm / LayerNorm   (Triton _layer_norm_fwd / _layer_norm_bwd, ops/triton/layernorm.py:120-364)
 # ---------------------------------------------------------------------------------------------------------------------
 def layer_norm_fwd(x, weight, bias, eps, residual=None, out_dtype=None, residual_dtype=None, is_rms_norm=False,
-                   x_bias=None, mod_scale=None, mod_shift=None, rows_per_batch=0):
+                   x_bias=None, mod_scale=None, mod_shift=None, rows_per_batch=0, split3=False):
     """x: (M, N) -> (y, mean, rstd, residual_out), like _layer_norm_fwd (layernorm.py:120-187).
     residual_out is x itself when no residual is added and no dtype change is requested.
     Extras: `x_bias` (N) is added to x first (the bias of the Linear that produced x); `mod_scale/mod_shift`
-    ((M / rows_per_batch, N), sharing a row stride) apply y * (1 + scale) + shift per batch element after the norm."""
+    ((M / rows_per_batch, N), sharing a row stride) apply y * (1 + scale) + shift per batch element after the norm;
+    `split3`: y is returned as the split-bf16 left operand image (M, 3N) bfloat16 of the Linear that consumes it (split3_rows)."""
     _gpu(x, weight, bias, residual)
     _check(x.dim() == 2 and x.stride(-1) == 1, "layer_norm_fwd: x must be (M, N) with contiguous rows")
     M, N = x.shape
@@ -206,7 +207,11 @@ def layer_norm_fwd(x, weight, bias, eps, residual=None, out_dtype=None, residual
     if residual is not None:
         _check(residual.shape == x.shape and residual.stride(-1) == 1, "layer_norm_fwd: bad residual")
         residual_dtype = residual.dtype
-    y = torch.empty((M, N), device=x.device, dtype=x.dtype if out_dtype is None else out_dtype)
+    if split3:
+        _check(N % 4 == 0 and out_dtype in (None, torch.bfloat16), "layer_norm_fwd: split3 needs N % 4 == 0 (bfloat16 output)")
+        y = torch.empty((M, 3 * N), device=x.device, dtype=torch.bfloat16)
+    else:
+        y = torch.empty((M, N), device=x.device, dtype=x.dtype if out_dtype is None else out_dtype)
     need_res_out = residual is not None or x_bias is not None or (residual_dtype is not None and residual_dtype != x.dtype)
     if residual_dtype is None:
         residual_dtype = x.dtype
@@ -216,7 +221,7 @@ def layer_norm_fwd(x, weight, bias, eps, residual=None, out_dtype=None, residual
     if M > 0:
         P = _lib.NormParams()
         P.rows, P.cols, P.is_rms_norm, P.eps = M, N, int(is_rms_norm), float(eps)
-        P.x_dtype, P.out_dtype = _DT[x.dtype], _DT[y.dtype]
+        P.x_dtype, P.out_dtype, P.y_split3 = _DT[x.dtype], _DT[y.dtype], int(split3)
         P.residual_dtype = _DT[residual_out.dtype] if residual_out is not None else _DT[x.dtype]
         P.x_row_stride, P.y_row_stride = x.stride(0), y.stride(0)
         if residual is not None:
@@ -393,19 +398,36 @@ def token_transform(x, kind, forward, in_index=None, out_index=None, gate=None, 
     return y if w is None else (y, wdot, wsum)
 
 
-def gated_gelu_fwd(x12, bias=None):
+def gated_gelu_fwd(x12, bias=None, split3=False):
     """x12: (..., 2H) fp32 contiguous (w12 GEMM output WITHOUT bias), bias (2H) or None
-    -> gelu_tanh(x12[..., :H] + bias[:H]) * (x12[..., H:] + bias[H:])   (mlp.py:66-70)"""
+    -> gelu_tanh(x12[..., :H] + bias[:H]) * (x12[..., H:] + bias[H:])   (mlp.py:66-70)
+    split3: the result as the split-bf16 left operand image (..., 3H) bfloat16 of the w3 GEMM (split3_rows)"""
     _gpu(x12, bias)
     _check(x12.dtype == torch.float32 and x12.is_contiguous() and x12.shape[-1] % 8 == 0, "gated_gelu: x12 must be contiguous float32 with 2H % 8 == 0")
     H = x12.shape[-1] // 2
     if bias is not None:
         _check(bias.dtype == torch.float32 and tuple(bias.shape) == (2 * H,) and bias.is_contiguous(), "gated_gelu: bias must be (2H,) float32")
-    h = torch.empty(x12.shape[:-1] + (H,), device=x12.device, dtype=torch.float32)
+    h = torch.empty(x12.shape[:-1] + ((3 * H,) if split3 else (H,)), device=x12.device, dtype=torch.bfloat16 if split3 else torch.float32)
     rows = x12.numel() // (2 * H)
+    fn = _lib.load().dimsum_gated_gelu_fwd_split3 if split3 else _lib.load().dimsum_gated_gelu_fwd
     with torch.cuda.device(x12.device):
-        _lib.check(_lib.load().dimsum_gated_gelu_fwd(_ptr(x12), _ptr(bias), _ptr(h), rows, H, _stream(x12)), "gated_gelu_fwd")
+        _lib.check(fn(_ptr(x12), _ptr(bias), _ptr(h), rows, H, _stream(x12)), "gated_gelu_fwd")
     return h
+
+
+def split3_rows(x, left):
+    """(R, K) float32 rows (stride(1) == 1) -> (R, 3K) bfloat16 split operand image: x = hi + lo, hi = bf16(x), lo = bf16(x - hi);
+    left: [hi | hi | lo] (activations), else [hi | lo | hi] (weights), so that  left_image @ weight_image.T  accumulates
+    hi.hi + hi.lo + lo.hi -- the three products of hipBLASLt's fp32-under-allow_tf32 path -- in ONE bf16 GEMM (csrc/operand_split.hip)."""
+    _gpu(x)
+    _check(x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1 and x.shape[1] % 4 == 0 and x.stride(0) % 4 == 0,
+           "split3_rows: x must be (R, K) float32 with contiguous rows, K % 4 == 0 and a row stride % 4 == 0")
+    R, K = x.shape
+    out = torch.empty((R, 3 * K), device=x.device, dtype=torch.bfloat16)
+    if R > 0:
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().dimsum_split3(_ptr(x), R, K, x.stride(0), _ptr(out), int(bool(left)), _stream(x)), "split3_rows")
+    return out
 
 
 def gated_gelu_bwd(x12, bias, dh, need_dbias=True):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DIMSUM_ABI_VERSION 8
+#define DIMSUM_ABI_VERSION 9
 
 typedef enum {
     DIMSUM_OK = 0,
@@ -162,6 +162,7 @@ int dimsum_causal_conv1d_bwd(const dimsum_conv_bwd_params_t *p, void *stream);
  *   (x_bias = the bias of the Linear that produced x, so that the GEMM runs without a bias epilogue; with it and the
  *   modulation, "h + proj(x) -> RMSNorm -> modulate" of a DiM block is ONE pass instead of three.)
  *   rstd (M) f32 always written; mean (M) f32 written for LayerNorm.
+ *   y_split3: y is written as the split-bf16 operand image the following Linear consumes (below, dimsum_split3).
  * bwd: dx = d(norm)/dr . dy (+ dresidual_out) ; dweight/dbias (N) f32 accumulated with atomics into zero-filled
  * buffers (the Triton reference reduces per-SM partials on the host, layernorm.py:324-359).
  * ------------------------------------------------------------------------------------------------------------- */
@@ -176,7 +177,9 @@ typedef struct {
     const void *xbias_ptr;                      /* (N) f32 or NULL */
     const void *mod_scale_ptr, *mod_shift_ptr;  /* (M / rows_per_batch, N) f32, both or none */
     int64_t mod_row_stride;
-    int32_t rows_per_batch, reserved;
+    int32_t rows_per_batch;
+    int32_t y_split3;   /* != 0: y is a split-bf16 left operand image, rows of 3 N bf16 [hi | hi | lo] (out_dtype BF16, N % 4 == 0,
+                         * y_row_stride >= 3 N): see dimsum_split3 */
 } dimsum_norm_params_t;
 
 typedef struct {
@@ -194,6 +197,17 @@ typedef struct {
 
 int dimsum_norm_fwd(const dimsum_norm_params_t *p, void *stream);
 int dimsum_norm_bwd(const dimsum_norm_bwd_params_t *p, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Split-bf16 operand images for the library GEMMs (csrc/operand_split.hip). No reference counterpart: the reference's
+ * Linears are TF32 GEMMs (allow_tf32, dimsum/train.py:20-21); gfx950 has no TF32 MFMA and hipBLASLt splits fp32 operands
+ * into hi + lo bf16 inside the GEMM. x = hi + lo with hi = bf16(x), lo = bf16(x - hi); a (rows, cols) f32 matrix becomes
+ * (rows, 3 cols) bf16:  left != 0: [hi | hi | lo]  (activations),  left == 0: [hi | lo | hi]  (weights), so that
+ *     left_image (M, 3K) . weight_image (N, 3K)^T  =  hi.hi + hi.lo + lo.hi   accumulated in f32 by ONE bf16 GEMM.
+ * Producer kernels write the left image directly (dimsum_norm_params_t.y_split3, dimsum_gated_gelu_fwd_split3).
+ * cols % 4 == 0, src rows 16-byte aligned (src_row_stride % 4 == 0), dst contiguous and 8-byte aligned.
+ * ------------------------------------------------------------------------------------------------------------- */
+int dimsum_split3(const void *src, int64_t rows, int64_t cols, int64_t src_row_stride, void *dst, int32_t left, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Token-space transforms on (batch, L = grid*grid tokens, channels) f32 tensors: ONE pass that fuses
@@ -287,6 +301,8 @@ int dimsum_xattn_fusion_bwd(const dimsum_xattn_bwd_params_t *p, void *stream);
  * bwd: dx12 (M, 2H); dbias (2H) f32 zero-filled by the caller (column sums of dx12, f32 atomics) or NULL.
  * ------------------------------------------------------------------------------------------------------------- */
 int dimsum_gated_gelu_fwd(const void *x12, const void *bias, void *h, int64_t rows, int64_t hidden, void *stream);
+/* same, h3 = the split-bf16 left operand image of the w3 GEMM: (rows, 3 hidden) bf16, [hi | hi | lo] (dimsum_split3) */
+int dimsum_gated_gelu_fwd_split3(const void *x12, const void *bias, void *h3, int64_t rows, int64_t hidden, void *stream);
 int dimsum_gated_gelu_bwd(const void *x12, const void *bias, const void *dh, void *dx12, void *dbias, int64_t rows,
                           int64_t hidden, void *stream);
 

@@ -1,5 +1,5 @@
 """Full-size oracle comparisons (not only properties): every streaming kernel of the hot path at BASELINE's launch shapes --
-config 2/3 (256, 1024, 256, 16) and config 5 (64, 1152, 1024, 16), operands in the layouts MambaInnerFn produces (d-major
+config 2/3 (256, 1024, 256, 16) and config 5 (64, 1152, 1024, 16; the scan also at the stress shape (16, 1152, 4096, 16)), operands in the layouts MambaInnerFn produces (d-major
 u / delta / z / dout) -- compared with the C / numpy oracle on three batch rows (first, middle, last; all channels, so the
 last channel tile and the largest in-tile offsets are covered). The ops are independent per batch row, so the oracle only
 computes those rows; batch-summed outputs (dA, dD, dweight ...) are pinned by the small-shape tests.
@@ -13,6 +13,7 @@ from conftest import assert_close
 pytestmark = pytest.mark.gpu
 
 SHAPES = [(256, 1024, 256, 16), (64, 1152, 1024, 16)]
+SCAN_SHAPES = SHAPES + [(16, 1152, 4096, 16)]     # + the long-sequence stress shape: one-lane-per-state forward, two 2048-step chunks
 
 
 def rows_of(B):
@@ -33,7 +34,7 @@ def scan_tol(L):
     return dict(rtol=2e-4, atol=0.0, scale_atol=1e-5) if L <= 512 else dict(rtol=6e-4, atol=0.0, scale_atol=1e-4)
 
 
-@pytest.mark.parametrize("B,D,L,N", SHAPES)
+@pytest.mark.parametrize("B,D,L,N", SCAN_SHAPES)
 def test_scan_fwd_bwd_rows_vs_oracle(B, D, L, N):
     from dimsum_amd import native
     from oracle import c_ops

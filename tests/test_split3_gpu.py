@@ -1,0 +1,131 @@
+"""Split-bf16 operand images (csrc/operand_split.hip, gemm.py "split3"): the producer kernels write the left operand of a Linear
+as [hi | hi | lo] bfloat16 rows and ONE plain bf16 library GEMM against the weight image [hi | lo | hi] forms the three
+products hipBLASLt's fp32-under-allow_tf32 path forms. Checked: the images bit for bit against torch's own bf16 rounding, the
+fused producers against the stand-alone converter, the product against float64, and the model with and without the carrier."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _images(x):
+    hi = x.bfloat16()
+    lo = (x - hi.float()).bfloat16()
+    return hi, lo
+
+
+@pytest.mark.parametrize("left", [True, False])
+def test_split3_rows_bit_exact(left):
+    from dimsum_amd import native
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(37, 72, device="cuda", generator=g) * torch.logspace(-6, 6, 72, device="cuda")
+    buf = torch.zeros(37, 80, device="cuda")
+    buf[:, :72] = x                                   # a row stride that is not the width
+    for src in (x, buf[:, :72]):
+        hi, lo = _images(src)
+        want = torch.cat([hi, hi, lo] if left else [hi, lo, hi], 1)
+        got = native.split3_rows(src, left=left)
+        assert got.dtype == torch.bfloat16 and tuple(got.shape) == (37, 216)
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    # hi + lo reproduces x to 2^-16 relative
+    hi, lo = _images(x)
+    assert ((hi.float() + lo.float() - x).abs() <= x.abs() * 2.0 ** -16 + 1e-37).all()
+
+
+def test_split3_rows_rejects_bad_layouts():
+    from dimsum_amd import native
+    with pytest.raises(RuntimeError):
+        native.split3_rows(torch.zeros(4, 6, device="cuda"), left=True)             # K % 4
+    with pytest.raises(RuntimeError):
+        native.split3_rows(torch.zeros(4, 8, device="cuda", dtype=torch.float16), left=True)
+    assert tuple(native.split3_rows(torch.zeros(0, 8, device="cuda"), left=True).shape) == (0, 24)
+
+
+def test_norm_split3_output_matches_converter():
+    from dimsum_amd import native
+    g = torch.Generator(device="cuda").manual_seed(1)
+    M, N, L = 96, 384, 16
+    x, res = torch.randn(M, N, device="cuda", generator=g), torch.randn(M, N, device="cuda", generator=g)
+    w, xb = torch.rand(N, device="cuda", generator=g) + 0.5, torch.randn(N, device="cuda", generator=g)
+    sc, sh = 0.1 * torch.randn(M // L, N, device="cuda", generator=g), torch.randn(M // L, N, device="cuda", generator=g)
+    kw = dict(residual=res, is_rms_norm=True, x_bias=xb, mod_scale=sc, mod_shift=sh, rows_per_batch=L)
+    y, _, rstd, r = native.layer_norm_fwd(x, w, None, 1e-5, **kw)
+    y3, _, rstd3, r3 = native.layer_norm_fwd(x, w, None, 1e-5, split3=True, **kw)
+    assert y3.dtype == torch.bfloat16 and tuple(y3.shape) == (M, 3 * N)
+    assert torch.equal(y3.view(torch.int16), native.split3_rows(y, left=True).view(torch.int16))
+    assert torch.equal(rstd, rstd3) and torch.equal(r, r3)
+    # LayerNorm with bias, no modulation
+    b = torch.randn(N, device="cuda", generator=g)
+    y, *_ = native.layer_norm_fwd(x, w, b, 1e-5)
+    y3, *_ = native.layer_norm_fwd(x, w, b, 1e-5, split3=True)
+    assert torch.equal(y3.view(torch.int16), native.split3_rows(y, left=True).view(torch.int16))
+
+
+def test_gated_gelu_split3_output_is_the_image_of_the_fp32_output():
+    from dimsum_amd import native
+    g = torch.Generator(device="cuda").manual_seed(2)
+    x12, bias = 2 * torch.randn(3, 50, 2 * 136, device="cuda", generator=g), torch.randn(2 * 136, device="cuda", generator=g)
+    for b in (bias, None):
+        h = native.gated_gelu_fwd(x12, b)
+        h3 = native.gated_gelu_fwd(x12, b, split3=True)
+        assert tuple(h3.shape) == (3, 50, 3 * 136) and h3.dtype == torch.bfloat16
+        # (the two instantiations of the kernel may contract gelu(a) * g differently: the image is checked against h to one fp32
+        # ulp + the 2^-16 of the split, and its two hi copies against each other bit for bit)
+        hi, hi2, lo = h3[..., :136], h3[..., 136:272], h3[..., 272:]
+        assert torch.equal(hi.contiguous().view(torch.int16), hi2.contiguous().view(torch.int16))
+        assert ((hi.float() + lo.float() - h).abs() <= h.abs() * (2.0 ** -16 + 2.0 ** -22) + 1e-30).all()
+        assert ((hi.float() - h).abs() <= h.abs() * 2.0 ** -8).all()
+
+
+@pytest.mark.parametrize("M,K,N", [(512, 1024, 768), (4096, 384, 1536), (100, 72, 40)])
+def test_linear_split3_is_an_fp32_class_product(M, K, N):
+    """max error of the 3-product GEMM against float64: 2e-5 of max|y| (the dropped lo.lo term and the bf16 rounding of lo are
+    ~2^-16 relative per product; plain bf16 operands would be ~4e-3) -- and no worse than 1.5x the library's own fp32 path + 1e-6"""
+    from dimsum_amd import gemm, native
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    x, w = torch.randn(M, K, device="cuda", generator=g), torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    ref = x.double() @ w.double().t()
+    y = gemm.linear_split3(native.split3_rows(x, left=True), w)
+    assert y.dtype == torch.float32 and tuple(y.shape) == (M, N)
+    scale = ref.abs().max().item()
+    err = (y - ref).abs().max().item() / scale
+    assert err < 2e-5, err
+    old = torch.backends.cuda.matmul.allow_tf32
+    try:
+        torch.backends.cuda.matmul.allow_tf32 = True
+        err_lib = (torch.nn.functional.linear(x, w) - ref).abs().max().item() / scale
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = old
+    assert err <= 1.5 * err_lib + 1e-6, (err, err_lib)
+
+
+def test_block_with_and_without_split3_carrier(monkeypatch):
+    """DiMBlockCombined(384) inference forward under allow_tf32 against the reference block golden, with the split3 carrier
+    (norm -> w12 -> gated GeLU -> w3 on operand images) and with fp32 operands: the same tolerance as the training-mode golden
+    test; and the two against each other (both are 3-product results: 2e-5 of max|y|)."""
+    from conftest import assert_close, golden
+    from procedural import procedural_fill, seeded
+    T = torch.from_numpy
+    from dimsum_amd.models_dim import create_block
+    g = golden("block_combined_384")
+    blk = create_block(384, norm_epsilon=1e-5, rms_norm=True, residual_in_fp32=True, fused_add_norm=True, layer_idx=1,
+                       scan_type="none", block_type="combined", reverse=True, transpose=True, cond_mamba=True,
+                       scanning_continuity=True, use_gated_mlp=True)
+    procedural_fill(blk, seed=9)
+    blk = blk.cuda()
+    x, res, cc = (T(seeded(sh, sd)).cuda() for sh, sd in (((1, 256, 384), 56), ((1, 256, 384), 57), ((1, 384), 58)))
+    old = torch.backends.cuda.matmul.allow_tf32
+    outs = {}
+    try:
+        torch.backends.cuda.matmul.allow_tf32 = True
+        for flag in ("1", "0"):
+            monkeypatch.setenv("DIMSUM_SPLIT3", flag)
+            with torch.no_grad():
+                outs[flag] = blk(x, res, cc)[0]
+            assert_close(outs[flag].cpu().numpy(), g["y"], what=f"y (DIMSUM_SPLIT3={flag})", rtol=2e-4, atol=0.0, scale_atol=2e-5)
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = old
+    assert not torch.equal(outs["1"], outs["0"])          # the carrier really ran (another summation order)
+    err = (outs["1"] - outs["0"]).abs().max().item() / outs["0"].abs().max().item()
+    assert err < 2e-5, err
