@@ -91,3 +91,17 @@ def test_ops_fail_loudly_without_gpu():
         rms_norm_fn(torch.randn(3, 16), torch.ones(16), None)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         native.selective_scan_fwd(u, u, -torch.rand(4, 8), torch.randn(1, 1, 8, 8), torch.randn(1, 1, 8, 8), None, None, None, True)
+
+
+def test_split3_carrier_is_never_enabled_off_gpu_or_under_autograd():
+    """gemm.split3_enabled: the operand-image carrier serves inference launches of fp32 CUDA tensors under allow_tf32 only"""
+    import torch
+    from dimsum_amd import gemm
+    x, w = torch.zeros(4, 8), torch.zeros(8, 8)
+    old = torch.backends.cuda.matmul.allow_tf32
+    try:
+        torch.backends.cuda.matmul.allow_tf32 = True
+        with torch.no_grad():
+            assert not gemm.split3_enabled(x, w)                    # CPU tensors
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = old

@@ -222,10 +222,13 @@ def test_tiny_model_fwd_bwd():
 
 @tiny
 @pytest.mark.gpu
-def test_hip_graph_replay_is_bit_identical():
+@pytest.mark.parametrize("tf32", [False, True])
+def test_hip_graph_replay_is_bit_identical(tf32, monkeypatch):
     """GraphedForward: the denoiser forward replayed from a captured hipGraph (every libdimsum_hip.so launch recorded on
-    the capture stream) returns exactly the eager result, also for new input values and through the Euler sampler."""
+    the capture stream) returns exactly the eager result, also for new input values and through the Euler sampler -- in exact
+    fp32 and under allow_tf32, where the MLP GEMMs run on split operand images whose weight halves are rebuilt inside the graph."""
     import torch
+    monkeypatch.setattr(torch.backends.cuda.matmul, "allow_tf32", tf32)
     from dimsum_amd.hip_graph import GraphedForward
     from dimsum_amd.models_dim import DiM
     from dimsum_amd.sample_ddp import sample_batch
@@ -252,6 +255,8 @@ def test_hip_graph_replay_is_bit_identical():
         if hasattr(mm, "A_log"):
             mm.A_log.data.add_(0.3)
             mm.in_proj.weight.data.mul_(1.01)
+        if hasattr(mm, "w12"):
+            mm.w12.weight.data.mul_(1.02)
     with torch.no_grad():
         ref2 = m(x, t, y)
     assert not torch.equal(ref2, before) and torch.equal(g(x, t, y), ref2)

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the cross-attention fusion forward kernel at the model's launch shapes (GPU box):
+DiM-L/2 (256 latents, 256 tokens, 8 heads x 64) and DiM-XL/2 at 512 px (64 latents, 1024 tokens, 8 heads x 72)."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dimsum_amd import native  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=256)
+    ap.add_argument("--L", type=int, default=256)
+    ap.add_argument("--heads", type=int, default=8)
+    ap.add_argument("--hd", type=int, default=64)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--exact", action="store_true", help="exact fp32 MFMA kernel instead of the split-bf16 one")
+    a = ap.parse_args()
+    W = 3 * a.heads * a.hd
+    g = torch.Generator(device="cuda").manual_seed(0)
+    q1, q2 = torch.randn(a.B, a.L, W, device="cuda", generator=g), torch.randn(a.B, a.L, W, device="cuda", generator=g)
+    b1, b2 = torch.randn(W, device="cuda", generator=g), torch.randn(W, device="cuda", generator=g)
+    f = lambda: native.xattn_fusion_fwd(q1, q2, a.heads, bias1=b1, bias2=b2, split_bf16=not a.exact)
+    for _ in range(3):
+        f()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.iters + 1)]
+    ev[0].record()
+    for i in range(a.iters):
+        f()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.iters))
+    flop = 2 * 4 * a.B * a.heads * a.L * a.L * a.hd
+    med = ms[len(ms) // 2]
+    print(json.dumps({"kernel": "xattn_fwd" + ("" if not a.exact else "_exact"), "shape": [a.B, a.L, a.heads, a.hd], "ms_median": med, "ms_min": ms[0],
+                      "GFLOP": flop / 1e9, "TFLOPs_equivalent": flop / med / 1e9}))
+
+
+if __name__ == "__main__":
+    main()

@@ -11,7 +11,9 @@ def timeit(f, n=10):
     for _ in range(n): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e3
 
-for (M, K, N) in [(65536, 1024, 8192), (65536, 4096, 1024), (65536, 512, 2048), (65536, 1024, 512)]:
+import sys
+SHAPES = [(65536, 1024, 8192), (65536, 4096, 1024), (65536, 512, 2048), (65536, 1024, 512)] if len(sys.argv) < 2 else [(65536, 1152, 9216), (65536, 4608, 1152), (65536, 1152, 3456), (32768, 1024, 8192), (32768, 4096, 1024)]
+for (M, K, N) in SHAPES:
     x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev)
     fl = 2 * M * K * N
     t0 = timeit(lambda: torch.nn.functional.linear(x, w))
