@@ -317,3 +317,45 @@ def test_bwd_half_dtypes(dtype, tol_rel):
         a, b = a.float().cpu().numpy(), np.asarray(r[name]).reshape(a.shape)
         err, scale = np.abs(a - b).max(), np.abs(b).max()
         assert err <= 1.5 * tol_rel * scale, (name, "vs oracle", err, scale)
+
+
+@pytest.mark.parametrize("variant", [0, 2, 4, 16])
+@pytest.mark.parametrize("B,D,L,G,has_z,has_D", [(2, 70, 151, 1, True, True),      # ragged: D % 4 != 0, L odd (element-wise staging)
+                                                 (2, 70, 152, 2, True, False),     # 2 groups of 35 channels: partial last tiles, vector I/O
+                                                 (1, 6, 4100, 1, False, True),     # two 2048-step chunks + a 4-step tail, no gate
+                                                 (3, 37, 64, 1, True, True)])      # one tile, fewer channels than a wave
+def test_forward_variants_vs_oracle_on_ragged_shapes(variant, B, D, L, G, has_z, has_D):
+    """every forward kernel (forced) at dstate 16 -- the only dstate all four serve -- on shapes that leave tiles partial in the
+    channel and the time direction, against the C oracle: out, out_z, the chunk states x and the saved states of the training variant
+    (the latter against the 64-channel kernel: the oracle has no such output)"""
+    from dimsum_amd import _lib, native
+    from oracle import c_ops
+    lib = _lib.load()
+    N = 16
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + D + L)
+    u = torch.randn(B, D, L, device="cuda", generator=g)
+    z = torch.randn(B, D, L, device="cuda", generator=g) if has_z else None
+    dl = 0.5 * torch.rand(B, D, L, device="cuda", generator=g)
+    A = -0.5 * torch.rand(D, N, device="cuda", generator=g)
+    Bm, Cm = torch.randn(B, G, N, L, device="cuda", generator=g), torch.randn(B, G, N, L, device="cuda", generator=g)
+    Dv = torch.randn(D, device="cuda", generator=g) if has_D else None
+    bias = 0.5 * torch.rand(D, device="cuda", generator=g)
+    n = lambda t: None if t is None else t.cpu().numpy()
+    y_ref, oz_ref, x_ref = c_ops.selective_scan_fwd(n(u), n(dl), n(A), n(Bm), n(Cm), n(Dv), n(z), n(bias), True)
+    try:
+        lib.dimsum_ssm_scan_fwd_force_variant(0)
+        ck0 = native.selective_scan_fwd(u, dl, A, Bm, Cm, Dv, z, bias, True, need_ckpt=True)[-1]
+        lib.dimsum_ssm_scan_fwd_force_variant(variant)
+        res = native.selective_scan_fwd(u, dl, A, Bm, Cm, Dv, z, bias, True, need_ckpt=True)
+        res_inf = native.selective_scan_fwd(u, dl, A, Bm, Cm, Dv, z, bias, True)
+    finally:
+        lib.dimsum_ssm_scan_fwd_force_variant(-1)
+    out, x = res[0], res[1]
+    tol = dict(rtol=2e-4, atol=0.0, scale_atol=1e-5) if L <= 512 else dict(rtol=6e-4, atol=0.0, scale_atol=1e-4)
+    assert_close(n(out), y_ref, what="out", **tol)
+    assert_close(n(x), x_ref, what="x", **tol)
+    if has_z:
+        assert_close(n(res[2]), oz_ref, what="out_z", **tol)
+        assert torch.equal(res_inf[2], res[2])
+    assert torch.equal(res_inf[0], out)
+    assert_close(n(res[-1]), n(ck0), what="saved states", **tol)
