@@ -16,7 +16,7 @@ proj, w12, w3 -- everything else is small).
              [hi | hi | lo] (csrc/operand_split.hip, native.split3_rows); `linear_split3` multiplies it with the weight image
              [hi | lo | hi] in ONE plain bf16 GEMM with fp32 accumulation and output: the same three products the library
              forms inside its fp32 kernels, on its faster bf16 kernels (w12: 2.99 -> 2.67 ms, w3: 1.45 -> 1.27 ms at 65536 rows).
-             `DIMSUM_SPLIT3=0` keeps the fp32 operands.
+             `DIMSUM_SPLIT3=0` keeps the fp32 operands; launches with fewer than `DIMSUM_SPLIT3_MIN_ROWS` (8192) rows keep them too.
 The operands are converted by a torch cast on every call -- weights too: DiM-L/2's 460 M parameters cost ~0.5 ms per
 forward (< 1 %) to cast, and a cached copy could not see in-place updates made through `.data` (EMA updates,
 load_state_dict), which do not bump a tensor's version counter. Outputs stay fp32."""
@@ -67,9 +67,13 @@ def matmul_wx(weight, xt):
 def split3_enabled(x, weight):
     """the split3 carrier serves exactly the launches the library would run as split-bf16 fp32 GEMMs: inference, fp32, allow_tf32"""
     import os
-    return (_policy == "default" and torch.backends.cuda.matmul.allow_tf32 and os.environ.get("DIMSUM_SPLIT3", "1") != "0"
+    if not (_policy == "default" and torch.backends.cuda.matmul.allow_tf32 and os.environ.get("DIMSUM_SPLIT3", "1") != "0"
             and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.shape[-1] % 4 == 0
-            and not torch.is_grad_enabled())
+            and not torch.is_grad_enabled()):
+        return False
+    # the weight image is rebuilt per call (one ~14 us launch): it pays from a few thousand rows on, and in the launch-bound
+    # small-batch regime every extra launch costs wall time -- fp32 operands below DIMSUM_SPLIT3_MIN_ROWS (default 8192) rows
+    return x.numel() // x.shape[-1] >= int(os.environ.get("DIMSUM_SPLIT3_MIN_ROWS", "8192"))
 
 
 def linear_split3(x3, weight):

@@ -229,6 +229,7 @@ def test_hip_graph_replay_is_bit_identical(tf32, monkeypatch):
     fp32 and under allow_tf32, where the MLP GEMMs run on split operand images whose weight halves are rebuilt inside the graph."""
     import torch
     monkeypatch.setattr(torch.backends.cuda.matmul, "allow_tf32", tf32)
+    monkeypatch.setenv("DIMSUM_SPLIT3_MIN_ROWS", "0")          # 4 x 256 rows: below the carrier's default threshold
     from dimsum_amd.hip_graph import GraphedForward
     from dimsum_amd.models_dim import DiM
     from dimsum_amd.sample_ddp import sample_batch

@@ -119,6 +119,7 @@ def test_block_with_and_without_split3_carrier(monkeypatch):
     outs = {}
     try:
         torch.backends.cuda.matmul.allow_tf32 = True
+        monkeypatch.setenv("DIMSUM_SPLIT3_MIN_ROWS", "0")      # 256 rows here: below the default threshold of the carrier
         for flag in ("1", "0"):
             monkeypatch.setenv("DIMSUM_SPLIT3", flag)
             with torch.no_grad():
