@@ -62,7 +62,7 @@ class NormBwdParams(C.Structure):
 
 
 class TtParams(C.Structure):
-    _fields_ = ([(n, i32) for n in ("batch", "tokens", "channels", "grid", "kind", "reserved")]
+    _fields_ = ([(n, i32) for n in ("batch", "tokens", "channels", "grid", "kind", "y_split3")]
                 + [(n, i64) for n in ("x_batch_stride", "x_token_stride", "res_batch_stride", "res_token_stride",
                                       "y_batch_stride", "y_token_stride", "mod_batch_stride", "w_batch_stride",
                                       "w_token_stride", "red_batch_stride")]
@@ -74,7 +74,7 @@ class XattnParams(C.Structure):
     _fields_ = ([(n, i32) for n in ("batch", "seqlen", "heads", "head_dim")] + [("scale", f32), ("n_dirs", i32)]
                 + [(n, i64) for n in ("qkv_batch_stride", "qkv_token_stride", "out_batch_stride", "out_token_stride")]
                 + [(n, vp) for n in ("qkv1_ptr", "qkv2_ptr", "out_ptr", "lse_ptr", "bias1_ptr", "bias2_ptr")]
-                + [("precision", i32), ("reserved", i32)])
+                + [("precision", i32), ("out_split3", i32)])
 
 
 class XattnBwdParams(C.Structure):

@@ -65,8 +65,24 @@ class CrossAttentionFusion(nn.Module):
         y, b = self.forward_deferred(x1, x2)
         return y if b is None else y + b
 
-    def forward_deferred(self, x1, x2):
-        """-> (y, b): the module's output is y + b; b (proj's bias) is left to the caller's fused residual pass."""
+    def takes_images(self, ref):
+        """whether forward_deferred(images=True) is served: the plain variant on the MFMA kernels, no dropout (ref: an fp32 activation)"""
+        return self._plain and not (self.training and (self.attn_drop.p > 0.0 or self.proj_drop.p > 0.0)) and native.xattn_supported(ref, self.head_dim)
+
+    def forward_deferred(self, x1, x2, images=False):
+        """-> (y, b): the module's output is y + b; b (proj's bias) is left to the caller's fused residual pass.
+        images (inference under allow_tf32, see takes_images): x1 / x2 are split-bf16 operand images (B, N, 3 C) written by the
+        branches' last pass; qkv and proj run as plain bf16 GEMMs over them and the attention kernel writes proj's image."""
+        if images:
+            B, N, C3 = x1.shape
+            b1, b2 = self.qkv1.bias, self.qkv2.bias
+            if (b1 is None) != (b2 is None):
+                raise RuntimeError("CrossAttentionFusion: qkv1 / qkv2 must both have a bias or none")
+            qkv1 = gemm.linear_split3(x1.reshape(B * N, C3), self.qkv1.weight).view(B, N, -1)
+            qkv2 = gemm.linear_split3(x2.reshape(B * N, C3), self.qkv2.weight).view(B, N, -1)
+            f3 = native.xattn_fusion_fwd(qkv1, qkv2, self.num_heads, bias1=None if b1 is None else b1.float().contiguous(),
+                                         bias2=None if b2 is None else b2.float().contiguous(), split_bf16=True, split3=True)
+            return gemm.linear_split3(f3.reshape(B * N, -1), self.proj.weight).view(B, N, -1), self.proj.bias
         B, N, C = x1.shape
         drop = self.attn_drop.p if self.training else 0.0
         if self._plain and drop == 0.0 and native.xattn_supported(x1, self.head_dim):

@@ -165,6 +165,13 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
         if (rb) { load_vec(rb + (int64_t)tok * p.res_token_stride + c, t);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) o[e] += t[e]; }
+        if constexpr (VEC == 4) {
+            if (p.y_split3) {       // split-bf16 operand image of the Linear that consumes y: rows of 3 C bf16, strides in bf16 elements
+                st_split3<true>(reinterpret_cast<unsigned short *>(p.y_ptr) + (int64_t)b * p.y_batch_stride + (int64_t)tok * p.y_token_stride, c, C,
+                                f32x4{{o[0], o[1], o[2], o[3]}});
+                return;
+            }
+        }
         float *dst = yb + (int64_t)tok * p.y_token_stride + c;
         if constexpr (VEC == 4) *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
         else dst[0] = o[0];
@@ -394,6 +401,7 @@ extern "C" int dimsum_token_transform(const dimsum_tt_params_t *p, void *stream)
                (!p->scale_ptr || aligned_to<float>(p->scale_ptr, 16)) && (!p->shift_ptr || aligned_to<float>(p->shift_ptr, 16));
     if (p->residual_ptr) vec = vec && aligned_to<float>(p->residual_ptr, 16) && p->res_batch_stride % 4 == 0 && p->res_token_stride % 4 == 0;
     if (p->w_ptr) vec = vec && aligned_to<float>(p->w_ptr, 16) && p->w_batch_stride % 4 == 0 && p->w_token_stride % 4 == 0;
+    if (p->y_split3 && (!vec || !p->y_ptr || p->y_token_stride < 3 * (int64_t)p->channels)) return DIMSUM_ERR_STRIDE;   // image rows: 8-byte pieces
     return vec ? launch_tt<4>(*p, s) : launch_tt<1>(*p, s);
 }
 

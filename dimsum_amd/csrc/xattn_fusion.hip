@@ -412,10 +412,16 @@ __global__ __launch_bounds__(256, (QT == 2 && HD <= 64) ? 3 : (QT == 2 ? 2 : 1))
         if (q_tok[t] < L) {
             const float inv = 1.0f / l_run[t];
             float *dst = reinterpret_cast<float *>(p.out_ptr) + (int64_t)b * p.out_batch_stride + (int64_t)q_tok[t] * p.out_token_stride + dir * C + h * HD;
+            // out_split3: the token's row is the split-bf16 operand image of the proj Linear (3 x ndir x C bf16; strides in bf16 elements)
+            unsigned short *img = reinterpret_cast<unsigned short *>(p.out_ptr) + (int64_t)b * p.out_batch_stride + (int64_t)q_tok[t] * p.out_token_stride;
 #pragma unroll
             for (int e = 0; e < ET; ++e) {
                 const int e0 = e * 16 + kg * 4;
-                if (e0 < HD) *reinterpret_cast<float4 *>(dst + e0) = make_float4(o[t][e][0] * inv, o[t][e][1] * inv, o[t][e][2] * inv, o[t][e][3] * inv);
+                if (e0 < HD) {
+                    const f32x4 v = {{o[t][e][0] * inv, o[t][e][1] * inv, o[t][e][2] * inv, o[t][e][3] * inv}};
+                    if (p.out_split3) st_split3<true>(img, dir * C + h * HD + e0, ndir * C, v);
+                    else *reinterpret_cast<float4 *>(dst + e0) = make_float4(v.v[0], v.v[1], v.v[2], v.v[3]);
+                }
             }
             if (p.lse_ptr && kg == 0)
                 reinterpret_cast<float *>(p.lse_ptr)[(((int64_t)b * ndir + dir) * H + h) * L + q_tok[t]] = (m_run[t] + __builtin_amdgcn_logf(l_run[t])) * kLn2;
@@ -442,6 +448,7 @@ extern "C" int dimsum_xattn_fusion_fwd(const dimsum_xattn_params_t *p, void *str
     if (nblk > 0x7fffffff) return DIMSUM_ERR_SHAPE;
     const dim3 grid((unsigned)nblk), block(256);
     if (p->precision != 0 && p->precision != 1) return DIMSUM_ERR_SHAPE;
+    if (p->out_split3 && (p->precision != 1 || p->out_token_stride < 3 * (int64_t)(self_attn ? 1 : 2) * p->heads * p->head_dim)) return DIMSUM_ERR_STRIDE;
     if (p->precision == 1) {
         // 2 query tiles per wave (128 queries per workgroup) halve the per-query staging work; short sequences keep 1
         const bool two = p->seqlen >= 128;

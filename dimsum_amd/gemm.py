@@ -81,3 +81,10 @@ def linear_split3(x3, weight):
     from . import native
     w3 = native.split3_rows(weight.detach(), left=False)
     return torch.mm(x3, w3.t(), out_dtype=torch.float32)
+
+
+def matmul_wx_split3(weight, x3):
+    """weight (N, K) @ x^T -> (N, M) float32 with x given as its left image x3 (M, 3K): the in_proj site (d-major output)"""
+    from . import native
+    w3 = native.split3_rows(weight.detach(), left=False)
+    return torch.mm(w3, x3.t(), out_dtype=torch.float32)

@@ -175,6 +175,11 @@ class Attention(nn.Module):
         B, N, C = x.shape
         if x3 is not None:
             qkv = gemm.linear_split3(x3, self.qkv.weight).view(B, N, 3 * C)
+            if native.xattn_supported(qkv, self.head_dim):
+                # the attention kernel writes the operand image of proj directly
+                qb = None if self.qkv.bias is None else self.qkv.bias.float().contiguous()
+                o3 = native.xattn_fusion_fwd(qkv, None, self.num_heads, bias1=qb, split_bf16=True, split3=True)
+                return gemm.linear_split3(o3.reshape(B * N, -1), self.proj.weight).view(B, N, C), self.proj.bias
         else:
             qkv = torch.nn.functional.linear(x, self.qkv.weight)      # bias-free GEMM (fast hipBLASLt path)
         if native.xattn_supported(qkv, self.head_dim):
@@ -242,6 +247,14 @@ def _mlp_tail(mlp, x, normed, shift, scale, gate):
     return token_ops.gate_residual(x, mlp(h), gate, None)
 
 
+def _mix_through_images(mixer, hidden_states, kind, table, shift, scale, c):
+    """mixer(pre_mixer(hidden_states)); at inference under allow_tf32 the pre-mixer pass writes the in_proj operand as a
+    split-bf16 image (gemm.py, split3) instead of fp32"""
+    if getattr(mixer, "takes_image", lambda: False)() and gemm.split3_enabled(hidden_states, mixer.in_proj.weight):
+        return mixer(None, c, x3=token_ops.pre_mixer(hidden_states, kind, table, shift, scale, split3=True))
+    return mixer(token_ops.pre_mixer(hidden_states, kind, table, shift, scale), c)
+
+
 # ---- shared block plumbing ----------------------------------------------------------------------------------------------
 class _BlockBase(nn.Module):
     """Add -> Norm prologue shared by all blocks (e.g. models_dim.py:1460-1494) + cached gather tables."""
@@ -305,12 +318,13 @@ class DiMBlockRaw(_BlockBase):
             return None
         return so.block_order_table(H, self.reverse, self.transpose, self.scanning_continuity)
 
-    def forward(self, hidden_states, residual=None, c=None, inference_params=None):
+    def forward(self, hidden_states, residual=None, c=None, inference_params=None, out_split3=False):
+        """out_split3 (inference, set by an enclosing combined block): the result as the split-bf16 operand image of the qkv Linear"""
         hidden_states, residual = self._prenorm(hidden_states, residual)
         table = self._table(hidden_states.shape[1], hidden_states.device, self._order)
         shift, scale, gate = self.adaLN_modulation(c).chunk(3, dim=1)
-        m = self.mixer(token_ops.pre_mixer(hidden_states, "none", table, shift, scale), c)
-        return token_ops.post_mixer(hidden_states, m, gate, "none", table), residual
+        m = _mix_through_images(self.mixer, hidden_states, "none", table, shift, scale, c)
+        return token_ops.post_mixer(hidden_states, m, gate, "none", table, **({"split3": True} if out_split3 else {})), residual
 
 
 class _FreqBlock(_BlockBase):
@@ -330,14 +344,15 @@ class _FreqBlock(_BlockBase):
             self.norm_2 = norm_cls(dim)
             self.mlp = _make_mlp(dim)
 
-    def forward(self, hidden_states, residual=None, c=None, inference_params=None):
+    def forward(self, hidden_states, residual=None, c=None, inference_params=None, out_split3=False):
         hidden_states, residual = self._prenorm(hidden_states, residual)
         table = self._table(hidden_states.shape[1], hidden_states.device, self._order)
         mods = self.adaLN_modulation(c).chunk(3 if self.no_ffn else 6, dim=1)
         shift, scale, gate = mods[:3]
         if self.no_ffn:
-            m = self.mixer(token_ops.pre_mixer(hidden_states, self.kind, table, shift, scale), c)
-            return token_ops.post_mixer(hidden_states, m, gate, self.kind, table), residual
+            m = _mix_through_images(self.mixer, hidden_states, self.kind, table, shift, scale, c)
+            return token_ops.post_mixer(hidden_states, m, gate, self.kind, table, **({"split3": True} if out_split3 else {})), residual
+        assert not out_split3
         # with an FFN the reference keeps working in the transformed / reordered token space (models_dim.py:678-684)
         t = token_ops.pre_mixer(hidden_states, self.kind, table, torch.zeros_like(shift), torch.zeros_like(scale))
         t = t + gate.unsqueeze(1) * self.mixer(modulate(t, shift, scale), c)
@@ -405,10 +420,13 @@ class _CombinedBase(_BlockBase):
     def forward(self, hidden_states, residual=None, c=None, inference_params=None):
         hidden_states, residual = self._prenorm(hidden_states, residual)
         x1, x2 = hidden_states.chunk(2, dim=2)
-        x1, _ = self.spatial_mamba(x1, None, c, inference_params)
-        x2, _ = self.freq_mamba(x2, None, c, inference_params)
+        # inference under allow_tf32: the branches hand their results over as split-bf16 operand images of the qkv Linears
+        img = gemm.split3_enabled(x1, self.proj.qkv1.weight) and self.proj.takes_images(hidden_states)
+        kw = {"out_split3": True} if img else {}
+        x1, _ = self.spatial_mamba(x1, None, c, inference_params, **kw)
+        x2, _ = self.freq_mamba(x2, None, c, inference_params, **kw)
         # residual tails as single fused passes; the Linear biases ride along (mlp.py / attention_fusion.py docstrings)
-        fused, pb = self.proj.forward_deferred(x1, x2)
+        fused, pb = self.proj.forward_deferred(x1, x2, **({"images": True} if img else {}))
         shift, scale, gate = self.adaLN_modulation(c).chunk(3, dim=1)
         if not torch.is_grad_enabled() and isinstance(self.norm_2, RMSNorm) and hasattr(self.mlp, "forward_deferred") and hidden_states.dtype == torch.float32:
             # inference: h' = h + proj(..) + b, RMSNorm(h'), modulate -- ONE pass (csrc/norm.hip with x_bias + modulation)

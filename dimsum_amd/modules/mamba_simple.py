@@ -85,14 +85,23 @@ class _MambaBase(nn.Module):
     def _is_zigzag(self):
         return self.scan_type.startswith(_ZIGZAG)
 
-    def _mix(self, hidden_states, cond):
-        bsz, L, _ = hidden_states.shape
+    def takes_image(self):
+        """whether `x3` (the input as a split-bf16 operand image, gemm.py) can replace hidden_states: not when this mixer
+        gathers its tokens itself"""
+        return not (self._is_zigzag() and not getattr(self, "_zigzag_folded", False))
+
+    def _mix(self, hidden_states, cond, x3=None):
+        bsz, L, _ = (hidden_states if x3 is None else x3).shape
         own_gather = self._is_zigzag() and not getattr(self, "_zigzag_folded", False)   # folded: the enclosing block's token
         if own_gather:                                                                  # tables already include the path
+            assert x3 is None
             # xz[..., j] = xz[..., perm[j]]: permuting the columns of xz == permuting the tokens before in_proj
             hidden_states = hidden_states.index_select(1, self.zigzag_paths[self.layer_idx])
         # in_proj with the transpose fused: (2D, d_model) @ (d_model, B*L) viewed as (B, 2D, L) -- d-major, no copy
-        xz = gemm.matmul_wx(self.in_proj.weight, hidden_states.reshape(bsz * L, -1).t()).view(2 * self.d_inner, bsz, L).permute(1, 0, 2)
+        if x3 is not None:
+            xz = gemm.matmul_wx_split3(self.in_proj.weight, x3.reshape(bsz * L, -1)).view(2 * self.d_inner, bsz, L).permute(1, 0, 2)
+        else:
+            xz = gemm.matmul_wx(self.in_proj.weight, hidden_states.reshape(bsz * L, -1).t()).view(2 * self.d_inner, bsz, L).permute(1, 0, 2)
         if self.in_proj.bias is not None:
             xz = xz + self.in_proj.bias.to(xz.dtype).view(1, -1, 1)
         # recomputed on every call (two tiny launches): a cached copy could not see in-place parameter updates made through
@@ -121,17 +130,18 @@ class _MambaBase(nn.Module):
 
 
 class Mamba(_MambaBase):
-    def forward(self, hidden_states, inference_params=None):
-        """hidden_states: (B, L, D) -> (B, L, D)."""
+    def forward(self, hidden_states, inference_params=None, x3=None):
+        """hidden_states: (B, L, D) -> (B, L, D).  x3: the input as a split-bf16 operand image instead (inference, gemm.py)."""
         assert inference_params is None, "autoregressive decode is outside the denoiser hot path"
-        return self._mix(hidden_states, None)
+        return self._mix(hidden_states, None, x3=x3)
 
 
 class CondMamba(_MambaBase):
-    def forward(self, hidden_states, cond_emb=None, inference_params=None):
-        """hidden_states: (B, L, D), cond_emb: (B, d_cond) -> (B, L, D). See the module docstring about cond_proj."""
+    def forward(self, hidden_states, cond_emb=None, inference_params=None, x3=None):
+        """hidden_states: (B, L, D), cond_emb: (B, d_cond) -> (B, L, D). See the module docstring about cond_proj.
+        x3: the input as a split-bf16 operand image instead (inference, gemm.py)."""
         assert inference_params is None, "autoregressive decode is outside the denoiser hot path"
         cond = None
         if cond_emb is not None and torch.is_grad_enabled() and self.d_cond is not None:
             cond = self.cond_proj(cond_emb)       # (B, d_inner): graph edge only, never read by a kernel
-        return self._mix(hidden_states, cond)
+        return self._mix(hidden_states, cond, x3=x3)

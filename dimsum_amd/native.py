@@ -343,13 +343,14 @@ _TT_KIND = {("none", True): 0, ("none", False): 0, ("haar", True): 1, ("haar", F
 
 
 def token_transform(x, kind, forward, in_index=None, out_index=None, gate=None, scale=None, shift=None, residual=None,
-                    w=None, want_y=True, want_wsum=False, want_tsum=False):
+                    w=None, want_y=True, want_wsum=False, want_tsum=False, split3=False):
     """y[b, out_index[s], c] = T(x[b, in_index[s], c] * gate[b, c])[s] * (1 + scale[b, c]) + shift[b, c] + residual[b, out_index[s], c]
     x: (B, L, C) fp32 with unit channel stride (may be a channel slice of a wider tensor); index tables int32 (L,).
     With a weight tensor `w` (indexed like y) the same pass also reduces, per (batch, channel),
         wdot = sum_s T(.)[s, c] * w[b, out_index[s], c]     and (want_wsum)  wsum = sum_s w[b, out_index[s], c]
     and returns (y or None, wdot, wsum or None) -- the adaLN-modulation gradients of the block backward.
-    `want_tsum` appends tsum = sum_s T(.)[s, c] (the plain token sum) to the returned tuple."""
+    `want_tsum` appends tsum = sum_s T(.)[s, c] (the plain token sum) to the returned tuple.
+    `split3`: y is returned as the split-bf16 left operand image (B, L, 3C) bfloat16 of the Linear that consumes it (split3_rows)."""
     _gpu(x, in_index, out_index, gate, scale, shift, residual, w)
     _check(x.dim() == 3 and x.dtype == torch.float32 and x.stride(2) == 1, "token_transform: x must be (B, L, C) float32, channel-contiguous")
     B, L, C = x.shape
@@ -357,7 +358,11 @@ def token_transform(x, kind, forward, in_index=None, out_index=None, gate=None, 
     if kind != "none":
         _check(grid * grid == L and grid % 4 == 0, "token_transform: the token grid must be square with side % 4 == 0")
     _check(want_y or w is not None or want_tsum, "token_transform: nothing to compute")
-    y = torch.empty((B, L, C), device=x.device, dtype=torch.float32) if want_y else None
+    if split3:
+        _check(want_y and C % 4 == 0, "token_transform: split3 needs an output and channels % 4 == 0")
+        y = torch.empty((B, L, 3 * C), device=x.device, dtype=torch.bfloat16)
+    else:
+        y = torch.empty((B, L, C), device=x.device, dtype=torch.float32) if want_y else None
     mods = [m for m in (gate, scale, shift) if m is not None]
     mstride = 0
     for m in mods:
@@ -379,6 +384,7 @@ def token_transform(x, kind, forward, in_index=None, out_index=None, gate=None, 
     if B > 0:
         P = _lib.TtParams()
         P.batch, P.tokens, P.channels, P.grid, P.kind = B, L, C, grid, _TT_KIND[(kind, bool(forward))]
+        P.y_split3 = int(split3)
         P.x_batch_stride, P.x_token_stride = x.stride(0), x.stride(1)
         if y is not None:
             P.y_batch_stride, P.y_token_stride = y.stride(0), y.stride(1)
@@ -451,12 +457,13 @@ def xattn_supported(qkv, head_dim):
     return qkv.is_cuda and qkv.dtype == torch.float32 and qkv.stride(-1) == 1 and head_dim in (24, 32, 48, 64, 72)
 
 
-def xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=False, bias1=None, bias2=None, split_bf16=None):
+def xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=False, bias1=None, bias2=None, split_bf16=None, split3=False):
     """qkv*: (B, L, 3*heads*hd) -> (B, L, 2*heads*hd) = cat(softmax(q1 k2^T/sqrt(hd)) v2, softmax(q2 k1^T/sqrt(hd)) v1).
     qkv2 = None: plain self-attention softmax(q1 k1^T/sqrt(hd)) v1 -> (B, L, heads*hd).
     bias1/bias2 (3*heads*hd): the qkv Linear biases when qkv* are bias-free GEMM outputs (added inside the kernel).
     split_bf16: None follows torch.backends.cuda.matmul.allow_tf32 (the reference's GEMM policy, train.py:20-21: the
-    QK^T / PV contractions then run as split-bf16 MFMA like the library GEMMs do); False = exact fp32 MFMA."""
+    QK^T / PV contractions then run as split-bf16 MFMA like the library GEMMs do); False = exact fp32 MFMA.
+    split3 (split-bf16 kernel only): the result as the split-bf16 left operand image (B, L, 3 * width) bfloat16 of the proj Linear."""
     self_attn = qkv2 is None
     if split_bf16 is None:
         split_bf16 = bool(torch.backends.cuda.matmul.allow_tf32)
@@ -471,7 +478,11 @@ def xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=False, bias1=None, bias2=None, 
     if not self_attn:
         _check(qkv1.shape == qkv2.shape and qkv2.dtype == torch.float32 and qkv1.stride() == qkv2.stride(), "xattn_fusion: qkv1/qkv2 must share shape and strides")
     nd = 1 if self_attn else 2
-    out = torch.empty((B, L, nd * heads * hd), device=qkv1.device, dtype=torch.float32)
+    if split3:
+        _check(split_bf16, "xattn_fusion: the operand image output exists for the split-bf16 kernel only")
+        out = torch.empty((B, L, 3 * nd * heads * hd), device=qkv1.device, dtype=torch.bfloat16)
+    else:
+        out = torch.empty((B, L, nd * heads * hd), device=qkv1.device, dtype=torch.float32)
     lse = torch.empty((B, nd, heads, L), device=qkv1.device, dtype=torch.float32) if need_lse else None
     if B > 0:
         P = _lib.XattnParams()
@@ -481,6 +492,7 @@ def xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=False, bias1=None, bias2=None, 
         P.qkv1_ptr, P.qkv2_ptr, P.out_ptr, P.lse_ptr = _ptr(qkv1), _ptr(qkv2), _ptr(out), _ptr(lse)
         P.bias1_ptr, P.bias2_ptr = _ptr(bias1), _ptr(bias2)
         P.precision = 1 if split_bf16 else 0
+        P.out_split3 = int(split3)
         with torch.cuda.device(qkv1.device):
             _lib.check(_lib.load().dimsum_xattn_fusion_fwd(P, _stream(qkv1)), "xattn_fusion_fwd")
     return (out, lse) if need_lse else out

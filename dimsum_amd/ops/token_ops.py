@@ -217,13 +217,19 @@ def gate_residual(res, m, gate=None, bias=None):
     return _GateResidual.apply(res, m, gate, bias)
 
 
-def pre_mixer(x, kind, table, shift, scale):
-    """y = modulate(P(T(x)))."""
+def pre_mixer(x, kind, table, shift, scale, split3=False):
+    """y = modulate(P(T(x))).  split3 (inference): y as the split-bf16 operand image (B, L, 3C) of the Linear that consumes it."""
     _require_gpu(x)
+    if split3:
+        from .. import native
+        return native.token_transform(_cc(x), kind, True, out_index=None if table is None else table["inv32"], scale=scale, shift=shift, split3=True)
     return _PreMixer.apply(x, shift, scale, kind, None if table is None else table["inv32"])
 
 
-def post_mixer(x, m, gate, kind, table):
-    """y = x + T^-1(P^-1(gate * m))."""
+def post_mixer(x, m, gate, kind, table, split3=False):
+    """y = x + T^-1(P^-1(gate * m)).  split3 (inference): y as the split-bf16 operand image (B, L, 3C)."""
     _require_gpu(x)
+    if split3:
+        from .. import native
+        return native.token_transform(_cc(m), kind, False, in_index=None if table is None else table["inv32"], gate=gate, residual=_cc(x), split3=True)
     return _PostMixer.apply(x, m, gate, kind, None if table is None else table["inv32"])

@@ -235,7 +235,8 @@ typedef enum {
 typedef struct {
     int32_t batch, tokens, channels, grid; /* tokens = grid*grid, grid % 4 == 0 unless kind == NONE */
     int32_t kind;                          /* dimsum_tt_kind_t */
-    int32_t reserved;
+    int32_t y_split3;                      /* != 0: y is the split-bf16 left operand image of the Linear that consumes it: rows of
+                                              3 C bf16 [hi | hi | lo] (dimsum_split3); y strides in bf16 elements, channels % 4 == 0 */
     int64_t x_batch_stride, x_token_stride;           /* channel stride 1 everywhere */
     int64_t res_batch_stride, res_token_stride;
     int64_t y_batch_stride, y_token_stride;
@@ -276,7 +277,8 @@ typedef struct {
                            x = hi + lo (two bf16), products hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_bf16 with fp32
                            accumulation, ~1e-5 relative: the same arithmetic hipBLASLt uses for the reference's
                            torch.backends.cuda.matmul.allow_tf32 = True policy (train.py:20-21) on gfx950 */
-    int32_t reserved;
+    int32_t out_split3; /* forward, precision 1 only. != 0: out rows are the split-bf16 operand image of the proj Linear:
+                           3 x (n_dirs' x heads x hd) bf16 [hi | hi | lo] (dimsum_split3); out strides in bf16 elements */
 } dimsum_xattn_params_t;
 
 int dimsum_xattn_fusion_fwd(const dimsum_xattn_params_t *p, void *stream);

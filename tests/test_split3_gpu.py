@@ -78,6 +78,44 @@ def test_gated_gelu_split3_output_is_the_image_of_the_fp32_output():
         assert ((hi.float() - h).abs() <= h.abs() * 2.0 ** -8).all()
 
 
+@pytest.mark.parametrize("kind", ["none", "haar", "dct"])
+def test_token_transform_split3_output_matches_converter(kind):
+    """pre- and post-mixer passes (modulate / gate + residual, token gather, 4x4 transforms) writing the operand image directly"""
+    from dimsum_amd import native
+    g = torch.Generator(device="cuda").manual_seed(3)
+    B, L, C = 3, 64, 40
+    wide = torch.randn(B, L, 2 * C, device="cuda", generator=g)
+    x, res = wide[:, :, :C], wide[:, :, C:]                     # channel slices of a wider tensor, like x1 / x2 of a combined block
+    sc, sh = 0.1 * torch.randn(B, C, device="cuda", generator=g), torch.randn(B, C, device="cuda", generator=g)
+    perm = torch.randperm(L, device="cuda", generator=g).to(torch.int32)
+    kw_pre = dict(out_index=perm, scale=sc, shift=sh)
+    kw_post = dict(in_index=perm, gate=sc, residual=res)
+    for fwd, kw in ((True, kw_pre), (False, kw_post)):
+        y = native.token_transform(x, kind, fwd, **kw)
+        y3 = native.token_transform(x, kind, fwd, split3=True, **kw)
+        assert y3.dtype == torch.bfloat16 and tuple(y3.shape) == (B, L, 3 * C)
+        assert torch.equal(y3.reshape(B * L, -1).view(torch.int16), native.split3_rows(y.reshape(B * L, C), left=True).view(torch.int16))
+
+
+@pytest.mark.parametrize("hd,self_attn", [(24, False), (64, False), (72, False), (64, True)])
+def test_xattn_split3_output_matches_converter(hd, self_attn):
+    from dimsum_amd import native
+    g = torch.Generator(device="cuda").manual_seed(hd)
+    B, L, H = 2, 200, 4
+    W = 3 * H * hd
+    q1 = torch.randn(B, L, W, device="cuda", generator=g)
+    q2 = None if self_attn else torch.randn(B, L, W, device="cuda", generator=g)
+    b1 = torch.randn(W, device="cuda", generator=g)
+    b2 = None if self_attn else torch.randn(W, device="cuda", generator=g)
+    o = native.xattn_fusion_fwd(q1, q2, H, bias1=b1, bias2=b2, split_bf16=True)
+    o3 = native.xattn_fusion_fwd(q1, q2, H, bias1=b1, bias2=b2, split_bf16=True, split3=True)
+    width = o.shape[-1]
+    assert o3.dtype == torch.bfloat16 and tuple(o3.shape) == (B, L, 3 * width)
+    assert torch.equal(o3.reshape(B * L, -1).view(torch.int16), native.split3_rows(o.reshape(B * L, width), left=True).view(torch.int16))
+    with pytest.raises(RuntimeError):
+        native.xattn_fusion_fwd(q1, q2, H, bias1=b1, bias2=b2, split_bf16=False, split3=True)      # exact-fp32 kernel has no image output
+
+
 @pytest.mark.parametrize("M,K,N", [(512, 1024, 768), (4096, 384, 1536), (100, 72, 40)])
 def test_linear_split3_is_an_fp32_class_product(M, K, N):
     """max error of the 3-product GEMM against float64: 2e-5 of max|y| (the dropped lo.lo term and the bf16 rounding of lo are

@@ -12,7 +12,7 @@ def timeit(f, n=10):
     torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e3
 
 import sys
-SHAPES = [(65536, 1024, 8192), (65536, 4096, 1024), (65536, 512, 2048), (65536, 1024, 512)] if len(sys.argv) < 2 else [(65536, 1152, 9216), (65536, 4608, 1152), (65536, 1152, 3456), (32768, 1024, 8192), (32768, 4096, 1024)]
+SHAPES = [(65536, 1024, 8192), (65536, 4096, 1024), (65536, 512, 2048), (65536, 1024, 512)] if len(sys.argv) < 2 else [(65536, 512, 1536), (65536, 1024, 1024), (65536, 1024, 3072), (65536, 576, 1728), (65536, 1152, 1152)]
 for (M, K, N) in SHAPES:
     x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev)
     fl = 2 * M * K * N
