@@ -73,6 +73,7 @@ template <> __device__ __forceinline__ void st4<__hip_bfloat16>(__hip_bfloat16 *
 // [hi | hi | lo] for the left operand, [hi | lo | hi] for the weights, 3 K bf16 per row), which turns the product into ONE
 // plain bf16 GEMM over 3 K -- the library's fastest kernels.
 __device__ __forceinline__ void split2(float x0, float x1, unsigned &hi, unsigned &lo) {   // packed [x0 | x1 << 16]
+#pragma clang fp contract(off)      // lo = bf16(x - hi) of the ROUNDED x: a producer's last multiply must not fuse into the subtraction
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     typedef float f2 __attribute__((ext_vector_type(2)));
     const bf16x2 h = __builtin_convertvector(f2{x0, x1}, bf16x2);

@@ -409,23 +409,63 @@ __global__ __launch_bounds__(256, (QT == 2 && HD <= 64) ? 3 : (QT == 2 ? 2 : 1))
 
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-        if (q_tok[t] < L) {
-            const float inv = 1.0f / l_run[t];
-            float *dst = reinterpret_cast<float *>(p.out_ptr) + (int64_t)b * p.out_batch_stride + (int64_t)q_tok[t] * p.out_token_stride + dir * C + h * HD;
-            // out_split3: the token's row is the split-bf16 operand image of the proj Linear (3 x ndir x C bf16; strides in bf16 elements)
-            unsigned short *img = reinterpret_cast<unsigned short *>(p.out_ptr) + (int64_t)b * p.out_batch_stride + (int64_t)q_tok[t] * p.out_token_stride;
+        const bool valid = q_tok[t] < L;
+        const float inv = 1.0f / l_run[t];
+        const int64_t row_off = (int64_t)b * p.out_batch_stride + (int64_t)min(q_tok[t], L - 1) * p.out_token_stride;
+        if (p.out_split3) {
+            // the token's row is the split-bf16 operand image of the proj Linear (3 x ndir x C bf16 [hi | hi | lo]; strides in bf16
+            // elements). The 4 lanes of a query (kg = 0..3) each hold 4 of every 16 e: a 4 x 4 block transpose over v_permlane32_swap /
+            // v_permlane16_swap gives lane kg the whole e-tile kg, i.e. 16 consecutive e = 32-byte pieces and 128 contiguous bytes per
+            // query and plane (8-byte pieces at a 32-byte stride cost the head_dim-64 kernel +86 us).
+            unsigned short *img = reinterpret_cast<unsigned short *>(p.out_ptr) + row_off;
+            const int N = ndir * C, col0 = dir * C + h * HD;
+            constexpr int kTr = ET >= 4 ? 4 : 0;          // e-tiles that go through the transpose
+            if constexpr (kTr == 4) {
+                float x[4][4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[e][r] = o[t][e][r] * inv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    { auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[0][r]), __float_as_uint(x[2][r]), false, false); x[0][r] = __uint_as_float(q[0]); x[2][r] = __uint_as_float(q[1]); }
+                    { auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[1][r]), __float_as_uint(x[3][r]), false, false); x[1][r] = __uint_as_float(q[0]); x[3][r] = __uint_as_float(q[1]); }
+                    { auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[0][r]), __float_as_uint(x[1][r]), false, false); x[0][r] = __uint_as_float(q[0]); x[1][r] = __uint_as_float(q[1]); }
+                    { auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[2][r]), __float_as_uint(x[3][r]), false, false); x[2][r] = __uint_as_float(q[0]); x[3][r] = __uint_as_float(q[1]); }
+                }
+                // lane kg: x[j][r] = e-tile kg, e = 16 kg + 4 j + r
+                unsigned hw[8], lw[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { split2(x[j][0], x[j][1], hw[2 * j], lw[2 * j]); split2(x[j][2], x[j][3], hw[2 * j + 1], lw[2 * j + 1]); }
+                if (valid) {
+                    unsigned short *d0 = img + col0 + 16 * kg;
+#pragma unroll
+                    for (int hlf = 0; hlf < 2; ++hlf) {
+                        const uint4 hv = make_uint4(hw[4 * hlf], hw[4 * hlf + 1], hw[4 * hlf + 2], hw[4 * hlf + 3]);
+                        const uint4 lv = make_uint4(lw[4 * hlf], lw[4 * hlf + 1], lw[4 * hlf + 2], lw[4 * hlf + 3]);
+                        *reinterpret_cast<uint4 *>(d0 + 8 * hlf) = hv;
+                        *reinterpret_cast<uint4 *>(d0 + N + 8 * hlf) = hv;
+                        *reinterpret_cast<uint4 *>(d0 + 2 * N + 8 * hlf) = lv;
+                    }
+                }
+            }
+            if (valid) {
+#pragma unroll
+                for (int e = kTr; e < ET; ++e) {
+                    const int e0 = e * 16 + kg * 4;
+                    if (e0 < HD) st_split3<true>(img, col0 + e0, N, f32x4{{o[t][e][0] * inv, o[t][e][1] * inv, o[t][e][2] * inv, o[t][e][3] * inv}});
+                }
+            }
+        } else if (valid) {
+            float *dst = reinterpret_cast<float *>(p.out_ptr) + row_off + dir * C + h * HD;
 #pragma unroll
             for (int e = 0; e < ET; ++e) {
                 const int e0 = e * 16 + kg * 4;
-                if (e0 < HD) {
-                    const f32x4 v = {{o[t][e][0] * inv, o[t][e][1] * inv, o[t][e][2] * inv, o[t][e][3] * inv}};
-                    if (p.out_split3) st_split3<true>(img, dir * C + h * HD + e0, ndir * C, v);
-                    else *reinterpret_cast<float4 *>(dst + e0) = make_float4(v.v[0], v.v[1], v.v[2], v.v[3]);
-                }
+                if (e0 < HD) *reinterpret_cast<float4 *>(dst + e0) = make_float4(o[t][e][0] * inv, o[t][e][1] * inv, o[t][e][2] * inv, o[t][e][3] * inv);
             }
-            if (p.lse_ptr && kg == 0)
-                reinterpret_cast<float *>(p.lse_ptr)[(((int64_t)b * ndir + dir) * H + h) * L + q_tok[t]] = (m_run[t] + __builtin_amdgcn_logf(l_run[t])) * kLn2;
         }
+        if (valid && p.lse_ptr && kg == 0)
+            reinterpret_cast<float *>(p.lse_ptr)[(((int64_t)b * ndir + dir) * H + h) * L + q_tok[t]] = (m_run[t] + __builtin_amdgcn_logf(l_run[t])) * kLn2;
     }
 }
 

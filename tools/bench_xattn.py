@@ -20,12 +20,13 @@ def main():
     ap.add_argument("--hd", type=int, default=64)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--exact", action="store_true", help="exact fp32 MFMA kernel instead of the split-bf16 one")
+    ap.add_argument("--split3", action="store_true", help="write the output as the split-bf16 operand image of the proj Linear")
     a = ap.parse_args()
     W = 3 * a.heads * a.hd
     g = torch.Generator(device="cuda").manual_seed(0)
     q1, q2 = torch.randn(a.B, a.L, W, device="cuda", generator=g), torch.randn(a.B, a.L, W, device="cuda", generator=g)
     b1, b2 = torch.randn(W, device="cuda", generator=g), torch.randn(W, device="cuda", generator=g)
-    f = lambda: native.xattn_fusion_fwd(q1, q2, a.heads, bias1=b1, bias2=b2, split_bf16=not a.exact)
+    f = lambda: native.xattn_fusion_fwd(q1, q2, a.heads, bias1=b1, bias2=b2, split_bf16=not a.exact, split3=a.split3)
     for _ in range(3):
         f()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.iters + 1)]
@@ -37,7 +38,7 @@ def main():
     ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.iters))
     flop = 2 * 4 * a.B * a.heads * a.L * a.L * a.hd
     med = ms[len(ms) // 2]
-    print(json.dumps({"kernel": "xattn_fwd" + ("" if not a.exact else "_exact"), "shape": [a.B, a.L, a.heads, a.hd], "ms_median": med, "ms_min": ms[0],
+    print(json.dumps({"kernel": "xattn_fwd" + ("" if not a.exact else "_exact") + ("_split3" if a.split3 else ""), "shape": [a.B, a.L, a.heads, a.hd], "ms_median": med, "ms_min": ms[0],
                       "GFLOP": flop / 1e9, "TFLOPs_equivalent": flop / med / 1e9}))
 
 
