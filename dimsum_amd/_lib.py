@@ -88,7 +88,7 @@ EXPORTS = (
     "dimsum_ssm_scan_fwd", "dimsum_ssm_scan_bwd", "dimsum_ssm_scan_bwd_workspace_bytes", "dimsum_ssm_scan_fwd_variant",
     "dimsum_ssm_scan_fwd_force_variant", "dimsum_causal_conv1d_fwd", "dimsum_causal_conv1d_bwd",
     "dimsum_norm_fwd", "dimsum_norm_bwd", "dimsum_token_transform", "dimsum_xattn_fusion_fwd", "dimsum_xattn_fusion_bwd",
-    "dimsum_gated_gelu_fwd", "dimsum_gated_gelu_bwd", "dimsum_gated_gelu_fwd_split3", "dimsum_split3",
+    "dimsum_gated_gelu_fwd", "dimsum_gated_gelu_bwd", "dimsum_gated_gelu_fwd_split3", "dimsum_gated_gelu_bwd_split3", "dimsum_split3",
 )
 
 _lib = None
@@ -116,7 +116,8 @@ def load():
             fn = getattr(lib, name)
             fn.restype = C.c_int
             fn.argtypes = [C.POINTER(ptype), vp]
-    for name, nptr in (("dimsum_gated_gelu_fwd", 3), ("dimsum_gated_gelu_bwd", 5), ("dimsum_gated_gelu_fwd_split3", 3)):
+    for name, nptr in (("dimsum_gated_gelu_fwd", 3), ("dimsum_gated_gelu_bwd", 5), ("dimsum_gated_gelu_fwd_split3", 3),
+                       ("dimsum_gated_gelu_bwd_split3", 5)):
         if hasattr(lib, name):
             fn = getattr(lib, name)
             fn.restype = C.c_int

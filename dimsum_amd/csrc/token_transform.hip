@@ -358,8 +358,12 @@ __global__ __launch_bounds__(256) void gated_gelu_fwd_kernel(const float *x12, c
         }
     }
 }
-__global__ __launch_bounds__(256) void gated_gelu_bwd_kernel(const float *x12, const float *bias, const float *dh, float *dx12, float *dbias,
+// kSplit: dx12 is written as the split-bf16 operand image of the two GEMMs that consume it (d input = dx12 W12, d weight = dx12^T h):
+// rows of 3 x 2H bf16 in WEIGHT order [hi | lo | hi] (common.hpp), to be paired with left-order images of W12^T and of h
+template <bool kSplit>
+__global__ __launch_bounds__(256) void gated_gelu_bwd_kernel(const float *x12, const float *bias, const float *dh, void *dx12v, float *dbias,
                                                              int64_t rows, int64_t H) {
+    float *dx12 = reinterpret_cast<float *>(dx12v);
     const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (c >= H) return;
     float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bg = ba, sa = ba, sg = ba;
@@ -373,8 +377,14 @@ __global__ __launch_bounds__(256) void gated_gelu_bwd_kernel(const float *x12, c
         g.x += bg.x; g.y += bg.y; g.z += bg.z; g.w += bg.w;
         const float4 da = make_float4(d.x * g.x * gelu_tanh_grad(a.x), d.y * g.y * gelu_tanh_grad(a.y), d.z * g.z * gelu_tanh_grad(a.z), d.w * g.w * gelu_tanh_grad(a.w));
         const float4 dg = make_float4(d.x * gelu_tanh(a.x), d.y * gelu_tanh(a.y), d.z * gelu_tanh(a.z), d.w * gelu_tanh(a.w));
-        *reinterpret_cast<float4 *>(dx12 + r * 2 * H + c) = da;
-        *reinterpret_cast<float4 *>(dx12 + r * 2 * H + H + c) = dg;
+        if constexpr (kSplit) {
+            unsigned short *row = reinterpret_cast<unsigned short *>(dx12v) + r * 6 * H;
+            st_split3<false>(row, c, 2 * H, f32x4{{da.x, da.y, da.z, da.w}});
+            st_split3<false>(row, H + c, 2 * H, f32x4{{dg.x, dg.y, dg.z, dg.w}});
+        } else {
+            *reinterpret_cast<float4 *>(dx12 + r * 2 * H + c) = da;
+            *reinterpret_cast<float4 *>(dx12 + r * 2 * H + H + c) = dg;
+        }
         sa.x += da.x; sa.y += da.y; sa.z += da.z; sa.w += da.w;
         sg.x += dg.x; sg.y += dg.y; sg.z += dg.z; sg.w += dg.w;
     }
@@ -430,8 +440,8 @@ extern "C" int dimsum_gated_gelu_fwd_split3(const void *x12, const void *bias, v
     return launch_gated_gelu_fwd<true>(x12, bias, h3, rows, hidden, stream);
 }
 
-extern "C" int dimsum_gated_gelu_bwd(const void *x12, const void *bias, const void *dh, void *dx12, void *dbias, int64_t rows,
-                                     int64_t hidden, void *stream) {
+template <bool kSplit>
+static int launch_gated_gelu_bwd(const void *x12, const void *bias, const void *dh, void *dx12, void *dbias, int64_t rows, int64_t hidden, void *stream) {
     using namespace dimsum;
     if (!x12 || !dh || !dx12) return DIMSUM_ERR_NULL;
     if (rows < 0 || hidden <= 0 || hidden % 4 != 0) return DIMSUM_ERR_SHAPE;
@@ -439,8 +449,18 @@ extern "C" int dimsum_gated_gelu_bwd(const void *x12, const void *bias, const vo
         return DIMSUM_ERR_STRIDE;
     if (rows == 0) return DIMSUM_OK;
     const dim3 grid((unsigned)((hidden / 4 + 255) / 256), (unsigned)((rows + kGGRows - 1) / kGGRows));
-    hipLaunchKernelGGL(gated_gelu_bwd_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(gated_gelu_bwd_kernel<kSplit>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        reinterpret_cast<const float *>(x12), reinterpret_cast<const float *>(bias), reinterpret_cast<const float *>(dh),
-                       reinterpret_cast<float *>(dx12), reinterpret_cast<float *>(dbias), rows, hidden);
+                       dx12, reinterpret_cast<float *>(dbias), rows, hidden);
     return launch_status();
+}
+
+extern "C" int dimsum_gated_gelu_bwd(const void *x12, const void *bias, const void *dh, void *dx12, void *dbias, int64_t rows,
+                                     int64_t hidden, void *stream) {
+    return launch_gated_gelu_bwd<false>(x12, bias, dh, dx12, dbias, rows, hidden, stream);
+}
+
+extern "C" int dimsum_gated_gelu_bwd_split3(const void *x12, const void *bias, const void *dh, void *dx12_image, void *dbias, int64_t rows,
+                                            int64_t hidden, void *stream) {
+    return launch_gated_gelu_bwd<true>(x12, bias, dh, dx12_image, dbias, rows, hidden, stream);
 }

@@ -88,3 +88,15 @@ def matmul_wx_split3(weight, x3):
     from . import native
     w3 = native.split3_rows(weight.detach(), left=False)
     return torch.mm(w3, x3.t(), out_dtype=torch.float32)
+
+
+def split3_train_enabled(x, weight):
+    """the operand-image carrier under autograd (mlp.py: forward AND backward GEMMs of the gated MLP): fp32 CUDA training under
+    allow_tf32, outside autocast; DIMSUM_SPLIT3_TRAIN=0 / DIMSUM_SPLIT3=0 switch it off; same row threshold as inference"""
+    import os
+    if not (_policy == "default" and torch.backends.cuda.matmul.allow_tf32 and os.environ.get("DIMSUM_SPLIT3", "1") != "0"
+            and os.environ.get("DIMSUM_SPLIT3_TRAIN", "1") != "0" and x.is_cuda and x.dtype == torch.float32
+            and weight.dtype == torch.float32 and x.shape[-1] % 4 == 0 and torch.is_grad_enabled()
+            and not torch.is_autocast_enabled("cuda")):
+        return False
+    return x.numel() // x.shape[-1] >= int(os.environ.get("DIMSUM_SPLIT3_MIN_ROWS", "8192"))

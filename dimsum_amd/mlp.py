@@ -30,6 +30,62 @@ def gated_gelu(x12, bias=None):
     return _GatedGeluFn.apply(x12, bias)
 
 
+class _ModGatedMlpImagesFn(torch.autograd.Function):
+    """m = w3(gated_gelu(w12(modulate(normed, shift, scale)) + b12))  WITHOUT w3's bias, training, with every GEMM of the forward
+    and the backward on split-bf16 operand images (gemm.py, split3):
+        forward : h3 = image(modulate(normed))   [token_transform y_split3]      x12 = h3 . W12img^T
+                  g3 = image(gelu(x12a + b) (x12g + b))  [gated GeLU split3]      m = g3 . W3img^T
+        backward: dm_w = image_w(dm)                                              dg = dm_w . (W3^T)img^T      dW3 = dm_w^T . g3
+                  dx12_w = image_w(gated GeLU backward)  [one pass]               dh = dx12_w . (W12^T)img^T   dW12 = dx12_w^T . h3
+                  d normed / d shift / d scale: the pre-mixer adjoints (ops/token_ops.py)
+    image = left order [hi | hi | lo], image_w = weight order [hi | lo | hi]; a (M, 3K) image viewed as (3M, K) is the row-stacked
+    image of the same matrix, which is what the weight-gradient products (reduction over the M rows) consume. The same three
+    products per fp32 product as hipBLASLt's fp32-under-allow_tf32 kernels, on its plain bf16 kernels: measured per GEMM at 65536
+    rows (tools/scratch/ksplit_probe3.py): dW12 4.07 -> 3.18 ms, dh 3.47 -> 2.59, dW3 2.80 -> 1.79, dg 1.79 -> 1.34."""
+
+    @staticmethod
+    def forward(ctx, normed, shift, scale, w12, b12, w3):
+        B, L, H = normed.shape
+        M = B * L
+        normed = normed if normed.stride(-1) == 1 else normed.contiguous()
+        h3 = native.token_transform(normed, "none", True, scale=scale, shift=shift, split3=True)          # (B, L, 3H)
+        x12 = gemm.linear_split3(h3.view(M, 3 * H), w12)                                                   # (M, 2F) fp32
+        b12f = None if b12 is None else b12.float()
+        g3 = native.gated_gelu_fwd(x12, b12f, split3=True)                                                 # (M, 3F)
+        m = gemm.linear_split3(g3, w3)                                                                     # (M, H)
+        ctx.save_for_backward(normed, scale, h3, x12, g3, w12, b12f, w3)
+        return m.view(B, L, w3.shape[0])
+
+    @staticmethod
+    def backward(ctx, dm):
+        normed, scale, h3, x12, g3, w12, b12f, w3 = ctx.saved_tensors
+        B, L, H = normed.shape
+        M, F2 = x12.shape
+        Fh = F2 // 2
+        Ho = w3.shape[0]
+        mm = lambda a, b: torch.mm(a, b, out_dtype=torch.float32)
+        dm_w = native.split3_rows(dm.reshape(M, Ho).contiguous(), left=False)                              # (M, 3Ho), weight order
+        dg = mm(dm_w, native.split3_rows(w3.detach().t().contiguous(), left=True).t())                     # (M, F)
+        dw3 = mm(dm_w.view(3 * M, Ho).t(), g3.view(3 * M, Fh)) if ctx.needs_input_grad[5] else None        # (Ho, F)
+        dx12_w, db12 = native.gated_gelu_bwd(x12, b12f, dg, need_dbias=b12f is not None and ctx.needs_input_grad[4], split3=True)
+        dh = mm(dx12_w, native.split3_rows(w12.detach().t().contiguous(), left=True).t())                  # (M, H)
+        dw12 = mm(dx12_w.view(3 * M, F2).t(), h3.view(3 * M, H)) if ctx.needs_input_grad[3] else None      # (2F, H)
+        dh = dh.view(B, L, H)
+        dnormed = dshift = dscale = None
+        if ctx.needs_input_grad[0]:
+            dnormed = native.token_transform(dh, "none", False, gate=1.0 + scale)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            _, dscale, dshift = native.token_transform(normed, "none", True, w=dh, want_y=False, want_wsum=True)
+        if db12 is not None and b12f is not None:
+            db12 = db12.to(b12f.dtype)
+        return dnormed, dshift, dscale, dw12, db12, dw3
+
+
+def mod_gated_mlp_images(mlp, normed, shift, scale):
+    """-> (m, b): mlp(modulate(normed, shift, scale)) = m + b for a fused GatedMLP, all GEMMs on operand images (training)"""
+    return _ModGatedMlpImagesFn.apply(normed, shift, scale, mlp.w12.weight, mlp.w12.bias, mlp.w3.weight), mlp.w3.bias
+
+
 class GatedMLP(nn.Module):
     def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=F.gelu, drop=0.0, bias=True):
         super().__init__()

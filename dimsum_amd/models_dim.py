@@ -240,6 +240,10 @@ def _make_mlp(dim, use_gated_mlp=True):
 
 def _mlp_tail(mlp, x, normed, shift, scale, gate):
     """x + gate * mlp(modulate(normed, shift, scale))  (models_dim.py:1111-1115, 1551-1553)"""
+    if getattr(mlp, "_fused", False) and gemm.split3_train_enabled(normed, mlp.w12.weight):
+        from .mlp import mod_gated_mlp_images
+        m, mb = mod_gated_mlp_images(mlp, normed, shift, scale)              # training: every MLP GEMM on operand images
+        return token_ops.gate_residual(x, m, gate, mb)
     h = token_ops.pre_mixer(normed, "none", None, shift, scale)               # modulate, one pass
     if hasattr(mlp, "forward_deferred"):
         m, mb = mlp.forward_deferred(h)

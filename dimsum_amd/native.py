@@ -436,16 +436,17 @@ def split3_rows(x, left):
     return out
 
 
-def gated_gelu_bwd(x12, bias, dh, need_dbias=True):
-    """-> (dx12, dbias or None)"""
+def gated_gelu_bwd(x12, bias, dh, need_dbias=True, split3=False):
+    """-> (dx12, dbias or None).  split3: dx12 as a split-bf16 operand image in weight order, (..., 3 * 2H) bfloat16 [hi | lo | hi]"""
     _gpu(x12, bias, dh)
     dh = dh.contiguous()
     H = x12.shape[-1] // 2
-    dx12 = torch.empty_like(x12)
+    dx12 = torch.empty(x12.shape[:-1] + (6 * H,), device=x12.device, dtype=torch.bfloat16) if split3 else torch.empty_like(x12)
     dbias = torch.zeros(2 * H, device=x12.device, dtype=torch.float32) if (bias is not None and need_dbias) else None
     rows = x12.numel() // (2 * H)
     with torch.cuda.device(x12.device):
-        _lib.check(_lib.load().dimsum_gated_gelu_bwd(_ptr(x12), _ptr(bias), _ptr(dh), _ptr(dx12), _ptr(dbias), rows, H, _stream(x12)), "gated_gelu_bwd")
+        fn = _lib.load().dimsum_gated_gelu_bwd_split3 if split3 else _lib.load().dimsum_gated_gelu_bwd
+        _lib.check(fn(_ptr(x12), _ptr(bias), _ptr(dh), _ptr(dx12), _ptr(dbias), rows, H, _stream(x12)), "gated_gelu_bwd")
     return dx12, dbias
 
 

@@ -307,6 +307,10 @@ int dimsum_gated_gelu_fwd(const void *x12, const void *bias, void *h, int64_t ro
 int dimsum_gated_gelu_fwd_split3(const void *x12, const void *bias, void *h3, int64_t rows, int64_t hidden, void *stream);
 int dimsum_gated_gelu_bwd(const void *x12, const void *bias, const void *dh, void *dx12, void *dbias, int64_t rows,
                           int64_t hidden, void *stream);
+/* same, dx12_image = dx12 as a split-bf16 operand image in WEIGHT order: (rows, 3 x 2 hidden) bf16 [hi | lo | hi] (dimsum_split3),
+ * paired with left-order images of W12^T (input gradient) and, through the (3 rows, .) view of both, of the MLP input (weight gradient) */
+int dimsum_gated_gelu_bwd_split3(const void *x12, const void *bias, const void *dh, void *dx12_image, void *dbias, int64_t rows,
+                                 int64_t hidden, void *stream);
 
 #ifdef __cplusplus
 }

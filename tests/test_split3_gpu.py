@@ -168,3 +168,59 @@ def test_block_with_and_without_split3_carrier(monkeypatch):
     assert not torch.equal(outs["1"], outs["0"])          # the carrier really ran (another summation order)
     err = (outs["1"] - outs["0"]).abs().max().item() / outs["0"].abs().max().item()
     assert err < 2e-5, err
+
+
+def test_gated_gelu_bwd_split3_output_matches_converter():
+    from dimsum_amd import native
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x12, bias = 2 * torch.randn(150, 2 * 136, device="cuda", generator=g), torch.randn(2 * 136, device="cuda", generator=g)
+    dh = torch.randn(150, 136, device="cuda", generator=g)
+    for b in (bias, None):
+        dx, db = native.gated_gelu_bwd(x12, b, dh)
+        dx3, db3 = native.gated_gelu_bwd(x12, b, dh, split3=True)
+        assert dx3.dtype == torch.bfloat16 and tuple(dx3.shape) == (150, 6 * 136)
+        assert torch.equal(dx3.view(torch.int16), native.split3_rows(dx, left=False).view(torch.int16))      # weight order [hi | lo | hi]
+        if b is not None:
+            assert torch.allclose(db, db3, rtol=1e-5, atol=1e-5)                                            # atomics: order differs
+
+
+def test_training_mlp_on_operand_images_matches_fp32_operands(monkeypatch):
+    """_ModGatedMlpImagesFn (forward + backward GEMMs on images) against the fp32-operand path of the same policy: the module
+    output and the gradients of the input, the modulation and all four parameters: 5e-5 of each tensor's max (both 3-product)"""
+    from dimsum_amd import models_dim
+    from dimsum_amd.mlp import GatedMLP
+    from dimsum_amd.ops import token_ops
+    torch.manual_seed(1)
+    H, B, L = 256, 4, 96
+    mlp = GatedMLP(in_features=H, hidden_features=4 * H, act_layer=models_dim._approx_gelu, drop=0).cuda()
+    for prm in mlp.parameters():
+        torch.nn.init.normal_(prm, std=0.05)
+    x = torch.randn(B, L, H, device="cuda")
+    normed0, shift0, scale0, gate0 = torch.randn(B, L, H, device="cuda"), torch.randn(B, H, device="cuda"), 0.1 * torch.randn(B, H, device="cuda"), torch.randn(B, H, device="cuda")
+    dout = torch.randn(B, L, H, device="cuda")
+    monkeypatch.setattr(torch.backends.cuda.matmul, "allow_tf32", True)
+    monkeypatch.setenv("DIMSUM_SPLIT3_MIN_ROWS", "0")
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DIMSUM_SPLIT3_TRAIN", flag)
+        leaves = [t.clone().requires_grad_() for t in (normed0, shift0, scale0, gate0)]
+        mlp.zero_grad()
+        out = models_dim._mlp_tail(mlp, x, *leaves[:3], leaves[3])
+        out.backward(dout)
+        res[flag] = [out.detach()] + [t.grad for t in leaves] + [p.grad.clone() for p in mlp.parameters()]
+    assert not torch.equal(res["1"][0], res["0"][0])              # the image path really ran
+    names = ["out", "d normed", "d shift", "d scale", "d gate"] + ["d " + n for n, _ in mlp.named_parameters()]
+    for n, a, b in zip(names, res["1"], res["0"]):
+        err = (a - b).abs().max().item() / b.abs().max().item()
+        assert err < 5e-5, (n, err)
+
+
+@pytest.mark.parametrize("train_images", ["1", "0"])
+def test_block_training_golden_with_operand_images(monkeypatch, train_images):
+    """the reference block golden (forward, input and parameter gradients) under allow_tf32 with the training MLP on operand
+    images (and without): same tolerances as tests/test_model_gpu.py::test_block_combined_384_fwd_bwd_all_hip"""
+    from test_model_cpu import check_block_384
+    monkeypatch.setattr(torch.backends.cuda.matmul, "allow_tf32", True)
+    monkeypatch.setenv("DIMSUM_SPLIT3_MIN_ROWS", "0")
+    monkeypatch.setenv("DIMSUM_SPLIT3_TRAIN", train_images)
+    check_block_384("cuda", dict(rtol=2e-4, atol=0.0, scale_atol=2e-5), dict(rtol=5e-4, atol=0.0, scale_atol=5e-5))
