@@ -181,7 +181,7 @@ class Attention(nn.Module):
                 o3 = native.xattn_fusion_fwd(qkv, None, self.num_heads, bias1=qb, split_bf16=True, split3=True)
                 return gemm.linear_split3(o3.reshape(B * N, -1), self.proj.weight).view(B, N, C), self.proj.bias
         else:
-            qkv = torch.nn.functional.linear(x, self.qkv.weight)      # bias-free GEMM (fast hipBLASLt path)
+            qkv = gemm.linear(x, self.qkv.weight)                     # bias-free GEMM (fast hipBLASLt path)
         if native.xattn_supported(qkv, self.head_dim):
             # MFMA self-attention core (csrc/xattn_fusion*.hip, n_dirs = 1); the qkv bias is added inside the kernels
             o = _XattnCoreFn.apply(qkv, None, self.qkv.bias, None, self.num_heads)
@@ -193,7 +193,7 @@ class Attention(nn.Module):
                 qkv = qkv + self.qkv.bias
             q, k, v = qkv.reshape(B, N, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4).unbind(0)
             o = torch.nn.functional.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, N, C)
-        return torch.nn.functional.linear(o, self.proj.weight), self.proj.bias
+        return gemm.linear(o, self.proj.weight), self.proj.bias
 
     def forward(self, x):
         y, b = self.forward_deferred(x)

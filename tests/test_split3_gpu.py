@@ -224,3 +224,26 @@ def test_block_training_golden_with_operand_images(monkeypatch, train_images):
     monkeypatch.setenv("DIMSUM_SPLIT3_MIN_ROWS", "0")
     monkeypatch.setenv("DIMSUM_SPLIT3_TRAIN", train_images)
     check_block_384("cuda", dict(rtol=2e-4, atol=0.0, scale_atol=2e-5), dict(rtol=5e-4, atol=0.0, scale_atol=5e-5))
+
+
+def test_linear_on_images_under_autograd(monkeypatch):
+    """gemm.linear under autograd (training policy): y, dx, dW on operand images against float64"""
+    from dimsum_amd import gemm
+    g = torch.Generator(device="cuda").manual_seed(7)
+    M, K, N = 1024, 384, 640
+    x0, w0 = torch.randn(4, M // 4, K, device="cuda", generator=g), torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    dy = torch.randn(4, M // 4, N, device="cuda", generator=g)
+    monkeypatch.setattr(torch.backends.cuda.matmul, "allow_tf32", True)
+    monkeypatch.setenv("DIMSUM_SPLIT3_MIN_ROWS", "0")
+    x, w = x0.clone().requires_grad_(), w0.clone().requires_grad_()
+    y = gemm.linear(x, w)
+    assert type(y.grad_fn).__name__ == "_LinearImagesFnBackward"
+    y.backward(dy)
+    xd, wd = x0.double().requires_grad_(), w0.double().requires_grad_()
+    yd = torch.nn.functional.linear(xd, wd)
+    yd.backward(dy.double())
+    for name, a, b in (("y", y, yd), ("dx", x.grad, xd.grad), ("dW", w.grad, wd.grad)):
+        err = (a.double() - b).abs().max().item() / b.abs().max().item()
+        assert err < 2e-5, (name, err)
+    monkeypatch.setenv("DIMSUM_SPLIT3_TRAIN", "0")
+    assert type(gemm.linear(x, w).grad_fn).__name__ != "_LinearImagesFnBackward"
