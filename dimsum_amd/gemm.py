@@ -46,6 +46,56 @@ def _w16(weight):
     return weight.detach().to(torch.float16)
 
 
+def _slices(rows, n_out, k_out):
+    """how many slices of a `rows`-long reduction to run as one batched GEMM: a weight gradient (n_out, k_out) of 256 x 256 output
+    tiles fills 256 CUs only if it has >= 256 tiles -- in_proj's (2048, 512) has 16 and took 1.59 ms as one GEMM, 0.46 ms as 16
+    slices + a sum (tools/scratch/splitk_probe.py). Slices stay >= 2048 rows long."""
+    tiles = ((n_out + 255) // 256) * ((k_out + 255) // 256)
+    s = 1
+    while s < 32 and tiles * s * 2 <= 256 and rows % (s * 2) == 0 and rows // (s * 2) >= 2048:
+        s *= 2
+    return s
+
+
+def mm_tn(a, b, out_dtype=None):
+    """a (R, N), b (R, K) -> a^T b (N, K): the weight-gradient shape (reduction over the R rows), split over row slices when the
+    output is small"""
+    R, N = a.shape
+    K = b.shape[1]
+    kw = {} if out_dtype is None else {"out_dtype": out_dtype}
+    s = _slices(R, N, K) if a.is_cuda else 1
+    if s == 1:
+        return torch.mm(a.t(), b, **kw)
+    return torch.bmm(a.view(s, R // s, N).transpose(1, 2), b.view(s, R // s, K), **kw).sum(0)
+
+
+def mm_nn_rows(a_rows, b, out_dtype=None):
+    """a_rows (N, R) (a d-major matrix: rows contiguous along the reduction), b (R, K) -> (N, K), split like mm_tn"""
+    N, R = a_rows.shape
+    K = b.shape[1]
+    kw = {} if out_dtype is None else {"out_dtype": out_dtype}
+    s = _slices(R, N, K) if a_rows.is_cuda else 1
+    if s == 1:
+        return torch.mm(a_rows, b, **kw)
+    return torch.bmm(a_rows.view(N, s, R // s).permute(1, 0, 2), b.view(s, R // s, K), **kw).sum(0)
+
+
+class _MatmulWxFn(torch.autograd.Function):
+    """weight (N, K) @ x^T (K, M) -> (N, M) (the in_proj site) with the weight gradient as a sliced reduction (mm_nn_rows)"""
+
+    @staticmethod
+    def forward(ctx, weight, x2):
+        ctx.save_for_backward(weight, x2)
+        return weight @ x2.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        weight, x2 = ctx.saved_tensors
+        dw = mm_nn_rows(dy.contiguous(), x2) if ctx.needs_input_grad[0] else None
+        dx = (weight.t() @ dy).t() if ctx.needs_input_grad[1] else None
+        return dw, dx
+
+
 class _LinearImagesFn(torch.autograd.Function):
     """y = x W^T under autograd with all three GEMMs (y, dx, dW) on split-bf16 operand images that this function builds itself
     (one conversion pass over x, one over dy): for a Linear whose producer kernel does not write the image. The weight-gradient
@@ -73,7 +123,7 @@ class _LinearImagesFn(torch.autograd.Function):
             wt3 = native.split3_rows(weight.detach().t().contiguous(), left=True)     # (K, 3N)
             dx = torch.mm(dy_w, wt3.t(), out_dtype=torch.float32).view(ctx.x_shape)
         if ctx.needs_input_grad[1]:
-            dw = torch.mm(dy_w.view(3 * M, N).t(), x3.view(3 * M, K), out_dtype=torch.float32)
+            dw = mm_tn(dy_w.view(3 * M, N), x3.view(3 * M, K), out_dtype=torch.float32)
         return dx, dw
 
 
@@ -98,6 +148,9 @@ def linear(x, weight):
 def matmul_wx(weight, xt):
     """weight (N, K) @ xt (K, M) -> (N, M): the in_proj site, whose output is consumed d-major without a copy"""
     if not _use_fp16(xt, weight):
+        x2 = xt.t()
+        if torch.is_grad_enabled() and weight.requires_grad and xt.is_cuda and x2.is_contiguous():
+            return _MatmulWxFn.apply(weight, x2)
         return weight @ xt
     return torch.mm(_w16(weight), xt.to(torch.float16), out_dtype=torch.float32)
 

@@ -66,10 +66,10 @@ class _ModGatedMlpImagesFn(torch.autograd.Function):
         mm = lambda a, b: torch.mm(a, b, out_dtype=torch.float32)
         dm_w = native.split3_rows(dm.reshape(M, Ho).contiguous(), left=False)                              # (M, 3Ho), weight order
         dg = mm(dm_w, native.split3_rows(w3.detach().t().contiguous(), left=True).t())                     # (M, F)
-        dw3 = mm(dm_w.view(3 * M, Ho).t(), g3.view(3 * M, Fh)) if ctx.needs_input_grad[5] else None        # (Ho, F)
+        dw3 = gemm.mm_tn(dm_w.view(3 * M, Ho), g3.view(3 * M, Fh), out_dtype=torch.float32) if ctx.needs_input_grad[5] else None   # (Ho, F)
         dx12_w, db12 = native.gated_gelu_bwd(x12, b12f, dg, need_dbias=b12f is not None and ctx.needs_input_grad[4], split3=True)
         dh = mm(dx12_w, native.split3_rows(w12.detach().t().contiguous(), left=True).t())                  # (M, H)
-        dw12 = mm(dx12_w.view(3 * M, F2).t(), h3.view(3 * M, H)) if ctx.needs_input_grad[3] else None      # (2F, H)
+        dw12 = gemm.mm_tn(dx12_w.view(3 * M, F2), h3.view(3 * M, H), out_dtype=torch.float32) if ctx.needs_input_grad[3] else None   # (2F, H)
         dh = dh.view(B, L, H)
         dnormed = dshift = dscale = None
         if ctx.needs_input_grad[0]:

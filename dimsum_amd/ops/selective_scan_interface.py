@@ -178,7 +178,8 @@ class _MambaInner(torch.autograd.Function):
         out_z = rest[0] if recompute else kept_out_z
         dout_proj_weight = dout_proj_bias = None
         if ctx.has_out_proj:
-            dout_proj_weight = dout2 @ _rows(out_z).t()                                                 # "eB,dB->ed"
+            # "eB,dB->ed": a (d_model, d_inner) output over a b*l-long reduction -- sliced, it would fill 8 of 256 CUs otherwise
+            dout_proj_weight = gemm.mm_nn_rows(_rows(out_z), dout.reshape(bsz * L, -1)).t()
             dout_proj_bias = dout.sum(dim=(0, 1)) if has_ob else None
         dx_dbl = torch.empty_like(x_dbl)
         dBf = dB.squeeze(1).permute(0, 2, 1).reshape(bsz * L, N)                                        # "b 1 n l -> (b l) n"
@@ -191,7 +192,7 @@ class _MambaInner(torch.autograd.Function):
         ddelta_proj_weight = ddelta2 @ x_dbl[:, :R]                                                     # "dB,Br->dr"
         dx_dbl[:, :R] = ddelta2.t() @ delta_proj_weight                                                 # "dB,dr->Br"
         dconv2 = _rows(dconv_out)                                                                       # (d, b l)
-        dx_proj_weight = dx_dbl.t() @ _rows(conv_out).t()                                               # "Br,Bd->rd"
+        dx_proj_weight = gemm.mm_nn_rows(_rows(conv_out), dx_dbl).t()                                   # "Br,Bd->rd", sliced reduction
         dconv2 = torch.addmm(dconv2, x_proj_weight.t(), dx_dbl.t())
         dconv_out = dconv2.view(d_inner, bsz, L).permute(1, 0, 2)
         _, dconv_w, dconv_b = native.causal_conv1d_bwd(x, conv_w, conv_b, dconv_out, dx, True)
