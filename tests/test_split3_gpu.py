@@ -247,3 +247,31 @@ def test_linear_on_images_under_autograd(monkeypatch):
         assert err < 2e-5, (name, err)
     monkeypatch.setenv("DIMSUM_SPLIT3_TRAIN", "0")
     assert type(gemm.linear(x, w).grad_fn).__name__ != "_LinearImagesFnBackward"
+
+
+def test_sliced_weight_gradient_products():
+    """gemm.mm_tn / mm_nn_rows (a long reduction run as a batched GEMM over row slices + a sum when the output is small) and the
+    in_proj autograd function built on them, against float64"""
+    from dimsum_amd import gemm
+    g = torch.Generator(device="cuda").manual_seed(11)
+    R, N, K = 32768, 384, 96
+    a, b = torch.randn(R, N, device="cuda", generator=g), torch.randn(R, K, device="cuda", generator=g)
+    assert gemm._slices(R, N, K) > 1 and gemm._slices(4096, N, K) == 1 and gemm._slices(R, 8192, 4096) == 1
+    ref = a.double().t() @ b.double()
+    for got in (gemm.mm_tn(a, b), gemm.mm_nn_rows(a.t().contiguous(), b)):
+        assert (got.double() - ref).abs().max().item() / ref.abs().max().item() < 2e-6
+    a16, b16 = a.bfloat16(), b.bfloat16()
+    got = gemm.mm_tn(a16, b16, out_dtype=torch.float32)
+    ref16 = a16.double().t() @ b16.double()
+    assert got.dtype == torch.float32 and (got.double() - ref16).abs().max().item() / ref16.abs().max().item() < 2e-6
+    # in_proj: W @ x^T with the weight gradient through the sliced product
+    w0, x0 = torch.randn(N, K, device="cuda", generator=g), torch.randn(R, K, device="cuda", generator=g)
+    dy = torch.randn(N, R, device="cuda", generator=g)
+    w, x = w0.clone().requires_grad_(), x0.clone().requires_grad_()
+    y = gemm.matmul_wx(w, x.t())
+    assert type(y.grad_fn).__name__ == "_MatmulWxFnBackward"
+    y.backward(dy)
+    wd, xd = w0.double().requires_grad_(), x0.double().requires_grad_()
+    (wd @ xd.t()).backward(dy.double())
+    for name, p, q in (("y", y, wd @ xd.t()), ("dW", w.grad, wd.grad), ("dx", x.grad, xd.grad)):
+        assert (p.double() - q).abs().max().item() / q.abs().max().item() < 2e-6, name
