@@ -275,3 +275,37 @@ def test_sliced_weight_gradient_products():
     (wd @ xd.t()).backward(dy.double())
     for name, p, q in (("y", y, wd @ xd.t()), ("dW", w.grad, wd.grad), ("dx", x.grad, xd.grad)):
         assert (p.double() - q).abs().max().item() / q.abs().max().item() < 2e-6, name
+
+
+def test_block_training_at_a_size_where_everything_is_active(monkeypatch):
+    """DiMBlockCombined(384) forward+backward on 32 x 256 = 8192 rows (the default threshold of the operand images; the weight
+    gradients run as sliced reductions): output, input gradients and every parameter gradient against the same block with fp32
+    operands and unsliced products -- 1e-4 of each tensor's max (summation order and 3-product rounding only)"""
+    from procedural import procedural_fill
+    from dimsum_amd import gemm
+    from dimsum_amd.models_dim import create_block
+    blk = create_block(384, norm_epsilon=1e-5, rms_norm=True, residual_in_fp32=True, fused_add_norm=True, layer_idx=1,
+                       scan_type="none", block_type="combined", reverse=True, transpose=True, cond_mamba=True,
+                       scanning_continuity=True, use_gated_mlp=True)
+    procedural_fill(blk, seed=9)
+    blk = blk.cuda()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x0, r0, c0 = (torch.randn(*sh, device="cuda", generator=g) for sh in ((32, 256, 384), (32, 256, 384), (32, 384)))
+    dy, dr = torch.randn(32, 256, 384, device="cuda", generator=g), torch.randn(32, 256, 384, device="cuda", generator=g)
+    monkeypatch.setattr(torch.backends.cuda.matmul, "allow_tf32", True)
+    res = {}
+    for mode in ("new", "old"):
+        if mode == "old":
+            monkeypatch.setenv("DIMSUM_SPLIT3", "0")
+            monkeypatch.setattr(gemm, "_slices", lambda rows, n, k: 1)
+        x, r, c = (t.clone().requires_grad_() for t in (x0, r0, c0))
+        blk.zero_grad()
+        y, ro = blk(x, r, c)
+        ((y * dy).sum() + (ro * dr).sum()).backward()
+        res[mode] = [y.detach(), x.grad, r.grad, c.grad] + [p.grad.clone() for p in blk.parameters() if p.grad is not None]
+    names = ["y", "dx", "dres", "dc"] + ["d " + n for n, p in blk.named_parameters() if p.grad is not None]     # (cond_proj is a graph edge only)
+    assert len(res["new"]) == len(res["old"]) == len(names) > 30
+    assert not torch.equal(res["new"][0], res["old"][0])
+    for n, a, b in zip(names, res["new"], res["old"]):
+        scale = b.abs().max().item()
+        assert (a - b).abs().max().item() <= 1e-4 * scale + 1e-12, (n, (a - b).abs().max().item(), scale)
