@@ -17,6 +17,11 @@ proj, w12, w3 -- everything else is small).
              [hi | lo | hi] in ONE plain bf16 GEMM with fp32 accumulation and output: the same three products the library
              forms inside its fp32 kernels, on its faster bf16 kernels (w12: 2.99 -> 2.67 ms, w3: 1.45 -> 1.27 ms at 65536 rows).
              `DIMSUM_SPLIT3=0` keeps the fp32 operands; launches with fewer than `DIMSUM_SPLIT3_MIN_ROWS` (8192) rows keep them too.
+             Under autograd (training) the gated MLP (mlp.py) and every bias-free Linear that goes through `linear` run their
+             forward, input-gradient and weight-gradient products on such images too (`DIMSUM_SPLIT3_TRAIN=0` switches that off).
+  sliced     weight gradients reduce over the batch's rows into a small output; `mm_tn` / `mm_nn_rows` run such a product as one
+             batched GEMM over row slices plus a sum when the output has fewer than 256 tiles of 256 x 256 (the library does
+             not split the reduction itself: in_proj's weight gradient 1.59 -> 0.46 ms).
 The operands are converted by a torch cast on every call -- weights too: DiM-L/2's 460 M parameters cost ~0.5 ms per
 forward (< 1 %) to cast, and a cached copy could not see in-place updates made through `.data` (EMA updates,
 load_state_dict), which do not bump a tensor's version counter. Outputs stay fp32."""
