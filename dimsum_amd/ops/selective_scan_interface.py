@@ -189,7 +189,7 @@ class _MambaInner(torch.autograd.Function):
         dx_dbl[:, R:R + N] = dBf
         dx_dbl[:, -N:] = dCf
         ddelta2 = _rows(ddelta)                                                                         # (d, b l)
-        ddelta_proj_weight = ddelta2 @ x_dbl[:, :R]                                                     # "dB,Br->dr"
+        ddelta_proj_weight = gemm.mm_nn_rows(ddelta2, x_dbl[:, :R])                                     # "dB,Br->dr", sliced reduction
         dx_dbl[:, :R] = ddelta2.t() @ delta_proj_weight                                                 # "dB,dr->Br"
         dconv2 = _rows(dconv_out)                                                                       # (d, b l)
         dx_proj_weight = gemm.mm_nn_rows(_rows(conv_out), dx_dbl).t()                                   # "Br,Bd->rd", sliced reduction
