@@ -427,9 +427,11 @@ class _CombinedBase(_BlockBase):
         # inference under allow_tf32: the branches hand their results over as split-bf16 operand images of the qkv Linears
         img = gemm.split3_enabled(x1, self.proj.qkv1.weight) and self.proj.takes_images(hidden_states)
         kw = {"out_split3": True} if img else {}
-        if (not torch.is_grad_enabled()) and hidden_states.is_cuda and os.environ.get("DIMSUM_BRANCH_STREAMS", "1") != "0":
-            # inference: the two branches are independent until the fusion -- the frequency branch runs on a second HIP stream, so
-            # the memory-bound passes of one branch (conv1d, scan, token passes) overlap the GEMMs of the other: -1.3 % per forward
+        if (not torch.is_grad_enabled()) and hidden_states.is_cuda and os.environ.get("DIMSUM_BRANCH_STREAMS", "0") == "1":
+            # OPT-IN (inference): the two branches are independent until the fusion -- the frequency branch on a second HIP stream lets
+            # the memory-bound passes of one branch (conv1d, scan, token passes) overlap the GEMMs of the other: -1.3 .. -2.4 % per
+            # forward, bit-identical. Off by default: kernels that share the chip cannot be timed individually any more (the scan's
+            # launch-to-launch time goes 0.33 -> 0.52 ms), and bench.py's roofline is such a per-kernel measurement.
             cur = torch.cuda.current_stream(hidden_states.device)
             side = self.__dict__.get("_side_stream")
             if side is None or side.device != hidden_states.device:
