@@ -322,3 +322,27 @@ def test_zigzag_paths_folded_into_block_tables():
     (a, fa), (b, fb) = res
     assert len(fa) > 0 and all(fa) and not any(fb)
     assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_two_stream_branches_are_bit_identical(monkeypatch):
+    """DIMSUM_BRANCH_STREAMS=1 (opt-in): the frequency branch of every combined block on a second HIP stream -- same kernels, same
+    operands, same result, also when the forward is called twice in a row and from a non-default stream"""
+    from dimsum_amd.models_dim import DiM
+    m = DiM(depth=4, hidden_size=384, patch_size=2, **_published())
+    procedural_fill(m, seed=3)
+    m = m.cuda().eval()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x, t = torch.randn(8, 4, 32, 32, device="cuda", generator=g), torch.rand(8, device="cuda", generator=g)
+    y = torch.randint(0, 1000, (8,), device="cuda", generator=g)
+    with torch.no_grad():
+        ref = m(x, t, y)
+        monkeypatch.setenv("DIMSUM_BRANCH_STREAMS", "1")
+        a, b = m(x, t, y), m(x, t, y)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            c = m(x, t, y)
+        torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    assert torch.equal(a, ref) and torch.equal(b, ref) and torch.equal(c, ref)
