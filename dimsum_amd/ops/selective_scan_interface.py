@@ -118,16 +118,26 @@ class _MambaInner(torch.autograd.Function):
             conv_out = native.causal_conv1d_fwd(x, conv_w, conv_b, True)
         bsz, d_inner = conv_out.shape[0], conv_out.shape[1]
         # layouts chosen like the reference (:622-626): the GEMM writes delta d-major so that it needs no transpose
-        x_dbl = F.linear(conv_out.transpose(1, 2).reshape(bsz * L, d_inner), x_proj_weight)            # (b l, R + 2N)
-        delta = (delta_proj_weight @ x_dbl[:, :R].t()).view(d_inner, bsz, L).permute(1, 0, 2)           # (b, d, l), strides (L, bL, 1)
-        Bm = x_dbl[:, R:R + N]
-        Cm = x_dbl[:, -N:]
-        if B_proj_bias is not None:
-            Bm = Bm + B_proj_bias.to(Bm.dtype)
-        if C_proj_bias is not None:
-            Cm = Cm + C_proj_bias.to(Cm.dtype)
-        Bm = Bm.reshape(bsz, L, N).permute(0, 2, 1).unsqueeze(1).contiguous()                           # (b, 1, N, l)
-        Cm = Cm.reshape(bsz, L, N).permute(0, 2, 1).unsqueeze(1).contiguous()
+        conv_rows = _rows(conv_out)
+        if not need_ckpt and B_proj_bias is None and C_proj_bias is None and conv_rows.stride(1) == 1:
+            # inference: x_proj written transposed, (R + 2N, b l): its rows are the d-major delta input, B and C as the scan reads
+            # them -- (b, 1, N, l) views with strides (l, ., b l, 1) -- without the two transposing copies per mixer
+            x_dbl_t = x_proj_weight @ conv_rows                                                          # (R + 2N, b l)
+            x_dbl = None
+            delta = (delta_proj_weight @ x_dbl_t[:R]).view(d_inner, bsz, L).permute(1, 0, 2)
+            Bm = x_dbl_t[R:R + N].view(N, bsz, L).permute(1, 0, 2).unsqueeze(1)
+            Cm = x_dbl_t[R + N:].view(N, bsz, L).permute(1, 0, 2).unsqueeze(1)
+        else:
+            x_dbl = F.linear(conv_out.transpose(1, 2).reshape(bsz * L, d_inner), x_proj_weight)        # (b l, R + 2N)
+            delta = (delta_proj_weight @ x_dbl[:, :R].t()).view(d_inner, bsz, L).permute(1, 0, 2)       # (b, d, l), strides (L, bL, 1)
+            Bm = x_dbl[:, R:R + N]
+            Cm = x_dbl[:, -N:]
+            if B_proj_bias is not None:
+                Bm = Bm + B_proj_bias.to(Bm.dtype)
+            if C_proj_bias is not None:
+                Cm = Cm + C_proj_bias.to(Cm.dtype)
+            Bm = Bm.reshape(bsz, L, N).permute(0, 2, 1).unsqueeze(1).contiguous()                       # (b, 1, N, l)
+            Cm = Cm.reshape(bsz, L, N).permute(0, 2, 1).unsqueeze(1).contiguous()
         D = D.contiguous() if D is not None else None
         # the tile-boundary states ride along to the backward (one activation tensor): it then needs no sweep of
         # its own to rebuild them. They depend on (conv_out, delta, A, B) only, which the backward recomputes identically.
