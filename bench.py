@@ -76,6 +76,15 @@ class ScanTimer:
 
     def reset(self):
         self.records = {"fwd": [], "bwd": []}
+        self._free = list(getattr(self, "_all", []))
+
+    def pool_event(self, lib):
+        """raw hipEvent_t handles, created once and reused after every reset()"""
+        if not getattr(self, "_free", None):
+            self._all = getattr(self, "_all", [])
+            self._all.append(lib.dimsum_event_create())
+            return self._all[-1]
+        return self._free.pop()
 
     def install(self):
         from dimsum_amd import _lib
@@ -96,10 +105,19 @@ class ScanTimer:
                     kernel = _lib.SCAN_FWD_KERNELS[lib.dimsum_ssm_scan_fwd_variant(p)] + (" (+ saved states)" if p.ckpt_ptr else "")
                 else:
                     kernel = "ssm_scan_bwd_kernel (+ ssm_scan_bwd_reduce_kernel)" + ("" if p.out_z_ptr else ", no out_z recompute")
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                rc = fn(P, stream)
-                e1.record()
+                # HIP events recorded at the begin of the call's first kernel and the end of its last one (dimsum_timing_events:
+                # hipExtLaunchKernel on the launch stream) -- the kernels' own time, like rocprofv3's; under a hipGraph capture
+                # (events are not capturable) plain event records around the call
+                if torch.cuda.is_current_stream_capturing():
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    rc = fn(P, stream)
+                    e1.record()
+                else:
+                    e0, e1 = timer.pool_event(lib), timer.pool_event(lib)
+                    lib.dimsum_timing_events(e0, e1)
+                    rc = fn(P, stream)
+                    lib.dimsum_timing_events(None, None)
                 s = {_lib.F32: 4}.get(p.dtype, 2)
                 shape = (p.batch, p.dim, p.seqlen, p.dstate)
                 nbytes = (scan_bwd_bytes(*shape, p.n_groups, s, recompute_out_z=bool(p.out_z_ptr)) if which == "bwd"
@@ -125,7 +143,10 @@ class ScanTimer:
         for r in recs:
             classes.setdefault((r[3], r[4]), []).append(r)
         (shape, kernel), rs = max(classes.items(), key=lambda kv: len(kv[1]))
-        avg_ms = sum(a.elapsed_time(b) for a, b, *_ in rs) / len(rs)
+        from dimsum_amd import _lib
+        lib = _lib.load()
+        ms = lambda a, b: a.elapsed_time(b) if isinstance(a, torch.cuda.Event) else float(lib.dimsum_event_elapsed_ms(a, b))
+        avg_ms = sum(ms(a, b) for a, b, *_ in rs) / len(rs)
         nbytes = rs[0][2]
         achieved = nbytes / (avg_ms * 1e-3) / 1e9
         traffic = None

@@ -85,6 +85,7 @@ class XattnBwdParams(C.Structure):
 # every symbol include/dimsum_hip.h declares (tests check the library exports all of them)
 EXPORTS = (
     "dimsum_status_string", "dimsum_abi_version", "dimsum_target_arch",
+    "dimsum_timing_events", "dimsum_event_create", "dimsum_event_destroy", "dimsum_event_elapsed_ms",
     "dimsum_ssm_scan_fwd", "dimsum_ssm_scan_bwd", "dimsum_ssm_scan_bwd_workspace_bytes", "dimsum_ssm_scan_fwd_variant",
     "dimsum_ssm_scan_fwd_force_variant", "dimsum_causal_conv1d_fwd", "dimsum_causal_conv1d_bwd",
     "dimsum_norm_fwd", "dimsum_norm_bwd", "dimsum_token_transform", "dimsum_xattn_fusion_fwd", "dimsum_xattn_fusion_bwd",
@@ -107,6 +108,11 @@ def load():
     lib.dimsum_status_string.argtypes = [C.c_int]
     lib.dimsum_target_arch.restype = C.c_char_p
     lib.dimsum_abi_version.restype = C.c_int
+    if hasattr(lib, "dimsum_timing_events"):
+        lib.dimsum_timing_events.restype, lib.dimsum_timing_events.argtypes = None, [vp, vp]
+        lib.dimsum_event_create.restype, lib.dimsum_event_create.argtypes = vp, []
+        lib.dimsum_event_destroy.restype, lib.dimsum_event_destroy.argtypes = None, [vp]
+        lib.dimsum_event_elapsed_ms.restype, lib.dimsum_event_elapsed_ms.argtypes = C.c_float, [vp, vp]
     for name, ptype in (("dimsum_ssm_scan_fwd", SsmParams), ("dimsum_ssm_scan_bwd", SsmBwdParams),
                         ("dimsum_causal_conv1d_fwd", ConvParams), ("dimsum_causal_conv1d_bwd", ConvBwdParams),
                         ("dimsum_norm_fwd", NormParams), ("dimsum_norm_bwd", NormBwdParams),

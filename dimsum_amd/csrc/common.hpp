@@ -1,6 +1,7 @@
 // common.hpp -- shared device/host helpers for libdimsum_hip (gfx950 only; wave64 hard-coded).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <hip/hip_fp16.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
@@ -121,6 +122,16 @@ __device__ __forceinline__ float softplus_if(float x, bool flag) {
 
 // ---- host ----------------------------------------------------------------------------------------------------------
 inline int launch_status() { return hipGetLastError() == hipSuccess ? DIMSUM_OK : DIMSUM_ERR_LAUNCH; }
+
+// Measurement hook (capi.hip, dimsum_timing_events): a benchmark may arm ONE pair of HIP events; the next selective-scan call
+// records them at its first kernel's begin and its last kernel's end (hipExtLaunchKernelGGL: the timestamps of the kernels' own
+// dispatch packets, what rocprofv3 reports) instead of as separate commands around the call. take_timing_events() disarms.
+void take_timing_events(hipEvent_t *start, hipEvent_t *stop);
+#define DIMSUM_LAUNCH_EV(KERNEL, GRID, BLOCK, STREAM, EV0, EV1, ...)                                              \
+    do {                                                                                                          \
+        if ((EV0) || (EV1)) hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, STREAM, EV0, EV1, 0, __VA_ARGS__);      \
+        else hipLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, STREAM, __VA_ARGS__);                                     \
+    } while (0)
 
 template <typename T> inline bool aligned_to(const void *p, size_t bytes) { return (reinterpret_cast<uintptr_t>(p) % bytes) == 0; }
 

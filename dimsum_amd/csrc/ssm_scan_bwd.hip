@@ -641,8 +641,11 @@ static int launch_bwd(const dimsum_ssm_bwd_params_t &q, const float *ckpt, float
         return DIMSUM_ERR_STRIDE;
     const bool full = vec && (dpg % kWC == 0);
     dim3 grid(tiles), block(kBW * kWave);
+    hipEvent_t ev0, ev1;
+    take_timing_events(&ev0, &ev1);     // armed by a benchmark (common.hpp): begin of the main kernel .. end of the reduce kernel
+    const hipEvent_t none = nullptr;
 #define DIMSUM_LAUNCH(HASZ, VEC, FULL) \
-    hipLaunchKernelGGL((ssm_scan_bwd_kernel<T, kN, HASZ, VEC, FULL>), grid, block, 0, stream, q, ckpt, part)
+    DIMSUM_LAUNCH_EV((ssm_scan_bwd_kernel<T, kN, HASZ, VEC, FULL>), grid, block, stream, ev0, none, q, ckpt, part)
     if (p.z_ptr) {
         if (full) DIMSUM_LAUNCH(true, true, true);
         else if (vec) DIMSUM_LAUNCH(true, true, false);
@@ -659,8 +662,8 @@ static int launch_bwd(const dimsum_ssm_bwd_params_t &q, const float *ckpt, float
                       q.dB_group_stride % 4 == 0 && q.dB_dstate_stride % 4 == 0 && q.dC_batch_stride % 4 == 0 && q.dC_group_stride % 4 == 0 &&
                       q.dC_dstate_stride % 4 == 0;
     const dim3 rgrid((unsigned)((total + 255) / 256)), rblock(256);
-    if (vec4) hipLaunchKernelGGL(ssm_scan_bwd_reduce_kernel<true>, rgrid, rblock, 0, stream, part, q, (dpg + kWC - 1) / kWC);
-    else hipLaunchKernelGGL(ssm_scan_bwd_reduce_kernel<false>, rgrid, rblock, 0, stream, part, q, (dpg + kWC - 1) / kWC);
+    if (vec4) DIMSUM_LAUNCH_EV(ssm_scan_bwd_reduce_kernel<true>, rgrid, rblock, stream, none, ev1, part, q, (dpg + kWC - 1) / kWC);
+    else DIMSUM_LAUNCH_EV(ssm_scan_bwd_reduce_kernel<false>, rgrid, rblock, stream, none, ev1, part, q, (dpg + kWC - 1) / kWC);
     return launch_status();
 }
 

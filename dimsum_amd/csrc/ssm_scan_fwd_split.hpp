@@ -287,10 +287,12 @@ __global__ __launch_bounds__(kWave, (kSP == 4 && kN <= 16) ? 5 : 3) void ssm_sca
 template <typename T, int kN, int kSP>
 void ssm_scan_fwd_launch_split(const dimsum_ssm_params_t &p, hipStream_t stream, int tiles, bool vec, bool full) {
     const dim3 grid(tiles), block(kWave);
+    hipEvent_t ev0, ev1;
+    take_timing_events(&ev0, &ev1);     // armed by a benchmark (common.hpp), else null
 #define DIMSUM_LAUNCH(HASZ, VEC, FULL)                                                                                               \
     do {                                                                                                                              \
-        if (p.ckpt_ptr) hipLaunchKernelGGL((ssm_scan_fwd_split_kernel<T, kN, kSP, HASZ, VEC, FULL, true>), grid, block, 0, stream, p); \
-        else hipLaunchKernelGGL((ssm_scan_fwd_split_kernel<T, kN, kSP, HASZ, VEC, FULL, false>), grid, block, 0, stream, p);           \
+        if (p.ckpt_ptr) DIMSUM_LAUNCH_EV((ssm_scan_fwd_split_kernel<T, kN, kSP, HASZ, VEC, FULL, true>), grid, block, stream, ev0, ev1, p); \
+        else DIMSUM_LAUNCH_EV((ssm_scan_fwd_split_kernel<T, kN, kSP, HASZ, VEC, FULL, false>), grid, block, stream, ev0, ev1, p);         \
     } while (0)
     if (p.z_ptr) {
         if (full) DIMSUM_LAUNCH(true, true, true);

@@ -47,6 +47,15 @@ typedef enum { DIMSUM_F32 = 0, DIMSUM_F16 = 1, DIMSUM_BF16 = 2 } dimsum_dtype_t;
 
 const char *dimsum_status_string(int status);
 int dimsum_abi_version(void);
+
+/* Measurement hook (benchmarks; no reference counterpart). dimsum_timing_events arms one pair of HIP events (hipEvent_t, e.g. from
+ * dimsum_event_create): the NEXT dimsum_ssm_scan_fwd / dimsum_ssm_scan_bwd call records them at the begin of its first kernel and the
+ * end of its last one (hipExtLaunchKernel: the kernels' own dispatch timestamps, the durations rocprofv3 reports), then disarms.
+ * Process-global, not thread-safe, not capturable into a hipGraph. */
+void dimsum_timing_events(void *start_event, void *stop_event);
+void *dimsum_event_create(void);
+void dimsum_event_destroy(void *event);
+float dimsum_event_elapsed_ms(void *start_event, void *stop_event);   /* after the stream has been synchronised; < 0 on error */
 /* name of the gfx target the kernels were compiled for ("gfx950") */
 const char *dimsum_target_arch(void);
 
