@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- the DiMSUM denoiser hot path on MI355X: every BASELINE.json config on one JSON line.
 
-  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+N > 1: one rank per GPU. Either the caller starts the ranks (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`:
+RANK / WORLD_SIZE in the environment) or, run plainly, this file starts them itself as child processes (launch_ranks).
 
 Headline (`value`, configs[1]): DiM-L/2 (256 px: 4x32x32 latents, 256 tokens) denoiser-forward throughput. A step = one
 forward of the denoiser (every Mamba / frequency / fusion op through libdimsum_hip.so, GEMMs in hipBLASLt) over one batch
@@ -24,7 +26,9 @@ attached only when the timed launches have exactly the profiled shape and kernel
 import argparse
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
 
@@ -208,13 +212,33 @@ def cpu_baseline(name, latents=4, image_size=256, runs=3):
                       f"median {med:.2f} s (runs: {', '.join(f'{v:.2f}' for v in times)})"}
 
 
+def free_port():
+    """a TCP port nobody listens on right now (the rendezvous of the ranks this process launches)"""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(gpus, argv):
+    """`python bench.py --gpus N` with N > 1 and no rank environment: this process is only the launcher. It starts N FRESH
+    rank processes (one per GPU) as children through torch.distributed.run -- the same command line the driver would use,
+    like the reference's `torchrun --nnodes=1 --nproc_per_node=N sample_ddp.py` (scripts/eval.sh:73) -- lets them inherit
+    stdout (rank 0 prints the JSON line) and returns their exit code. It never touches the GPU itself: no HIP call has
+    happened in this process (import torch does not initialise the device), and nothing is exec'ed."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__), *argv]
+    return subprocess.run(cmd, env=env).returncode
+
+
 class Bench:
     def __init__(self, args):
         self.args = args
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        assert self.world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={self.world}: launch with torch.distributed.run"
+        assert self.world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={self.world} in the environment"
         torch.cuda.set_device(self.local_rank)            # before the process group: every rank binds its own GPU
         self.dev = torch.device("cuda", self.local_rank)
         if self.world > 1:
@@ -289,7 +313,7 @@ class Bench:
         out = {"workload": f"{model_name} denoiser forward, {image_size}px (4x{r}x{r} latents, {(r // 2) ** 2} tokens), {batch} latents per GPU, "
                            + WEIGHTS + (f", scan_type={scan_type}" if scan_type != "none" else ""),
                "value": batch * self.world * steps / elapsed, "unit": "latents/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
-               "warmup": warmup, "launch": "hipGraph replay" if a.hip_graph else "eager"}
+               "warmup": warmup, "batch_per_gpu": batch, "launch": "hipGraph replay" if a.hip_graph else "eager"}
         rf = self.timer.roofline("fwd")
         if rf is not None:
             out["roofline"] = rf
@@ -329,7 +353,7 @@ class Bench:
         elapsed = self.timed(step, steps, warmup)
         out = {"workload": f"ONE DiMBlockCombined({hidden}) of {model_name} (scan + Haar + attention fusion + gated MLP) forward+backward, "
                            f"{ntok} tokens, batch {batch}, " + WEIGHTS,
-               "value": batch * self.world * steps / elapsed, "unit": "latents/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup}
+               "value": batch * self.world * steps / elapsed, "unit": "latents/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup, "batch_per_gpu": batch}
         for key, which in (("roofline", "fwd"), ("roofline_bwd", "bwd")):
             rf = self.timer.roofline(which)
             if rf is not None:
@@ -354,7 +378,8 @@ class Bench:
         out = {"workload": f"{model_name} {nfe}-NFE fixed-step Euler flow-matching sampling, {image_size}px, {batch} latents per GPU "
                            f"(global batch {batch * self.world}), one all_gather_into_tensor of the final latents, " + WEIGHTS,
                "value": batch * self.world / elapsed, "unit": "samples/s", "nfe": nfe, "s_per_batch": elapsed,
-               "ms_per_nfe": 1e3 * elapsed / nfe, "gathered_shape": list(res["out"].shape), "finite": bool(torch.isfinite(res["out"]).all().item()),
+               "ms_per_nfe": 1e3 * elapsed / nfe, "batch_per_gpu": batch,
+               "seed_rule": f"global_seed * world + rank = 0 * {self.world} + {self.rank} (sample_ddp.py:64)", "gathered_shape": list(res["out"].shape), "finite": bool(torch.isfinite(res["out"]).all().item()),
                "launch": "hipGraph replay" if a.hip_graph else "eager"}
         rf = self.timer.roofline("fwd")
         if rf is not None:
@@ -374,7 +399,7 @@ class Bench:
         elapsed = self.timed(lambda: train_step(ddp, ema, opt, transport, x, y), steps, warmup)
         out = {"workload": f"{model_name} flow-matching training step (GVP velocity loss, backward, grad all-reduce, clip, AdamW, EMA), "
                            f"{batch} latents per GPU, " + WEIGHTS,
-               "value": batch * self.world * steps / elapsed, "unit": "latents/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup}
+               "value": batch * self.world * steps / elapsed, "unit": "latents/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup, "batch_per_gpu": batch}
         rb = self.timer.roofline("bwd")
         if rb is not None:
             out["roofline_bwd"] = rb
@@ -409,6 +434,8 @@ def main():
                          "fp16 = opt-in, inference only: fp16 operands (TF32's 10 mantissa bits, NOT its exponent range) with "
                          "fp32 accumulation for the large Linears (dimsum_amd/gemm.py); never the headline.")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))           # before anything touches the GPU
     b = Bench(args)
     world, rank = b.world, b.rank
     policy = {"tf32": "allow_tf32=True like the reference (train.py:20-21); gfx950 split-bf16 path (3 bf16 products per fp32 product), 4e-6 rms rel err"
@@ -447,7 +474,7 @@ def main():
         line = {"metric": metric, "value": head["value"], "unit": head["unit"], "n_gpus": world, "steps": head["steps"], "warmup": head["warmup"],
                 "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                 "data": "synthetic",
-                "config": {"workload": head["workload"], "global_batch": (args.batch if args.mode != "sample" else args.sample_batch) * world,
+                "config": {"workload": head["workload"], "global_batch": head["batch_per_gpu"] * world,
                            "parallelism": f"dp{world} (replicas, independent latents)", "launch": head.get("launch", "eager"), "matmul_policy": policy},
                 "dist": {"world_size": dist.get_world_size() if world > 1 else 1,
                          "backend": (dist.get_backend() + " (RCCL)") if world > 1 else "none (single process)"}}

@@ -46,9 +46,92 @@ def test_command_line_contract(monkeypatch):
     a = seen["args"]
     assert (a.gpus, a.steps, a.warmup, a.mode, a.model, a.batch, a.nfe, a.sample_batch) == (1, 10, 2, "all", "DiM-L/2", 256, 250, 128)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    monkeypatch.setenv("WORLD_SIZE", "8")           # as a rank of torch.distributed.run (without it: the launcher, below)
     try:
         b.main()
     except Stop:
         pass
     a = seen["args"]
     assert (a.gpus, a.steps, a.warmup) == (8, 20, 5)
+
+
+def test_gpus_n_without_rank_env_launches_child_ranks(monkeypatch):
+    """`python bench.py --gpus 2` as the driver may invoke it (no RANK / WORLD_SIZE): the process becomes a launcher BEFORE
+    anything touches the GPU -- N fresh children through torch.distributed.run (scripts/eval.sh:73's torchrun), the same
+    argv handed down, their exit code handed up. With the rank environment present it runs as a rank instead."""
+    import pytest
+    b = _bench()
+    calls = []
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        calls.append((cmd, env))
+        return Done()
+
+    def no_bench(args):
+        raise AssertionError("the launcher process must not construct Bench (that is where the GPU is first touched)")
+
+    monkeypatch.setattr(b.subprocess, "run", fake_run)
+    monkeypatch.setattr(b, "Bench", no_bench)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        b.main()
+    assert e.value.code == 7                                    # the children's exit code is the launcher's
+    (cmd, env), = calls
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=2" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 0 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+    # inside a rank (WORLD_SIZE set by the launcher): no second launch
+    calls.clear()
+    seen = {}
+
+    class Stop(Exception):
+        pass
+
+    def fake_bench(args):
+        seen["gpus"] = args.gpus
+        raise Stop
+
+    monkeypatch.setattr(b, "Bench", fake_bench)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(Stop):
+        b.main()
+    assert seen["gpus"] == 2 and not calls
+
+
+def test_launcher_runs_real_children_and_relays_rank0_line(tmp_path):
+    """the launch path for real, without a GPU: a stand-in script (not bench.py: that needs the device) is started by
+    bench.launch_ranks' command line as 2 ranks over gloo; rank 0's line comes back on the inherited stdout and a failing
+    rank makes the launcher return non-zero."""
+    import subprocess
+    child = tmp_path / "child.py"
+    child.write_text(
+        "import os, sys, json\n"
+        "import torch.distributed as dist\n"
+        "dist.init_process_group('gloo')\n"
+        "if dist.get_rank() == 0:\n"
+        "    print(json.dumps({'world': dist.get_world_size(), 'argv': sys.argv[1:]}), flush=True)\n"
+        "dist.barrier()\n"
+        "dist.destroy_process_group()\n"
+        "sys.exit(3 if '--fail' in sys.argv and os.environ['RANK'] == '1' else 0)\n")
+    prog = ("import sys, importlib.util\n"
+            f"spec = importlib.util.spec_from_file_location('b', {os.path.join(ROOT, 'bench.py')!r})\n"
+            "b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+            f"b.__file__ = {str(child)!r}\n"
+            "sys.exit(b.launch_ranks(2, sys.argv[1:]))\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    ok = subprocess.run([sys.executable, "-c", prog, "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    import json
+    line = [l for l in ok.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1 and json.loads(line[0]) == {"world": 2, "argv": ["--gpus", "2"]}
+    bad = subprocess.run([sys.executable, "-c", prog, "--gpus", "2", "--fail"], capture_output=True, text=True, env=env, timeout=300)
+    assert bad.returncode != 0
