@@ -92,9 +92,7 @@ class CrossAttentionFusion(nn.Module):
                 raise RuntimeError("CrossAttentionFusion: qkv1 / qkv2 must both have a bias or none")
             fused = _XattnCoreFn.apply(gemm.linear(x1, self.qkv1.weight), gemm.linear(x2, self.qkv2.weight), b1, b2, self.num_heads)
         else:
-            if not x1.is_cuda:
-                pass        # only reachable with the CPU oracle backend of the tests installed (every other op raises on CPU)
-            elif self._plain and drop == 0.0:
+            if self._plain and drop == 0.0:
                 note_torch_path(f"CrossAttentionFusion core for head_dim {self.head_dim} / {x1.dtype}", required_opt_in=True)
             else:
                 note_torch_path("CrossAttentionFusion variant (qk_norm / swap_k / attention dropout: unused by the published configs)")

@@ -186,9 +186,8 @@ class Attention(nn.Module):
             # MFMA self-attention core (csrc/xattn_fusion*.hip, n_dirs = 1); the qkv bias is added inside the kernels
             o = _XattnCoreFn.apply(qkv, None, self.qkv.bias, None, self.num_heads)
         else:
-            if qkv.is_cuda:     # (on the CPU only reachable with the tests' oracle backend installed)
-                from .utils import note_torch_path
-                note_torch_path(f"Attention (shared DiTBlock) core for head_dim {self.head_dim} / {qkv.dtype}", required_opt_in=True)
+            from .utils import note_torch_path
+            note_torch_path(f"Attention (shared DiTBlock) core for head_dim {self.head_dim} / {qkv.dtype}", required_opt_in=True)
             if self.qkv.bias is not None:
                 qkv = qkv + self.qkv.bias
             q, k, v = qkv.reshape(B, N, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4).unbind(0)

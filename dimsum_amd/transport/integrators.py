@@ -178,14 +178,20 @@ class sde:
         self.dt = float(self.t[1] - self.t[0])
         self.drift, self.diffusion, self.sampler_type = drift, diffusion, sampler_type
 
+    @staticmethod
+    def _noise(x):
+        """drawn from the CPU generator and moved to x's device, like the reference (integrators.py:28,37
+        `th.randn(x.size()).to(x)`): the same `torch.manual_seed` gives the same samples on every device"""
+        return th.randn(x.size()).to(x)
+
     def _euler_maruyama(self, x, t, model, **kw):
-        dw = th.randn_like(x) * self.dt ** 0.5
+        dw = self._noise(x) * self.dt ** 0.5
         tt = th.ones(x.size(0), device=x.device, dtype=x.dtype) * t
         mean_x = x + self.drift(x, tt, model, **kw) * self.dt
         return mean_x + th.sqrt(2 * self.diffusion(x, tt)) * dw
 
     def _heun(self, x, t, model, **kw):
-        dw = th.randn_like(x) * self.dt ** 0.5
+        dw = self._noise(x) * self.dt ** 0.5
         tt = th.ones(x.size(0), device=x.device, dtype=x.dtype) * t
         xhat = x + th.sqrt(2 * self.diffusion(x, tt)) * dw
         k1 = self.drift(xhat, tt, model, **kw)

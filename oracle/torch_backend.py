@@ -146,16 +146,20 @@ def xattn_supported(qkv, head_dim):
 
 @contextlib.contextmanager
 def cpu_oracle_backend():
-    from dimsum_amd import native
+    from dimsum_amd import attention_fusion, native, utils
     from dimsum_amd.ops import token_ops
     names = ["selective_scan_fwd", "selective_scan_bwd", "causal_conv1d_fwd", "causal_conv1d_fwd_cond", "causal_conv1d_bwd",
              "layer_norm_fwd", "layer_norm_bwd", "gated_gelu_fwd", "gated_gelu_bwd", "token_transform", "xattn_supported"]
     saved = {n: getattr(native, n, None) for n in names}
-    guard = token_ops._require_gpu
+    guard, note = token_ops._require_gpu, utils.note_torch_path
     try:
         for n in names:
             setattr(native, n, globals()[n])
         token_ops._require_gpu = lambda x: None
+        # with xattn_supported() == False the host code takes its torch-SDPA branch, which the product counts and (for the
+        # plain published form) refuses without an opt-in: here that branch IS the checker (SDPA math on the CPU), so the
+        # bookkeeping is lifted for the duration -- the product code itself knows nothing about this backend
+        utils.note_torch_path = attention_fusion.note_torch_path = lambda *a, **k: None
         yield
     finally:
         for n, f in saved.items():
@@ -164,3 +168,4 @@ def cpu_oracle_backend():
             else:
                 setattr(native, n, f)
         token_ops._require_gpu = guard
+        utils.note_torch_path = attention_fusion.note_torch_path = note

@@ -67,3 +67,13 @@ def seeded(shape, seed, scale=1.0, kind="normal"):
     rs = np.random.RandomState(seed)
     v = rs.standard_normal(shape) if kind == "normal" else rs.uniform(size=shape)
     return (scale * v).astype(np.float32)
+
+
+def toy_denoiser(x, t, y=None):
+    """Closed-form stand-in for the denoiser in the transport fixtures (tools/gen_golden.py:gen_transport and
+    tests/test_transport_golden.py call the same function): smooth, bounded, depends on x, t and the label."""
+    tt = t.view(t.shape[0], *([1] * (x.dim() - 1))).to(x)
+    out = torch.tanh(0.7 * x + 0.3 * tt) - 0.25 * x * tt
+    if y is not None:
+        out = out + 0.01 * y.view(tt.shape).to(x)
+    return out

@@ -155,6 +155,26 @@ def test_block_combined_384_fwd_bwd_all_hip(tf32):
     assert utils.torch_path_counts() == before
 
 
+@pytest.mark.parametrize("policy", ["fp32", "tf32", "tf32_images"])
+def test_block_combined_1024_fwd_bwd_all_hip(policy, monkeypatch):
+    """BASELINE configs[2]'s block at config-3's width (hidden 1024, head_dim 64, batch 2) vs the reference golden: exact fp32;
+    the reference's allow_tf32 policy (split-bf16 library GEMMs + split-bf16 attention forward / backward at head_dim 64); and
+    the same with the split operand images forced on (512 rows is below their default threshold), i.e. exactly the kernels the
+    block_fwdbwd leg of bench.py runs at batch 256."""
+    from dimsum_amd import utils
+    from test_model_cpu import check_block_1024
+    before = utils.torch_path_counts()
+    old = torch.backends.cuda.matmul.allow_tf32
+    if policy == "tf32_images":
+        monkeypatch.setenv("DIMSUM_SPLIT3_MIN_ROWS", "0")
+    try:
+        torch.backends.cuda.matmul.allow_tf32 = policy != "fp32"
+        check_block_1024("cuda", dict(rtol=2e-4, atol=0.0, scale_atol=2e-5), dict(rtol=5e-4, atol=0.0, scale_atol=5e-5))
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = old
+    assert utils.torch_path_counts() == before
+
+
 def test_no_torch_library_attention_on_published_configs():
     """"no silent fallback": a published-config forward + backward never touches torch's SDPA (dimsum_amd.utils counts every
     such call), and a head size without an MFMA kernel raises instead of quietly running elsewhere"""

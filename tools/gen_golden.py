@@ -22,7 +22,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 warnings.filterwarnings("ignore", category=FutureWarning)
 
 import ref_shim  # noqa: E402
-from procedural import procedural_fill, seeded  # noqa: E402
+from procedural import procedural_fill, seeded, toy_denoiser  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 T = torch.from_numpy
@@ -365,6 +365,29 @@ def gen_block(ns):
          g_norm2=f16(blk.norm_2.weight.grad))
 
 
+def gen_block_1024(ns):
+    """BASELINE configs[2]'s block at ITS width: DiMBlockCombined(1024) (DiM-L/2: mixers d_model 512 / D 1024 / R 32, fusion
+    head_dim 64, MLP 1024 -> 8192 -> 4096 -> 1024), reverse + transpose on, continuity off (published), batch 2."""
+    hidden, B, L = 1024, 2, 256
+    x, res, c = T(seeded((B, L, hidden), 91)), T(seeded((B, L, hidden), 92)), T(seeded((B, hidden), 93))
+    gy, gr = T(seeded((B, L, hidden), 94)), T(seeded((B, L, hidden), 95))
+    blk = _mk_block(ns, hidden, True, True, False)
+    procedural_fill(blk, seed=9)
+    xi, ri, ci = x.clone().requires_grad_(), res.clone().requires_grad_(), c.clone().requires_grad_()
+    y, ro = blk(xi, ri, ci)
+    ((y * gy).sum() + (ro * gr).sum()).backward()
+    f = lambda t: t.detach().numpy().astype(np.float32)
+    sm, fm = blk.spatial_mamba.mixer, blk.freq_mamba.mixer
+    save("block_combined_1024", "DiMBlockCombined.forward + input grads + parameter grads (dimsum/models_dim.py:974-1117 via create_block "
+         ":2001-2160), hidden 1024, reverse / transpose on, continuity off, batch 2, procedural weights seed 9; inputs = seeded(91..95)",
+         y=f(y), res_out=f(ro), dx=f(xi.grad), dres=f(ri.grad), dc=f(ci.grad),
+         g_qkv1_rows64=f(blk.proj.qkv1.weight.grad[:64]), g_qkv2_bias=f(blk.proj.qkv2.bias.grad), g_proj_bias=f(blk.proj.proj.bias.grad),
+         g_A_log=f(sm.A_log.grad), g_D_freq=f(fm.D.grad), g_x_proj=f(sm.x_proj.weight.grad), g_dt_bias_freq=f(fm.dt_proj.bias.grad),
+         g_conv1d=f(sm.conv1d.weight.grad), g_in_proj_rows64=f(fm.in_proj.weight.grad[:64]), g_out_proj_rows64=f(sm.out_proj.weight.grad[:64]),
+         g_norm2=f(blk.norm_2.weight.grad), g_norm=f(blk.norm.weight.grad), g_w12_bias=f(blk.mlp.w12.bias.grad),
+         g_w3_rows16=f(blk.mlp.w3.weight.grad[:16]), g_adaLN_bias=f(blk.adaLN_modulation[1].bias.grad))
+
+
 def _mk_model(ns, name, **over):
     md = ns.models_dim
     kw = dict(img_resolution=32, in_channels=4, label_dropout=0.15, num_classes=1000, learn_sigma=False,
@@ -435,6 +458,87 @@ def gen_models(ns, which, only_tags=()):
         del m
 
 
+TRANSPORT_PATHS = ("GVP", "Linear", "VP")
+TRANSPORT_PREDS = ("velocity", "noise", "score")
+# explicit end-point margins: with the defaults the reference leaves sample_eps = None for VP and for noise / score
+# prediction (transport/__init__.py:50-55 tests `train_eps is None` after assigning it), which its samplers cannot use
+TRANSPORT_EPS = dict(train_eps=1e-3, sample_eps=2e-3)
+SDE_CASES = (  # (sampling_method, diffusion_form, diffusion_norm, last_step, last_step_size)
+    ("Euler", "SBDM", 1.0, "Mean", 0.04), ("Euler", "SBDM", 1.0, None, 0.04), ("Euler", "SBDM", 1.0, "Tweedie", 0.04),
+    ("Euler", "SBDM", 1.0, "Euler", -1), ("Heun", "SBDM", 1.0, "Mean", 0.04), ("Heun", "SBDM", 1.0, "Tweedie", -1),
+    ("Heun", "sigma", 0.7, "Euler", 0.04), ("Heun", "constant", 0.5, None, 0.04), ("Euler", "constant", 0.5, "Mean", 0.04),
+    ("Euler", "sigma", 1.0, "Mean", 0.04), ("Euler", "linear", 1.0, "Mean", 0.04), ("Euler", "decreasing", 1.0, "Mean", 0.04),
+    ("Euler", "increasing-decreasing", 1.0, "Tweedie", 0.04), ("Euler", "log", 1.0, "Euler", 0.04), ("Euler", "none", 1.0, "Mean", 0.04),
+)
+
+
+def gen_transport(_ns=None):
+    """The reference's flow-matching harness around a closed-form denoiser (tests/golden/procedural.py:toy_denoiser):
+    Transport.training_losses (dimsum/transport/transport.py:127-164) for {GVP, Linear, VP} x {velocity, noise, score} x
+    loss weights; Sampler.sample_sde (:286-341; integrators.py:5-73) for Euler-Maruyama / Heun x diffusion forms x last
+    steps; Sampler.sample_ode (:343-386) on the fixed Euler grid (through ref_shim's declared
+    stand-in for torchdiffeq's euler). Random draws come from the CPU generator after torch.manual_seed(seed) exactly as
+    the reference draws them (randn_like(x1) then rand(B); randn(x.size()) per SDE step)."""
+    tp = ref_shim.load_transport()
+    arrs = {}
+    x1 = T(seeded((5, 3, 4, 4), 81))
+    y = torch.tensor([3, 0, 7, 1, 5])
+    arrs.update(loss_x1=x1, y=y)
+    for pt in TRANSPORT_PATHS:
+        for pred in TRANSPORT_PREDS:
+            for lw in ((None,) if pred == "velocity" else (None, "velocity", "likelihood")):
+                tr = tp.create_transport(pt, pred, lw, **TRANSPORT_EPS)
+                seen = {}
+
+                def model(xt, t, y=None):
+                    seen["xt"], seen["t"] = xt, t
+                    return toy_denoiser(xt, t, y)
+
+                seed = 1000 + len(arrs)
+                torch.manual_seed(seed)
+                terms = tr.training_losses(model, x1, dict(y=y))
+                tag = f"loss_{pt}_{pred}_{lw}"
+                arrs.update({tag + "_seed": np.array(seed), tag + "_t": seen["t"], tag + "_xt": seen["xt"],
+                             tag + "_loss": terms["loss"], tag + "_pred": terms["pred"]})
+    # logit-normal time sampling (transport.py:116-121)
+    tr = tp.create_transport("GVP", "velocity", None, t_sample_mode="logitnormal")
+    torch.manual_seed(77)
+    seen = {}
+
+    def model(xt, t, y=None):
+        seen["t"] = t
+        return toy_denoiser(xt, t, y)
+
+    terms = tr.training_losses(model, x1, dict(y=y))
+    arrs.update(loss_logitnormal_t=seen["t"], loss_logitnormal_loss=terms["loss"])
+
+    z = T(seeded((3, 3, 4, 4), 82))
+    yz = torch.tensor([2, 9, 4])
+    arrs.update(z=z, yz=yz)
+    for pt in TRANSPORT_PATHS:
+        for pred in TRANSPORT_PREDS:
+            tr = tp.create_transport(pt, pred, **TRANSPORT_EPS)
+            # velocity prediction on GVP / Linear: create_transport forces both margins to 0 (__init__.py:56-58), with which the
+            # SBDM diffusion (alpha' / alpha at t = 0) is infinite; the SDE fixtures set the margin on the object instead
+            tr.train_eps, tr.sample_eps = TRANSPORT_EPS["train_eps"], TRANSPORT_EPS["sample_eps"]
+            smp = tp.Sampler(tr)
+            for i, (method, form, norm, last, lss) in enumerate(SDE_CASES):
+                torch.manual_seed(2000 + i)
+                xs = smp.sample_sde(sampling_method=method, diffusion_form=form, diffusion_norm=norm, last_step=last,
+                                    last_step_size=lss, num_steps=10)(z, toy_denoiser, y=yz)
+                arrs[f"sde_{pt}_{pred}_{i}_last"] = xs[-1]
+                arrs[f"sde_{pt}_{pred}_{i}_prev"] = xs[-2]
+                arrs[f"sde_{pt}_{pred}_{i}_len"] = np.array(len(xs))
+            # (reverse=True cannot run in the reference: check_interval returns t0 > t1 and integrators.py:90 asserts)
+            traj = smp.sample_ode(sampling_method="euler", num_steps=9)(z, toy_denoiser, y=yz)
+            arrs[f"ode_{pt}_{pred}"] = traj[-1]
+            arrs[f"ode_{pt}_{pred}_mid"] = traj[4]
+    arrs["sde_cases"] = np.array([repr(c) for c in SDE_CASES])
+    save("transport", "dimsum/transport: Transport.training_losses (transport.py:127-164), Sampler.sample_sde (:286-341, "
+         "integrators.py:5-73), Sampler.sample_ode on the euler grid (:343-386, integrators.py:98-111 with the declared torchdiffeq "
+         "euler stand-in of tools/ref_shim.py:load_transport), path.py:21-246; denoiser = tests/golden/procedural.py:toy_denoiser", **arrs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
@@ -450,6 +554,7 @@ def main():
         "XL2": lambda: gen_models(ns, {"model_XL2_512"}),
         "zigzag": lambda: gen_models(ns, {"tiny"}, only_tags=("tiny_zigma8", "tiny_jpeg8", "tiny_sweep8")),
         "XL2zigzag": lambda: gen_models(ns, {"model_XL2_512_zigma8"}),
+        "transport": lambda: gen_transport(ns), "block1024": lambda: gen_block_1024(ns),
     }
     for k, fn in steps.items():
         if args.only is None or k in args.only:

@@ -119,7 +119,7 @@ _LOADED = {}
 
 def load():
     """Returns a namespace with the reference modules routed to their own CPU refs."""
-    if _LOADED:
+    if "ns" in _LOADED:
         return _LOADED["ns"]
     assert available(), "reference tree not present"
     _stub_native(); _stub_mamba_pkg(); _stub_timm(); _stub_pywt()
@@ -163,6 +163,38 @@ def load():
                                attention_fusion=attention_fusion, mlp=mlp, models_dim=models_dim)
     _LOADED["ns"] = ns
     return ns
+
+
+def load_transport():
+    """The reference's flow-matching harness (dimsum/transport/: Transport.training_losses :127-164, Sampler.sample_sde
+    :286-341, Sampler.sample_ode :343-386, path.py, integrators.py) imported as the package `transport`. Its one missing
+    import is `torchdiffeq.odeint` (requirements.txt:172, absent from this image): the stand-in below does explicit Euler
+    on the given grid -- `x += (t[i+1] - t[i]) f(t[i], x)`, torchdiffeq's published fixed-grid "euler" -- and refuses
+    every other method, so fixtures made through it pin the reference's OWN code around the solver (the drift of each
+    model type, `t` as ones(B) * t, check_interval's end points, reverse time), not torchdiffeq."""
+    if "transport" in _LOADED:
+        return _LOADED["transport"]
+    assert available(), "reference tree not present"
+    if "torchdiffeq" not in sys.modules:
+        m = types.ModuleType("torchdiffeq")
+
+        def odeint(fn, x, t, method=None, atol=None, rtol=None):
+            assert method == "euler", "stand-in for torchdiffeq: fixed-grid euler only"
+            out = [x]
+            for a, b in zip(t[:-1], t[1:]):
+                x = x + (b - a) * fn(a, x)
+                out.append(x)
+            return torch.stack(out)
+
+        m.odeint = odeint
+        sys.modules["torchdiffeq"] = m
+    p = os.path.join(REF, "dimsum")
+    if p not in sys.path:
+        sys.path.insert(0, p)
+    import transport
+    assert os.path.realpath(transport.__file__).startswith(os.path.realpath(REF)), transport.__file__
+    _LOADED["transport"] = transport
+    return transport
 
 
 def slow_path(model):
