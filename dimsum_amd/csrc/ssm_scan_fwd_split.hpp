@@ -47,10 +47,9 @@ __global__ __launch_bounds__(kWave, (kSP == 4 && kN <= 16) ? 5 : 3) void ssm_sca
     // XOR-permuted by n / kNL, so the parts read different slots (no padding: 8 KB of LDS per wave = 20 waves per CU).
     constexpr int kBS = kST;
     auto bc_off = [](int n, int col4) { return n * kST + (((kSP == 4 ? col4 ^ (n / kNL) : col4)) << 2); };
-    __shared__ __attribute__((aligned(16))) float tileU[kSC * kST];
-    __shared__ __attribute__((aligned(16))) float tileD[kSC * kST];
-    __shared__ __attribute__((aligned(16))) float tileB[kN * kBS];
-    __shared__ __attribute__((aligned(16))) float tileC[kN * kBS];
+    // one LDS block, [u | dt | B | C]: the sequential loop addresses it with byte offsets formed by ONE v_xor per tile
+    __shared__ __attribute__((aligned(16))) float smem[2 * kSC * kST + 2 * kN * kBS];
+    float *const tileU = smem, *const tileD = smem + kSC * kST, *const tileB = smem + 2 * kSC * kST, *const tileC = tileB + kN * kBS;
 
     const int lane = threadIdx.x, c = lane & (kSC - 1), sh = lane / kSC;
     const int ns0 = sh * kNL;
@@ -86,11 +85,21 @@ __global__ __launch_bounds__(kWave, (kSP == 4 && kN <= 16) ? 5 : 3) void ssm_sca
 #pragma unroll
         for (int k = 0; k < kNL; ++k) { A2[k] = Ap[(ns0 + k) * p.A_dstate_stride] * kLog2e; h[k] = 0.f; }
     }
-    const float Dval = (p.D_ptr && sh == 0) ? reinterpret_cast<const float *>(p.D_ptr)[d] : 0.f;   // D u is added by the low half only
+    const float Dval = p.D_ptr ? reinterpret_cast<const float *>(p.D_ptr)[d] : 0.f;   // D u_t is added by the lane that ends up with step t
     const float *bias_p = reinterpret_cast<const float *>(p.delta_bias_ptr);
     const bool softplus = p.delta_softplus != 0;
     const bool has_out = out_base != nullptr;
-    float sum_dt = 0.f;   // prod_t a_t[n] = exp2(A2[n] * sum_t dt_t)
+    // prod_t a_t[n] = exp2(A2[n] * sum_t dt_t). Vector path: the sum is kept per STAGED row in the load layout (4 adds per
+    // 16-byte piece instead of 4 per lane and 4-step group in the sequential loop) and joined only where x is stored.
+    float sum_dt = 0.f, sdt[kNPc];
+#pragma unroll
+    for (int i = 0; i < kNPc; ++i) sdt[i] = 0.f;
+    // LDS offsets (floats) of this lane's u / dt row and B / C rows: the 16-byte slot index enters by XOR and the row bases have
+    // no bits below 32, so stile_off(c, j) == uoff0 ^ (j << 2) and bc_off(ns0, j) == boff0 ^ (j << 2): one v_xor per 4-step group
+    // (byte offsets into smem; the tile bases are multiples of 512 B as well)
+    const unsigned uoff0 = 4u * (unsigned)stile_off(c, 0), boff0 = 4u * (unsigned)(2 * kSC * kST + ns0 * kST + ((kSP == 4 ? sh : 0) << 2));
+    const unsigned soff0 = uoff0 + 4u * (unsigned)sh;      // the slot this lane's finished y goes to (kSP == 2: and the one 8 B above)
+    auto lds4 = [&](unsigned off) -> const f32x4 & { return *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(smem) + off); };
     float *ck_base = (kCkpt && p.ckpt_ptr && live) ? reinterpret_cast<float *>(p.ckpt_ptr) + (int64_t)b * ((L + 7) / 8) * kN * p.dim + (int64_t)ns0 * p.dim + d : nullptr;
 
     const int n_tiles = (L + kST - 1) / kST;
@@ -145,6 +154,7 @@ __global__ __launch_bounds__(kWave, (kSP == 4 && kN <= 16) ? 5 : 3) void ssm_sca
                 f32x4 vd = widen(rd[i]);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) vd.v[s] = col_ok ? softplus_if(vd.v[s] + brow[i], softplus) : 0.f;
+                sdt[i] += (vd.v[0] + vd.v[1]) + (vd.v[2] + vd.v[3]);
                 *reinterpret_cast<f32x4 *>(&tileU[stile_off(row, lc4)]) = widen(ru[i]);
                 *reinterpret_cast<f32x4 *>(&tileD[stile_off(row, lc4)]) = vd;
             }
@@ -191,26 +201,32 @@ __global__ __launch_bounds__(kWave, (kSP == 4 && kN <= 16) ? 5 : 3) void ssm_sca
 #pragma unroll
                 for (int k = 0; k < kNL; ++k) ck[(int64_t)k * p.dim] = h[k];
             }
-            const f32x4 u4 = *reinterpret_cast<const f32x4 *>(&tileU[stile_off(c, j)]);
-            const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&tileD[stile_off(c, j)]);
-            const int brow0 = bc_off(ns0, j);        // rows ns0 .. ns0 + kNL - 1 share the slot permutation
-            f32x4 bq_nxt = *reinterpret_cast<const f32x4 *>(&tileB[brow0]);
-            f32x4 cq_nxt = *reinterpret_cast<const f32x4 *>(&tileC[brow0]);
+            const unsigned jx = (unsigned)j << 4, uo = uoff0 ^ jx, bo = boff0 ^ jx;
+            const f32x4 u4 = lds4(uo);
+            const f32x4 d4 = lds4(uo + 4u * kSC * kST);
+            f32x4 bq_nxt = lds4(bo);
+            f32x4 cq_nxt = lds4(bo + 4u * kN * kBS);
+            // u of the step(s) whose total this lane ends up with (for D u): one b32 read of the slot it overwrites below
+            float *slot = reinterpret_cast<float *>(reinterpret_cast<char *>(smem) + (soff0 ^ jx));
+            const float uown0 = slot[0], uown2 = kSP == 2 ? slot[2] : 0.f;
             float du[4], y[4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) { sum_dt += d4.v[s]; du[s] = d4.v[s] * u4.v[s]; y[s] = Dval * u4.v[s]; }
+            for (int s = 0; s < 4; ++s) {
+                if constexpr (!kVec) sum_dt += d4.v[s];
+                du[s] = d4.v[s] * u4.v[s];
+            }
 #pragma unroll
             for (int k = 0; k < kNL; ++k) {
                 const f32x4 bq = bq_nxt, cq = cq_nxt;
                 if (k + 1 < kNL) {
-                    bq_nxt = *reinterpret_cast<const f32x4 *>(&tileB[brow0 + (k + 1) * kBS]);
-                    cq_nxt = *reinterpret_cast<const f32x4 *>(&tileC[brow0 + (k + 1) * kBS]);
+                    bq_nxt = lds4(bo + 4u * (k + 1) * kBS);
+                    cq_nxt = lds4(bo + 4u * (kN + k + 1) * kBS);
                 }
                 float hn = h[k];
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     hn = fmaf(fast_exp2(d4.v[s] * A2[k]), hn, bq.v[s] * du[s]);
-                    y[s] = fmaf(hn, cq.v[s], y[s]);
+                    y[s] = k == 0 ? hn * cq.v[s] : fmaf(hn, cq.v[s], y[s]);
                 }
                 h[k] = hn;
             }
@@ -218,10 +234,8 @@ __global__ __launch_bounds__(kWave, (kSP == 4 && kN <= 16) ? 5 : 3) void ssm_sca
                 // join the halves: low lane <- totals of steps 0 and 2, high lane <- totals of steps 1 and 3
                 swap_halves(y[0], y[1]);
                 swap_halves(y[2], y[3]);
-                const float ya = y[0] + y[1], yb = y[2] + y[3];
-                float *slot = &tileU[stile_off(c, j)] + sh;
-                slot[0] = ya;
-                slot[2] = yb;
+                slot[0] = fmaf(Dval, uown0, y[0] + y[1]);
+                slot[2] = fmaf(Dval, uown2, y[2] + y[3]);
             } else {
                 // join the quarters (rows of 16 lanes): rows 0, 1 <- sums over rows {r, r + 2} of steps 0 / 1, rows 2, 3 of
                 // steps 2 / 3; then the even row of each pair keeps the first, the odd row the second: quarter q <- step q
@@ -229,12 +243,19 @@ __global__ __launch_bounds__(kWave, (kSP == 4 && kN <= 16) ? 5 : 3) void ssm_sca
                 swap_halves(y[1], y[3]);
                 float w0 = y[0] + y[2], w1 = y[1] + y[3];
                 swap_rows(w0, w1);
-                tileU[stile_off(c, j) + sh] = w0 + w1;
+                slot[0] = fmaf(Dval, uown0, w0 + w1);
             }
         }
 
         // ---- chunk-state store at every 2048 boundary and at the end (selective_scan_fwd_kernel.cuh:251-254) ---
         const int t_end = min(t0 + kST, L);
+        if (kVec && p.x_ptr && ((t_end & 2047) == 0 || t_end == L)) {
+            // join the staged rows' dt sums: 8 partials per row through LDS (the dt tile is consumed), row c read back by lane c
+#pragma unroll
+            for (int i = 0; i < kNPc; ++i) tileD[(i * 8 + lrow) * 8 + lc4] = sdt[i];
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(&tileD[c * 8]), b2 = *reinterpret_cast<const f32x4 *>(&tileD[c * 8 + 4]);
+            sum_dt = ((a.v[0] + a.v[1]) + (a.v[2] + a.v[3])) + ((b2.v[0] + b2.v[1]) + (b2.v[2] + b2.v[3]));
+        }
         if (p.x_ptr && ((t_end & 2047) == 0 || t_end == L) && live) {
             float *xr = reinterpret_cast<float *>(p.x_ptr) + (((int64_t)b * p.dim + d) * p.n_chunks + (t_end - 1) / 2048) * (2 * kN) + 2 * ns0;
 #pragma unroll

@@ -86,17 +86,11 @@ def test_adacfg_and_sde_drift_hip_vs_cpu_oracle():
     got, ref = _both(run_ada)
     assert_close(got, ref, 1e-3, 0, "ada-cfg euler", scale_atol=1e-4)
 
-    noise = T(seeded((4, 4, 32, 32), 94))
-
     def run_sde(m, dev):
         sampler = Sampler(create_transport("GVP", "velocity"))
-        old = torch.randn_like
-        torch.randn_like = lambda x, **k: noise.to(x)          # the one stochastic input of the step, fixed
-        try:
-            xs = sampler.sample_sde(sampling_method="Euler", diffusion_form="sigma", diffusion_norm=1.0, last_step="Mean",
-                                    last_step_size=0.04, num_steps=3)(z.to(dev), m.forward, y=y.to(dev))
-        finally:
-            torch.randn_like = old
+        torch.manual_seed(94)          # the noise is drawn from the CPU generator on either device (like the reference): same draws
+        xs = sampler.sample_sde(sampling_method="Euler", diffusion_form="sigma", diffusion_norm=1.0, last_step="Mean",
+                                last_step_size=0.04, num_steps=3)(z.to(dev), m.forward, y=y.to(dev))
         return xs[-1].cpu().numpy()
     got, ref = _both(run_sde)
     assert_close(got, ref, 2e-3, 0, "sde euler-maruyama + mean last step", scale_atol=2e-4)
