@@ -19,8 +19,10 @@ Further legs on the same line (default `--mode all`; each is also a `--mode` of 
   train_step     SURVEY 8 f2: one whole flow-matching training step of DiM-L/2 (loss, backward, clip, fused AdamW, EMA), batch 64 (N = 1)
   cpu_baseline   the same forward on the host cores through the CPU oracle ("port"): 1 warm-up + 3 runs, median (N = 1)
 Every `roofline*` object: algorithmic bytes per launch (SURVEY.md 8d formula) / average launch duration of the scan
-kernel measured live with HIP events on the launch stream during that leg's timed steps; the kernel name comes from the
-library's own dispatch (dimsum_ssm_scan_fwd_variant); `traffic` (HBM bytes from rocprofv3 --pmc, profiles/scan_pmc.json) is
+kernel measured live with HIP events on the launch stream -- during the timed steps of the training legs (one stream), and
+for the inference legs (whose blocks run their two branches on two HIP streams: overlapped kernels have no duration of
+their own) in a short single-stream pass right after the timed region (`roofline.timed_in`); the kernel name comes from
+the library's own dispatch (dimsum_ssm_scan_fwd_variant); `traffic` (HBM bytes from rocprofv3 --pmc, profiles/scan_pmc.json) is
 attached only when the timed launches have exactly the profiled shape and kernel, otherwise null.
 """
 import argparse
@@ -109,9 +111,10 @@ class ScanTimer:
                     kernel = _lib.SCAN_FWD_KERNELS[lib.dimsum_ssm_scan_fwd_variant(p)] + (" (+ saved states)" if p.ckpt_ptr else "")
                 else:
                     kernel = "ssm_scan_bwd_kernel (+ ssm_scan_bwd_reduce_kernel)" + ("" if p.out_z_ptr else ", no out_z recompute")
-                # HIP events recorded at the begin of the call's first kernel and the end of its last one (dimsum_timing_events:
-                # hipExtLaunchKernel on the launch stream) -- the kernels' own time, like rocprofv3's; under a hipGraph capture
-                # (events are not capturable) plain event records around the call
+                # HIP events recorded at the begin of the call's first kernel and the end of its last one (the per-call
+                # timing_start_event / timing_stop_event fields of the parameters: hipExtLaunchKernel on the launch stream) --
+                # the kernels' own time, like rocprofv3's; under a hipGraph capture (events are not capturable) plain event
+                # records around the call
                 if torch.cuda.is_current_stream_capturing():
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
@@ -119,9 +122,9 @@ class ScanTimer:
                     e1.record()
                 else:
                     e0, e1 = timer.pool_event(lib), timer.pool_event(lib)
-                    lib.dimsum_timing_events(e0, e1)
+                    p.timing_start_event, p.timing_stop_event = e0, e1
                     rc = fn(P, stream)
-                    lib.dimsum_timing_events(None, None)
+                    p.timing_start_event = p.timing_stop_event = None
                 s = {_lib.F32: 4}.get(p.dtype, 2)
                 shape = (p.batch, p.dim, p.seqlen, p.dstate)
                 nbytes = (scan_bwd_bytes(*shape, p.n_groups, s, recompute_out_z=bool(p.out_z_ptr)) if which == "bwd"
@@ -263,13 +266,15 @@ class Bench:
             dist.barrier(device_ids=[self.local_rank])
         torch.cuda.synchronize()
 
-    def timed(self, step, steps, warmup):
-        """`warmup` untimed steps, then exactly `steps` steps between two fences; max over ranks. -> seconds"""
+    def timed(self, step, steps, warmup, time_scans=True):
+        """`warmup` untimed steps, then exactly `steps` steps between two fences; max over ranks. -> seconds.
+        time_scans=False: no per-launch HIP events (inference legs: the two branches of a block run on two streams there, and a
+        kernel that shares the chip has no duration of its own -- see scan_roofline_pass)."""
         for _ in range(warmup):
             step()
         self.fence()
         self.timer.reset()
-        self.timer.enabled = True
+        self.timer.enabled = time_scans
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
@@ -281,6 +286,38 @@ class Bench:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = tmax.item()
         return elapsed
+
+    def scan_roofline_pass(self, step, n=2):
+        """Inference runs the two branches of every block on two HIP streams (dimsum_amd/models_dim.py, the default): the scan of
+        one branch overlaps the GEMMs of the other and its launch-to-launch time is no longer its own. The roofline of the scan
+        kernel is therefore measured in a short pass of `n` more steps of the SAME step function on ONE stream
+        (DIMSUM_BRANCH_STREAMS=0), right after the timed region, with one HIP-event pair per launch; the line says so."""
+        old = os.environ.get("DIMSUM_BRANCH_STREAMS")
+        os.environ["DIMSUM_BRANCH_STREAMS"] = "0"
+        try:
+            step()
+            torch.cuda.synchronize()
+            self.timer.reset()
+            self.timer.enabled = True
+            for _ in range(n):
+                step()
+            torch.cuda.synchronize()
+        finally:
+            self.timer.enabled = False
+            if old is None:
+                del os.environ["DIMSUM_BRANCH_STREAMS"]
+            else:
+                os.environ["DIMSUM_BRANCH_STREAMS"] = old
+        rf = self.timer.roofline("fwd")
+        if rf is not None:
+            rf["timed_in"] = (f"single-stream pass of {n} steps right after the timed region ({rf['launches_timed']} launches, HIP events at the "
+                              "kernels' own begin / end); the timed region itself runs the two branches of every block on two HIP streams")
+        return rf
+
+    @staticmethod
+    def streams_note():
+        return ("one stream (DIMSUM_BRANCH_STREAMS=0)" if os.environ.get("DIMSUM_BRANCH_STREAMS", "1") == "0"
+                else "two HIP streams per block (spatial || frequency branch), bit-identical to one stream")
 
     def inputs(self, batch, r):
         gen = torch.Generator(device=self.dev).manual_seed(0 * self.world + self.rank)      # sample_ddp.py:64 seeding rule
@@ -309,12 +346,13 @@ class Bench:
             def step():
                 with torch.no_grad():
                     return model(x, t, y)
-        elapsed = self.timed(step, steps, warmup)
+        elapsed = self.timed(step, steps, warmup, time_scans=False)
         out = {"workload": f"{model_name} denoiser forward, {image_size}px (4x{r}x{r} latents, {(r // 2) ** 2} tokens), {batch} latents per GPU, "
                            + WEIGHTS + (f", scan_type={scan_type}" if scan_type != "none" else ""),
                "value": batch * self.world * steps / elapsed, "unit": "latents/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
-               "warmup": warmup, "batch_per_gpu": batch, "launch": "hipGraph replay" if a.hip_graph else "eager"}
-        rf = self.timer.roofline("fwd")
+               "warmup": warmup, "batch_per_gpu": batch, "launch": "hipGraph replay" if a.hip_graph else "eager",
+               "branch_streams": "one stream (captured graph)" if a.hip_graph else self.streams_note()}
+        rf = None if a.hip_graph else self.scan_roofline_pass(step)          # (a replayed graph makes no library calls to time)
         if rf is not None:
             out["roofline"] = rf
         if extra_precisions and self.world == 1 and a.matmul == "tf32" and not a.hip_graph:
@@ -374,16 +412,23 @@ class Bench:
 
         def step():
             res["out"] = sample_batch(model, x, y, num_steps=nfe, world_size=self.world, hip_graph=graphs)
-        elapsed = self.timed(step, 1, 0)
+        elapsed = self.timed(step, 1, 0, time_scans=False)
         out = {"workload": f"{model_name} {nfe}-NFE fixed-step Euler flow-matching sampling, {image_size}px, {batch} latents per GPU "
                            f"(global batch {batch * self.world}), one all_gather_into_tensor of the final latents, " + WEIGHTS,
                "value": batch * self.world / elapsed, "unit": "samples/s", "nfe": nfe, "s_per_batch": elapsed,
                "ms_per_nfe": 1e3 * elapsed / nfe, "batch_per_gpu": batch,
                "seed_rule": f"global_seed * world + rank = 0 * {self.world} + {self.rank} (sample_ddp.py:64)", "gathered_shape": list(res["out"].shape), "finite": bool(torch.isfinite(res["out"]).all().item()),
-               "launch": "hipGraph replay" if a.hip_graph else "eager"}
-        rf = self.timer.roofline("fwd")
-        if rf is not None:
-            out["roofline"] = rf
+               "launch": "hipGraph replay" if a.hip_graph else "eager",
+               "branch_streams": "one stream (captured graph)" if a.hip_graph else self.streams_note()}
+        if not a.hip_graph:
+            tt = torch.full((batch,), 0.5, device=self.dev)
+
+            def one_nfe():
+                with torch.no_grad():
+                    return model(x, tt, y)
+            rf = self.scan_roofline_pass(one_nfe)
+            if rf is not None:
+                out["roofline"] = rf
         del model
         self.free()
         return out

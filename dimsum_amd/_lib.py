@@ -17,7 +17,8 @@ class SsmParams(C.Structure):
                                       "z_batch_stride", "z_d_stride", "out_batch_stride", "out_d_stride",
                                       "out_z_batch_stride", "out_z_d_stride")]
                 + [(n, vp) for n in ("A_ptr", "B_ptr", "C_ptr", "D_ptr", "u_ptr", "delta_ptr", "delta_bias_ptr",
-                                     "z_ptr", "out_ptr", "x_ptr", "out_z_ptr", "ckpt_ptr")])
+                                     "z_ptr", "out_ptr", "x_ptr", "out_z_ptr", "ckpt_ptr")]
+                + [("kernel_variant", i32), ("timing_start_event", vp), ("timing_stop_event", vp)])
 
 
 class SsmBwdParams(C.Structure):
@@ -85,9 +86,9 @@ class XattnBwdParams(C.Structure):
 # every symbol include/dimsum_hip.h declares (tests check the library exports all of them)
 EXPORTS = (
     "dimsum_status_string", "dimsum_abi_version", "dimsum_target_arch",
-    "dimsum_timing_events", "dimsum_event_create", "dimsum_event_destroy", "dimsum_event_elapsed_ms",
+    "dimsum_event_create", "dimsum_event_destroy", "dimsum_event_elapsed_ms",
     "dimsum_ssm_scan_fwd", "dimsum_ssm_scan_bwd", "dimsum_ssm_scan_bwd_workspace_bytes", "dimsum_ssm_scan_fwd_variant",
-    "dimsum_ssm_scan_fwd_force_variant", "dimsum_causal_conv1d_fwd", "dimsum_causal_conv1d_bwd",
+    "dimsum_causal_conv1d_fwd", "dimsum_causal_conv1d_bwd",
     "dimsum_norm_fwd", "dimsum_norm_bwd", "dimsum_token_transform", "dimsum_xattn_fusion_fwd", "dimsum_xattn_fusion_bwd",
     "dimsum_gated_gelu_fwd", "dimsum_gated_gelu_bwd", "dimsum_gated_gelu_fwd_split3", "dimsum_gated_gelu_bwd_split3", "dimsum_split3",
 )
@@ -108,8 +109,7 @@ def load():
     lib.dimsum_status_string.argtypes = [C.c_int]
     lib.dimsum_target_arch.restype = C.c_char_p
     lib.dimsum_abi_version.restype = C.c_int
-    if hasattr(lib, "dimsum_timing_events"):
-        lib.dimsum_timing_events.restype, lib.dimsum_timing_events.argtypes = None, [vp, vp]
+    if hasattr(lib, "dimsum_event_create"):
         lib.dimsum_event_create.restype, lib.dimsum_event_create.argtypes = vp, []
         lib.dimsum_event_destroy.restype, lib.dimsum_event_destroy.argtypes = None, [vp]
         lib.dimsum_event_elapsed_ms.restype, lib.dimsum_event_elapsed_ms.argtypes = C.c_float, [vp, vp]
@@ -137,15 +137,13 @@ def load():
     if hasattr(lib, "dimsum_ssm_scan_fwd_variant"):
         lib.dimsum_ssm_scan_fwd_variant.restype = C.c_int
         lib.dimsum_ssm_scan_fwd_variant.argtypes = [C.POINTER(SsmParams)]
-        lib.dimsum_ssm_scan_fwd_force_variant.restype = None
-        lib.dimsum_ssm_scan_fwd_force_variant.argtypes = [C.c_int]
-    if lib.dimsum_abi_version() != 9:
+    if lib.dimsum_abi_version() != 10:
         raise RuntimeError("dimsum_amd: libdimsum_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib
 
 
-SCAN_FWD_KERNELS = {0: "ssm_scan_fwd_kernel", 2: "ssm_scan_fwd_split_kernel<2 lanes per channel>",
+SCAN_FWD_KERNELS = {1: "ssm_scan_fwd_kernel", 2: "ssm_scan_fwd_split_kernel<2 lanes per channel>",
                     4: "ssm_scan_fwd_split_kernel<4 lanes per channel>",
                     16: "ssm_scan_fwd_lanes_kernel<one lane per state>"}      # dimsum_ssm_scan_fwd_variant() -> kernel
 

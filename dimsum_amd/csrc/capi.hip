@@ -17,19 +17,7 @@ extern "C" const char *dimsum_status_string(int status) {
 extern "C" int dimsum_abi_version(void) { return DIMSUM_ABI_VERSION; }
 extern "C" const char *dimsum_target_arch(void) { return "gfx950"; }
 
-// ---- measurement hook: kernel-boundary timing of the next selective-scan call (common.hpp) ---------------------------------------
-namespace dimsum {
-static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
-void take_timing_events(hipEvent_t *start, hipEvent_t *stop) {
-    *start = g_ev0; *stop = g_ev1;
-    g_ev0 = nullptr; g_ev1 = nullptr;
-}
-}  // namespace dimsum
-
-extern "C" void dimsum_timing_events(void *start, void *stop) {
-    dimsum::g_ev0 = reinterpret_cast<hipEvent_t>(start);
-    dimsum::g_ev1 = reinterpret_cast<hipEvent_t>(stop);
-}
+// ---- measurement helpers: HIP events for the per-call timing_start_event / timing_stop_event fields of the scan parameters ----
 extern "C" void *dimsum_event_create(void) {
     hipEvent_t e = nullptr;
     return hipEventCreate(&e) == hipSuccess ? e : nullptr;

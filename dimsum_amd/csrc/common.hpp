@@ -123,10 +123,8 @@ __device__ __forceinline__ float softplus_if(float x, bool flag) {
 // ---- host ----------------------------------------------------------------------------------------------------------
 inline int launch_status() { return hipGetLastError() == hipSuccess ? DIMSUM_OK : DIMSUM_ERR_LAUNCH; }
 
-// Measurement hook (capi.hip, dimsum_timing_events): a benchmark may arm ONE pair of HIP events; the next selective-scan call
-// records them at its first kernel's begin and its last kernel's end (hipExtLaunchKernelGGL: the timestamps of the kernels' own
-// dispatch packets, what rocprofv3 reports) instead of as separate commands around the call. take_timing_events() disarms.
-void take_timing_events(hipEvent_t *start, hipEvent_t *stop);
+// Kernel-boundary timing (dimsum_ssm_params_t.timing_start_event / timing_stop_event): hipExtLaunchKernelGGL records the events
+// at the begin / end of the kernel's own dispatch packet -- what rocprofv3 reports -- instead of as separate commands around it.
 #define DIMSUM_LAUNCH_EV(KERNEL, GRID, BLOCK, STREAM, EV0, EV1, ...)                                              \
     do {                                                                                                          \
         if ((EV0) || (EV1)) hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, STREAM, EV0, EV1, 0, __VA_ARGS__);      \

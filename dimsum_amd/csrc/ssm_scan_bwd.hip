@@ -615,8 +615,9 @@ __global__ __launch_bounds__(256) void ssm_scan_bwd_reduce_kernel(const float *_
     }
 }
 
+// ev0: recorded at the begin of the main kernel unless the state-rebuild sweep of this call already took it (then null)
 template <typename T, int kN>
-static int launch_bwd(const dimsum_ssm_bwd_params_t &q, const float *ckpt, float *part, hipStream_t stream) {
+static int launch_bwd(const dimsum_ssm_bwd_params_t &q, const float *ckpt, float *part, hipStream_t stream, hipEvent_t ev0) {
     const dimsum_ssm_params_t &p = q.fwd;
     const int dpg = p.dim / p.n_groups;
     constexpr int kWC = kBW * kBC;            // channels per workgroup
@@ -641,9 +642,7 @@ static int launch_bwd(const dimsum_ssm_bwd_params_t &q, const float *ckpt, float
         return DIMSUM_ERR_STRIDE;
     const bool full = vec && (dpg % kWC == 0);
     dim3 grid(tiles), block(kBW * kWave);
-    hipEvent_t ev0, ev1;
-    take_timing_events(&ev0, &ev1);     // armed by a benchmark (common.hpp): begin of the main kernel .. end of the reduce kernel
-    const hipEvent_t none = nullptr;
+    const hipEvent_t ev1 = reinterpret_cast<hipEvent_t>(p.timing_stop_event), none = nullptr;   // end of the reduce kernel
 #define DIMSUM_LAUNCH(HASZ, VEC, FULL) \
     DIMSUM_LAUNCH_EV((ssm_scan_bwd_kernel<T, kN, HASZ, VEC, FULL>), grid, block, stream, ev0, none, q, ckpt, part)
     if (p.z_ptr) {
@@ -668,12 +667,12 @@ static int launch_bwd(const dimsum_ssm_bwd_params_t &q, const float *ckpt, float
 }
 
 template <typename T>
-static int dispatch_bwd(const dimsum_ssm_bwd_params_t &q, const float *ckpt, float *part, hipStream_t stream) {
+static int dispatch_bwd(const dimsum_ssm_bwd_params_t &q, const float *ckpt, float *part, hipStream_t stream, hipEvent_t ev0) {
     switch (q.fwd.dstate) {
-        case 4: return launch_bwd<T, 4>(q, ckpt, part, stream);
-        case 8: return launch_bwd<T, 8>(q, ckpt, part, stream);
-        case 32: return launch_bwd<T, 32>(q, ckpt, part, stream);
-        case 16: return launch_bwd<T, 16>(q, ckpt, part, stream);
+        case 4: return launch_bwd<T, 4>(q, ckpt, part, stream, ev0);
+        case 8: return launch_bwd<T, 8>(q, ckpt, part, stream, ev0);
+        case 32: return launch_bwd<T, 32>(q, ckpt, part, stream, ev0);
+        case 16: return launch_bwd<T, 16>(q, ckpt, part, stream, ev0);
         default: return DIMSUM_ERR_SHAPE;
     }
 }
@@ -711,20 +710,23 @@ extern "C" int dimsum_ssm_scan_bwd(const dimsum_ssm_bwd_params_t *q, void *strea
     const float *ckpt = reinterpret_cast<const float *>(p.ckpt_ptr);
     if (q->workspace_bytes < pbytes + (ckpt ? 0 : ckpt_bytes(p.batch, p.dim, p.seqlen, p.dstate))) return DIMSUM_ERR_SHAPE;
     float *part = reinterpret_cast<float *>(q->workspace_ptr);
+    hipEvent_t ev0 = reinterpret_cast<hipEvent_t>(p.timing_start_event);     // begin of the call's FIRST kernel
     if (!ckpt) {
         // reference-shaped call (no saved states): one state-only forward sweep rebuilds them in the workspace
         dimsum_ssm_params_t f = p;
         f.z_ptr = nullptr; f.out_ptr = nullptr; f.out_z_ptr = nullptr; f.x_ptr = nullptr; f.D_ptr = nullptr;
         f.ckpt_ptr = reinterpret_cast<char *>(q->workspace_ptr) + pbytes;
+        f.timing_stop_event = nullptr;          // (the sweep's begin is the call's begin; its end is not the call's end)
         const int frc = dimsum_ssm_scan_fwd(&f, stream);
         if (frc != DIMSUM_OK) return frc;
+        ev0 = nullptr;
         ckpt = reinterpret_cast<const float *>(f.ckpt_ptr);
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (p.dtype) {
-        case DIMSUM_F32: return dispatch_bwd<float>(*q, ckpt, part, s);
-        case DIMSUM_F16: return dispatch_bwd<__half>(*q, ckpt, part, s);
-        case DIMSUM_BF16: return dispatch_bwd<__hip_bfloat16>(*q, ckpt, part, s);
+        case DIMSUM_F32: return dispatch_bwd<float>(*q, ckpt, part, s, ev0);
+        case DIMSUM_F16: return dispatch_bwd<__half>(*q, ckpt, part, s, ev0);
+        case DIMSUM_BF16: return dispatch_bwd<__hip_bfloat16>(*q, ckpt, part, s, ev0);
         default: return DIMSUM_ERR_DTYPE;
     }
 }

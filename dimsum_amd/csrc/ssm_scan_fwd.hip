@@ -19,38 +19,37 @@ int ssm_check(const dimsum_ssm_params_t *p, bool forward) {
     return DIMSUM_OK;
 }
 
-// Which forward kernel serves a shape: 0 = lane = channel (64 channels per wave), 2 / 4 = lanes per channel of the
-// state-split kernel (32 / 16 channels per wave), 16 = one lane per state (dstate 16: 4 channels per wave).
-// dimsum_ssm_scan_fwd_force_variant() overrides the choice (tests, tuning).
-static int g_force_variant = -1;
+// Which forward kernel serves a call, as lanes per channel: 1 = lane = channel (64 channels per wave), 2 / 4 = the state-split
+// kernel (32 / 16 channels per wave), 16 = one lane per state (dstate 16: 4 channels per wave). p.kernel_variant != 0 asks
+// for one of them (tests, tuning); a pure function of the parameters.
 constexpr int64_t kLanesBelowWaves = 2048;
 
 static bool variant_ok(const dimsum_ssm_params_t &p, int v) {
-    return v == 0 || (v == 2 && p.dstate % 4 == 0) || (v == 4 && p.dstate % 8 == 0) || (v == 16 && p.dstate == 16);
+    return v == 1 || (v == 2 && p.dstate % 4 == 0) || (v == 4 && p.dstate % 8 == 0) || (v == 16 && p.dstate == 16);
 }
 
 int ssm_scan_fwd_variant(const dimsum_ssm_params_t &p) {
-    if (g_force_variant >= 0) return variant_ok(p, g_force_variant) ? g_force_variant : 0;
+    if (p.kernel_variant != 0) return variant_ok(p, p.kernel_variant) ? p.kernel_variant : 1;
     // The 64-channel kernel keeps 8 waves per CU resident (2048 on the chip) and is HBM-bound when they are all there.
     // A launch that does not fill those slots is latency-bound per wave: splitting the states over 2 or 4 lanes gives it
     // 2x / 4x the waves, each with 1/2 / 1/4 of the sequential work per step. Measured (fp32, dstate 16):
     //   (256, 1024, 256): 64-channel 0.33 ms, kSP = 2 equal;   (64, 1152, 1024): 0.534 / 0.475 / see DESIGN.md section 3.1
     const int64_t dpg = p.dim / p.n_groups;
     const int64_t waves = (int64_t)p.batch * p.n_groups * ((dpg + kWave - 1) / kWave);
-    if (waves >= 2048) return 0;
+    if (waves >= 2048) return 1;
     // fewer than 2 waves per SIMD even at 16 channels per wave: one lane per state (4 channels per wave). Measured (fp32):
     //   (16, 1152, 4096): 0.71 -> 0.57 ms, (8, 1152, 4096): 0.54 -> 0.34 ms; (32, 1152, 1024), 2304 waves: equal
     const int64_t waves4 = (int64_t)p.batch * p.n_groups * ((dpg + 15) / 16);
     if (waves4 < kLanesBelowWaves && variant_ok(p, 16)) return 16;
     if (variant_ok(p, 4)) return 4;
-    return variant_ok(p, 2) ? 2 : 0;
+    return variant_ok(p, 2) ? 2 : 1;
 }
 
 template <typename T, int kN>
 static int launch_fwd(const dimsum_ssm_params_t &p, hipStream_t stream) {
     const int dpg = p.dim / p.n_groups;
-    const int sp = ssm_scan_fwd_variant(p);                // 0, 2, 4 or 16
-    const int cpw = sp == 0 ? kWave : kWave / sp;          // channels per wave
+    const int sp = ssm_scan_fwd_variant(p);                // lanes per channel: 1, 2, 4 or 16
+    const int cpw = kWave / sp;                            // channels per wave
     const int tiles = p.batch * p.n_groups * ((dpg + cpw - 1) / cpw);
     const size_t va = 4 * sizeof(T);  // vector path: every row base 4-element aligned
     bool vec = (p.seqlen % 4 == 0) && aligned_to<T>(p.u_ptr, va) && aligned_to<T>(p.delta_ptr, va) &&
@@ -99,8 +98,6 @@ extern "C" int dimsum_ssm_scan_fwd_variant(const dimsum_ssm_params_t *p) {
     if (!p || p->n_groups <= 0) return -1;
     return dimsum::ssm_scan_fwd_variant(*p);
 }
-
-extern "C" void dimsum_ssm_scan_fwd_force_variant(int variant) { dimsum::g_force_variant = variant; }
 
 extern "C" int dimsum_ssm_scan_fwd(const dimsum_ssm_params_t *p, void *stream) {
     using namespace dimsum;

@@ -488,7 +488,10 @@ extern "C" int dimsum_xattn_fusion_fwd(const dimsum_xattn_params_t *p, void *str
     if (nblk > 0x7fffffff) return DIMSUM_ERR_SHAPE;
     const dim3 grid((unsigned)nblk), block(256);
     if (p->precision != 0 && p->precision != 1) return DIMSUM_ERR_SHAPE;
-    if (p->out_split3 && (p->precision != 1 || p->out_token_stride < 3 * (int64_t)(self_attn ? 1 : 2) * p->heads * p->head_dim)) return DIMSUM_ERR_STRIDE;
+    // the operand image is written in 16-byte pieces (8 bf16): its base and both strides must keep that alignment
+    if (p->out_split3 && (p->precision != 1 || p->out_token_stride < 3 * (int64_t)(self_attn ? 1 : 2) * p->heads * p->head_dim ||
+                          reinterpret_cast<uintptr_t>(p->out_ptr) % 16 != 0 || p->out_batch_stride % 8 != 0 || p->out_token_stride % 8 != 0))
+        return DIMSUM_ERR_STRIDE;
     if (p->precision == 1) {
         // 2 query tiles per wave (128 queries per workgroup) halve the per-query staging work; short sequences keep 1
         const bool two = p->seqlen >= 128;

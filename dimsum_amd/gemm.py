@@ -22,13 +22,49 @@ proj, w12, w3 -- everything else is small).
   sliced     weight gradients reduce over the batch's rows into a small output; `mm_tn` / `mm_nn_rows` run such a product as one
              batched GEMM over row slices plus a sum when the output has fewer than 256 tiles of 256 x 256 (the library does
              not split the reduction itself: in_proj's weight gradient 1.59 -> 0.46 ms).
-The operands are converted by a torch cast on every call -- weights too: DiM-L/2's 460 M parameters cost ~0.5 ms per
-forward (< 1 %) to cast, and a cached copy could not see in-place updates made through `.data` (EMA updates,
-load_state_dict), which do not bump a tensor's version counter. Outputs stay fp32."""
+The operands are converted on every call -- weights too (a cached copy could not see in-place updates made through `.data`:
+EMA updates, load_state_dict do not bump a tensor's version counter) -- except inside `frozen_weights()`, the scope a sampler
+opens around its NFE loop, where each weight image is built once. Outputs stay fp32."""
+import contextlib
+
 import torch
 import torch.nn.functional as F
 
 _policy = "default"
+_frozen = None          # weight-image cache of the innermost frozen_weights() scope, else None
+
+
+@contextlib.contextmanager
+def frozen_weights():
+    """Scope in which the caller guarantees that no weight changes (the NFE loop of a sampler: 250 forwards over constant
+    weights): the split-bf16 weight images [hi | lo | hi] (and the fp16 copies of the opt-in policy) are built once per weight
+    instead of once per call -- 128 ~14 us launches per DiM-L/2 forward. Outside such a scope every call converts afresh, because a
+    cached image cannot see in-place updates made through `.data` (EMA, load_state_dict). The cache dies with the scope."""
+    global _frozen
+    outer = _frozen
+    if outer is None:
+        _frozen = {}
+    try:
+        yield
+    finally:
+        if outer is None:
+            _frozen = None
+
+
+def _cached(kind, weight, make):
+    if _frozen is None:
+        return make()
+    key = (kind, weight.data_ptr(), tuple(weight.shape), tuple(weight.stride()), weight.dtype)
+    hit = _frozen.get(key)
+    if hit is None:
+        hit = _frozen[key] = make()
+    return hit
+
+
+def weight_image(weight):
+    """weight (N, K) float32 -> its split-bf16 image (N, 3K) bfloat16 in weight order [hi | lo | hi]"""
+    from . import native
+    return _cached("w3", weight, lambda: native.split3_rows(weight.detach(), left=False))
 
 
 def set_policy(policy):
@@ -48,7 +84,7 @@ def _use_fp16(x, weight):
 
 
 def _w16(weight):
-    return weight.detach().to(torch.float16)
+    return _cached("w16", weight, lambda: weight.detach().to(torch.float16))
 
 
 def _slices(rows, n_out, k_out):
@@ -154,7 +190,8 @@ def matmul_wx(weight, xt):
     """weight (N, K) @ xt (K, M) -> (N, M): the in_proj site, whose output is consumed d-major without a copy"""
     if not _use_fp16(xt, weight):
         x2 = xt.t()
-        if torch.is_grad_enabled() and weight.requires_grad and xt.is_cuda and x2.is_contiguous():
+        if (torch.is_grad_enabled() and weight.requires_grad and xt.is_cuda and x2.is_contiguous()
+                and not torch.is_autocast_enabled("cuda")):          # (under autocast the plain product differentiates with mixed dtypes)
             return _MatmulWxFn.apply(weight, x2)
         return weight @ xt
     return torch.mm(_w16(weight), xt.to(torch.float16), out_dtype=torch.float32)
@@ -174,16 +211,12 @@ def split3_enabled(x, weight):
 
 def linear_split3(x3, weight):
     """x3 (M, 3K) bfloat16 left image [hi | hi | lo] @ weight (N, K)^T -> (M, N) float32"""
-    from . import native
-    w3 = native.split3_rows(weight.detach(), left=False)
-    return torch.mm(x3, w3.t(), out_dtype=torch.float32)
+    return torch.mm(x3, weight_image(weight).t(), out_dtype=torch.float32)
 
 
 def matmul_wx_split3(weight, x3):
     """weight (N, K) @ x^T -> (N, M) float32 with x given as its left image x3 (M, 3K): the in_proj site (d-major output)"""
-    from . import native
-    w3 = native.split3_rows(weight.detach(), left=False)
-    return torch.mm(w3, x3.t(), out_dtype=torch.float32)
+    return torch.mm(weight_image(weight), x3.t(), out_dtype=torch.float32)
 
 
 def split3_train_enabled(x, weight):

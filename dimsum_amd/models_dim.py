@@ -426,11 +426,13 @@ class _CombinedBase(_BlockBase):
         # inference under allow_tf32: the branches hand their results over as split-bf16 operand images of the qkv Linears
         img = gemm.split3_enabled(x1, self.proj.qkv1.weight) and self.proj.takes_images(hidden_states)
         kw = {"out_split3": True} if img else {}
-        if (not torch.is_grad_enabled()) and hidden_states.is_cuda and os.environ.get("DIMSUM_BRANCH_STREAMS", "0") == "1":
-            # OPT-IN (inference): the two branches are independent until the fusion -- the frequency branch on a second HIP stream lets
-            # the memory-bound passes of one branch (conv1d, scan, token passes) overlap the GEMMs of the other: -1.3 .. -2.4 % per
-            # forward, bit-identical. Off by default: kernels that share the chip cannot be timed individually any more (the scan's
-            # launch-to-launch time goes 0.33 -> 0.52 ms), and bench.py's roofline is such a per-kernel measurement.
+        if ((not torch.is_grad_enabled()) and hidden_states.is_cuda and os.environ.get("DIMSUM_BRANCH_STREAMS", "1") != "0"
+                and not torch.cuda.is_current_stream_capturing()):
+            # inference: the two branches are independent until the fusion -- the frequency branch on a second HIP stream lets the
+            # memory-bound passes of one branch (conv1d, scan, token passes) overlap the GEMMs of the other: -1.3 .. -2.4 % per
+            # forward, bit-identical (tests/test_model_gpu.py::test_two_stream_branches_are_bit_identical). DIMSUM_BRANCH_STREAMS=0
+            # keeps one stream: kernels that share the chip cannot be timed individually (the scan's launch-to-launch time goes
+            # 0.33 -> 0.52 ms), so bench.py measures its per-kernel roofline in a short single-stream pass and says so on the line.
             cur = torch.cuda.current_stream(hidden_states.device)
             side = self.__dict__.get("_side_stream")
             if side is None or side.device != hidden_states.device:

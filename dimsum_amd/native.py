@@ -9,6 +9,8 @@ Conventions kept from the reference host wrappers:
   * launches go to torch's CURRENT stream of the input's device, no synchronisation.
 There is no CPU path: a non-GPU tensor or a missing library is an error.
 """
+import contextlib
+
 import torch
 
 from . import _lib
@@ -39,7 +41,23 @@ def _ptr(t):
 # ---------------------------------------------------------------------------------------------------------------------
 # selective_scan_cuda.fwd / .bwd   (mamba/csrc/selective_scan/selective_scan.cpp:226-492)
 # ---------------------------------------------------------------------------------------------------------------------
+_scan_fwd_variant = 0     # dimsum_ssm_params_t.kernel_variant of the calls made from here: 0 = the library's own choice
+
+
+@contextlib.contextmanager
+def scan_fwd_variant(v):
+    """tests / tuning: ask for one forward scan kernel (lanes per channel: 1, 2, 4, 16; 0 = automatic) for the calls made inside.
+    A per-call field of the C ABI -- the library keeps no state; this host-side setting is not thread-safe."""
+    global _scan_fwd_variant
+    old, _scan_fwd_variant = _scan_fwd_variant, int(v)
+    try:
+        yield
+    finally:
+        _scan_fwd_variant = old
+
+
 def _fill_ssm(P, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, x, out_z, ckpt=None):
+    P.kernel_variant = _scan_fwd_variant
     batch, dim, seqlen = u.shape
     P.batch, P.dim, P.seqlen, P.dstate = batch, dim, seqlen, A.shape[1]
     P.n_groups, P.n_chunks = B.shape[1], (seqlen + 2047) // 2048

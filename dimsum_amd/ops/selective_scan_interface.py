@@ -215,7 +215,8 @@ def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_wei
                    B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True):
     return _MambaInner.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
                              out_proj_bias, A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, None, True, 1,
-                             _will_backprop(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias, A, D, delta_bias))
+                             _will_backprop(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias, A, B, C, D, delta_bias,
+                                            B_proj_bias, C_proj_bias, None))
 
 
 def mamba_inner_fn_cond(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
@@ -223,14 +224,15 @@ def mamba_inner_fn_cond(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
                         delta_softplus=True, init_states=None):
     return _MambaInner.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
                              out_proj_bias, A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, init_states,
-                             True, 1, _will_backprop(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias, A, D, delta_bias))
+                             True, 1, _will_backprop(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias, A, B, C, D, delta_bias,
+                                            B_proj_bias, C_proj_bias, init_states))
 
 
 def mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B=None, C=None,
                                D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True):
     return _MambaInner.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, None, None, A, B, C, D,
                              delta_bias, B_proj_bias, C_proj_bias, delta_softplus, None, False, 1,
-                             _will_backprop(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias))
+                             _will_backprop(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, None))
 
 
 def mamba_inner_fn_no_out_proj_cond(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B=None, C=None,
@@ -238,7 +240,7 @@ def mamba_inner_fn_no_out_proj_cond(xz, conv1d_weight, conv1d_bias, x_proj_weigh
                                     init_states=None):
     return _MambaInner.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, None, None, A, B, C, D,
                              delta_bias, B_proj_bias, C_proj_bias, delta_softplus, init_states, False, 1,
-                             _will_backprop(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias))
+                             _will_backprop(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, init_states))
 
 
 def bimamba_inner_fn(*args, **kwargs):

@@ -11,6 +11,7 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import gemm
 from .transport import Sampler, create_transport
 
 
@@ -33,13 +34,14 @@ def sample_batch(model, z, y, num_steps=250, sampling_method="euler", cfg_scale=
             fwd_cfg = hip_graph.setdefault("cfg", GraphedForward(fwd_cfg))
     sampler = Sampler(create_transport(path_type, "velocity"))
     fn = sampler.sample_ode(sampling_method=sampling_method, num_steps=num_steps + 1)
-    if cfg_scale is not None and cfg_scale > 1.0:
-        n = z.shape[0]
-        zz = torch.cat([z, z], 0)
-        y_null = torch.full_like(y, getattr(model, "num_classes", 1000))
-        out = fn(zz, fwd_cfg, return_trajectory=False, y=torch.cat([y, y_null], 0), cfg_scale=cfg_scale)[:n]
-    else:
-        out = fn(z, fwd, return_trajectory=False, y=y)
+    with gemm.frozen_weights():       # the weights are constant over the NFE loop: every weight image is built once per batch
+        if cfg_scale is not None and cfg_scale > 1.0:
+            n = z.shape[0]
+            zz = torch.cat([z, z], 0)
+            y_null = torch.full_like(y, getattr(model, "num_classes", 1000))
+            out = fn(zz, fwd_cfg, return_trajectory=False, y=torch.cat([y, y_null], 0), cfg_scale=cfg_scale)[:n]
+        else:
+            out = fn(z, fwd, return_trajectory=False, y=y)
     ws = world_size if world_size is not None else (dist.get_world_size() if _dist_ready() else 1)
     if gather and _dist_ready() and (ws > 1 or gather == "force"):      # "force": also with one rank (collective bring-up tests)
         out = out.contiguous()

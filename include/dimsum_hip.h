@@ -17,7 +17,7 @@
  *   - plain pointers, sizes and ELEMENT strides; no torch types. The caller allocates every output, including the
  *     zero-filled fp32 accumulators of the backward passes (selective_scan.cpp:458-466, causal_conv1d.cpp:405-407).
  *   - asynchronous on the hipStream_t passed in (`stream`, a `void*` so that plain C / ctypes can include this);
- *     no allocation, no synchronisation, no global state. Re-entrant.
+ *     no allocation, no synchronisation, no global state (the library has no mutable statics at all). Re-entrant.
  *   - return value: DIMSUM_OK or an error code; dimsum_status_string() gives the message the host layer raises
  *     (the reference raises RuntimeError from TORCH_CHECK at the same places).
  *   - innermost (sequence / feature) stride must be 1 for every activation tensor, like selective_scan.cpp:252-253.
@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DIMSUM_ABI_VERSION 9
+#define DIMSUM_ABI_VERSION 10
 
 typedef enum {
     DIMSUM_OK = 0,
@@ -48,11 +48,8 @@ typedef enum { DIMSUM_F32 = 0, DIMSUM_F16 = 1, DIMSUM_BF16 = 2 } dimsum_dtype_t;
 const char *dimsum_status_string(int status);
 int dimsum_abi_version(void);
 
-/* Measurement hook (benchmarks; no reference counterpart). dimsum_timing_events arms one pair of HIP events (hipEvent_t, e.g. from
- * dimsum_event_create): the NEXT dimsum_ssm_scan_fwd / dimsum_ssm_scan_bwd call records them at the begin of its first kernel and the
- * end of its last one (hipExtLaunchKernel: the kernels' own dispatch timestamps, the durations rocprofv3 reports), then disarms.
- * Process-global, not thread-safe, not capturable into a hipGraph. */
-void dimsum_timing_events(void *start_event, void *stop_event);
+/* Measurement helpers (benchmarks; no reference counterpart): HIP events (hipEvent_t behind void*) for the per-call
+ * `timing_start_event` / `timing_stop_event` fields of dimsum_ssm_params_t. Stateless wrappers of hipEventCreate / Destroy / ElapsedTime. */
 void *dimsum_event_create(void);
 void dimsum_event_destroy(void *event);
 float dimsum_event_elapsed_ms(void *start_event, void *stop_event);   /* after the stream has been synchronised; < 0 on error */
@@ -91,6 +88,14 @@ typedef struct {
                          forward: written when non-NULL (training callers keep it for the backward);
                          backward: read when non-NULL, otherwise rebuilt into workspace_ptr by one extra sweep.
                          Not part of the reference interface (its backward re-scans whole rows instead). */
+    /* per-call extras, all 0 / NULL by default (no reference counterpart; nothing here is process state): */
+    int32_t kernel_variant;   /* forward kernel: 0 = automatic (dimsum_ssm_scan_fwd_variant tells which), else lanes per channel:
+                                 1 (64 channels per wave), 2, 4, 16 (one lane per state; dstate 16). A variant the shape does
+                                 not support (dstate % 4, % 8, != 16) falls back to 1. For tests and tuning. */
+    void *timing_start_event, *timing_stop_event;   /* optional hipEvent_t pair: recorded at the begin of the call's first kernel
+                                 and the end of its last one (hipExtLaunchKernel: the kernels' own dispatch timestamps, the
+                                 durations rocprofv3 reports). In dimsum_ssm_bwd_params_t.fwd they bracket the whole backward
+                                 call incl. the state-rebuild sweep of a caller without ckpt_ptr. Not capturable into a hipGraph. */
 } dimsum_ssm_params_t;
 
 typedef struct {
@@ -121,17 +126,15 @@ int dimsum_ssm_scan_fwd(const dimsum_ssm_params_t *p, void *stream);
 int dimsum_ssm_scan_bwd(const dimsum_ssm_bwd_params_t *p, void *stream);
 /* upper bound of the backward's workspace (partial dB / dC + rebuilt states) */
 int64_t dimsum_ssm_scan_bwd_workspace_bytes(int32_t batch, int32_t dim, int32_t seqlen, int32_t dstate, int32_t n_groups);
-/* Which forward kernel dimsum_ssm_scan_fwd launches for these parameters (measurement / diagnostics; no reference
- * counterpart: the reference has one kernel, selective_scan_fwd_kernel.cuh:67-303):
- *   0 = ssm_scan_fwd_kernel        lane = channel, 64 channels per wave (launches that fill the chip)
+/* Which forward kernel dimsum_ssm_scan_fwd launches for these parameters, p->kernel_variant included (a pure function of *p;
+ * measurement / diagnostics; no reference counterpart: the reference has one kernel, selective_scan_fwd_kernel.cuh:67-303).
+ * Lanes per channel:
+ *   1 = ssm_scan_fwd_kernel        lane = channel, 64 channels per wave (launches that fill the chip)
  *   2 = ssm_scan_fwd_split_kernel  lane = (channel, state half), 32 channels per wave
  *   4 = ssm_scan_fwd_split_kernel  lane = (channel, state quarter), 16 channels per wave (few channels, long sequences)
  *  16 = ssm_scan_fwd_lanes_kernel  lane = (channel, state), 4 channels per wave, dstate 16 (fewer channels still)
  * -1 on invalid parameters. */
 int dimsum_ssm_scan_fwd_variant(const dimsum_ssm_params_t *p);
-/* Process-global override of that choice for subsequent launches: 0 / 2 / 4 / 16, or -1 = automatic (the default). A variant
- * the shape does not support (dstate % 4, % 8, != 16) falls back to 0. For tests and tuning; not thread-safe. */
-void dimsum_ssm_scan_fwd_force_variant(int variant);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Causal depthwise conv1d, width 2..4, optional bias, optional SiLU.  Mirrors ConvParamsBase / ConvParamsBwd

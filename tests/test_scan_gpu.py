@@ -25,11 +25,9 @@ def fwd_kernel(request):
     """runs a forward test under the automatic kernel choice and with each forward kernel forced (64 channels per wave /
     lane = (channel, state half) / lane = (channel, state quarter) / lane = (channel, state), the last for dstate 16 only -- other
     dstates fall back to the 64-channel kernel): small test shapes would otherwise all take one"""
-    from dimsum_amd import _lib
-    lib = _lib.load()
-    lib.dimsum_ssm_scan_fwd_force_variant({"auto": -1, "64ch": 0, "split2": 2, "split4": 4, "lanes16": 16}[request.param])
-    yield request.param
-    lib.dimsum_ssm_scan_fwd_force_variant(-1)
+    from dimsum_amd import native
+    with native.scan_fwd_variant({"auto": 0, "64ch": 1, "split2": 2, "split4": 4, "lanes16": 16}[request.param]):
+        yield request.param
 
 
 def _t(a, dev="cuda"):
@@ -134,18 +132,18 @@ def test_forward_kernel_variants_agree():
     Bm, Cm = torch.randn(B, 1, N, L, device="cuda", generator=g), torch.randn(B, 1, N, L, device="cuda", generator=g)
     Dv, bias = torch.randn(D, device="cuda", generator=g), 0.5 * torch.rand(D, device="cuda", generator=g)
     res = {}
-    try:
-        for v in (0, 2, 4, 16):
-            lib.dimsum_ssm_scan_fwd_force_variant(v)
+    for v in (1, 2, 4, 16):
+        with native.scan_fwd_variant(v):
             out, x, oz, ck = native.selective_scan_fwd(u, dl, A, Bm, Cm, Dv, z, bias, True, need_ckpt=True)
             res[v] = [t.cpu().numpy() for t in (out, x, oz, ck)]
             P = _lib.SsmParams()
             native._fill_ssm(P, u, dl, A, Bm, Cm, Dv, z, bias, True, out, x, oz)
-            assert lib.dimsum_ssm_scan_fwd_variant(P) == v
-    finally:
-        lib.dimsum_ssm_scan_fwd_force_variant(-1)
+            assert P.kernel_variant == v and lib.dimsum_ssm_scan_fwd_variant(P) == v
+    P = _lib.SsmParams()
+    native._fill_ssm(P, u, dl, A, Bm, Cm, Dv, z, bias, True, out, x, oz)
+    assert P.kernel_variant == 0                # the request ends with its scope: nothing sticks in the library or the host layer
     for v in (2, 4, 16):
-        for name, a, b in zip(("out", "x", "out_z", "saved states"), res[v], res[0]):
+        for name, a, b in zip(("out", "x", "out_z", "saved states"), res[v], res[1]):
             assert_close(a, b, 2e-5, 0, f"{name} (variant {v})", scale_atol=2e-6)
 
 
@@ -153,8 +151,8 @@ def test_forward_dispatch_by_shape():
     """launches that fill the 2048 wave slots take the 64-channel kernel; smaller ones a state split: 4 lanes per channel, one lane per state (dstate 16) when even that leaves < 2 waves per SIMD"""
     from dimsum_amd import _lib
     lib = _lib.load()
-    for (B, D, N, G), want in {(256, 1024, 16, 1): 0, (64, 1152, 16, 1): 4, (16, 1152, 16, 1): 16, (32, 1152, 16, 1): 4, (16, 1152, 8, 1): 4, (4, 384, 4, 1): 2, (2, 70, 6, 1): 0,
-                               (2048, 64, 16, 1): 0}.items():
+    for (B, D, N, G), want in {(256, 1024, 16, 1): 1, (64, 1152, 16, 1): 4, (16, 1152, 16, 1): 16, (32, 1152, 16, 1): 4, (16, 1152, 8, 1): 4, (4, 384, 4, 1): 2, (2, 70, 6, 1): 1,
+                               (2048, 64, 16, 1): 1}.items():
         P = _lib.SsmParams()
         P.batch, P.dim, P.seqlen, P.dstate, P.n_groups, P.n_chunks = B, D, 256, N, G, 1
         assert lib.dimsum_ssm_scan_fwd_variant(P) == want, (B, D, N, G)
@@ -319,7 +317,7 @@ def test_bwd_half_dtypes(dtype, tol_rel):
         assert err <= 1.5 * tol_rel * scale, (name, "vs oracle", err, scale)
 
 
-@pytest.mark.parametrize("variant", [0, 2, 4, 16])
+@pytest.mark.parametrize("variant", [1, 2, 4, 16])
 @pytest.mark.parametrize("B,D,L,G,has_z,has_D", [(2, 70, 151, 1, True, True),      # ragged: D % 4 != 0, L odd (element-wise staging)
                                                  (2, 70, 152, 2, True, False),     # 2 groups of 35 channels: partial last tiles, vector I/O
                                                  (1, 6, 4100, 1, False, True),     # two 2048-step chunks + a 4-step tail, no gate
@@ -342,14 +340,11 @@ def test_forward_variants_vs_oracle_on_ragged_shapes(variant, B, D, L, G, has_z,
     bias = 0.5 * torch.rand(D, device="cuda", generator=g)
     n = lambda t: None if t is None else t.cpu().numpy()
     y_ref, oz_ref, x_ref = c_ops.selective_scan_fwd(n(u), n(dl), n(A), n(Bm), n(Cm), n(Dv), n(z), n(bias), True)
-    try:
-        lib.dimsum_ssm_scan_fwd_force_variant(0)
+    with native.scan_fwd_variant(1):
         ck0 = native.selective_scan_fwd(u, dl, A, Bm, Cm, Dv, z, bias, True, need_ckpt=True)[-1]
-        lib.dimsum_ssm_scan_fwd_force_variant(variant)
+    with native.scan_fwd_variant(variant):
         res = native.selective_scan_fwd(u, dl, A, Bm, Cm, Dv, z, bias, True, need_ckpt=True)
         res_inf = native.selective_scan_fwd(u, dl, A, Bm, Cm, Dv, z, bias, True)
-    finally:
-        lib.dimsum_ssm_scan_fwd_force_variant(-1)
     out, x = res[0], res[1]
     tol = dict(rtol=2e-4, atol=0.0, scale_atol=1e-5) if L <= 512 else dict(rtol=6e-4, atol=0.0, scale_atol=1e-4)
     assert_close(n(out), y_ref, what="out", **tol)
@@ -359,3 +354,44 @@ def test_forward_variants_vs_oracle_on_ragged_shapes(variant, B, D, L, G, has_z,
         assert torch.equal(res_inf[2], res[2])
     assert torch.equal(res_inf[0], out)
     assert_close(n(res[-1]), n(ck0), what="saved states", **tol)
+
+
+def test_timing_events_bracket_the_whole_backward_call(monkeypatch):
+    """dimsum_ssm_params_t.timing_start_event / timing_stop_event (per call, no process state): in a backward call they are
+    recorded at the begin of its FIRST kernel and the end of its LAST one -- with saved states that is main kernel .. reduce
+    kernel; for a reference-shaped call (no saved states) the interval also contains the state-rebuild sweep, so it is longer by
+    about a forward launch. A call without events records nothing."""
+    import importlib.util
+    import os
+    from dimsum_amd import _lib, native
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_timing", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setattr(_lib, "load", _lib.load)            # ScanTimer.install() replaces it: restored after the test
+    timer = bench.ScanTimer()
+    timer.install()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    B, D, L, N = 64, 512, 256, 16
+    u, z = torch.randn(B, D, L, device="cuda", generator=g), torch.randn(B, D, L, device="cuda", generator=g)
+    dl = 0.5 * torch.rand(B, D, L, device="cuda", generator=g)
+    A = -0.5 * torch.rand(D, N, device="cuda", generator=g)
+    Bm, Cm = torch.randn(B, 1, N, L, device="cuda", generator=g), torch.randn(B, 1, N, L, device="cuda", generator=g)
+    Dv, bias = torch.randn(D, device="cuda", generator=g), 0.5 * torch.rand(D, device="cuda", generator=g)
+    dout = torch.randn(B, D, L, device="cuda", generator=g)
+    out, x, out_z, ckpt = native.selective_scan_fwd(u, dl, A, Bm, Cm, Dv, z, bias, True, need_ckpt=True)
+    assert not timer.records["fwd"]                       # timer off: the call above carried no events
+    ms = {}
+    for name, ck in (("saved", ckpt), ("rebuilt", None)):
+        for _ in range(2):
+            native.selective_scan_bwd(u, dl, A, Bm, Cm, Dv, z, bias, dout, x, out, None, True, False, ckpt=ck)
+        torch.cuda.synchronize()
+        timer.reset()
+        timer.enabled = True
+        for _ in range(5):
+            native.selective_scan_bwd(u, dl, A, Bm, Cm, Dv, z, bias, dout, x, out, None, True, False, ckpt=ck)
+        timer.enabled = False
+        torch.cuda.synchronize()
+        assert len(timer.records["bwd"]) == 5 and not timer.records["fwd"]     # the internal sweep is not a second record
+        ms[name] = timer.roofline("bwd")["avg_launch_ms"]
+    assert ms["saved"] > 0 and ms["rebuilt"] > 1.15 * ms["saved"], ms

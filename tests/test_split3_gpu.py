@@ -309,3 +309,66 @@ def test_block_training_at_a_size_where_everything_is_active(monkeypatch):
     for n, a, b in zip(names, res["new"], res["old"]):
         scale = b.abs().max().item()
         assert (a - b).abs().max().item() <= 1e-4 * scale + 1e-12, (n, (a - b).abs().max().item(), scale)
+
+
+def test_frozen_weights_scope_caches_weight_images(monkeypatch):
+    """gemm.frozen_weights(): inside the scope a weight's split image is built once (same object on the second call, bit-identical
+    product); outside every call converts afresh, so an in-place update through .data is seen; the cache dies with the scope."""
+    from dimsum_amd import gemm, native
+    g = torch.Generator(device="cuda").manual_seed(11)
+    w = torch.randn(256, 128, device="cuda", generator=g)
+    x = torch.randn(512, 128, device="cuda", generator=g)
+    x3 = native.split3_rows(x, left=True)
+    ref = gemm.linear_split3(x3, w)
+    assert gemm.weight_image(w) is not gemm.weight_image(w)                   # no scope: nothing is kept
+    with gemm.frozen_weights():
+        a = gemm.weight_image(w)
+        assert gemm.weight_image(w) is a
+        assert torch.equal(gemm.linear_split3(x3, w), ref)
+        with gemm.frozen_weights():                                            # nested scopes share the outer cache
+            assert gemm.weight_image(w) is a
+        assert gemm.weight_image(w) is a
+    w.data.mul_(2.0)                                                           # an update the version counter does not see
+    assert torch.equal(gemm.linear_split3(x3, w), 2.0 * ref)                   # ... is seen outside the scope
+    assert gemm._frozen is None
+
+
+def test_sample_batch_builds_each_weight_image_once(monkeypatch):
+    """sample_batch opens the frozen-weights scope around its NFE loop: the converter runs once per weight and batch, not once
+    per evaluation, and the samples are bit-identical to the uncached run"""
+    from procedural import procedural_fill
+    from dimsum_amd import gemm, native
+    from dimsum_amd.models_dim import DiM
+    from dimsum_amd.sample_ddp import sample_batch
+    kw = dict(img_resolution=32, in_channels=4, label_dropout=0.15, num_classes=1000, scan_type="none", pe_type="ape",
+              block_type="combined", cond_mamba=True, rms_norm=True, fused_add_norm=True, learnable_pe=True, use_attn_every_k_layers=4)
+    m = DiM(depth=2, hidden_size=384, patch_size=2, **kw).eval()
+    procedural_fill(m, seed=3)
+    m = m.cuda()
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    z, y = torch.randn(4, 4, 32, 32, device="cuda", generator=gen), torch.tensor([1, 2, 3, 4], device="cuda")
+    monkeypatch.setenv("DIMSUM_SPLIT3_MIN_ROWS", "0")
+    old = torch.backends.cuda.matmul.allow_tf32
+    calls = {"w": 0}
+    real = native.split3_rows
+
+    def counting(t, left=True):
+        calls["w"] += (not left)
+        return real(t, left=left)
+
+    try:
+        torch.backends.cuda.matmul.allow_tf32 = True
+        monkeypatch.setattr(native, "split3_rows", counting)
+        a = sample_batch(m, z, y, num_steps=3, gather=False)
+        per_batch = calls["w"]
+        calls["w"] = 0
+
+        @__import__("contextlib").contextmanager
+        def no_scope():
+            yield
+        monkeypatch.setattr(gemm, "frozen_weights", no_scope)
+        b = sample_batch(m, z, y, num_steps=3, gather=False)
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = old
+    assert per_batch > 0 and calls["w"] == 3 * per_batch, (per_batch, calls["w"])
+    assert torch.equal(a, b)

@@ -31,11 +31,11 @@ def main():
     ap.add_argument("--no-out-z", action="store_true", help="--bwd without the out_z recompute (what dimsum_amd.ops requests: it keeps the forward's out_z)")
     ap.add_argument("--pad", type=int, default=0, help="--dmajor: extra elements in the channel stride (B*L + pad): probes L2 / HBM channel camping "
                                                        "of power-of-two strides")
-    ap.add_argument("--variant", type=int, default=-1, help="force a forward kernel: 0 = 64 channels per wave, 2 / 4 / 16 = lanes per channel (-1: automatic)")
+    ap.add_argument("--variant", type=int, default=-1, help="ask for a forward kernel: lanes per channel 1 (64 channels per wave) / 2 / 4 / 16 (0 or -1: automatic)")
     ap.add_argument("--train-fwd", action="store_true", help="time the forward's training variant (also stores the states the backward consumes)")
     a = ap.parse_args()
     from dimsum_amd import _lib
-    _lib.load().dimsum_ssm_scan_fwd_force_variant(a.variant)
+    native._scan_fwd_variant = max(a.variant, 0)          # per-call field of the C ABI (dimsum_ssm_params_t.kernel_variant)
     dt = getattr(torch, a.dtype)
     B, D, L, N = a.B, a.D, a.L, a.N
     dev = "cuda"
@@ -85,6 +85,7 @@ def main():
     med = ms[len(ms) // 2]
     P = _lib.SsmParams()
     P.batch, P.dim, P.seqlen, P.dstate, P.n_groups, P.n_chunks = B, D, L, N, 1, (L + 2047) // 2048
+    P.kernel_variant = native._scan_fwd_variant
     print(json.dumps({"kernel": "bwd" if a.bwd else "fwd", "fwd_variant": _lib.load().dimsum_ssm_scan_fwd_variant(P), "shape": [B, D, L, N], "dtype": a.dtype, "ms_median": med, "ms_min": ms[0], "algorithmic_GB": nbytes / 1e9,
                       "GBps": nbytes / med / 1e6, "frac_of_8TBps": nbytes / med / 1e6 / 8000}))
 
