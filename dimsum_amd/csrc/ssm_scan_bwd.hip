@@ -6,8 +6,8 @@
 //     dy_t  = dout_t silu(z_t)                dz_t = dout_t y_t sig(z_t) (1 + z_t (1 - sig(z_t)))     (bwd_kernel.cuh:171-207)
 //     dh_t  = e_{t+1} + C_t dy_t,  e_t = a_t dh_t   (reverse recurrence, carried as e = a dh: no seam bookkeeping)
 //     dC_t[n] = sum_d dy_t h_t[n]             dB_t[n] = sum_d dh_t[n] dt_t u_t
-//     dA[n]  += dh_t[n] dt_t (a_t h_{t-1})[n]                       with a_t h_{t-1} = h_t - b_t     (bwd_kernel.cuh:289)
-//     ddt_t  = u_t s1_t + s2_t,  s1 = sum_n dh B,  s2 = sum_n dh A (h_t - b_t);   ddelta = ddt * sigmoid(delta+bias)  (:439-452)
+//     dA[n]  += dh_t[n] dt_t (a_t h_{t-1})[n] = dt_t e_t[n] h_{t-1}[n]                                  (bwd_kernel.cuh:289)
+//     ddt_t  = u_t s1_t + s2_t,  s1 = sum_n dh B,  s2 = sum_n A e_t h_{t-1};   ddelta = ddt * sigmoid(delta+bias)  (:439-452)
 //     du_t   = dt_t s1_t + D dy_t             dD += dy_t u_t        ddelta_bias += ddelta_t
 //
 // MI355X design. lane = (channel, state quarter): a wave64 owns 16 channels of one batch element, DPP row q (16 lanes)
@@ -19,8 +19,8 @@
 //     states are requested one whole half (~1 us of VALU work) before they are needed;
 //   * 32-step tiles (128-B row segments: every HBM line is fetched exactly once) are walked backwards as four 8-step
 //     halves. With dstate 16 a lane's 4 states x 8 steps are ONE register sweep: the forward sweep keeps h_t AND
-//     a_t = exp2(dt_t A) in 2 x 32 VGPRs, the reverse sweep runs over the same registers (a_t h_{t-1} = h_t - b_t: no
-//     division, no second v_exp_f32): 3 + 1 exp VALU ops per (t, n) forward, 8 backward. Nothing per-(t, n) touches memory;
+//     a_t = exp2(dt_t A) in 2 x 32 VGPRs, the reverse sweep runs over the same registers (dh_t a_t h_{t-1} = e_t h_{t-1}
+//     with h_{t-1} still in its register: no division, no second v_exp_f32): 3 + 1 exp VALU ops per (t, n) forward, 7 backward. Nothing per-(t, n) touches memory;
 //   * sums over the states of a channel (s1, s2) are lane-local over dstate/4 states, then a TRANSPOSED exchange over the
 //     4 quarters (v_permlane32_swap, v_permlane16_swap: 12 swaps + 12 adds per half) leaves quarter q with the totals of
 //     steps 2q, 2q+1 only -- so each lane finishes du / ddelta (softplus chain) for 2 of the 8 steps instead of all of them;
@@ -130,6 +130,23 @@ template <typename Gen> __device__ __forceinline__ void transposed_reduce_row32_
     r[1] = v[1];
 }
 
+// The same for values that are PRODUCTS y[i & 7] * h[i] (dC): the partner's product dpp(y h) = dpp(y) * dpp(h), and dpp(y) is
+// one of only 8 values per lane (yp), so the first level is  v = fma(dpp(h[i + 16]), yp[i & 7], y[i & 7] * h[i])  -- a v_mul
+// and a v_fmac with a DPP source instead of two v_mul, a v_mov_dpp and a v_add per output.
+__device__ __forceinline__ void transposed_reduce_row32_perm_prod(const float (&y)[8], const float (&h)[32], int lane, float (&r)[2]) {
+    float yp[8], v[16];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) yp[t] = dpp<0x128>(y[t]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = fmaf(dpp<0x128>(h[i + 16]), yp[i & 7], y[i & 7] * h[i]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += dpp<0x141>(v[i + 8]);
+    reduce_level<0x4E, 8>(v, lane & 2);
+    reduce_level<0xB1, 4>(v, lane & 1);
+    r[0] = v[0];
+    r[1] = v[1];
+}
+
 // sigmoid(x) for dt = softplus(x) = log(1 + e^x):  sigmoid(x) = 1 - exp(-dt)  (for x > 20 the reference takes dt = x and
 // a derivative of 1: 1 - exp(-20) rounds to 1). Small dt: alternating series (the direct form cancels).
 __device__ __forceinline__ float dsoftplus_from_dt(float dt) {
@@ -149,12 +166,21 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
     constexpr int kNPc = kBC / 8;                 // 16-byte pieces per lane of a 16 x 32 tile (a piece = 8 rows x 128 B)
     static_assert(kN % kBQ == 0 && kNL % kBG == 0 && (NV == 32 || NV == 16 || NV == 8), "dstate must be 4, 8, 16 or 32");
     const dimsum_ssm_params_t &p = q.fwd;
-    __shared__ __attribute__((aligned(16))) float sU[kBW][kBC * kBT], sD[kBW][kBC * kBT], sY[kBW][kBC * kBT];   // u, dt (softplus'ed), dy
-    __shared__ __attribute__((aligned(16))) float sdB[kBW][kN * kDS], sdC[kBW][kN * kDS];                      // a wave's dB / dC sums of the tile
-    __shared__ __attribute__((aligned(16))) float tB[kN * kBCS], tC[kN * kBCS];                                // shared by the 4 waves
+    // ONE LDS block: [u | dt (softplus'ed) | dy] per wave, [a wave's dB | dC sums of the tile] per wave, [B | C] shared by the 4 waves.
+    // The sweeps address it with byte offsets: the same per-lane offset serves u, dt and dy (constant distances = immediate offsets of
+    // the ds instructions), and the 16-byte slot index of a half tile enters by one XOR (btile_off: the row bases have no bits below 128).
+    constexpr int kTile = kBC * kBT, kSums = kN * kDS;
+    constexpr unsigned kOffD = 4u * kBW * kTile, kOffY = 8u * kBW * kTile;                      // dt, dy tiles relative to the u tile (bytes)
+    constexpr unsigned kOffB = 4u * (3 * kBW * kTile + 2 * kBW * kSums), kOffC = kOffB + 4u * kN * kBCS;   // B, C tiles (bytes)
+    __shared__ __attribute__((aligned(16))) float smem[3 * kBW * kTile + 2 * kBW * kSums + 2 * kN * kBCS];
+    float(*const sdB)[kSums] = reinterpret_cast<float(*)[kSums]>(smem + 3 * kBW * kTile);
+    float(*const sdC)[kSums] = reinterpret_cast<float(*)[kSums]>(smem + 3 * kBW * kTile + kBW * kSums);
+    float *const tB = smem + kOffB / 4, *const tC = smem + kOffC / 4;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & (kBC - 1), sh = lane >> 4;
-    float *tU = sU[wave], *tD = sD[wave], *tY = sY[wave], *tdB = sdB[wave], *tdC = sdC[wave];
+    float *tU = smem + wave * kTile, *tD = tU + kBW * kTile, *tY = tD + kBW * kTile, *tdB = sdB[wave], *tdC = sdC[wave];
+    auto lds4 = [&](unsigned off) -> const f32x4 & { return *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(smem) + off); };
+    const unsigned ubase = 4u * (unsigned)(wave * kTile + btile_off(c, 0));       // u4 of 4-step slot j of this lane's row: ubase ^ (j << 4)
     const int ns0 = sh * kNL;                     // first state of this lane
     const int L = p.seqlen;
     const int dpg = p.dim / p.n_groups;
@@ -199,6 +225,12 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
     int sidx[kNL], brow[kNL];                     // state index of slot j (relative to ns0); its row offset in tB / tC
 #pragma unroll
     for (int k = 0; k < kNL; ++k) { sidx[k] = k ^ kperm; brow[k] = (ns0 + sidx[k]) * kBCS; }
+    unsigned bbyte[kNL];                          // byte offset of slot k's B row in smem (C row: + kOffC - kOffB)
+#pragma unroll
+    for (int k = 0; k < kNL; ++k) bbyte[k] = kOffB + 4u * (unsigned)brow[k];
+    // this lane's 2 steps of a half in the per-(d, t) epilogue: columns 2 q, 2 q + 1 of the half (q = sh)
+    const unsigned ebase = ubase ^ ((unsigned)(sh >> 1) << 4) ^ ((unsigned)(sh & 1) << 3);
+    const unsigned sums_base = 4u * (unsigned)((3 * kBW * kTile) + wave * kSums + (ns0 + (c >> 2)) * kDS + 2 * (c & 3));   // NV == 32 layout
     // per-lane constants and carries, all in registers (only ever indexed with compile-time constants)
     float A2[kNL], re[kNL], rdA[kNL];             // A log2 e; e = a_{t+1} dh_{t+1} carried across halves; dA accumulators
     {
@@ -228,10 +260,10 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
     for (int k = 0; k < kNL; ++k) hpre[k] = wave_live ? ck_lane[((int64_t)(n_halves - 1) * kN + sidx[k]) * ck_ns] : 0.f;
 
     // Register-staged prefetch (vector path): the next tile's delta rows -- the operand with the longest dependent chain behind
-    // it (softplus) -- are requested right after the current tile has been staged, so they fly under the tile's sweeps; the
-    // register budget (256 VGPRs at 2 waves per SIMD) has no room for more: also prefetching u costs 104 B of scratch per
-    // lane and 8 % (measured). Branch-free: rows beyond nd are clamped to the last live row, columns beyond L to the last
-    // 4-column group; the masks are applied when the registers are staged.
+    // it (softplus) -- and its u rows are requested right after the current tile has been staged, so they fly under the tile's
+    // sweeps (16 VGPRs; the kernel sits at 239 of the 256 that 2 waves per SIMD allow, no scratch). dout / z / out are requested
+    // where they are staged. Branch-free: rows beyond nd are clamped to the last live row, columns beyond L to the last 4-column
+    // group; the masks are applied when the registers are staged.
     Raw4<T> pu[kNPc], pd[kNPc], pg[kNPc], pz[kNPc], py[kNPc];
     auto tile_addr = [&](const T *base, int ds, int i, int col) -> const T * {
         if constexpr (kFull) return at(base + i * 8 * ds, (unsigned)(lrow * ds + col));
@@ -240,13 +272,12 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
     auto issue_d = [&](int t0n) {
         const int col = min(t0n + lcol, L - 4);
 #pragma unroll
-        for (int i = 0; i < kNPc; ++i) pd[i] = ld4<T>(tile_addr(dl_base, dl_ds, i, col));
+        for (int i = 0; i < kNPc; ++i) { pd[i] = ld4<T>(tile_addr(dl_base, dl_ds, i, col)); pu[i] = ld4<T>(tile_addr(u_base, u_ds, i, col)); }
     };
     auto issue_rest = [&](int t0n) {
         const int col = min(t0n + lcol, L - 4);
 #pragma unroll
         for (int i = 0; i < kNPc; ++i) {
-            pu[i] = ld4<T>(tile_addr(u_base, u_ds, i, col));
             pg[i] = ld4<T>(tile_addr(do_base, do_ds, i, col));
             if constexpr (kHasZ) { pz[i] = ld4<T>(tile_addr(z_base, z_ds, i, col)); py[i] = ld4<T>(tile_addr(y_base, y_ds, i, col)); }
         }
@@ -362,6 +393,13 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
                 float s1[kBS], s2[kBS];
 #pragma unroll
                 for (int t = 0; t < kBS; ++t) { s1[t] = 0.f; s2[t] = 0.f; }
+                // byte offsets of the half's two 4-step slots of this lane's u row (dt: + kOffD, dy: + kOffY) and of its B rows
+                const unsigned hx = (unsigned)half << 5;
+                const unsigned uo[2] = {ubase ^ hx, ubase ^ (hx | 16u)};
+                static_assert(kBS == 8, "two 4-step slots per half");
+                unsigned bb[kNL];
+#pragma unroll
+                for (int k = 0; k < kNL; ++k) bb[k] = bbyte[k] + hx;
 
                 // one register sweep over kBG states x kBS steps per iteration (ONE iteration up to dstate 16). With two groups
                 // (dstate 32) the loop stays rolled: one copy of the body, uniform selects on statically indexed register arrays
@@ -383,18 +421,21 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
                             Ak[k] = (G == gq) ? A2[gq * kBG + k] : Ak[k];
                         }
                     }
+                    float hin[kBG];                           // h before the half's first step (the reverse sweep's h_{t-1} at t = 0)
+#pragma unroll
+                    for (int k = 0; k < kBG; ++k) hin[k] = hk[k];
                     const int nrow = ns0 + n0;                // row of the group's first state in tB / tC / tdB / tdC
                     // ---- forward sweep: h_t, a_t for the 8 steps of the half ---------------------------------------------------
 #pragma unroll
                     for (int jj = 0; jj < kBS / 4; ++jj) {
-                        const f32x4 u4 = *reinterpret_cast<const f32x4 *>(&tU[btile_off(c, jb + jj)]);
-                        const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&tD[btile_off(c, jb + jj)]);
+                        const f32x4 u4 = lds4(uo[jj]);
+                        const f32x4 d4 = lds4(uo[jj] + kOffD);
                         float du[4];
 #pragma unroll
                         for (int s = 0; s < 4; ++s) du[s] = d4.v[s] * u4.v[s];
 #pragma unroll
                         for (int k = 0; k < kBG; ++k) {
-                            const f32x4 bq = *reinterpret_cast<const f32x4 *>(&tB[(kPerm ? brow[k] : (nrow + k) * kBCS) + (jb + jj) * 4]);
+                            const f32x4 bq = kPerm ? lds4(bb[k] + 16u * jj) : *reinterpret_cast<const f32x4 *>(&tB[(nrow + k) * kBCS + (jb + jj) * 4]);
 #pragma unroll
                             for (int s = 0; s < 4; ++s) {
                                 const float a = fast_exp2(d4.v[s] * Ak[k]);
@@ -409,15 +450,16 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
                         float y8[kBS];
 #pragma unroll
                         for (int jj = 0; jj < kBS / 4; ++jj) {
-                            const f32x4 y4 = *reinterpret_cast<const f32x4 *>(&tY[btile_off(c, jb + jj)]);
+                            const f32x4 y4 = lds4(uo[jj] + kOffY);
 #pragma unroll
                             for (int s = 0; s < 4; ++s) y8[jj * 4 + s] = y4.v[s];
                         }
                         float r[2];
-                        if constexpr (kPerm) transposed_reduce_row32_perm([&](int i) { return y8[i & (kBS - 1)] * H[i]; }, lane, r);
+                        if constexpr (kPerm) transposed_reduce_row32_perm_prod(y8, H, lane, r);
                         else transposed_reduce_row<NV>([&](int i) { return y8[i & (kBS - 1)] * H[i]; }, lane, r);
                         if constexpr (NV == 32) {
-                            *reinterpret_cast<float2 *>(&tdC[(nrow + (c >> 2)) * kDS + half * kBS + 2 * (c & 3)]) = make_float2(r[0], r[1]);
+                            if constexpr (kPerm) *reinterpret_cast<float2 *>(reinterpret_cast<char *>(smem) + (sums_base + 4u * kBW * kSums + hx)) = make_float2(r[0], r[1]);
+                            else *reinterpret_cast<float2 *>(&tdC[(nrow + (c >> 2)) * kDS + half * kBS + 2 * (c & 3)]) = make_float2(r[0], r[1]);
                         } else if constexpr (NV == 16) {
                             tdC[(nrow + (c >> 3)) * kDS + half * kBS + (c & 7)] = r[0];
                         } else {
@@ -427,23 +469,23 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
                     // ---- reverse sweep ---------------------------------------------------------------------------------------------
 #pragma unroll
                     for (int jj = kBS / 4 - 1; jj >= 0; --jj) {
-                        const f32x4 u4 = *reinterpret_cast<const f32x4 *>(&tU[btile_off(c, jb + jj)]);
-                        const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&tD[btile_off(c, jb + jj)]);
-                        const f32x4 y4 = *reinterpret_cast<const f32x4 *>(&tY[btile_off(c, jb + jj)]);
+                        const f32x4 u4 = lds4(uo[jj]);
+                        const f32x4 d4 = lds4(uo[jj] + kOffD);
+                        const f32x4 y4 = lds4(uo[jj] + kOffY);
                         float du[4];
 #pragma unroll
                         for (int s = 0; s < 4; ++s) du[s] = d4.v[s] * u4.v[s];
 #pragma unroll
                         for (int k = 0; k < kBG; ++k) {
-                            const f32x4 bq = *reinterpret_cast<const f32x4 *>(&tB[(kPerm ? brow[k] : (nrow + k) * kBCS) + (jb + jj) * 4]);
-                            const f32x4 cq = *reinterpret_cast<const f32x4 *>(&tC[(kPerm ? brow[k] : (nrow + k) * kBCS) + (jb + jj) * 4]);
+                            const f32x4 bq = kPerm ? lds4(bb[k] + 16u * jj) : *reinterpret_cast<const f32x4 *>(&tB[(nrow + k) * kBCS + (jb + jj) * 4]);
+                            const f32x4 cq = kPerm ? lds4(bb[k] + 16u * jj + (kOffC - kOffB)) : *reinterpret_cast<const f32x4 *>(&tC[(nrow + k) * kBCS + (jb + jj) * 4]);
 #pragma unroll
                             for (int s = 3; s >= 0; --s) {
                                 const int t = jj * 4 + s;
                                 const float dhn = fmaf(cq.v[s], y4.v[s], ek[k]);            // dh_t = a_{t+1} dh_{t+1} + C_t dy_t
-                                ek[k] = AE[k * kBS + t] * dhn;
-                                const float ah = fmaf(-bq.v[s], du[s], H[k * kBS + t]);     // a_t h_{t-1} = h_t - b_t
-                                const float gterm = dhn * ah;
+                                ek[k] = AE[k * kBS + t] * dhn;                              // e_t = a_t dh_t
+                                // dh_t (a_t h_{t-1}) = e_t h_{t-1}: h_{t-1} still sits in H (the sweep runs backwards), no h_t - b_t
+                                const float gterm = ek[k] * (t == 0 ? hin[k] : H[k * kBS + (t > 0 ? t - 1 : 0)]);
                                 dAk[k] = fmaf(gterm, d4.v[s], dAk[k]);
                                 s2[t] = fmaf(gterm, Ak[k], s2[t]);
                                 s1[t] = fmaf(dhn, bq.v[s], s1[t]);
@@ -464,7 +506,8 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
                         if constexpr (kPerm) transposed_reduce_row32_perm([&](int i) { return H[i]; }, lane, r);
                         else transposed_reduce_row<NV>([&](int i) { return H[i]; }, lane, r);
                         if constexpr (NV == 32) {
-                            *reinterpret_cast<float2 *>(&tdB[(nrow + (c >> 2)) * kDS + half * kBS + 2 * (c & 3)]) = make_float2(r[0], r[1]);
+                            if constexpr (kPerm) *reinterpret_cast<float2 *>(reinterpret_cast<char *>(smem) + (sums_base + hx)) = make_float2(r[0], r[1]);
+                            else *reinterpret_cast<float2 *>(&tdB[(nrow + (c >> 2)) * kDS + half * kBS + 2 * (c & 3)]) = make_float2(r[0], r[1]);
                         } else if constexpr (NV == 16) {
                             tdB[(nrow + (c >> 3)) * kDS + half * kBS + (c & 7)] = r[0];
                         } else {
@@ -484,7 +527,7 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
                     float val[16];
 #pragma unroll
                     for (int jj = 0; jj < kBS / 4; ++jj) {
-                        const f32x4 u4 = *reinterpret_cast<const f32x4 *>(&tU[btile_off(c, jb + jj)]);
+                        const f32x4 u4 = lds4(uo[jj]);
 #pragma unroll
                         for (int s = 0; s < 4; ++s) {
                             const int t = jj * 4 + s;
@@ -499,10 +542,10 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
                     for (int j = 0; j < 4; ++j) { float x = w[j], y = w[j + 4]; swap16(x, y); z4[j] = x + y; }      // even rows keep w[j], odd rows w[j + 4]
                 }
                 {
-                    const int off = btile_off(c, jb + (sh >> 1)) + (sh & 1) * 2;       // columns half * 8 + 2 q, + 1 of row c
-                    const float2 u2 = *reinterpret_cast<const float2 *>(&tU[off]);
-                    const float2 d2 = *reinterpret_cast<const float2 *>(&tD[off]);
-                    const float2 y2 = *reinterpret_cast<const float2 *>(&tY[off]);
+                    char *const eo = reinterpret_cast<char *>(smem) + (ebase ^ hx);      // columns half * 8 + 2 q, + 1 of row c
+                    const float2 u2 = *reinterpret_cast<const float2 *>(eo);
+                    const float2 d2 = *reinterpret_cast<const float2 *>(eo + kOffD);
+                    const float2 y2 = *reinterpret_cast<const float2 *>(eo + kOffY);
                     // dead steps (t >= L) have dt = 0 -> factor 0 with softplus; without it they carry u = dy = 0 -> ddt = 0
                     float dsp0 = dsoftplus_from_dt(d2.x), dsp1 = dsoftplus_from_dt(d2.y);
                     asm volatile("" : "+v"(dsp0), "+v"(dsp1));
@@ -510,8 +553,8 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
                     const float dd0 = softplus ? z4[1] * dsp0 : z4[1], dd1 = softplus ? z4[3] * dsp1 : z4[3];
                     dD = fmaf(y2.x, u2.x, fmaf(y2.y, u2.y, dD));
                     dbias += dd0 + dd1;
-                    *reinterpret_cast<float2 *>(&tU[off]) = make_float2(du0, du1);
-                    *reinterpret_cast<float2 *>(&tY[off]) = make_float2(dd0, dd1);
+                    *reinterpret_cast<float2 *>(eo) = make_float2(du0, du1);
+                    *reinterpret_cast<float2 *>(eo + kOffY) = make_float2(dd0, dd1);
                 }
             }
 

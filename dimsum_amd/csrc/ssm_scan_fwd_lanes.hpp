@@ -36,10 +36,10 @@ template <typename T, bool kHasZ, bool kVec, bool kFull, bool kCkpt = false>
 __global__ __launch_bounds__(kWave, 4) void ssm_scan_fwd_lanes_kernel(const dimsum_ssm_params_t p) {
     static_assert(!kFull || kVec, "kFull implies kVec");
     constexpr int kN = 16;
-    __shared__ __attribute__((aligned(16))) float tileU[kLC * kLT];   // dt * u, then y in place
-    __shared__ __attribute__((aligned(16))) float tileD[kLC * kLT];   // dt
-    __shared__ __attribute__((aligned(16))) float tileB[kN * kLT];
-    __shared__ __attribute__((aligned(16))) float tileC[kN * kLT];
+    // one LDS block [dt * u (then y in place) | dt | B | C]: the sequential loop addresses it with byte offsets formed by ONE
+    // v_xor per operand pair (the 16-byte slot index enters lt_off / bc_off by XOR and the row bases have no bits below 256)
+    __shared__ __attribute__((aligned(16))) float smem[2 * kLC * kLT + 2 * kN * kLT];
+    float *const tileU = smem, *const tileD = smem + kLC * kLT, *const tileB = smem + 2 * kLC * kLT, *const tileC = tileB + kN * kLT;
 
     const int lane = threadIdx.x;
     const int c = (lane >> 2) & 3;                         // channel of the wave's 4
@@ -169,14 +169,19 @@ __global__ __launch_bounds__(kWave, 4) void ssm_scan_fwd_lanes_kernel(const dims
         // ---- 64 sequential steps in 4 groups of 16; per step and lane: mul, v_exp_f32, mul, fma, mul. The operands of the next 4
         //      steps are requested from LDS before the current 4 are computed (also across the join below) ----------------------
         struct Ops { f32x4 du, dt, b, c; };
+        auto lds4 = [&](unsigned off) -> const f32x4 & { return *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(smem) + off); };
+        const unsigned ub = 4u * (unsigned)lt_off(c, 0), bb = 4u * (unsigned)(2 * kLC * kLT + bc_off(n, 0));
         auto fetch = [&](int col4) {
+            const unsigned cx = (unsigned)col4 << 4;
             Ops o;
-            o.du = *reinterpret_cast<const f32x4 *>(&tileU[lt_off(c, col4)]);
-            o.dt = *reinterpret_cast<const f32x4 *>(&tileD[lt_off(c, col4)]);
-            o.b = *reinterpret_cast<const f32x4 *>(&tileB[bc_off(n, col4)]);
-            o.c = *reinterpret_cast<const f32x4 *>(&tileC[bc_off(n, col4)]);
+            o.du = lds4(ub ^ cx);
+            o.dt = lds4((ub ^ cx) + 4u * kLC * kLT);
+            o.b = lds4(bb ^ cx);
+            o.c = lds4((bb ^ cx) + 4u * kN * kLT);
             return o;
         };
+        // the slot lane (c, n) writes its finished y of a 16-step group to: step n of the group = column 4 (gq * 4 + n / 4) + n % 4
+        const unsigned yb = 4u * (unsigned)(lt_off(c, n >> 2) + (n & 3));
         Ops nxt = fetch(0);
 #pragma unroll 1
         for (int gq = 0; gq < kLT / 16; ++gq) {
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(kWave, 4) void ssm_scan_fwd_lanes_kernel(const dims
                 const bool hi = lane & 1;                                                       // state bit 0
                 y[0] = (hi ? y[1] : y[0]) + lanes_dpp<0xB1>(hi ? y[0] : y[1]);
             }
-            tileU[lt_off(c, gq * 4 + (n >> 2)) + (n & 3)] = y[0];
+            *reinterpret_cast<float *>(reinterpret_cast<char *>(smem) + (yb ^ ((unsigned)gq << 6))) = y[0];
         }
 
         // ---- chunk-state store at every 2048 boundary and at the end (selective_scan_fwd_kernel.cuh:251-254) ---
