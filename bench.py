@@ -60,9 +60,12 @@ def usable_cores():
     return n
 
 
-def scan_bytes(B, D, L, N, G=1, s=4):
-    """5 B D L s + 2 B G N L s + B D ceil(L/2048) 2N 4 + (D N + 2 D) 4"""
-    return 5 * B * D * L * s + 2 * B * G * N * L * s + B * D * ((L + 2047) // 2048) * 2 * N * 4 + (D * N + 2 * D) * 4
+def scan_bytes(B, D, L, N, G=1, s=4, has_out=True, has_x=True):
+    """5 B D L s + 2 B G N L s + B D ceil(L/2048) 2N 4 + (D N + 2 D) 4 for the full interface (reads u, delta, z,
+    B, C, A, D, delta_bias; writes out, out_z, x). A launch that skips the `out` / `x` stores (inference: out_ptr / x_ptr NULL)
+    is priced with what it moves: one B D L s term / the chunk-state term less -- 8(d)'s "inference-only lower bound" 1.082 GB."""
+    return ((5 if has_out else 4) * B * D * L * s + 2 * B * G * N * L * s + (B * D * ((L + 2047) // 2048) * 2 * N * 4 if has_x else 0)
+            + (D * N + 2 * D) * 4)
 
 
 def scan_bwd_bytes(B, D, L, N, G=1, s=4, recompute_out_z=True):
@@ -108,7 +111,8 @@ class ScanTimer:
                     return fn(P, stream)
                 p = P.fwd if which == "bwd" else P
                 if which == "fwd":
-                    kernel = _lib.SCAN_FWD_KERNELS[lib.dimsum_ssm_scan_fwd_variant(p)] + (" (+ saved states)" if p.ckpt_ptr else "")
+                    kernel = (_lib.SCAN_FWD_KERNELS[lib.dimsum_ssm_scan_fwd_variant(p)] + (" (+ saved states)" if p.ckpt_ptr else "")
+                              + ("" if (p.out_ptr and p.x_ptr) else " (inference: no out / x stores)"))
                 else:
                     kernel = "ssm_scan_bwd_kernel (+ ssm_scan_bwd_reduce_kernel)" + ("" if p.out_z_ptr else ", no out_z recompute")
                 # HIP events recorded at the begin of the call's first kernel and the end of its last one (the per-call
@@ -128,7 +132,7 @@ class ScanTimer:
                 s = {_lib.F32: 4}.get(p.dtype, 2)
                 shape = (p.batch, p.dim, p.seqlen, p.dstate)
                 nbytes = (scan_bwd_bytes(*shape, p.n_groups, s, recompute_out_z=bool(p.out_z_ptr)) if which == "bwd"
-                          else scan_bytes(*shape, p.n_groups, s))
+                          else scan_bytes(*shape, p.n_groups, s, has_out=bool(p.out_ptr), has_x=bool(p.x_ptr)))
                 timer.records[which].append((e0, e1, nbytes, shape, kernel))
                 return rc
 
@@ -531,6 +535,8 @@ def main():
         line.update(extras)
         if world == 1 and not args.no_cpu_baseline and args.mode in ("all", "fwd", "sample"):
             line["cpu_baseline"] = cpu_baseline(args.model, 4, args.image_size)
+            if args.mode == "all":      # BASELINE configs[0], SURVEY 8(d): DiM-S/2, batch 4 on the same host cores
+                line["cpu_baseline"]["config0_S2_batch4"] = cpu_baseline("DiM-S/2", 4, args.image_size)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier(device_ids=[b.local_rank])     # nobody tears the communicator down while rank 0 is still reporting

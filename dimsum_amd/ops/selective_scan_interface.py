@@ -142,8 +142,13 @@ class _MambaInner(torch.autograd.Function):
         # the tile-boundary states ride along to the backward (one activation tensor): it then needs no sweep of
         # its own to rebuild them. They depend on (conv_out, delta, A, B) only, which the backward recomputes identically.
         need = need_ckpt        # decided by the caller (grad mode is off in here)
+        # `out` (ungated) and the chunk states `x` only serve the backward. The reference's kernel always stores them
+        # (selective_scan_fwd_kernel.cuh:239-254) and so does this call by default -- SURVEY 8(d) prices the launch with them.
+        # DIMSUM_SCAN_INFER_STORES=0 skips both at inference (1.082 instead of 1.384 GB per launch at DiM-L/2, batch 256:
+        # measured 0.320 -> 0.298 ms in the model, i.e. -22 % bytes buy -7 % time: the kernel is not bound by HBM alone).
+        keep = need or os.environ.get("DIMSUM_SCAN_INFER_STORES", "1") != "0"
         out, scan_x, out_z, *rest = native.selective_scan_fwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus,
-                                                              need_ckpt=need)
+                                                              need_out=keep, need_x=keep, need_ckpt=need)
         ckpt = rest[0] if need else None
         ctx.delta_softplus, ctx.has_out_proj, ctx.checkpoint_lvl = delta_softplus, has_out_proj, checkpoint_lvl
         ctx.flags = (conv1d_bias is not None, D is not None, delta_bias is not None, B_proj_bias is not None,

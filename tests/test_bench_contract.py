@@ -23,6 +23,8 @@ def test_algorithmic_bytes_match_survey_8d():
     assert b.scan_bwd_bytes(256, 1024, 256, 16, recompute_out_z=False) == 2466324480 - 256 * 1024 * 256 * 4 == 2197889024
     # half-precision I/O halves the activation terms only; two 2048-chunks double the chunk-state term
     assert b.scan_bytes(2, 64, 4096, 16, s=2) == 5 * 2 * 64 * 4096 * 2 + 2 * 2 * 16 * 4096 * 2 + 2 * 64 * 2 * 32 * 4 + (64 * 16 + 128) * 4
+    # a launch without the `out` / `x` stores (the model's inference calls) is priced with what it moves: 8(d)'s 1.082 GB
+    assert b.scan_bytes(256, 1024, 256, 16, has_out=False, has_x=False) == 4 * 256 * 1024 * 256 * 4 + 2 * 256 * 16 * 256 * 4 + (1024 * 16 + 2048) * 4 == 1082204160
     assert b.HBM_PEAK_GBPS == 8000.0
 
 

@@ -26,12 +26,15 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dtype", default="float32")
     ap.add_argument("--dmajor", action="store_true", help="u and z d-major too, exactly like inside MambaInnerFn (xz = in_proj GEMM view)")
+    ap.add_argument("--contig", action="store_true", help="every activation (u, delta, z, out, dout) contiguous (B, D, L): the layout probe "
+                                                          "against MambaInnerFn's d-major tensors (channel stride B * L)")
     ap.add_argument("--bwd", action="store_true", help="time selective_scan_bwd (with the saved states of the forward)")
     ap.add_argument("--no-ckpt", action="store_true", help="--bwd without saved states: the kernel pair of the reference-shaped call")
     ap.add_argument("--no-out-z", action="store_true", help="--bwd without the out_z recompute (what dimsum_amd.ops requests: it keeps the forward's out_z)")
     ap.add_argument("--pad", type=int, default=0, help="--dmajor: extra elements in the channel stride (B*L + pad): probes L2 / HBM channel camping "
                                                        "of power-of-two strides")
     ap.add_argument("--variant", type=int, default=-1, help="ask for a forward kernel: lanes per channel 1 (64 channels per wave) / 2 / 4 / 16 (0 or -1: automatic)")
+    ap.add_argument("--infer", action="store_true", help="forward as the model calls it at inference: no `out` / `x` stores (1.082 GB at the default shape)")
     ap.add_argument("--train-fwd", action="store_true", help="time the forward's training variant (also stores the states the backward consumes)")
     a = ap.parse_args()
     from dimsum_amd import _lib
@@ -57,6 +60,12 @@ def main():
         xz = dm(torch.randn(2 * D, B, L, device=dev, dtype=dt))                      # strides (L, B L, 1)
         z = xz.chunk(2, 1)[1]
         u = dm(u.permute(1, 0, 2).contiguous())                                      # conv_out = empty_like(x): d-major
+    if a.contig:
+        delta = delta.contiguous()
+        xz = torch.randn(B, 2 * D, L, device=dev, dtype=dt)
+        z = xz.chunk(2, 1)[1]
+        u = torch.randn(B, D, L, device=dev, dtype=dt)
+        dm = lambda t: t.permute(1, 0, 2).contiguous()      # noqa: E731  (dout below)
     if a.bwd:
         out, x, out_z, ckpt = native.selective_scan_fwd(u, delta, A, Bm, Cm, Dv, z, bias, True, need_ckpt=True)
         dout = dm(torch.randn(D, B, L, device=dev).to(dt))
@@ -70,8 +79,8 @@ def main():
         nbytes = (8 if a.no_out_z else 9) * B * D * L * s_ + 2 * B * N * L * (s_ + 4) + B * D * ((L + 2047) // 2048) * 2 * N * 4 + (D * N + 2 * D) * 4
     else:
         def call():
-            return native.selective_scan_fwd(u, delta, A, Bm, Cm, Dv, z, bias, True, need_ckpt=a.train_fwd)
-        nbytes = scan_bytes(B, D, L, N, 1, u.element_size())
+            return native.selective_scan_fwd(u, delta, A, Bm, Cm, Dv, z, bias, True, need_out=not a.infer, need_x=not a.infer, need_ckpt=a.train_fwd)
+        nbytes = scan_bytes(B, D, L, N, 1, u.element_size()) - ((B * D * L * u.element_size() + B * D * ((L + 2047) // 2048) * 2 * N * 4) if a.infer else 0)
     for _ in range(3):
         call()
     torch.cuda.synchronize()

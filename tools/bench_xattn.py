@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--hd", type=int, default=64)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--exact", action="store_true", help="exact fp32 MFMA kernel instead of the split-bf16 one")
+    ap.add_argument("--bwd", action="store_true", help="time the backward pair (xattn_bwd_dq + xattn_bwd_dkv) instead of the forward")
     ap.add_argument("--split3", action="store_true", help="write the output as the split-bf16 operand image of the proj Linear")
     a = ap.parse_args()
     W = 3 * a.heads * a.hd
@@ -27,6 +28,10 @@ def main():
     q1, q2 = torch.randn(a.B, a.L, W, device="cuda", generator=g), torch.randn(a.B, a.L, W, device="cuda", generator=g)
     b1, b2 = torch.randn(W, device="cuda", generator=g), torch.randn(W, device="cuda", generator=g)
     f = lambda: native.xattn_fusion_fwd(q1, q2, a.heads, bias1=b1, bias2=b2, split_bf16=not a.exact, split3=a.split3)
+    if a.bwd:
+        out, lse = native.xattn_fusion_fwd(q1, q2, a.heads, need_lse=True, bias1=b1, bias2=b2, split_bf16=not a.exact)
+        dout = torch.randn(out.shape, device="cuda", generator=g)
+        f = lambda: native.xattn_fusion_bwd(q1, q2, out, lse, dout, a.heads, bias1=b1, bias2=b2, split_bf16=not a.exact)
     for _ in range(3):
         f()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.iters + 1)]
@@ -36,9 +41,9 @@ def main():
         ev[i + 1].record()
     torch.cuda.synchronize()
     ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.iters))
-    flop = 2 * 4 * a.B * a.heads * a.L * a.L * a.hd
+    flop = 2 * 4 * a.B * a.heads * a.L * a.L * a.hd * (3.5 if a.bwd else 1.0)      # backward: 3 + 4 GEMM-equivalents against the forward's 2
     med = ms[len(ms) // 2]
-    print(json.dumps({"kernel": "xattn_fwd" + ("" if not a.exact else "_exact") + ("_split3" if a.split3 else ""), "shape": [a.B, a.L, a.heads, a.hd], "ms_median": med, "ms_min": ms[0],
+    print(json.dumps({"kernel": ("xattn_bwd" if a.bwd else "xattn_fwd") + ("" if not a.exact else "_exact") + ("_split3" if a.split3 else ""), "shape": [a.B, a.L, a.heads, a.hd], "ms_median": med, "ms_min": ms[0],
                       "GFLOP": flop / 1e9, "TFLOPs_equivalent": flop / med / 1e9}))
 
 

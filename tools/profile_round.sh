@@ -20,9 +20,14 @@ for r in rows:
 P
   tail -1 $out/${name}.log | cut -c1-300
 }
+# the headline forward twice: as shipped (two HIP streams per block: overlapped kernels, the wall time) and on ONE stream
+# (DIMSUM_BRANCH_STREAMS=0: per-kernel durations that mean something -- this is what bench.py's single-stream roofline pass times)
+stats fwd2s --mode fwd --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg
+export DIMSUM_BRANCH_STREAMS=0
 stats fwd --mode fwd --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg
 stats block --mode block --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg
 stats xl512 --mode xl512 --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg
+unset DIMSUM_BRANCH_STREAMS
 stats all --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg --nfe 10
 # PMC: forward (inference), forward + saved states, backward (as dimsum_amd.ops calls it: no out_z recompute; and with it), config-5 forward,
 # the long-sequence stress shape (one lane per state)
@@ -32,5 +37,7 @@ bash tools/pmc_scan.sh $out/pmc_bwd --dmajor --bwd --no-out-z > $out/${tag}_scan
 bash tools/pmc_scan.sh $out/pmc_bwd_oz --dmajor --bwd > $out/${tag}_scan_bwd_outz_pmc.txt 2>&1
 bash tools/pmc_scan.sh $out/pmc_fwd_xl --dmajor --B 64 --D 1152 --L 1024 > $out/${tag}_scan_fwd_xl512_pmc.txt 2>&1
 bash tools/pmc_scan.sh $out/pmc_fwd_stress --dmajor --B 16 --D 1152 --L 4096 > $out/${tag}_scan_fwd_stress_pmc.txt 2>&1
+bash tools/scratch/xattn_pmc.sh fwd > $out/${tag}_xattn_fwd_pmc.txt 2>&1
+bash tools/scratch/xattn_pmc.sh bwd > $out/${tag}_xattn_bwd_pmc.txt 2>&1
 rm -rf $out/pmc_fwd $out/pmc_fwd_train $out/pmc_bwd $out/pmc_bwd_oz $out/pmc_fwd_xl $out/pmc_fwd_stress     # raw csv trees: only the summaries travel back
 ls -la $out
