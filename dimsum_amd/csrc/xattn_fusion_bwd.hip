@@ -304,12 +304,19 @@ __global__ __launch_bounds__(256) void xattn_bwd_dkv_kernel(const dimsum_xattn_b
 constexpr int kSQW = 128;        // queries per workgroup of the split dq kernel (8 waves)
 
 template <int HD>
-__global__ __launch_bounds__(512, 4) void xattn_bwd_dq_split_kernel(const dimsum_xattn_bwd_params_t p) {
+// (head_dim 72: 76 KB of LDS allow 2 workgroups per CU anyway -- asking for 4 capped the kernel at 64 VGPRs and 292 B of scratch per
+// lane: 5.2 ms per launch at 1024 tokens, profiles/r03_xattn_bwd_pmc.txt)
+__global__ __launch_bounds__(512, HD > 64 ? 2 : 4) void xattn_bwd_dq_split_kernel(const dimsum_xattn_bwd_params_t p) {
     constexpr int EP = (HD + 31) / 32 * 32, EC = EP / 32, ET = (HD + 15) / 16;
     constexpr int KS = EP + 8;               // [key][e] rows of K and V (bf16 elements, 16 B of padding)
     constexpr int TS = kBKT + 8;             // [e][key slot] rows of K^T
     __shared__ __attribute__((aligned(16))) unsigned short Kh[kBKT * KS], Kl[kBKT * KS], Vh[kBKT * KS], Vl[kBKT * KS];
     __shared__ __attribute__((aligned(16))) unsigned short Th[ET * 16 * TS], Tl[ET * 16 * TS];
+    static_assert((KS / 8) % 2 == 1 && (TS / 8) % 2 == 1, "odd number of 16-byte slots per row");
+    // conflict-free fragment reads (xattn_fusion.hip): a ds_read_b128 is serviced in four fixed groups of 16 lanes, in which rows 4-11
+    // of a 16-row fragment read k-slot a ^ 1 while rows 0-3 / 12-15 read slot a -- rows 4-11 keep their 16-byte slot PAIRS swapped
+    // (8 bf16 elements), in the staging writes and in the lanes' base addresses alike
+    auto flip = [](int row) { return (((row & 15) + 4) & 8); };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = p.fwd.seqlen, H = p.fwd.heads;
@@ -361,10 +368,10 @@ __global__ __launch_bounds__(512, 4) void xattn_bwd_dq_split_kernel(const dimsum
 #pragma unroll
     for (int e = 0; e < ET; ++e) acc[e] = f4{0.f, 0.f, 0.f, 0.f};
     if constexpr (EP > HD) {      // padding that is never rewritten: columns e in [hd, EP) of K and V
-        for (int i = tid; i < kBKT * (EP - HD); i += 512) { const int key = i / (EP - HD), e = HD + i % (EP - HD); Kh[key * KS + e] = 0; Kl[key * KS + e] = 0; Vh[key * KS + e] = 0; Vl[key * KS + e] = 0; }
+        for (int i = tid; i < kBKT * (EP - HD); i += 512) { const int key = i / (EP - HD), e = (HD + i % (EP - HD)) ^ flip(key); Kh[key * KS + e] = 0; Kl[key * KS + e] = 0; Vh[key * KS + e] = 0; Vl[key * KS + e] = 0; }
     }
     if constexpr (ET * 16 > HD) {  // rows e in [hd, ET*16) of K^T
-        for (int i = tid; i < (ET * 16 - HD) * kBKT; i += 512) { const int e = HD + i / kBKT, k = i % kBKT; Th[e * TS + k] = 0; Tl[e * TS + k] = 0; }
+        for (int i = tid; i < (ET * 16 - HD) * kBKT; i += 512) { const int e = HD + i / kBKT, k = (i % kBKT) ^ flip(e); Th[e * TS + k] = 0; Tl[e * TS + k] = 0; }
     }
 
     // The K / V rows of the NEXT key tile are requested right after the current tile has been staged (register-staged
@@ -393,15 +400,16 @@ __global__ __launch_bounds__(512, 4) void xattn_bwd_dq_split_kernel(const dimsum
             const int kp = i / (HD / 4), e4 = i - kp * (HD / 4), key = 2 * kp;
             const float4 ka = pka[it], kb = pkb[it], va = pva[it], vb = pvb[it];
             unsigned h0, l0, h1, l1;
+            const int ke = (e4 * 4) ^ flip(key);                    // key even: key and key + 1 are rows of the same kind
             split2(ka.x, ka.y, h0, l0); split2(ka.z, ka.w, h1, l1);
-            *reinterpret_cast<uint2 *>(&Kh[key * KS + e4 * 4]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Kl[key * KS + e4 * 4]) = make_uint2(l0, l1);
+            *reinterpret_cast<uint2 *>(&Kh[key * KS + ke]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Kl[key * KS + ke]) = make_uint2(l0, l1);
             split2(kb.x, kb.y, h0, l0); split2(kb.z, kb.w, h1, l1);
-            *reinterpret_cast<uint2 *>(&Kh[(key + 1) * KS + e4 * 4]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Kl[(key + 1) * KS + e4 * 4]) = make_uint2(l0, l1);
+            *reinterpret_cast<uint2 *>(&Kh[(key + 1) * KS + ke]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Kl[(key + 1) * KS + ke]) = make_uint2(l0, l1);
             split2(va.x, va.y, h0, l0); split2(va.z, va.w, h1, l1);
-            *reinterpret_cast<uint2 *>(&Vh[key * KS + e4 * 4]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Vl[key * KS + e4 * 4]) = make_uint2(l0, l1);
+            *reinterpret_cast<uint2 *>(&Vh[key * KS + ke]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Vl[key * KS + ke]) = make_uint2(l0, l1);
             split2(vb.x, vb.y, h0, l0); split2(vb.z, vb.w, h1, l1);
-            *reinterpret_cast<uint2 *>(&Vh[(key + 1) * KS + e4 * 4]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Vl[(key + 1) * KS + e4 * 4]) = make_uint2(l0, l1);
-            const int pos = (key & ~31) + cslot(key & 31);
+            *reinterpret_cast<uint2 *>(&Vh[(key + 1) * KS + ke]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Vl[(key + 1) * KS + ke]) = make_uint2(l0, l1);
+            const int pos = ((key & ~31) + cslot(key & 31)) ^ flip(e4 * 4);      // rows e4*4 .. +3 of K^T: one kind
             const float a4[4] = {ka.x, ka.y, ka.z, ka.w}, b4[4] = {kb.x, kb.y, kb.z, kb.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -417,7 +425,7 @@ __global__ __launch_bounds__(512, 4) void xattn_bwd_dq_split_kernel(const dimsum
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             f4 sacc = f4{0.f, 0.f, 0.f, 0.f}, pacc = f4{0.f, 0.f, 0.f, 0.f};
-            const int krow = (kt * 16 + qi) * KS + 8 * kg;
+            const int krow = (kt * 16 + qi) * KS + ((8 * kg) ^ flip(qi));
 #pragma unroll
             for (int c = 0; c < EC; ++c) {
                 const u4v kh = *reinterpret_cast<const u4v *>(&Kh[krow + 32 * c]), kl = *reinterpret_cast<const u4v *>(&Kl[krow + 32 * c]);
@@ -437,7 +445,7 @@ __global__ __launch_bounds__(512, 4) void xattn_bwd_dq_split_kernel(const dimsum
         split_c2(ds[2], ds[3], dh[1], dl[1]);
 #pragma unroll
         for (int e = 0; e < ET; ++e) {
-            const int trow = (e * 16 + qi) * TS + 8 * kg;
+            const int trow = (e * 16 + qi) * TS + ((8 * kg) ^ flip(qi));
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const u4v th = *reinterpret_cast<const u4v *>(&Th[trow + 32 * c]), tl = *reinterpret_cast<const u4v *>(&Tl[trow + 32 * c]);
@@ -457,13 +465,15 @@ __global__ __launch_bounds__(512, 4) void xattn_bwd_dq_split_kernel(const dimsum
 }
 
 template <int HD>
-__global__ __launch_bounds__(256, 3) void xattn_bwd_dkv_split_kernel(const dimsum_xattn_bwd_params_t p) {
+__global__ __launch_bounds__(256, HD > 64 ? 2 : 3) void xattn_bwd_dkv_split_kernel(const dimsum_xattn_bwd_params_t p) {
     constexpr int EP = (HD + 31) / 32 * 32, EC = EP / 32, ET = (HD + 15) / 16;
     constexpr int RS = EP + 8;               // [query][e] rows of Q and dO
     constexpr int TS = kBQT + 8;             // [e][query slot] rows of Q^T and dO^T
     __shared__ __attribute__((aligned(16))) unsigned short Qh[kBQT * RS], Ql[kBQT * RS], Gh[kBQT * RS], Gl[kBQT * RS];
     __shared__ __attribute__((aligned(16))) unsigned short QTh[ET * 16 * TS], QTl[ET * 16 * TS], GTh[ET * 16 * TS], GTl[ET * 16 * TS];
     __shared__ __attribute__((aligned(16))) float sL[kBQT], sD[kBQT];      // lse (log2 domain) and D of the tile's queries
+    static_assert((RS / 8) % 2 == 1 && (TS / 8) % 2 == 1, "odd number of 16-byte slots per row");
+    auto flip = [](int row) { return (((row & 15) + 4) & 8); };      // slot-pair swap of rows 4-11 of a fragment (see the dq kernel)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = p.fwd.seqlen, H = p.fwd.heads;
@@ -507,10 +517,10 @@ __global__ __launch_bounds__(256, 3) void xattn_bwd_dkv_split_kernel(const dimsu
     for (int e = 0; e < ET; ++e) { dk[e] = f4{0.f, 0.f, 0.f, 0.f}; dv[e] = f4{0.f, 0.f, 0.f, 0.f}; }
     const bool key_live = k_tok < L;
     if constexpr (EP > HD) {
-        for (int i = tid; i < kBQT * (EP - HD); i += 256) { const int q = i / (EP - HD), e = HD + i % (EP - HD); Qh[q * RS + e] = 0; Ql[q * RS + e] = 0; Gh[q * RS + e] = 0; Gl[q * RS + e] = 0; }
+        for (int i = tid; i < kBQT * (EP - HD); i += 256) { const int q = i / (EP - HD), e = (HD + i % (EP - HD)) ^ flip(q); Qh[q * RS + e] = 0; Ql[q * RS + e] = 0; Gh[q * RS + e] = 0; Gl[q * RS + e] = 0; }
     }
     if constexpr (ET * 16 > HD) {
-        for (int i = tid; i < (ET * 16 - HD) * kBQT; i += 256) { const int e = HD + i / kBQT, q = i % kBQT; QTh[e * TS + q] = 0; QTl[e * TS + q] = 0; GTh[e * TS + q] = 0; GTl[e * TS + q] = 0; }
+        for (int i = tid; i < (ET * 16 - HD) * kBQT; i += 256) { const int e = HD + i / kBQT, q = (i % kBQT) ^ flip(e); QTh[e * TS + q] = 0; QTl[e * TS + q] = 0; GTh[e * TS + q] = 0; GTl[e * TS + q] = 0; }
     }
 
     // The Q / dO rows of the NEXT query tile are requested right after the current tile has been staged, so their HBM
@@ -540,15 +550,16 @@ __global__ __launch_bounds__(256, 3) void xattn_bwd_dkv_split_kernel(const dimsu
             const int qp = i / (HD / 4), e4 = i - qp * (HD / 4), q = 2 * qp;
             const float4 qa = pqa[it], qb = pqb[it], ga = pga[it], gb = pgb[it];
             unsigned h0, l0, h1, l1;
+            const int qe = (e4 * 4) ^ flip(q);                      // q even: q and q + 1 are rows of the same kind
             split2(qa.x, qa.y, h0, l0); split2(qa.z, qa.w, h1, l1);
-            *reinterpret_cast<uint2 *>(&Qh[q * RS + e4 * 4]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Ql[q * RS + e4 * 4]) = make_uint2(l0, l1);
+            *reinterpret_cast<uint2 *>(&Qh[q * RS + qe]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Ql[q * RS + qe]) = make_uint2(l0, l1);
             split2(qb.x, qb.y, h0, l0); split2(qb.z, qb.w, h1, l1);
-            *reinterpret_cast<uint2 *>(&Qh[(q + 1) * RS + e4 * 4]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Ql[(q + 1) * RS + e4 * 4]) = make_uint2(l0, l1);
+            *reinterpret_cast<uint2 *>(&Qh[(q + 1) * RS + qe]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Ql[(q + 1) * RS + qe]) = make_uint2(l0, l1);
             split2(ga.x, ga.y, h0, l0); split2(ga.z, ga.w, h1, l1);
-            *reinterpret_cast<uint2 *>(&Gh[q * RS + e4 * 4]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Gl[q * RS + e4 * 4]) = make_uint2(l0, l1);
+            *reinterpret_cast<uint2 *>(&Gh[q * RS + qe]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Gl[q * RS + qe]) = make_uint2(l0, l1);
             split2(gb.x, gb.y, h0, l0); split2(gb.z, gb.w, h1, l1);
-            *reinterpret_cast<uint2 *>(&Gh[(q + 1) * RS + e4 * 4]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Gl[(q + 1) * RS + e4 * 4]) = make_uint2(l0, l1);
-            const int pos = cslot(q);
+            *reinterpret_cast<uint2 *>(&Gh[(q + 1) * RS + qe]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Gl[(q + 1) * RS + qe]) = make_uint2(l0, l1);
+            const int pos = cslot(q) ^ flip(e4 * 4);                // rows e4*4 .. +3 of Q^T / dO^T: one kind
             const float qa4[4] = {qa.x, qa.y, qa.z, qa.w}, qb4[4] = {qb.x, qb.y, qb.z, qb.w};
             const float ga4[4] = {ga.x, ga.y, ga.z, ga.w}, gb4[4] = {gb.x, gb.y, gb.z, gb.w};
 #pragma unroll
@@ -572,7 +583,7 @@ __global__ __launch_bounds__(256, 3) void xattn_bwd_dkv_split_kernel(const dimsu
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             f4 sacc = f4{0.f, 0.f, 0.f, 0.f}, pacc = f4{0.f, 0.f, 0.f, 0.f};
-            const int qrow = (qt * 16 + ki) * RS + 8 * kg;
+            const int qrow = (qt * 16 + ki) * RS + ((8 * kg) ^ flip(ki));
 #pragma unroll
             for (int c = 0; c < EC; ++c) {
                 const u4v qh_ = *reinterpret_cast<const u4v *>(&Qh[qrow + 32 * c]), ql_ = *reinterpret_cast<const u4v *>(&Ql[qrow + 32 * c]);
@@ -593,7 +604,7 @@ __global__ __launch_bounds__(256, 3) void xattn_bwd_dkv_split_kernel(const dimsu
         split_c2(dsv[0], dsv[1], sh_, sl_);
 #pragma unroll
         for (int e = 0; e < ET; ++e) {
-            const int row = (e * 16 + ki) * TS + 8 * kg;
+            const int row = (e * 16 + ki) * TS + ((8 * kg) ^ flip(ki));
             const u4v gth = *reinterpret_cast<const u4v *>(&GTh[row]), gtl = *reinterpret_cast<const u4v *>(&GTl[row]);
             const u4v qth = *reinterpret_cast<const u4v *>(&QTh[row]), qtl = *reinterpret_cast<const u4v *>(&QTl[row]);
             dv[e] = mfma_split(gth, gtl, ph, pl, dv[e]);
