@@ -464,8 +464,11 @@ __global__ __launch_bounds__(512, HD > 64 ? 2 : 4) void xattn_bwd_dq_split_kerne
     }
 }
 
-template <int HD>
-__global__ __launch_bounds__(256, HD > 64 ? 2 : 3) void xattn_bwd_dkv_split_kernel(const dimsum_xattn_bwd_params_t p) {
+// KT = 16-key tiles per wave: a workgroup covers 64 * KT keys, so the staging of a query tile (loads, 16 hi / lo splits and 24 LDS
+// writes per thread: more VALU work than the tile's 48 MFMAs per key tile take on the matrix cores) and every A-operand
+// ds_read_b128 are shared by KT key tiles -- the forward's QT = 2 trick; 2 workgroups per CU instead of 3 (head_dim <= 64).
+template <int HD, int KT>
+__global__ __launch_bounds__(256, (HD > 64 || KT == 2) ? 2 : 3) void xattn_bwd_dkv_split_kernel(const dimsum_xattn_bwd_params_t p) {
     constexpr int EP = (HD + 31) / 32 * 32, EC = EP / 32, ET = (HD + 15) / 16;
     constexpr int RS = EP + 8;               // [query][e] rows of Q and dO
     constexpr int TS = kBQT + 8;             // [e][query slot] rows of Q^T and dO^T
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(256, HD > 64 ? 2 : 3) void xattn_bwd_dkv_split_kern
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = p.fwd.seqlen, H = p.fwd.heads;
-    const int kblocks = (L + 63) / 64;
+    const int kblocks = (L + 64 * KT - 1) / (64 * KT);
     int idx = blockIdx.x;
     const int kblk = idx % kblocks; idx /= kblocks;
     const int ndir = p.fwd.n_dirs == 1 ? 1 : 2;
@@ -493,29 +496,36 @@ __global__ __launch_bounds__(256, HD > 64 ? 2 : 3) void xattn_bwd_dkv_split_kern
     const float *dlt = reinterpret_cast<const float *>(p.delta_ptr) + stat0;
 
     const int ki = lane & 15, kg = lane >> 4;
-    const int k_tok = kblk * 64 + wave * 16 + ki;
-    const int k_ld = min(k_tok, L - 1);
     const float kscale = p.fwd.scale * kLog2e;
-    // K^T (scaled) and V^T fragments of this lane's key (B operands): chunk c, slots j <-> e = 32c + 8 kg + j
-    u4v kh[EC], kl[EC], vh[EC], vl[EC];
+    // K^T (scaled) and V^T fragments of this lane's keys (B operands): chunk c, slots j <-> e = 32c + 8 kg + j
+    int k_tok[KT];
+    bool key_live[KT];
+    u4v kh[KT][EC], kl[KT][EC], vh[KT][EC], vl[KT][EC];
 #pragma unroll
-    for (int c = 0; c < EC; ++c) {
-        float kv[8], vv[8];
+    for (int t = 0; t < KT; ++t) {
+        k_tok[t] = kblk * (64 * KT) + (wave * KT + t) * 16 + ki;
+        key_live[t] = k_tok[t] < L;
+        const int k_ld = min(k_tok[t], L - 1);
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int e0 = 32 * c + 8 * kg + 4 * half;
-            float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), v4 = kk;
-            if (e0 < HD) { kk = ld_bias4(s.k + (int64_t)k_ld * ts, s.kb, e0); v4 = ld_bias4(s.v + (int64_t)k_ld * ts, s.vb, e0); }
-            kv[4 * half + 0] = kk.x * kscale; kv[4 * half + 1] = kk.y * kscale; kv[4 * half + 2] = kk.z * kscale; kv[4 * half + 3] = kk.w * kscale;
-            vv[4 * half + 0] = v4.x; vv[4 * half + 1] = v4.y; vv[4 * half + 2] = v4.z; vv[4 * half + 3] = v4.w;
+        for (int c = 0; c < EC; ++c) {
+            float kv[8], vv[8];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int e0 = 32 * c + 8 * kg + 4 * half;
+                float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), v4 = kk;
+                if (e0 < HD) { kk = ld_bias4(s.k + (int64_t)k_ld * ts, s.kb, e0); v4 = ld_bias4(s.v + (int64_t)k_ld * ts, s.vb, e0); }
+                kv[4 * half + 0] = kk.x * kscale; kv[4 * half + 1] = kk.y * kscale; kv[4 * half + 2] = kk.z * kscale; kv[4 * half + 3] = kk.w * kscale;
+                vv[4 * half + 0] = v4.x; vv[4 * half + 1] = v4.y; vv[4 * half + 2] = v4.z; vv[4 * half + 3] = v4.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { split2(kv[2 * i], kv[2 * i + 1], kh[t][c].w[i], kl[t][c].w[i]); split2(vv[2 * i], vv[2 * i + 1], vh[t][c].w[i], vl[t][c].w[i]); }
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { split2(kv[2 * i], kv[2 * i + 1], kh[c].w[i], kl[c].w[i]); split2(vv[2 * i], vv[2 * i + 1], vh[c].w[i], vl[c].w[i]); }
     }
-    f4 dk[ET], dv[ET];
+    f4 dk[KT][ET], dv[KT][ET];
 #pragma unroll
-    for (int e = 0; e < ET; ++e) { dk[e] = f4{0.f, 0.f, 0.f, 0.f}; dv[e] = f4{0.f, 0.f, 0.f, 0.f}; }
-    const bool key_live = k_tok < L;
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int e = 0; e < ET; ++e) { dk[t][e] = f4{0.f, 0.f, 0.f, 0.f}; dv[t][e] = f4{0.f, 0.f, 0.f, 0.f}; }
     if constexpr (EP > HD) {
         for (int i = tid; i < kBQT * (EP - HD); i += 256) { const int q = i / (EP - HD), e = (HD + i % (EP - HD)) ^ flip(q); Qh[q * RS + e] = 0; Ql[q * RS + e] = 0; Gh[q * RS + e] = 0; Gl[q * RS + e] = 0; }
     }
@@ -578,48 +588,62 @@ __global__ __launch_bounds__(256, HD > 64 ? 2 : 3) void xattn_bwd_dkv_split_kern
         __syncthreads();
         if (q0 + kBQT < L) fetch(q0 + kBQT);
 
-        // ---- S = Q K^T, dP = dO V^T for the two 16-query tiles: C layout key = lane & 15 (column), queries qt*16 + kg*4 + r ----
-        f4 pp[2], dsv[2];
+        // ---- S = Q K^T, dP = dO V^T for the two 16-query tiles: C layout key = lane & 15 (column), queries qt*16 + kg*4 + r;
+        //      every Q / dO fragment read serves the wave's KT key tiles ---------------------------------------------------------
+        f4 pp[KT][2], dsv[KT][2];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            f4 sacc = f4{0.f, 0.f, 0.f, 0.f}, pacc = f4{0.f, 0.f, 0.f, 0.f};
+            f4 sacc[KT], pacc[KT];
+#pragma unroll
+            for (int t = 0; t < KT; ++t) { sacc[t] = f4{0.f, 0.f, 0.f, 0.f}; pacc[t] = f4{0.f, 0.f, 0.f, 0.f}; }
             const int qrow = (qt * 16 + ki) * RS + ((8 * kg) ^ flip(ki));
 #pragma unroll
             for (int c = 0; c < EC; ++c) {
                 const u4v qh_ = *reinterpret_cast<const u4v *>(&Qh[qrow + 32 * c]), ql_ = *reinterpret_cast<const u4v *>(&Ql[qrow + 32 * c]);
                 const u4v gh_ = *reinterpret_cast<const u4v *>(&Gh[qrow + 32 * c]), gl_ = *reinterpret_cast<const u4v *>(&Gl[qrow + 32 * c]);
-                sacc = mfma_split(qh_, ql_, kh[c], kl[c], sacc);
-                pacc = mfma_split(gh_, gl_, vh[c], vl[c], pacc);
+#pragma unroll
+                for (int t = 0; t < KT; ++t) {
+                    sacc[t] = mfma_split(qh_, ql_, kh[t][c], kl[t][c], sacc[t]);
+                    pacc[t] = mfma_split(gh_, gl_, vh[t][c], vl[t][c], pacc[t]);
+                }
             }
             const float4 l4 = *reinterpret_cast<const float4 *>(&sL[qt * 16 + kg * 4]);
             const float4 d4 = *reinterpret_cast<const float4 *>(&sD[qt * 16 + kg * 4]);
-            pp[qt][0] = key_live ? fast_exp2(sacc[0] - l4.x) : 0.f; pp[qt][1] = key_live ? fast_exp2(sacc[1] - l4.y) : 0.f;
-            pp[qt][2] = key_live ? fast_exp2(sacc[2] - l4.z) : 0.f; pp[qt][3] = key_live ? fast_exp2(sacc[3] - l4.w) : 0.f;
-            dsv[qt][0] = pp[qt][0] * (pacc[0] - d4.x); dsv[qt][1] = pp[qt][1] * (pacc[1] - d4.y);
-            dsv[qt][2] = pp[qt][2] * (pacc[2] - d4.z); dsv[qt][3] = pp[qt][3] * (pacc[3] - d4.w);
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                pp[t][qt][0] = key_live[t] ? fast_exp2(sacc[t][0] - l4.x) : 0.f; pp[t][qt][1] = key_live[t] ? fast_exp2(sacc[t][1] - l4.y) : 0.f;
+                pp[t][qt][2] = key_live[t] ? fast_exp2(sacc[t][2] - l4.z) : 0.f; pp[t][qt][3] = key_live[t] ? fast_exp2(sacc[t][3] - l4.w) : 0.f;
+                dsv[t][qt][0] = pp[t][qt][0] * (pacc[t][0] - d4.x); dsv[t][qt][1] = pp[t][qt][1] * (pacc[t][1] - d4.y);
+                dsv[t][qt][2] = pp[t][qt][2] * (pacc[t][2] - d4.z); dsv[t][qt][3] = pp[t][qt][3] * (pacc[t][3] - d4.w);
+            }
         }
         // ---- dV^T += dO^T P, dK^T += Q^T dS: ONE 32-deep chunk whose slots are the tile's queries --------------------------------
-        u4v ph, pl, sh_, sl_;
-        split_c2(pp[0], pp[1], ph, pl);
-        split_c2(dsv[0], dsv[1], sh_, sl_);
+        u4v ph[KT], pl[KT], sh_[KT], sl_[KT];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) { split_c2(pp[t][0], pp[t][1], ph[t], pl[t]); split_c2(dsv[t][0], dsv[t][1], sh_[t], sl_[t]); }
 #pragma unroll
         for (int e = 0; e < ET; ++e) {
             const int row = (e * 16 + ki) * TS + ((8 * kg) ^ flip(ki));
             const u4v gth = *reinterpret_cast<const u4v *>(&GTh[row]), gtl = *reinterpret_cast<const u4v *>(&GTl[row]);
             const u4v qth = *reinterpret_cast<const u4v *>(&QTh[row]), qtl = *reinterpret_cast<const u4v *>(&QTl[row]);
-            dv[e] = mfma_split(gth, gtl, ph, pl, dv[e]);
-            dk[e] = mfma_split(qth, qtl, sh_, sl_, dk[e]);
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                dv[t][e] = mfma_split(gth, gtl, ph[t], pl[t], dv[t][e]);
+                dk[t][e] = mfma_split(qth, qtl, sh_[t], sl_[t], dk[t][e]);
+            }
         }
     }
-    if (key_live) {
-        float *dkd = s.dk + (int64_t)k_tok * dts, *dvd = s.dv + (int64_t)k_tok * dts;
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        if (!key_live[t]) continue;
+        float *dkd = s.dk + (int64_t)k_tok[t] * dts, *dvd = s.dv + (int64_t)k_tok[t] * dts;
         const float sc = p.fwd.scale;
 #pragma unroll
         for (int e = 0; e < ET; ++e) {
             const int e0 = e * 16 + kg * 4;
             if (e0 < HD) {
-                *reinterpret_cast<float4 *>(dkd + e0) = make_float4(dk[e][0] * sc, dk[e][1] * sc, dk[e][2] * sc, dk[e][3] * sc);
-                *reinterpret_cast<float4 *>(dvd + e0) = make_float4(dv[e][0], dv[e][1], dv[e][2], dv[e][3]);
+                *reinterpret_cast<float4 *>(dkd + e0) = make_float4(dk[t][e][0] * sc, dk[t][e][1] * sc, dk[t][e][2] * sc, dk[t][e][3] * sc);
+                *reinterpret_cast<float4 *>(dvd + e0) = make_float4(dv[t][e][0], dv[t][e][1], dv[t][e][2], dv[t][e][3]);
             }
         }
     }
@@ -633,7 +657,13 @@ static int launch_xbwd(const dimsum_xattn_bwd_params_t &p, hipStream_t s) {
         const int64_t nq = (int64_t)p.fwd.batch * p.fwd.heads * (p.fwd.n_dirs == 1 ? 1 : 2) * ((p.fwd.seqlen + kSQW - 1) / kSQW);
         hipLaunchKernelGGL(xattn_bwd_dq_split_kernel<HD>, dim3((unsigned)nq), dim3(512), 0, s, p);
         if (launch_status() != DIMSUM_OK) return DIMSUM_ERR_LAUNCH;
-        hipLaunchKernelGGL(xattn_bwd_dkv_split_kernel<HD>, dim3((unsigned)nblk), dim3(256), 0, s, p);
+        // two key tiles per wave (128 keys per workgroup) halve the per-key staging work; short sequences and the wide head keep one
+        if (HD <= 64 && p.fwd.seqlen >= 128) {
+            const int64_t nk2 = (int64_t)p.fwd.batch * p.fwd.heads * (p.fwd.n_dirs == 1 ? 1 : 2) * ((p.fwd.seqlen + 127) / 128);
+            hipLaunchKernelGGL((xattn_bwd_dkv_split_kernel<HD, (HD <= 64 ? 2 : 1)>), dim3((unsigned)nk2), dim3(256), 0, s, p);
+        } else {
+            hipLaunchKernelGGL((xattn_bwd_dkv_split_kernel<HD, 1>), dim3((unsigned)nblk), dim3(256), 0, s, p);
+        }
         return launch_status();
     }
     hipLaunchKernelGGL(xattn_bwd_dq_kernel<HD>, dim3((unsigned)nblk), dim3(256), 0, s, p);
