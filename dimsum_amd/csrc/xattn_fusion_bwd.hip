@@ -301,12 +301,18 @@ __global__ __launch_bounds__(256) void xattn_bwd_dkv_kernel(const dimsum_xattn_b
 // holds in the C registers of two stacked 16-row tiles, and the transposed LDS images (K^T; Q^T, dO^T) are staged with
 // that permutation (cslot), so no operand changes layout. Softmax probabilities, D and all accumulators stay fp32.
 // =====================================================================================================================
-constexpr int kSQW = 128;        // queries per workgroup of the split dq kernel (8 waves)
+constexpr int kSQW = 128;        // queries per workgroup of the split dq kernel
 
-template <int HD>
-// (head_dim 72: 76 KB of LDS allow 2 workgroups per CU anyway -- asking for 4 capped the kernel at 64 VGPRs and 292 B of scratch per
-// lane: 5.2 ms per launch at 1024 tokens, profiles/r03_xattn_bwd_pmc.txt)
-__global__ __launch_bounds__(512, HD > 64 ? 2 : 4) void xattn_bwd_dq_split_kernel(const dimsum_xattn_bwd_params_t p) {
+// QT = 16-query tiles per wave, NW waves per workgroup (NW * QT * 16 = 128 queries either way). QT = 2 (4 waves): every K / V / K^T
+// fragment read serves two query tiles and the two tiles' MFMA chains interleave -- used for head_dim <= 32, where two tiles take 163
+// VGPRs (3 waves per SIMD): 0.778 -> 0.717 ms for the backward pair at head_dim 24. At head_dim 48 / 64 two tiles need ~250 VGPRs
+// (2 waves per SIMD) and measured 1.33 against 1.24 ms for QT = 1 at 128 VGPRs (8 waves per workgroup, 4 per SIMD): latency hiding by
+// occupancy wins there; head_dim 72 does not fit two tiles at all.
+// (head_dim 72: 76 KB of LDS allow 2 workgroups per CU anyway -- asking for 4 waves per SIMD capped the kernel at 128 VGPRs and 292 B of
+// scratch per lane: 5.2 ms per launch at 1024 tokens, profiles/r03_xattn_bwd_pmc.txt)
+template <int HD, int QT>
+__global__ __launch_bounds__(kSQW / QT * 4, (QT == 1 && HD <= 64) ? 4 : 2) void xattn_bwd_dq_split_kernel(const dimsum_xattn_bwd_params_t p) {
+    constexpr int NT = kSQW / QT * 4;        // threads per workgroup: 512 (QT = 1) or 256 (QT = 2)
     constexpr int EP = (HD + 31) / 32 * 32, EC = EP / 32, ET = (HD + 15) / 16;
     constexpr int KS = EP + 8;               // [key][e] rows of K and V (bf16 elements, 16 B of padding)
     constexpr int TS = kBKT + 8;             // [e][key slot] rows of K^T
@@ -332,56 +338,63 @@ __global__ __launch_bounds__(512, HD > 64 ? 2 : 4) void xattn_bwd_dq_split_kerne
     const int64_t ts = p.fwd.qkv_token_stride, dts = p.dqkv_token_stride;
 
     const int qi = lane & 15, kg = lane >> 4;
-    const int q_tok = qblk * kSQW + wave * 16 + qi;
-    const int q_ld = min(q_tok, L - 1);
     const float qscale = p.fwd.scale * kLog2e;
-    const float *dorow = reinterpret_cast<const float *>(p.dout_ptr) + (int64_t)b * p.fwd.out_batch_stride + (int64_t)q_ld * p.fwd.out_token_stride + dir * C + h * HD;
-    const float *orow = reinterpret_cast<const float *>(p.fwd.out_ptr) + (int64_t)b * p.fwd.out_batch_stride + (int64_t)q_ld * p.fwd.out_token_stride + dir * C + h * HD;
-    // Q^T (scaled into the log2 domain) and dO^T fragments (B operands): chunk c, slots j <-> e = 32c + 8 kg + j
-    u4v qh[EC], ql[EC], gh[EC], gl[EC];
-    float dpart = 0.f;
+    // Q^T (scaled into the log2 domain) and dO^T fragments (B operands) of the wave's QT query tiles: chunk c, slots j <-> e = 32c + 8 kg + j
+    int q_tok[QT];
+    float dpart[QT], lse2[QT];
+    u4v qh[QT][EC], ql[QT][EC], gh[QT][EC], gl[QT][EC];
 #pragma unroll
-    for (int c = 0; c < EC; ++c) {
-        float qv[8], gv[8];
+    for (int t = 0; t < QT; ++t) {
+        q_tok[t] = qblk * kSQW + (wave * QT + t) * 16 + qi;
+        const int q_ld = min(q_tok[t], L - 1);
+        const float *dorow = reinterpret_cast<const float *>(p.dout_ptr) + (int64_t)b * p.fwd.out_batch_stride + (int64_t)q_ld * p.fwd.out_token_stride + dir * C + h * HD;
+        const float *orow = reinterpret_cast<const float *>(p.fwd.out_ptr) + (int64_t)b * p.fwd.out_batch_stride + (int64_t)q_ld * p.fwd.out_token_stride + dir * C + h * HD;
+        float dp = 0.f;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int e0 = 32 * c + 8 * kg + 4 * half;
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f), g = t;
-            if (e0 < HD) {
-                t = ld_bias4(s.q + (int64_t)q_ld * ts, s.qb, e0);
-                g = *reinterpret_cast<const float4 *>(dorow + e0);
-                const float4 o = *reinterpret_cast<const float4 *>(orow + e0);
-                dpart += g.x * o.x + g.y * o.y + g.z * o.z + g.w * o.w;
+        for (int c = 0; c < EC; ++c) {
+            float qv[8], gv[8];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int e0 = 32 * c + 8 * kg + 4 * half;
+                float4 tq = make_float4(0.f, 0.f, 0.f, 0.f), g = tq;
+                if (e0 < HD) {
+                    tq = ld_bias4(s.q + (int64_t)q_ld * ts, s.qb, e0);
+                    g = *reinterpret_cast<const float4 *>(dorow + e0);
+                    const float4 o = *reinterpret_cast<const float4 *>(orow + e0);
+                    dp += g.x * o.x + g.y * o.y + g.z * o.z + g.w * o.w;
+                }
+                qv[4 * half + 0] = tq.x * qscale; qv[4 * half + 1] = tq.y * qscale; qv[4 * half + 2] = tq.z * qscale; qv[4 * half + 3] = tq.w * qscale;
+                gv[4 * half + 0] = g.x; gv[4 * half + 1] = g.y; gv[4 * half + 2] = g.z; gv[4 * half + 3] = g.w;
             }
-            qv[4 * half + 0] = t.x * qscale; qv[4 * half + 1] = t.y * qscale; qv[4 * half + 2] = t.z * qscale; qv[4 * half + 3] = t.w * qscale;
-            gv[4 * half + 0] = g.x; gv[4 * half + 1] = g.y; gv[4 * half + 2] = g.z; gv[4 * half + 3] = g.w;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { split2(qv[2 * i], qv[2 * i + 1], qh[t][c].w[i], ql[t][c].w[i]); split2(gv[2 * i], gv[2 * i + 1], gh[t][c].w[i], gl[t][c].w[i]); }
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { split2(qv[2 * i], qv[2 * i + 1], qh[c].w[i], ql[c].w[i]); split2(gv[2 * i], gv[2 * i + 1], gh[c].w[i], gl[c].w[i]); }
+        dpart[t] = quad_sum(dp);                              // D of this lane's query
+        const int64_t stat = (((int64_t)b * ndir + dir) * H + h) * L + q_ld;
+        lse2[t] = reinterpret_cast<const float *>(p.fwd.lse_ptr)[stat] * kLog2e;
+        if (q_tok[t] < L && kg == 0) reinterpret_cast<float *>(p.delta_ptr)[stat] = dpart[t];
     }
-    dpart = quad_sum(dpart);                                  // D of this lane's query
-    const int64_t stat = (((int64_t)b * ndir + dir) * H + h) * L + q_ld;
-    const float lse2 = reinterpret_cast<const float *>(p.fwd.lse_ptr)[stat] * kLog2e;
-    if (q_tok < L && kg == 0) reinterpret_cast<float *>(p.delta_ptr)[stat] = dpart;
 
-    f4 acc[ET];
+    f4 acc[QT][ET];
 #pragma unroll
-    for (int e = 0; e < ET; ++e) acc[e] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int e = 0; e < ET; ++e) acc[t][e] = f4{0.f, 0.f, 0.f, 0.f};
     if constexpr (EP > HD) {      // padding that is never rewritten: columns e in [hd, EP) of K and V
-        for (int i = tid; i < kBKT * (EP - HD); i += 512) { const int key = i / (EP - HD), e = (HD + i % (EP - HD)) ^ flip(key); Kh[key * KS + e] = 0; Kl[key * KS + e] = 0; Vh[key * KS + e] = 0; Vl[key * KS + e] = 0; }
+        for (int i = tid; i < kBKT * (EP - HD); i += NT) { const int key = i / (EP - HD), e = (HD + i % (EP - HD)) ^ flip(key); Kh[key * KS + e] = 0; Kl[key * KS + e] = 0; Vh[key * KS + e] = 0; Vl[key * KS + e] = 0; }
     }
     if constexpr (ET * 16 > HD) {  // rows e in [hd, ET*16) of K^T
-        for (int i = tid; i < (ET * 16 - HD) * kBKT; i += 512) { const int e = HD + i / kBKT, k = (i % kBKT) ^ flip(e); Th[e * TS + k] = 0; Tl[e * TS + k] = 0; }
+        for (int i = tid; i < (ET * 16 - HD) * kBKT; i += NT) { const int e = HD + i / kBKT, k = (i % kBKT) ^ flip(e); Th[e * TS + k] = 0; Tl[e * TS + k] = 0; }
     }
 
     // The K / V rows of the NEXT key tile are requested right after the current tile has been staged (register-staged
     // prefetch: one thread = 2 keys x 4 e, kIt items per tile), so their HBM latency hides under the tile's MFMA work.
-    constexpr int kItems = (kBKT / 2) * (HD / 4), kIt = (kItems + 511) / 512;
+    constexpr int kItems = (kBKT / 2) * (HD / 4), kIt = (kItems + NT - 1) / NT;
     float4 pka[kIt], pkb[kIt], pva[kIt], pvb[kIt];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int it = 0; it < kIt; ++it) {
-            const int i = min(tid + it * 512, kItems - 1);
+            const int i = min(tid + it * NT, kItems - 1);
             const int kp = i / (HD / 4), e4 = i - kp * (HD / 4), key = 2 * kp;
             const int tok0 = min(k0 + key, L - 1), tok1 = min(k0 + key + 1, L - 1);
             pka[it] = ld_bias4(s.k + (int64_t)tok0 * ts, s.kb, e4 * 4); pkb[it] = ld_bias4(s.k + (int64_t)tok1 * ts, s.kb, e4 * 4);
@@ -395,7 +408,7 @@ __global__ __launch_bounds__(512, HD > 64 ? 2 : 4) void xattn_bwd_dq_split_kerne
         // ---- stage K, V [key][e] and K^T [e][slot(key)] as hi / lo bf16 images; one thread = 2 keys x 4 e -----------------
 #pragma unroll
         for (int it = 0; it < kIt; ++it) {
-            const int i = tid + it * 512;
+            const int i = tid + it * NT;
             if (i >= kItems) break;
             const int kp = i / (HD / 4), e4 = i - kp * (HD / 4), key = 2 * kp;
             const float4 ka = pka[it], kb = pkb[it], va = pva[it], vb = pvb[it];
@@ -421,45 +434,58 @@ __global__ __launch_bounds__(512, HD > 64 ? 2 : 4) void xattn_bwd_dq_split_kerne
         __syncthreads();
         if (k0 + kBKT < L) fetch(k0 + kBKT);
 
-        f4 ds[4];
+        f4 ds[QT][4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            f4 sacc = f4{0.f, 0.f, 0.f, 0.f}, pacc = f4{0.f, 0.f, 0.f, 0.f};
+            f4 sacc[QT], pacc[QT];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) { sacc[t] = f4{0.f, 0.f, 0.f, 0.f}; pacc[t] = f4{0.f, 0.f, 0.f, 0.f}; }
             const int krow = (kt * 16 + qi) * KS + ((8 * kg) ^ flip(qi));
 #pragma unroll
             for (int c = 0; c < EC; ++c) {
                 const u4v kh = *reinterpret_cast<const u4v *>(&Kh[krow + 32 * c]), kl = *reinterpret_cast<const u4v *>(&Kl[krow + 32 * c]);
                 const u4v vh = *reinterpret_cast<const u4v *>(&Vh[krow + 32 * c]), vl = *reinterpret_cast<const u4v *>(&Vl[krow + 32 * c]);
-                sacc = mfma_split(kh, kl, qh[c], ql[c], sacc);      // S^T  (log2 domain)
-                pacc = mfma_split(vh, vl, gh[c], gl[c], pacc);      // dP^T
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    sacc[t] = mfma_split(kh, kl, qh[t][c], ql[t][c], sacc[t]);      // S^T  (log2 domain)
+                    pacc[t] = mfma_split(vh, vl, gh[t][c], gl[t][c], pacc[t]);      // dP^T
+                }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {     // dS^T = P^T o (dP^T - D); keys beyond L contribute nothing
-                const float pr = (k0 + kt * 16 + kg * 4 + r < L) ? fast_exp2(sacc[r] - lse2) : 0.f;
-                ds[kt][r] = pr * (pacc[r] - dpart);
-            }
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {     // dS^T = P^T o (dP^T - D); keys beyond L contribute nothing
+                    const float pr = (k0 + kt * 16 + kg * 4 + r < L) ? fast_exp2(sacc[t][r] - lse2[t]) : 0.f;
+                    ds[t][kt][r] = pr * (pacc[t][r] - dpart[t]);
+                }
         }
         // ---- dQ^T += K^T dS^T: chunk c = key tiles 2c, 2c + 1 -----------------------------------------------------------------
-        u4v dh[2], dl[2];
-        split_c2(ds[0], ds[1], dh[0], dl[0]);
-        split_c2(ds[2], ds[3], dh[1], dl[1]);
+        u4v dh[QT][2], dl[QT][2];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            split_c2(ds[t][0], ds[t][1], dh[t][0], dl[t][0]);
+            split_c2(ds[t][2], ds[t][3], dh[t][1], dl[t][1]);
+        }
 #pragma unroll
         for (int e = 0; e < ET; ++e) {
             const int trow = (e * 16 + qi) * TS + ((8 * kg) ^ flip(qi));
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const u4v th = *reinterpret_cast<const u4v *>(&Th[trow + 32 * c]), tl = *reinterpret_cast<const u4v *>(&Tl[trow + 32 * c]);
-                acc[e] = mfma_split(th, tl, dh[c], dl[c], acc[e]);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) acc[t][e] = mfma_split(th, tl, dh[t][c], dl[t][c], acc[t][e]);
             }
         }
     }
-    if (q_tok < L) {
-        float *dst = s.dq + (int64_t)q_tok * dts;
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        if (q_tok[t] >= L) continue;
+        float *dst = s.dq + (int64_t)q_tok[t] * dts;
         const float sc = p.fwd.scale;
 #pragma unroll
         for (int e = 0; e < ET; ++e) {
             const int e0 = e * 16 + kg * 4;
-            if (e0 < HD) *reinterpret_cast<float4 *>(dst + e0) = make_float4(acc[e][0] * sc, acc[e][1] * sc, acc[e][2] * sc, acc[e][3] * sc);
+            if (e0 < HD) *reinterpret_cast<float4 *>(dst + e0) = make_float4(acc[t][e][0] * sc, acc[t][e][1] * sc, acc[t][e][2] * sc, acc[t][e][3] * sc);
         }
     }
 }
@@ -655,15 +681,19 @@ static int launch_xbwd(const dimsum_xattn_bwd_params_t &p, hipStream_t s) {
     if (nblk > 0x7fffffff) return DIMSUM_ERR_SHAPE;
     if (p.fwd.precision == 1) {
         const int64_t nq = (int64_t)p.fwd.batch * p.fwd.heads * (p.fwd.n_dirs == 1 ? 1 : 2) * ((p.fwd.seqlen + kSQW - 1) / kSQW);
-        hipLaunchKernelGGL(xattn_bwd_dq_split_kernel<HD>, dim3((unsigned)nq), dim3(512), 0, s, p);
+        if constexpr (HD <= 32) hipLaunchKernelGGL((xattn_bwd_dq_split_kernel<HD, 2>), dim3((unsigned)nq), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((xattn_bwd_dq_split_kernel<HD, 1>), dim3((unsigned)nq), dim3(512), 0, s, p);
         if (launch_status() != DIMSUM_OK) return DIMSUM_ERR_LAUNCH;
         // two key tiles per wave (128 keys per workgroup) halve the per-key staging work; short sequences and the wide head keep one
-        if (HD <= 64 && p.fwd.seqlen >= 128) {
-            const int64_t nk2 = (int64_t)p.fwd.batch * p.fwd.heads * (p.fwd.n_dirs == 1 ? 1 : 2) * ((p.fwd.seqlen + 127) / 128);
-            hipLaunchKernelGGL((xattn_bwd_dkv_split_kernel<HD, (HD <= 64 ? 2 : 1)>), dim3((unsigned)nk2), dim3(256), 0, s, p);
-        } else {
-            hipLaunchKernelGGL((xattn_bwd_dkv_split_kernel<HD, 1>), dim3((unsigned)nblk), dim3(256), 0, s, p);
+        bool two = false;
+        if constexpr (HD <= 64) {
+            if (p.fwd.seqlen >= 128) {
+                const int64_t nk2 = (int64_t)p.fwd.batch * p.fwd.heads * (p.fwd.n_dirs == 1 ? 1 : 2) * ((p.fwd.seqlen + 127) / 128);
+                hipLaunchKernelGGL((xattn_bwd_dkv_split_kernel<HD, 2>), dim3((unsigned)nk2), dim3(256), 0, s, p);
+                two = true;
+            }
         }
+        if (!two) hipLaunchKernelGGL((xattn_bwd_dkv_split_kernel<HD, 1>), dim3((unsigned)nblk), dim3(256), 0, s, p);
         return launch_status();
     }
     hipLaunchKernelGGL(xattn_bwd_dq_kernel<HD>, dim3((unsigned)nblk), dim3(256), 0, s, p);

@@ -370,3 +370,38 @@ def test_two_stream_branches_are_bit_identical(monkeypatch):
         torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
     assert torch.equal(a, ref) and torch.equal(b, ref) and torch.equal(c, ref)
+
+
+@pytest.mark.gpu
+def test_inference_without_out_and_x_stores_is_bit_identical(monkeypatch):
+    """DIMSUM_SCAN_INFER_STORES=0 (opt-in): the mixers' inference scans skip the stores of the ungated `out` and of the chunk
+    states `x` (NULL out_ptr / x_ptr in the C ABI) -- only a backward reads them. Same kernel, same arithmetic: the model output
+    is bit-identical; and under autograd the switch changes nothing (the backward needs both)."""
+    from dimsum_amd import native
+    from dimsum_amd.models_dim import DiM
+    m = DiM(depth=4, hidden_size=384, patch_size=2, **_published())
+    procedural_fill(m, seed=3)
+    m = m.cuda().eval()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x, t = torch.randn(4, 4, 32, 32, device="cuda", generator=g), torch.rand(4, device="cuda", generator=g)
+    y = torch.randint(0, 1000, (4,), device="cuda", generator=g)
+    seen = []
+    real = native.selective_scan_fwd
+
+    def spy(*a, need_out=True, need_x=True, **k):
+        seen.append((need_out, need_x))
+        return real(*a, need_out=need_out, need_x=need_x, **k)
+
+    monkeypatch.setattr(native, "selective_scan_fwd", spy)
+    with torch.no_grad():
+        ref = m(x, t, y)
+        assert seen and all(s == (True, True) for s in seen)          # the default keeps the reference interface's stores
+        seen.clear()
+        monkeypatch.setenv("DIMSUM_SCAN_INFER_STORES", "0")
+        got = m(x, t, y)
+        assert seen and all(s == (False, False) for s in seen)
+    assert torch.equal(got, ref)
+    seen.clear()
+    xg = x.clone().requires_grad_()
+    m(xg, t, y).sum().backward()
+    assert seen and all(s == (True, True) for s in seen)              # training: the backward reads out and x
