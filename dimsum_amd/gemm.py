@@ -57,8 +57,9 @@ def _cached(kind, weight, make):
     key = (kind, weight.data_ptr(), tuple(weight.shape), tuple(weight.stride()), weight.dtype)
     hit = _frozen.get(key)
     if hit is None:
-        hit = _frozen[key] = make()
-    return hit
+        # the entry keeps the weight alive: its storage cannot be freed and handed to another tensor while the image is cached
+        hit = _frozen[key] = (make(), weight)
+    return hit[0]
 
 
 def weight_image(weight):

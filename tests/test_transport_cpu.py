@@ -182,3 +182,20 @@ def test_dopri5_accepted_steps_never_shrink():
     shrank = [(a, b) for a, b in zip(hs[:-1], hs[1:]) if b < a]
     assert all(0.2 - 1e-12 <= b / a < 0.9 for a, b in shrank), shrank
     assert any(b >= a for a, b in zip(hs[:-1], hs[1:]))
+
+
+def test_dopri5_tableau_against_scipy_rk45():
+    """The Dormand-Prince 5(4) coefficients of the dopri5 restatement (torchdiffeq is absent: parity with IT stays unpinned)
+    against an independent published implementation, scipy's RK45: nodes c, stage matrix A and the 5th-order weights b are the
+    same numbers; the error weights are proportional -- torchdiffeq uses Shampine's embedded 4th-order weights
+    (b4 = 1951/21600, 0, 22642/50085, 451/720, -12231/42400, 649/6300, 1/60), whose difference to b5 is -2/3 of the classic
+    pair's that scipy carries."""
+    import numpy as np
+    from scipy.integrate._ivp.rk import RK45
+    from dimsum_amd.transport import integrators as I
+    assert np.allclose(np.asarray(I._DP_C[:5]), RK45.C[1:], rtol=0, atol=1e-15)
+    for i, row in enumerate(I._DP_A[:5]):                      # stages 2..6
+        assert np.allclose(np.asarray(row), RK45.A[i + 1, :len(row)], rtol=0, atol=1e-15), i
+    assert np.allclose(np.asarray(I._DP_A[5][:6]), RK45.B, rtol=0, atol=1e-15)       # 7th stage = the 5th-order solution (FSAL)
+    assert np.allclose(np.asarray(I._DP_B[:6]), RK45.B, rtol=0, atol=1e-15) and I._DP_B[6] == 0.0
+    assert np.allclose(np.asarray(I._DP_E), -2.0 / 3.0 * RK45.E, rtol=0, atol=1e-15)
