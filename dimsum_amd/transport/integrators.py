@@ -145,7 +145,25 @@ class ode:
         return (len(self.t) - 1) * self.nfe_per_step if self.stepper is not None else self.last_nfe
 
     def sample(self, x, model, return_trajectory=True, **model_kwargs):
-        """-> stacked states at every grid point like odeint (index [-1] = the sample), or only the last state."""
+        """-> stacked states at every grid point like odeint (index [-1] = the sample), or only the last state.
+        A TUPLE state (the likelihood ODE's (x, delta_logp)) is integrated as one flat system, the way torchdiffeq handles
+        tuples -- in particular dopri5's error norm runs over all components together -- and comes back as a tuple."""
+        if isinstance(x, tuple):
+            shapes, sizes = [c.shape for c in x], [c.numel() for c in x]
+            batch, dev = x[0].size(0), x[0].device
+
+            def unpack(v, lead=()):
+                return tuple(p.reshape(lead + tuple(sh)) for p, sh in zip(v.split(sizes, dim=-1), shapes))
+
+            def flat_drift(v, t, mdl, **kw):          # t arrives as ones(1) * t (the flat state has "batch" 1)
+                out = self.drift(unpack(v[0]), th.ones(batch, device=dev) * t[0], mdl, **kw)
+                return th.cat([o.reshape(-1) for o in out])[None]
+
+            inner = ode(flat_drift, t0=0.0, t1=1.0, sampler_type=self.method, num_steps=2, atol=self.atol, rtol=self.rtol)
+            inner.t = self.t
+            out = inner.sample(th.cat([c.reshape(-1) for c in x])[None], model, return_trajectory=return_trajectory, **model_kwargs)
+            self.last_nfe = inner.last_nfe
+            return unpack(out[:, 0], (out.shape[0],)) if return_trajectory else unpack(out[0])
         ones = th.ones(x.size(0), device=x.device)
 
         def f(t, x):

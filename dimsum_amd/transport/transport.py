@@ -1,6 +1,7 @@
-"""Flow-matching transport: training loss, ODE and SDE samplers around the denoiser (dimsum/transport/transport.py).
-The likelihood ODE and the DCT blurring of the path are not part of the denoiser hot path and are left out."""
+"""Flow-matching transport: training loss, ODE / SDE samplers and the likelihood ODE around the denoiser
+(dimsum/transport/transport.py). The DCT blurring of the path (never enabled by the published configs) is left out."""
 import enum
+import math
 
 import torch as th
 
@@ -36,6 +37,11 @@ class Transport:
         self.loss_type, self.model_type = loss_type, model_type
         self.path_sampler = plans[path_type](**path_args)
         self.train_eps, self.sample_eps, self.t_sample_mode = train_eps, sample_eps, t_sample_mode
+
+    def prior_logp(self, z):
+        """log density of the standard normal prior, per batch element (transport.py:69-77)"""
+        n = z[0].numel()
+        return -n / 2.0 * math.log(2 * math.pi) - z.reshape(z.shape[0], -1).pow(2).sum(1) / 2.0
 
     def check_interval(self, train_eps, sample_eps, *, diffusion_form="SBDM", sde=False, reverse=False, eval=False, last_step_size=0.0):
         """integration interval (transport.py:79-107)"""
@@ -128,6 +134,33 @@ class Sampler:
         t0, t1 = self.transport.check_interval(self.transport.train_eps, self.transport.sample_eps, sde=False, eval=True,
                                                reverse=reverse, last_step_size=0.0)
         return ode(drift=drift, t0=t0, t1=t1, sampler_type=sampling_method, num_steps=num_steps, atol=atol, rtol=rtol).sample
+
+    def sample_ode_likelihood(self, *, sampling_method="dopri5", num_steps=50, atol=1e-6, rtol=1e-3):
+        """-> fn(x, model, **model_kwargs) = (log p(x), z): integrates the probability-flow ODE from the data x (t = 1) back to the
+        prior (t = 0) together with the change of log density, whose divergence term is Hutchinson's estimator with one
+        Rademacher probe per drift evaluation (transport.py:388-443). The state is the pair (x, delta_logp), which the solver
+        treats as ONE flat system (integrators.ode). One denoiser evaluation (forward + input gradient) per drift evaluation;
+        the reference evaluates the model a second time for the same drift value."""
+        def likelihood_drift(state, t, model, **kw):
+            x, _ = state
+            eps = th.randint(2, x.size(), dtype=th.float, device=x.device) * 2 - 1
+            t = th.ones_like(t) * (1 - t)
+            with th.enable_grad():
+                x = x.detach().requires_grad_(True)
+                d = self.drift(x, t, model, **kw)
+                grad = th.autograd.grad(th.sum(d * eps), x)[0]
+            return -d.detach(), th.sum(grad * eps, dim=tuple(range(1, x.dim())))
+
+        t0, t1 = self.transport.check_interval(self.transport.train_eps, self.transport.sample_eps, sde=False, eval=True,
+                                               reverse=False, last_step_size=0.0)
+        solver = ode(drift=likelihood_drift, t0=t0, t1=t1, sampler_type=sampling_method, num_steps=num_steps, atol=atol, rtol=rtol)
+
+        @th.no_grad()
+        def _sample(x, model, **model_kwargs):
+            z, delta_logp = solver.sample((x, th.zeros(x.size(0)).to(x)), model, return_trajectory=False, **model_kwargs)
+            return self.transport.prior_logp(z) - delta_logp, z
+
+        return _sample
 
     def sample_sde(self, *, sampling_method="Euler", diffusion_form="SBDM", diffusion_norm=1.0, last_step="Mean",
                    last_step_size=0.04, num_steps=250):

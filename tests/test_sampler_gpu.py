@@ -94,3 +94,23 @@ def test_adacfg_and_sde_drift_hip_vs_cpu_oracle():
         return xs[-1].cpu().numpy()
     got, ref = _both(run_sde)
     assert_close(got, ref, 2e-3, 0, "sde euler-maruyama + mean last step", scale_atol=2e-4)
+
+
+def test_likelihood_ode_hip_vs_cpu_oracle(monkeypatch):
+    """Sampler.sample_ode_likelihood (transport.py:388-443) around the real denoiser: every drift evaluation is a forward AND an
+    input-gradient backward of the model through the HIP kernels, chained over 3 Euler steps from the data to the prior. Same
+    Rademacher probes on both sides (drawn on the CPU generator and moved: the reference draws them on the state's device)."""
+    from dimsum_amd.transport import Sampler, create_transport
+    x, y = T(seeded((2, 4, 32, 32), 95)), torch.tensor([7, 400])
+    real = torch.randint
+    monkeypatch.setattr(torch, "randint", lambda *a, device=None, **k: real(*a, **k).to(device or "cpu"))
+
+    def run(m, dev):
+        torch.manual_seed(96)
+        logp, z = Sampler(create_transport("GVP", "velocity")).sample_ode_likelihood(sampling_method="euler", num_steps=4)(
+            x.to(dev), m.forward, y=y.to(dev))
+        return logp.cpu().numpy(), z.cpu().numpy()
+    (lp, z), (lp_ref, z_ref) = _both(run)
+    assert np.isfinite(lp).all()
+    assert_close(z, z_ref, 1e-3, 0, "likelihood: state at the prior end", scale_atol=1e-4)
+    assert_close(lp, lp_ref, 2e-3, 0, "likelihood: log p", scale_atol=2e-4)

@@ -533,6 +533,12 @@ def gen_transport(_ns=None):
             traj = smp.sample_ode(sampling_method="euler", num_steps=9)(z, toy_denoiser, y=yz)
             arrs[f"ode_{pt}_{pred}"] = traj[-1]
             arrs[f"ode_{pt}_{pred}_mid"] = traj[4]
+            # likelihood ODE (transport.py:388-443): data -> prior with Hutchinson's divergence estimate, (x, delta_logp) tuple state;
+            # under no_grad like its callers (the reference sets x.requires_grad on the solver's state, which must be a leaf)
+            torch.manual_seed(3000)
+            with torch.no_grad():
+                logp, zprior = smp.sample_ode_likelihood(sampling_method="euler", num_steps=9)(z, toy_denoiser, y=yz)
+            arrs[f"lik_{pt}_{pred}_logp"], arrs[f"lik_{pt}_{pred}_z"] = logp, zprior
     arrs["sde_cases"] = np.array([repr(c) for c in SDE_CASES])
     save("transport", "dimsum/transport: Transport.training_losses (transport.py:127-164), Sampler.sample_sde (:286-341, "
          "integrators.py:5-73), Sampler.sample_ode on the euler grid (:343-386, integrators.py:98-111 with the declared torchdiffeq "

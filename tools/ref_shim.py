@@ -180,6 +180,12 @@ def load_transport():
 
         def odeint(fn, x, t, method=None, atol=None, rtol=None):
             assert method == "euler", "stand-in for torchdiffeq: fixed-grid euler only"
+            if isinstance(x, tuple):              # tuple states (the likelihood ODE): component-wise, one stacked tensor each
+                out = [x]
+                for a, b in zip(t[:-1], t[1:]):
+                    x = tuple(c + (b - a) * d for c, d in zip(x, fn(a, x)))
+                    out.append(x)
+                return tuple(torch.stack(c) for c in zip(*out))
             out = [x]
             for a, b in zip(t[:-1], t[1:]):
                 x = x + (b - a) * fn(a, x)
