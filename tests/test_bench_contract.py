@@ -130,10 +130,13 @@ def test_launcher_runs_real_children_and_relays_rank0_line(tmp_path):
             f"b.__file__ = {str(child)!r}\n"
             "sys.exit(b.launch_ranks(2, sys.argv[1:]))\n")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    ok = subprocess.run([sys.executable, "-c", prog, "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+    for attempt in range(2):          # (the rendezvous port is picked, released and re-bound by the children: one retry covers a lost race)
+        ok = subprocess.run([sys.executable, "-c", prog, "--gpus", "2"], capture_output=True, text=True, env=env, timeout=600)
+        if ok.returncode == 0:
+            break
     assert ok.returncode == 0, ok.stderr[-2000:]
     import json
     line = [l for l in ok.stdout.splitlines() if l.startswith("{")]
     assert len(line) == 1 and json.loads(line[0]) == {"world": 2, "argv": ["--gpus", "2"]}
-    bad = subprocess.run([sys.executable, "-c", prog, "--gpus", "2", "--fail"], capture_output=True, text=True, env=env, timeout=300)
+    bad = subprocess.run([sys.executable, "-c", prog, "--gpus", "2", "--fail"], capture_output=True, text=True, env=env, timeout=600)
     assert bad.returncode != 0
