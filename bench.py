@@ -28,7 +28,6 @@ attached only when the timed launches have exactly the profiled shape and kernel
 import argparse
 import json
 import os
-import socket
 import statistics
 import subprocess
 import sys
@@ -219,13 +218,6 @@ def cpu_baseline(name, latents=4, image_size=256, runs=3):
                       f"median {med:.2f} s (runs: {', '.join(f'{v:.2f}' for v in times)})"}
 
 
-def free_port():
-    """a TCP port nobody listens on right now (the rendezvous of the ranks this process launches)"""
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
 def launch_ranks(gpus, argv):
     """`python bench.py --gpus N` with N > 1 and no rank environment: this process is only the launcher. It starts N FRESH
     rank processes (one per GPU) as children through torch.distributed.run -- the same command line the driver would use,
@@ -234,8 +226,10 @@ def launch_ranks(gpus, argv):
     happened in this process (import torch does not initialise the device), and nothing is exec'ed."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), os.path.abspath(__file__), *argv]
+    # --standalone: torchrun hosts the rendezvous itself on a port it binds (no pick-then-rebind race); 127.0.0.1 because the
+    # container hostname may not resolve
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={gpus}", os.path.abspath(__file__), *argv]
     return subprocess.run(cmd, env=env).returncode
 
 

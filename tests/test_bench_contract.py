@@ -86,7 +86,7 @@ def test_gpus_n_without_rank_env_launches_child_ranks(monkeypatch):
     (cmd, env), = calls
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
     assert "--nnodes=1" in cmd and "--nproc-per-node=2" in cmd
-    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 0 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    assert "--standalone" in cmd and cmd[cmd.index("--local-addr") + 1] == "127.0.0.1"
     i = cmd.index(os.path.join(ROOT, "bench.py"))
     assert cmd[i + 1:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]
     assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
