@@ -193,7 +193,8 @@ def test_split_bf16_backward_vs_exact(B, L, heads, hd, self_attn):
         assert rms < 2e-5, (name, rms)
 
 
-@pytest.mark.parametrize("B,L,heads,hd,bias", [(2, 256, 8, 64, True), (1, 1024, 8, 72, False), (2, 100, 4, 24, True), (2, 256, 8, 48, True)])
+@pytest.mark.parametrize("B,L,heads,hd,bias", [(2, 256, 8, 64, True), (1, 1024, 8, 72, False), (2, 100, 4, 24, True), (2, 256, 8, 48, True),
+                                               (1, 200, 4, 32, True), (1, 328, 8, 64, False)])      # ragged key / query blocks of the 2-tile kernels
 def test_split_bf16_backward_vs_sdpa_math_float64(B, L, heads, hd, bias):
     """The backward that training and `bench.py --mode block` run under the reference's allow_tf32 policy (precision = 1,
     split-bf16 MFMA in xattn_bwd_dq_split / xattn_bwd_dkv_split) against an independent oracle: torch autograd through
