@@ -83,6 +83,14 @@ class XattnBwdParams(C.Structure):
                 + [(n, vp) for n in ("dout_ptr", "dqkv1_ptr", "dqkv2_ptr", "delta_ptr")])
 
 
+class GemmParams(C.Structure):
+    _fields_ = ([(n, i32) for n in ("m", "n", "k", "operand_dtype", "epilogue")] + [("out_scale", f32)]
+                + [(n, i64) for n in ("lda", "ldb", "ldc")]
+                + [(n, vp) for n in ("a_ptr", "b_ptr", "bias_ptr", "c_ptr", "timing_start_event", "timing_stop_event")])
+
+
+GEMM_EPI_F32, GEMM_EPI_GATED_GELU_SPLIT3, GEMM_EPI_GATED_GELU_F16, GEMM_EPI_F32_BIAS = 0, 1, 2, 3
+
 # every symbol include/dimsum_hip.h declares (tests check the library exports all of them)
 EXPORTS = (
     "dimsum_status_string", "dimsum_abi_version", "dimsum_target_arch",
@@ -91,6 +99,7 @@ EXPORTS = (
     "dimsum_causal_conv1d_fwd", "dimsum_causal_conv1d_bwd",
     "dimsum_norm_fwd", "dimsum_norm_bwd", "dimsum_token_transform", "dimsum_xattn_fusion_fwd", "dimsum_xattn_fusion_bwd",
     "dimsum_gated_gelu_fwd", "dimsum_gated_gelu_bwd", "dimsum_gated_gelu_fwd_split3", "dimsum_gated_gelu_bwd_split3", "dimsum_split3",
+    "dimsum_gemm_nt",
 )
 
 _lib = None
@@ -117,7 +126,7 @@ def load():
                         ("dimsum_causal_conv1d_fwd", ConvParams), ("dimsum_causal_conv1d_bwd", ConvBwdParams),
                         ("dimsum_norm_fwd", NormParams), ("dimsum_norm_bwd", NormBwdParams),
                         ("dimsum_token_transform", TtParams), ("dimsum_xattn_fusion_fwd", XattnParams),
-                        ("dimsum_xattn_fusion_bwd", XattnBwdParams)):
+                        ("dimsum_xattn_fusion_bwd", XattnBwdParams), ("dimsum_gemm_nt", GemmParams)):
         if hasattr(lib, name):
             fn = getattr(lib, name)
             fn.restype = C.c_int
@@ -137,7 +146,7 @@ def load():
     if hasattr(lib, "dimsum_ssm_scan_fwd_variant"):
         lib.dimsum_ssm_scan_fwd_variant.restype = C.c_int
         lib.dimsum_ssm_scan_fwd_variant.argtypes = [C.POINTER(SsmParams)]
-    if lib.dimsum_abi_version() != 10:
+    if lib.dimsum_abi_version() != 11:
         raise RuntimeError("dimsum_amd: libdimsum_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -1,0 +1,66 @@
+// gemm_nt.hip -- C ABI of the hand-written NT GEMM (gemm_nt_kernel.hpp): plain fp32 output, and the w12 GEMM of the gated MLP with
+// bias + tanh-GeLU + gate as its epilogue (dimsum/mlp.py:66-70), written directly as the operand image of the w3 GEMM.
+#include "gemm_nt_kernel.hpp"
+
+namespace dimsum {
+namespace gemm_nt {
+
+template <int kOp, int kEpi> int launch(const Args &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    const dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(512);
+    if (e0 || e1) hipExtLaunchKernelGGL((gemm_nt_kernel<kOp, kEpi>), grid, block, 0, s, e0, e1, 0, a);
+    else hipLaunchKernelGGL((gemm_nt_kernel<kOp, kEpi>), grid, block, 0, s, a);
+    return launch_status();
+}
+
+}  // namespace gemm_nt
+}  // namespace dimsum
+
+extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
+    using namespace dimsum;
+    using namespace dimsum::gemm_nt;
+    if (!p || !p->a_ptr || !p->b_ptr || !p->c_ptr) return DIMSUM_ERR_NULL;
+    if (p->operand_dtype != DIMSUM_F16 && p->operand_dtype != DIMSUM_BF16) return DIMSUM_ERR_DTYPE;
+    if (p->m <= 0 || p->n <= 0 || p->k < 2 * kBK || p->m % kBM != 0 || p->k % kBK != 0 || p->n % 4 != 0) return DIMSUM_ERR_SHAPE;
+    if (p->lda % 8 != 0 || p->ldb % 8 != 0 || p->lda < p->k || p->ldb < p->k || !aligned_to<char>(p->a_ptr, 16) || !aligned_to<char>(p->b_ptr, 16))
+        return DIMSUM_ERR_STRIDE;
+    // one 32-bit byte offset per lane inside a 256-row panel
+    if ((int64_t)256 * p->lda * 2 >= ((int64_t)1 << 31) || (int64_t)256 * p->ldb * 2 >= ((int64_t)1 << 31)) return DIMSUM_ERR_STRIDE;
+    Args a{};
+    a.A = reinterpret_cast<const char *>(p->a_ptr);
+    a.C = p->c_ptr;
+    a.lda = p->lda; a.ldb = p->ldb; a.ldc = p->ldc;
+    a.M = p->m; a.K = p->k;
+    a.tiles_m = p->m / kBM;
+    a.out_scale = p->out_scale;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipEvent_t e0 = reinterpret_cast<hipEvent_t>(p->timing_start_event), e1 = reinterpret_cast<hipEvent_t>(p->timing_stop_event);
+    const bool bf = p->operand_dtype == DIMSUM_BF16;
+    if (p->epilogue == DIMSUM_GEMM_EPI_F32 || p->epilogue == DIMSUM_GEMM_EPI_F32_BIAS) {
+        if (p->ldc % 4 != 0 || p->ldc < p->n || !aligned_to<char>(p->c_ptr, 16)) return DIMSUM_ERR_STRIDE;
+        const bool bias = p->epilogue == DIMSUM_GEMM_EPI_F32_BIAS;
+        if (bias && (!p->bias_ptr || !aligned_to<char>(p->bias_ptr, 16))) return DIMSUM_ERR_NULL;
+        a.B0 = a.B1 = reinterpret_cast<const char *>(p->b_ptr);
+        a.bias0 = reinterpret_cast<const float *>(p->bias_ptr);
+        a.N = p->n;
+        a.tiles_n = (p->n + kBN - 1) / kBN;
+        if (bias) return bf ? launch<kOpBf16, kEpiF32Bias>(a, s, e0, e1) : launch<kOpF16, kEpiF32Bias>(a, s, e0, e1);
+        return bf ? launch<kOpBf16, kEpiF32>(a, s, e0, e1) : launch<kOpF16, kEpiF32>(a, s, e0, e1);
+    }
+    if (p->epilogue == DIMSUM_GEMM_EPI_GATED_GELU_SPLIT3 || p->epilogue == DIMSUM_GEMM_EPI_GATED_GELU_F16) {
+        // b_ptr: the (2 F, K) weight of w12; n = 2 F; output: (M, 3 F) bf16 left image [hi | hi | lo] or (M, F) fp16
+        if (p->n % 8 != 0) return DIMSUM_ERR_SHAPE;
+        const int F = p->n / 2;
+        const bool img = p->epilogue == DIMSUM_GEMM_EPI_GATED_GELU_SPLIT3;
+        if (p->ldc % 4 != 0 || p->ldc < (img ? 3 : 1) * (int64_t)F || !aligned_to<char>(p->c_ptr, 8)) return DIMSUM_ERR_STRIDE;
+        if (p->bias_ptr && !aligned_to<char>(p->bias_ptr, 16)) return DIMSUM_ERR_STRIDE;
+        a.B0 = reinterpret_cast<const char *>(p->b_ptr);
+        a.B1 = a.B0 + (int64_t)F * p->ldb * 2;
+        a.bias0 = reinterpret_cast<const float *>(p->bias_ptr);
+        a.bias1 = a.bias0 ? a.bias0 + F : nullptr;
+        a.N = F;
+        a.tiles_n = (F + 127) / 128;
+        if (img) return bf ? launch<kOpBf16, kEpiGatedSplit3>(a, s, e0, e1) : launch<kOpF16, kEpiGatedSplit3>(a, s, e0, e1);
+        return bf ? launch<kOpBf16, kEpiGatedF16>(a, s, e0, e1) : launch<kOpF16, kEpiGatedF16>(a, s, e0, e1);
+    }
+    return DIMSUM_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,343 @@
+// gemm_nt_kernel.hpp -- C (M, N) = A (M, K) . B (N, K)^T on v_mfma_f32_16x16x32_{bf16,f16}, fp32 accumulation, with the epilogue of the
+// Linear it serves fused into the accumulator registers (gfx950 only).
+//
+// Both operands are K-contiguous rows ("NT"): A = the activations of a Linear (tokens x features), B = its weight (out x in) --
+// dimsum/mlp.py:66-70 (w12, w3), modules/mamba_simple.py in_proj / out_proj, attention_fusion.py qkv / proj. Under the reference's
+// allow_tf32 policy (train.py:20-21) the operands are split-bf16 images (operand_split.hip: [hi | hi | lo] x [hi | lo | hi] over 3 K),
+// under the scaled-fp16 policy plain fp16 rows: the kernel only sees 16-bit rows of length K.
+//
+// Structure (one workgroup = 8 waves = one 256 x 256 output tile, 64-deep K tiles, 128 KB of LDS):
+//  * half tiles: a K tile is four 16-KB half tiles A0, A1 (128 rows each), B0, B1 (128 weight rows each). A half tile lives in LDS as
+//    16 subtiles [16 rows][32 k] of 1024 B; inside a subtile byte p holds logical byte p ^ (((p >> 9) & 1) << 5), which makes the
+//    ds_read_b128 of an MFMA operand (lane l: row l & 15, k chunk l >> 4) hit 16 distinct 16-B slots per 16-lane service group.
+//  * LDS-DMA staging: every wave fills one row block (16 rows x 64 k = 2 subtiles) of a half tile with two global_load_lds_dwordx4; the
+//    LDS image of such a load is lane-linear, so the swizzle sits in the per-lane SOURCE address.
+//  * wave tile: wave (wr, wc) owns rows {mi * 128 + wr * 64 + [0, 64)} x cols {ni * 128 + wc * 32 + [0, 32)}, mi, ni in {0, 1}: each
+//    half tile feeds exactly one of the four quadrants' operand reads, so a half tile's slot is free one phase after it was read.
+//  * phases: a K tile is 4 phases; phase p = {ds_read the operand that becomes live | stage one half tile 7 phases ahead |
+//    s_waitcnt vmcnt(12): the half tile read NEXT phase has landed | lgkmcnt(0) | s_barrier | 16 MFMA (one quadrant x K = 64) |
+//    s_barrier}. The two wave rows run one barrier apart (the waves 0-3 / 4-7 of a workgroup share SIMDs pairwise): while one
+//    wave of a SIMD issues its 16 MFMAs, its partner reads LDS and issues DMA.
+//      P1: read B0(t)   stage A0(t+2)   mfma q(0,0) = A0 . B0
+//      P2: read B1(t)   stage B0(t+2)   mfma q(0,1) = A0 . B1
+//      P3: read A1(t)   stage B1(t+2)   mfma q(1,1) = A1 . B1
+//      P4: read A0(t+1) stage A1(t+2)   mfma q(1,0) = A1 . B0
+//    Hazards: (RAW) a half tile is read one phase after the counted vmcnt + barrier that retires its DMA in every wave; (WAR) a slot
+//    is re-staged one phase after its read, whose lgkmcnt(0) sits BEFORE the reading phase's first barrier.
+//  * the MFMA takes the weight fragment as its A operand and the activation fragment as B: D[n][m], so a lane ends up with 4
+//    CONSECUTIVE output columns of one row (16-B fp32 / 8-B 16-bit stores), and the two weight halves B0 / B1 can be two different
+//    row ranges of the weight: with B0 = W12[c .. c+128) and B1 = W12[F + c ..) a lane holds x1 and x2 of the same output element
+//    in acc[.][0] and acc[.][1] -- the gated GeLU of dimsum/mlp.py:66-70 is a per-register epilogue.
+#pragma once
+#include "common.hpp"
+
+namespace dimsum {
+namespace gemm_nt {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+constexpr int kBM = 256, kBN = 256, kBK = 64;
+constexpr int kHalf = 16384;               // bytes of one half tile (128 rows x 64 k x 2 B)
+constexpr int kParity = 4 * kHalf;         // bytes of one K tile in LDS
+constexpr int kSlotA0 = 0, kSlotA1 = kHalf, kSlotB0 = 2 * kHalf, kSlotB1 = 3 * kHalf;
+
+enum { kOpBf16 = 0, kOpF16 = 1 };
+enum { kEpiF32 = 0, kEpiGatedSplit3 = 1, kEpiGatedF16 = 2, kEpiF32Bias = 3 };
+
+struct Args {
+    const char *A, *B0, *B1;       // B0 / B1: first weight row of the two 128-row halves' matrices (B1 = B0 + 128 rows for a plain GEMM)
+    void *C;
+    const float *bias0, *bias1;    // per output column (gated: of x1 / x2), may be NULL
+    const float *row_scale;        // kEpiGatedF16: unused (the image carries a global scale) -- reserved
+    int64_t lda, ldb, ldc;         // in elements
+    int M, N, K;                   // N = columns per B half matrix row range handled as [0, N) for plain, hidden width F for gated
+    int tiles_m, tiles_n;
+    float out_scale;               // kEpiGatedF16: h is stored as fp16(h * out_scale)
+};
+
+template <int kOp> __device__ __forceinline__ f4 mma(const u32x4 &a, const u32x4 &b, f4 c) {
+    if constexpr (kOp == kOpBf16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+#define DIMSUM_DS_READ_B128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+#define DIMSUM_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define DIMSUM_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) = x sigmoid(2 u): the same form as token_transform.hip's gated GeLU pass
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return x * fast_rcp(1.0f + fast_exp2(-2.0f * kLog2e * u));
+}
+
+template <int kOp, int kEpi>
+__global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
+    __shared__ __attribute__((aligned(1024))) char lds[2 * kParity];
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = w >> 2, wc = w & 3;
+
+    // ---- block -> tile: every XCD (block b runs on XCD b % 8) walks a contiguous range of the tile list, ordered in groups of 8 tile
+    // rows (consecutive tiles walk down the rows of a group, then to the next tile column): the 32 workgroups an XCD runs at a time
+    // form an 8 x 4 patch that shares its A and B panels through that XCD's L2.
+    int tile_m, tile_n;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        constexpr int GM = 8;
+        const int per_group = GM * p.tiles_n;
+        const int g = t / per_group, within = t - g * per_group;
+        const int first_m = g * GM;
+        const int gsz = min(p.tiles_m - first_m, GM);
+        tile_n = within / gsz;
+        tile_m = first_m + (within - tile_n * gsz);
+    }
+    const int m0 = tile_m * kBM, n0 = tile_n * (kEpi == kEpiGatedSplit3 || kEpi == kEpiGatedF16 ? 128 : kBN);
+
+    // ---- staging addresses: wave w fills row block w (16 rows) of every half tile; lane l -> LDS byte 16 l of a subtile = logical row l >> 2,
+    // k chunk (l & 3) ^ (2 if l >= 32)
+    const int st_row = w * 16 + (lane >> 2);
+    const int st_kc = (lane & 3) ^ ((lane >> 5) << 1);
+    const unsigned a_voff = (unsigned)((st_row * p.lda + st_kc * 8) * 2);
+    // weight rows beyond N are clamped to the last row (their products land in columns the epilogue masks)
+    unsigned b_voff[2];
+    const char *b_base[2];
+    if constexpr (kEpi == kEpiGatedSplit3 || kEpi == kEpiGatedF16) {
+        b_base[0] = p.B0 + (int64_t)n0 * p.ldb * 2;
+        b_base[1] = p.B1 + (int64_t)n0 * p.ldb * 2;
+        const int row = min(st_row, p.N - 1 - n0);
+        b_voff[0] = b_voff[1] = (unsigned)((row * p.ldb + st_kc * 8) * 2);
+    } else {
+        b_base[0] = b_base[1] = p.B0 + (int64_t)n0 * p.ldb * 2;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int row = min(ni * 128 + st_row, p.N - 1 - n0);
+            b_voff[ni] = (unsigned)((row * p.ldb + st_kc * 8) * 2);
+        }
+    }
+    const char *a_base = p.A + (int64_t)m0 * p.lda * 2;
+    const int64_t a_half = (int64_t)128 * p.lda * 2;
+
+    // stage(kind, kt): the two DMA pieces (k halves) of this wave's row block of half tile `kind` of K tile kt
+    const unsigned st_lds = lds0 + w * 2048;
+    auto stage = [&](int slot, const char *base, unsigned voff, int kt) {      // base: wave-uniform (SGPR pair), voff: this lane's byte offset
+        const unsigned dst = st_lds + (kt & 1) * kParity + slot;
+        const char *s = base + (int64_t)kt * (kBK * 2);
+        __builtin_amdgcn_global_load_lds((glb_void_t *)(s + voff), (lds_void_t *)(uintptr_t)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void_t *)(s + 64 + voff), (lds_void_t *)(uintptr_t)(dst + 1024), 16, 0, 0);
+    };
+    auto stage_a0 = [&](int kt) { stage(kSlotA0, a_base, a_voff, kt); };
+    auto stage_a1 = [&](int kt) { stage(kSlotA1, a_base + a_half, a_voff, kt); };
+    auto stage_b0 = [&](int kt) { stage(kSlotB0, b_base[0], b_voff[0], kt); };
+    auto stage_b1 = [&](int kt) { stage(kSlotB1, b_base[1], b_voff[1], kt); };
+
+    // ---- operand read addresses: lane l reads row l & 15, k chunk l >> 4 of a subtile (swizzled: rows 8-15 swap chunk pairs)
+    const unsigned rd = (unsigned)((lane & 15) * 64 + (((lane >> 4) ^ (((lane >> 3) & 1) << 1)) * 16));
+    const unsigned a_rd = lds0 + wr * 4 * 2048 + rd;       // + slot A0 / A1, + i * 2048 (row block), + kh * 1024
+    const unsigned b_rd = lds0 + wc * 2 * 2048 + rd;       // + slot B0 / B1, + j * 2048, + kh * 1024
+
+    u32x4 a0[4][2], a1[4][2], b0[2][2], b1[2][2];
+    f4 acc[2][2][4][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[mi][ni][i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+#define DIMSUM_READ_A(dst, slot, par)                                                      \
+    do {                                                                                   \
+        const unsigned ad_ = a_rd + (par);                                                 \
+        DIMSUM_DS_READ_B128(dst[0][0], ad_, (slot) + 0 * 2048);                            \
+        DIMSUM_DS_READ_B128(dst[0][1], ad_, (slot) + 0 * 2048 + 1024);                     \
+        DIMSUM_DS_READ_B128(dst[1][0], ad_, (slot) + 1 * 2048);                            \
+        DIMSUM_DS_READ_B128(dst[1][1], ad_, (slot) + 1 * 2048 + 1024);                     \
+        DIMSUM_DS_READ_B128(dst[2][0], ad_, (slot) + 2 * 2048);                            \
+        DIMSUM_DS_READ_B128(dst[2][1], ad_, (slot) + 2 * 2048 + 1024);                     \
+        DIMSUM_DS_READ_B128(dst[3][0], ad_, (slot) + 3 * 2048);                            \
+        DIMSUM_DS_READ_B128(dst[3][1], ad_, (slot) + 3 * 2048 + 1024);                     \
+    } while (0)
+#define DIMSUM_READ_B(dst, slot, par)                                                      \
+    do {                                                                                   \
+        const unsigned ad_ = b_rd + (par);                                                 \
+        DIMSUM_DS_READ_B128(dst[0][0], ad_, (slot) + 0 * 2048);                            \
+        DIMSUM_DS_READ_B128(dst[0][1], ad_, (slot) + 0 * 2048 + 1024);                     \
+        DIMSUM_DS_READ_B128(dst[1][0], ad_, (slot) + 1 * 2048);                            \
+        DIMSUM_DS_READ_B128(dst[1][1], ad_, (slot) + 1 * 2048 + 1024);                     \
+    } while (0)
+    // one quadrant x K = 64: 16 MFMAs, the same accumulator recurs after 8
+#define DIMSUM_QUADRANT(MI, NI, AF, BF)                                                    \
+    do {                                                                                   \
+        __builtin_amdgcn_s_setprio(1);                                                     \
+        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                   \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                  \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                              \
+                    acc[MI][NI][i][j] = mma<kOp>(BF[j][kh], AF[i][kh], acc[MI][NI][i][j]); \
+        __builtin_amdgcn_s_setprio(0);                                                     \
+    } while (0)
+#define DIMSUM_PHASE_SYNC()                                                                \
+    do {                                                                                   \
+        DIMSUM_WAIT_LGKM0();                                                               \
+        __builtin_amdgcn_s_barrier();                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+    } while (0)
+#define DIMSUM_PHASE_END()                                                                 \
+    do {                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        __builtin_amdgcn_s_barrier();                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+    } while (0)
+
+    const int nk = p.K / kBK;      // >= 2
+
+    // ---- prologue: the 8 half tiles of K tiles 0 and 1 in read order; A0(0) and B0(0) must have landed before the first reads
+    stage_a0(0); stage_b0(0); stage_b1(0); stage_a1(0);
+    stage_a0(1); stage_b0(1); stage_b1(1); stage_a1(1);
+    DIMSUM_WAIT_VM(12);
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();       // from here on the second wave row runs one barrier behind the first
+    __builtin_amdgcn_sched_barrier(0);
+    DIMSUM_READ_A(a0, kSlotA0, 0);                    // "phase -1": A0(0), retired in every wave before anything re-stages its slot
+    DIMSUM_PHASE_SYNC();
+    DIMSUM_PHASE_END();
+
+    // ---- main loop: K tile kt is computed while K tile kt + 2 is staged into the slots kt frees
+    int kt = 0;
+    for (; kt < nk - 2; ++kt) {
+        const unsigned par = (kt & 1) * kParity, par_next = kParity - par;
+        // P1
+        DIMSUM_READ_B(b0, kSlotB0, par);
+        stage_a0(kt + 2);
+        DIMSUM_WAIT_VM(12);
+        DIMSUM_PHASE_SYNC();
+        DIMSUM_QUADRANT(0, 0, a0, b0);
+        DIMSUM_PHASE_END();
+        // P2
+        DIMSUM_READ_B(b1, kSlotB1, par);
+        stage_b0(kt + 2);
+        DIMSUM_WAIT_VM(12);
+        DIMSUM_PHASE_SYNC();
+        DIMSUM_QUADRANT(0, 1, a0, b1);
+        DIMSUM_PHASE_END();
+        // P3
+        DIMSUM_READ_A(a1, kSlotA1, par);
+        stage_b1(kt + 2);
+        DIMSUM_WAIT_VM(12);
+        DIMSUM_PHASE_SYNC();
+        DIMSUM_QUADRANT(1, 1, a1, b1);
+        DIMSUM_PHASE_END();
+        // P4
+        DIMSUM_READ_A(a0, kSlotA0, par_next);
+        stage_a1(kt + 2);
+        DIMSUM_WAIT_VM(12);
+        DIMSUM_PHASE_SYNC();
+        DIMSUM_QUADRANT(1, 0, a1, b0);
+        DIMSUM_PHASE_END();
+    }
+    // ---- the last two K tiles: nothing left to stage, the counted waits run down (5, 4, 3, 2, 1, 0 half tiles behind the one needed next)
+    {
+        const unsigned par = (kt & 1) * kParity, par_next = kParity - par;
+        DIMSUM_READ_B(b0, kSlotB0, par);
+        DIMSUM_WAIT_VM(10);
+        DIMSUM_PHASE_SYNC();
+        DIMSUM_QUADRANT(0, 0, a0, b0);
+        DIMSUM_PHASE_END();
+        DIMSUM_READ_B(b1, kSlotB1, par);
+        DIMSUM_WAIT_VM(8);
+        DIMSUM_PHASE_SYNC();
+        DIMSUM_QUADRANT(0, 1, a0, b1);
+        DIMSUM_PHASE_END();
+        DIMSUM_READ_A(a1, kSlotA1, par);
+        DIMSUM_WAIT_VM(6);
+        DIMSUM_PHASE_SYNC();
+        DIMSUM_QUADRANT(1, 1, a1, b1);
+        DIMSUM_PHASE_END();
+        DIMSUM_READ_A(a0, kSlotA0, par_next);
+        DIMSUM_WAIT_VM(4);
+        DIMSUM_PHASE_SYNC();
+        DIMSUM_QUADRANT(1, 0, a1, b0);
+        DIMSUM_PHASE_END();
+        DIMSUM_READ_B(b0, kSlotB0, par_next);
+        DIMSUM_WAIT_VM(2);
+        DIMSUM_PHASE_SYNC();
+        DIMSUM_QUADRANT(0, 0, a0, b0);
+        DIMSUM_PHASE_END();
+        DIMSUM_READ_B(b1, kSlotB1, par_next);
+        DIMSUM_WAIT_VM(0);
+        DIMSUM_PHASE_SYNC();
+        DIMSUM_QUADRANT(0, 1, a0, b1);
+        DIMSUM_PHASE_END();
+        DIMSUM_READ_A(a1, kSlotA1, par_next);
+        DIMSUM_PHASE_SYNC();
+        DIMSUM_QUADRANT(1, 1, a1, b1);
+        DIMSUM_PHASE_END();
+        DIMSUM_QUADRANT(1, 0, a1, b0);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();       // matches the second wave row's extra barrier
+
+    // ---- epilogue: acc[mi][ni][i][j] = rows m0 + mi * 128 + wr * 64 + i * 16 + (lane & 15), 4 columns from ni * 128 + wc * 32 + j * 16 + (lane >> 4) * 4
+    const int erow = m0 + wr * 64 + (lane & 15);
+    const int ecol = wc * 32 + (lane >> 4) * 4;
+    if constexpr (kEpi == kEpiF32 || kEpi == kEpiF32Bias) {
+        float *C = reinterpret_cast<float *>(p.C);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + ni * 128 + ecol + j * 16;
+                if (col < p.N) {
+                    f4 bv = f4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (kEpi == kEpiF32Bias) bv = *reinterpret_cast<const f4 *>(p.bias0 + col);
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int row = erow + mi * 128 + i * 16;
+                            *reinterpret_cast<f4 *>(C + (int64_t)row * p.ldc + col) = acc[mi][ni][i][j] + bv;
+                        }
+                }
+            }
+    } else {
+        // gated GeLU: h = gelu_tanh(x1 + b1) (x2 + b2) with x1 = acc[mi][0], x2 = acc[mi][1] of the same hidden column
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + ecol + j * 16;
+            if (col < p.N) {
+                f4 bv1 = f4{0.f, 0.f, 0.f, 0.f}, bv2 = bv1;
+                if (p.bias0) {
+                    bv1 = *reinterpret_cast<const f4 *>(p.bias0 + col);
+                    bv2 = *reinterpret_cast<const f4 *>(p.bias1 + col);
+                }
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = erow + mi * 128 + i * 16;
+                        const f4 x1 = acc[mi][0][i][j] + bv1, x2 = acc[mi][1][i][j] + bv2;
+                        f32x4 h;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) h.v[e] = gelu_tanh_f(x1[e]) * x2[e];
+                        if constexpr (kEpi == kEpiGatedSplit3) {
+                            st_split3<true>(reinterpret_cast<unsigned short *>(p.C) + (int64_t)row * p.ldc, col, p.N, h);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) h.v[e] *= p.out_scale;
+                            st4<__half>(reinterpret_cast<__half *>(p.C) + (int64_t)row * p.ldc + col, h);
+                        }
+                    }
+            }
+        }
+    }
+}
+
+}  // namespace gemm_nt
+}  // namespace dimsum

@@ -52,7 +52,11 @@ def frozen_weights():
 
 
 def _cached(kind, weight, make):
-    if _frozen is None:
+    # Under hipGraph capture the cache is bypassed: a captured GEMM holds the raw pointer of the image it read, and the graph
+    # (hip_graph.GraphedForward, kept by the caller across batches) outlives this scope -- a cached image would be freed under it
+    # and would also freeze the weights of the first capture into every replay. Built inside the capture, the conversion kernel
+    # is part of the graph (it re-reads the parameter on every replay) and its output lives in the graph's private pool.
+    if _frozen is None or (weight.is_cuda and torch.cuda.is_current_stream_capturing()):
         return make()
     key = (kind, weight.data_ptr(), tuple(weight.shape), tuple(weight.stride()), weight.dtype)
     hit = _frozen.get(key)

@@ -454,6 +454,63 @@ def split3_rows(x, left):
     return out
 
 
+def gemm_nt_supported(a, b, gated=False):
+    """shapes the hand-written NT GEMM takes (csrc/gemm_nt_kernel.hpp): 256-row panels of 16-bit rows, 64-deep K tiles"""
+    if not (a.is_cuda and a.dim() == 2 and b.dim() == 2 and a.dtype == b.dtype and a.dtype in (torch.bfloat16, torch.float16)):
+        return False
+    M, K = a.shape
+    N = b.shape[0]
+    return (b.shape[1] == K and M > 0 and M % 256 == 0 and K % 64 == 0 and K >= 128 and N % (8 if gated else 4) == 0
+            and a.stride(1) == 1 and b.stride(1) == 1 and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0
+            and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and 512 * max(a.stride(0), b.stride(0)) < 2 ** 31)
+
+
+def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=None):
+    """a (M, K) @ b (N, K)^T on the hand-written MFMA kernel, 16-bit operands (bfloat16: split-bf16 images over 3 K; float16: scaled rows),
+    fp32 accumulation.
+      epilogue "f32"          -> (M, N) float32 (+ bias[N])
+               "gated_split3" -> b = the (2F, K) w12 weight image, bias (2F) or None: the LEFT split-bf16 image (M, 3F) bfloat16 of
+                                 gelu_tanh(x1 + b1) * (x2 + b2)   (mlp.py:66-70; the fp32 (M, 2F) x12 never exists)
+               "gated_f16"    -> same, (M, F) float16 of h * out_scale
+    events: optional (start, stop) raw hipEvent_t handles recorded at the kernel's dispatch boundaries (bench.py)."""
+    _gpu(a, b, bias)
+    gated = epilogue != "f32"
+    _check(gemm_nt_supported(a, b, gated), "gemm_nt: unsupported operands (M % 256, K % 64, K >= 128, 16-bit K-contiguous rows, 16-byte aligned)")
+    M, K = a.shape
+    N = b.shape[0]
+    P = _lib.GemmParams()
+    P.m, P.n, P.k = M, N, K
+    P.operand_dtype = _DT[a.dtype]
+    P.out_scale = float(out_scale)
+    P.lda, P.ldb = a.stride(0), b.stride(0)
+    if bias is not None:
+        _check(bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == N, "gemm_nt: bias must be (N,) float32")
+    if epilogue == "f32":
+        P.epilogue = _lib.GEMM_EPI_F32 if bias is None else _lib.GEMM_EPI_F32_BIAS
+        if out is None:
+            out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+        _check(out.dtype == torch.float32 and out.shape == (M, N) and out.stride(1) == 1, "gemm_nt: out must be (M, N) float32 rows")
+    elif epilogue == "gated_split3":
+        P.epilogue = _lib.GEMM_EPI_GATED_GELU_SPLIT3
+        if out is None:
+            out = torch.empty((M, 3 * (N // 2)), device=a.device, dtype=torch.bfloat16)
+        _check(out.dtype == torch.bfloat16 and out.shape == (M, 3 * (N // 2)) and out.stride(1) == 1, "gemm_nt: out must be (M, 3F) bfloat16 rows")
+    elif epilogue == "gated_f16":
+        P.epilogue = _lib.GEMM_EPI_GATED_GELU_F16
+        if out is None:
+            out = torch.empty((M, N // 2), device=a.device, dtype=torch.float16)
+        _check(out.dtype == torch.float16 and out.shape == (M, N // 2) and out.stride(1) == 1, "gemm_nt: out must be (M, F) float16 rows")
+    else:
+        raise ValueError(f"gemm_nt: unknown epilogue {epilogue!r}")
+    P.ldc = out.stride(0)
+    P.a_ptr, P.b_ptr, P.bias_ptr, P.c_ptr = _ptr(a), _ptr(b), _ptr(bias), _ptr(out)
+    if events is not None:
+        P.timing_start_event, P.timing_stop_event = events
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.load().dimsum_gemm_nt(P, _stream(a)), "gemm_nt")
+    return out
+
+
 def gated_gelu_bwd(x12, bias, dh, need_dbias=True, split3=False):
     """-> (dx12, dbias or None).  split3: dx12 as a split-bf16 operand image in weight order, (..., 3 * 2H) bfloat16 [hi | lo | hi]"""
     _gpu(x12, bias, dh)

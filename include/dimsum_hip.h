@@ -12,6 +12,8 @@
  *   dimsum_token_transform     <- einops/flip/local_scan/DWT/DCT chains          dimsum/models_dim.py:572-604,656-705,876-928,1496-1524
  *   dimsum_xattn_fusion_fwd/_bwd <- F.scaled_dot_product_attention x2 (+ autograd)  dimsum/attention_fusion.py:44-75
  *   dimsum_gated_gelu_fwd/_bwd <- gelu_tanh(x1) * x2                             dimsum/mlp.py:66-70
+ *   dimsum_gemm_nt             <- nn.Linear / F.linear of the bias-free projections (cuBLAS TF32 GEMMs under train.py:20-21), and
+ *                                 w12 + bias + gelu_tanh(x1) * x2 of the GatedMLP as ONE kernel    dimsum/mlp.py:49-70
  *
  * Conventions (same as the reference's host wrappers, minus ATen):
  *   - plain pointers, sizes and ELEMENT strides; no torch types. The caller allocates every output, including the
@@ -31,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DIMSUM_ABI_VERSION 10
+#define DIMSUM_ABI_VERSION 11
 
 typedef enum {
     DIMSUM_OK = 0,
@@ -323,6 +325,37 @@ int dimsum_gated_gelu_bwd(const void *x12, const void *bias, const void *dh, voi
  * paired with left-order images of W12^T (input gradient) and, through the (3 rows, .) view of both, of the MLP input (weight gradient) */
 int dimsum_gated_gelu_bwd_split3(const void *x12, const void *bias, const void *dh, void *dx12_image, void *dbias, int64_t rows,
                                  int64_t hidden, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * NT GEMM with a fused Linear epilogue: C (m, n) = A (m, k) . B (n, k)^T, 16-bit operands (bf16 or fp16 rows, k contiguous), fp32
+ * accumulation on v_mfma_f32_16x16x32_*. Replaces the library GEMM behind F.linear(x, weight) for the large bias-free projections
+ * of the denoiser (dimsum/mlp.py:66-70 w12 / w3, mamba_simple.py in_proj / out_proj, attention_fusion.py qkv / proj). The operands are
+ * what the producer kernels of this library write: split-bf16 images over 3 K ([hi | hi | lo] rows against [hi | lo | hi] weights:
+ * the reference's TF32 policy, dimsum_split3) or scaled fp16 rows.
+ *   epilogue F32            : C fp32 (m, n), row stride ldc
+ *            F32_BIAS       : C = A B^T + bias[n]
+ *            GATED_GELU_SPLIT3 : B = the w12 weight (n = 2 F rows: x1 rows [0, F), x2 rows [F, 2 F)), bias (2 F) fp32 or NULL;
+ *                             C = the LEFT split-bf16 image (m, 3 F) of h = gelu_tanh(x1 + b1) * (x2 + b2), ldc in bf16 elements:
+ *                             the fp32 x12 tensor of mlp.py:68 never exists
+ *            GATED_GELU_F16 : same, C = fp16 (m, F) of h * out_scale
+ * Shapes: m % 256 == 0, k % 64 == 0, k >= 128, n % 4 == 0 (gated: n % 8 == 0); lda, ldb % 8 == 0; a_ptr, b_ptr 16-byte aligned.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef enum {
+    DIMSUM_GEMM_EPI_F32 = 0, DIMSUM_GEMM_EPI_GATED_GELU_SPLIT3 = 1, DIMSUM_GEMM_EPI_GATED_GELU_F16 = 2, DIMSUM_GEMM_EPI_F32_BIAS = 3
+} dimsum_gemm_epilogue_t;
+
+typedef struct {
+    int32_t m, n, k;
+    int32_t operand_dtype;        /* DIMSUM_BF16 or DIMSUM_F16 (both operands) */
+    int32_t epilogue;             /* dimsum_gemm_epilogue_t */
+    float out_scale;              /* GATED_GELU_F16 only */
+    int64_t lda, ldb, ldc;        /* row strides in elements of the respective dtype */
+    const void *a_ptr, *b_ptr, *bias_ptr;
+    void *c_ptr;
+    void *timing_start_event, *timing_stop_event;   /* optional hipEvent_t pair recorded at the kernel's own dispatch boundaries */
+} dimsum_gemm_params_t;
+
+int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream);
 
 #ifdef __cplusplus
 }

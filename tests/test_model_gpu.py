@@ -283,8 +283,25 @@ def test_hip_graph_replay_is_bit_identical(tf32, monkeypatch):
     assert not torch.equal(ref2, before) and torch.equal(g(x, t, y), ref2)
     z, y = torch.randn(4, 4, 32, 32, device="cuda", generator=gen), torch.randint(0, 1000, (4,), device="cuda", generator=gen)
     a = sample_batch(m, z, y, num_steps=5, gather=False)
-    b = sample_batch(m, z, y, num_steps=5, gather=False, hip_graph={})
+    graphs = {}
+    b = sample_batch(m, z, y, num_steps=5, gather=False, hip_graph=graphs)
     assert torch.equal(a, b)
+    # the SAME graphs dict across batches (sample_ddp.main with --hip-graph): the graph was captured inside the first batch's
+    # frozen_weights() scope, which is closed now -- a replay must neither read weight images that died with that scope nor
+    # keep the first capture's weights. Churn the allocator and update weights through .data in between.
+    junk = [torch.randn(1 << 20, device="cuda") for _ in range(8)]
+    del junk
+    torch.cuda.empty_cache()
+    for mm in m.modules():
+        if hasattr(mm, "in_proj"):
+            mm.in_proj.weight.data.mul_(0.97)
+        if hasattr(mm, "w12"):
+            mm.w12.weight.data.mul_(1.03)
+    junk = [torch.full((1 << 18,), float("nan"), device="cuda") for _ in range(16)]     # whatever was freed is overwritten
+    del junk
+    a2 = sample_batch(m, z, y, num_steps=5, gather=False)
+    b2 = sample_batch(m, z, y, num_steps=5, gather=False, hip_graph=graphs)
+    assert not torch.equal(a2, a) and torch.equal(a2, b2)
 
 
 @pytest.mark.gpu

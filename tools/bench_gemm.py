@@ -1,0 +1,156 @@
+"""tools/bench_gemm.py (GPU box): the hand-written NT GEMM (csrc/gemm_nt_kernel.hpp) against the library GEMM it replaces.
+
+  python tools/bench_gemm.py --check          correctness + race screen on small / ragged / full shapes
+  python tools/bench_gemm.py --perf           interleaved A / B rounds on the DiM-L/2 shapes (random operands), TFLOP/s
+Numbers quoted in DESIGN.md section 3.5 come from here."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dimsum_amd import native  # noqa: E402
+
+
+def rnd(shape, dtype, seed, scale=1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(shape, device="cuda", generator=g) * scale).to(dtype)
+
+
+def check_plain(M, N, K, dtype, reps=3):
+    a, b = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2)
+    ref = (a.double() @ b.double().t())
+    got = native.gemm_nt(a, b)
+    err = (got.double() - ref).abs().max().item() / ref.abs().max().item()
+    same = all(torch.equal(native.gemm_nt(a, b), got) for _ in range(reps))
+    lib = torch.mm(a, b.t(), out_dtype=torch.float32)
+    lib_err = (lib.double() - ref).abs().max().item() / ref.abs().max().item()
+    ok = err < 2e-6 * max(1.0, (K / 1024) ** 0.5) + 1e-7 and same
+    print(f"plain {str(dtype)[6:]:9s} M={M:6d} N={N:5d} K={K:5d}  rel err {err:.2e} (library {lib_err:.2e})  repeatable {same}  {'ok' if ok else 'FAIL'}", flush=True)
+    return ok
+
+
+def check_bias(M, N, K, dtype):
+    a, b = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2)
+    bias = rnd((N,), torch.float32, 3)
+    ref = a.double() @ b.double().t() + bias.double()
+    got = native.gemm_nt(a, b, bias=bias)
+    err = (got.double() - ref).abs().max().item() / ref.abs().max().item()
+    ok = err < 3e-6
+    print(f"bias  {str(dtype)[6:]:9s} M={M:6d} N={N:5d} K={K:5d}  rel err {err:.2e}  {'ok' if ok else 'FAIL'}", flush=True)
+    return ok
+
+
+def check_gated(M, F, H, with_bias=True):
+    """the split3 epilogue against the unfused pair (library GEMM + gated GeLU pass) and against float64"""
+    x = rnd((M, H), torch.float32, 4)
+    w12 = rnd((2 * F, H), torch.float32, 5, scale=H ** -0.5)
+    bias = rnd((2 * F,), torch.float32, 6, scale=0.1) if with_bias else None
+    x3 = native.split3_rows(x, left=True)
+    w3 = native.split3_rows(w12, left=False)
+    got = native.gemm_nt(x3, w3, bias=bias, epilogue="gated_split3")                 # (M, 3F) bf16 [hi | hi | lo]
+    x12 = x.double() @ w12.double().t()
+    if bias is not None:
+        x12 = x12 + bias.double()
+    ref = torch.nn.functional.gelu(x12[:, :F], approximate="tanh") * x12[:, F:]
+    hi, hi2, lo = got[:, :F].double(), got[:, F:2 * F].double(), got[:, 2 * F:].double()
+    err = ((hi + lo) - ref).abs().max().item() / ref.abs().max().item()
+    unf = native.gated_gelu_fwd(torch.mm(x3, w3.t(), out_dtype=torch.float32), bias, split3=True)
+    uerr = ((unf[:, :F].double() + unf[:, 2 * F:].double()) - ref).abs().max().item() / ref.abs().max().item()
+    ok = err < 2e-5 and torch.equal(hi, hi2)
+    print(f"gated split3 M={M:6d} F={F:5d} H={H:5d} bias={with_bias}  rel err vs float64 {err:.2e} (unfused pair {uerr:.2e})  {'ok' if ok else 'FAIL'}", flush=True)
+    # fp16 image
+    s = 8.0
+    x16, w16 = x.half(), w12.half()
+    g16 = native.gemm_nt(x16, w16, bias=bias, epilogue="gated_f16", out_scale=s)
+    x12h = x16.double() @ w16.double().t()
+    if bias is not None:
+        x12h = x12h + bias.double()
+    refh = torch.nn.functional.gelu(x12h[:, :F], approximate="tanh") * x12h[:, F:]
+    e16 = (g16.double() / s - refh).abs().max().item() / refh.abs().max().item()
+    ok16 = e16 < 1e-3
+    print(f"gated f16    M={M:6d} F={F:5d} H={H:5d}               rel err vs float64 (same operands) {e16:.2e}  {'ok' if ok16 else 'FAIL'}", flush=True)
+    return ok and ok16
+
+
+def timed(fn, n):
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(n):
+        fn()
+    ev[1].record()
+    torch.cuda.synchronize()
+    return ev[0].elapsed_time(ev[1]) / n
+
+
+def perf(shapes, rounds, inner):
+    out = []
+    for name, M, N, K, dtype in shapes:
+        a, b = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, scale=K ** -0.5)
+        c = torch.empty((M, N), device="cuda", dtype=torch.float32)
+        arms = {"library": lambda: torch.mm(a, b.t(), out=c) if False else torch.mm(a, b.t(), out_dtype=torch.float32),
+                "gemm_nt": lambda: native.gemm_nt(a, b, out=c)}
+        if N % 8 == 0:
+            h3 = torch.empty((M, 3 * (N // 2)), device="cuda", dtype=torch.bfloat16)
+            h16 = torch.empty((M, N // 2), device="cuda", dtype=torch.float16)
+            if dtype == torch.bfloat16:
+                arms["gemm_nt+gate->split3"] = lambda: native.gemm_nt(a, b, epilogue="gated_split3", out=h3)
+                arms["library+gate pass"] = lambda: native.gated_gelu_fwd(torch.mm(a, b.t(), out_dtype=torch.float32), None, split3=True)
+            else:
+                arms["gemm_nt+gate->f16"] = lambda: native.gemm_nt(a, b, epilogue="gated_f16", out=h16)
+        for f in arms.values():
+            f()
+        torch.cuda.synchronize()
+        res = {k: [] for k in arms}
+        for _ in range(rounds):
+            for k, f in arms.items():
+                res[k].append(timed(f, inner))
+        fl = 2.0 * M * N * K
+        row = {"shape": name, "M": M, "N": N, "K": K, "dtype": str(dtype)[6:]}
+        for k, v in res.items():
+            v.sort()
+            med = v[len(v) // 2]
+            row[k] = {"ms_median": round(med, 4), "ms_min": round(v[0], 4), "TF_median": round(fl / med / 1e9, 1)}
+        print(json.dumps(row), flush=True)
+        out.append(row)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check", action="store_true")
+    ap.add_argument("--perf", action="store_true")
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--inner", type=int, default=10)
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    ok = True
+    if args.check:
+        for dtype in (torch.bfloat16, torch.float16):
+            for (M, N, K) in ((256, 256, 128), (256, 256, 192), (512, 512, 256), (512, 384, 320), (768, 1152, 1152), (256, 132, 128),
+                              (1024, 8192, 3072)):
+                ok &= check_plain(M, N, K, dtype)
+        ok &= check_bias(512, 384, 256, torch.bfloat16)
+        ok &= check_gated(512, 256, 128)
+        ok &= check_gated(512, 1536, 384, with_bias=False)
+        ok &= check_gated(1024, 4608, 1152)
+        ok &= check_plain(65536, 8192, 3072, torch.bfloat16, reps=2) if not args.quick else True
+        print("CHECK", "ok" if ok else "FAILED", flush=True)
+    if args.perf:
+        shapes = [("w12 split3", 65536, 8192, 3072, torch.bfloat16),
+                  ("w3 split3", 65536, 1024, 12288, torch.bfloat16),
+                  ("in_proj split3", 65536, 2048, 3072, torch.bfloat16),
+                  ("w12 fp16", 65536, 8192, 1024, torch.float16),
+                  ("w3 fp16", 65536, 1024, 4096, torch.float16),
+                  ("square 8192 bf16", 8192, 8192, 8192, torch.bfloat16)]
+        if args.quick:
+            shapes = shapes[:1]
+        perf(shapes, args.rounds, args.inner)
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()
