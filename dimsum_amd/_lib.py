@@ -86,7 +86,8 @@ class XattnBwdParams(C.Structure):
 class GemmParams(C.Structure):
     _fields_ = ([(n, i32) for n in ("m", "n", "k", "operand_dtype", "epilogue")] + [("out_scale", f32)]
                 + [(n, i64) for n in ("lda", "ldb", "ldc")]
-                + [(n, vp) for n in ("a_ptr", "b_ptr", "bias_ptr", "c_ptr", "timing_start_event", "timing_stop_event")])
+                + [(n, vp) for n in ("a_ptr", "b_ptr", "bias_ptr", "c_ptr", "timing_start_event", "timing_stop_event")]
+                + [(n, i32) for n in ("tune_variant", "tune_group_m", "tune_start_delay")])
 
 
 GEMM_EPI_F32, GEMM_EPI_GATED_GELU_SPLIT3, GEMM_EPI_GATED_GELU_F16, GEMM_EPI_F32_BIAS = 0, 1, 2, 3

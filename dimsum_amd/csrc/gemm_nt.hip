@@ -5,10 +5,10 @@
 namespace dimsum {
 namespace gemm_nt {
 
-template <int kOp, int kEpi> int launch(const Args &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+template <int kOp, int kEpi, int kVar = 0> int launch(const Args &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     const dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(512);
-    if (e0 || e1) hipExtLaunchKernelGGL((gemm_nt_kernel<kOp, kEpi>), grid, block, 0, s, e0, e1, 0, a);
-    else hipLaunchKernelGGL((gemm_nt_kernel<kOp, kEpi>), grid, block, 0, s, a);
+    if (e0 || e1) hipExtLaunchKernelGGL((gemm_nt_kernel<kOp, kEpi, kVar>), grid, block, 0, s, e0, e1, 0, a);
+    else hipLaunchKernelGGL((gemm_nt_kernel<kOp, kEpi, kVar>), grid, block, 0, s, a);
     return launch_status();
 }
 
@@ -24,7 +24,8 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
     if (p->lda % 8 != 0 || p->ldb % 8 != 0 || p->lda < p->k || p->ldb < p->k || !aligned_to<char>(p->a_ptr, 16) || !aligned_to<char>(p->b_ptr, 16))
         return DIMSUM_ERR_STRIDE;
     // one 32-bit byte offset per lane inside a 256-row panel
-    if ((int64_t)256 * p->lda * 2 >= ((int64_t)1 << 31) || (int64_t)256 * p->ldb * 2 >= ((int64_t)1 << 31)) return DIMSUM_ERR_STRIDE;
+    if ((int64_t)256 * p->lda * 2 >= ((int64_t)1 << 31) || (int64_t)256 * p->ldb * 2 >= ((int64_t)1 << 31) || (int64_t)257 * p->ldc * 4 >= ((int64_t)1 << 31))
+        return DIMSUM_ERR_STRIDE;
     Args a{};
     a.A = reinterpret_cast<const char *>(p->a_ptr);
     a.C = p->c_ptr;
@@ -32,6 +33,8 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
     a.M = p->m; a.K = p->k;
     a.tiles_m = p->m / kBM;
     a.out_scale = p->out_scale;
+    a.group_m = p->tune_group_m > 0 ? p->tune_group_m : 4;
+    a.start_delay = p->tune_start_delay;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t e0 = reinterpret_cast<hipEvent_t>(p->timing_start_event), e1 = reinterpret_cast<hipEvent_t>(p->timing_stop_event);
     const bool bf = p->operand_dtype == DIMSUM_BF16;
@@ -43,15 +46,33 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
         a.bias0 = reinterpret_cast<const float *>(p->bias_ptr);
         a.N = p->n;
         a.tiles_n = (p->n + kBN - 1) / kBN;
-        if (bias) return bf ? launch<kOpBf16, kEpiF32Bias>(a, s, e0, e1) : launch<kOpF16, kEpiF32Bias>(a, s, e0, e1);
-        return bf ? launch<kOpBf16, kEpiF32>(a, s, e0, e1) : launch<kOpF16, kEpiF32>(a, s, e0, e1);
+        constexpr int kShip = kVarFullLineStores | kVarNtStores;      // 128-byte row segments, streaming stores (tools/bench_gemm.py --tune)
+        if (bias) return bf ? launch<kOpBf16, kEpiF32Bias, kShip>(a, s, e0, e1) : launch<kOpF16, kEpiF32Bias, kShip>(a, s, e0, e1);
+        if (bf) switch (p->tune_variant) {       // tuning builds only
+            case 0: break;
+            case 100: return launch<kOpBf16, kEpiF32, 0>(a, s, e0, e1);
+            case 1: return launch<kOpBf16, kEpiF32, 1>(a, s, e0, e1);
+            case 2: return launch<kOpBf16, kEpiF32, 2>(a, s, e0, e1);
+            case 4: return launch<kOpBf16, kEpiF32, 4>(a, s, e0, e1);
+            case 8: return launch<kOpBf16, kEpiF32, 8>(a, s, e0, e1);
+            case 12: return launch<kOpBf16, kEpiF32, 12>(a, s, e0, e1);
+            case 16: return launch<kOpBf16, kEpiF32, 16>(a, s, e0, e1);
+            case 3: return launch<kOpBf16, kEpiF32, 3>(a, s, e0, e1);
+            case 40: return launch<kOpBf16, kEpiF32, 40>(a, s, e0, e1);
+            case 44: return launch<kOpBf16, kEpiF32, 44>(a, s, e0, e1);
+            case 72: return launch<kOpBf16, kEpiF32, 72>(a, s, e0, e1);
+            case 104: return launch<kOpBf16, kEpiF32, 104>(a, s, e0, e1);
+            default: return DIMSUM_ERR_UNSUPPORTED;
+        }
+        return bf ? launch<kOpBf16, kEpiF32, kShip>(a, s, e0, e1) : launch<kOpF16, kEpiF32, kShip>(a, s, e0, e1);
     }
     if (p->epilogue == DIMSUM_GEMM_EPI_GATED_GELU_SPLIT3 || p->epilogue == DIMSUM_GEMM_EPI_GATED_GELU_F16) {
         // b_ptr: the (2 F, K) weight of w12; n = 2 F; output: (M, 3 F) bf16 left image [hi | hi | lo] or (M, F) fp16
-        if (p->n % 8 != 0) return DIMSUM_ERR_SHAPE;
+        if (p->n % 16 != 0) return DIMSUM_ERR_SHAPE;
         const int F = p->n / 2;
         const bool img = p->epilogue == DIMSUM_GEMM_EPI_GATED_GELU_SPLIT3;
-        if (p->ldc % 4 != 0 || p->ldc < (img ? 3 : 1) * (int64_t)F || !aligned_to<char>(p->c_ptr, 8)) return DIMSUM_ERR_STRIDE;
+        if (p->ldc % 8 != 0 || p->ldc < (img ? 3 : 1) * (int64_t)F || !aligned_to<char>(p->c_ptr, 16) || (int64_t)257 * p->ldc * 2 + 6 * (int64_t)F >= ((int64_t)1 << 31))
+            return DIMSUM_ERR_STRIDE;
         if (p->bias_ptr && !aligned_to<char>(p->bias_ptr, 16)) return DIMSUM_ERR_STRIDE;
         a.B0 = reinterpret_cast<const char *>(p->b_ptr);
         a.B1 = a.B0 + (int64_t)F * p->ldb * 2;

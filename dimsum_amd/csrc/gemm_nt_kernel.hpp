@@ -58,7 +58,19 @@ struct Args {
     int M, N, K;                   // N = columns per B half matrix row range handled as [0, N) for plain, hidden width F for gated
     int tiles_m, tiles_n;
     float out_scale;               // kEpiGatedF16: h is stored as fp16(h * out_scale)
+    int group_m;                   // tile rows per group of the tile order (L2 patch shape)
+    int start_delay;               // tuning: first-round workgroups sleep (blockIdx % 8) * start_delay * 64 cycles
 };
+// tuning variants (bit mask; 0 = the shipped schedule)
+enum { kVarLgkmAfterBarrier = 1, kVarNoEpilogue = 2, kVarNtStores = 4, kVarFullLineStores = 8, kVarNoSetprio = 16, kVarSc1Stores = 32, kVarSc0Stores = 64 };
+
+__device__ __forceinline__ float dpp_row_ror8(float x) {      // lane l <- lane l ^ 8 (rotation by 8 inside each row of 16 lanes)
+    const int v = __builtin_bit_cast(int, x);                  // (old = the source: with a constant `old` hipcc 7.2 merges the calls of an unrolled loop)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false));
+}
+template <int kAux> __device__ __forceinline__ void store_f4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, const f4 &v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, voff, 0, kAux);
+}
 
 template <int kOp> __device__ __forceinline__ f4 mma(const u32x4 &a, const u32x4 &b, f4 c) {
     if constexpr (kOp == kOpBf16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
@@ -75,7 +87,7 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
     return x * fast_rcp(1.0f + fast_exp2(-2.0f * kLog2e * u));
 }
 
-template <int kOp, int kEpi>
+template <int kOp, int kEpi, int kVar = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
     __shared__ __attribute__((aligned(1024))) char lds[2 * kParity];
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds;
@@ -91,7 +103,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
         const int nwg = gridDim.x, bid = blockIdx.x;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        constexpr int GM = 8;
+        const int GM = p.group_m;
         const int per_group = GM * p.tiles_n;
         const int g = t / per_group, within = t - g * per_group;
         const int first_m = g * GM;
@@ -177,17 +189,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
     // one quadrant x K = 64: 16 MFMAs, the same accumulator recurs after 8
 #define DIMSUM_QUADRANT(MI, NI, AF, BF)                                                    \
     do {                                                                                   \
-        __builtin_amdgcn_s_setprio(1);                                                     \
+        if constexpr (!(kVar & kVarNoSetprio)) __builtin_amdgcn_s_setprio(1);              \
         _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                   \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                  \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j)                              \
                     acc[MI][NI][i][j] = mma<kOp>(BF[j][kh], AF[i][kh], acc[MI][NI][i][j]); \
-        __builtin_amdgcn_s_setprio(0);                                                     \
+        if constexpr (!(kVar & kVarNoSetprio)) __builtin_amdgcn_s_setprio(0);              \
     } while (0)
 #define DIMSUM_PHASE_SYNC()                                                                \
     do {                                                                                   \
-        DIMSUM_WAIT_LGKM0();                                                               \
+        if constexpr (!(kVar & kVarLgkmAfterBarrier)) DIMSUM_WAIT_LGKM0();                 \
         __builtin_amdgcn_s_barrier();                                                      \
+        if constexpr (kVar & kVarLgkmAfterBarrier) DIMSUM_WAIT_LGKM0();                    \
         __builtin_amdgcn_sched_barrier(0);                                                 \
     } while (0)
 #define DIMSUM_PHASE_END()                                                                 \
@@ -198,6 +211,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
     } while (0)
 
     const int nk = p.K / kBK;      // >= 2
+    if (p.start_delay > 0 && blockIdx.x < 256) {
+        for (int d = (blockIdx.x >> 3 & 7) * p.start_delay; d > 0; --d) __builtin_amdgcn_s_sleep(1);
+    }
 
     // ---- prologue: the 8 half tiles of K tiles 0 and 1 in read order; A0(0) and B0(0) must have landed before the first reads
     stage_a0(0); stage_b0(0); stage_b1(0); stage_a1(0);
@@ -285,55 +301,132 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
     if (wr == 0) __builtin_amdgcn_s_barrier();       // matches the second wave row's extra barrier
 
     // ---- epilogue: acc[mi][ni][i][j] = rows m0 + mi * 128 + wr * 64 + i * 16 + (lane & 15), 4 columns from ni * 128 + wc * 32 + j * 16 + (lane >> 4) * 4
-    const int erow = m0 + wr * 64 + (lane & 15);
     const int ecol = wc * 32 + (lane >> 4) * 4;
-    if constexpr (kEpi == kEpiF32 || kEpi == kEpiF32Bias) {
-        float *C = reinterpret_cast<float *>(p.C);
+    if constexpr (kVar & kVarNoEpilogue) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = n0 + ni * 128 + ecol + j * 16;
-                if (col < p.N) {
-                    f4 bv = f4{0.f, 0.f, 0.f, 0.f};
-                    if constexpr (kEpi == kEpiF32Bias) bv = *reinterpret_cast<const f4 *>(p.bias0 + col);
+            for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int row = erow + mi * 128 + i * 16;
-                            *reinterpret_cast<f4 *>(C + (int64_t)row * p.ldc + col) = acc[mi][ni][i][j] + bv;
-                        }
-                }
-            }
-    } else {
-        // gated GeLU: h = gelu_tanh(x1 + b1) (x2 + b2) with x1 = acc[mi][0], x2 = acc[mi][1] of the same hidden column
+                    for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[mi][ni][i][j]));
+    } else if constexpr (kEpi == kEpiF32 || kEpi == kEpiF32Bias) {
+        // one buffer descriptor per tile (base = the tile's first element: wave-uniform), a 32-bit byte offset per lane
+        constexpr int kAux = ((kVar & kVarNtStores) ? 2 : 0) | ((kVar & kVarSc1Stores) ? 16 : 0) | ((kVar & kVarSc0Stores) ? 1 : 0);
+        float *Ct = reinterpret_cast<float *>(p.C) + (int64_t)m0 * p.ldc + n0;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(Ct, 0, 0x7fffffff, 0x00020000);
+        if constexpr (kVar & kVarFullLineStores) {
+            // 128-byte row segments per store: lanes r and r + 8 of a 16-lane row trade their j = 1 / j = 0 registers (row_ror:8), after
+            // which a lane owns (row r, j = lane bit 3) for the first store and (row r + 8, same columns) for the second
+            const bool up = (lane & 8) != 0;
+            const int frow = wr * 64 + (lane & 7);
+            const int fcol = wc * 32 + (lane >> 4) * 4 + (up ? 16 : 0);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + ecol + j * 16;
-            if (col < p.N) {
-                f4 bv1 = f4{0.f, 0.f, 0.f, 0.f}, bv2 = bv1;
-                if (p.bias0) {
-                    bv1 = *reinterpret_cast<const f4 *>(p.bias0 + col);
-                    bv2 = *reinterpret_cast<const f4 *>(p.bias1 + col);
+            for (int ni = 0; ni < 2; ++ni) {
+                const int col = ni * 128 + fcol;
+                const bool live = n0 + col < p.N;          // (the lane exchange below runs in every lane: only the stores are predicated)
+                f4 bv = f4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (kEpi == kEpiF32Bias) {
+                    if (live) bv = *reinterpret_cast<const f4 *>(p.bias0 + n0 + col);
                 }
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const int row = erow + mi * 128 + i * 16;
-                        const f4 x1 = acc[mi][0][i][j] + bv1, x2 = acc[mi][1][i][j] + bv2;
-                        f32x4 h;
+                        const f4 x0 = acc[mi][ni][i][0], x1 = acc[mi][ni][i][1];
+                        f4 s0, s1;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) h.v[e] = gelu_tanh_f(x1[e]) * x2[e];
-                        if constexpr (kEpi == kEpiGatedSplit3) {
-                            st_split3<true>(reinterpret_cast<unsigned short *>(p.C) + (int64_t)row * p.ldc, col, p.N, h);
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) h.v[e] *= p.out_scale;
-                            st4<__half>(reinterpret_cast<__half *>(p.C) + (int64_t)row * p.ldc + col, h);
+                        for (int e = 0; e < 4; ++e) {
+                            const float r0 = dpp_row_ror8(x0[e]), r1 = dpp_row_ror8(x1[e]);
+                            s0[e] = up ? r1 : x0[e];
+                            s1[e] = up ? x1[e] : r0;
+                        }
+                        const unsigned voff = (unsigned)(((frow + mi * 128 + i * 16) * p.ldc + col) * 4);
+                        if (live) {
+                            store_f4<kAux>(rsrc, voff, s0 + bv);
+                            store_f4<kAux>(rsrc, voff + (unsigned)(8 * p.ldc * 4), s1 + bv);
                         }
                     }
+            }
+        } else {
+            const int frow = wr * 64 + (lane & 15);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = ni * 128 + ecol + j * 16;
+                    if (n0 + col < p.N) {
+                        f4 bv = f4{0.f, 0.f, 0.f, 0.f};
+                        if constexpr (kEpi == kEpiF32Bias) bv = *reinterpret_cast<const f4 *>(p.bias0 + n0 + col);
+#pragma unroll
+                        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                store_f4<kAux>(rsrc, (unsigned)(((frow + mi * 128 + i * 16) * p.ldc + col) * 4), acc[mi][ni][i][j] + bv);
+                    }
+                }
+        }
+    } else {
+        // gated GeLU: h = gelu_tanh(x1 + b1) (x2 + b2) with x1 = acc[mi][0], x2 = acc[mi][1] of the same hidden column. The 256 x 128 tile of h
+        // goes through LDS (free now: every wave's operand reads retired before the barrier it passed last, no DMA is pending) so that
+        // the global stores are whole rows: plane 0 = hi (or the fp16 image), plane 1 = lo, [256 rows][128 cols] 16-bit, 256 B per row.
+        // The 8-byte unit u of row r sits at u ^ (r & 15): the 16 lanes of a ds_write_b64 service group (same columns, 16 rows)
+        // hit 16 distinct units, and a 16-byte read (units 2 v, 2 v + 1) finds both in slot v ^ ((r & 15) >> 1), swapped when r is odd.
+        constexpr bool kImg = kEpi == kEpiGatedSplit3;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + ecol + j * 16;
+            f4 bv1 = f4{0.f, 0.f, 0.f, 0.f}, bv2 = bv1;
+            if (p.bias0 && col < p.N) {
+                bv1 = *reinterpret_cast<const f4 *>(p.bias0 + col);
+                bv2 = *reinterpret_cast<const f4 *>(p.bias1 + col);
+            }
+            const int unit = (ecol + j * 16) >> 2;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = mi * 128 + wr * 64 + i * 16 + (lane & 15);
+                    const f4 x1 = acc[mi][0][i][j] + bv1, x2 = acc[mi][1][i][j] + bv2;
+                    float h[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[e] = gelu_tanh_f(x1[e]) * x2[e];
+                    char *dst = lds + r * 256 + ((unit ^ (lane & 15)) << 3);
+                    if constexpr (kImg) {
+                        unsigned h0, l0, h1, l1;
+                        split2(h[0], h[1], h0, l0);
+                        split2(h[2], h[3], h1, l1);
+                        *reinterpret_cast<uint2 *>(dst) = make_uint2(h0, h1);
+                        *reinterpret_cast<uint2 *>(dst + 65536) = make_uint2(l0, l1);
+                    } else {
+                        const __half2 a = __floats2half2_rn(h[0] * p.out_scale, h[1] * p.out_scale), b = __floats2half2_rn(h[2] * p.out_scale, h[3] * p.out_scale);
+                        *reinterpret_cast<uint2 *>(dst) = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+                    }
+                }
+        }
+        __syncthreads();
+        // wave w stores rows 32 w .. 32 w + 31, four rows (256 B of one plane each) per instruction
+        char *Ct = reinterpret_cast<char *>(p.C) + ((int64_t)m0 * p.ldc + n0) * 2;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(Ct, 0, 0x7fffffff, 0x00020000);
+        const int piece = lane & 15;
+        const bool live = n0 + piece * 8 < p.N;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int r = w * 32 + it * 4 + (lane >> 4);
+            const char *src = lds + r * 256 + ((piece ^ ((r & 15) >> 1)) << 4);
+            const bool odd = (r & 1) != 0;
+            const unsigned voff = (unsigned)((r * p.ldc + piece * 8) * 2);
+            u32x4 v = *reinterpret_cast<const u32x4 *>(src);
+            v = odd ? u32x4{v[2], v[3], v[0], v[1]} : v;
+            if (live) {
+                __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, 2);
+                if constexpr (kImg) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff + (unsigned)(p.N * 2), 0, 2);
+            }
+            if constexpr (kImg) {
+                u32x4 l = *reinterpret_cast<const u32x4 *>(src + 65536);
+                l = odd ? u32x4{l[2], l[3], l[0], l[1]} : l;
+                if (live) __builtin_amdgcn_raw_buffer_store_b128(l, rsrc, voff + (unsigned)(p.N * 4), 0, 2);
             }
         }
     }

@@ -167,7 +167,7 @@ class _LinearImagesFn(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             wt3 = native.split3_rows(weight.detach().t().contiguous(), left=True)     # (K, 3N)
-            dx = torch.mm(dy_w, wt3.t(), out_dtype=torch.float32).view(ctx.x_shape)
+            dx = _nt(dy_w, wt3).view(ctx.x_shape)
         if ctx.needs_input_grad[1]:
             dw = mm_tn(dy_w.view(3 * M, N), x3.view(3 * M, K), out_dtype=torch.float32)
         return dx, dw
@@ -214,14 +214,41 @@ def split3_enabled(x, weight):
     return x.numel() // x.shape[-1] >= int(os.environ.get("DIMSUM_SPLIT3_MIN_ROWS", "8192"))
 
 
+def own_gemm_enabled():
+    """the image GEMMs run on this package's MFMA kernel (csrc/gemm_nt_kernel.hpp); DIMSUM_GEMM_NT=0 hands them back to the library"""
+    import os
+    return os.environ.get("DIMSUM_GEMM_NT", "1") != "0"
+
+
+def _nt(a, b, **kw):
+    """a (M, K) @ b (N, K)^T -> float32 (M, N) (or the fused epilogue's image), 16-bit K-contiguous operands: the hand-written kernel
+    when the shape fits its tiling (256-row panels, 64-deep K tiles), else the library"""
+    from . import native
+    if own_gemm_enabled() and native.gemm_nt_supported(a, b):
+        return native.gemm_nt(a, b, **kw)
+    y = torch.mm(a, b.t(), out_dtype=torch.float32)
+    return y if kw.get("bias") is None else y + kw["bias"]
+
+
 def linear_split3(x3, weight):
     """x3 (M, 3K) bfloat16 left image [hi | hi | lo] @ weight (N, K)^T -> (M, N) float32"""
-    return torch.mm(x3, weight_image(weight).t(), out_dtype=torch.float32)
+    return _nt(x3, weight_image(weight))
 
 
 def matmul_wx_split3(weight, x3):
     """weight (N, K) @ x^T -> (N, M) float32 with x given as its left image x3 (M, 3K): the in_proj site (d-major output)"""
-    return torch.mm(weight_image(weight), x3.t(), out_dtype=torch.float32)
+    return _nt(weight_image(weight), x3)
+
+
+def gated_mlp_hidden_split3(x3, w12, b12):
+    """x3 (M, 3K) left image, w12 (2F, K), b12 (2F) or None -> the left image (M, 3F) of gelu_tanh(x W12a^T + b) * (x W12b^T + b)
+    (dimsum/mlp.py:66-70): ONE kernel, the gate in the GEMM's epilogue -- the fp32 (M, 2F) tensor never exists; the library GEMM + the
+    gated-GeLU pass (csrc/token_transform.hip) when the shape does not fit the kernel's tiling."""
+    from . import native
+    w3i = weight_image(w12)
+    if own_gemm_enabled() and native.gemm_nt_supported(x3, w3i, gated=True):
+        return native.gemm_nt(x3, w3i, bias=b12, epilogue="gated_split3")
+    return native.gated_gelu_fwd(torch.mm(x3, w3i.t(), out_dtype=torch.float32), b12, split3=True)
 
 
 def split3_train_enabled(x, weight):

@@ -63,12 +63,11 @@ class _ModGatedMlpImagesFn(torch.autograd.Function):
         M, F2 = x12.shape
         Fh = F2 // 2
         Ho = w3.shape[0]
-        mm = lambda a, b: torch.mm(a, b, out_dtype=torch.float32)
         dm_w = native.split3_rows(dm.reshape(M, Ho).contiguous(), left=False)                              # (M, 3Ho), weight order
-        dg = mm(dm_w, native.split3_rows(w3.detach().t().contiguous(), left=True).t())                     # (M, F)
+        dg = gemm._nt(dm_w, native.split3_rows(w3.detach().t().contiguous(), left=True))                    # (M, F)
         dw3 = gemm.mm_tn(dm_w.view(3 * M, Ho), g3.view(3 * M, Fh), out_dtype=torch.float32) if ctx.needs_input_grad[5] else None   # (Ho, F)
         dx12_w, db12 = native.gated_gelu_bwd(x12, b12f, dg, need_dbias=b12f is not None and ctx.needs_input_grad[4], split3=True)
-        dh = mm(dx12_w, native.split3_rows(w12.detach().t().contiguous(), left=True).t())                  # (M, H)
+        dh = gemm._nt(dx12_w, native.split3_rows(w12.detach().t().contiguous(), left=True))                 # (M, H)
         dw12 = gemm.mm_tn(dx12_w.view(3 * M, F2), h3.view(3 * M, H), out_dtype=torch.float32) if ctx.needs_input_grad[3] else None   # (2F, H)
         dh = dh.view(B, L, H)
         dnormed = dshift = dscale = None
@@ -102,7 +101,7 @@ class GatedMLP(nn.Module):
         run as plain bf16 GEMMs over the hi / lo images, the gated GeLU writes the w3 GEMM's image directly."""
         if x3 is not None:
             b12 = self.w12.bias
-            h3 = native.gated_gelu_fwd(gemm.linear_split3(x3, self.w12.weight), None if b12 is None else b12.float(), split3=True)
+            h3 = gemm.gated_mlp_hidden_split3(x3, self.w12.weight, None if b12 is None else b12.float())
             return gemm.linear_split3(h3, self.w3.weight).view(*x.shape[:-1], self.w3.weight.shape[0]), self.w3.bias
         if self._fused and x.dtype == torch.float32:
             b12 = self.w12.bias

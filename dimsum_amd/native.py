@@ -460,12 +460,12 @@ def gemm_nt_supported(a, b, gated=False):
         return False
     M, K = a.shape
     N = b.shape[0]
-    return (b.shape[1] == K and M > 0 and M % 256 == 0 and K % 64 == 0 and K >= 128 and N % (8 if gated else 4) == 0
+    return (b.shape[1] == K and M > 0 and M % 256 == 0 and K % 64 == 0 and K >= 128 and N % (16 if gated else 4) == 0
             and a.stride(1) == 1 and b.stride(1) == 1 and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0
             and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and 512 * max(a.stride(0), b.stride(0)) < 2 ** 31)
 
 
-def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=None):
+def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=None, tune=None):
     """a (M, K) @ b (N, K)^T on the hand-written MFMA kernel, 16-bit operands (bfloat16: split-bf16 images over 3 K; float16: scaled rows),
     fp32 accumulation.
       epilogue "f32"          -> (M, N) float32 (+ bias[N])
@@ -506,6 +506,8 @@ def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=Non
     P.a_ptr, P.b_ptr, P.bias_ptr, P.c_ptr = _ptr(a), _ptr(b), _ptr(bias), _ptr(out)
     if events is not None:
         P.timing_start_event, P.timing_stop_event = events
+    if tune is not None:
+        P.tune_variant, P.tune_group_m, P.tune_start_delay = tune
     with torch.cuda.device(a.device):
         _lib.check(_lib.load().dimsum_gemm_nt(P, _stream(a)), "gemm_nt")
     return out

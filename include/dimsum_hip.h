@@ -338,7 +338,8 @@ int dimsum_gated_gelu_bwd_split3(const void *x12, const void *bias, const void *
  *                             C = the LEFT split-bf16 image (m, 3 F) of h = gelu_tanh(x1 + b1) * (x2 + b2), ldc in bf16 elements:
  *                             the fp32 x12 tensor of mlp.py:68 never exists
  *            GATED_GELU_F16 : same, C = fp16 (m, F) of h * out_scale
- * Shapes: m % 256 == 0, k % 64 == 0, k >= 128, n % 4 == 0 (gated: n % 8 == 0); lda, ldb % 8 == 0; a_ptr, b_ptr 16-byte aligned.
+ * Shapes: m % 256 == 0, k % 64 == 0, k >= 128, n % 4 == 0 (gated: n % 16 == 0, ldc % 8 == 0); lda, ldb % 8 == 0; a_ptr, b_ptr, c_ptr
+ * 16-byte aligned.
  * ------------------------------------------------------------------------------------------------------------- */
 typedef enum {
     DIMSUM_GEMM_EPI_F32 = 0, DIMSUM_GEMM_EPI_GATED_GELU_SPLIT3 = 1, DIMSUM_GEMM_EPI_GATED_GELU_F16 = 2, DIMSUM_GEMM_EPI_F32_BIAS = 3
@@ -353,6 +354,7 @@ typedef struct {
     const void *a_ptr, *b_ptr, *bias_ptr;
     void *c_ptr;
     void *timing_start_event, *timing_stop_event;   /* optional hipEvent_t pair recorded at the kernel's own dispatch boundaries */
+    int32_t tune_variant, tune_group_m, tune_start_delay;   /* 0 = the shipped schedule (tools/bench_gemm.py sweeps) */
 } dimsum_gemm_params_t;
 
 int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream);

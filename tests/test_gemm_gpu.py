@@ -1,0 +1,104 @@
+"""The hand-written NT GEMM (csrc/gemm_nt_kernel.hpp, dimsum_gemm_nt) through the C ABI: plain fp32 output against float64 products of
+the same 16-bit operands, ragged N, biases, and the gated-GeLU epilogues (dimsum/mlp.py:66-70) against the float64 expression and
+against the unfused pair (library GEMM + csrc/token_transform.hip gated GeLU pass) they replace."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _rnd(shape, dtype, seed, scale=1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(shape, device="cuda", generator=g) * scale).to(dtype)
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (256, 256, 192), (512, 384, 320), (768, 1152, 1152), (256, 132, 128), (512, 4, 256),
+                                    (1024, 2048, 3072)])
+def test_plain_product_vs_float64(M, N, K, dtype):
+    """fp32 accumulation of exact 16-bit products: the only error is the accumulation order (<= 2e-6 of max |C| here); repeated
+    launches are bit-identical (a race in the LDS-DMA pipeline would show as run-to-run differences)"""
+    from dimsum_amd import native
+    dt = getattr(torch, dtype)
+    a, b = _rnd((M, K), dt, 1), _rnd((N, K), dt, 2)
+    ref = a.double() @ b.double().t()
+    got = native.gemm_nt(a, b)
+    assert got.shape == (M, N) and got.dtype == torch.float32
+    err = (got.double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-6 * max(1.0, (K / 1024) ** 0.5) + 1e-7, err
+    for _ in range(3):
+        assert torch.equal(native.gemm_nt(a, b), got)
+
+
+def test_transpose_detecting_operands():
+    """A = one-hot rows against an asymmetric B: C must be exactly the selected rows of B^T (a swapped fragment or epilogue mapping fails)"""
+    from dimsum_amd import native
+    M, N, K = 256, 512, 256
+    a = torch.zeros((M, K), device="cuda", dtype=torch.bfloat16)
+    idx = (torch.arange(M, device="cuda") * 7 + 3) % K
+    a[torch.arange(M, device="cuda"), idx] = 1.0
+    b = ((torch.arange(N, device="cuda")[:, None] * 3 + torch.arange(K, device="cuda")[None, :] * 5) % 251).to(torch.bfloat16)
+    got = native.gemm_nt(a, b)
+    assert torch.equal(got, b.float()[:, idx].t().contiguous())
+
+
+def test_bias_and_strided_rows():
+    """row strides larger than the row length on all three matrices (views into wider buffers), per-column bias"""
+    from dimsum_amd import native
+    M, N, K = 512, 384, 256
+    abuf, bbuf = _rnd((M, K + 64), torch.bfloat16, 3), _rnd((N, K + 8), torch.bfloat16, 4)
+    a, b = abuf[:, :K], bbuf[:, :K]
+    bias = _rnd((N,), torch.float32, 5)
+    out = torch.full((M, N + 16), 7.0, device="cuda")
+    native.gemm_nt(a, b, bias=bias, out=out[:, :N])
+    ref = a.double() @ b.double().t() + bias.double()
+    assert (out[:, :N].double() - ref).abs().max().item() / ref.abs().max().item() < 3e-6
+    assert torch.all(out[:, N:] == 7.0)
+
+
+@pytest.mark.parametrize("M,F,H,with_bias", [(512, 256, 128, True), (512, 1536, 384, False), (1024, 4608, 1152, True), (256, 136, 192, True)])
+def test_gated_gelu_epilogues(M, F, H, with_bias):
+    """w12 + bias + gelu_tanh(x1) * x2 as one kernel: the split-bf16 image decodes (hi + lo) to the float64 expression within the
+    split-image error (2e-5 of max |h|, tests/test_split3_gpu.py's bound), both hi copies are identical, and the result is as close
+    to float64 as the unfused pair it replaces; the fp16 image carries the TF32-class operand rounding"""
+    from dimsum_amd import native
+    x = _rnd((M, H), torch.float32, 4)
+    w12 = _rnd((2 * F, H), torch.float32, 5, scale=H ** -0.5)
+    bias = _rnd((2 * F,), torch.float32, 6, scale=0.1) if with_bias else None
+    x3, w3 = native.split3_rows(x, left=True), native.split3_rows(w12, left=False)
+    got = native.gemm_nt(x3, w3, bias=bias, epilogue="gated_split3")
+    assert got.shape == (M, 3 * F) and got.dtype == torch.bfloat16
+    x12 = x.double() @ w12.double().t() + (0 if bias is None else bias.double())
+    ref = torch.nn.functional.gelu(x12[:, :F], approximate="tanh") * x12[:, F:]
+    hi, hi2, lo = got[:, :F], got[:, F:2 * F], got[:, 2 * F:]
+    assert torch.equal(hi, hi2)
+    scale = ref.abs().max().item()
+    err = ((hi.double() + lo.double()) - ref).abs().max().item() / scale
+    unf = native.gated_gelu_fwd(torch.mm(x3, w3.t(), out_dtype=torch.float32), bias, split3=True)
+    uerr = ((unf[:, :F].double() + unf[:, 2 * F:].double()) - ref).abs().max().item() / scale
+    assert err < 2e-5 and err < 1.5 * uerr + 1e-6, (err, uerr)
+    x16, w16 = x.half(), w12.half()
+    g16 = native.gemm_nt(x16, w16, bias=bias, epilogue="gated_f16", out_scale=8.0)
+    x12h = x16.double() @ w16.double().t() + (0 if bias is None else bias.double())
+    refh = torch.nn.functional.gelu(x12h[:, :F], approximate="tanh") * x12h[:, F:]
+    assert (g16.double() / 8.0 - refh).abs().max().item() / refh.abs().max().item() < 1e-3
+
+
+def test_rejects_what_the_tiling_cannot_take():
+    from dimsum_amd import native
+    a, b = _rnd((255, 128), torch.bfloat16, 1), _rnd((256, 128), torch.bfloat16, 2)
+    assert not native.gemm_nt_supported(a, b)
+    with pytest.raises(RuntimeError):
+        native.gemm_nt(a, b)
+    assert not native.gemm_nt_supported(_rnd((256, 64), torch.bfloat16, 1), _rnd((256, 64), torch.bfloat16, 2))      # K < 128
+    assert not native.gemm_nt_supported(_rnd((256, 128), torch.float32, 1), _rnd((256, 128), torch.float32, 2))
+
+
+def test_full_size_w12_against_library():
+    """BASELINE config 2's w12 launch (65536 x 8192 x 3072 split images): equal to the library's bf16 GEMM within accumulation order"""
+    from dimsum_amd import native
+    a, b = _rnd((65536, 3072), torch.bfloat16, 1), _rnd((8192, 3072), torch.bfloat16, 2, scale=3072 ** -0.5)
+    got = native.gemm_nt(a, b)
+    lib = torch.mm(a, b.t(), out_dtype=torch.float32)
+    assert (got - lib).abs().max().item() <= 2e-5 * lib.abs().max().item()

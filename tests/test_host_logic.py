@@ -66,16 +66,16 @@ def test_struct_sizes_match_header():
     import tempfile
     from dimsum_amd import _lib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = '#include <stdio.h>\n#include "dimsum_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",' \
+    src = '#include <stdio.h>\n#include "dimsum_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",' \
           'sizeof(dimsum_ssm_params_t),sizeof(dimsum_ssm_bwd_params_t),sizeof(dimsum_conv_params_t),' \
           'sizeof(dimsum_conv_bwd_params_t),sizeof(dimsum_norm_params_t),sizeof(dimsum_norm_bwd_params_t),' \
-          'sizeof(dimsum_tt_params_t),sizeof(dimsum_xattn_params_t),sizeof(dimsum_xattn_bwd_params_t));return 0;}\n'
+          'sizeof(dimsum_tt_params_t),sizeof(dimsum_xattn_params_t),sizeof(dimsum_xattn_bwd_params_t),sizeof(dimsum_gemm_params_t));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(src)
         subprocess.run(["gcc", "-I", os.path.join(root, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")], check=True)
         sizes = [int(v) for v in subprocess.run([os.path.join(d, "s")], capture_output=True, text=True, check=True).stdout.split()]
     mirrors = [_lib.SsmParams, _lib.SsmBwdParams, _lib.ConvParams, _lib.ConvBwdParams, _lib.NormParams, _lib.NormBwdParams,
-               _lib.TtParams, _lib.XattnParams, _lib.XattnBwdParams]
+               _lib.TtParams, _lib.XattnParams, _lib.XattnBwdParams, _lib.GemmParams]
     assert sizes == [ctypes.sizeof(m) for m in mirrors]
 
 

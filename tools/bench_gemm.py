@@ -119,6 +119,47 @@ def perf(shapes, rounds, inner):
     return out
 
 
+def tune(M, N, K, dtype, rounds, inner, check=True):
+    """interleaved rounds of the tuning variants of the plain fp32-output kernel (dimsum_gemm_params_t.tune_*)"""
+    a, b = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, scale=K ** -0.5)
+    c = torch.empty((M, N), device="cuda", dtype=torch.float32)
+    arms = {"library": lambda: torch.mm(a, b.t(), out_dtype=torch.float32)}
+    if N % 16 == 0 and dtype == torch.bfloat16:
+        h3 = torch.empty((M, 3 * (N // 2)), device="cuda", dtype=torch.bfloat16)
+        for gm in (2, 4, 8):
+            arms[f"gate->split3 gm{gm}"] = (lambda gm=gm: native.gemm_nt(a, b, epilogue="gated_split3", out=h3, tune=(0, gm, 0)))
+        h16 = torch.empty((M, N // 2), device="cuda", dtype=torch.float16)
+        for gm in (2, 4, 8):
+            arms[f"gate->f16 gm{gm}"] = (lambda gm=gm: native.gemm_nt(a, b, epilogue="gated_f16", out=h16, tune=(0, gm, 0)))
+    variants = [("ship gm4", (0, 4, 0)), ("ship gm8", (0, 8, 0)), ("ship gm2", (0, 2, 0)), ("plain-stores gm8", (100, 8, 0)), ("no-epilogue", (2, 8, 0))]
+    for name, t in variants:
+        if dtype != torch.bfloat16 and t[0] != 0:
+            continue
+        arms[name] = (lambda t=t: native.gemm_nt(a, b, out=c, tune=t))
+    if check:
+        ref = torch.mm(a, b.t(), out_dtype=torch.float32)
+        for name, f in arms.items():
+            if "no-epi" in name or "gate" in name:
+                continue
+            c.zero_()
+            r = f()
+            if not torch.allclose(r, ref, rtol=1e-4, atol=1e-4 * ref.abs().max().item()):
+                print("MISMATCH", name, (r - ref).abs().max().item(), flush=True)
+    for f in arms.values():
+        f()
+    torch.cuda.synchronize()
+    res = {k: [] for k in arms}
+    for _ in range(rounds):
+        for k, f in arms.items():
+            res[k].append(timed(f, inner))
+    fl = 2.0 * M * N * K
+    print(f"tune M={M} N={N} K={K} {dtype}", flush=True)
+    for k, v in res.items():
+        v.sort()
+        med = v[len(v) // 2]
+        print(f"  {k:22s} median {med:7.4f} ms  min {v[0]:7.4f}  {fl / med / 1e9:7.1f} TF", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
@@ -126,6 +167,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--inner", type=int, default=10)
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--tune", action="store_true")
+    ap.add_argument("--pmc-run", action="store_true", help="a few launches of the w12-shape kernels (under rocprofv3 --pmc)")
     args = ap.parse_args()
     ok = True
     if args.check:
@@ -139,6 +182,20 @@ def main():
         ok &= check_gated(1024, 4608, 1152)
         ok &= check_plain(65536, 8192, 3072, torch.bfloat16, reps=2) if not args.quick else True
         print("CHECK", "ok" if ok else "FAILED", flush=True)
+    if args.pmc_run:
+        a, b = rnd((65536, 3072), torch.bfloat16, 1), rnd((8192, 3072), torch.bfloat16, 2, scale=3072 ** -0.5)
+        c = torch.empty((65536, 8192), device="cuda", dtype=torch.float32)
+        h3 = torch.empty((65536, 3 * 4096), device="cuda", dtype=torch.bfloat16)
+        for _ in range(3):
+            native.gemm_nt(a, b, out=c)
+            native.gemm_nt(a, b, epilogue="gated_split3", out=h3)
+            native.gemm_nt(a, b, out=c, tune=(2, 8, 0))
+            torch.mm(a, b.t(), out_dtype=torch.float32)
+        torch.cuda.synchronize()
+    if args.tune:
+        tune(65536, 8192, 3072, torch.bfloat16, args.rounds, args.inner)
+        tune(65536, 8192, 1024, torch.bfloat16, args.rounds, args.inner)
+        tune(65536, 1024, 12288, torch.bfloat16, args.rounds, args.inner)
     if args.perf:
         shapes = [("w12 split3", 65536, 8192, 3072, torch.bfloat16),
                   ("w3 split3", 65536, 1024, 12288, torch.bfloat16),
