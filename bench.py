@@ -470,7 +470,7 @@ def main():
                                                              "(dimsum_amd/hip_graph.py): for per-GPU batches below ~32, where eager is launch-bound")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the extra exact-fp32 / fp16-operand timings (for profiling runs)")
-    ap.add_argument("--matmul", choices=["tf32", "fp32", "fp16"], default="tf32",
+    ap.add_argument("--matmul", choices=["tf32", "fp32", "fp16", "f16s"], default="tf32",
                     help="library-GEMM policy. tf32 = the reference's own setting (torch.backends.cuda.matmul.allow_tf32 = "
                          "True, dimsum/train.py:20-21, sample_ddp.py:56); on gfx950 hipBLASLt serves it with a split-bf16 "
                          "MFMA path measured at 4e-6 rms relative error (real TF32: ~5e-4). fp32 = exact fp32 MFMA. "
@@ -521,7 +521,7 @@ def main():
                            "parallelism": f"dp{world} (replicas, independent latents)", "launch": head.get("launch", "eager"), "matmul_policy": policy},
                 "dist": {"world_size": dist.get_world_size() if world > 1 else 1,
                          "backend": (dist.get_backend() + " (RCCL)") if world > 1 else "none (single process)"}}
-        for k in ("roofline", "roofline_bwd", "fp32_exact_matmul", "fp16_operand_matmul_optin", "nfe", "s_per_batch", "gathered_shape", "finite"):
+        for k in ("roofline", "roofline_bwd", "fp32_exact_matmul", "tf32_single_product_f16s", "fp16_operand_matmul_optin", "nfe", "s_per_batch", "gathered_shape", "finite"):
             if k in head:
                 line[k] = head[k]
         if "sample_250nfe" in extras:

@@ -52,7 +52,7 @@ class NormParams(C.Structure):
                 + [(n, i64) for n in ("x_row_stride", "residual_row_stride", "y_row_stride", "residual_out_row_stride")]
                 + [(n, vp) for n in ("x_ptr", "residual_ptr", "weight_ptr", "bias_ptr", "y_ptr", "residual_out_ptr",
                                      "mean_ptr", "rstd_ptr", "xbias_ptr", "mod_scale_ptr", "mod_shift_ptr")]
-                + [("mod_row_stride", i64), ("rows_per_batch", i32), ("y_split3", i32)])
+                + [("mod_row_stride", i64), ("rows_per_batch", i32), ("y_split3", i32), ("y_inv_scale_ptr", vp)])
 
 
 class NormBwdParams(C.Structure):
@@ -68,7 +68,8 @@ class TtParams(C.Structure):
                                       "y_batch_stride", "y_token_stride", "mod_batch_stride", "w_batch_stride",
                                       "w_token_stride", "red_batch_stride")]
                 + [(n, vp) for n in ("x_ptr", "in_index_ptr", "out_index_ptr", "gate_ptr", "scale_ptr", "shift_ptr",
-                                     "residual_ptr", "y_ptr", "w_ptr", "wdot_ptr", "wsum_ptr", "tsum_ptr")])
+                                     "residual_ptr", "y_ptr", "w_ptr", "wdot_ptr", "wsum_ptr", "tsum_ptr", "y_inv_scale_ptr")]
+                + [("y_f16s_lds_offset", i32)])
 
 
 class XattnParams(C.Structure):
@@ -87,7 +88,8 @@ class GemmParams(C.Structure):
     _fields_ = ([(n, i32) for n in ("m", "n", "k", "operand_dtype", "epilogue")] + [("out_scale", f32)]
                 + [(n, i64) for n in ("lda", "ldb", "ldc")]
                 + [(n, vp) for n in ("a_ptr", "b_ptr", "bias_ptr", "c_ptr", "timing_start_event", "timing_stop_event")]
-                + [(n, i32) for n in ("tune_variant", "tune_group_m", "tune_start_delay")])
+                + [(n, i32) for n in ("tune_variant", "tune_group_m", "tune_start_delay")]
+                + [(n, vp) for n in ("a_inv_scale_ptr", "b_inv_scale_ptr", "gate_bound_ptr", "h_inv_scale_ptr")])
 
 
 GEMM_EPI_F32, GEMM_EPI_GATED_GELU_SPLIT3, GEMM_EPI_GATED_GELU_F16, GEMM_EPI_F32_BIAS = 0, 1, 2, 3
@@ -100,7 +102,7 @@ EXPORTS = (
     "dimsum_causal_conv1d_fwd", "dimsum_causal_conv1d_bwd",
     "dimsum_norm_fwd", "dimsum_norm_bwd", "dimsum_token_transform", "dimsum_xattn_fusion_fwd", "dimsum_xattn_fusion_bwd",
     "dimsum_gated_gelu_fwd", "dimsum_gated_gelu_bwd", "dimsum_gated_gelu_fwd_split3", "dimsum_gated_gelu_bwd_split3", "dimsum_split3",
-    "dimsum_gemm_nt",
+    "dimsum_gemm_nt", "dimsum_rows_f16s",
 )
 
 _lib = None
@@ -141,6 +143,9 @@ def load():
     if hasattr(lib, "dimsum_split3"):
         lib.dimsum_split3.restype = C.c_int
         lib.dimsum_split3.argtypes = [vp, i64, i64, i64, vp, i32, vp]
+    if hasattr(lib, "dimsum_rows_f16s"):
+        lib.dimsum_rows_f16s.restype = C.c_int
+        lib.dimsum_rows_f16s.argtypes = [vp, i64, i64, i64, vp, i64, vp, vp, vp]
     if hasattr(lib, "dimsum_ssm_scan_bwd_workspace_bytes"):
         lib.dimsum_ssm_scan_bwd_workspace_bytes.restype = i64
         lib.dimsum_ssm_scan_bwd_workspace_bytes.argtypes = [i32] * 5

@@ -93,6 +93,30 @@ template <bool kLeft> __device__ __forceinline__ void st_split3(unsigned short *
     *reinterpret_cast<uint2 *>(row + 2 * N + c) = kLeft ? make_uint2(l0, l1) : make_uint2(h0, h1);
 }
 
+// ---- scaled-fp16 operand images ("f16s") ------------------------------------------------------------------------------
+// The reference multiplies under TF32 (train.py:20-21): operands rounded to 10 mantissa bits, fp32 accumulation. fp16 has exactly that
+// mantissa; what it lacks is range, so a row travels as fp16(row * 2^s) plus the exact power of two 2^-s that the consuming GEMM's
+// epilogue multiplies back (dimsum_gemm_params_t.a_inv_scale / b_inv_scale). s comes from an upper bound m >= max|row|: m * 2^s lies in
+// [2^14, 2^15) < 65504, so nothing overflows, and every element down to 2^-28 m keeps its full 11-bit significand (below that it is
+// a subnormal / zero with absolute error <= 2^-39 m, invisible next to the 2^-12 m rounding of the row's leading elements, which
+// TF32 has too). The exponent of m is clamped to [-112, 127] so that both powers of two are normal fp32 numbers: rows below 2^-112
+// (incl. all-zero rows) take s = 126.
+__device__ __forceinline__ void f16s_scales(float m, float &scale, float &inv) {
+    int e = (int)((__float_as_uint(m) >> 23) & 0xffu) - 127;
+    e = min(max(e, -112), 127);
+    scale = __uint_as_float((unsigned)(127 + 14 - e) << 23);
+    inv = __uint_as_float((unsigned)(127 - 14 + e) << 23);
+}
+__device__ __forceinline__ uint2 f16s_pack4(const f32x4 &v, float scale) {     // 4 consecutive columns, round to nearest even
+    const __half2 a = __floats2half2_rn(v.v[0] * scale, v.v[1] * scale), b = __floats2half2_rn(v.v[2] * scale, v.v[3] * scale);
+    return make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+}
+__device__ __forceinline__ float wave_allmax(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
+    return v;
+}
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }        // v_exp_f32
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
 __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * kLn2; }   // v_log_f32

@@ -34,6 +34,10 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
     a.tiles_m = p->m / kBM;
     a.out_scale = p->out_scale;
     a.group_m = p->tune_group_m > 0 ? p->tune_group_m : 4;
+    if ((p->a_inv_scale_ptr == nullptr) != (p->b_inv_scale_ptr == nullptr)) return DIMSUM_ERR_NULL;
+    a.sa = reinterpret_cast<const float *>(p->a_inv_scale_ptr);
+    a.sb = reinterpret_cast<const float *>(p->b_inv_scale_ptr);
+    if (a.sb && !aligned_to<char>(a.sb, 16)) return DIMSUM_ERR_STRIDE;
     a.start_delay = p->tune_start_delay;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t e0 = reinterpret_cast<hipEvent_t>(p->timing_start_event), e1 = reinterpret_cast<hipEvent_t>(p->timing_stop_event);
@@ -80,6 +84,11 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
         a.bias1 = a.bias0 ? a.bias0 + F : nullptr;
         a.N = F;
         a.tiles_n = (F + 127) / 128;
+        if (p->gate_bound_ptr) {
+            if (img || !a.sa || !p->h_inv_scale_ptr) return DIMSUM_ERR_NULL;
+            a.gate_bound = reinterpret_cast<const float *>(p->gate_bound_ptr);
+            a.inv_out = reinterpret_cast<float *>(p->h_inv_scale_ptr);
+        }
         if (img) return bf ? launch<kOpBf16, kEpiGatedSplit3>(a, s, e0, e1) : launch<kOpF16, kEpiGatedSplit3>(a, s, e0, e1);
         return bf ? launch<kOpBf16, kEpiGatedF16>(a, s, e0, e1) : launch<kOpF16, kEpiGatedF16>(a, s, e0, e1);
     }

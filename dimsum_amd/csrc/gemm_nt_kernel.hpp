@@ -53,7 +53,9 @@ struct Args {
     const char *A, *B0, *B1;       // B0 / B1: first weight row of the two 128-row halves' matrices (B1 = B0 + 128 rows for a plain GEMM)
     void *C;
     const float *bias0, *bias1;    // per output column (gated: of x1 / x2), may be NULL
-    const float *row_scale;        // kEpiGatedF16: unused (the image carries a global scale) -- reserved
+    const float *sa, *sb;          // scaled-fp16 operands: inverse scale per A row (M) / per B row (N; gated: 2 F), NULL = 1
+    const float *gate_bound;       // kEpiGatedF16 with per-row scales: {max_n sum_k |w_nk| (true units), max |bias|}; NULL = out_scale
+    float *inv_out;                // kEpiGatedF16 with per-row scales: (M) inverse scales of the h image
     int64_t lda, ldb, ldc;         // in elements
     int M, N, K;                   // N = columns per B half matrix row range handled as [0, N) for plain, hidden width F for gated
     int tiles_m, tiles_n;
@@ -326,10 +328,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
             for (int ni = 0; ni < 2; ++ni) {
                 const int col = ni * 128 + fcol;
                 const bool live = n0 + col < p.N;          // (the lane exchange below runs in every lane: only the stores are predicated)
-                f4 bv = f4{0.f, 0.f, 0.f, 0.f};
+                f4 bv = f4{0.f, 0.f, 0.f, 0.f}, sbv = f4{1.f, 1.f, 1.f, 1.f};
                 if constexpr (kEpi == kEpiF32Bias) {
                     if (live) bv = *reinterpret_cast<const f4 *>(p.bias0 + n0 + col);
                 }
+                if (p.sb && live) sbv = *reinterpret_cast<const f4 *>(p.sb + n0 + col);
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -342,7 +345,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
                             s0[e] = up ? r1 : x0[e];
                             s1[e] = up ? x1[e] : r0;
                         }
-                        const unsigned voff = (unsigned)(((frow + mi * 128 + i * 16) * p.ldc + col) * 4);
+                        const int lrow = frow + mi * 128 + i * 16;
+                        const unsigned voff = (unsigned)((lrow * p.ldc + col) * 4);
+                        if (p.sa) {             // scaled-fp16 operands: exact powers of two
+                            s0 = s0 * (sbv * p.sa[m0 + lrow]);
+                            s1 = s1 * (sbv * p.sa[m0 + lrow + 8]);
+                        }
                         if (live) {
                             store_f4<kAux>(rsrc, voff, s0 + bv);
                             store_f4<kAux>(rsrc, voff + (unsigned)(8 * p.ldc * 4), s1 + bv);
@@ -377,10 +385,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + ecol + j * 16;
-            f4 bv1 = f4{0.f, 0.f, 0.f, 0.f}, bv2 = bv1;
+            f4 bv1 = f4{0.f, 0.f, 0.f, 0.f}, bv2 = bv1, sb1 = f4{1.f, 1.f, 1.f, 1.f}, sb2 = sb1;
             if (p.bias0 && col < p.N) {
                 bv1 = *reinterpret_cast<const f4 *>(p.bias0 + col);
                 bv2 = *reinterpret_cast<const f4 *>(p.bias1 + col);
+            }
+            if (p.sb && col < p.N) {
+                sb1 = *reinterpret_cast<const f4 *>(p.sb + col);
+                sb2 = *reinterpret_cast<const f4 *>(p.sb + p.N + col);
             }
             const int unit = (ecol + j * 16) >> 2;
 #pragma unroll
@@ -388,7 +400,26 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int r = mi * 128 + wr * 64 + i * 16 + (lane & 15);
-                    const f4 x1 = acc[mi][0][i][j] + bv1, x2 = acc[mi][1][i][j] + bv2;
+                    f4 x1 = acc[mi][0][i][j], x2 = acc[mi][1][i][j];
+                    float hs = p.out_scale;
+                    if (p.sa) {
+                        const float sar = p.sa[m0 + r];
+                        x1 = x1 * (sb1 * sar);
+                        x2 = x2 * (sb2 * sar);
+                        if constexpr (!kImg) {
+                            if (p.gate_bound) {
+                                // |x1|, |x2| <= max|a_r| * max_n sum_k |w_nk| + max|b| (max|a_r| < 2^15 sar by the image's construction), |gelu(x)| <= |x|:
+                                // the row's scale needs no reduction over the row -- every column tile derives the same power of two. The factor 4
+                                // covers the fp16 rounding of the operands and the fp32 accumulation many times over.
+                                const float xb = 32768.0f * sar * p.gate_bound[0] + p.gate_bound[1];
+                                float inv;
+                                f16s_scales(4.0f * xb * xb, hs, inv);
+                                if (tile_n == 0 && wc == 0 && j == 0 && lane < 16) p.inv_out[m0 + r] = inv;
+                            }
+                        }
+                    }
+                    x1 = x1 + bv1;
+                    x2 = x2 + bv2;
                     float h[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) h[e] = gelu_tanh_f(x1[e]) * x2[e];
@@ -400,7 +431,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
                         *reinterpret_cast<uint2 *>(dst) = make_uint2(h0, h1);
                         *reinterpret_cast<uint2 *>(dst + 65536) = make_uint2(l0, l1);
                     } else {
-                        const __half2 a = __floats2half2_rn(h[0] * p.out_scale, h[1] * p.out_scale), b = __floats2half2_rn(h[2] * p.out_scale, h[3] * p.out_scale);
+                        const __half2 a = __floats2half2_rn(h[0] * hs, h[1] * hs), b = __floats2half2_rn(h[2] * hs, h[3] * hs);
                         *reinterpret_cast<uint2 *>(dst) = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
                     }
                 }

@@ -97,6 +97,7 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const dimsum_norm_params_
             if (p.rstd_ptr) reinterpret_cast<float *>(p.rstd_ptr)[row] = rstd;
             if (p.mean_ptr && !p.is_rms_norm) reinterpret_cast<float *>(p.mean_ptr)[row] = mean;
         }
+        float ymax = 0.f;                           // y_split3 == 2: the row waits in r[] for its exact maximum (scaled-fp16 image)
 #pragma unroll
         for (int i = 0; i < kPieces; ++i) {
             const int c = (i * kWave + lane) * 4;
@@ -111,9 +112,24 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const dimsum_norm_params_
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o.v[e] = fmaf(o.v[e], 1.0f + sc.v[e], sh.v[e]);
                 }
-                if (p.y_split3) st_split3<true>(reinterpret_cast<unsigned short *>(p.y_ptr) + row * p.y_row_stride, c, N, o);
+                if (p.y_split3 == 2) {
+                    r[i] = o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ymax = fmaxf(ymax, fabsf(o.v[e]));
+                } else if (p.y_split3) st_split3<true>(reinterpret_cast<unsigned short *>(p.y_ptr) + row * p.y_row_stride, c, N, o);
                 else st_cols<TY>(y, c, N, vec, o);
             }
+        }
+        if (p.y_split3 == 2) {
+            float sc, inv;
+            f16s_scales(wave_allmax(ymax), sc, inv);
+            __half *yh = reinterpret_cast<__half *>(p.y_ptr) + row * p.y_row_stride;
+#pragma unroll
+            for (int i = 0; i < kPieces; ++i) {
+                const int c = (i * kWave + lane) * 4;
+                if (c < N) *reinterpret_cast<uint2 *>(yh + c) = f16s_pack4(r[i], sc);
+            }
+            if (lane == 0) reinterpret_cast<float *>(p.y_inv_scale_ptr)[row] = inv;
         }
     }
 }
@@ -255,6 +271,12 @@ extern "C" int dimsum_norm_fwd(const dimsum_norm_params_t *p, void *stream) {
     if (p->rows < 0 || p->cols <= 0) return DIMSUM_ERR_SHAPE;
     if ((p->mod_scale_ptr == nullptr) != (p->mod_shift_ptr == nullptr)) return DIMSUM_ERR_NULL;
     if (p->mod_scale_ptr && p->rows_per_batch <= 0) return DIMSUM_ERR_SHAPE;
+    // scaled-fp16 image: fp16 rows of N + one inverse scale per row
+    if (p->y_split3 == 2) {
+        if (!p->y_inv_scale_ptr) return DIMSUM_ERR_NULL;
+        if (p->out_dtype != DIMSUM_F16 || p->cols % 4 != 0 || p->y_row_stride % 4 != 0 || p->y_row_stride < p->cols || !dimsum::aligned_to<char>(p->y_ptr, 8))
+            return DIMSUM_ERR_STRIDE;
+    } else
     // split3 output: bf16 rows of 3 N, written 8 bytes at a time
     if (p->y_split3 && (p->out_dtype != DIMSUM_BF16 || p->cols % 4 != 0 || p->y_row_stride % 4 != 0 || p->y_row_stride < 3 * (int64_t)p->cols ||
                         !dimsum::aligned_to<char>(p->y_ptr, 8)))

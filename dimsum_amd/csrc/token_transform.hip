@@ -99,7 +99,10 @@ __device__ __forceinline__ void dct16(const float *X, float *Y, bool inverse) { 
     for (int c = 0; c < 4; ++c) dct4(t + c, 4, Y + c, 4, inverse);               // along y (v)
 }
 
-template <int KIND, int VEC>
+// F16S: y is the scaled-fp16 operand image of the Linear that consumes it (common.hpp, f16s): a token's row of C channels is spread over
+// the workgroup's threads, so the 16 tokens' outputs wait in registers for their exact row maxima (wave butterflies + 4 x 16 floats of
+// LDS); C <= 4 * kTTThreads (one channel group per thread).
+template <int KIND, int VEC, bool F16S = false>
 __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsum_tt_params_t p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -116,6 +119,11 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
         for (int k = 0; k < 16; ++k) s_of[k] = (bh * 4 + (k >> 2)) * G + bw * 4 + (k & 3);
     }
     auto pos_of = [&](int k) { return KIND == DIMSUM_TT_NONE ? (int)blockIdx.x * 16 + k : s_of[k]; };   // NONE: k may be dynamic
+    float stash[F16S ? 16 : 1][VEC], tmax[F16S ? 16 : 1];      // F16S: the outputs of this thread's channel group, the running row maxima
+    if constexpr (F16S) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tmax[k] = 0.f;
+    }
     const float *xb = reinterpret_cast<const float *>(p.x_ptr) + (int64_t)b * p.x_batch_stride;
     float *yb = p.y_ptr ? reinterpret_cast<float *>(p.y_ptr) + (int64_t)b * p.y_batch_stride : nullptr;
     const float *rb = p.residual_ptr ? reinterpret_cast<const float *>(p.residual_ptr) + (int64_t)b * p.res_batch_stride : nullptr;
@@ -165,6 +173,11 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
         if (rb) { load_vec(rb + (int64_t)tok * p.res_token_stride + c, t);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) o[e] += t[e]; }
+        if constexpr (F16S) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { stash[k][e] = o[e]; tmax[k] = fmaxf(tmax[k], fabsf(o[e])); }
+            return;
+        }
         if constexpr (VEC == 4) {
             if (p.y_split3) {       // split-bf16 operand image of the Linear that consumes y: rows of 3 C bf16, strides in bf16 elements
                 st_split3<true>(reinterpret_cast<unsigned short *>(p.y_ptr) + (int64_t)b * p.y_batch_stride + (int64_t)tok * p.y_token_stride, c, C,
@@ -195,7 +208,7 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
         // active, 8 (or 4) tokens with all their loads in flight per thread.
         const int cg = (C + VEC - 1) / VEC;
         const int nsub = cg <= kTTThreads / 4 ? 4 : (cg <= kTTThreads / 2 ? 2 : 1);
-        if (nsub > 1 && C % VEC == 0) {
+        if (!F16S && nsub > 1 && C % VEC == 0) {
             const int sub = tid / cg, c = (tid - sub * cg) * VEC;
             if (sub < nsub) {
                 auto pass = [&](auto perc) {
@@ -288,6 +301,34 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
             flush_red(c);
         }
     }
+
+    if constexpr (F16S && VEC == 4) {
+        // exact row maxima of the 16 tokens: butterflies inside each wave, then the 4 waves through LDS (behind the Haar image)
+        float *red = lds + p.y_f16s_lds_offset;
+        const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tmax[k] = wave_allmax(tmax[k]);
+        if (lane < 16) {
+            float m = tmax[0];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) m = lane == k ? tmax[k] : m;
+            red[wave * 16 + lane] = m;
+        }
+        __syncthreads();
+        const int c = tid * VEC;
+        __half *yh = reinterpret_cast<__half *>(p.y_ptr) + (int64_t)b * p.y_batch_stride;
+        float *inv_out = reinterpret_cast<float *>(p.y_inv_scale_ptr) + (int64_t)b * p.tokens;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (pos_of(k) >= p.tokens) continue;
+            const float m = fmaxf(fmaxf(red[k], red[16 + k]), fmaxf(red[32 + k], red[48 + k]));
+            float sc, inv;
+            f16s_scales(m, sc, inv);
+            const int tok = p.out_index_ptr ? p.out_index_ptr[pos_of(k)] : pos_of(k);
+            if (c < C) *reinterpret_cast<uint2 *>(yh + (int64_t)tok * p.y_token_stride + c) = f16s_pack4(f32x4{{stash[k][0], stash[k][1], stash[k][2], stash[k][3]}}, sc);
+            if (tid == k) inv_out[tok] = inv;
+        }
+    }
 }
 
 template <int VEC>
@@ -295,8 +336,27 @@ static int launch_tt(const dimsum_tt_params_t &p, hipStream_t s) {
     const bool blocked = p.kind != DIMSUM_TT_NONE;
     const int nblk = blocked ? (p.grid / 4) * (p.grid / 4) : (p.tokens + 15) / 16;
     const dim3 grid(nblk, p.batch), block(kTTThreads);
-    const size_t lds = (p.kind == DIMSUM_TT_HAAR_FWD || p.kind == DIMSUM_TT_HAAR_INV) ? (size_t)((p.channels + 3) / 4) * 68 * 4 : 0;
+    size_t lds = (p.kind == DIMSUM_TT_HAAR_FWD || p.kind == DIMSUM_TT_HAAR_INV) ? (size_t)((p.channels + 3) / 4) * 68 * 4 : 0;
     if (lds > 160 * 1024) return DIMSUM_ERR_SHAPE;
+    if (p.y_split3 == 2) {
+        if constexpr (VEC == 4) {
+            dimsum_tt_params_t q = p;
+            q.y_f16s_lds_offset = (int32_t)(lds / 4);
+            lds += 64 * 4;
+#define DIMSUM_TTH(K) hipLaunchKernelGGL((token_transform_kernel<K, 4, true>), grid, block, lds, s, q)
+            switch (p.kind) {
+                case DIMSUM_TT_NONE: DIMSUM_TTH(DIMSUM_TT_NONE); break;
+                case DIMSUM_TT_HAAR_FWD: DIMSUM_TTH(DIMSUM_TT_HAAR_FWD); break;
+                case DIMSUM_TT_HAAR_INV: DIMSUM_TTH(DIMSUM_TT_HAAR_INV); break;
+                case DIMSUM_TT_DCT_FWD: DIMSUM_TTH(DIMSUM_TT_DCT_FWD); break;
+                case DIMSUM_TT_DCT_INV: DIMSUM_TTH(DIMSUM_TT_DCT_INV); break;
+                default: return DIMSUM_ERR_SHAPE;
+            }
+#undef DIMSUM_TTH
+            return launch_status();
+        }
+        return DIMSUM_ERR_STRIDE;
+    }
 #define DIMSUM_TT(K) hipLaunchKernelGGL((token_transform_kernel<K, VEC>), grid, block, lds, s, p)
     switch (p.kind) {
         case DIMSUM_TT_NONE: DIMSUM_TT(DIMSUM_TT_NONE); break;
@@ -411,6 +471,10 @@ extern "C" int dimsum_token_transform(const dimsum_tt_params_t *p, void *stream)
                (!p->scale_ptr || aligned_to<float>(p->scale_ptr, 16)) && (!p->shift_ptr || aligned_to<float>(p->shift_ptr, 16));
     if (p->residual_ptr) vec = vec && aligned_to<float>(p->residual_ptr, 16) && p->res_batch_stride % 4 == 0 && p->res_token_stride % 4 == 0;
     if (p->w_ptr) vec = vec && aligned_to<float>(p->w_ptr, 16) && p->w_batch_stride % 4 == 0 && p->w_token_stride % 4 == 0;
+    if (p->y_split3 == 2) {       // scaled-fp16 image rows + (batch, tokens) inverse scales; no reductions alongside
+        if (!p->y_ptr || !p->y_inv_scale_ptr) return DIMSUM_ERR_NULL;
+        if (!vec || p->y_token_stride < p->channels || p->channels > 4 * kTTThreads || p->w_ptr || p->tsum_ptr) return DIMSUM_ERR_STRIDE;
+    } else
     if (p->y_split3 && (!vec || !p->y_ptr || p->y_token_stride < 3 * (int64_t)p->channels)) return DIMSUM_ERR_STRIDE;   // image rows: 8-byte pieces
     return vec ? launch_tt<4>(*p, s) : launch_tt<1>(*p, s);
 }

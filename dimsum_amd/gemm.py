@@ -74,7 +74,7 @@ def weight_image(weight):
 
 def set_policy(policy):
     global _policy
-    if policy not in ("default", "fp16"):
+    if policy not in ("default", "fp16", "f16s"):
         raise ValueError(f"unknown GEMM policy {policy!r}")
     _policy = policy
 
@@ -203,15 +203,27 @@ def matmul_wx(weight, xt):
 
 
 def split3_enabled(x, weight):
-    """the split3 carrier serves exactly the launches the library would run as split-bf16 fp32 GEMMs: inference, fp32, allow_tf32"""
+    """the operand-image carriers serve exactly the launches the library would run as split-bf16 fp32 GEMMs: inference, fp32, allow_tf32.
+    -> False, True (split-bf16 images: three bf16 products per fp32 product) or "f16s" (policy "f16s": scaled-fp16 images, ONE product):
+    the value is what the producer kernels take as their `split3` argument."""
     import os
-    if not (_policy == "default" and torch.backends.cuda.matmul.allow_tf32 and os.environ.get("DIMSUM_SPLIT3", "1") != "0"
+    mode = "f16s" if _policy == "f16s" else True
+    if mode == "f16s" and x.shape[-1] > 1024:
+        mode = True        # the token passes hold one channel group per thread (C <= 1024): wider models keep the split-bf16 images
+    if not (_policy in ("default", "f16s") and torch.backends.cuda.matmul.allow_tf32 and os.environ.get("DIMSUM_SPLIT3", "1") != "0"
             and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.shape[-1] % 4 == 0
             and not torch.is_grad_enabled()):
         return False
     # the weight image is rebuilt per call (one ~14 us launch): it pays from a few thousand rows on, and in the launch-bound
     # small-batch regime every extra launch costs wall time -- fp32 operands below DIMSUM_SPLIT3_MIN_ROWS (default 8192) rows
-    return x.numel() // x.shape[-1] >= int(os.environ.get("DIMSUM_SPLIT3_MIN_ROWS", "8192"))
+    return mode if x.numel() // x.shape[-1] >= int(os.environ.get("DIMSUM_SPLIT3_MIN_ROWS", "8192")) else False
+
+
+def weight_f16s(weight):
+    """weight (N, K) float32 -> (F16Image (N, K), gate_bound_l1): its scaled-fp16 image (one exact power-of-two scale per row) and
+    max_n sum_k |w_nk| as a 1-element device tensor (the gated epilogue's bound), built once per frozen_weights() scope"""
+    from . import native
+    return _cached("w16s", weight, lambda: native.rows_f16s(weight.detach(), want_l1=True))
 
 
 def own_gemm_enabled():
@@ -230,13 +242,27 @@ def _nt(a, b, **kw):
     return y if kw.get("bias") is None else y + kw["bias"]
 
 
+def _nt_f16s(a, b):
+    """F16Image a (M, K) x F16Image b (N, K)^T -> (M, N) float32: ONE fp16 product per element, the row scales undone in the epilogue"""
+    from . import native
+    if own_gemm_enabled() and native.gemm_nt_supported(a.data, b.data):
+        return native.gemm_nt(a.data, b.data, scales=(a.inv, b.inv))
+    return torch.mm(a.data, b.data.t(), out_dtype=torch.float32) * a.inv[:, None] * b.inv[None, :]
+
+
 def linear_split3(x3, weight):
-    """x3 (M, 3K) bfloat16 left image [hi | hi | lo] @ weight (N, K)^T -> (M, N) float32"""
+    """x3 (M, 3K) bfloat16 left image [hi | hi | lo] (or a scaled-fp16 F16Image (M, K)) @ weight (N, K)^T -> (M, N) float32"""
+    from . import native
+    if isinstance(x3, native.F16Image):
+        return _nt_f16s(x3, weight_f16s(weight)[0])
     return _nt(x3, weight_image(weight))
 
 
 def matmul_wx_split3(weight, x3):
-    """weight (N, K) @ x^T -> (N, M) float32 with x given as its left image x3 (M, 3K): the in_proj site (d-major output)"""
+    """weight (N, K) @ x^T -> (N, M) float32 with x given as its left image x3 (M, 3K) / F16Image: the in_proj site (d-major output)"""
+    from . import native
+    if isinstance(x3, native.F16Image):
+        return _nt_f16s(weight_f16s(weight)[0], x3)
     return _nt(weight_image(weight), x3)
 
 
@@ -245,6 +271,16 @@ def gated_mlp_hidden_split3(x3, w12, b12):
     (dimsum/mlp.py:66-70): ONE kernel, the gate in the GEMM's epilogue -- the fp32 (M, 2F) tensor never exists; the library GEMM + the
     gated-GeLU pass (csrc/token_transform.hip) when the shape does not fit the kernel's tiling."""
     from . import native
+    if isinstance(x3, native.F16Image):
+        w16, l1 = weight_f16s(w12)
+        if own_gemm_enabled() and native.gemm_nt_supported(x3.data, w16.data, gated=True):
+            # the h image's per-row scale comes from the bound |x1|, |x2| <= max|x_r| * max_n sum_k |w_nk| + max|b| -- no row reduction.
+            # (the 2^-10 on the weight bound covers the fp16 rounding of the operands)
+            bmax = b12.abs().max().reshape(1) if b12 is not None else torch.zeros(1, device=l1.device)
+            bound = _cached("w16s_bound", w12, lambda: torch.cat([l1 * (1.0 + 2.0 ** -10), bmax]).contiguous())
+            return native.gemm_nt(x3.data, w16.data, bias=b12, epilogue="gated_f16", scales=(x3.inv, w16.inv), gate_bound=bound)
+        x12 = _nt_f16s(x3, w16)
+        return native.rows_f16s(native.gated_gelu_fwd(x12, b12))
     w3i = weight_image(w12)
     if own_gemm_enabled() and native.gemm_nt_supported(x3, w3i, gated=True):
         return native.gemm_nt(x3, w3i, bias=b12, epilogue="gated_split3")

@@ -141,7 +141,7 @@ def _ln_modulate(norm, x, shift, scale, split3=False):
     if ones is None or ones.device != x.device:
         ones = norm.__dict__["_dimsum_ones"] = torch.ones(H, device=x.device, dtype=torch.float32)
     y = native.layer_norm_fwd(x.reshape(B * L, H), ones, None, norm.eps, is_rms_norm=False, mod_scale=scale, mod_shift=shift, rows_per_batch=L,
-                              **({"split3": True} if split3 else {}))[0]
+                              **({"split3": split3} if split3 else {}))[0]
     return y if split3 else y.view(B, L, H)
 
 
@@ -254,7 +254,8 @@ def _mix_through_images(mixer, hidden_states, kind, table, shift, scale, c):
     """mixer(pre_mixer(hidden_states)); at inference under allow_tf32 the pre-mixer pass writes the in_proj operand as a
     split-bf16 image (gemm.py, split3) instead of fp32"""
     if getattr(mixer, "takes_image", lambda: False)() and gemm.split3_enabled(hidden_states, mixer.in_proj.weight):
-        return mixer(None, c, x3=token_ops.pre_mixer(hidden_states, kind, table, shift, scale, split3=True))
+        return mixer(None, c, x3=token_ops.pre_mixer(hidden_states, kind, table, shift, scale,
+                                                     split3=gemm.split3_enabled(hidden_states, mixer.in_proj.weight)))
     return mixer(token_ops.pre_mixer(hidden_states, kind, table, shift, scale), c)
 
 
@@ -327,7 +328,7 @@ class DiMBlockRaw(_BlockBase):
         table = self._table(hidden_states.shape[1], hidden_states.device, self._order)
         shift, scale, gate = self.adaLN_modulation(c).chunk(3, dim=1)
         m = _mix_through_images(self.mixer, hidden_states, "none", table, shift, scale, c)
-        return token_ops.post_mixer(hidden_states, m, gate, "none", table, **({"split3": True} if out_split3 else {})), residual
+        return token_ops.post_mixer(hidden_states, m, gate, "none", table, **({"split3": out_split3} if out_split3 else {})), residual
 
 
 class _FreqBlock(_BlockBase):
@@ -354,7 +355,7 @@ class _FreqBlock(_BlockBase):
         shift, scale, gate = mods[:3]
         if self.no_ffn:
             m = _mix_through_images(self.mixer, hidden_states, self.kind, table, shift, scale, c)
-            return token_ops.post_mixer(hidden_states, m, gate, self.kind, table, **({"split3": True} if out_split3 else {})), residual
+            return token_ops.post_mixer(hidden_states, m, gate, self.kind, table, **({"split3": out_split3} if out_split3 else {})), residual
         assert not out_split3
         # with an FFN the reference keeps working in the transformed / reordered token space (models_dim.py:678-684)
         t = token_ops.pre_mixer(hidden_states, self.kind, table, torch.zeros_like(shift), torch.zeros_like(scale))
@@ -425,7 +426,7 @@ class _CombinedBase(_BlockBase):
         x1, x2 = hidden_states.chunk(2, dim=2)
         # inference under allow_tf32: the branches hand their results over as split-bf16 operand images of the qkv Linears
         img = gemm.split3_enabled(x1, self.proj.qkv1.weight) and self.proj.takes_images(hidden_states)
-        kw = {"out_split3": True} if img else {}
+        kw = {"out_split3": img} if img else {}
         if ((not torch.is_grad_enabled()) and hidden_states.is_cuda and os.environ.get("DIMSUM_BRANCH_STREAMS", "1") != "0"
                 and not torch.cuda.is_current_stream_capturing()):
             # inference: the two branches are independent until the fusion -- the frequency branch on a second HIP stream lets the
@@ -457,7 +458,7 @@ class _CombinedBase(_BlockBase):
             s3 = gemm.split3_enabled(hidden_states, self.mlp.w12.weight) and getattr(self.mlp, "_fused", False)
             y, _, _, hnew = native.layer_norm_fwd(fused.reshape(B * L, H), self.norm_2.weight, self.norm_2.bias, self.norm_2.eps,
                                                   residual=hidden_states.reshape(B * L, H), is_rms_norm=True, x_bias=pb,
-                                                  mod_scale=scale, mod_shift=shift, rows_per_batch=L, **({"split3": True} if s3 else {}))
+                                                  mod_scale=scale, mod_shift=shift, rows_per_batch=L, **({"split3": s3} if s3 else {}))
             m, mb = self.mlp.forward_deferred(hidden_states, x3=y) if s3 else self.mlp.forward_deferred(y.view(B, L, H))
             return token_ops.gate_residual(hnew.view(B, L, H), m, gate, mb), residual
         hidden_states = token_ops.gate_residual(hidden_states, fused, None, pb)

@@ -217,7 +217,8 @@ def layer_norm_fwd(x, weight, bias, eps, residual=None, out_dtype=None, residual
     residual_out is x itself when no residual is added and no dtype change is requested.
     Extras: `x_bias` (N) is added to x first (the bias of the Linear that produced x); `mod_scale/mod_shift`
     ((M / rows_per_batch, N), sharing a row stride) apply y * (1 + scale) + shift per batch element after the norm;
-    `split3`: y is returned as the split-bf16 left operand image (M, 3N) bfloat16 of the Linear that consumes it (split3_rows)."""
+    `split3`: y is returned as the split-bf16 left operand image (M, 3N) bfloat16 of the Linear that consumes it (split3_rows);
+    `split3="f16s"`: as a scaled-fp16 image (F16Image, rows_f16s)."""
     _gpu(x, weight, bias, residual)
     _check(x.dim() == 2 and x.stride(-1) == 1, "layer_norm_fwd: x must be (M, N) with contiguous rows")
     M, N = x.shape
@@ -225,7 +226,12 @@ def layer_norm_fwd(x, weight, bias, eps, residual=None, out_dtype=None, residual
     if residual is not None:
         _check(residual.shape == x.shape and residual.stride(-1) == 1, "layer_norm_fwd: bad residual")
         residual_dtype = residual.dtype
-    if split3:
+    y_inv = None
+    if split3 == "f16s":
+        _check(N % 4 == 0, "layer_norm_fwd: the f16s image needs N % 4 == 0")
+        y = torch.empty((M, N), device=x.device, dtype=torch.float16)
+        y_inv = torch.empty((M,), device=x.device, dtype=torch.float32)
+    elif split3:
         _check(N % 4 == 0 and out_dtype in (None, torch.bfloat16), "layer_norm_fwd: split3 needs N % 4 == 0 (bfloat16 output)")
         y = torch.empty((M, 3 * N), device=x.device, dtype=torch.bfloat16)
     else:
@@ -239,7 +245,8 @@ def layer_norm_fwd(x, weight, bias, eps, residual=None, out_dtype=None, residual
     if M > 0:
         P = _lib.NormParams()
         P.rows, P.cols, P.is_rms_norm, P.eps = M, N, int(is_rms_norm), float(eps)
-        P.x_dtype, P.out_dtype, P.y_split3 = _DT[x.dtype], _DT[y.dtype], int(split3)
+        P.x_dtype, P.out_dtype, P.y_split3 = _DT[x.dtype], _DT[y.dtype], (2 if split3 == "f16s" else int(bool(split3)))
+        P.y_inv_scale_ptr = _ptr(y_inv)
         P.residual_dtype = _DT[residual_out.dtype] if residual_out is not None else _DT[x.dtype]
         P.x_row_stride, P.y_row_stride = x.stride(0), y.stride(0)
         if residual is not None:
@@ -264,6 +271,8 @@ def layer_norm_fwd(x, weight, bias, eps, residual=None, out_dtype=None, residual
             P.mod_scale_ptr, P.mod_shift_ptr, P.mod_row_stride, P.rows_per_batch = _ptr(mod_scale), _ptr(mod_shift), mod_scale.stride(0), rows_per_batch
         with torch.cuda.device(x.device):
             _lib.check(_lib.load().dimsum_norm_fwd(P, _stream(x)), "layer_norm_fwd")
+    if y_inv is not None:
+        y = F16Image(y, y_inv)
     return y, mean, rstd, residual_out if residual_out is not None else x
 
 
@@ -368,7 +377,8 @@ def token_transform(x, kind, forward, in_index=None, out_index=None, gate=None, 
         wdot = sum_s T(.)[s, c] * w[b, out_index[s], c]     and (want_wsum)  wsum = sum_s w[b, out_index[s], c]
     and returns (y or None, wdot, wsum or None) -- the adaLN-modulation gradients of the block backward.
     `want_tsum` appends tsum = sum_s T(.)[s, c] (the plain token sum) to the returned tuple.
-    `split3`: y is returned as the split-bf16 left operand image (B, L, 3C) bfloat16 of the Linear that consumes it (split3_rows)."""
+    `split3`: y is returned as the split-bf16 left operand image (B, L, 3C) bfloat16 of the Linear that consumes it (split3_rows);
+    `split3="f16s"`: as a scaled-fp16 image (F16Image: data (B, L, C) float16, inv (B, L); C <= 1024)."""
     _gpu(x, in_index, out_index, gate, scale, shift, residual, w)
     _check(x.dim() == 3 and x.dtype == torch.float32 and x.stride(2) == 1, "token_transform: x must be (B, L, C) float32, channel-contiguous")
     B, L, C = x.shape
@@ -376,7 +386,12 @@ def token_transform(x, kind, forward, in_index=None, out_index=None, gate=None, 
     if kind != "none":
         _check(grid * grid == L and grid % 4 == 0, "token_transform: the token grid must be square with side % 4 == 0")
     _check(want_y or w is not None or want_tsum, "token_transform: nothing to compute")
-    if split3:
+    y_inv = None
+    if split3 == "f16s":
+        _check(want_y and C % 4 == 0 and C <= 1024 and w is None and not want_tsum, "token_transform: the f16s image needs channels % 4 == 0, <= 1024, no reductions")
+        y = torch.empty((B, L, C), device=x.device, dtype=torch.float16)
+        y_inv = torch.empty((B, L), device=x.device, dtype=torch.float32)
+    elif split3:
         _check(want_y and C % 4 == 0, "token_transform: split3 needs an output and channels % 4 == 0")
         y = torch.empty((B, L, 3 * C), device=x.device, dtype=torch.bfloat16)
     else:
@@ -402,7 +417,8 @@ def token_transform(x, kind, forward, in_index=None, out_index=None, gate=None, 
     if B > 0:
         P = _lib.TtParams()
         P.batch, P.tokens, P.channels, P.grid, P.kind = B, L, C, grid, _TT_KIND[(kind, bool(forward))]
-        P.y_split3 = int(split3)
+        P.y_split3 = 2 if split3 == "f16s" else int(bool(split3))
+        P.y_inv_scale_ptr = _ptr(y_inv)
         P.x_batch_stride, P.x_token_stride = x.stride(0), x.stride(1)
         if y is not None:
             P.y_batch_stride, P.y_token_stride = y.stride(0), y.stride(1)
@@ -417,6 +433,8 @@ def token_transform(x, kind, forward, in_index=None, out_index=None, gate=None, 
         P.w_ptr, P.wdot_ptr, P.wsum_ptr, P.tsum_ptr = _ptr(w), _ptr(wdot), _ptr(wsum), _ptr(tsum)
         with torch.cuda.device(x.device):
             _lib.check(_lib.load().dimsum_token_transform(P, _stream(x)), "token_transform")
+    if y_inv is not None:
+        return F16Image(y, y_inv)
     if want_tsum:
         return (y, wdot, wsum, tsum)
     return y if w is None else (y, wdot, wsum)
@@ -454,6 +472,50 @@ def split3_rows(x, left):
     return out
 
 
+class F16Image:
+    """scaled-fp16 operand image (csrc/common.hpp, f16s): data (..., K) float16 = fp16(x * 2^s), one s per row, inv (...) float32 = 2^-s.
+    Quacks like the tensor it replaces where the host layer only reshapes it and hands it to the next GEMM."""
+    __slots__ = ("data", "inv")
+
+    def __init__(self, data, inv):
+        self.data, self.inv = data, inv
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+    def reshape(self, *shape):
+        d = self.data.reshape(*shape)
+        return F16Image(d, self.inv.reshape(d.shape[:-1]))
+
+    view = reshape
+
+    def record_stream(self, stream):
+        self.data.record_stream(stream)
+        self.inv.record_stream(stream)
+
+    def float(self):
+        return self.data.float() * self.inv.unsqueeze(-1)
+
+
+def rows_f16s(x, want_l1=False):
+    """(R, K) float32 rows (stride(1) == 1) -> F16Image [, l1max]: row r = fp16(x_r * 2^s_r) with 2^s_r max|x_r| in [2^14, 2^15) and
+    inv[r] = 2^-s_r (csrc/operand_split.hip). want_l1: also max_r sum_k |x_rk| as a 1-element float32 tensor (weights: the bound of
+    the gated GEMM epilogue)."""
+    _gpu(x)
+    _check(x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1 and x.shape[1] % 4 == 0 and x.stride(0) % 4 == 0,
+           "rows_f16s: x must be (R, K) float32 with contiguous rows, K % 4 == 0 and a row stride % 4 == 0")
+    R, K = x.shape
+    out = torch.empty((R, K), device=x.device, dtype=torch.float16)
+    inv = torch.empty((R,), device=x.device, dtype=torch.float32)
+    l1 = torch.zeros((1,), device=x.device, dtype=torch.float32) if want_l1 else None
+    if R > 0:
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().dimsum_rows_f16s(_ptr(x), R, K, x.stride(0), _ptr(out), K, _ptr(inv), _ptr(l1), _stream(x)), "rows_f16s")
+    img = F16Image(out, inv)
+    return (img, l1) if want_l1 else img
+
+
 def gemm_nt_supported(a, b, gated=False):
     """shapes the hand-written NT GEMM takes (csrc/gemm_nt_kernel.hpp): 256-row panels of 16-bit rows, 64-deep K tiles"""
     if not (a.is_cuda and a.dim() == 2 and b.dim() == 2 and a.dtype == b.dtype and a.dtype in (torch.bfloat16, torch.float16)):
@@ -465,13 +527,16 @@ def gemm_nt_supported(a, b, gated=False):
             and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and 512 * max(a.stride(0), b.stride(0)) < 2 ** 31)
 
 
-def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=None, tune=None):
+def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=None, tune=None, scales=None, gate_bound=None):
     """a (M, K) @ b (N, K)^T on the hand-written MFMA kernel, 16-bit operands (bfloat16: split-bf16 images over 3 K; float16: scaled rows),
     fp32 accumulation.
       epilogue "f32"          -> (M, N) float32 (+ bias[N])
                "gated_split3" -> b = the (2F, K) w12 weight image, bias (2F) or None: the LEFT split-bf16 image (M, 3F) bfloat16 of
                                  gelu_tanh(x1 + b1) * (x2 + b2)   (mlp.py:66-70; the fp32 (M, 2F) x12 never exists)
                "gated_f16"    -> same, (M, F) float16 of h * out_scale
+    scales: (a_inv (M,), b_inv (N,)) float32 inverse scales of scaled-fp16 operand images (F16Image): C[m, n] *= a_inv[m] * b_inv[n].
+    gate_bound ("gated_f16" over scaled operands): 2-element float32 device tensor {max_n sum_k |w_nk|, max |bias|}: the h image gets a
+    per-row power-of-two scale derived from it and the call returns (h16, h_inv).
     events: optional (start, stop) raw hipEvent_t handles recorded at the kernel's dispatch boundaries (bench.py)."""
     _gpu(a, b, bias)
     gated = epilogue != "f32"
@@ -503,6 +568,19 @@ def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=Non
     else:
         raise ValueError(f"gemm_nt: unknown epilogue {epilogue!r}")
     P.ldc = out.stride(0)
+    h_inv = None
+    if scales is not None:
+        sa, sb = scales
+        _gpu(sa, sb)
+        _check(sa.dtype == torch.float32 and sb.dtype == torch.float32 and sa.is_contiguous() and sb.is_contiguous() and sa.numel() == M
+               and sb.numel() == N, "gemm_nt: scales must be contiguous float32 (M,) and (N,)")
+        P.a_inv_scale_ptr, P.b_inv_scale_ptr = _ptr(sa), _ptr(sb)
+        if gate_bound is not None:
+            _gpu(gate_bound)
+            _check(epilogue == "gated_f16" and gate_bound.dtype == torch.float32 and gate_bound.numel() == 2 and gate_bound.is_contiguous(),
+                   "gemm_nt: gate_bound is a 2-element float32 tensor for the gated_f16 epilogue")
+            h_inv = torch.empty((M,), device=a.device, dtype=torch.float32)
+            P.gate_bound_ptr, P.h_inv_scale_ptr = _ptr(gate_bound), _ptr(h_inv)
     P.a_ptr, P.b_ptr, P.bias_ptr, P.c_ptr = _ptr(a), _ptr(b), _ptr(bias), _ptr(out)
     if events is not None:
         P.timing_start_event, P.timing_stop_event = events
@@ -510,7 +588,7 @@ def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=Non
         P.tune_variant, P.tune_group_m, P.tune_start_delay = tune
     with torch.cuda.device(a.device):
         _lib.check(_lib.load().dimsum_gemm_nt(P, _stream(a)), "gemm_nt")
-    return out
+    return out if h_inv is None else F16Image(out, h_inv)
 
 
 def gated_gelu_bwd(x12, bias, dh, need_dbias=True, split3=False):

@@ -222,7 +222,7 @@ def pre_mixer(x, kind, table, shift, scale, split3=False):
     _require_gpu(x)
     if split3:
         from .. import native
-        return native.token_transform(_cc(x), kind, True, out_index=None if table is None else table["inv32"], scale=scale, shift=shift, split3=True)
+        return native.token_transform(_cc(x), kind, True, out_index=None if table is None else table["inv32"], scale=scale, shift=shift, split3=split3)
     return _PreMixer.apply(x, shift, scale, kind, None if table is None else table["inv32"])
 
 
@@ -231,5 +231,5 @@ def post_mixer(x, m, gate, kind, table, split3=False):
     _require_gpu(x)
     if split3:
         from .. import native
-        return native.token_transform(_cc(m), kind, False, in_index=None if table is None else table["inv32"], gate=gate, residual=_cc(x), split3=True)
+        return native.token_transform(_cc(m), kind, False, in_index=None if table is None else table["inv32"], gate=gate, residual=_cc(x), split3=split3)
     return _PostMixer.apply(x, m, gate, kind, None if table is None else table["inv32"])

@@ -192,8 +192,10 @@ typedef struct {
     const void *mod_scale_ptr, *mod_shift_ptr;  /* (M / rows_per_batch, N) f32, both or none */
     int64_t mod_row_stride;
     int32_t rows_per_batch;
-    int32_t y_split3;   /* != 0: y is a split-bf16 left operand image, rows of 3 N bf16 [hi | hi | lo] (out_dtype BF16, N % 4 == 0,
-                         * y_row_stride >= 3 N): see dimsum_split3 */
+    int32_t y_split3;   /* 1: y is a split-bf16 left operand image, rows of 3 N bf16 [hi | hi | lo] (out_dtype BF16, N % 4 == 0,
+                         * y_row_stride >= 3 N): see dimsum_split3.  2: y is a scaled-fp16 operand image (out_dtype F16, N % 4 == 0):
+                         * row r = fp16(y_r * 2^s_r) with 2^-s_r written to y_inv_scale_ptr[r]: see dimsum_rows_f16s */
+    void *y_inv_scale_ptr;                      /* (M) f32, y_split3 == 2 only */
 } dimsum_norm_params_t;
 
 typedef struct {
@@ -223,6 +225,16 @@ int dimsum_norm_bwd(const dimsum_norm_bwd_params_t *p, void *stream);
  * ------------------------------------------------------------------------------------------------------------- */
 int dimsum_split3(const void *src, int64_t rows, int64_t cols, int64_t src_row_stride, void *dst, int32_t left, void *stream);
 
+/* Scaled-fp16 operand image ("f16s") -- the single-product carrier of the same policy: TF32 keeps 10 mantissa bits of each operand and
+ * accumulates in fp32; fp16 has exactly that mantissa, and its narrow exponent is taken out of the picture by an exact power-of-two
+ * scale per row: dst[r, :] = fp16(src[r, :] * 2^s_r), 2^s_r * max|src[r, :]| in [2^14, 2^15), inv_scale[r] = 2^-s_r. The GEMM multiplies
+ * the images (v_mfma_f32_16x16x32_f16, fp32 accumulation) and its epilogue applies a_inv_scale[m] * b_inv_scale[n] (dimsum_gemm_nt).
+ *   src (rows, cols) f32, cols % 4 == 0; dst (rows, cols) f16; inv_scale (rows) f32;
+ *   l1max: NULL, or one f32 (zeroed by the caller) that receives max_r sum_c |src[r, c]| (weights: the bound the gated epilogue uses).
+ * Producer kernels write the image directly (dimsum_norm_params_t.y_split3 == 2, dimsum_tt_params_t.y_split3 == 2, GATED_GELU_F16). */
+int dimsum_rows_f16s(const void *src, int64_t rows, int64_t cols, int64_t src_row_stride, void *dst, int64_t dst_row_stride,
+                     void *inv_scale, void *l1max, void *stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * Token-space transforms on (batch, L = grid*grid tokens, channels) f32 tensors: ONE pass that fuses
  *   - a per-channel gate at load:             v[s, c] = x[b, in_index[s], c] * gate[b, c]
@@ -249,8 +261,10 @@ typedef enum {
 typedef struct {
     int32_t batch, tokens, channels, grid; /* tokens = grid*grid, grid % 4 == 0 unless kind == NONE */
     int32_t kind;                          /* dimsum_tt_kind_t */
-    int32_t y_split3;                      /* != 0: y is the split-bf16 left operand image of the Linear that consumes it: rows of
-                                              3 C bf16 [hi | hi | lo] (dimsum_split3); y strides in bf16 elements, channels % 4 == 0 */
+    int32_t y_split3;                      /* 1: y is the split-bf16 left operand image of the Linear that consumes it: rows of
+                                              3 C bf16 [hi | hi | lo] (dimsum_split3); y strides in bf16 elements, channels % 4 == 0.
+                                              2: y is the scaled-fp16 image (dimsum_rows_f16s): fp16 rows of C (strides in fp16 elements,
+                                              channels % 4 == 0, channels <= 1024), y_inv_scale_ptr[b * tokens + token] = 2^-s */
     int64_t x_batch_stride, x_token_stride;           /* channel stride 1 everywhere */
     int64_t res_batch_stride, res_token_stride;
     int64_t y_batch_stride, y_token_stride;
@@ -264,6 +278,8 @@ typedef struct {
     const void *w_ptr;                                /* (batch, tokens, channels) f32 or NULL */
     void *wdot_ptr, *wsum_ptr;                        /* (batch, channels) f32 accumulators (atomicAdd) or NULL */
     void *tsum_ptr;                                   /* (batch, channels) f32: tsum[b, c] += sum_s T(v)[s, c], or NULL */
+    void *y_inv_scale_ptr;                            /* (batch, tokens) f32, y_split3 == 2 only */
+    int32_t y_f16s_lds_offset;                        /* internal (set by the library) */
 } dimsum_tt_params_t;
 
 int dimsum_token_transform(const dimsum_tt_params_t *p, void *stream);
@@ -355,6 +371,14 @@ typedef struct {
     void *c_ptr;
     void *timing_start_event, *timing_stop_event;   /* optional hipEvent_t pair recorded at the kernel's own dispatch boundaries */
     int32_t tune_variant, tune_group_m, tune_start_delay;   /* 0 = the shipped schedule (tools/bench_gemm.py sweeps) */
+    /* scaled-fp16 operand images (dimsum_rows_f16s): C[m, n] = acc * a_inv_scale[m] * b_inv_scale[n] (exact powers of two), both or none */
+    const void *a_inv_scale_ptr;  /* (m) f32 */
+    const void *b_inv_scale_ptr;  /* (n) f32 */
+    /* GATED_GELU_F16 over scaled operands: the h image gets one power-of-two scale per row, derived WITHOUT a row reduction from the bound
+     * |x1|, |x2| <= max|a_m| * gate_bound[0] + gate_bound[1]  (gate_bound = {max_n sum_k |w_nk|, max |bias|}, 2 f32 on the device);
+     * its inverse goes to h_inv_scale[m] -- the a_inv_scale of the w3 GEMM. NULL: out_scale for every row. */
+    const void *gate_bound_ptr;
+    void *h_inv_scale_ptr;        /* (m) f32 */
 } dimsum_gemm_params_t;
 
 int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream);

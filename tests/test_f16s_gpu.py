@@ -1,0 +1,221 @@
+"""Scaled-fp16 operand images ("f16s", csrc/common.hpp): the single-product carrier of the reference's TF32 matmul policy
+(dimsum/train.py:20-21). A row travels as fp16(row * 2^s) + the exact inverse scale; one v_mfma_f32_16x16x32_f16 product per element
+with fp32 accumulation is then the TF32 arithmetic itself (10-bit mantissas, fp32 sums), with the range taken care of by construction.
+Checked: the images against torch's own fp16 rounding, the producers against the stand-alone converter, the products against float64
+next to an emulated-TF32 product (tests/tf32_emulation.py), adversarial ranges, and blocks / models against exact fp32 next to
+the emulated-TF32 run of the same module."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _expected_image(x):
+    m = x.abs().amax(-1, keepdim=True)
+    e = torch.floor(torch.log2(m.double().clamp_min(2.0 ** -112))).clamp(-112, 127)
+    scale = torch.pow(torch.tensor(2.0, dtype=torch.float64, device=x.device), 14 - e).float()
+    return (x * scale).half(), (1.0 / scale.double()).float().squeeze(-1)
+
+
+def test_rows_f16s_bit_exact_and_in_range():
+    from dimsum_amd import native
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(67, 200, device="cuda", generator=g) * torch.logspace(-30, 30, 67, device="cuda")[:, None]
+    x[5] = 0.0
+    x[6, 3] = 1e4 * x[6].abs().max()                      # an outlier
+    buf = torch.zeros(67, 208, device="cuda")
+    buf[:, :200] = x
+    for src in (x, buf[:, :200]):
+        img, l1 = native.rows_f16s(src, want_l1=True)
+        want, inv = _expected_image(src)
+        assert img.data.dtype == torch.float16 and tuple(img.data.shape) == (67, 200)
+        assert torch.equal(img.data.view(torch.int16), want.view(torch.int16)) and torch.equal(img.inv, inv)
+        assert torch.isfinite(img.data).all()
+        top = img.data.float().abs().amax(-1)
+        assert ((top >= 2.0 ** 14) & (top < 2.0 ** 15))[src.abs().amax(-1) > 0].all()
+        assert abs(l1.item() - src.abs().sum(-1).max().item()) <= 1e-5 * l1.item()
+    # every element at or above 2^-28 of its row's maximum keeps fp16's full significand: relative error <= 2^-11
+    img = native.rows_f16s(x)
+    back = img.float()
+    big = x.abs() >= x.abs().amax(-1, keepdim=True) * 2.0 ** -28
+    assert ((back - x).abs()[big] <= x.abs()[big] * 2.0 ** -11).all()
+
+
+def test_norm_and_token_passes_write_the_image_of_their_fp32_output():
+    from dimsum_amd import native
+    g = torch.Generator(device="cuda").manual_seed(1)
+    M, N, L = 96, 384, 16
+    x, res = torch.randn(M, N, device="cuda", generator=g) * torch.logspace(-4, 4, M, device="cuda")[:, None], torch.randn(M, N, device="cuda", generator=g)
+    w, xb = torch.rand(N, device="cuda", generator=g) + 0.5, torch.randn(N, device="cuda", generator=g)
+    sc, sh = 0.1 * torch.randn(M // L, N, device="cuda", generator=g), torch.randn(M // L, N, device="cuda", generator=g)
+    kw = dict(residual=res, is_rms_norm=True, x_bias=xb, mod_scale=sc, mod_shift=sh, rows_per_batch=L)
+    y, _, rstd, r = native.layer_norm_fwd(x, w, None, 1e-5, **kw)
+    yi, _, rstd2, r2 = native.layer_norm_fwd(x, w, None, 1e-5, split3="f16s", **kw)
+    want = native.rows_f16s(y)
+    assert torch.equal(yi.data.view(torch.int16), want.data.view(torch.int16)) and torch.equal(yi.inv, want.inv)
+    assert torch.equal(rstd, rstd2) and torch.equal(r, r2)
+    B, L, C = 3, 64, 40
+    for kind in ("none", "haar", "dct"):
+        wide = torch.randn(B, L, 2 * C, device="cuda", generator=g) * torch.logspace(-3, 3, L, device="cuda")[None, :, None]
+        xs, rs = wide[:, :, :C], wide[:, :, C:]
+        sc, sh = 0.1 * torch.randn(B, C, device="cuda", generator=g), torch.randn(B, C, device="cuda", generator=g)
+        perm = torch.randperm(L, device="cuda", generator=g).to(torch.int32)
+        for fwd, kw in ((True, dict(out_index=perm, scale=sc, shift=sh)), (False, dict(in_index=perm, gate=sc, residual=rs))):
+            y = native.token_transform(xs, kind, fwd, **kw)
+            yi = native.token_transform(xs, kind, fwd, split3="f16s", **kw)
+            want = native.rows_f16s(y.reshape(B * L, C))
+            assert torch.equal(yi.data.reshape(B * L, C).view(torch.int16), want.data.view(torch.int16)), (kind, fwd)
+            assert torch.equal(yi.inv.reshape(-1), want.inv)
+    # full width of a DiM-L/2 branch (512 channels) and of a whole block (1024)
+    for C in (512, 1024):
+        xs = torch.randn(2, 256, C, device="cuda", generator=g)
+        sc, sh = 0.1 * torch.randn(2, C, device="cuda", generator=g), torch.randn(2, C, device="cuda", generator=g)
+        y = native.token_transform(xs, "haar", True, scale=sc, shift=sh)
+        yi = native.token_transform(xs, "haar", True, scale=sc, shift=sh, split3="f16s")
+        want = native.rows_f16s(y.reshape(512, C))
+        assert torch.equal(yi.data.reshape(512, C).view(torch.int16), want.data.view(torch.int16)) and torch.equal(yi.inv.reshape(-1), want.inv)
+
+
+def _errs(got, ref):
+    d = (got.double() - ref).abs()
+    return d.max().item(), d.pow(2).mean().sqrt().item()
+
+
+@pytest.mark.parametrize("M,K,N", [(512, 256, 384), (1024, 1024, 2048)])
+@pytest.mark.parametrize("adversarial", [False, True])
+def test_product_is_never_less_accurate_than_tf32(M, K, N, adversarial):
+    """x W^T on scaled-fp16 images against float64, next to the emulated TF32 product of the same operands: the same 10-bit
+    mantissas, so the same error (<= 1.05 x in max and rms). adversarial: rows scaled by 10^-6 .. 10^6 plus one 10^4 outlier per row --
+    what plain fp16 operands cannot carry (overflow / flush) and per-row scales absorb exactly."""
+    from tf32_emulation import round_tf32
+    from dimsum_amd import gemm, native
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x, w = torch.randn(M, K, device="cuda", generator=g), torch.randn(N, K, device="cuda", generator=g) * K ** -0.5
+    if adversarial:
+        x = x * torch.logspace(-6, 6, M, device="cuda")[:, None]
+        x[torch.arange(M), torch.randint(0, K, (M,), device="cuda", generator=g)] *= 1e4
+        w = w * torch.logspace(-3, 3, N, device="cuda")[:, None]
+    ref = x.double() @ w.double().t()
+    row = ref.abs().amax(-1, keepdim=True)                                        # errors are judged per output row (its own magnitude)
+    got = gemm._nt_f16s(native.rows_f16s(x), native.rows_f16s(w))
+    tf = (round_tf32(x).double() @ round_tf32(w).double().t()).float()           # exact products of TF32 operands, then one fp32 rounding
+    e_got, e_tf = ((got.double() - ref).abs() / row), ((tf.double() - ref).abs() / row)
+    assert torch.isfinite(got).all()
+    assert e_got.max().item() <= 1.05 * e_tf.max().item() + 1e-6, (e_got.max().item(), e_tf.max().item())
+    assert e_got.pow(2).mean().sqrt().item() <= 1.05 * e_tf.pow(2).mean().sqrt().item() + 1e-7
+    if adversarial:                                                               # ... where unscaled fp16 operands fail outright
+        plain = torch.mm(x.half(), w.half().t(), out_dtype=torch.float32)
+        assert not torch.isfinite(plain).all() or ((plain.double() - ref).abs() / row).max().item() > 10 * e_got.max().item()
+
+
+def test_gated_mlp_on_scaled_images_vs_tf32():
+    """w12 + bias + gelu_tanh * gate -> h image (per-row scale from the bound, no row reduction) -> w3: against float64 next to the
+    emulated-TF32 evaluation of the same MLP; with rows of very different magnitude and outliers"""
+    from tf32_emulation import round_tf32
+    from dimsum_amd import gemm, native
+    g = torch.Generator(device="cuda").manual_seed(6)
+    M, H, F = 1024, 512, 2048
+    x = torch.randn(M, H, device="cuda", generator=g) * torch.logspace(-3, 3, M, device="cuda")[:, None]
+    x[torch.arange(M), torch.randint(0, H, (M,), device="cuda", generator=g)] *= 50.0
+    w12, b12 = torch.randn(2 * F, H, device="cuda", generator=g) * H ** -0.5, 0.1 * torch.randn(2 * F, device="cuda", generator=g)
+    w3 = torch.randn(H, F, device="cuda", generator=g) * F ** -0.5
+
+    def mlp64(xx, a, b):
+        x12 = xx.double() @ a.double().t() + b12.double()
+        h = torch.nn.functional.gelu(x12[:, :F], approximate="tanh") * x12[:, F:]
+        return h, h @ b.double().t()
+    h_ref, y_ref = mlp64(x, w12, w3)
+    himg = gemm.gated_mlp_hidden_split3(native.rows_f16s(x), w12, b12)
+    assert isinstance(himg, native.F16Image) and torch.isfinite(himg.data).all()
+    assert himg.data.float().abs().max().item() < 2.0 ** 15                       # the bound-derived scale keeps every row in range
+    y = gemm.linear_split3(himg, w3)
+    # emulated TF32: both GEMMs on operands rounded to 10 mantissa bits, everything else in float64
+    x12 = round_tf32(x).double() @ round_tf32(w12).double().t() + b12.double()
+    h_tf = (torch.nn.functional.gelu(x12[:, :F], approximate="tanh") * x12[:, F:]).float()
+    y_tf = round_tf32(h_tf).double() @ round_tf32(w3).double().t()
+    row = y_ref.abs().amax(-1, keepdim=True)
+    e, e_tf = (y.double() - y_ref).abs() / row, (y_tf - y_ref).abs() / row
+    assert e.max().item() <= 1.1 * e_tf.max().item() + 1e-6, (e.max().item(), e_tf.max().item())
+    assert e.pow(2).mean().sqrt().item() <= 1.1 * e_tf.pow(2).mean().sqrt().item() + 1e-7
+    hrow = h_ref.abs().amax(-1, keepdim=True)
+    assert ((himg.float().double() - h_ref).abs() / hrow).max().item() <= 1.1 * ((h_tf.double() - h_ref).abs() / hrow).max().item() + 1e-6
+
+
+def _block_1024():
+    from procedural import procedural_fill, seeded
+    from dimsum_amd.models_dim import create_block
+    blk = create_block(1024, norm_epsilon=1e-5, rms_norm=True, residual_in_fp32=True, fused_add_norm=True, layer_idx=1,
+                       scan_type="none", block_type="combined", reverse=True, transpose=True, cond_mamba=True,
+                       scanning_continuity=True, use_gated_mlp=True)
+    procedural_fill(blk, seed=9)
+    T = torch.from_numpy
+    x, res, cc = (T(seeded(sh, sd)).cuda() for sh, sd in (((2, 256, 1024), 56), ((2, 256, 1024), 57), ((2, 1024), 58)))
+    return blk.cuda().eval(), (x, res, cc)
+
+
+def test_block_under_f16s_policy_vs_emulated_tf32(monkeypatch):
+    """DiMBlockCombined(1024), inference: the deviation of the f16s policy from the exact-fp32 forward is not larger than the deviation
+    of the emulated-TF32 forward (the reference's own arithmetic) -- and the block still meets the reference golden's tolerance"""
+    from tf32_emulation import emulated_tf32
+    from dimsum_amd import gemm
+    blk, args = _block_1024()
+    monkeypatch.setenv("DIMSUM_SPLIT3_MIN_ROWS", "0")
+    old = torch.backends.cuda.matmul.allow_tf32
+    try:
+        with torch.no_grad():
+            torch.backends.cuda.matmul.allow_tf32 = False
+            ref = blk(*args)[0].double()
+            with emulated_tf32():
+                tf = blk(*args)[0]
+            torch.backends.cuda.matmul.allow_tf32 = True
+            three = blk(*args)[0]
+            gemm.set_policy("f16s")
+            one = blk(*args)[0]
+    finally:
+        gemm.set_policy("default")
+        torch.backends.cuda.matmul.allow_tf32 = old
+    scale = ref.abs().max().item()
+    (m1, r1), (mt, rt), (m3, r3) = _errs(one, ref), _errs(tf, ref), _errs(three, ref)
+    print(f"block_1024: max / rms deviation from exact fp32 over max|y|: f16s {m1 / scale:.2e} / {r1 / scale:.2e}, emulated TF32 {mt / scale:.2e} / {rt / scale:.2e}, "
+          f"3-product {m3 / scale:.2e} / {r3 / scale:.2e}")
+    assert not torch.equal(one, three)
+    assert m1 <= 1.25 * mt and r1 <= 1.1 * rt, ((m1, r1), (mt, rt))
+    assert m1 / scale < 1e-3
+
+
+@pytest.mark.parametrize("name", ["DiM-L/2"])
+def test_model_under_f16s_policy_vs_emulated_tf32(name):
+    """the whole denoiser (reference init, zero tensors re-drawn): f16s deviation from exact fp32 <= emulated-TF32 deviation"""
+    from tf32_emulation import emulated_tf32
+    from dimsum_amd import gemm
+    from dimsum_amd.create_model import create_model, published_config
+    from dimsum_amd.utils import rerandomize_zeros
+    torch.manual_seed(0)
+    m = create_model(published_config(model=name, image_size=256))
+    rerandomize_zeros(m, std=0.02, seed=0)
+    m = m.cuda().eval()
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    B = 32                                                   # 8192 rows: the image carriers are on at their default threshold
+    x, t = torch.randn(B, 4, 32, 32, device="cuda", generator=gen), torch.rand(B, device="cuda", generator=gen)
+    y = torch.randint(0, 1000, (B,), device="cuda", generator=gen)
+    old = torch.backends.cuda.matmul.allow_tf32
+    try:
+        with torch.no_grad():
+            torch.backends.cuda.matmul.allow_tf32 = False
+            ref = m(x, t, y).double()
+            with emulated_tf32():
+                tf = m(x, t, y)
+            torch.backends.cuda.matmul.allow_tf32 = True
+            three = m(x, t, y)
+            gemm.set_policy("f16s")
+            one = m(x, t, y)
+    finally:
+        gemm.set_policy("default")
+        torch.backends.cuda.matmul.allow_tf32 = old
+    scale = ref.abs().max().item()
+    (m1, r1), (mt, rt), (m3, r3) = _errs(one, ref), _errs(tf, ref), _errs(three, ref)
+    print(f"{name}: max / rms deviation from exact fp32 over max|out|: f16s {m1 / scale:.2e} / {r1 / scale:.2e}, emulated TF32 {mt / scale:.2e} / {rt / scale:.2e}, "
+          f"3-product {m3 / scale:.2e} / {r3 / scale:.2e}")
+    assert m1 <= 1.25 * mt and r1 <= 1.1 * rt, ((m1, r1), (mt, rt))
+    assert m1 / scale < 1e-3
