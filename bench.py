@@ -255,9 +255,9 @@ class Bench:
     @staticmethod
     def set_matmul(policy):
         from dimsum_amd import gemm
-        torch.backends.cuda.matmul.allow_tf32 = policy in ("tf32", "fp16")
-        torch.backends.cudnn.allow_tf32 = policy in ("tf32", "fp16")
-        gemm.set_policy("fp16" if policy == "fp16" else "default")
+        torch.backends.cuda.matmul.allow_tf32 = policy in ("tf32", "fp16", "f16s")
+        torch.backends.cudnn.allow_tf32 = policy in ("tf32", "fp16", "f16s")
+        gemm.set_policy(policy if policy in ("fp16", "f16s") else "default")
 
     def fence(self):
         if self.world > 1:
@@ -353,16 +353,34 @@ class Bench:
         rf = None if a.hip_graph else self.scan_roofline_pass(step)          # (a replayed graph makes no library calls to time)
         if rf is not None:
             out["roofline"] = rf
-        if extra_precisions and self.world == 1 and a.matmul == "tf32" and not a.hip_graph:
+        if extra_precisions and self.world == 1 and a.matmul == "tf32" and not a.hip_graph:      # (extras: the shipped policy is the reference line)
             # the same step with exact-fp32 library GEMMs, and with the opt-in fp16-operand policy (never the headline).
             # (skipped under --hip-graph: a captured graph has the policy of its capture baked in)
+            def dev(got, ref):
+                d = (got.double() - ref.double()).abs()
+                return {"max_over_max_abs": (d.max() / ref.abs().max()).item(), "rms_over_max_abs": (d.pow(2).mean().sqrt() / ref.abs().max()).item()}
+            three = step()
             self.set_matmul("fp32")
-            dt = self.timed(step, 2, 2) / 2
+            dt = self.timed(step, 2, 2, time_scans=False) / 2
             out["fp32_exact_matmul"] = {"value_per_gpu": batch / dt, "ms_per_step": 1e3 * dt}
             ref = step()
+            # the reference's own arithmetic, emulated: every torch matmul with operands rounded to TF32 (10 mantissa bits), fp32 sums
+            from dimsum_amd.utils.tf32_emulation import emulated_tf32
+            with emulated_tf32():
+                tf = step()
+            self.set_matmul("f16s")
+            one = step()
+            n1 = max(3, steps // 2)
+            dt = self.timed(step, n1, 2, time_scans=False) / n1
+            out["tf32_single_product_f16s"] = {
+                "what": "the large Linears (in_proj, qkv, w12 + gate, w3) on scaled-fp16 operand images: ONE v_mfma_f32_16x16x32_f16 product per "
+                        "element, fp32 accumulation, exact power-of-two row scales undone in the GEMM epilogue (dimsum_amd.gemm policy 'f16s'); "
+                        "NOT the headline value this round",
+                "value_per_gpu": batch / dt, "ms_per_step": 1e3 * dt, "steps": n1, "deviation_vs_exact_fp32": dev(one, ref),
+                "emulated_tf32_deviation_vs_exact_fp32": dev(tf, ref), "headline_three_product_deviation_vs_exact_fp32": dev(three, ref)}
             self.set_matmul("fp16")
             got = step()
-            dt = self.timed(step, 3, 1) / 3
+            dt = self.timed(step, 3, 1, time_scans=False) / 3
             out["fp16_operand_matmul_optin"] = {"value_per_gpu": batch / dt, "ms_per_step": 1e3 * dt,
                                                 "max_abs_dev_over_max_abs_vs_exact_fp32": ((got - ref).abs().max() / ref.abs().max()).item()}
             self.set_matmul("tf32")
@@ -485,6 +503,8 @@ def main():
                       + ("; the inference GEMMs in_proj / qkv / proj / w12 / w3 take their left operands as split images written by the producer kernels, the training GEMMs of qkv / proj / w12 / w3 run forward and backward on such images (dimsum_amd/gemm.py, split3)"
                          if os.environ.get("DIMSUM_SPLIT3", "1") != "0" else "; DIMSUM_SPLIT3=0: fp32 operands everywhere"),
               "fp32": "exact fp32",
+              "f16s": "TF32-equivalent single product: the large Linears on scaled-fp16 operand images (10-bit mantissas like TF32, exact power-of-two row "
+                      "scales: no range loss), fp32 accumulation; split-bf16 (3 products) elsewhere",
               "fp16": "OPT-IN: fp16 operands (TF32 mantissa, fp16 exponent range) + fp32 accumulation for the large Linears, split-bf16 elsewhere"}[args.matmul]
 
     extras = {}

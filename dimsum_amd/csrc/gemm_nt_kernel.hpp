@@ -382,6 +382,27 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
         // The 8-byte unit u of row r sits at u ^ (r & 15): the 16 lanes of a ds_write_b64 service group (same columns, 16 rows)
         // hit 16 distinct units, and a 16-byte read (units 2 v, 2 v + 1) finds both in slot v ^ ((r & 15) >> 1), swapped when r is odd.
         constexpr bool kImg = kEpi == kEpiGatedSplit3;
+        // scaled-fp16 operands: the inverse scale of each of this lane's 8 rows, and (fp16 image of h) the row's output scale from the bound
+        //   |x1|, |x2| <= max|a_r| * max_n sum_k |w_nk| + max|b|   (max|a_r| < 2^15 sa[r] by the image's construction), |gelu(x)| <= |x|:
+        // no reduction over the row -- every column tile derives the same power of two. The factor 4 covers the fp16 rounding of the
+        // operands and the fp32 accumulation many times over.
+        float row_sa[2][4], row_hs[2][4];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = mi * 128 + wr * 64 + i * 16 + (lane & 15);
+                row_sa[mi][i] = p.sa ? p.sa[m0 + r] : 1.0f;
+                row_hs[mi][i] = p.out_scale;
+                if constexpr (!kImg) {
+                    if (p.sa && p.gate_bound) {
+                        const float xb = 32768.0f * row_sa[mi][i] * p.gate_bound[0] + p.gate_bound[1];
+                        float inv;
+                        f16s_scales(4.0f * xb * xb, row_hs[mi][i], inv);
+                        if (tile_n == 0 && wc == 0 && lane < 16) p.inv_out[m0 + r] = inv;
+                    }
+                }
+            }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + ecol + j * 16;
@@ -401,22 +422,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
                 for (int i = 0; i < 4; ++i) {
                     const int r = mi * 128 + wr * 64 + i * 16 + (lane & 15);
                     f4 x1 = acc[mi][0][i][j], x2 = acc[mi][1][i][j];
-                    float hs = p.out_scale;
+                    const float hs = row_hs[mi][i];
                     if (p.sa) {
-                        const float sar = p.sa[m0 + r];
-                        x1 = x1 * (sb1 * sar);
-                        x2 = x2 * (sb2 * sar);
-                        if constexpr (!kImg) {
-                            if (p.gate_bound) {
-                                // |x1|, |x2| <= max|a_r| * max_n sum_k |w_nk| + max|b| (max|a_r| < 2^15 sar by the image's construction), |gelu(x)| <= |x|:
-                                // the row's scale needs no reduction over the row -- every column tile derives the same power of two. The factor 4
-                                // covers the fp16 rounding of the operands and the fp32 accumulation many times over.
-                                const float xb = 32768.0f * sar * p.gate_bound[0] + p.gate_bound[1];
-                                float inv;
-                                f16s_scales(4.0f * xb * xb, hs, inv);
-                                if (tile_n == 0 && wc == 0 && j == 0 && lane < 16) p.inv_out[m0 + r] = inv;
-                            }
-                        }
+                        x1 = x1 * (sb1 * row_sa[mi][i]);
+                        x2 = x2 * (sb2 * row_sa[mi][i]);
                     }
                     x1 = x1 + bv1;
                     x2 = x2 + bv2;

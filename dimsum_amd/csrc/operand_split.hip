@@ -23,33 +23,53 @@ __global__ __launch_bounds__(256) void split3_kernel(const float *src, int64_t r
 
 // scaled-fp16 image of fp32 rows (common.hpp, f16s): one wave per row, exact row maximum. Converts what has no producer kernel of its
 // own: the weights (whose largest row L1 norm -- the bound sum_k |w_nk| on |x W^T| / max|x| -- the gated epilogue of the GEMM needs).
+template <int kPieces>      // kPieces * 256 >= cols: the row lives in registers (one pass); 0: two passes over a row of any length
 __global__ __launch_bounds__(256) void rows_f16s_kernel(const float *src, int64_t rows, int64_t cols, int64_t src_stride, __half *dst, int64_t dst_stride,
                                                        float *inv_scale, float *l1max) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float l1top = 0.f;
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
         const float *x = src + row * src_stride;
         float m = 0.f, l1 = 0.f;
-        for (int64_t c = lane * 4; c < cols; c += 256) {
-            const float4 v = *reinterpret_cast<const float4 *>(x + c);
-            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-            l1 += (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
+        float4 r[kPieces > 0 ? kPieces : 1];
+        if constexpr (kPieces > 0) {
+#pragma unroll
+            for (int i = 0; i < kPieces; ++i) {
+                const int64_t c = (int64_t)(i * 64 + lane) * 4;
+                r[i] = c < cols ? *reinterpret_cast<const float4 *>(x + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(r[i].x), fabsf(r[i].y))), fmaxf(fabsf(r[i].z), fabsf(r[i].w)));
+                l1 += (fabsf(r[i].x) + fabsf(r[i].y)) + (fabsf(r[i].z) + fabsf(r[i].w));
+            }
+        } else {
+            for (int64_t c = lane * 4; c < cols; c += 256) {
+                const float4 v = *reinterpret_cast<const float4 *>(x + c);
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                l1 += (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
+            }
         }
         m = wave_allmax(m);
         float sc, inv;
         f16s_scales(m, sc, inv);
-        for (int64_t c = lane * 4; c < cols; c += 256) {         // (the row is re-read from the cache)
-            const float4 v = *reinterpret_cast<const float4 *>(x + c);
-            *reinterpret_cast<uint2 *>(dst + row * dst_stride + c) = f16s_pack4(f32x4{{v.x, v.y, v.z, v.w}}, sc);
+        if constexpr (kPieces > 0) {
+#pragma unroll
+            for (int i = 0; i < kPieces; ++i) {
+                const int64_t c = (int64_t)(i * 64 + lane) * 4;
+                if (c < cols) *reinterpret_cast<uint2 *>(dst + row * dst_stride + c) = f16s_pack4(f32x4{{r[i].x, r[i].y, r[i].z, r[i].w}}, sc);
+            }
+        } else {
+            for (int64_t c = lane * 4; c < cols; c += 256) {         // (the row is re-read from the cache)
+                const float4 v = *reinterpret_cast<const float4 *>(x + c);
+                *reinterpret_cast<uint2 *>(dst + row * dst_stride + c) = f16s_pack4(f32x4{{v.x, v.y, v.z, v.w}}, sc);
+            }
         }
         if (l1max) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) l1 += __shfl_xor(l1, o, kWave);
+            l1top = fmaxf(l1top, l1);
         }
-        if (lane == 0) {
-            inv_scale[row] = inv;
-            if (l1max) atomicMax(reinterpret_cast<int *>(l1max), __float_as_int(l1));      // non-negative floats order like their bit patterns
-        }
+        if (lane == 0) inv_scale[row] = inv;
     }
+    if (l1max && lane == 0) atomicMax(reinterpret_cast<int *>(l1max), __float_as_int(l1top));      // non-negative floats order like their bit patterns
 }
 
 }  // namespace dimsum
@@ -65,9 +85,16 @@ extern "C" int dimsum_rows_f16s(const void *src, int64_t rows, int64_t cols, int
     if (rows == 0) return DIMSUM_OK;
     int64_t blocks = (rows + 3) / 4;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(rows_f16s_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const float *>(src),
-                       rows, cols, src_row_stride, reinterpret_cast<__half *>(dst), dst_row_stride, reinterpret_cast<float *>(inv_scale),
-                       reinterpret_cast<float *>(l1max));
+#define DIMSUM_F16S(P)                                                                                                                             \
+    hipLaunchKernelGGL(rows_f16s_kernel<P>, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const float *>(src), \
+                       rows, cols, src_row_stride, reinterpret_cast<__half *>(dst), dst_row_stride, reinterpret_cast<float *>(inv_scale),                  \
+                       reinterpret_cast<float *>(l1max))
+    if (cols <= 512) DIMSUM_F16S(2);
+    else if (cols <= 1024) DIMSUM_F16S(4);
+    else if (cols <= 2048) DIMSUM_F16S(8);
+    else if (cols <= 4096) DIMSUM_F16S(16);
+    else DIMSUM_F16S(0);
+#undef DIMSUM_F16S
     return launch_status();
 }
 

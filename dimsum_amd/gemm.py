@@ -219,11 +219,13 @@ def split3_enabled(x, weight):
     return mode if x.numel() // x.shape[-1] >= int(os.environ.get("DIMSUM_SPLIT3_MIN_ROWS", "8192")) else False
 
 
-def weight_f16s(weight):
-    """weight (N, K) float32 -> (F16Image (N, K), gate_bound_l1): its scaled-fp16 image (one exact power-of-two scale per row) and
-    max_n sum_k |w_nk| as a 1-element device tensor (the gated epilogue's bound), built once per frozen_weights() scope"""
+def weight_f16s(weight, want_l1=False):
+    """weight (N, K) float32 -> F16Image (N, K) [, l1]: its scaled-fp16 image (one exact power-of-two scale per row); want_l1: and
+    max_n sum_k |w_nk| as a 1-element device tensor (the gated epilogue's bound). Built once per frozen_weights() scope."""
     from . import native
-    return _cached("w16s", weight, lambda: native.rows_f16s(weight.detach(), want_l1=True))
+    if want_l1:
+        return _cached("w16s_l1", weight, lambda: native.rows_f16s(weight.detach(), want_l1=True))
+    return _cached("w16s", weight, lambda: native.rows_f16s(weight.detach()))
 
 
 def own_gemm_enabled():
@@ -254,7 +256,7 @@ def linear_split3(x3, weight):
     """x3 (M, 3K) bfloat16 left image [hi | hi | lo] (or a scaled-fp16 F16Image (M, K)) @ weight (N, K)^T -> (M, N) float32"""
     from . import native
     if isinstance(x3, native.F16Image):
-        return _nt_f16s(x3, weight_f16s(weight)[0])
+        return _nt_f16s(x3, weight_f16s(weight))
     return _nt(x3, weight_image(weight))
 
 
@@ -262,7 +264,7 @@ def matmul_wx_split3(weight, x3):
     """weight (N, K) @ x^T -> (N, M) float32 with x given as its left image x3 (M, 3K) / F16Image: the in_proj site (d-major output)"""
     from . import native
     if isinstance(x3, native.F16Image):
-        return _nt_f16s(weight_f16s(weight)[0], x3)
+        return _nt_f16s(weight_f16s(weight), x3)
     return _nt(weight_image(weight), x3)
 
 
@@ -272,7 +274,7 @@ def gated_mlp_hidden_split3(x3, w12, b12):
     gated-GeLU pass (csrc/token_transform.hip) when the shape does not fit the kernel's tiling."""
     from . import native
     if isinstance(x3, native.F16Image):
-        w16, l1 = weight_f16s(w12)
+        w16, l1 = weight_f16s(w12, want_l1=True)
         if own_gemm_enabled() and native.gemm_nt_supported(x3.data, w16.data, gated=True):
             # the h image's per-row scale comes from the bound |x1|, |x2| <= max|x_r| * max_n sum_k |w_nk| + max|b| -- no row reduction.
             # (the 2^-10 on the weight bound covers the fp16 rounding of the operands)

@@ -425,7 +425,7 @@ class _CombinedBase(_BlockBase):
         hidden_states, residual = self._prenorm(hidden_states, residual)
         x1, x2 = hidden_states.chunk(2, dim=2)
         # inference under allow_tf32: the branches hand their results over as split-bf16 operand images of the qkv Linears
-        img = gemm.split3_enabled(x1, self.proj.qkv1.weight) and self.proj.takes_images(hidden_states)
+        img = self.proj.takes_images(hidden_states) and gemm.split3_enabled(x1, self.proj.qkv1.weight)      # False / True / "f16s"
         kw = {"out_split3": img} if img else {}
         if ((not torch.is_grad_enabled()) and hidden_states.is_cuda and os.environ.get("DIMSUM_BRANCH_STREAMS", "1") != "0"
                 and not torch.cuda.is_current_stream_capturing()):
@@ -455,7 +455,7 @@ class _CombinedBase(_BlockBase):
             from . import native
             B, L, H = hidden_states.shape
             # ... written directly as the split-bf16 operand image of the w12 GEMM when the library would split it anyway (gemm.py)
-            s3 = gemm.split3_enabled(hidden_states, self.mlp.w12.weight) and getattr(self.mlp, "_fused", False)
+            s3 = getattr(self.mlp, "_fused", False) and gemm.split3_enabled(hidden_states, self.mlp.w12.weight)   # False / True / "f16s"
             y, _, _, hnew = native.layer_norm_fwd(fused.reshape(B * L, H), self.norm_2.weight, self.norm_2.bias, self.norm_2.eps,
                                                   residual=hidden_states.reshape(B * L, H), is_rms_norm=True, x_bias=pb,
                                                   mod_scale=scale, mod_shift=shift, rows_per_batch=L, **({"split3": s3} if s3 else {}))
@@ -518,7 +518,7 @@ class DiTBlock(nn.Module):
         else:
             a, ab = self.attn.forward_deferred(token_ops.pre_mixer(self.norm1(x), "none", None, sa, ca) if h is None else h)
         x = token_ops.gate_residual(x, a, ga, ab)
-        s3 = s3 and getattr(self.mlp, "_fused", False)
+        s3 = getattr(self.mlp, "_fused", False) and s3        # (keeps the mode: False / True / "f16s")
         h = _ln_modulate(self.norm2, x, sm, cm, split3=s3)
         if h is None:
             return _mlp_tail(self.mlp, x, self.norm2(x), sm, cm, gm)

@@ -2,7 +2,7 @@
 (dimsum/train.py:20-21). A row travels as fp16(row * 2^s) + the exact inverse scale; one v_mfma_f32_16x16x32_f16 product per element
 with fp32 accumulation is then the TF32 arithmetic itself (10-bit mantissas, fp32 sums), with the range taken care of by construction.
 Checked: the images against torch's own fp16 rounding, the producers against the stand-alone converter, the products against float64
-next to an emulated-TF32 product (tests/tf32_emulation.py), adversarial ranges, and blocks / models against exact fp32 next to
+next to an emulated-TF32 product (dimsum_amd/utils/tf32_emulation.py), adversarial ranges, and blocks / models against exact fp32 next to
 the emulated-TF32 run of the same module."""
 import numpy as np
 import pytest
@@ -88,7 +88,7 @@ def test_product_is_never_less_accurate_than_tf32(M, K, N, adversarial):
     """x W^T on scaled-fp16 images against float64, next to the emulated TF32 product of the same operands: the same 10-bit
     mantissas, so the same error (<= 1.05 x in max and rms). adversarial: rows scaled by 10^-6 .. 10^6 plus one 10^4 outlier per row --
     what plain fp16 operands cannot carry (overflow / flush) and per-row scales absorb exactly."""
-    from tf32_emulation import round_tf32
+    from dimsum_amd.utils.tf32_emulation import round_tf32
     from dimsum_amd import gemm, native
     g = torch.Generator(device="cuda").manual_seed(5)
     x, w = torch.randn(M, K, device="cuda", generator=g), torch.randn(N, K, device="cuda", generator=g) * K ** -0.5
@@ -112,7 +112,7 @@ def test_product_is_never_less_accurate_than_tf32(M, K, N, adversarial):
 def test_gated_mlp_on_scaled_images_vs_tf32():
     """w12 + bias + gelu_tanh * gate -> h image (per-row scale from the bound, no row reduction) -> w3: against float64 next to the
     emulated-TF32 evaluation of the same MLP; with rows of very different magnitude and outliers"""
-    from tf32_emulation import round_tf32
+    from dimsum_amd.utils.tf32_emulation import round_tf32
     from dimsum_amd import gemm, native
     g = torch.Generator(device="cuda").manual_seed(6)
     M, H, F = 1024, 512, 2048
@@ -157,7 +157,7 @@ def _block_1024():
 def test_block_under_f16s_policy_vs_emulated_tf32(monkeypatch):
     """DiMBlockCombined(1024), inference: the deviation of the f16s policy from the exact-fp32 forward is not larger than the deviation
     of the emulated-TF32 forward (the reference's own arithmetic) -- and the block still meets the reference golden's tolerance"""
-    from tf32_emulation import emulated_tf32
+    from dimsum_amd.utils.tf32_emulation import emulated_tf32
     from dimsum_amd import gemm
     blk, args = _block_1024()
     monkeypatch.setenv("DIMSUM_SPLIT3_MIN_ROWS", "0")
@@ -187,7 +187,7 @@ def test_block_under_f16s_policy_vs_emulated_tf32(monkeypatch):
 @pytest.mark.parametrize("name", ["DiM-L/2"])
 def test_model_under_f16s_policy_vs_emulated_tf32(name):
     """the whole denoiser (reference init, zero tensors re-drawn): f16s deviation from exact fp32 <= emulated-TF32 deviation"""
-    from tf32_emulation import emulated_tf32
+    from dimsum_amd.utils.tf32_emulation import emulated_tf32
     from dimsum_amd import gemm
     from dimsum_amd.create_model import create_model, published_config
     from dimsum_amd.utils import rerandomize_zeros
