@@ -193,7 +193,7 @@ def build_block(name, device):
     return blk.to(device).train(), hidden
 
 
-def cpu_baseline(name, latents=4, image_size=256, runs=3):
+def cpu_baseline(name, latents=4, image_size=256, runs=3, scan="c"):
     """Bounded CPU sample of the headline workload: DiM forwards of `latents` latents through the CPU oracle
     ("port" of the reference's pure-PyTorch path: GEMMs in torch-CPU, scan / conv / norm in oracle/ssm_oracle.c with OpenMP),
     1 warm-up + `runs` timed runs, median."""
@@ -206,16 +206,39 @@ def cpu_baseline(name, latents=4, image_size=256, runs=3):
     r = image_size // 8
     x, t, y = torch.randn(latents, 4, r, r), torch.rand(latents), torch.randint(0, 1000, (latents,))
     times = []
-    with torch.no_grad(), cpu_oracle_backend():
+    with torch.no_grad(), cpu_oracle_backend(scan=scan):
         model(x, t, y)                               # warm-up (allocator, oracle build/load, page-in of the weights)
         for _ in range(runs):
             t0 = time.perf_counter()
             model(x, t, y)
             times.append(time.perf_counter() - t0)
     med = statistics.median(times)
+    how = ("torch-CPU GEMMs + OpenMP C oracle" if scan == "c" else
+           "torch-CPU GEMMs, the scan as the reference's pure-PyTorch selective_scan_ref restated (two (B, D, L, N) temporaries + a Python loop "
+           "over L), conv / norm in the C oracle")
     return {"value": latents / med, "unit": "latents/s", "cores": cores, "kind": "port",
-            "sample": f"{name} forward on {latents} latents (fp32, torch-CPU GEMMs + OpenMP C oracle): 1 warm-up + {runs} runs, "
+            "sample": f"{name} forward on {latents} latents (fp32, {how}): 1 warm-up + {runs} runs, "
                       f"median {med:.2f} s (runs: {', '.join(f'{v:.2f}' for v in times)})"}
+
+
+def rank_summary(elapsed_s, issue_s, steps, extra=None):
+    """At N > 1 the line must explain itself (a sub-linear curve could be a straggler, the collective or the host): every rank
+    contributes its own timed-region wall time, the time its host needed to ISSUE the steps (before the closing fence: close to the
+    wall time = launch-bound, far below = GPU-bound) and its thread count; rank-agnostic (gloo / nccl)."""
+    mine = {"rank": dist.get_rank(), "ms_per_step": 1e3 * elapsed_s / steps, "host_issue_fraction": issue_s / max(elapsed_s, 1e-12),
+            "torch_threads": torch.get_num_threads()}
+    if extra:
+        mine.update(extra)
+    every = [None] * dist.get_world_size()
+    dist.all_gather_object(every, mine)
+    ms = [e["ms_per_step"] for e in every]
+    out = {"per_rank_ms_per_step": {"min": min(ms), "max": max(ms), "rank_of_max": ms.index(max(ms)), "all": [round(v, 3) for v in ms]},
+           "host_issue_fraction_max": max(e["host_issue_fraction"] for e in every),
+           "torch_threads_per_rank": sorted({e["torch_threads"] for e in every})}
+    for k in (extra or {}):
+        vals = [e[k] for e in every]
+        out[k] = {"min": min(vals), "max": max(vals)} if all(isinstance(v, (int, float)) and not isinstance(v, bool) for v in vals) else all(vals)
+    return out
 
 
 def launch_ranks(gpus, argv):
@@ -236,6 +259,7 @@ def launch_ranks(gpus, argv):
 class Bench:
     def __init__(self, args):
         self.args = args
+        self.ranks = None
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -276,10 +300,16 @@ class Bench:
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
+        issued = time.perf_counter() - t0
+        if self.world > 1:
+            torch.cuda.synchronize()
+            own = time.perf_counter() - t0           # this rank's own wall time, before it waits for the others
         self.fence()
         elapsed = time.perf_counter() - t0
         self.timer.enabled = False
+        self.ranks = None
         if self.world > 1:
+            self.ranks = rank_summary(own, issued, steps, getattr(self, "rank_extra", None))
             tmax = torch.tensor([elapsed], device=self.dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = tmax.item()
@@ -350,6 +380,8 @@ class Bench:
                "value": batch * self.world * steps / elapsed, "unit": "latents/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
                "warmup": warmup, "batch_per_gpu": batch, "launch": "hipGraph replay" if a.hip_graph else "eager",
                "branch_streams": "one stream (captured graph)" if a.hip_graph else self.streams_note()}
+        if self.ranks:
+            out["ranks"] = self.ranks
         rf = None if a.hip_graph else self.scan_roofline_pass(step)          # (a replayed graph makes no library calls to time)
         if rf is not None:
             out["roofline"] = rf
@@ -426,9 +458,13 @@ class Bench:
         sample_batch(model, x[:8], y[:8], num_steps=2, world_size=1, gather=False)       # warm-up: allocator, GEMM heuristics
         res = {}
 
+        stats = {}
+        self.rank_extra = stats                     # (filled by the step, read by timed() after it: the all-gather's own time per rank)
+
         def step():
-            res["out"] = sample_batch(model, x, y, num_steps=nfe, world_size=self.world, hip_graph=graphs)
+            res["out"] = sample_batch(model, x, y, num_steps=nfe, world_size=self.world, hip_graph=graphs, stats=stats if self.world > 1 else None)
         elapsed = self.timed(step, 1, 0, time_scans=False)
+        self.rank_extra = None
         out = {"workload": f"{model_name} {nfe}-NFE fixed-step Euler flow-matching sampling, {image_size}px, {batch} latents per GPU "
                            f"(global batch {batch * self.world}), one all_gather_into_tensor of the final latents, " + WEIGHTS,
                "value": batch * self.world / elapsed, "unit": "samples/s", "nfe": nfe, "s_per_batch": elapsed,
@@ -436,6 +472,9 @@ class Bench:
                "seed_rule": f"global_seed * world + rank = 0 * {self.world} + {self.rank} (sample_ddp.py:64)", "gathered_shape": list(res["out"].shape), "finite": bool(torch.isfinite(res["out"]).all().item()),
                "launch": "hipGraph replay" if a.hip_graph else "eager",
                "branch_streams": "one stream (captured graph)" if a.hip_graph else self.streams_note()}
+        if self.ranks:
+            out["ranks"] = self.ranks
+            assert self.ranks["gathered_block_equals_own_output"], "a rank's block of the gathered latents differs from its own output"
         if not a.hip_graph:
             tt = torch.full((batch,), 0.5, device=self.dev)
 
@@ -549,6 +588,8 @@ def main():
         line.update(extras)
         if world == 1 and not args.no_cpu_baseline and args.mode in ("all", "fwd", "sample"):
             line["cpu_baseline"] = cpu_baseline(args.model, 4, args.image_size)
+            # the SHAPE of the reference's own CPU path: its pure-PyTorch selective_scan_ref, at batch 16
+            line["cpu_baseline"]["reference_shaped"] = cpu_baseline(args.model, 16, args.image_size, runs=1, scan="torch_loop")
             if args.mode == "all":      # BASELINE configs[0], SURVEY 8(d): DiM-S/2, batch 4 on the same host cores
                 line["cpu_baseline"]["config0_S2_batch4"] = cpu_baseline("DiM-S/2", 4, args.image_size)
         print(json.dumps(line), flush=True)

@@ -21,10 +21,12 @@ def _dist_ready():
 
 @torch.no_grad()
 def sample_batch(model, z, y, num_steps=250, sampling_method="euler", cfg_scale=None, path_type="GVP", world_size=None, gather=True,
-                 hip_graph=None):
+                 hip_graph=None, stats=None):
     """Integrates dx/dt = model(x, t, y) from t = 0 (noise z) to t = 1 on linspace(0, 1, num_steps + 1): exactly
     `num_steps` function evaluations with Euler. With cfg_scale the batch is doubled like sample_ddp.py:168-173.
-    Returns this rank's samples, or the all-gathered (world * B, C, H, W) tensor when a process group is up."""
+    Returns this rank's samples, or the all-gathered (world * B, C, H, W) tensor when a process group is up.
+    stats (a dict, measurement only): receives the collective's own duration ("all_gather_ms": device events on a GPU, host clock
+    after the call on a CPU process group) and "gathered_block_equals_own_output": this rank's block of the gathered tensor is its output."""
     fwd = model.forward if hasattr(model, "forward") else model
     fwd_cfg = getattr(model, "forward_with_cfg", None)
     if hip_graph is not None:                     # a dict owned by the caller: the captured graphs live across batches
@@ -46,7 +48,23 @@ def sample_batch(model, z, y, num_steps=250, sampling_method="euler", cfg_scale=
     if gather and _dist_ready() and (ws > 1 or gather == "force"):      # "force": also with one rank (collective bring-up tests)
         out = out.contiguous()
         full = torch.empty((ws * out.shape[0],) + tuple(out.shape[1:]), device=out.device, dtype=out.dtype)
-        dist.all_gather_into_tensor(full, out)
+        if stats is None:
+            dist.all_gather_into_tensor(full, out)
+            return full
+        import time
+        if out.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_gather_into_tensor(full, out)
+            e1.record()
+            e1.synchronize()
+            stats["all_gather_ms"] = e0.elapsed_time(e1)
+        else:
+            t0 = time.perf_counter()
+            dist.all_gather_into_tensor(full, out)
+            stats["all_gather_ms"] = 1e3 * (time.perf_counter() - t0)
+        r, n = dist.get_rank(), out.shape[0]
+        stats["gathered_block_equals_own_output"] = bool(torch.equal(full[r * n:(r + 1) * n], out))
         return full
     return out
 

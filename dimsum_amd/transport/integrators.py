@@ -57,12 +57,16 @@ def _rms(x):
 
 class _Dopri5:
     """adaptive RK45 over the whole batch as ONE system (like odeint on a stacked state): the error norm is the RMS over
-    all elements, so the step sequence -- and the number of function evaluations -- is shared by every latent."""
+    all elements, so the step sequence -- and the number of function evaluations -- is shared by every latent.
+    split_sizes: the flat state is a flattened TUPLE with these component sizes; the norm is then torchdiffeq 0.2.3's `_mixed_norm`
+    (odeint's `_check_inputs` installs it for tuple input): the MAX over the components' RMS norms -- so that a small component (the
+    likelihood ODE's B values of delta_logp next to 4096 B of x) keeps its own say in the step-size control."""
 
-    def __init__(self, f, atol, rtol, safety=0.9, ifactor=10.0, dfactor=0.2, max_steps=2 ** 31 - 1):
+    def __init__(self, f, atol, rtol, safety=0.9, ifactor=10.0, dfactor=0.2, max_steps=2 ** 31 - 1, split_sizes=None):
         self.f, self.atol, self.rtol = f, atol, rtol
         self.safety, self.ifactor, self.dfactor, self.max_steps = safety, ifactor, dfactor, max_steps
         self.nfe = 0
+        self.norm = _rms if not split_sizes else (lambda v: max(_rms(c) for c in v.split(list(split_sizes), dim=-1)))
 
     def _f(self, t, x):
         self.nfe += 1
@@ -70,10 +74,10 @@ class _Dopri5:
 
     def _initial_step(self, t0, x0, f0):
         scale = self.atol + x0.abs() * self.rtol
-        d0, d1 = _rms(x0 / scale), _rms(f0 / scale)
+        d0, d1 = self.norm(x0 / scale), self.norm(f0 / scale)
         h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else float(0.01 * d0 / d1)
         f1 = self._f(t0 + h0, x0 + h0 * f0)
-        d2 = float(_rms((f1 - f0) / scale)) / h0
+        d2 = float(self.norm((f1 - f0) / scale)) / h0
         h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(float(d1), d2)) ** (1.0 / 5)
         return min(100 * h0, h1)
 
@@ -112,7 +116,7 @@ class _Dopri5:
             steps += 1
             x1, f1, err, mid = self._step(t, h, x, f0)
             tol = self.atol + self.rtol * th.maximum(x.abs(), x1.abs())
-            ratio = float(_rms(err / tol))
+            ratio = float(self.norm(err / tol))
             if ratio <= 1.0:          # accept
                 while nxt < len(ts) and ts[nxt] <= t + h:
                     theta = (ts[nxt] - t) / h
@@ -147,7 +151,8 @@ class ode:
     def sample(self, x, model, return_trajectory=True, **model_kwargs):
         """-> stacked states at every grid point like odeint (index [-1] = the sample), or only the last state.
         A TUPLE state (the likelihood ODE's (x, delta_logp)) is integrated as one flat system, the way torchdiffeq handles
-        tuples -- in particular dopri5's error norm runs over all components together -- and comes back as a tuple."""
+        tuples; dopri5's error norm is then the maximum over the components' RMS norms (torchdiffeq 0.2.3 `_mixed_norm`), and the state
+        comes back as a tuple."""
         if isinstance(x, tuple):
             shapes, sizes = [c.shape for c in x], [c.numel() for c in x]
             batch, dev = x[0].size(0), x[0].device
@@ -161,6 +166,7 @@ class ode:
 
             inner = ode(flat_drift, t0=0.0, t1=1.0, sampler_type=self.method, num_steps=2, atol=self.atol, rtol=self.rtol)
             inner.t = self.t
+            inner._split_sizes = sizes
             out = inner.sample(th.cat([c.reshape(-1) for c in x])[None], model, return_trajectory=return_trajectory, **model_kwargs)
             self.last_nfe = inner.last_nfe
             return unpack(out[:, 0], (out.shape[0],)) if return_trajectory else unpack(out[0])
@@ -171,7 +177,7 @@ class ode:
 
         ts = self.t.tolist()
         if self.stepper is None:
-            solver = _Dopri5(f, self.atol, self.rtol)
+            solver = _Dopri5(f, self.atol, self.rtol, split_sizes=getattr(self, "_split_sizes", None))
             out = solver.integrate(x, ts, return_trajectory)
             self.last_nfe = solver.nfe
             return out

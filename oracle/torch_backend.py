@@ -34,6 +34,44 @@ def selective_scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus, need
     return res
 
 
+def selective_scan_fwd_torch_loop(u, delta, A, B, C, D, z, delta_bias, delta_softplus, need_out=True, need_x=True, need_ckpt=False):
+    """The reference's own CPU evaluation of the scan, restated: `selective_scan_ref` (mamba/mamba_ssm/ops/selective_scan_interface.py:
+    104-171) materialises exp(delta A) and delta B u as two (B, D, L, N) fp32 tensors (:140-148) and then walks the sequence in a Python
+    loop of elementwise torch ops (:154-166). Same arithmetic as oracle/ssm_oracle.c; kept only so that bench.py can time the SHAPE of
+    the reference's pure-PyTorch path (cpu_baseline.reference_shaped) -- checked against the C oracle in tests/test_oracle_golden.py."""
+    dt = delta.float()
+    if delta_bias is not None:
+        dt = dt + delta_bias.float()[:, None]
+    if delta_softplus:
+        dt = torch.nn.functional.softplus(dt)
+    uf = u.float()
+    Bsz, Dm, L = uf.shape
+    G = B.shape[1]
+    Bx = B.float().repeat_interleave(Dm // G, dim=1).permute(0, 1, 3, 2)           # (B, D, L, N)
+    Cx = C.float().repeat_interleave(Dm // G, dim=1).permute(0, 1, 3, 2)
+    decay = torch.exp(dt[..., None] * A.float()[None, :, None, :])                 # (B, D, L, N)
+    drive = (dt * uf)[..., None] * Bx
+    h = torch.zeros(Bsz, Dm, A.shape[1])
+    ys = []
+    for t in range(L):
+        h = decay[:, :, t] * h + drive[:, :, t]
+        ys.append((h * Cx[:, :, t]).sum(-1))
+    y = torch.stack(ys, dim=2)
+    if D is not None:
+        y = y + uf * D.float()[:, None]
+    out = torch.empty_like(delta)
+    out.copy_(y.to(u.dtype))
+    res = [out, torch.stack([torch.zeros_like(h), h], -1).reshape(Bsz, Dm, 1, -1)]  # (B, D, 1, 2N): last_state = x[:, :, -1, 1::2]
+    if z is not None:
+        zz = z.float()
+        out_z = torch.empty_like(z)
+        out_z.copy_((y * zz * torch.sigmoid(zz)).to(u.dtype))
+        res.append(out_z)
+    if need_ckpt:
+        res.append(None)
+    return res
+
+
 def selective_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, dz, delta_softplus, recompute_out_z, ckpt=None):
     r = c_ops.selective_scan_bwd(_np(u), _np(delta), _np(A), _np(B), _np(C), _np(D), _np(z), _np(delta_bias), delta_softplus, _np(dout))
     du = torch.empty_like(u).copy_(_like(r["du"], u))
@@ -145,7 +183,8 @@ def xattn_supported(qkv, head_dim):
 
 
 @contextlib.contextmanager
-def cpu_oracle_backend():
+def cpu_oracle_backend(scan="c"):
+    """scan="torch_loop": the forward scan as the reference's pure-PyTorch loop (selective_scan_fwd_torch_loop) instead of the C oracle"""
     from dimsum_amd import attention_fusion, native, utils
     from dimsum_amd.ops import token_ops
     names = ["selective_scan_fwd", "selective_scan_bwd", "causal_conv1d_fwd", "causal_conv1d_fwd_cond", "causal_conv1d_bwd",
@@ -155,6 +194,8 @@ def cpu_oracle_backend():
     try:
         for n in names:
             setattr(native, n, globals()[n])
+        if scan == "torch_loop":
+            native.selective_scan_fwd = selective_scan_fwd_torch_loop
         token_ops._require_gpu = lambda x: None
         # with xattn_supported() == False the host code takes its torch-SDPA branch, which the product counts and (for the
         # plain published form) refuses without an opt-in: here that branch IS the checker (SDPA math on the CPU), so the

@@ -140,3 +140,64 @@ def test_launcher_runs_real_children_and_relays_rank0_line(tmp_path):
     assert len(line) == 1 and json.loads(line[0]) == {"world": 2, "argv": ["--gpus", "2"]}
     bad = subprocess.run([sys.executable, "-c", prog, "--gpus", "2", "--fail"], capture_output=True, text=True, env=env, timeout=600)
     assert bad.returncode != 0
+
+
+def _diag_worker(rank, world, port, q):
+    import importlib.util
+    import time
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    from dimsum_amd.sample_ddp import sample_batch
+
+    class Field(torch.nn.Module):
+        in_channels, num_classes = 2, 10
+
+        def forward(self, x, t, y=None):
+            return -x * (1 + y.view(-1, 1, 1, 1).float())
+
+    torch.manual_seed(rank)
+    z, y = torch.randn(4, 2, 4, 4), torch.full((4,), rank)
+    stats = {}
+    t0 = time.perf_counter()
+    full = sample_batch(Field(), z, y, num_steps=2, world_size=world, stats=stats)            # --nfe 2
+    issued = time.perf_counter() - t0
+    if rank == 1:
+        time.sleep(0.2)                                                                       # a straggler the summary must name
+    own = time.perf_counter() - t0
+    summary = b.rank_summary(own, issued, 1, stats)
+    q.put((rank, summary, tuple(full.shape)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_line_explains_itself():
+    """what bench.py adds to its line at N > 1 (rank_summary + sample_batch(stats=...)), on 2 gloo ranks: per-rank step times with the
+    slowest rank named, the all-gather's own time, the host-issue fraction, the thread count, and the in-line check that every rank's
+    block of the gathered latents is its own output"""
+    import multiprocessing as mp
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_diag_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, s0, shape0), (_, s1, shape1) = res
+    assert s0 == s1 and shape0 == shape1 == (8, 2, 4, 4)                 # every rank reports the same summary
+    pr = s0["per_rank_ms_per_step"]
+    assert pr["rank_of_max"] == 1 and pr["max"] >= pr["min"] + 150 and len(pr["all"]) == 2
+    assert s0["gathered_block_equals_own_output"] is True
+    assert 0 <= s0["all_gather_ms"]["min"] <= s0["all_gather_ms"]["max"]
+    assert 0 < s0["host_issue_fraction_max"] <= 1.0 and s0["torch_threads_per_rank"]

@@ -141,6 +141,49 @@ def test_gated_gelu_rows_vs_oracle(M, H):
     assert_close(f(h[rows]), np_ops.gated_gelu(f(x12[rows] + bias)), 2e-5, 0, "gated gelu", scale_atol=2e-6)
 
 
+def test_batch_reduced_gradients_at_full_reduction_depth():
+    """dA, dD, ddelta_bias of the scan, dweight / dbias of the conv, dweight of the norm: sums over batch x sequence that the row-wise
+    tests above cannot see at depth. Config 2/3's batch (256) and sequence (256) on a 64-channel slice, EVERY batch row through the
+    oracle: 65536 positions per reduced element, accumulated on the GPU through fp32 atomics / register partials in another order."""
+    from dimsum_amd import native
+    from oracle import c_ops
+    B, D, L, N = 256, 64, 256, 16
+    g = torch.Generator(device="cuda").manual_seed(77)
+    u, z, dout = dmajor(g, B, D, L), dmajor(g, B, D, L), dmajor(g, B, D, L)
+    delta = dmajor(g, B, D, L, 0.5, uniform=True)
+    A = -0.5 * torch.rand(D, N, device="cuda", generator=g)
+    Bm, Cm = torch.randn(B, 1, N, L, device="cuda", generator=g), torch.randn(B, 1, N, L, device="cuda", generator=g)
+    Dv, bias = torch.randn(D, device="cuda", generator=g), 0.5 * torch.rand(D, device="cuda", generator=g)
+    out, x, out_z, ckpt = native.selective_scan_fwd(u, delta, A, Bm, Cm, Dv, z, bias, True, need_ckpt=True)
+    dz = torch.empty_like(z)
+    res = native.selective_scan_bwd(u, delta, A, Bm, Cm, Dv, z, bias, dout, x, out, dz, True, True, ckpt=ckpt)
+    dA, dD, ddb = res[2], res[5], res[6]
+    gr = c_ops.selective_scan_bwd(f(u), f(delta), f(A), f(Bm), f(Cm), f(Dv), f(z), f(bias), True, f(dout))
+    # the sums have ~65536 terms of mixed sign: tolerance relative to the largest element of each reduced tensor
+    assert_close(f(dA), gr["dA"], what="dA (sum over 256 x 256 positions)", rtol=1e-3, atol=0.0, scale_atol=2e-4)
+    assert_close(f(dD), gr["dD"], what="dD", rtol=1e-3, atol=0.0, scale_atol=2e-4)
+    assert_close(f(ddb), gr["ddelta_bias"], what="ddelta_bias", rtol=1e-3, atol=0.0, scale_atol=2e-4)
+    # conv1d (width 4, SiLU): dweight (D, 4), dbias (D)
+    xz = torch.randn(2 * D, B, L, device="cuda", generator=g).permute(1, 0, 2)
+    xc = xz[:, :D]
+    w, b = torch.randn(D, 4, device="cuda", generator=g), torch.randn(D, device="cuda", generator=g)
+    dx, dw, db = native.causal_conv1d_bwd(xc, w, b, dout, None, True)
+    rdx, rdw, rdb = c_ops.causal_conv1d_bwd(f(xc), f(w), f(b), f(dout), True)
+    assert_close(f(dw), rdw, what="conv dweight (sum over 256 x 256 positions)", rtol=1e-3, atol=0.0, scale_atol=2e-4)
+    assert_close(f(db), rdb, what="conv dbias", rtol=1e-3, atol=0.0, scale_atol=2e-4)
+    assert_close(f(dx), rdx, 1e-4, 0, "conv dx", scale_atol=1e-5)
+    # RMSNorm dweight over 65536 rows (H = 64 columns of a prenorm)
+    M, H = B * L, 64
+    xr, rr = torch.randn(M, H, device="cuda", generator=g), torch.randn(M, H, device="cuda", generator=g)
+    wn = 1 + 0.1 * torch.randn(H, device="cuda", generator=g)
+    _, _, rstd, res_out = native.layer_norm_fwd(xr, wn, None, 1e-5, residual=rr, is_rms_norm=True)
+    dy, dres = torch.randn(M, H, device="cuda", generator=g), torch.randn(M, H, device="cuda", generator=g)
+    dxn, dwn, _, _ = native.layer_norm_bwd(dy, res_out, wn, None, 1e-5, None, rstd, dresidual=dres, has_residual=True, is_rms_norm=True)
+    dr_ref, dw_ref, _ = c_ops.norm_bwd(f(res_out), f(wn), f(dy), f(dres), 1e-5, True)
+    assert_close(f(dwn), dw_ref, what="norm dweight (sum over 65536 rows)", rtol=1e-3, atol=0.0, scale_atol=2e-4)
+    assert_close(f(dxn), dr_ref, 1e-4, 0, "norm dx", scale_atol=1e-5)
+
+
 def test_scan_32bit_offset_guards():
     """the scan kernels address inside a tile with one 32-bit byte offset per lane: a channel stride for which
     (channels per wave) x stride + seqlen does not fit must be refused by the host (DIMSUM_ERR_STRIDE = 4), forward and

@@ -29,6 +29,23 @@ def test_scan_fwd(name):
 
 
 @pytest.mark.parametrize("name", SCAN_CASES)
+def test_scan_fwd_torch_loop_restatement(name):
+    """the reference-shaped pure-PyTorch scan (oracle/torch_backend.py, timed by bench.py as cpu_baseline.reference_shaped)
+    against the reference's own outputs"""
+    import torch
+    from oracle.torch_backend import selective_scan_fwd_torch_loop
+    g = golden(name)
+    T = lambda k: None if _opt(g, k) is None else torch.from_numpy(np.asarray(g[k]))
+    Bm, Cm = T("B"), T("C")
+    if Bm.dim() == 3:
+        Bm, Cm = Bm[:, None], Cm[:, None]
+    res = selective_scan_fwd_torch_loop(T("u"), T("delta"), T("A"), Bm, Cm, T("D"), T("z"), T("delta_bias"), bool(g["softplus"]))
+    assert_close(res[0].numpy(), g["y"], 2e-4, 2e-5, "y")
+    assert_close(res[2].numpy() if len(res) > 2 else res[0].numpy(), g["out"], 2e-4, 2e-5, "out")
+    assert_close(res[1][:, :, -1, 1::2].numpy(), g["last_state"], 2e-4, 2e-5, "last_state")
+
+
+@pytest.mark.parametrize("name", SCAN_CASES)
 def test_scan_bwd(name):
     g = golden(name)
     r = c_ops.selective_scan_bwd(g["u"], g["delta"], g["A"], g["B"], g["C"], _opt(g, "D"), _opt(g, "z"),

@@ -184,6 +184,36 @@ def test_dopri5_accepted_steps_never_shrink():
     assert any(b >= a for a, b in zip(hs[:-1], hs[1:]))
 
 
+def test_dopri5_tuple_state_uses_the_mixed_norm():
+    """torchdiffeq 0.2.3 `_check_inputs`: a tuple state is integrated flat but with `_mixed_norm` = max over the components' RMS norms.
+    A state (x: 4096 slowly varying values, delta_logp: 1 fast-varying value): with ONE flat RMS the fast component's error is diluted
+    by 1 / sqrt(4097) and the controller takes far larger steps; with the mixed norm it alone rejects them. Checked: (a) the norm itself,
+    (b) the tuple path takes many more steps than the diluted norm would and tracks the fast component to its tolerance,
+    (c) single-tensor states keep the plain RMS."""
+    from dimsum_amd.transport.integrators import _Dopri5, _rms, ode
+    v = torch.cat([torch.full((4096,), 1e-3), torch.tensor([5.0])])
+    mixed = _Dopri5(lambda t, x: x, 1e-6, 1e-3, split_sizes=[4096, 1]).norm(v)
+    assert abs(float(mixed) - 5.0) < 1e-6 and abs(float(_rms(v)) - (4096e-6 / 4097 + 25.0 / 4097) ** 0.5) < 1e-6
+
+    def drift(state, t, model, **kw):          # x' = -0.01 x (slow), logp' = 40 cos(40 t) (fast: logp(t) = sin(40 t))
+        x, lp = state
+        return (-0.01 * x, 40.0 * torch.cos(40.0 * t[:1]).expand_as(lp))
+
+    x0 = (torch.ones(1, 4096, dtype=torch.float64), torch.zeros(1, dtype=torch.float64))
+    solver = ode(drift, t0=0.0, t1=1.0, sampler_type="dopri5", num_steps=2, atol=1e-7, rtol=1e-6)
+    x1, lp1 = solver.sample(x0, None, return_trajectory=False)
+    nfe_mixed = solver.last_nfe
+    assert abs(float(lp1) - torch.sin(torch.tensor(40.0, dtype=torch.float64)).item()) < 1e-5
+
+    def flat_drift(t, v):
+        return torch.cat([-0.01 * v[:4096], 40.0 * torch.cos(torch.tensor(40.0 * t, dtype=torch.float64)).reshape(1)])
+    diluted = _Dopri5(flat_drift, 1e-7, 1e-6)                                   # the same system under ONE flat RMS
+    out = diluted.integrate(torch.cat([x0[0].reshape(-1), x0[1]]), [0.0, 1.0], False)
+    assert nfe_mixed > 1.5 * diluted.nfe, (nfe_mixed, diluted.nfe)
+    assert abs(float(lp1) - torch.sin(torch.tensor(40.0, dtype=torch.float64)).item()) < abs(float(out[-1]) - torch.sin(torch.tensor(40.0, dtype=torch.float64)).item())
+    assert _Dopri5(lambda t, x: x, 1e-6, 1e-3).norm is _rms
+
+
 def test_dopri5_tableau_against_scipy_rk45():
     """The Dormand-Prince 5(4) coefficients of the dopri5 restatement (torchdiffeq is absent: parity with IT stays unpinned)
     against an independent published implementation, scipy's RK45: nodes c, stage matrix A and the 5th-order weights b are the
