@@ -76,7 +76,8 @@ class XattnParams(C.Structure):
     _fields_ = ([(n, i32) for n in ("batch", "seqlen", "heads", "head_dim")] + [("scale", f32), ("n_dirs", i32)]
                 + [(n, i64) for n in ("qkv_batch_stride", "qkv_token_stride", "out_batch_stride", "out_token_stride")]
                 + [(n, vp) for n in ("qkv1_ptr", "qkv2_ptr", "out_ptr", "lse_ptr", "bias1_ptr", "bias2_ptr")]
-                + [("precision", i32), ("out_split3", i32)])
+                + [("precision", i32), ("out_split3", i32)]
+                + [(n, vp) for n in ("x1_inv_ptr", "x2_inv_ptr", "kv_bound_ptr", "out_inv_ptr")])
 
 
 class XattnBwdParams(C.Structure):

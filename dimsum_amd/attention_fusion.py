@@ -80,6 +80,12 @@ class CrossAttentionFusion(nn.Module):
                 raise RuntimeError("CrossAttentionFusion: qkv1 / qkv2 must both have a bias or none")
             qkv1 = gemm.linear_split3(x1.reshape(B * N, C3), self.qkv1.weight).view(B, N, -1)
             qkv2 = gemm.linear_split3(x2.reshape(B * N, C3), self.qkv2.weight).view(B, N, -1)
+            if isinstance(x1, native.F16Image) and (self.num_heads * self.head_dim) % 8 == 0:
+                # scaled-fp16 policy: ONE fp16 product per element in QK^T / PV too, proj's operand image written with the same kind of scale
+                f3 = native.xattn_fusion_fwd(qkv1, qkv2, self.num_heads, bias1=None if b1 is None else b1.float().contiguous(),
+                                             bias2=None if b2 is None else b2.float().contiguous(), split3="f16s",
+                                             f16s=(x1.inv.reshape(B, N), x2.inv.reshape(B, N), gemm.attn_kv_bound(self.qkv1.weight, b1, self.qkv2.weight, b2)))
+                return gemm.linear_split3(f3.reshape(B * N, -1), self.proj.weight).view(B, N, -1), self.proj.bias
             f3 = native.xattn_fusion_fwd(qkv1, qkv2, self.num_heads, bias1=None if b1 is None else b1.float().contiguous(),
                                          bias2=None if b2 is None else b2.float().contiguous(), split_bf16=True, split3=True)
             return gemm.linear_split3(f3.reshape(B * N, -1), self.proj.weight).view(B, N, -1), self.proj.bias

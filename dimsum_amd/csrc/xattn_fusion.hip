@@ -469,6 +469,8 @@ __global__ __launch_bounds__(256, (QT == 2 && HD <= 64) ? 3 : (QT == 2 ? 2 : 1))
     }
 }
 
+int launch_xattn_f16(const dimsum_xattn_params_t &p, hipStream_t s);      // xattn_fusion_f16.hip (precision 2)
+
 }  // namespace dimsum
 
 extern "C" int dimsum_xattn_fusion_fwd(const dimsum_xattn_params_t *p, void *stream) {
@@ -487,6 +489,14 @@ extern "C" int dimsum_xattn_fusion_fwd(const dimsum_xattn_params_t *p, void *str
     const int64_t nblk = (int64_t)p->batch * p->heads * (self_attn ? 1 : 2) * ((p->seqlen + 63) / 64);
     if (nblk > 0x7fffffff) return DIMSUM_ERR_SHAPE;
     const dim3 grid((unsigned)nblk), block(256);
+    if (p->precision == 2) {
+        if (!p->x1_inv_ptr || (!self_attn && !p->x2_inv_ptr) || !p->kv_bound_ptr) return DIMSUM_ERR_NULL;
+        if (p->out_split3 != 0 && p->out_split3 != 2) return DIMSUM_ERR_SHAPE;
+        if (p->out_split3 == 2 && (!p->out_inv_ptr || p->out_token_stride < (int64_t)(self_attn ? 1 : 2) * p->heads * p->head_dim ||
+                                   p->out_batch_stride % 8 != 0 || p->out_token_stride % 8 != 0 || (p->heads * p->head_dim) % 8 != 0))
+            return DIMSUM_ERR_STRIDE;
+        return launch_xattn_f16(*p, s);
+    }
     if (p->precision != 0 && p->precision != 1) return DIMSUM_ERR_SHAPE;
     // the operand image is written in 16-byte pieces (8 bf16): its base and both strides must keep that alignment
     if (p->out_split3 && (p->precision != 1 || p->out_token_stride < 3 * (int64_t)(self_attn ? 1 : 2) * p->heads * p->head_dim ||

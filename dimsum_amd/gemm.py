@@ -228,6 +228,16 @@ def weight_f16s(weight, want_l1=False):
     return _cached("w16s", weight, lambda: native.rows_f16s(weight.detach()))
 
 
+def attn_kv_bound(w1, b1, w2=None, b2=None):
+    """the 4-element bound tensor of the fp16 attention kernel (native.xattn_fusion_fwd(f16s=...)): {max_n sum_c |W1_nc|, max|b1|, the same
+    for the second qkv Linear (self-attention: the first again)}; the weight sums come with the weights' scaled-fp16 images (cached in a
+    frozen_weights() scope), the 2^-10 covers the fp16 rounding of the operands"""
+    def one(w, b):
+        l1 = weight_f16s(w, want_l1=True)[1] * (1.0 + 2.0 ** -10)
+        return [l1, b.detach().float().abs().max().reshape(1) if b is not None else torch.zeros(1, device=w.device)]
+    return _cached("kvbound", w1, lambda: torch.cat(one(w1, b1) + (one(w2, b2) if w2 is not None else one(w1, b1))).contiguous())
+
+
 def own_gemm_enabled():
     """the image GEMMs run on this package's MFMA kernel (csrc/gemm_nt_kernel.hpp); DIMSUM_GEMM_NT=0 hands them back to the library"""
     import os

@@ -178,6 +178,10 @@ class Attention(nn.Module):
             if native.xattn_supported(qkv, self.head_dim):
                 # the attention kernel writes the operand image of proj directly
                 qb = None if self.qkv.bias is None else self.qkv.bias.float().contiguous()
+                if isinstance(x3, native.F16Image) and C % 8 == 0:         # scaled-fp16 policy: the single-product attention kernel
+                    o3 = native.xattn_fusion_fwd(qkv, None, self.num_heads, bias1=qb, split3="f16s",
+                                                 f16s=(x3.inv.reshape(B, N), None, gemm.attn_kv_bound(self.qkv.weight, self.qkv.bias)))
+                    return gemm.linear_split3(o3.reshape(B * N, -1), self.proj.weight).view(B, N, C), self.proj.bias
                 o3 = native.xattn_fusion_fwd(qkv, None, self.num_heads, bias1=qb, split_bf16=True, split3=True)
                 return gemm.linear_split3(o3.reshape(B * N, -1), self.proj.weight).view(B, N, C), self.proj.bias
         else:

@@ -613,13 +613,16 @@ def xattn_supported(qkv, head_dim):
     return qkv.is_cuda and qkv.dtype == torch.float32 and qkv.stride(-1) == 1 and head_dim in (24, 32, 48, 64, 72)
 
 
-def xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=False, bias1=None, bias2=None, split_bf16=None, split3=False):
+def xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=False, bias1=None, bias2=None, split_bf16=None, split3=False, f16s=None):
     """qkv*: (B, L, 3*heads*hd) -> (B, L, 2*heads*hd) = cat(softmax(q1 k2^T/sqrt(hd)) v2, softmax(q2 k1^T/sqrt(hd)) v1).
     qkv2 = None: plain self-attention softmax(q1 k1^T/sqrt(hd)) v1 -> (B, L, heads*hd).
     bias1/bias2 (3*heads*hd): the qkv Linear biases when qkv* are bias-free GEMM outputs (added inside the kernel).
     split_bf16: None follows torch.backends.cuda.matmul.allow_tf32 (the reference's GEMM policy, train.py:20-21: the
     QK^T / PV contractions then run as split-bf16 MFMA like the library GEMMs do); False = exact fp32 MFMA.
-    split3 (split-bf16 kernel only): the result as the split-bf16 left operand image (B, L, 3 * width) bfloat16 of the proj Linear."""
+    split3 (split-bf16 kernel only): the result as the split-bf16 left operand image (B, L, 3 * width) bfloat16 of the proj Linear.
+    f16s = (x1_inv, x2_inv or None, kv_bound): the single-product fp16 kernel (csrc/xattn_fusion_f16.hip, the "f16s" GEMM policy):
+    x*_inv (B, L) are the inverse row scales of the scaled-fp16 images the qkv GEMMs consumed, kv_bound a 4-element float32 tensor
+    {max_n sum_c |W1_nc|, max|bias1|, the same for qkv2}; with split3="f16s" the result is the scaled-fp16 image (F16Image) of proj."""
     self_attn = qkv2 is None
     if split_bf16 is None:
         split_bf16 = bool(torch.backends.cuda.matmul.allow_tf32)
@@ -634,7 +637,19 @@ def xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=False, bias1=None, bias2=None, 
     if not self_attn:
         _check(qkv1.shape == qkv2.shape and qkv2.dtype == torch.float32 and qkv1.stride() == qkv2.stride(), "xattn_fusion: qkv1/qkv2 must share shape and strides")
     nd = 1 if self_attn else 2
-    if split3:
+    out_inv = None
+    if f16s is not None:
+        x1_inv, x2_inv, kv_bound = f16s
+        _gpu(x1_inv, x2_inv, kv_bound)
+        _check(x1_inv.dtype == torch.float32 and x1_inv.numel() == B * L and x1_inv.is_contiguous()
+               and (self_attn or (x2_inv is not None and x2_inv.dtype == torch.float32 and x2_inv.numel() == B * L and x2_inv.is_contiguous()))
+               and kv_bound.dtype == torch.float32 and kv_bound.numel() == 4 and kv_bound.is_contiguous(), "xattn_fusion: bad f16s arguments")
+        _check(split3 in (False, "f16s"), "xattn_fusion: the fp16 kernel writes fp32 or the scaled-fp16 image")
+    if split3 == "f16s":
+        _check(f16s is not None and (heads * hd) % 8 == 0, "xattn_fusion: the scaled-fp16 image needs the fp16 kernel")
+        out = torch.empty((B, L, nd * heads * hd), device=qkv1.device, dtype=torch.float16)
+        out_inv = torch.empty((B, L), device=qkv1.device, dtype=torch.float32)
+    elif split3:
         _check(split_bf16, "xattn_fusion: the operand image output exists for the split-bf16 kernel only")
         out = torch.empty((B, L, 3 * nd * heads * hd), device=qkv1.device, dtype=torch.bfloat16)
     else:
@@ -648,9 +663,14 @@ def xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=False, bias1=None, bias2=None, 
         P.qkv1_ptr, P.qkv2_ptr, P.out_ptr, P.lse_ptr = _ptr(qkv1), _ptr(qkv2), _ptr(out), _ptr(lse)
         P.bias1_ptr, P.bias2_ptr = _ptr(bias1), _ptr(bias2)
         P.precision = 1 if split_bf16 else 0
-        P.out_split3 = int(split3)
+        P.out_split3 = 2 if split3 == "f16s" else int(bool(split3))
+        if f16s is not None:
+            P.precision = 2
+            P.x1_inv_ptr, P.x2_inv_ptr, P.kv_bound_ptr, P.out_inv_ptr = _ptr(x1_inv), _ptr(x2_inv), _ptr(kv_bound), _ptr(out_inv)
         with torch.cuda.device(qkv1.device):
             _lib.check(_lib.load().dimsum_xattn_fusion_fwd(P, _stream(qkv1)), "xattn_fusion_fwd")
+    if out_inv is not None:
+        out = F16Image(out, out_inv)
     return (out, lse) if need_lse else out
 
 

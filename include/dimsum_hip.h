@@ -308,7 +308,15 @@ typedef struct {
                            accumulation, ~1e-5 relative: the same arithmetic hipBLASLt uses for the reference's
                            torch.backends.cuda.matmul.allow_tf32 = True policy (train.py:20-21) on gfx950 */
     int32_t out_split3; /* forward, precision 1 only. != 0: out rows are the split-bf16 operand image of the proj Linear:
-                           3 x (n_dirs' x heads x hd) bf16 [hi | hi | lo] (dimsum_split3); out strides in bf16 elements */
+                           3 x (n_dirs' x heads x hd) bf16 [hi | hi | lo] (dimsum_split3); out strides in bf16 elements.
+                           precision 2: 0 (fp32 out) or 2 = the scaled-fp16 image (dimsum_rows_f16s): fp16 rows of n_dirs' x heads x hd
+                           (strides in fp16 elements) + out_inv_ptr[b * L + token] */
+    /* precision 2 (forward only): ONE fp16 MFMA product per element, the TF32-equivalent arithmetic (10-bit mantissas, fp32
+     * accumulation). q is scaled per query row (exact), k / v per batch element from the bound
+     *   |k|, |v| <= max_t (2^15 x_inv[b, t]) * wl1 + bmax,   kv_bound = {wl1 of qkv1's weight, max|bias1|, wl1 of qkv2's, max|bias2|}
+     * where x*_inv are the inverse row scales (batch, L) of the scaled-fp16 images the qkv GEMMs consumed (wl1 = max_n sum_c |W_nc|). */
+    const void *x1_inv_ptr, *x2_inv_ptr, *kv_bound_ptr;
+    void *out_inv_ptr;  /* (batch, L) f32, out_split3 == 2 */
 } dimsum_xattn_params_t;
 
 int dimsum_xattn_fusion_fwd(const dimsum_xattn_params_t *p, void *stream);

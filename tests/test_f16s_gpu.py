@@ -219,3 +219,57 @@ def test_model_under_f16s_policy_vs_emulated_tf32(name):
           f"3-product {m3 / scale:.2e} / {r3 / scale:.2e}")
     assert m1 <= 1.25 * mt and r1 <= 1.1 * rt, ((m1, r1), (mt, rt))
     assert m1 / scale < 1e-3
+
+
+@pytest.mark.parametrize("hd,heads,L,self_attn", [(64, 8, 256, False), (64, 4, 200, False), (72, 4, 320, False), (24, 4, 256, True), (64, 16, 256, True)])
+def test_attention_single_product_vs_tf32(hd, heads, L, self_attn):
+    """the fp16 single-product attention kernel (csrc/xattn_fusion_f16.hip) against float64 SDPA math, next to the emulated-TF32
+    evaluation (q, k, v and p rounded to 10 mantissa bits, fp32 products): the deviation is of the same size; the scaled-fp16 image
+    output decodes to the fp32 output within fp16's significand; rows of very different magnitude (10^-3 .. 10^3) per token"""
+    from dimsum_amd.utils.tf32_emulation import round_tf32
+    from dimsum_amd import gemm, native
+    g = torch.Generator(device="cuda").manual_seed(7)
+    B, C = 2, heads * hd
+    mag = torch.logspace(-3, 3, B * L, device="cuda").reshape(B, L, 1)
+    xs = [torch.randn(B, L, C, device="cuda", generator=g) * mag for _ in range(2)]
+    ws = [torch.randn(3 * C, C, device="cuda", generator=g) * C ** -0.5 for _ in range(2)]
+    bs = [0.1 * torch.randn(3 * C, device="cuda", generator=g) for _ in range(2)]
+    imgs = [native.rows_f16s(x.reshape(B * L, C)) for x in xs]
+    qkvs = [gemm.linear_split3(i, w).view(B, L, 3 * C) for i, w in zip(imgs, ws)]
+    if self_attn:
+        bound = gemm.attn_kv_bound(ws[0], bs[0])
+        args = (qkvs[0], None, heads)
+        kw = dict(bias1=bs[0], f16s=(imgs[0].inv.reshape(B, L), None, bound))
+    else:
+        bound = gemm.attn_kv_bound(ws[0], bs[0], ws[1], bs[1])
+        args = (qkvs[0], qkvs[1], heads)
+        kw = dict(bias1=bs[0], bias2=bs[1], f16s=(imgs[0].inv.reshape(B, L), imgs[1].inv.reshape(B, L), bound))
+    out = native.xattn_fusion_fwd(*args, **kw)
+    img = native.xattn_fusion_fwd(*args, split3="f16s", **kw)
+
+    def sdpa(q, k, v, rnd):
+        q, k, v = (t.reshape(B, L, heads, hd).transpose(1, 2) for t in (q, k, v))
+        if rnd:
+            s = (round_tf32(q.float()).double() @ round_tf32(k.float()).double().transpose(-1, -2)) * hd ** -0.5
+            pm = torch.softmax(s, -1)
+            o = round_tf32(pm.float()).double() @ round_tf32(v.float()).double()
+        else:
+            o = torch.softmax((q @ k.transpose(-1, -2)) * hd ** -0.5, -1) @ v
+        return o.transpose(1, 2).reshape(B, L, C)
+
+    def ref(rnd):
+        (q1, k1, v1), (q2, k2, v2) = ((qk.double() + b.double()).split(C, -1) for qk, b in zip(qkvs, bs))
+        if self_attn:
+            return sdpa(q1, k1, v1, rnd)
+        return torch.cat([sdpa(q1, k2, v2, rnd), sdpa(q2, k1, v1, rnd)], -1)
+    r64, rtf = ref(False), ref(True)
+    row = r64.abs().amax(-1, keepdim=True)
+    e, etf = (out.double() - r64).abs() / row, (rtf - r64).abs() / row
+    assert torch.isfinite(out).all()
+    assert e.max().item() <= 1.5 * etf.max().item() + 1e-6, (e.max().item(), etf.max().item())
+    assert e.pow(2).mean().sqrt().item() <= 1.25 * etf.pow(2).mean().sqrt().item() + 1e-7, (e.pow(2).mean().sqrt().item(), etf.pow(2).mean().sqrt().item())
+    assert isinstance(img, native.F16Image) and torch.isfinite(img.data).all() and img.data.float().abs().max().item() < 2.0 ** 15
+    assert ((img.float().double() - out.double()).abs() / row).max().item() <= 2.0 ** -10
+    # the split-bf16 kernel on the same inputs agrees to the TF32 class
+    three = native.xattn_fusion_fwd(args[0], args[1], heads, bias1=bs[0], bias2=None if self_attn else bs[1], split_bf16=True)
+    assert ((out - three).abs() / row.float()).max().item() <= 3 * etf.max().item() + 1e-6
