@@ -90,10 +90,11 @@ class GemmParams(C.Structure):
                 + [(n, i64) for n in ("lda", "ldb", "ldc")]
                 + [(n, vp) for n in ("a_ptr", "b_ptr", "bias_ptr", "c_ptr", "timing_start_event", "timing_stop_event")]
                 + [(n, i32) for n in ("tune_variant", "tune_group_m", "tune_start_delay")]
-                + [(n, vp) for n in ("a_inv_scale_ptr", "b_inv_scale_ptr", "gate_bound_ptr", "h_inv_scale_ptr")])
+                + [(n, vp) for n in ("a_inv_scale_ptr", "b_inv_scale_ptr", "gate_bound_ptr", "h_inv_scale_ptr", "residual_ptr", "gate_ptr")]
+                + [("residual_ld", i64), ("gate_ld", i64), ("rows_per_batch", i32)])
 
 
-GEMM_EPI_F32, GEMM_EPI_GATED_GELU_SPLIT3, GEMM_EPI_GATED_GELU_F16, GEMM_EPI_F32_BIAS = 0, 1, 2, 3
+GEMM_EPI_F32, GEMM_EPI_GATED_GELU_SPLIT3, GEMM_EPI_GATED_GELU_F16, GEMM_EPI_F32_BIAS, GEMM_EPI_F32_GATE_RESIDUAL = 0, 1, 2, 3, 4
 
 # every symbol include/dimsum_hip.h declares (tests check the library exports all of them)
 EXPORTS = (

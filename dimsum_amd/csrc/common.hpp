@@ -111,10 +111,22 @@ __device__ __forceinline__ uint2 f16s_pack4(const f32x4 &v, float scale) {     /
     const __half2 a = __floats2half2_rn(v.v[0] * scale, v.v[1] * scale), b = __floats2half2_rn(v.v[2] * scale, v.v[3] * scale);
     return make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
 }
+// maximum over the 64 lanes, in every lane, on the VALU only: 4 DPP steps inside each row of 16 lanes (quad_perm, row_half_mirror,
+// row_mirror), then the two row exchanges v_permlane16_swap / v_permlane32_swap. (__shfl_xor is a ds_bpermute: an LDS round trip per
+// step -- 96 of them per thread in the token pass that reduces 16 row maxima.)
+template <int kCtrl> __device__ __forceinline__ float dpp_mov(float x) {
+    const int v = __builtin_bit_cast(int, x);                  // (old = the source: see gemm_nt_kernel.hpp dpp_row_ror8)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(v, v, kCtrl, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_allmax(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
-    return v;
+    v = fmaxf(v, dpp_mov<0xB1>(v));        // quad_perm [1, 0, 3, 2]
+    v = fmaxf(v, dpp_mov<0x4E>(v));        // quad_perm [2, 3, 0, 1]
+    v = fmaxf(v, dpp_mov<0x141>(v));       // row_half_mirror
+    v = fmaxf(v, dpp_mov<0x140>(v));       // row_mirror
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }        // v_exp_f32

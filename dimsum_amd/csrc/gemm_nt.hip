@@ -42,6 +42,24 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t e0 = reinterpret_cast<hipEvent_t>(p->timing_start_event), e1 = reinterpret_cast<hipEvent_t>(p->timing_stop_event);
     const bool bf = p->operand_dtype == DIMSUM_BF16;
+    if (p->epilogue == DIMSUM_GEMM_EPI_F32_GATE_RESIDUAL) {
+        if (!p->residual_ptr) return DIMSUM_ERR_NULL;
+        if (p->ldc % 4 != 0 || p->ldc < p->n || !aligned_to<char>(p->c_ptr, 16) || p->residual_ld % 4 != 0 || p->residual_ld < p->n ||
+            !aligned_to<char>(p->residual_ptr, 16) || (p->bias_ptr && !aligned_to<char>(p->bias_ptr, 16)) ||
+            (p->gate_ptr && (p->gate_ld % 4 != 0 || !aligned_to<char>(p->gate_ptr, 16))))
+            return DIMSUM_ERR_STRIDE;
+        if (p->gate_ptr && (p->rows_per_batch <= 0 || p->rows_per_batch % kBM != 0 || p->m % p->rows_per_batch != 0)) return DIMSUM_ERR_SHAPE;
+        a.B0 = a.B1 = reinterpret_cast<const char *>(p->b_ptr);
+        a.bias0 = reinterpret_cast<const float *>(p->bias_ptr);
+        a.res = reinterpret_cast<const float *>(p->residual_ptr);
+        a.gate = reinterpret_cast<const float *>(p->gate_ptr);
+        a.ldr = p->residual_ld; a.ldg = p->gate_ld;
+        a.rows_per_batch = p->gate_ptr ? p->rows_per_batch : p->m;
+        a.N = p->n;
+        a.tiles_n = (p->n + kBN - 1) / kBN;
+        constexpr int kShipR = kVarFullLineStores | kVarNtStores;
+        return bf ? launch<kOpBf16, kEpiF32GateRes, kShipR>(a, s, e0, e1) : launch<kOpF16, kEpiF32GateRes, kShipR>(a, s, e0, e1);
+    }
     if (p->epilogue == DIMSUM_GEMM_EPI_F32 || p->epilogue == DIMSUM_GEMM_EPI_F32_BIAS) {
         if (p->ldc % 4 != 0 || p->ldc < p->n || !aligned_to<char>(p->c_ptr, 16)) return DIMSUM_ERR_STRIDE;
         const bool bias = p->epilogue == DIMSUM_GEMM_EPI_F32_BIAS;

@@ -47,7 +47,7 @@ constexpr int kParity = 4 * kHalf;         // bytes of one K tile in LDS
 constexpr int kSlotA0 = 0, kSlotA1 = kHalf, kSlotB0 = 2 * kHalf, kSlotB1 = 3 * kHalf;
 
 enum { kOpBf16 = 0, kOpF16 = 1 };
-enum { kEpiF32 = 0, kEpiGatedSplit3 = 1, kEpiGatedF16 = 2, kEpiF32Bias = 3 };
+enum { kEpiF32 = 0, kEpiGatedSplit3 = 1, kEpiGatedF16 = 2, kEpiF32Bias = 3, kEpiF32GateRes = 4 };
 
 struct Args {
     const char *A, *B0, *B1;       // B0 / B1: first weight row of the two 128-row halves' matrices (B1 = B0 + 128 rows for a plain GEMM)
@@ -56,6 +56,9 @@ struct Args {
     const float *sa, *sb;          // scaled-fp16 operands: inverse scale per A row (M) / per B row (N; gated: 2 F), NULL = 1
     const float *gate_bound;       // kEpiGatedF16 with per-row scales: {max_n sum_k |w_nk| (true units), max |bias|}; NULL = out_scale
     float *inv_out;                // kEpiGatedF16 with per-row scales: (M) inverse scales of the h image
+    const float *res, *gate;       // kEpiF32GateRes: C = res + gate[row / rows_per_batch] * (A B^T + bias); res (M, N), gate (M / rows_per_batch, N) or NULL (= 1)
+    int64_t ldr, ldg;
+    int rows_per_batch;            // a multiple of 256: a tile lies inside one batch element
     int64_t lda, ldb, ldc;         // in elements
     int M, N, K;                   // N = columns per B half matrix row range handled as [0, N) for plain, hidden width F for gated
     int tiles_m, tiles_n;
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[mi][ni][i][j]));
-    } else if constexpr (kEpi == kEpiF32 || kEpi == kEpiF32Bias) {
+    } else if constexpr (kEpi == kEpiF32 || kEpi == kEpiF32Bias || kEpi == kEpiF32GateRes) {
         // one buffer descriptor per tile (base = the tile's first element: wave-uniform), a 32-bit byte offset per lane
         constexpr int kAux = ((kVar & kVarNtStores) ? 2 : 0) | ((kVar & kVarSc1Stores) ? 16 : 0) | ((kVar & kVarSc0Stores) ? 1 : 0);
         float *Ct = reinterpret_cast<float *>(p.C) + (int64_t)m0 * p.ldc + n0;
@@ -328,9 +331,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
             for (int ni = 0; ni < 2; ++ni) {
                 const int col = ni * 128 + fcol;
                 const bool live = n0 + col < p.N;          // (the lane exchange below runs in every lane: only the stores are predicated)
-                f4 bv = f4{0.f, 0.f, 0.f, 0.f}, sbv = f4{1.f, 1.f, 1.f, 1.f};
+                f4 bv = f4{0.f, 0.f, 0.f, 0.f}, sbv = f4{1.f, 1.f, 1.f, 1.f}, gv = sbv;
                 if constexpr (kEpi == kEpiF32Bias) {
                     if (live) bv = *reinterpret_cast<const f4 *>(p.bias0 + n0 + col);
+                }
+                if constexpr (kEpi == kEpiF32GateRes) {    // the residual tail of a block: out = res + gate * (x W^T + b), one pass less
+                    if (live && p.bias0) bv = *reinterpret_cast<const f4 *>(p.bias0 + n0 + col);
+                    if (live && p.gate) gv = *reinterpret_cast<const f4 *>(p.gate + (int64_t)(m0 / p.rows_per_batch) * p.ldg + n0 + col);
                 }
                 if (p.sb && live) sbv = *reinterpret_cast<const f4 *>(p.sb + n0 + col);
 #pragma unroll
@@ -351,7 +358,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
                             s0 = s0 * (sbv * p.sa[m0 + lrow]);
                             s1 = s1 * (sbv * p.sa[m0 + lrow + 8]);
                         }
-                        if (live) {
+                        if constexpr (kEpi == kEpiF32GateRes) {
+                            if (live) {
+                                const float *rp = p.res + (int64_t)(m0 + lrow) * p.ldr + n0 + col;
+                                const f4 r0 = *reinterpret_cast<const f4 *>(rp), r1 = *reinterpret_cast<const f4 *>(rp + 8 * p.ldr);
+                                store_f4<kAux>(rsrc, voff, r0 + gv * (s0 + bv));
+                                store_f4<kAux>(rsrc, voff + (unsigned)(8 * p.ldc * 4), r1 + gv * (s1 + bv));
+                            }
+                        } else if (live) {
                             store_f4<kAux>(rsrc, voff, s0 + bv);
                             store_f4<kAux>(rsrc, voff + (unsigned)(8 * p.ldc * 4), s1 + bv);
                         }

@@ -106,6 +106,7 @@ template <int KIND, int VEC, bool F16S = false>
 __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsum_tt_params_t p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
+    const int nthreads = F16S ? (int)blockDim.x : kTTThreads;       // F16S: one channel group per thread, the block is sized to the channel count
     const int b = blockIdx.y;
     const int C = p.channels, G = p.grid;
     // 16 positions s of this workgroup: a 4x4 block of the grid (or 16 consecutive tokens when KIND == NONE)
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
 
     if constexpr (KIND == DIMSUM_TT_HAAR_INV) {
         // phase 1: the (token p, channel c') image goes to LDS at flat j = c'*16 + p
-        for (int c = tid * VEC; c < C; c += kTTThreads * VEC) {
+        for (int c = tid * VEC; c < C; c += nthreads * VEC) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 float v[VEC];
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
         __syncthreads();
     }
 
-    for (int c = tid * VEC; c < C; c += kTTThreads * VEC) {
+    for (int c = tid * VEC; c < C; c += nthreads * VEC) {
         float X[VEC][16], Y[VEC][16];
         if constexpr (KIND == DIMSUM_TT_HAAR_INV) {
 #pragma unroll
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
     if constexpr (KIND == DIMSUM_TT_HAAR_FWD) {
         __syncthreads();
         // phase 2: output token p, channels c'..c'+VEC-1 <- flat j = c'*16 + p  (16-byte LDS reads when VEC == 4)
-        for (int c = tid * VEC; c < C; c += kTTThreads * VEC) {
+        for (int c = tid * VEC; c < C; c += nthreads * VEC) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 float o[VEC];
@@ -321,7 +322,8 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             if (pos_of(k) >= p.tokens) continue;
-            const float m = fmaxf(fmaxf(red[k], red[16 + k]), fmaxf(red[32 + k], red[48 + k]));
+            float m = red[k];
+            for (int w = 1; w < (nthreads >> 6); ++w) m = fmaxf(m, red[w * 16 + k]);
             float sc, inv;
             f16s_scales(m, sc, inv);
             const int tok = p.out_index_ptr ? p.out_index_ptr[pos_of(k)] : pos_of(k);
@@ -343,7 +345,9 @@ static int launch_tt(const dimsum_tt_params_t &p, hipStream_t s) {
             dimsum_tt_params_t q = p;
             q.y_f16s_lds_offset = (int32_t)(lds / 4);
             lds += 64 * 4;
-#define DIMSUM_TTH(K) hipLaunchKernelGGL((token_transform_kernel<K, 4, true>), grid, block, lds, s, q)
+            const int cg = (p.channels + 3) / 4;
+            const dim3 blockh(cg <= 64 ? 64 : (cg <= 128 ? 128 : kTTThreads));
+#define DIMSUM_TTH(K) hipLaunchKernelGGL((token_transform_kernel<K, 4, true>), grid, blockh, lds, s, q)
             switch (p.kind) {
                 case DIMSUM_TT_NONE: DIMSUM_TTH(DIMSUM_TT_NONE); break;
                 case DIMSUM_TT_HAAR_FWD: DIMSUM_TTH(DIMSUM_TT_HAAR_FWD); break;

@@ -254,20 +254,38 @@ def _nt(a, b, **kw):
     return y if kw.get("bias") is None else y + kw["bias"]
 
 
-def _nt_f16s(a, b):
+def _tail(y, bias, residual, gate, rows_per_batch):
+    """the unfused form of the gate + residual epilogue: residual + gate[row // rows_per_batch] * (y + bias)"""
+    if bias is not None:
+        y = y + bias
+    if residual is None:
+        return y
+    if gate is not None:
+        y = (y.view(-1, rows_per_batch, y.shape[-1]) * gate.unsqueeze(1)).view(y.shape)
+    return residual + y
+
+
+def _nt_f16s(a, b, bias=None, residual=None, gate=None, rows_per_batch=None):
     """F16Image a (M, K) x F16Image b (N, K)^T -> (M, N) float32: ONE fp16 product per element, the row scales undone in the epilogue"""
     from . import native
-    if own_gemm_enabled() and native.gemm_nt_supported(a.data, b.data):
-        return native.gemm_nt(a.data, b.data, scales=(a.inv, b.inv))
-    return torch.mm(a.data, b.data.t(), out_dtype=torch.float32) * a.inv[:, None] * b.inv[None, :]
+    if own_gemm_enabled() and native.gemm_nt_supported(a.data, b.data) and (gate is None or rows_per_batch % 256 == 0):
+        return native.gemm_nt(a.data, b.data, bias=bias, scales=(a.inv, b.inv), residual=residual, gate=gate, rows_per_batch=rows_per_batch)
+    return _tail(torch.mm(a.data, b.data.t(), out_dtype=torch.float32) * a.inv[:, None] * b.inv[None, :], bias, residual, gate, rows_per_batch)
 
 
-def linear_split3(x3, weight):
-    """x3 (M, 3K) bfloat16 left image [hi | hi | lo] (or a scaled-fp16 F16Image (M, K)) @ weight (N, K)^T -> (M, N) float32"""
+def linear_split3(x3, weight, bias=None, residual=None, gate=None, rows_per_batch=None):
+    """x3 (M, 3K) bfloat16 left image [hi | hi | lo] (or a scaled-fp16 F16Image (M, K)) @ weight (N, K)^T -> (M, N) float32.
+    bias (N) / residual (M, N) / gate (M / rows_per_batch, N): residual + gate[row // rows_per_batch] * (x W^T + bias) -- the residual
+    tail of a block ("x = x + gate * mlp(...)", models_dim.py:1107-1113) in the epilogue of the GEMM instead of a pass of its own."""
     from . import native
     if isinstance(x3, native.F16Image):
-        return _nt_f16s(x3, weight_f16s(weight))
-    return _nt(x3, weight_image(weight))
+        return _nt_f16s(x3, weight_f16s(weight), bias, residual, gate, rows_per_batch)
+    w3i = weight_image(weight)
+    if residual is None and bias is None:
+        return _nt(x3, w3i)
+    if own_gemm_enabled() and native.gemm_nt_supported(x3, w3i) and (gate is None or rows_per_batch % 256 == 0):
+        return native.gemm_nt(x3, w3i, bias=bias, residual=residual, gate=gate, rows_per_batch=rows_per_batch)
+    return _tail(torch.mm(x3, w3i.t(), out_dtype=torch.float32), bias, residual, gate, rows_per_batch)
 
 
 def matmul_wx_split3(weight, x3):

@@ -95,13 +95,20 @@ class GatedMLP(nn.Module):
         self.act_layer = act_layer()
         self._fused = isinstance(self.act_layer, nn.GELU) and self.act_layer.approximate == "tanh"
 
-    def forward_deferred(self, x, x3=None):
+    def forward_deferred(self, x, x3=None, residual=None, gate=None):
         """-> (y, b): the module's output is y + b; b (w3's bias or None) is left to the caller's fused residual pass.
         x3: the caller's producer kernel already wrote x as a split-bf16 operand image (gemm.py, split3): both GEMMs then
-        run as plain bf16 GEMMs over the hi / lo images, the gated GeLU writes the w3 GEMM's image directly."""
+        run as plain bf16 GEMMs over the hi / lo images, the gated GeLU writes the w3 GEMM's image directly.
+        residual (B, L, H) [, gate (B, H)] (with x3): the block's residual tail rides in the w3 GEMM's epilogue -- the call returns
+        (residual + gate * (mlp(x) + b3), None)."""
         if x3 is not None:
             b12 = self.w12.bias
             h3 = gemm.gated_mlp_hidden_split3(x3, self.w12.weight, None if b12 is None else b12.float())
+            if residual is not None:
+                H = self.w3.weight.shape[0]
+                b3 = None if self.w3.bias is None else self.w3.bias.float()
+                y = gemm.linear_split3(h3, self.w3.weight, bias=b3, residual=residual.reshape(-1, H), gate=gate, rows_per_batch=residual.shape[-2])
+                return y.view(residual.shape), None
             return gemm.linear_split3(h3, self.w3.weight).view(*x.shape[:-1], self.w3.weight.shape[0]), self.w3.bias
         if self._fused and x.dtype == torch.float32:
             b12 = self.w12.bias

@@ -463,6 +463,8 @@ class _CombinedBase(_BlockBase):
             y, _, _, hnew = native.layer_norm_fwd(fused.reshape(B * L, H), self.norm_2.weight, self.norm_2.bias, self.norm_2.eps,
                                                   residual=hidden_states.reshape(B * L, H), is_rms_norm=True, x_bias=pb,
                                                   mod_scale=scale, mod_shift=shift, rows_per_batch=L, **({"split3": s3} if s3 else {}))
+            if s3 and hnew.is_contiguous():       # ... and the residual tail "h + gate * (mlp + b)" in the epilogue of the w3 GEMM
+                return self.mlp.forward_deferred(hidden_states, x3=y, residual=hnew.view(B, L, H), gate=gate)[0], residual
             m, mb = self.mlp.forward_deferred(hidden_states, x3=y) if s3 else self.mlp.forward_deferred(y.view(B, L, H))
             return token_ops.gate_residual(hnew.view(B, L, H), m, gate, mb), residual
         hidden_states = token_ops.gate_residual(hidden_states, fused, None, pb)
@@ -527,6 +529,8 @@ class DiTBlock(nn.Module):
         if h is None:
             return _mlp_tail(self.mlp, x, self.norm2(x), sm, cm, gm)
         if hasattr(self.mlp, "forward_deferred"):
+            if s3 and x.is_contiguous():
+                return self.mlp.forward_deferred(x, x3=h, residual=x, gate=gm)[0]
             m, mb = self.mlp.forward_deferred(x, x3=h) if s3 else self.mlp.forward_deferred(h)
             return token_ops.gate_residual(x, m, gm, mb)
         return token_ops.gate_residual(x, self.mlp(h), gm, None)

@@ -527,13 +527,16 @@ def gemm_nt_supported(a, b, gated=False):
             and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and 512 * max(a.stride(0), b.stride(0)) < 2 ** 31)
 
 
-def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=None, tune=None, scales=None, gate_bound=None):
+def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=None, tune=None, scales=None, gate_bound=None, residual=None,
+            gate=None, rows_per_batch=None):
     """a (M, K) @ b (N, K)^T on the hand-written MFMA kernel, 16-bit operands (bfloat16: split-bf16 images over 3 K; float16: scaled rows),
     fp32 accumulation.
       epilogue "f32"          -> (M, N) float32 (+ bias[N])
                "gated_split3" -> b = the (2F, K) w12 weight image, bias (2F) or None: the LEFT split-bf16 image (M, 3F) bfloat16 of
                                  gelu_tanh(x1 + b1) * (x2 + b2)   (mlp.py:66-70; the fp32 (M, 2F) x12 never exists)
                "gated_f16"    -> same, (M, F) float16 of h * out_scale
+    residual (M, N) float32 [, gate (M / rows_per_batch, N) float32]: epilogue "f32" becomes residual + gate[row // rows_per_batch] * (a b^T + bias)
+    -- the residual tail of a block in the epilogue of its last Linear (rows_per_batch % 256 == 0).
     scales: (a_inv (M,), b_inv (N,)) float32 inverse scales of scaled-fp16 operand images (F16Image): C[m, n] *= a_inv[m] * b_inv[n].
     gate_bound ("gated_f16" over scaled operands): 2-element float32 device tensor {max_n sum_k |w_nk|, max |bias|}: the h image gets a
     per-row power-of-two scale derived from it and the call returns (h16, h_inv).
@@ -555,6 +558,15 @@ def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=Non
         if out is None:
             out = torch.empty((M, N), device=a.device, dtype=torch.float32)
         _check(out.dtype == torch.float32 and out.shape == (M, N) and out.stride(1) == 1, "gemm_nt: out must be (M, N) float32 rows")
+        if residual is not None:
+            _gpu(residual, gate)
+            _check(residual.dtype == torch.float32 and residual.shape == (M, N) and residual.stride(1) == 1, "gemm_nt: residual must be (M, N) float32 rows")
+            P.epilogue = _lib.GEMM_EPI_F32_GATE_RESIDUAL
+            P.residual_ptr, P.residual_ld = _ptr(residual), residual.stride(0)
+            if gate is not None:
+                _check(rows_per_batch and rows_per_batch % 256 == 0 and M % rows_per_batch == 0 and gate.dtype == torch.float32
+                       and gate.shape == (M // rows_per_batch, N) and gate.stride(1) == 1, "gemm_nt: gate must be (M / rows_per_batch, N) float32, rows_per_batch % 256 == 0")
+                P.gate_ptr, P.gate_ld, P.rows_per_batch = _ptr(gate), gate.stride(0), rows_per_batch
     elif epilogue == "gated_split3":
         P.epilogue = _lib.GEMM_EPI_GATED_GELU_SPLIT3
         if out is None:

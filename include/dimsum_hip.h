@@ -362,11 +362,15 @@ int dimsum_gated_gelu_bwd_split3(const void *x12, const void *bias, const void *
  *                             C = the LEFT split-bf16 image (m, 3 F) of h = gelu_tanh(x1 + b1) * (x2 + b2), ldc in bf16 elements:
  *                             the fp32 x12 tensor of mlp.py:68 never exists
  *            GATED_GELU_F16 : same, C = fp16 (m, F) of h * out_scale
+ *            F32_GATE_RESIDUAL : C = residual + gate[row / rows_per_batch] * (A B^T + bias): the residual tail of a block
+ *                             ("x = x + gate * mlp(...)", models_dim.py:1107-1113) in the epilogue of its last Linear; residual (m, n) f32,
+ *                             gate (m / rows_per_batch, n) f32 or NULL (= 1), rows_per_batch % 256 == 0, bias NULL or (n)
  * Shapes: m % 256 == 0, k % 64 == 0, k >= 128, n % 4 == 0 (gated: n % 16 == 0, ldc % 8 == 0); lda, ldb % 8 == 0; a_ptr, b_ptr, c_ptr
  * 16-byte aligned.
  * ------------------------------------------------------------------------------------------------------------- */
 typedef enum {
-    DIMSUM_GEMM_EPI_F32 = 0, DIMSUM_GEMM_EPI_GATED_GELU_SPLIT3 = 1, DIMSUM_GEMM_EPI_GATED_GELU_F16 = 2, DIMSUM_GEMM_EPI_F32_BIAS = 3
+    DIMSUM_GEMM_EPI_F32 = 0, DIMSUM_GEMM_EPI_GATED_GELU_SPLIT3 = 1, DIMSUM_GEMM_EPI_GATED_GELU_F16 = 2, DIMSUM_GEMM_EPI_F32_BIAS = 3,
+    DIMSUM_GEMM_EPI_F32_GATE_RESIDUAL = 4
 } dimsum_gemm_epilogue_t;
 
 typedef struct {
@@ -387,6 +391,10 @@ typedef struct {
      * its inverse goes to h_inv_scale[m] -- the a_inv_scale of the w3 GEMM. NULL: out_scale for every row. */
     const void *gate_bound_ptr;
     void *h_inv_scale_ptr;        /* (m) f32 */
+    /* F32_GATE_RESIDUAL */
+    const void *residual_ptr, *gate_ptr;
+    int64_t residual_ld, gate_ld;
+    int32_t rows_per_batch;
 } dimsum_gemm_params_t;
 
 int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream);

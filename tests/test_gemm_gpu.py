@@ -102,3 +102,44 @@ def test_full_size_w12_against_library():
     got = native.gemm_nt(a, b)
     lib = torch.mm(a, b.t(), out_dtype=torch.float32)
     assert (got - lib).abs().max().item() <= 2e-5 * lib.abs().max().item()
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("with_gate,with_bias", [(True, True), (True, False), (False, True)])
+def test_gate_residual_epilogue(dtype, with_gate, with_bias):
+    """out = residual + gate[row // rows_per_batch] * (a b^T + bias): the residual tail of a block (models_dim.py:1107-1113) in the
+    epilogue of its last Linear, against the float64 expression; ragged N; the residual may be the output buffer's neighbour view"""
+    from dimsum_amd import native
+    dt = getattr(torch, dtype)
+    B, L, N, K = 3, 256, 392, 320
+    M = B * L
+    a, b = _rnd((M, K), dt, 1), _rnd((N, K), dt, 2, scale=K ** -0.5)
+    res = _rnd((M, N), torch.float32, 3)
+    gate = _rnd((B, 3 * N), torch.float32, 4)[:, N:2 * N] if with_gate else None        # a chunk of the adaLN output: row stride 3 N
+    bias = _rnd((N,), torch.float32, 5) if with_bias else None
+    got = native.gemm_nt(a, b, bias=bias, residual=res, gate=gate, rows_per_batch=L if with_gate else None)
+    y = a.double() @ b.double().t() + (0 if bias is None else bias.double())
+    if gate is not None:
+        y = (y.view(B, L, N) * gate.double().unsqueeze(1)).view(M, N)
+    ref = res.double() + y
+    assert (got.double() - ref).abs().max().item() / ref.abs().max().item() < 3e-6
+
+
+def test_mlp_tail_in_the_epilogue_matches_the_separate_pass(monkeypatch):
+    """GatedMLP.forward_deferred(x3=..., residual=..., gate=...) == token_ops.gate_residual(residual, mlp(x), gate, b3), split-bf16 and
+    scaled-fp16 images"""
+    from dimsum_amd import gemm, native
+    from dimsum_amd.mlp import GatedMLP
+    from dimsum_amd.ops import token_ops
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    B, L, H = 2, 256, 384
+    mlp = GatedMLP(H, 4 * H, act_layer=lambda: torch.nn.GELU(approximate="tanh")).cuda()
+    x, res, gate = _rnd((B, L, H), torch.float32, 1), _rnd((B, L, H), torch.float32, 2), _rnd((B, H), torch.float32, 3)
+    with torch.no_grad():
+        for img in (native.split3_rows(x.reshape(B * L, H), left=True), native.rows_f16s(x.reshape(B * L, H))):
+            m, mb = mlp.forward_deferred(x, x3=img)
+            want = token_ops.gate_residual(res, m, gate, mb)
+            got, none = mlp.forward_deferred(x, x3=img, residual=res, gate=gate)
+            assert none is None and got.shape == want.shape
+            assert (got - want).abs().max().item() <= 2e-6 * want.abs().max().item()
