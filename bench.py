@@ -320,22 +320,18 @@ class Bench:
         one branch overlaps the GEMMs of the other and its launch-to-launch time is no longer its own. The roofline of the scan
         kernel is therefore measured in a short pass of `n` more steps of the SAME step function on ONE stream
         (DIMSUM_BRANCH_STREAMS=0), right after the timed region, with one HIP-event pair per launch; the line says so."""
-        old = os.environ.get("DIMSUM_BRANCH_STREAMS")
-        os.environ["DIMSUM_BRANCH_STREAMS"] = "0"
+        from dimsum_amd.models_dim import branch_streams
         try:
-            step()
-            torch.cuda.synchronize()
-            self.timer.reset()
-            self.timer.enabled = True
-            for _ in range(n):
+            with branch_streams(False):
                 step()
-            torch.cuda.synchronize()
+                torch.cuda.synchronize()
+                self.timer.reset()
+                self.timer.enabled = True
+                for _ in range(n):
+                    step()
+                torch.cuda.synchronize()
         finally:
             self.timer.enabled = False
-            if old is None:
-                del os.environ["DIMSUM_BRANCH_STREAMS"]
-            else:
-                os.environ["DIMSUM_BRANCH_STREAMS"] = old
         rf = self.timer.roofline("fwd")
         if rf is not None:
             rf["timed_in"] = (f"single-stream pass of {n} steps right after the timed region ({rf['launches_timed']} launches, HIP events at the "
@@ -344,7 +340,8 @@ class Bench:
 
     @staticmethod
     def streams_note():
-        return ("one stream (DIMSUM_BRANCH_STREAMS=0)" if os.environ.get("DIMSUM_BRANCH_STREAMS", "1") == "0"
+        from dimsum_amd.models_dim import branch_streams_enabled
+        return ("one stream (DIMSUM_BRANCH_STREAMS=0)" if not branch_streams_enabled()
                 else "two HIP streams per block (spatial || frequency branch), bit-identical to one stream")
 
     def inputs(self, batch, r):

@@ -30,8 +30,16 @@ import contextlib
 import torch
 import torch.nn.functional as F
 
+import threading
+
 _policy = "default"
-_frozen = None          # weight-image cache of the innermost frozen_weights() scope, else None
+
+
+class _Local(threading.local):
+    frozen = None       # weight-image cache of the innermost frozen_weights() scope of THIS thread, else None
+
+
+_tls = _Local()
 
 
 @contextlib.contextmanager
@@ -40,15 +48,14 @@ def frozen_weights():
     weights): the split-bf16 weight images [hi | lo | hi] (and the fp16 copies of the opt-in policy) are built once per weight
     instead of once per call -- 128 ~14 us launches per DiM-L/2 forward. Outside such a scope every call converts afresh, because a
     cached image cannot see in-place updates made through `.data` (EMA, load_state_dict). The cache dies with the scope."""
-    global _frozen
-    outer = _frozen
+    outer = _tls.frozen
     if outer is None:
-        _frozen = {}
+        _tls.frozen = {}
     try:
         yield
     finally:
         if outer is None:
-            _frozen = None
+            _tls.frozen = None
 
 
 def _cached(kind, weight, make):
@@ -56,13 +63,14 @@ def _cached(kind, weight, make):
     # (hip_graph.GraphedForward, kept by the caller across batches) outlives this scope -- a cached image would be freed under it
     # and would also freeze the weights of the first capture into every replay. Built inside the capture, the conversion kernel
     # is part of the graph (it re-reads the parameter on every replay) and its output lives in the graph's private pool.
-    if _frozen is None or (weight.is_cuda and torch.cuda.is_current_stream_capturing()):
+    frozen = _tls.frozen
+    if frozen is None or (weight.is_cuda and torch.cuda.is_current_stream_capturing()):
         return make()
     key = (kind, weight.data_ptr(), tuple(weight.shape), tuple(weight.stride()), weight.dtype)
-    hit = _frozen.get(key)
+    hit = frozen.get(key)
     if hit is None:
         # the entry keeps the weight alive: its storage cannot be freed and handed to another tensor while the image is cached
-        hit = _frozen[key] = (make(), weight)
+        hit = frozen[key] = (make(), weight)
     return hit[0]
 
 

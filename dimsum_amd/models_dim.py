@@ -128,6 +128,35 @@ class LabelEmbedder(nn.Module):
         return self.in_channels
 
 
+# Two-stream branches (inference): read ONCE from DIMSUM_BRANCH_STREAMS when the module is imported; `branch_streams(False)` overrides it for
+# the calls made inside the scope of the calling thread (bench.py's single-stream roofline pass) -- no per-forward environment lookups,
+# no process-wide mutation from a measurement.
+import contextvars as _contextvars
+
+_BRANCH_STREAMS_DEFAULT = os.environ.get("DIMSUM_BRANCH_STREAMS", "1") != "0"
+_branch_streams = _contextvars.ContextVar("dimsum_branch_streams", default=None)
+
+
+def branch_streams_enabled():
+    v = _branch_streams.get()
+    return _BRANCH_STREAMS_DEFAULT if v is None else v
+
+
+class branch_streams:
+    """with branch_streams(False): the two branches of every combined block run on ONE stream inside the scope"""
+
+    def __init__(self, enabled):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        self.token = _branch_streams.set(self.enabled)
+        return self
+
+    def __exit__(self, *exc):
+        _branch_streams.reset(self.token)
+        return False
+
+
 def _ln_modulate(norm, x, shift, scale, split3=False):
     """modulate(LayerNorm(x), shift, scale) for the affine-free LayerNorms of DiTBlock / FinalLayer (models_dim.py:1536-1553,
     214-219). Inference on the GPU: ONE pass of the fused norm kernel (csrc/norm.hip with the modulation folded in) instead of
@@ -431,7 +460,7 @@ class _CombinedBase(_BlockBase):
         # inference under allow_tf32: the branches hand their results over as split-bf16 operand images of the qkv Linears
         img = self.proj.takes_images(hidden_states) and gemm.split3_enabled(x1, self.proj.qkv1.weight)      # False / True / "f16s"
         kw = {"out_split3": img} if img else {}
-        if ((not torch.is_grad_enabled()) and hidden_states.is_cuda and os.environ.get("DIMSUM_BRANCH_STREAMS", "1") != "0"
+        if ((not torch.is_grad_enabled()) and hidden_states.is_cuda and branch_streams_enabled()
                 and not torch.cuda.is_current_stream_capturing()):
             # inference: the two branches are independent until the fusion -- the frequency branch on a second HIP stream lets the
             # memory-bound passes of one branch (conv1d, scan, token passes) overlap the GEMMs of the other: -1.3 .. -2.4 % per

@@ -362,11 +362,11 @@ def test_zigzag_paths_folded_into_block_tables():
 
 
 @pytest.mark.gpu
-def test_two_stream_branches_are_bit_identical(monkeypatch):
-    """two-stream branches (the inference default; DIMSUM_BRANCH_STREAMS=0 keeps one stream): the frequency branch of every combined
+def test_two_stream_branches_are_bit_identical():
+    """two-stream branches (the inference default; DIMSUM_BRANCH_STREAMS=0 at import / `branch_streams(False)` keep one stream): the frequency branch of every combined
     block on a second HIP stream -- same kernels, same operands, same result, also when the forward is called twice in a row and
     from a non-default stream"""
-    from dimsum_amd.models_dim import DiM
+    from dimsum_amd.models_dim import DiM, branch_streams
     m = DiM(depth=4, hidden_size=384, patch_size=2, **_published())
     procedural_fill(m, seed=3)
     m = m.cuda().eval()
@@ -374,15 +374,15 @@ def test_two_stream_branches_are_bit_identical(monkeypatch):
     x, t = torch.randn(8, 4, 32, 32, device="cuda", generator=g), torch.rand(8, device="cuda", generator=g)
     y = torch.randint(0, 1000, (8,), device="cuda", generator=g)
     with torch.no_grad():
-        monkeypatch.setenv("DIMSUM_BRANCH_STREAMS", "0")
-        ref = m(x, t, y)
+        with branch_streams(False):
+            ref = m(x, t, y)
         assert all("_side_stream" not in blk.__dict__ for blk in m.blocks)
-        monkeypatch.delenv("DIMSUM_BRANCH_STREAMS")           # the default
-        a, b = m(x, t, y), m(x, t, y)
+        with branch_streams(True):                             # (the default unless DIMSUM_BRANCH_STREAMS=0 was exported)
+            a, b = m(x, t, y), m(x, t, y)
         assert any("_side_stream" in blk.__dict__ for blk in m.blocks)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
+        with torch.cuda.stream(s), branch_streams(True):
             c = m(x, t, y)
         torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()

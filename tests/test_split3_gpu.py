@@ -330,7 +330,7 @@ def test_frozen_weights_scope_caches_weight_images(monkeypatch):
         assert gemm.weight_image(w) is a
     w.data.mul_(2.0)                                                           # an update the version counter does not see
     assert torch.equal(gemm.linear_split3(x3, w), 2.0 * ref)                   # ... is seen outside the scope
-    assert gemm._frozen is None
+    assert gemm._tls.frozen is None
 
 
 def test_sample_batch_builds_each_weight_image_once(monkeypatch):
