@@ -22,11 +22,26 @@ P
 }
 # the headline forward twice: as shipped (two HIP streams per block: overlapped kernels, the wall time) and on ONE stream
 # (DIMSUM_BRANCH_STREAMS=0: per-kernel durations that mean something -- this is what bench.py's single-stream roofline pass times)
+stats() {   # (every profiled run is bounded: a hung profiler must not eat the round's GPU minutes)
+  name=$1; shift
+  rm -rf /tmp/prof_$name
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python3 bench.py "$@" > $out/${name}.log 2>&1
+  f=$(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && python3 - "$f" "$out/${tag}_${name}_kernel_stats.csv" <<'P'
+import csv, sys
+rows = list(csv.reader(open(sys.argv[1])))
+w = csv.writer(open(sys.argv[2], "w"))
+for r in rows:
+    w.writerow([c[:200] for c in r])          # kernel names truncated to 200 chars
+P
+  tail -1 $out/${name}.log | cut -c1-300
+}
 stats fwd2s --mode fwd --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg
 export DIMSUM_BRANCH_STREAMS=0
 stats fwd --mode fwd --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg
 stats block --mode block --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg
 stats xl512 --mode xl512 --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg
+stats fwd_f16s --mode fwd --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg --matmul f16s
 unset DIMSUM_BRANCH_STREAMS
 stats all --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg --nfe 10
 # PMC: forward (inference), forward + saved states, backward (as dimsum_amd.ops calls it: no out_z recompute; and with it), config-5 forward,
@@ -37,6 +52,8 @@ bash tools/pmc_scan.sh $out/pmc_bwd --dmajor --bwd --no-out-z > $out/${tag}_scan
 bash tools/pmc_scan.sh $out/pmc_bwd_oz --dmajor --bwd > $out/${tag}_scan_bwd_outz_pmc.txt 2>&1
 bash tools/pmc_scan.sh $out/pmc_fwd_xl --dmajor --B 64 --D 1152 --L 1024 > $out/${tag}_scan_fwd_xl512_pmc.txt 2>&1
 bash tools/pmc_scan.sh $out/pmc_fwd_stress --dmajor --B 16 --D 1152 --L 4096 > $out/${tag}_scan_fwd_stress_pmc.txt 2>&1
+timeout 600 bash tools/scratch/gemm_pmc.sh $tag > /dev/null 2>&1; cp gpurun_out/gemm/pmc_${tag}.txt $out/${tag}_gemm_gated_pmc.txt; rm -rf gpurun_out/gemm/pmc_${tag}
+timeout 300 python3 tools/bench_gemm.py --perf --rounds 5 2>/dev/null | grep -v amdgpu > $out/${tag}_gemm_perf.jsonl
 bash tools/scratch/xattn_pmc.sh fwd > $out/${tag}_xattn_fwd_pmc.txt 2>&1
 bash tools/scratch/xattn_pmc.sh bwd > $out/${tag}_xattn_bwd_pmc.txt 2>&1
 rm -rf $out/pmc_fwd $out/pmc_fwd_train $out/pmc_bwd $out/pmc_bwd_oz $out/pmc_fwd_xl $out/pmc_fwd_stress     # raw csv trees: only the summaries travel back
