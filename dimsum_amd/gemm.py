@@ -210,14 +210,16 @@ def matmul_wx(weight, xt):
     return torch.mm(_w16(weight), xt.to(torch.float16), out_dtype=torch.float32)
 
 
-def split3_enabled(x, weight):
+def split3_enabled(x, weight, producer="token"):
     """the operand-image carriers serve exactly the launches the library would run as split-bf16 fp32 GEMMs: inference, fp32, allow_tf32.
     -> False, True (split-bf16 images: three bf16 products per fp32 product) or "f16s" (policy "f16s": scaled-fp16 images, ONE product):
-    the value is what the producer kernels take as their `split3` argument."""
+    the value is what the producer kernels take as their `split3` argument. producer: which kernel family writes the image ("token":
+    csrc/token_transform.hip, "norm": csrc/norm.hip) -- their scaled-fp16 variants hold rows of different width."""
     import os
     mode = "f16s" if _policy == "f16s" else True
-    if mode == "f16s" and x.shape[-1] > 1024:
-        mode = True        # the token passes hold one channel group per thread (C <= 1024): wider models keep the split-bf16 images
+    if mode == "f16s" and x.shape[-1] > (1024 if producer == "token" else 2048):
+        mode = True        # the token passes hold one channel group per thread (C <= 1024), the norm passes a row in registers (<= 2048):
+                           # wider rows keep the split-bf16 images
     if not (_policy in ("default", "f16s") and torch.backends.cuda.matmul.allow_tf32 and os.environ.get("DIMSUM_SPLIT3", "1") != "0"
             and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.shape[-1] % 4 == 0
             and not torch.is_grad_enabled()):

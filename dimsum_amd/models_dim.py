@@ -488,7 +488,7 @@ class _CombinedBase(_BlockBase):
             from . import native
             B, L, H = hidden_states.shape
             # ... written directly as the split-bf16 operand image of the w12 GEMM when the library would split it anyway (gemm.py)
-            s3 = getattr(self.mlp, "_fused", False) and gemm.split3_enabled(hidden_states, self.mlp.w12.weight)   # False / True / "f16s"
+            s3 = getattr(self.mlp, "_fused", False) and gemm.split3_enabled(hidden_states, self.mlp.w12.weight, producer="norm")   # False / True / "f16s"
             y, _, _, hnew = native.layer_norm_fwd(fused.reshape(B * L, H), self.norm_2.weight, self.norm_2.bias, self.norm_2.eps,
                                                   residual=hidden_states.reshape(B * L, H), is_rms_norm=True, x_bias=pb,
                                                   mod_scale=scale, mod_shift=shift, rows_per_batch=L, **({"split3": s3} if s3 else {}))
@@ -546,7 +546,7 @@ class DiTBlock(nn.Module):
 
     def forward(self, x, c=None, **kwargs):
         sa, ca, ga, sm, cm, gm = self.adaLN_modulation(c).chunk(6, dim=1)
-        s3 = gemm.split3_enabled(x, self.attn.qkv.weight)      # inference under allow_tf32: the norm passes write operand images
+        s3 = gemm.split3_enabled(x, self.attn.qkv.weight, producer="norm")      # inference under allow_tf32: the norm passes write operand images
         h = _ln_modulate(self.norm1, x, sa, ca, split3=s3)
         if h is not None and s3:
             a, ab = self.attn.forward_deferred(x, x3=h)

@@ -184,20 +184,20 @@ def test_block_under_f16s_policy_vs_emulated_tf32(monkeypatch):
     assert m1 / scale < 1e-3
 
 
-@pytest.mark.parametrize("name", ["DiM-L/2"])
-def test_model_under_f16s_policy_vs_emulated_tf32(name):
+@pytest.mark.parametrize("name,image_size,B", [("DiM-L/2", 256, 32), ("DiM-XL/2", 512, 8)])
+def test_model_under_f16s_policy_vs_emulated_tf32(name, image_size, B):
     """the whole denoiser (reference init, zero tensors re-drawn): f16s deviation from exact fp32 <= emulated-TF32 deviation"""
     from dimsum_amd.utils.tf32_emulation import emulated_tf32
     from dimsum_amd import gemm
     from dimsum_amd.create_model import create_model, published_config
     from dimsum_amd.utils import rerandomize_zeros
     torch.manual_seed(0)
-    m = create_model(published_config(model=name, image_size=256))
+    m = create_model(published_config(model=name, image_size=image_size))
     rerandomize_zeros(m, std=0.02, seed=0)
     m = m.cuda().eval()
     gen = torch.Generator(device="cuda").manual_seed(0)
-    B = 32                                                   # 8192 rows: the image carriers are on at their default threshold
-    x, t = torch.randn(B, 4, 32, 32, device="cuda", generator=gen), torch.rand(B, device="cuda", generator=gen)
+    r = image_size // 8                                      # B x tokens = 8192 rows: the image carriers are on at their default threshold
+    x, t = torch.randn(B, 4, r, r, device="cuda", generator=gen), torch.rand(B, device="cuda", generator=gen)
     y = torch.randint(0, 1000, (B,), device="cuda", generator=gen)
     old = torch.backends.cuda.matmul.allow_tf32
     try:
