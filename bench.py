@@ -413,6 +413,13 @@ class Bench:
             out["fp16_operand_matmul_optin"] = {"value_per_gpu": batch / dt, "ms_per_step": 1e3 * dt,
                                                 "max_abs_dev_over_max_abs_vs_exact_fp32": ((got - ref).abs().max() / ref.abs().max()).item()}
             self.set_matmul("tf32")
+        elif self.world == 1 and a.matmul == "tf32" and not a.hip_graph and not a.no_fp32_leg:
+            # (legs without the full extras: only the single-product timing, 3 steps)
+            self.set_matmul("f16s")
+            dt = self.timed(step, 3, 2, time_scans=False) / 3
+            out["tf32_single_product_f16s"] = {"value_per_gpu": batch / dt, "ms_per_step": 1e3 * dt, "steps": 3,
+                                               "what": "dimsum_amd.gemm policy 'f16s' (see the headline leg's key of the same name); NOT this leg's value"}
+            self.set_matmul("tf32")
         del model
         self.free()
         return out
