@@ -89,7 +89,7 @@ class GemmParams(C.Structure):
     _fields_ = ([(n, i32) for n in ("m", "n", "k", "operand_dtype", "epilogue")] + [("out_scale", f32)]
                 + [(n, i64) for n in ("lda", "ldb", "ldc")]
                 + [(n, vp) for n in ("a_ptr", "b_ptr", "bias_ptr", "c_ptr", "timing_start_event", "timing_stop_event")]
-                + [(n, i32) for n in ("tune_variant", "tune_group_m", "tune_start_delay")]
+                + [(n, i32) for n in ("tune_variant", "tune_group_m", "tune_reserved")]
                 + [(n, vp) for n in ("a_inv_scale_ptr", "b_inv_scale_ptr", "gate_bound_ptr", "h_inv_scale_ptr", "residual_ptr", "gate_ptr")]
                 + [("residual_ld", i64), ("gate_ld", i64), ("rows_per_batch", i32)])
 

@@ -40,7 +40,6 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
     a.sa = reinterpret_cast<const float *>(p->a_inv_scale_ptr);
     a.sb = reinterpret_cast<const float *>(p->b_inv_scale_ptr);
     if (a.sb && !aligned_to<char>(a.sb, 16)) return DIMSUM_ERR_STRIDE;
-    a.start_delay = p->tune_start_delay;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t e0 = reinterpret_cast<hipEvent_t>(p->timing_start_event), e1 = reinterpret_cast<hipEvent_t>(p->timing_stop_event);
     const bool bf = p->operand_dtype == DIMSUM_BF16;

@@ -64,7 +64,6 @@ struct Args {
     int tiles_m, tiles_n;
     float out_scale;               // kEpiGatedF16: h is stored as fp16(h * out_scale)
     int group_m;                   // tile rows per group of the tile order (L2 patch shape)
-    int start_delay;               // tuning: first-round workgroups sleep (blockIdx % 8) * start_delay * 64 cycles
 };
 // tuning variants (bit mask; 0 = the shipped schedule)
 enum { kVarLgkmAfterBarrier = 1, kVarNoEpilogue = 2, kVarNtStores = 4, kVarFullLineStores = 8, kVarNoSetprio = 16, kVarSc1Stores = 32, kVarSc0Stores = 64 };
@@ -216,9 +215,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
     } while (0)
 
     const int nk = p.K / kBK;      // >= 2
-    if (p.start_delay > 0 && blockIdx.x < 256) {
-        for (int d = (blockIdx.x >> 3 & 7) * p.start_delay; d > 0; --d) __builtin_amdgcn_s_sleep(1);
-    }
 
     // ---- prologue: the 8 half tiles of K tiles 0 and 1 in read order; A0(0) and B0(0) must have landed before the first reads
     stage_a0(0); stage_b0(0); stage_b1(0); stage_a1(0);
@@ -485,6 +481,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
         }
     }
 }
+
+#undef DIMSUM_READ_A
+#undef DIMSUM_READ_B
+#undef DIMSUM_QUADRANT
+#undef DIMSUM_PHASE_SYNC
+#undef DIMSUM_PHASE_END
+#undef DIMSUM_DS_READ_B128
+#undef DIMSUM_WAIT_VM
+#undef DIMSUM_WAIT_LGKM0
 
 }  // namespace gemm_nt
 }  // namespace dimsum

@@ -333,6 +333,49 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
     }
 }
 
+// kind NONE with a scaled-fp16 image output: no transform ties tokens together, so ONE WAVE owns a token row (like the norm kernel): the row
+// waits in registers for its exact maximum (6 VALU steps, no LDS, no barrier), 16-byte loads and 8-byte stores of whole rows.
+template <int kPieces>
+__global__ __launch_bounds__(256) void token_rows_f16s_kernel(const dimsum_tt_params_t p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = p.channels, T = p.tokens;
+    const int64_t rows = (int64_t)p.batch * T;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const int b = (int)(row / T), s = (int)(row - (int64_t)b * T);
+        const int src = p.in_index_ptr ? p.in_index_ptr[s] : s, dst = p.out_index_ptr ? p.out_index_ptr[s] : s;
+        const float *x = reinterpret_cast<const float *>(p.x_ptr) + (int64_t)b * p.x_batch_stride + (int64_t)src * p.x_token_stride;
+        const float *res = p.residual_ptr ? reinterpret_cast<const float *>(p.residual_ptr) + (int64_t)b * p.res_batch_stride + (int64_t)dst * p.res_token_stride : nullptr;
+        const float *gate = p.gate_ptr ? reinterpret_cast<const float *>(p.gate_ptr) + (int64_t)b * p.mod_batch_stride : nullptr;
+        const float *scale = p.scale_ptr ? reinterpret_cast<const float *>(p.scale_ptr) + (int64_t)b * p.mod_batch_stride : nullptr;
+        const float *shift = p.shift_ptr ? reinterpret_cast<const float *>(p.shift_ptr) + (int64_t)b * p.mod_batch_stride : nullptr;
+        f32x4 v[kPieces];
+        float m = 0.f;
+#pragma unroll
+        for (int i = 0; i < kPieces; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < C) {
+                const float4 t = *reinterpret_cast<const float4 *>(x + c);
+                v[i] = f32x4{{t.x, t.y, t.z, t.w}};
+                if (gate) { const float4 g = *reinterpret_cast<const float4 *>(gate + c); v[i].v[0] *= g.x; v[i].v[1] *= g.y; v[i].v[2] *= g.z; v[i].v[3] *= g.w; }
+                if (scale) { const float4 g = *reinterpret_cast<const float4 *>(scale + c); v[i].v[0] *= 1.0f + g.x; v[i].v[1] *= 1.0f + g.y; v[i].v[2] *= 1.0f + g.z; v[i].v[3] *= 1.0f + g.w; }
+                if (shift) { const float4 g = *reinterpret_cast<const float4 *>(shift + c); v[i].v[0] += g.x; v[i].v[1] += g.y; v[i].v[2] += g.z; v[i].v[3] += g.w; }
+                if (res) { const float4 g = *reinterpret_cast<const float4 *>(res + c); v[i].v[0] += g.x; v[i].v[1] += g.y; v[i].v[2] += g.z; v[i].v[3] += g.w; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v[i].v[e]));
+            }
+        }
+        float sc, inv;
+        f16s_scales(wave_allmax(m), sc, inv);
+        __half *y = reinterpret_cast<__half *>(p.y_ptr) + (int64_t)b * p.y_batch_stride + (int64_t)dst * p.y_token_stride;
+#pragma unroll
+        for (int i = 0; i < kPieces; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < C) *reinterpret_cast<uint2 *>(y + c) = f16s_pack4(v[i], sc);
+        }
+        if (lane == 0) reinterpret_cast<float *>(p.y_inv_scale_ptr)[(int64_t)b * T + dst] = inv;
+    }
+}
+
 template <int VEC>
 static int launch_tt(const dimsum_tt_params_t &p, hipStream_t s) {
     const bool blocked = p.kind != DIMSUM_TT_NONE;
@@ -340,6 +383,19 @@ static int launch_tt(const dimsum_tt_params_t &p, hipStream_t s) {
     const dim3 grid(nblk, p.batch), block(kTTThreads);
     size_t lds = (p.kind == DIMSUM_TT_HAAR_FWD || p.kind == DIMSUM_TT_HAAR_INV) ? (size_t)((p.channels + 3) / 4) * 68 * 4 : 0;
     if (lds > 160 * 1024) return DIMSUM_ERR_SHAPE;
+    if (p.y_split3 == 2 && p.kind == DIMSUM_TT_NONE) {
+        if constexpr (VEC == 4) {
+            const int64_t rows = (int64_t)p.batch * p.tokens;
+            int64_t blocks = (rows + 3) / 4;
+            if (blocks > 256 * 16) blocks = 256 * 16;
+            const dim3 g1((unsigned)blocks), b1(256);
+            if (p.channels <= 512) hipLaunchKernelGGL(token_rows_f16s_kernel<2>, g1, b1, 0, s, p);
+            else if (p.channels <= 1024) hipLaunchKernelGGL(token_rows_f16s_kernel<4>, g1, b1, 0, s, p);
+            else hipLaunchKernelGGL(token_rows_f16s_kernel<8>, g1, b1, 0, s, p);
+            return launch_status();
+        }
+        return DIMSUM_ERR_STRIDE;
+    }
     if (p.y_split3 == 2) {
         if constexpr (VEC == 4) {
             dimsum_tt_params_t q = p;
@@ -477,7 +533,8 @@ extern "C" int dimsum_token_transform(const dimsum_tt_params_t *p, void *stream)
     if (p->w_ptr) vec = vec && aligned_to<float>(p->w_ptr, 16) && p->w_batch_stride % 4 == 0 && p->w_token_stride % 4 == 0;
     if (p->y_split3 == 2) {       // scaled-fp16 image rows + (batch, tokens) inverse scales; no reductions alongside
         if (!p->y_ptr || !p->y_inv_scale_ptr) return DIMSUM_ERR_NULL;
-        if (!vec || p->y_token_stride < p->channels || p->channels > 4 * kTTThreads || p->w_ptr || p->tsum_ptr) return DIMSUM_ERR_STRIDE;
+        if (!vec || p->y_token_stride < p->channels || p->channels > (p->kind == DIMSUM_TT_NONE ? 2048 : 4 * kTTThreads) || p->w_ptr || p->tsum_ptr)
+            return DIMSUM_ERR_STRIDE;
     } else
     if (p->y_split3 && (!vec || !p->y_ptr || p->y_token_stride < 3 * (int64_t)p->channels)) return DIMSUM_ERR_STRIDE;   // image rows: 8-byte pieces
     return vec ? launch_tt<4>(*p, s) : launch_tt<1>(*p, s);

@@ -388,7 +388,8 @@ def token_transform(x, kind, forward, in_index=None, out_index=None, gate=None, 
     _check(want_y or w is not None or want_tsum, "token_transform: nothing to compute")
     y_inv = None
     if split3 == "f16s":
-        _check(want_y and C % 4 == 0 and C <= 1024 and w is None and not want_tsum, "token_transform: the f16s image needs channels % 4 == 0, <= 1024, no reductions")
+        _check(want_y and C % 4 == 0 and C <= (2048 if kind == "none" else 1024) and w is None and not want_tsum,
+               "token_transform: the f16s image needs channels % 4 == 0, <= 1024 (2048 without a transform), no reductions")
         y = torch.empty((B, L, C), device=x.device, dtype=torch.float16)
         y_inv = torch.empty((B, L), device=x.device, dtype=torch.float32)
     elif split3:
@@ -597,7 +598,7 @@ def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=Non
     if events is not None:
         P.timing_start_event, P.timing_stop_event = events
     if tune is not None:
-        P.tune_variant, P.tune_group_m, P.tune_start_delay = tune
+        P.tune_variant, P.tune_group_m = tune[:2]
     with torch.cuda.device(a.device):
         _lib.check(_lib.load().dimsum_gemm_nt(P, _stream(a)), "gemm_nt")
     return out if h_inv is None else F16Image(out, h_inv)

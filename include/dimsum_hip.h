@@ -382,7 +382,7 @@ typedef struct {
     const void *a_ptr, *b_ptr, *bias_ptr;
     void *c_ptr;
     void *timing_start_event, *timing_stop_event;   /* optional hipEvent_t pair recorded at the kernel's own dispatch boundaries */
-    int32_t tune_variant, tune_group_m, tune_start_delay;   /* 0 = the shipped schedule (tools/bench_gemm.py sweeps) */
+    int32_t tune_variant, tune_group_m, tune_reserved;      /* 0 = the shipped schedule and tile order (tools/bench_gemm.py --tune sweeps them) */
     /* scaled-fp16 operand images (dimsum_rows_f16s): C[m, n] = acc * a_inv_scale[m] * b_inv_scale[n] (exact powers of two), both or none */
     const void *a_inv_scale_ptr;  /* (m) f32 */
     const void *b_inv_scale_ptr;  /* (n) f32 */
