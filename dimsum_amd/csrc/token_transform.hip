@@ -106,7 +106,7 @@ template <int KIND, int VEC, bool F16S = false>
 __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsum_tt_params_t p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
-    const int nthreads = F16S ? (int)blockDim.x : kTTThreads;       // F16S: one channel group per thread, the block is sized to the channel count
+    const int nthreads = (F16S || KIND != DIMSUM_TT_NONE) ? (int)blockDim.x : kTTThreads;   // blocked kinds / images: the block is sized to the channel count
     const int b = blockIdx.y;
     const int C = p.channels, G = p.grid;
     // 16 positions s of this workgroup: a 4x4 block of the grid (or 16 consecutive tokens when KIND == NONE)
@@ -380,7 +380,10 @@ template <int VEC>
 static int launch_tt(const dimsum_tt_params_t &p, hipStream_t s) {
     const bool blocked = p.kind != DIMSUM_TT_NONE;
     const int nblk = blocked ? (p.grid / 4) * (p.grid / 4) : (p.tokens + 15) / 16;
-    const dim3 grid(nblk, p.batch), block(kTTThreads);
+    // a thread owns 4 channels of all 16 tokens of a 4 x 4 block: with 512 channels (a branch of DiM-L/2) a 256-thread block would idle half
+    // its threads at 2 blocks per CU (230-240 VGPRs): the blocked kinds get a block of the channel-group count instead
+    const int cgs = (p.channels + VEC - 1) / VEC;
+    const dim3 grid(nblk, p.batch), block(blocked ? (cgs <= 64 ? 64 : (cgs <= 128 ? 128 : kTTThreads)) : kTTThreads);
     size_t lds = (p.kind == DIMSUM_TT_HAAR_FWD || p.kind == DIMSUM_TT_HAAR_INV) ? (size_t)((p.channels + 3) / 4) * 68 * 4 : 0;
     if (lds > 160 * 1024) return DIMSUM_ERR_SHAPE;
     if (p.y_split3 == 2 && p.kind == DIMSUM_TT_NONE) {
