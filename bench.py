@@ -193,7 +193,7 @@ def build_block(name, device):
     return blk.to(device).train(), hidden
 
 
-def cpu_baseline(name, latents=4, image_size=256, runs=3, scan="c"):
+def cpu_baseline(name, latents=4, image_size=256, runs=3, scan="c", warm=True):
     """Bounded CPU sample of the headline workload: DiM forwards of `latents` latents through the CPU oracle
     ("port" of the reference's pure-PyTorch path: GEMMs in torch-CPU, scan / conv / norm in oracle/ssm_oracle.c with OpenMP),
     1 warm-up + `runs` timed runs, median."""
@@ -207,7 +207,8 @@ def cpu_baseline(name, latents=4, image_size=256, runs=3, scan="c"):
     x, t, y = torch.randn(latents, 4, r, r), torch.rand(latents), torch.randint(0, 1000, (latents,))
     times = []
     with torch.no_grad(), cpu_oracle_backend(scan=scan):
-        model(x, t, y)                               # warm-up (allocator, oracle build/load, page-in of the weights)
+        if warm:
+            model(x, t, y)                           # warm-up (allocator, oracle build/load, page-in of the weights)
         for _ in range(runs):
             t0 = time.perf_counter()
             model(x, t, y)
@@ -217,7 +218,7 @@ def cpu_baseline(name, latents=4, image_size=256, runs=3, scan="c"):
            "torch-CPU GEMMs, the scan as the reference's pure-PyTorch selective_scan_ref restated (two (B, D, L, N) temporaries + a Python loop "
            "over L), conv / norm in the C oracle")
     return {"value": latents / med, "unit": "latents/s", "cores": cores, "kind": "port",
-            "sample": f"{name} forward on {latents} latents (fp32, {how}): 1 warm-up + {runs} runs, "
+            "sample": f"{name} forward on {latents} latents (fp32, {how}): {1 if warm else 0} warm-up + {runs} runs, "
                       f"median {med:.2f} s (runs: {', '.join(f'{v:.2f}' for v in times)})"}
 
 
@@ -593,7 +594,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.mode in ("all", "fwd", "sample"):
             line["cpu_baseline"] = cpu_baseline(args.model, 4, args.image_size)
             # the SHAPE of the reference's own CPU path: its pure-PyTorch selective_scan_ref, at batch 16
-            line["cpu_baseline"]["reference_shaped"] = cpu_baseline(args.model, 16, args.image_size, runs=1, scan="torch_loop")
+            line["cpu_baseline"]["reference_shaped"] = cpu_baseline(args.model, 16, args.image_size, runs=1, scan="torch_loop", warm=False)   # (33 s per run: the port's runs above warmed the process)
             if args.mode == "all":      # BASELINE configs[0], SURVEY 8(d): DiM-S/2, batch 4 on the same host cores
                 line["cpu_baseline"]["config0_S2_batch4"] = cpu_baseline("DiM-S/2", 4, args.image_size)
         print(json.dumps(line), flush=True)
