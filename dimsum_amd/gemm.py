@@ -1,5 +1,7 @@
-"""Library-GEMM precision policy of the host layer (the large bias-free Linears of the denoiser: in_proj, out_proj, qkv,
-proj, w12, w3 -- everything else is small).
+"""GEMM precision policy and dispatch of the host layer (the large bias-free Linears of the denoiser: in_proj, out_proj, qkv,
+proj, w12, w3 -- everything else is small). Since round 4 the operand-image products below run on this package's own MFMA kernel
+(csrc/gemm_nt_kernel.hpp, native.gemm_nt: `_nt`, `_nt_f16s`, `gated_mlp_hidden_split3`; DIMSUM_GEMM_NT=0 or a shape outside its tiling
+hands them to the library), with the gated GeLU and the block's residual tail as epilogues.
 
   "default"  whatever torch is set to: torch.backends.cuda.matmul.allow_tf32 = True (the reference's own setting,
              dimsum/train.py:20-21) makes hipBLASLt run its split-bf16 path on gfx950 (3 bf16 products per fp32 product,
@@ -11,6 +13,12 @@ proj, w12, w3 -- everything else is small).
              RMS-normalised / gated O(1..1e2) values and the weights O(1e-2), so the model's outputs stay within the
              TF32-class error (~5e-4 relative; tests/test_model_gpu.py::test_fp16_product_gemm_policy) -- but this is a
              weaker guarantee than the default and is therefore never the default nor bench.py's headline.
+  "f16s"     the TF32-equivalent single product (inference): the large Linears take SCALED fp16 operand images
+             (native.F16Image: fp16(row * 2^s) + the exact 2^-s per row, written by the producer kernels with exact row maxima or
+             bound-derived scales), ONE fp16 MFMA product per element, fp32 accumulation, the scales undone in the GEMM epilogue;
+             the attention fusion runs its single-product kernel. 10-bit mantissas like TF32, no range loss by construction:
+             deviation from exact fp32 below an emulated-TF32 run's (tests/test_f16s_gpu.py). Not the default; bench.py reports it
+             as `tf32_single_product_f16s` next to the headline.
   split3     (not a policy: a faster carrier of the "default" policy, inference only) when allow_tf32 is set, a kernel of this
              package that produces the left operand of a Linear can write it as a split-bf16 image (M, 3K) bfloat16
              [hi | hi | lo] (csrc/operand_split.hip, native.split3_rows); `linear_split3` multiplies it with the weight image
@@ -27,10 +35,10 @@ EMA updates, load_state_dict do not bump a tensor's version counter) -- except i
 opens around its NFE loop, where each weight image is built once. Outputs stay fp32."""
 import contextlib
 
+import threading
+
 import torch
 import torch.nn.functional as F
-
-import threading
 
 _policy = "default"
 
