@@ -105,3 +105,28 @@ def test_split3_carrier_is_never_enabled_off_gpu_or_under_autograd():
             assert not gemm.split3_enabled(x, w)                    # CPU tensors
     finally:
         torch.backends.cuda.matmul.allow_tf32 = old
+
+
+def test_gemm_tail_fallback_semantics():
+    """gemm._tail = the unfused form of the GEMM's gate + residual epilogue (what runs when a shape does not fit the kernel's tiling):
+    residual + gate[row // rows_per_batch] * (y + bias), every optional part omitted independently"""
+    import torch
+    from dimsum_amd import gemm
+    g = torch.Generator().manual_seed(0)
+    B, L, N = 3, 5, 8
+    y, res = torch.randn(B * L, N, generator=g), torch.randn(B * L, N, generator=g)
+    bias, gate = torch.randn(N, generator=g), torch.randn(B, N, generator=g)
+    want = res + gate.repeat_interleave(L, 0) * (y + bias)
+    assert torch.allclose(gemm._tail(y, bias, res, gate, L), want)
+    assert torch.allclose(gemm._tail(y, None, res, None, None), res + y)
+    assert torch.allclose(gemm._tail(y, bias, None, None, None), y + bias)
+    assert gemm._tail(y, None, None, None, None) is y
+
+
+def test_f16image_quacks_like_its_tensor():
+    import torch
+    from dimsum_amd.native import F16Image
+    img = F16Image(torch.zeros(2, 6, 8, dtype=torch.float16), torch.ones(2, 6))
+    flat = img.reshape(12, -1)
+    assert tuple(flat.shape) == (12, 8) and tuple(flat.inv.shape) == (12,) and tuple(img.shape) == (2, 6, 8)
+    assert tuple(flat.view(2, 6, 8).inv.shape) == (2, 6) and img.float().shape == (2, 6, 8)
