@@ -242,13 +242,15 @@ def test_tiny_model_fwd_bwd():
 
 @tiny
 @pytest.mark.gpu
-@pytest.mark.parametrize("tf32", [False, True])
+@pytest.mark.parametrize("tf32", [False, True, "f16s"])
 def test_hip_graph_replay_is_bit_identical(tf32, monkeypatch):
     """GraphedForward: the denoiser forward replayed from a captured hipGraph (every libdimsum_hip.so launch recorded on
     the capture stream) returns exactly the eager result, also for new input values and through the Euler sampler -- in exact
     fp32 and under allow_tf32, where the MLP GEMMs run on split operand images whose weight halves are rebuilt inside the graph."""
     import torch
-    monkeypatch.setattr(torch.backends.cuda.matmul, "allow_tf32", tf32)
+    from dimsum_amd import gemm
+    monkeypatch.setattr(torch.backends.cuda.matmul, "allow_tf32", bool(tf32))
+    monkeypatch.setattr(gemm, "_policy", "f16s" if tf32 == "f16s" else "default")      # (the scaled-fp16 images and their scale tensors under capture)
     monkeypatch.setenv("DIMSUM_SPLIT3_MIN_ROWS", "0")          # 4 x 256 rows: below the carrier's default threshold
     from dimsum_amd.hip_graph import GraphedForward
     from dimsum_amd.models_dim import DiM
