@@ -333,10 +333,12 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
     }
 }
 
-// kind NONE with a scaled-fp16 image output: no transform ties tokens together, so ONE WAVE owns a token row (like the norm kernel): the row
-// waits in registers for its exact maximum (6 VALU steps, no LDS, no barrier), 16-byte loads and 8-byte stores of whole rows.
-template <int kPieces>
-__global__ __launch_bounds__(256) void token_rows_f16s_kernel(const dimsum_tt_params_t p) {
+// kind NONE at inference (no reductions): no transform ties tokens together, so ONE WAVE owns a token row (like the norm kernel): whole-row
+// 16-byte loads, and for the scaled-fp16 image the row waits in registers for its exact maximum (6 VALU steps, no LDS, no barrier).
+// kOut: 0 = fp32 y, 1 = split-bf16 image [hi | hi | lo], 2 = scaled-fp16 image + inverse scale. 5.5 TB/s where the 16-tokens-per-workgroup
+// form reaches 4.2-4.8 (tools/bench_token.py).
+template <int kPieces, int kOut>
+__global__ __launch_bounds__(256) void token_rows_kernel(const dimsum_tt_params_t p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C = p.channels, T = p.tokens;
     const int64_t rows = (int64_t)p.batch * T;
@@ -364,15 +366,31 @@ __global__ __launch_bounds__(256) void token_rows_f16s_kernel(const dimsum_tt_pa
                 for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v[i].v[e]));
             }
         }
-        float sc, inv;
-        f16s_scales(wave_allmax(m), sc, inv);
-        __half *y = reinterpret_cast<__half *>(p.y_ptr) + (int64_t)b * p.y_batch_stride + (int64_t)dst * p.y_token_stride;
+        if constexpr (kOut == 2) {
+            float sc, inv;
+            f16s_scales(wave_allmax(m), sc, inv);
+            __half *y = reinterpret_cast<__half *>(p.y_ptr) + (int64_t)b * p.y_batch_stride + (int64_t)dst * p.y_token_stride;
 #pragma unroll
-        for (int i = 0; i < kPieces; ++i) {
-            const int c = (i * 64 + lane) * 4;
-            if (c < C) *reinterpret_cast<uint2 *>(y + c) = f16s_pack4(v[i], sc);
+            for (int i = 0; i < kPieces; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                if (c < C) *reinterpret_cast<uint2 *>(y + c) = f16s_pack4(v[i], sc);
+            }
+            if (lane == 0) reinterpret_cast<float *>(p.y_inv_scale_ptr)[(int64_t)b * T + dst] = inv;
+        } else if constexpr (kOut == 1) {
+            unsigned short *y = reinterpret_cast<unsigned short *>(p.y_ptr) + (int64_t)b * p.y_batch_stride + (int64_t)dst * p.y_token_stride;
+#pragma unroll
+            for (int i = 0; i < kPieces; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                if (c < C) st_split3<true>(y, c, C, v[i]);
+            }
+        } else {
+            float *y = reinterpret_cast<float *>(p.y_ptr) + (int64_t)b * p.y_batch_stride + (int64_t)dst * p.y_token_stride;
+#pragma unroll
+            for (int i = 0; i < kPieces; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                if (c < C) *reinterpret_cast<float4 *>(y + c) = make_float4(v[i].v[0], v[i].v[1], v[i].v[2], v[i].v[3]);
+            }
         }
-        if (lane == 0) reinterpret_cast<float *>(p.y_inv_scale_ptr)[(int64_t)b * T + dst] = inv;
     }
 }
 
@@ -386,18 +404,24 @@ static int launch_tt(const dimsum_tt_params_t &p, hipStream_t s) {
     const dim3 grid(nblk, p.batch), block(blocked ? (cgs <= 64 ? 64 : (cgs <= 128 ? 128 : kTTThreads)) : kTTThreads);
     size_t lds = (p.kind == DIMSUM_TT_HAAR_FWD || p.kind == DIMSUM_TT_HAAR_INV) ? (size_t)((p.channels + 3) / 4) * 68 * 4 : 0;
     if (lds > 160 * 1024) return DIMSUM_ERR_SHAPE;
-    if (p.y_split3 == 2 && p.kind == DIMSUM_TT_NONE) {
+    // kind NONE without reductions (every inference token pass outside the frequency branch): one wave per token row
+    if (p.kind == DIMSUM_TT_NONE && p.y_ptr && !p.w_ptr && !p.tsum_ptr && p.channels <= 2048) {
         if constexpr (VEC == 4) {
             const int64_t rows = (int64_t)p.batch * p.tokens;
             int64_t blocks = (rows + 3) / 4;
             if (blocks > 256 * 16) blocks = 256 * 16;
             const dim3 g1((unsigned)blocks), b1(256);
-            if (p.channels <= 512) hipLaunchKernelGGL(token_rows_f16s_kernel<2>, g1, b1, 0, s, p);
-            else if (p.channels <= 1024) hipLaunchKernelGGL(token_rows_f16s_kernel<4>, g1, b1, 0, s, p);
-            else hipLaunchKernelGGL(token_rows_f16s_kernel<8>, g1, b1, 0, s, p);
+#define DIMSUM_TTR(O)                                                                                    \
+            if (p.channels <= 512) hipLaunchKernelGGL((token_rows_kernel<2, O>), g1, b1, 0, s, p);          \
+            else if (p.channels <= 1024) hipLaunchKernelGGL((token_rows_kernel<4, O>), g1, b1, 0, s, p);    \
+            else hipLaunchKernelGGL((token_rows_kernel<8, O>), g1, b1, 0, s, p)
+            if (p.y_split3 == 2) { DIMSUM_TTR(2); }
+            else if (p.y_split3) { DIMSUM_TTR(1); }
+            else { DIMSUM_TTR(0); }
+#undef DIMSUM_TTR
             return launch_status();
         }
-        return DIMSUM_ERR_STRIDE;
+        if (p.y_split3 == 2) return DIMSUM_ERR_STRIDE;
     }
     if (p.y_split3 == 2) {
         if constexpr (VEC == 4) {
