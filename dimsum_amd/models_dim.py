@@ -196,9 +196,11 @@ class Attention(nn.Module):
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
         self.proj = nn.Linear(dim, dim)
 
-    def forward_deferred(self, x, x3=None):
+    def forward_deferred(self, x, x3=None, residual=None, gate=None):
         """-> (y, b): the module's output is y + b (proj's bias is left to the caller's fused residual pass).
-        x3: x as a split-bf16 operand image written by the caller's norm kernel (gemm.py, split3); x then only carries the shape."""
+        x3: x as a split-bf16 operand image written by the caller's norm kernel (gemm.py, split3); x then only carries the shape.
+        residual (B, N, C) [, gate (B, C)] (with x3 on the MFMA attention kernels): the block's residual tail rides in the proj GEMM's
+        epilogue -- the call returns (residual + gate * (attn(x) + b), None)."""
         from . import native
         from .attention_fusion import _XattnCoreFn
         B, N, C = x.shape
@@ -210,8 +212,12 @@ class Attention(nn.Module):
                 if isinstance(x3, native.F16Image) and C % 8 == 0:         # scaled-fp16 policy: the single-product attention kernel
                     o3 = native.xattn_fusion_fwd(qkv, None, self.num_heads, bias1=qb, split3="f16s",
                                                  f16s=(x3.inv.reshape(B, N), None, gemm.attn_kv_bound(self.qkv.weight, self.qkv.bias)))
-                    return gemm.linear_split3(o3.reshape(B * N, -1), self.proj.weight).view(B, N, C), self.proj.bias
-                o3 = native.xattn_fusion_fwd(qkv, None, self.num_heads, bias1=qb, split_bf16=True, split3=True)
+                else:
+                    o3 = native.xattn_fusion_fwd(qkv, None, self.num_heads, bias1=qb, split_bf16=True, split3=True)
+                if residual is not None:
+                    pb = None if self.proj.bias is None else self.proj.bias.float()
+                    y = gemm.linear_split3(o3.reshape(B * N, -1), self.proj.weight, bias=pb, residual=residual.reshape(B * N, C), gate=gate, rows_per_batch=N)
+                    return y.view(B, N, C), None
                 return gemm.linear_split3(o3.reshape(B * N, -1), self.proj.weight).view(B, N, C), self.proj.bias
         else:
             qkv = gemm.linear(x, self.qkv.weight)                     # bias-free GEMM (fast hipBLASLt path)
@@ -548,11 +554,15 @@ class DiTBlock(nn.Module):
         sa, ca, ga, sm, cm, gm = self.adaLN_modulation(c).chunk(6, dim=1)
         s3 = gemm.split3_enabled(x, self.attn.qkv.weight, producer="norm")      # inference under allow_tf32: the norm passes write operand images
         h = _ln_modulate(self.norm1, x, sa, ca, split3=s3)
-        if h is not None and s3:
-            a, ab = self.attn.forward_deferred(x, x3=h)
+        from . import native
+        if h is not None and s3 and x.is_contiguous() and native.xattn_supported(x, self.attn.head_dim):
+            x = self.attn.forward_deferred(x, x3=h, residual=x, gate=ga)[0]      # "x + gate_msa * attn(..)" in the proj GEMM's epilogue
         else:
-            a, ab = self.attn.forward_deferred(token_ops.pre_mixer(self.norm1(x), "none", None, sa, ca) if h is None else h)
-        x = token_ops.gate_residual(x, a, ga, ab)
+            if h is not None and s3:
+                a, ab = self.attn.forward_deferred(x, x3=h)
+            else:
+                a, ab = self.attn.forward_deferred(token_ops.pre_mixer(self.norm1(x), "none", None, sa, ca) if h is None else h)
+            x = token_ops.gate_residual(x, a, ga, ab)
         s3 = getattr(self.mlp, "_fused", False) and s3        # (keeps the mode: False / True / "f16s")
         h = _ln_modulate(self.norm2, x, sm, cm, split3=s3)
         if h is None:
