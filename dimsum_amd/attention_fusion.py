@@ -69,10 +69,11 @@ class CrossAttentionFusion(nn.Module):
         """whether forward_deferred(images=True) is served: the plain variant on the MFMA kernels, no dropout (ref: an fp32 activation)"""
         return self._plain and not (self.training and (self.attn_drop.p > 0.0 or self.proj_drop.p > 0.0)) and native.xattn_supported(ref, self.head_dim)
 
-    def forward_deferred(self, x1, x2, images=False):
+    def forward_deferred(self, x1, x2, images=False, residual=None):
         """-> (y, b): the module's output is y + b; b (proj's bias) is left to the caller's fused residual pass.
         images (inference under allow_tf32, see takes_images): x1 / x2 are split-bf16 operand images (B, N, 3 C) written by the
-        branches' last pass; qkv and proj run as plain bf16 GEMMs over them and the attention kernel writes proj's image."""
+        branches' last pass; qkv and proj run as plain bf16 GEMMs over them and the attention kernel writes proj's image.
+        residual (B, N, dim), with images: "hidden + proj(...) + b" in the proj GEMM's epilogue -- the call returns (that sum, None)."""
         if images:
             B, N, C3 = x1.shape
             b1, b2 = self.qkv1.bias, self.qkv2.bias
@@ -85,9 +86,13 @@ class CrossAttentionFusion(nn.Module):
                 f3 = native.xattn_fusion_fwd(qkv1, qkv2, self.num_heads, bias1=None if b1 is None else b1.float().contiguous(),
                                              bias2=None if b2 is None else b2.float().contiguous(), split3="f16s",
                                              f16s=(x1.inv.reshape(B, N), x2.inv.reshape(B, N), gemm.attn_kv_bound(self.qkv1.weight, b1, self.qkv2.weight, b2)))
-                return gemm.linear_split3(f3.reshape(B * N, -1), self.proj.weight).view(B, N, -1), self.proj.bias
-            f3 = native.xattn_fusion_fwd(qkv1, qkv2, self.num_heads, bias1=None if b1 is None else b1.float().contiguous(),
-                                         bias2=None if b2 is None else b2.float().contiguous(), split_bf16=True, split3=True)
+            else:
+                f3 = native.xattn_fusion_fwd(qkv1, qkv2, self.num_heads, bias1=None if b1 is None else b1.float().contiguous(),
+                                             bias2=None if b2 is None else b2.float().contiguous(), split_bf16=True, split3=True)
+            if residual is not None:
+                pb = None if self.proj.bias is None else self.proj.bias.float()
+                y = gemm.linear_split3(f3.reshape(B * N, -1), self.proj.weight, bias=pb, residual=residual.reshape(B * N, -1))
+                return y.view(residual.shape), None
             return gemm.linear_split3(f3.reshape(B * N, -1), self.proj.weight).view(B, N, -1), self.proj.bias
         B, N, C = x1.shape
         drop = self.attn_drop.p if self.training else 0.0

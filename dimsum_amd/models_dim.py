@@ -487,16 +487,20 @@ class _CombinedBase(_BlockBase):
             x1, _ = self.spatial_mamba(x1, None, c, inference_params, **kw)
             x2, _ = self.freq_mamba(x2, None, c, inference_params, **kw)
         # residual tails as single fused passes; the Linear biases ride along (mlp.py / attention_fusion.py docstrings)
-        fused, pb = self.proj.forward_deferred(x1, x2, **({"images": True} if img else {}))
+        fast_tail = (not torch.is_grad_enabled() and isinstance(self.norm_2, RMSNorm) and hasattr(self.mlp, "forward_deferred")
+                     and hidden_states.dtype == torch.float32)
+        # (inference on operand images: "h + proj(..) + b" already in the proj GEMM's epilogue, the norm pass then reads ONE tensor)
+        in_epilogue = bool(img) and fast_tail and hidden_states.is_contiguous()
+        fused, pb = self.proj.forward_deferred(x1, x2, **({"images": True} if img else {}), **({"residual": hidden_states} if in_epilogue else {}))
         shift, scale, gate = self.adaLN_modulation(c).chunk(3, dim=1)
-        if not torch.is_grad_enabled() and isinstance(self.norm_2, RMSNorm) and hasattr(self.mlp, "forward_deferred") and hidden_states.dtype == torch.float32:
+        if fast_tail:
             # inference: h' = h + proj(..) + b, RMSNorm(h'), modulate -- ONE pass (csrc/norm.hip with x_bias + modulation)
             from . import native
             B, L, H = hidden_states.shape
             # ... written directly as the split-bf16 operand image of the w12 GEMM when the library would split it anyway (gemm.py)
             s3 = getattr(self.mlp, "_fused", False) and gemm.split3_enabled(hidden_states, self.mlp.w12.weight, producer="norm")   # False / True / "f16s"
             y, _, _, hnew = native.layer_norm_fwd(fused.reshape(B * L, H), self.norm_2.weight, self.norm_2.bias, self.norm_2.eps,
-                                                  residual=hidden_states.reshape(B * L, H), is_rms_norm=True, x_bias=pb,
+                                                  residual=None if in_epilogue else hidden_states.reshape(B * L, H), is_rms_norm=True, x_bias=pb,
                                                   mod_scale=scale, mod_shift=shift, rows_per_batch=L, **({"split3": s3} if s3 else {}))
             if s3 and hnew.is_contiguous():       # ... and the residual tail "h + gate * (mlp + b)" in the epilogue of the w3 GEMM
                 return self.mlp.forward_deferred(hidden_states, x3=y, residual=hnew.view(B, L, H), gate=gate)[0], residual
