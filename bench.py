@@ -165,9 +165,12 @@ class ScanTimer:
             for e in json.load(open(prof)).get("entries", []):
                 if tuple(e.get("shape_BDLN", ())) == shape and e.get("bench_kernel") == kernel:
                     traffic = e.get("hbm_bytes_per_launch")
-        return {"kernel": kernel, "shape_BDLN": list(shape), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": avg_ms,
-                "launches_timed": len(rs)}
+        rf = {"kernel": kernel, "shape_BDLN": list(shape), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+              "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": avg_ms,
+              "launches_timed": len(rs)}
+        if _BOX:
+            rf["frac_of_box_copy"] = achieved / _BOX["copy_GBps"]
+        return rf
 
 
 def build_model(name, device, image_size=256, scan_type="none"):
@@ -276,6 +279,7 @@ class Bench:
         _lib.load()                                   # fail loudly if the HIP library is missing
         self.timer = ScanTimer()
         self.timer.install()
+        box_probe(self.dev)
 
     @staticmethod
     def set_matmul(policy):
@@ -513,6 +517,33 @@ class Bench:
         return out
 
 
+_BOX = {}
+
+
+def box_probe(dev):
+    """This box's own memory system, measured in THIS process (boxes of the pool differ by 7-10 % on memory-bound kernels): a 1-GiB
+    device copy (read + write) and a 3-stream add, GB/s by HIP events. Every roofline object carries `frac_of_box_copy` next to
+    `frac`, so a fraction quoted on one box can be compared with one quoted on another."""
+    if not _BOX:
+        n = 1 << 28
+        a, b2 = torch.empty(n, device=dev), torch.empty(n, device=dev)
+        c = torch.empty(n, device=dev)
+        a.normal_(); b2.normal_()
+        def ev(fn, reps=10):
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+        _BOX.update(copy_GBps=2 * 4 * n / (ev(lambda: c.copy_(a)) * 1e-3) / 1e9, add_GBps=3 * 4 * n / (ev(lambda: torch.add(a, b2, out=c)) * 1e-3) / 1e9,
+                    what="torch copy_ / add(out=) over 1 GiB fp32 operands, HIP events, this process, before the legs")
+        del a, b2, c
+        torch.cuda.empty_cache()
+    return _BOX
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -583,6 +614,7 @@ def main():
                 "data": "synthetic",
                 "config": {"workload": head["workload"], "global_batch": head["batch_per_gpu"] * world,
                            "parallelism": f"dp{world} (replicas, independent latents)", "launch": head.get("launch", "eager"), "matmul_policy": policy},
+                "box": dict(_BOX),
                 "dist": {"world_size": dist.get_world_size() if world > 1 else 1,
                          "backend": (dist.get_backend() + " (RCCL)") if world > 1 else "none (single process)"}}
         for k in ("roofline", "roofline_bwd", "fp32_exact_matmul", "tf32_single_product_f16s", "fp16_operand_matmul_optin", "nfe", "s_per_batch", "gathered_shape", "finite"):

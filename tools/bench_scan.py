@@ -92,11 +92,22 @@ def main():
     torch.cuda.synchronize()
     ms = sorted(s.elapsed_time(e) for s, e in evs)
     med = ms[len(ms) // 2]
+    # this box's own copy bandwidth, same process (fractions normalised per box)
+    ca, cb = torch.empty(1 << 28, device="cuda"), torch.empty(1 << 28, device="cuda")
+    cb.copy_(ca)
+    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    c0.record()
+    for _ in range(5):
+        cb.copy_(ca)
+    c1.record()
+    torch.cuda.synchronize()
+    copy_gbps = 5 * 2 * 4 * (1 << 28) / (c0.elapsed_time(c1) * 1e-3) / 1e9
     P = _lib.SsmParams()
     P.batch, P.dim, P.seqlen, P.dstate, P.n_groups, P.n_chunks = B, D, L, N, 1, (L + 2047) // 2048
     P.kernel_variant = native._scan_fwd_variant
     print(json.dumps({"kernel": "bwd" if a.bwd else "fwd", "fwd_variant": _lib.load().dimsum_ssm_scan_fwd_variant(P), "shape": [B, D, L, N], "dtype": a.dtype, "ms_median": med, "ms_min": ms[0], "algorithmic_GB": nbytes / 1e9,
-                      "GBps": nbytes / med / 1e6, "frac_of_8TBps": nbytes / med / 1e6 / 8000}))
+                      "GBps": nbytes / med / 1e6, "frac_of_8TBps": nbytes / med / 1e6 / 8000,
+                      "box_copy_GBps": copy_gbps, "frac_of_box_copy": nbytes / med / 1e6 / copy_gbps, "timed_by": "HIP events, this process"}))
 
 
 if __name__ == "__main__":
