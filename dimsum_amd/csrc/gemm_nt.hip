@@ -108,6 +108,14 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
             a.gate_bound = reinterpret_cast<const float *>(p->gate_bound_ptr);
             a.inv_out = reinterpret_cast<float *>(p->h_inv_scale_ptr);
         }
+        if (p->x12_ptr) {       // training forward: keep the fp32 [x1 | x2] for the backward (split-bf16 images only)
+            if (!img || !bf || a.sa) return DIMSUM_ERR_UNSUPPORTED;
+            if (p->x12_ld % 4 != 0 || p->x12_ld < p->n || !aligned_to<char>(p->x12_ptr, 16) || (int64_t)257 * p->x12_ld * 4 + (int64_t)p->n * 4 >= ((int64_t)1 << 31))
+                return DIMSUM_ERR_STRIDE;
+            a.x12 = reinterpret_cast<float *>(p->x12_ptr);
+            a.ldx = p->x12_ld;
+            return launch<kOpBf16, kEpiGatedSplit3, kVarKeepX12>(a, s, e0, e1);
+        }
         if (img) return bf ? launch<kOpBf16, kEpiGatedSplit3>(a, s, e0, e1) : launch<kOpF16, kEpiGatedSplit3>(a, s, e0, e1);
         return bf ? launch<kOpBf16, kEpiGatedF16>(a, s, e0, e1) : launch<kOpF16, kEpiGatedF16>(a, s, e0, e1);
     }

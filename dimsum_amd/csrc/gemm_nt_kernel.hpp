@@ -64,9 +64,11 @@ struct Args {
     int tiles_m, tiles_n;
     float out_scale;               // kEpiGatedF16: h is stored as fp16(h * out_scale)
     int group_m;                   // tile rows per group of the tile order (L2 patch shape)
+    float *x12;                    // kVarKeepX12 (gated epilogues, training): the bias-free fp32 (M, 2 F) [x1 | x2] is stored as well
+    int64_t ldx;
 };
 // tuning variants (bit mask; 0 = the shipped schedule)
-enum { kVarLgkmAfterBarrier = 1, kVarNoEpilogue = 2, kVarNtStores = 4, kVarFullLineStores = 8, kVarNoSetprio = 16, kVarSc1Stores = 32, kVarSc0Stores = 64 };
+enum { kVarLgkmAfterBarrier = 1, kVarNoEpilogue = 2, kVarNtStores = 4, kVarFullLineStores = 8, kVarNoSetprio = 16, kVarSc1Stores = 32, kVarSc0Stores = 64, kVarKeepX12 = 128 };
 
 __device__ __forceinline__ float dpp_row_ror8(float x) {      // lane l <- lane l ^ 8 (rotation by 8 inside each row of 16 lanes)
     const int v = __builtin_bit_cast(int, x);                  // (old = the source: with a constant `old` hipcc 7.2 merges the calls of an unrolled loop)
@@ -413,6 +415,37 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
                     }
                 }
             }
+        if constexpr ((kVar & kVarKeepX12) != 0) {
+            // training forward: the backward's gated-GeLU adjoint needs x1, x2 -- stored from the accumulators (128-byte row segments, the
+            // F32 epilogue's lane exchange) instead of a plain GEMM + a gate pass that reads them back (2.1 GB at 65536 x 8192)
+            float *Xt = p.x12 + (int64_t)m0 * p.ldx + n0;
+            const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(Xt, 0, 0x7fffffff, 0x00020000);
+            const bool up = (lane & 8) != 0;
+            const int frow = wr * 64 + (lane & 7);
+            const int fcol = wc * 32 + (lane >> 4) * 4 + (up ? 16 : 0);
+            const bool xlive = n0 + fcol < p.N;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f4 x0 = acc[mi][ni][i][0], x1 = acc[mi][ni][i][1];
+                        f4 s0, s1;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float r0 = dpp_row_ror8(x0[e]), r1 = dpp_row_ror8(x1[e]);
+                            s0[e] = up ? r1 : x0[e];
+                            s1[e] = up ? x1[e] : r0;
+                        }
+                        const int lrow = frow + mi * 128 + i * 16;
+                        const unsigned voff = (unsigned)((lrow * p.ldx + ni * p.N + fcol) * 4);
+                        if (xlive) {
+                            store_f4<2>(xrsrc, voff, s0);
+                            store_f4<2>(xrsrc, voff + (unsigned)(8 * p.ldx * 4), s1);
+                        }
+                    }
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + ecol + j * 16;

@@ -34,7 +34,7 @@ class _ModGatedMlpImagesFn(torch.autograd.Function):
     """m = w3(gated_gelu(w12(modulate(normed, shift, scale)) + b12))  WITHOUT w3's bias, training, with every GEMM of the forward
     and the backward on split-bf16 operand images (gemm.py, split3):
         forward : h3 = image(modulate(normed))   [token_transform y_split3]      x12 = h3 . W12img^T
-                  g3 = image(gelu(x12a + b) (x12g + b))  [gated GeLU split3]      m = g3 . W3img^T
+                  g3 = image(gelu(x12a + b) (x12g + b))  [the GEMM's epilogue]    m = g3 . W3img^T
         backward: dm_w = image_w(dm)                                              dg = dm_w . (W3^T)img^T      dW3 = dm_w^T . g3
                   dx12_w = image_w(gated GeLU backward)  [one pass]               dh = dx12_w . (W12^T)img^T   dW12 = dx12_w^T . h3
                   d normed / d shift / d scale: the pre-mixer adjoints (ops/token_ops.py)
@@ -49,9 +49,8 @@ class _ModGatedMlpImagesFn(torch.autograd.Function):
         M = B * L
         normed = normed if normed.stride(-1) == 1 else normed.contiguous()
         h3 = native.token_transform(normed, "none", True, scale=scale, shift=shift, split3=True)          # (B, L, 3H)
-        x12 = gemm.linear_split3(h3.view(M, 3 * H), w12)                                                   # (M, 2F) fp32
         b12f = None if b12 is None else b12.float()
-        g3 = native.gated_gelu_fwd(x12, b12f, split3=True)                                                 # (M, 3F)
+        g3, x12 = gemm.gated_mlp_hidden_split3_train(h3.view(M, 3 * H), w12, b12f)                         # (M, 3F) image, (M, 2F) fp32
         m = gemm.linear_split3(g3, w3)                                                                     # (M, H)
         ctx.save_for_backward(normed, scale, h3, x12, g3, w12, b12f, w3)
         return m.view(B, L, w3.shape[0])

@@ -529,12 +529,13 @@ def gemm_nt_supported(a, b, gated=False):
 
 
 def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=None, tune=None, scales=None, gate_bound=None, residual=None,
-            gate=None, rows_per_batch=None):
+            gate=None, rows_per_batch=None, keep_x12=False):
     """a (M, K) @ b (N, K)^T on the hand-written MFMA kernel, 16-bit operands (bfloat16: split-bf16 images over 3 K; float16: scaled rows),
     fp32 accumulation.
       epilogue "f32"          -> (M, N) float32 (+ bias[N])
                "gated_split3" -> b = the (2F, K) w12 weight image, bias (2F) or None: the LEFT split-bf16 image (M, 3F) bfloat16 of
                                  gelu_tanh(x1 + b1) * (x2 + b2)   (mlp.py:66-70; the fp32 (M, 2F) x12 never exists)
+                                 keep_x12 (training forward): the bias-free float32 (M, 2F) [x1 | x2] is stored too -> (image, x12)
                "gated_f16"    -> same, (M, F) float16 of h * out_scale
     residual (M, N) float32 [, gate (M / rows_per_batch, N) float32]: epilogue "f32" becomes residual + gate[row // rows_per_batch] * (a b^T + bias)
     -- the residual tail of a block in the epilogue of its last Linear (rows_per_batch % 256 == 0).
@@ -595,12 +596,19 @@ def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=Non
             h_inv = torch.empty((M,), device=a.device, dtype=torch.float32)
             P.gate_bound_ptr, P.h_inv_scale_ptr = _ptr(gate_bound), _ptr(h_inv)
     P.a_ptr, P.b_ptr, P.bias_ptr, P.c_ptr = _ptr(a), _ptr(b), _ptr(bias), _ptr(out)
+    x12 = None
+    if keep_x12:
+        _check(epilogue == "gated_split3" and a.dtype == torch.bfloat16 and scales is None, "gemm_nt: keep_x12 goes with the gated_split3 epilogue over bf16 images")
+        x12 = torch.empty((M, N), device=a.device, dtype=torch.float32)
+        P.x12_ptr, P.x12_ld = _ptr(x12), N
     if events is not None:
         P.timing_start_event, P.timing_stop_event = events
     if tune is not None:
         P.tune_variant, P.tune_group_m = tune[:2]
     with torch.cuda.device(a.device):
         _lib.check(_lib.load().dimsum_gemm_nt(P, _stream(a)), "gemm_nt")
+    if x12 is not None:
+        return out, x12
     return out if h_inv is None else F16Image(out, h_inv)
 
 

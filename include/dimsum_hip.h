@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DIMSUM_ABI_VERSION 11
+#define DIMSUM_ABI_VERSION 12
 
 typedef enum {
     DIMSUM_OK = 0,
@@ -395,6 +395,11 @@ typedef struct {
     const void *residual_ptr, *gate_ptr;
     int64_t residual_ld, gate_ld;
     int32_t rows_per_batch;
+    /* GATED_GELU_SPLIT3, training forward (mlp.py:66-70 under autograd): when non-NULL the bias-free accumulators [x1 | x2] are ALSO stored
+       as float32 (m, n) rows with stride x12_ld -- what the gated-GeLU adjoint of the backward reads; bf16 images only. */
+    int32_t reserved0;
+    void *x12_ptr;
+    int64_t x12_ld;
 } dimsum_gemm_params_t;
 
 int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream);

@@ -78,6 +78,11 @@ def test_gated_gelu_epilogues(M, F, H, with_bias):
     unf = native.gated_gelu_fwd(torch.mm(x3, w3.t(), out_dtype=torch.float32), bias, split3=True)
     uerr = ((unf[:, :F].double() + unf[:, 2 * F:].double()) - ref).abs().max().item() / scale
     assert err < 2e-5 and err < 1.5 * uerr + 1e-6, (err, uerr)
+    # training forward: the same image, bit for bit, plus the bias-free accumulators [x1 | x2] the backward's adjoint reads
+    got2, kept = native.gemm_nt(x3, w3, bias=bias, epilogue="gated_split3", keep_x12=True)
+    assert torch.equal(got2, got)
+    assert kept.shape == (M, 2 * F) and kept.dtype == torch.float32
+    assert torch.equal(kept, native.gemm_nt(x3, w3))
     x16, w16 = x.half(), w12.half()
     g16 = native.gemm_nt(x16, w16, bias=bias, epilogue="gated_f16", out_scale=8.0)
     x12h = x16.double() @ w16.double().t() + (0 if bias is None else bias.double())
