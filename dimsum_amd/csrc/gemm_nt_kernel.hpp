@@ -28,6 +28,15 @@
 //    CONSECUTIVE output columns of one row (16-B fp32 / 8-B 16-bit stores), and the two weight halves B0 / B1 can be two different
 //    row ranges of the weight: with B0 = W12[c .. c+128) and B1 = W12[F + c ..) a lane holds x1 and x2 of the same output element
 //    in acc[.][0] and acc[.][1] -- the gated GeLU of dimsum/mlp.py:66-70 is a per-register epilogue.
+//
+// TN variant (kVarTN, the weight-gradient shape dW = dY^T X of a Linear: C (P, Q) = sum_r A[r, p] B[r, q], both operands stored as rows over
+// the REDUCTION index -- dimsum/mlp.py's w12 / w3, attention_fusion.py's qkv / proj under autograd): same tiles, phases and epilogue; a half
+// tile is [64 r][128 columns] (256 B per row, 16 KB), filled by the same two DMA pieces per wave (4 rows each), and an MFMA operand
+// (16 columns x 32 r) is assembled by two ds_read_b64_tr_b16 -- the hardware transpose read hands lane (t = l & 15, g = l >> 4) the four
+// rows 4 g .. 4 g + 3 of column t from the 8-byte pieces its 16-lane group addresses (tools/ubench/tr_read.hip prints the mapping). The
+// r order inside an MFMA differs from the NT kernel's; both operands use the same one, which is all a dot product needs. The 32-byte
+// pair u of row r sits at u ^ (r & 7): the 8 rows a 32-lane half of the read touches land in 8 distinct bank ranges. A launch may
+// split the reduction (grid = tiles x splits, partial results `c_split_stride` apart: the host adds them in a fixed order).
 #pragma once
 #include "common.hpp"
 
@@ -38,6 +47,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
@@ -66,9 +76,11 @@ struct Args {
     int group_m;                   // tile rows per group of the tile order (L2 patch shape)
     float *x12;                    // kVarKeepX12 (gated epilogues, training): the bias-free fp32 (M, 2 F) [x1 | x2] is stored as well
     int64_t ldx;
+    int splits;                    // kVarTN: the reduction is cut into `splits` ranges of K rows each (K = rows per range)
+    int64_t c_split_stride;        // elements between the partial results
 };
 // tuning variants (bit mask; 0 = the shipped schedule)
-enum { kVarLgkmAfterBarrier = 1, kVarNoEpilogue = 2, kVarNtStores = 4, kVarFullLineStores = 8, kVarNoSetprio = 16, kVarSc1Stores = 32, kVarSc0Stores = 64, kVarKeepX12 = 128 };
+enum { kVarLgkmAfterBarrier = 1, kVarNoEpilogue = 2, kVarNtStores = 4, kVarFullLineStores = 8, kVarNoSetprio = 16, kVarSc1Stores = 32, kVarSc0Stores = 64, kVarKeepX12 = 128, kVarTN = 256 };
 
 __device__ __forceinline__ float dpp_row_ror8(float x) {      // lane l <- lane l ^ 8 (rotation by 8 inside each row of 16 lanes)
     const int v = __builtin_bit_cast(int, x);                  // (old = the source: with a constant `old` hipcc 7.2 merges the calls of an unrolled loop)
@@ -84,6 +96,7 @@ template <int kOp> __device__ __forceinline__ f4 mma(const u32x4 &a, const u32x4
 }
 
 #define DIMSUM_DS_READ_B128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+#define DIMSUM_DS_READ_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
 #define DIMSUM_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define DIMSUM_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
@@ -104,11 +117,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
     // ---- block -> tile: every XCD (block b runs on XCD b % 8) walks a contiguous range of the tile list, ordered in groups of 8 tile
     // rows (consecutive tiles walk down the rows of a group, then to the next tile column): the 32 workgroups an XCD runs at a time
     // form an 8 x 4 patch that shares its A and B panels through that XCD's L2.
-    int tile_m, tile_n;
+    constexpr bool kTN = (kVar & kVarTN) != 0;
+    static_assert(!kTN || kEpi == kEpiF32, "the TN variant has the plain fp32 epilogue");
+    int tile_m, tile_n, split = 0;
     {
         const int nwg = gridDim.x, bid = blockIdx.x;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        if constexpr (kTN) {       // (the splits of one tile are `tiles` apart in the list: they run at the same time on different XCDs' ranges)
+            const int tiles = p.tiles_m * p.tiles_n;
+            split = t / tiles;
+            t -= split * tiles;
+        }
         const int GM = p.group_m;
         const int per_group = GM * p.tiles_n;
         const int g = t / per_group, within = t - g * per_group;
@@ -143,6 +163,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
     const char *a_base = p.A + (int64_t)m0 * p.lda * 2;
     const int64_t a_half = (int64_t)128 * p.lda * 2;
 
+    // TN: wave w fills rows 8 w .. 8 w + 7 of every half tile (two pieces of 4 rows x 256 B); lane l -> row l >> 4 of the piece, 16-byte
+    // slot l & 15, which holds the source chunk whose 32-byte pair index is (slot >> 1) ^ (row & 7)
+    unsigned tn_voff_a[2], tn_voff_b[2];
+    const char *tn_a = nullptr, *tn_b = nullptr;
+    int64_t tn_a_tile = 0, tn_b_tile = 0;
+    if constexpr (kTN) {
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+            const int row = w * 8 + pc * 4 + (lane >> 4), key = pc * 4 + (lane >> 4);
+            const int chunk = ((((lane & 15) >> 1) ^ key) << 1) | (lane & 1);
+            tn_voff_a[pc] = (unsigned)(row * p.lda * 2 + chunk * 16);
+            tn_voff_b[pc] = (unsigned)(row * p.ldb * 2 + chunk * 16);
+        }
+        tn_a = p.A + ((int64_t)split * p.K * p.lda + m0) * 2;
+        tn_b = p.B0 + ((int64_t)split * p.K * p.ldb + n0) * 2;
+        tn_a_tile = (int64_t)kBK * p.lda * 2;
+        tn_b_tile = (int64_t)kBK * p.ldb * 2;
+    }
     // stage(kind, kt): the two DMA pieces (k halves) of this wave's row block of half tile `kind` of K tile kt
     const unsigned st_lds = lds0 + w * 2048;
     auto stage = [&](int slot, const char *base, unsigned voff, int kt) {      // base: wave-uniform (SGPR pair), voff: this lane's byte offset
@@ -151,15 +189,32 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
         __builtin_amdgcn_global_load_lds((glb_void_t *)(s + voff), (lds_void_t *)(uintptr_t)dst, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((glb_void_t *)(s + 64 + voff), (lds_void_t *)(uintptr_t)(dst + 1024), 16, 0, 0);
     };
-    auto stage_a0 = [&](int kt) { stage(kSlotA0, a_base, a_voff, kt); };
-    auto stage_a1 = [&](int kt) { stage(kSlotA1, a_base + a_half, a_voff, kt); };
-    auto stage_b0 = [&](int kt) { stage(kSlotB0, b_base[0], b_voff[0], kt); };
-    auto stage_b1 = [&](int kt) { stage(kSlotB1, b_base[1], b_voff[1], kt); };
+    auto stage_tn = [&](int slot, const char *base, int64_t tile_bytes, const unsigned (&voff)[2], int kt) {
+        const unsigned dst = st_lds + (kt & 1) * kParity + slot;
+        const char *s = base + (int64_t)kt * tile_bytes;
+        __builtin_amdgcn_global_load_lds((glb_void_t *)(s + voff[0]), (lds_void_t *)(uintptr_t)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void_t *)(s + voff[1]), (lds_void_t *)(uintptr_t)(dst + 1024), 16, 0, 0);
+    };
+    auto stage_a0 = [&](int kt) { if constexpr (kTN) stage_tn(kSlotA0, tn_a, tn_a_tile, tn_voff_a, kt); else stage(kSlotA0, a_base, a_voff, kt); };
+    auto stage_a1 = [&](int kt) { if constexpr (kTN) stage_tn(kSlotA1, tn_a + 256, tn_a_tile, tn_voff_a, kt); else stage(kSlotA1, a_base + a_half, a_voff, kt); };
+    auto stage_b0 = [&](int kt) { if constexpr (kTN) stage_tn(kSlotB0, tn_b, tn_b_tile, tn_voff_b, kt); else stage(kSlotB0, b_base[0], b_voff[0], kt); };
+    auto stage_b1 = [&](int kt) { if constexpr (kTN) stage_tn(kSlotB1, tn_b + 256, tn_b_tile, tn_voff_b, kt); else stage(kSlotB1, b_base[1], b_voff[1], kt); };
 
     // ---- operand read addresses: lane l reads row l & 15, k chunk l >> 4 of a subtile (swizzled: rows 8-15 swap chunk pairs)
     const unsigned rd = (unsigned)((lane & 15) * 64 + (((lane >> 4) ^ (((lane >> 3) & 1) << 1)) * 16));
     const unsigned a_rd = lds0 + wr * 4 * 2048 + rd;       // + slot A0 / A1, + i * 2048 (row block), + kh * 1024
     const unsigned b_rd = lds0 + wc * 2 * 2048 + rd;       // + slot B0 / B1, + j * 2048, + kh * 1024
+
+    // TN: lane (t, g) addresses row 4 g + (t >> 2) of a 16-row block, 8 bytes at (t & 3) * 8 of the 32-byte pair (column block ^ key)
+    unsigned a_rd_tn[4], b_rd_tn[2];
+    if constexpr (kTN) {
+        const int t = lane & 15, g = lane >> 4, key = ((g & 1) << 2) | (t >> 2);
+        const unsigned base = lds0 + (unsigned)((4 * g + (t >> 2)) * 256 + (t & 3) * 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_rd_tn[i] = base + (unsigned)(((wr * 4 + i) ^ key) << 5);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b_rd_tn[j] = base + (unsigned)(((wc * 2 + j) ^ key) << 5);
+    }
 
     u32x4 a0[4][2], a1[4][2], b0[2][2], b1[2][2];
     f4 acc[2][2][4][2];
@@ -172,8 +227,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[mi][ni][i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
+    // one TN operand fragment: rows kh * 32 + [0, 16) and + [16, 32) of the K tile
+#define DIMSUM_READ_TN1(dst, addr, slot, kh)                                               \
+    do {                                                                                   \
+        u32x2 lo_, hi_;                                                                    \
+        DIMSUM_DS_READ_TR(lo_, addr, (slot) + (kh) * 8192);                                \
+        DIMSUM_DS_READ_TR(hi_, addr, (slot) + (kh) * 8192 + 4096);                         \
+        dst = u32x4{lo_[0], lo_[1], hi_[0], hi_[1]};                                       \
+    } while (0)
 #define DIMSUM_READ_A(dst, slot, par)                                                      \
     do {                                                                                   \
+        if constexpr (kTN) {                                                               \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                             \
+                const unsigned ad_ = a_rd_tn[i_] + (par);                                  \
+                DIMSUM_READ_TN1(dst[i_][0], ad_, slot, 0);                                 \
+                DIMSUM_READ_TN1(dst[i_][1], ad_, slot, 1);                                 \
+            }                                                                              \
+            break;                                                                         \
+        }                                                                                  \
         const unsigned ad_ = a_rd + (par);                                                 \
         DIMSUM_DS_READ_B128(dst[0][0], ad_, (slot) + 0 * 2048);                            \
         DIMSUM_DS_READ_B128(dst[0][1], ad_, (slot) + 0 * 2048 + 1024);                     \
@@ -186,6 +257,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
     } while (0)
 #define DIMSUM_READ_B(dst, slot, par)                                                      \
     do {                                                                                   \
+        if constexpr (kTN) {                                                               \
+            _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                             \
+                const unsigned ad_ = b_rd_tn[j_] + (par);                                  \
+                DIMSUM_READ_TN1(dst[j_][0], ad_, slot, 0);                                 \
+                DIMSUM_READ_TN1(dst[j_][1], ad_, slot, 1);                                 \
+            }                                                                              \
+            break;                                                                         \
+        }                                                                                  \
         const unsigned ad_ = b_rd + (par);                                                 \
         DIMSUM_DS_READ_B128(dst[0][0], ad_, (slot) + 0 * 2048);                            \
         DIMSUM_DS_READ_B128(dst[0][1], ad_, (slot) + 0 * 2048 + 1024);                     \
@@ -317,7 +396,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
     } else if constexpr (kEpi == kEpiF32 || kEpi == kEpiF32Bias || kEpi == kEpiF32GateRes) {
         // one buffer descriptor per tile (base = the tile's first element: wave-uniform), a 32-bit byte offset per lane
         constexpr int kAux = ((kVar & kVarNtStores) ? 2 : 0) | ((kVar & kVarSc1Stores) ? 16 : 0) | ((kVar & kVarSc0Stores) ? 1 : 0);
-        float *Ct = reinterpret_cast<float *>(p.C) + (int64_t)m0 * p.ldc + n0;
+        float *Ct = reinterpret_cast<float *>(p.C) + (int64_t)m0 * p.ldc + n0 + (kTN ? (int64_t)split * p.c_split_stride : (int64_t)0);
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(Ct, 0, 0x7fffffff, 0x00020000);
         if constexpr (kVar & kVarFullLineStores) {
             // 128-byte row segments per store: lanes r and r + 8 of a 16-lane row trade their j = 1 / j = 0 registers (row_ror:8), after
@@ -516,6 +595,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
 }
 
 #undef DIMSUM_READ_A
+#undef DIMSUM_READ_TN1
+#undef DIMSUM_DS_READ_TR
 #undef DIMSUM_READ_B
 #undef DIMSUM_QUADRANT
 #undef DIMSUM_PHASE_SYNC

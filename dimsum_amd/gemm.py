@@ -124,6 +124,11 @@ def mm_tn(a, b, out_dtype=None):
     output is small"""
     R, N = a.shape
     K = b.shape[1]
+    if a.is_cuda and a.dtype in (torch.bfloat16, torch.float16) and out_dtype in (None, torch.float32) and own_gemm_enabled():
+        from . import native
+        if native.gemm_tn_supported(a, b):      # operand images: the transposing-read variant of the hand-written kernel (dW12 2.99 -> 2.42 ms)
+            y = native.gemm_tn(a, b)
+            return y if out_dtype is not None else y.to(a.dtype)
     kw = {} if out_dtype is None else {"out_dtype": out_dtype}
     s = _slices(R, N, K) if a.is_cuda else 1
     if s == 1:

@@ -528,6 +528,56 @@ def gemm_nt_supported(a, b, gated=False):
             and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and 512 * max(a.stride(0), b.stride(0)) < 2 ** 31)
 
 
+def gemm_tn_supported(a, b):
+    """shapes the TN variant takes (csrc/gemm_nt_kernel.hpp, kVarTN): a (R, P), b (R, Q) 16-bit rows over the reduction index R, whole
+    256 x 256 output tiles, 64-row reduction tiles"""
+    if not (a.is_cuda and a.dim() == 2 and b.dim() == 2 and a.dtype == b.dtype and a.dtype in (torch.bfloat16, torch.float16)):
+        return False
+    R, P = a.shape
+    Q = b.shape[1]
+    return (b.shape[0] == R and R % 64 == 0 and R >= 128 and P % 256 == 0 and Q % 256 == 0 and P > 0 and Q > 0
+            and a.stride(1) == 1 and b.stride(1) == 1 and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0
+            and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and 128 * max(a.stride(0), b.stride(0)) + 512 < 2 ** 31)
+
+
+def gemm_tn_splits(R, P, Q):
+    """reduction ranges of a TN launch: enough workgroups to fill the 256 CUs when the output has few tiles (a weight gradient (8192, 1024)
+    is 128 tiles, (1536, 512) is 12), ranges of whole 64-row tiles, at least 2048 rows each"""
+    tiles = (P // 256) * (Q // 256)
+    s = 1
+    ok = lambda s2: R % (s2 * 64) == 0 and R // s2 >= 2048
+    while tiles * s < 192 and ok(2 * s):         # three quarters of the 256 CUs at least ...
+        s *= 2
+    if tiles >= 64 and tiles * s < 512 and ok(2 * s):       # ... and a second round where the partial results are few (tools/scratch/tn_perf.py)
+        s *= 2
+    return s
+
+
+def gemm_tn(a, b, splits=None, events=None):
+    """a (R, P)^T @ b (R, Q) -> (P, Q) float32 on the hand-written MFMA kernel's TN variant: the weight-gradient product of a Linear
+    (reduction over the rows). The reduction is cut into `splits` ranges whose partial results are added in a fixed order."""
+    _gpu(a, b)
+    _check(gemm_tn_supported(a, b), "gemm_tn: unsupported operands (R % 64, P % 256, Q % 256, 16-bit rows, 16-byte aligned)")
+    R, P = a.shape
+    Q = b.shape[1]
+    if splits is None:
+        splits = gemm_tn_splits(R, P, Q)
+    _check(splits >= 1 and R % (splits * 64) == 0 and R // splits >= 128, "gemm_tn: splits must cut R into ranges of whole 64-row tiles (>= 2)")
+    out = torch.empty((splits, P, Q), device=a.device, dtype=torch.float32)
+    G = _lib.GemmParams()
+    G.m, G.n, G.k = P, Q, R
+    G.operand_dtype = _DT[a.dtype]
+    G.epilogue = _lib.GEMM_EPI_F32
+    G.out_scale = 1.0
+    G.lda, G.ldb, G.ldc = a.stride(0), b.stride(0), Q
+    G.a_ptr, G.b_ptr, G.c_ptr = _ptr(a), _ptr(b), _ptr(out)
+    if events is not None:
+        G.timing_start_event, G.timing_stop_event = events
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.load().dimsum_gemm_tn(G, splits, P * Q, _stream(a)), "gemm_tn")
+    return out[0] if splits == 1 else out.sum(0)
+
+
 def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=None, tune=None, scales=None, gate_bound=None, residual=None,
             gate=None, rows_per_batch=None, keep_x12=False):
     """a (M, K) @ b (N, K)^T on the hand-written MFMA kernel, 16-bit operands (bfloat16: split-bf16 images over 3 K; float16: scaled rows),

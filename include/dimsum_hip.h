@@ -404,6 +404,13 @@ typedef struct {
 
 int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream);
 
+/* The weight-gradient shape of the same Linears under autograd (torch.mm(dy.t(), x) in the reference's autograd graph; dimsum/mlp.py:66-70,
+   attention_fusion.py:44-79): C[s] (m, n) float32 = sum over the rows r of reduction range s of A[r, 0..m)^T B[r, 0..n). a_ptr: (k, m) rows
+   with stride lda, b_ptr: (k, n) rows with stride ldb (16-bit, the split-bf16 images viewed as (3 rows, features) stacks), k = all
+   reduction rows, cut into `splits` equal ranges (k % (64 splits) == 0) whose partial results lie c_split_stride floats apart in c_ptr --
+   the caller adds them (a fixed order: bitwise reproducible). m % 256 == 0, n % 256 == 0; epilogue F32 only; the other fields as above. */
+int dimsum_gemm_tn(const dimsum_gemm_params_t *p, int32_t splits, int64_t c_split_stride, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

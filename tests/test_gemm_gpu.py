@@ -148,3 +148,44 @@ def test_mlp_tail_in_the_epilogue_matches_the_separate_pass(monkeypatch):
             got, none = mlp.forward_deferred(x, x3=img, residual=res, gate=gate)
             assert none is None and got.shape == want.shape
             assert (got - want).abs().max().item() <= 2e-6 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("R,P,Q,splits", [(128, 256, 256, 1), (4096, 512, 256, 4), (12288, 256, 768, None), (3 * 2048, 1536, 512, 2)])
+def test_gemm_tn_against_float64(dtype, R, P, Q, splits):
+    """the weight-gradient shape C = A^T B (reduction over the rows of both operands) on the transposing-read variant of the kernel:
+    float64 products of the same 16-bit operands, strided operand views (a column range of a wider matrix), bit-repeatable launches"""
+    from dimsum_amd import native
+    dt = getattr(torch, dtype)
+    a = _rnd((R, P + 64), dt, 11)[:, 64:]                     # row stride P + 64, 128-byte aligned start
+    b = _rnd((R, Q), dt, 12, scale=R ** -0.5)
+    assert native.gemm_tn_supported(a, b)
+    got = native.gemm_tn(a, b, splits=splits)
+    ref = a.double().t() @ b.double()
+    assert got.shape == (P, Q) and got.dtype == torch.float32
+    assert (got.double() - ref).abs().max().item() / ref.abs().max().item() < 3e-6
+    assert torch.equal(got, native.gemm_tn(a, b, splits=splits))
+
+
+def test_gemm_tn_one_hot_rows_pin_the_operand_layout():
+    """A = one-hot rows: C[p, :] = the sum of the B rows whose A row selects column p -- any mix-up of the transposing read's lane / row
+    mapping or of the staging swizzle shows as a wrong row, not as a rounding difference"""
+    from dimsum_amd import native
+    R, P, Q = 1024, 256, 256
+    g = torch.Generator(device="cuda").manual_seed(5)
+    sel = torch.randint(0, P, (R,), device="cuda", generator=g)
+    a = torch.zeros((R, P), device="cuda", dtype=torch.bfloat16)
+    a[torch.arange(R, device="cuda"), sel] = 1.0
+    b = torch.randint(-8, 9, (R, Q), device="cuda", generator=g).to(torch.bfloat16)      # small integers: every sum is exact
+    ref = torch.zeros((P, Q), device="cuda", dtype=torch.float32).index_add_(0, sel, b.float())
+    assert torch.equal(native.gemm_tn(a, b, splits=1), ref)
+    assert torch.equal(native.gemm_tn(a, b, splits=4), ref)
+    assert torch.equal(native.gemm_tn(b, a, splits=2), ref.t())
+
+
+def test_gemm_tn_rejects_what_it_cannot_take():
+    from dimsum_amd import native
+    assert not native.gemm_tn_supported(_rnd((128, 255), torch.bfloat16, 1), _rnd((128, 256), torch.bfloat16, 2))
+    assert not native.gemm_tn_supported(_rnd((96, 256), torch.bfloat16, 1), _rnd((96, 256), torch.bfloat16, 2))
+    with pytest.raises(RuntimeError):
+        native.gemm_tn(_rnd((256, 256), torch.bfloat16, 1), _rnd((256, 256), torch.bfloat16, 2), splits=3)
