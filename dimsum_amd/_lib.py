@@ -18,7 +18,7 @@ class SsmParams(C.Structure):
                                       "out_z_batch_stride", "out_z_d_stride")]
                 + [(n, vp) for n in ("A_ptr", "B_ptr", "C_ptr", "D_ptr", "u_ptr", "delta_ptr", "delta_bias_ptr",
                                      "z_ptr", "out_ptr", "x_ptr", "out_z_ptr", "ckpt_ptr")]
-                + [("kernel_variant", i32), ("timing_start_event", vp), ("timing_stop_event", vp)])
+                + [("kernel_variant", i32), ("timing_start_event", vp), ("timing_stop_event", vp), ("out_z_lo_offset", i64)])
 
 
 class SsmBwdParams(C.Structure):
@@ -91,7 +91,7 @@ class GemmParams(C.Structure):
                 + [(n, vp) for n in ("a_ptr", "b_ptr", "bias_ptr", "c_ptr", "timing_start_event", "timing_stop_event")]
                 + [(n, i32) for n in ("tune_variant", "tune_group_m", "tune_reserved")]
                 + [(n, vp) for n in ("a_inv_scale_ptr", "b_inv_scale_ptr", "gate_bound_ptr", "h_inv_scale_ptr", "residual_ptr", "gate_ptr")]
-                + [("residual_ld", i64), ("gate_ld", i64), ("rows_per_batch", i32), ("reserved0", i32), ("x12_ptr", vp), ("x12_ld", i64)])
+                + [("residual_ld", i64), ("gate_ld", i64), ("rows_per_batch", i32), ("reserved0", i32), ("x12_ptr", vp), ("x12_ld", i64), ("a_alias_rows", i64)])
 
 
 GEMM_EPI_F32, GEMM_EPI_GATED_GELU_SPLIT3, GEMM_EPI_GATED_GELU_F16, GEMM_EPI_F32_BIAS, GEMM_EPI_F32_GATE_RESIDUAL = 0, 1, 2, 3, 4

@@ -1,4 +1,5 @@
 // ssm_scan_fwd.hip -- C entry point of the selective-scan forward (kernel: ssm_scan_fwd_kernel.hpp).
+#include <type_traits>
 #include <cstdlib>
 
 #include "common.hpp"
@@ -61,6 +62,10 @@ static int launch_fwd(const dimsum_ssm_params_t &p, hipStream_t stream) {
     if (p.z_ptr)
         vec = vec && aligned_to<T>(p.z_ptr, va) && aligned_to<T>(p.out_z_ptr, va) && (p.z_batch_stride % 4 == 0) &&
               (p.z_d_stride % 4 == 0) && (p.out_z_batch_stride % 4 == 0) && (p.out_z_d_stride % 4 == 0);
+    if (p.out_z_lo_offset != 0) {      // out_z as its split-bf16 pair of planes: float32 I/O, vector path, 8-byte aligned 4-element stores
+        if (!std::is_same<T, float>::value || !p.z_ptr) return DIMSUM_ERR_UNSUPPORTED;
+        if (!vec || !aligned_to<char>(p.out_z_ptr, 8) || p.out_z_lo_offset % 4 != 0) return DIMSUM_ERR_STRIDE;
+    }
     if (p.x_ptr && !aligned_to<float>(p.x_ptr, 16)) return DIMSUM_ERR_STRIDE;
     // In-tile offsets are 32-bit BYTE offsets (saddr + voffset addressing): the farthest element of a tile is
     // (channels_per_wave - 1) * d_stride + seqlen elements from the tile base.

@@ -98,6 +98,20 @@ template <typename T> __device__ __forceinline__ T *at(T *base, unsigned elem_of
     return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + (unsigned)(elem_off * (unsigned)sizeof(T)));
 }
 
+// out_z either as a `T` tensor or (planes != nullptr) as its split-bf16 pair: hi plane at `planes`, lo plane lo_off elements behind it
+template <typename T> __device__ __forceinline__ void st4_out_z(T *base, unsigned short *planes, int64_t lo_off, unsigned elem_off, const f32x4 &y) {
+    if (planes) {
+        unsigned h0, l0, h1, l1;
+        split2(y.v[0], y.v[1], h0, l0);
+        split2(y.v[2], y.v[3], h1, l1);
+        *reinterpret_cast<uint2 *>(at(planes, elem_off)) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2 *>(at(planes + lo_off, elem_off)) = make_uint2(l0, l1);
+    } else {
+        st4<T>(at(base, elem_off), y);
+    }
+}
+
+
 // kVec : every row base is 4-element aligned and L % 4 == 0 -> 16-byte (fp32) vector I/O, register-staged prefetch.
 // kFull: dim/n_groups % 64 == 0 -> all 64 lanes own a live channel, no row masks anywhere (needs kVec).
 template <typename T, int kN, bool kHasZ, bool kVec, bool kFull, bool kCkpt = false>
@@ -130,6 +144,7 @@ __global__ __launch_bounds__(kWave, kScanWaves) void ssm_scan_fwd_kernel(const d
     const T *z_base = kHasZ ? reinterpret_cast<const T *>(p.z_ptr) + (int64_t)b * p.z_batch_stride + (int64_t)d0 * p.z_d_stride : nullptr;
     T *out_base = p.out_ptr ? reinterpret_cast<T *>(p.out_ptr) + (int64_t)b * p.out_batch_stride + (int64_t)d0 * p.out_d_stride : nullptr;
     T *oz_base = kHasZ ? reinterpret_cast<T *>(p.out_z_ptr) + (int64_t)b * p.out_z_batch_stride + (int64_t)d0 * p.out_z_d_stride : nullptr;
+    unsigned short *oz_planes = (kHasZ && p.out_z_lo_offset) ? reinterpret_cast<unsigned short *>(p.out_z_ptr) + (int64_t)b * p.out_z_batch_stride + (int64_t)d0 * p.out_z_d_stride : nullptr;
     const int u_ds = (int)p.u_d_stride, dl_ds = (int)p.delta_d_stride, z_ds = (int)p.z_d_stride;
     const int out_ds = (int)p.out_d_stride, oz_ds = (int)p.out_z_d_stride;
     // wave-uniform B/C rows of this (batch, group)
@@ -308,7 +323,7 @@ __global__ __launch_bounds__(kWave, kScanWaves) void ssm_scan_fwd_kernel(const d
                             const f32x4 z4 = widen(rz[i]);
 #pragma unroll
                             for (int s = 0; s < 4; ++s) y4.v[s] *= z4.v[s] * sigmoidf_fast(z4.v[s]);
-                            st4<T>(at(oz_base + i * kRPP * oz_ds, (unsigned)(lrow * oz_ds + t0 + lcol)), y4);
+                            st4_out_z<T>(oz_base + i * kRPP * oz_ds, oz_planes ? oz_planes + i * kRPP * oz_ds : nullptr, p.out_z_lo_offset, (unsigned)(lrow * oz_ds + t0 + lcol), y4);
                         }
                     }
                 }

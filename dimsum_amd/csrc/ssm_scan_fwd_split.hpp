@@ -73,6 +73,7 @@ __global__ __launch_bounds__(kWave, (kSP == 4 && kN <= 16) ? 5 : 3) void ssm_sca
     const T *z_base = kHasZ ? reinterpret_cast<const T *>(p.z_ptr) + (int64_t)b * p.z_batch_stride + (int64_t)d0 * p.z_d_stride : nullptr;
     T *out_base = p.out_ptr ? reinterpret_cast<T *>(p.out_ptr) + (int64_t)b * p.out_batch_stride + (int64_t)d0 * p.out_d_stride : nullptr;
     T *oz_base = kHasZ ? reinterpret_cast<T *>(p.out_z_ptr) + (int64_t)b * p.out_z_batch_stride + (int64_t)d0 * p.out_z_d_stride : nullptr;
+    unsigned short *oz_planes = (kHasZ && p.out_z_lo_offset) ? reinterpret_cast<unsigned short *>(p.out_z_ptr) + (int64_t)b * p.out_z_batch_stride + (int64_t)d0 * p.out_z_d_stride : nullptr;
     const int u_ds = (int)p.u_d_stride, dl_ds = (int)p.delta_d_stride, z_ds = (int)p.z_d_stride;
     const int out_ds = (int)p.out_d_stride, oz_ds = (int)p.out_z_d_stride;
     const T *Bp = reinterpret_cast<const T *>(p.B_ptr) + (int64_t)b * p.B_batch_stride + (int64_t)g * p.B_group_stride;
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(kWave, (kSP == 4 && kN <= 16) ? 5 : 3) void ssm_sca
                             const f32x4 z4 = widen(rz[i]);
 #pragma unroll
                             for (int s = 0; s < 4; ++s) y4.v[s] *= z4.v[s] * sigmoidf_fast(z4.v[s]);
-                            st4<T>(at(oz_base + i * 8 * oz_ds, (unsigned)(lrow * oz_ds + t0 + lcol)), y4);
+                            st4_out_z<T>(oz_base + i * 8 * oz_ds, oz_planes ? oz_planes + i * 8 * oz_ds : nullptr, p.out_z_lo_offset, (unsigned)(lrow * oz_ds + t0 + lcol), y4);
                         }
                     }
                 }

@@ -98,6 +98,11 @@ typedef struct {
                                  and the end of its last one (hipExtLaunchKernel: the kernels' own dispatch timestamps, the
                                  durations rocprofv3 reports). In dimsum_ssm_bwd_params_t.fwd they bracket the whole backward
                                  call incl. the state-rebuild sweep of a caller without ckpt_ptr. Not capturable into a hipGraph. */
+    int64_t out_z_lo_offset;  /* forward, float32 I/O only; 0 = out_z is a `dtype` tensor (the reference's interface). != 0: out_z is written as
+                                 its split-bf16 pair -- out_z_ptr = the bfloat16 `hi` plane (out_z_*_stride in bfloat16 elements), the `lo`
+                                 plane lies out_z_lo_offset elements behind it; hi = bf16(x), lo = bf16(x - hi): the same 4 bytes per
+                                 element, already the operand image of out_proj's GEMM (dimsum_gemm_tn with a_alias_rows), which then
+                                 needs no conversion pass (mamba_simple.py:352-354 out_proj under allow_tf32). */
 } dimsum_ssm_params_t;
 
 typedef struct {
@@ -400,6 +405,9 @@ typedef struct {
     int32_t reserved0;
     void *x12_ptr;
     int64_t x12_ld;
+    /* dimsum_gemm_tn only: != 0 = the A operand's reduction rows r >= a_alias_rows are the rows r - a_alias_rows of a_ptr (k = 3 a_alias_rows):
+       a [hi; lo] pair of planes serves as the row stack [hi; hi; lo] of a left operand image without storing hi twice. % 64 == 0. */
+    int64_t a_alias_rows;
 } dimsum_gemm_params_t;
 
 int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream);
