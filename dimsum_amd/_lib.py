@@ -103,7 +103,7 @@ EXPORTS = (
     "dimsum_ssm_scan_fwd", "dimsum_ssm_scan_bwd", "dimsum_ssm_scan_bwd_workspace_bytes", "dimsum_ssm_scan_fwd_variant",
     "dimsum_causal_conv1d_fwd", "dimsum_causal_conv1d_bwd",
     "dimsum_norm_fwd", "dimsum_norm_bwd", "dimsum_token_transform", "dimsum_xattn_fusion_fwd", "dimsum_xattn_fusion_bwd",
-    "dimsum_gated_gelu_fwd", "dimsum_gated_gelu_bwd", "dimsum_gated_gelu_fwd_split3", "dimsum_gated_gelu_bwd_split3", "dimsum_split3",
+    "dimsum_gated_gelu_fwd", "dimsum_gated_gelu_bwd", "dimsum_gated_gelu_fwd_split3", "dimsum_gated_gelu_bwd_split3", "dimsum_split3", "dimsum_split3_t",
     "dimsum_gemm_nt", "dimsum_gemm_tn", "dimsum_rows_f16s",
 )
 
@@ -148,6 +148,9 @@ def load():
     if hasattr(lib, "dimsum_split3"):
         lib.dimsum_split3.restype = C.c_int
         lib.dimsum_split3.argtypes = [vp, i64, i64, i64, vp, i32, vp]
+    if hasattr(lib, "dimsum_split3_t"):
+        lib.dimsum_split3_t.restype = C.c_int
+        lib.dimsum_split3_t.argtypes = [vp, i64, i64, i64, vp, vp]
     if hasattr(lib, "dimsum_rows_f16s"):
         lib.dimsum_rows_f16s.restype = C.c_int
         lib.dimsum_rows_f16s.argtypes = [vp, i64, i64, i64, vp, i64, vp, vp, vp]

@@ -146,6 +146,10 @@ extern "C" int dimsum_gemm_tn(const dimsum_gemm_params_t *p, int32_t splits, int
     a.tiles_m = p->m / kBM;
     a.tiles_n = p->n / kBN;
     a.group_m = p->tune_group_m > 0 ? p->tune_group_m : (a.tiles_m <= 16 ? a.tiles_m : 4);
+    if (p->a_alias_rows != 0) {
+        if (splits != 1 || p->a_alias_rows < 0 || p->a_alias_rows % kBK != 0 || p->k != 3 * p->a_alias_rows) return DIMSUM_ERR_SHAPE;
+        a.a_alias_tiles = (int)(p->a_alias_rows / kBK);
+    }
     a.splits = splits;
     a.c_split_stride = c_split_stride;
     a.out_scale = 1.0f;

@@ -78,6 +78,7 @@ struct Args {
     int64_t ldx;
     int splits;                    // kVarTN: the reduction is cut into `splits` ranges of K rows each (K = rows per range)
     int64_t c_split_stride;        // elements between the partial results
+    int a_alias_tiles;             // kVarTN: != 0 = K tiles kt >= a_alias_tiles of A are the tiles kt - a_alias_tiles (a [hi; lo] pair read as [hi; hi; lo])
 };
 // tuning variants (bit mask; 0 = the shipped schedule)
 enum { kVarLgkmAfterBarrier = 1, kVarNoEpilogue = 2, kVarNtStores = 4, kVarFullLineStores = 8, kVarNoSetprio = 16, kVarSc1Stores = 32, kVarSc0Stores = 64, kVarKeepX12 = 128, kVarTN = 256 };
@@ -195,8 +196,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
         __builtin_amdgcn_global_load_lds((glb_void_t *)(s + voff[0]), (lds_void_t *)(uintptr_t)dst, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((glb_void_t *)(s + voff[1]), (lds_void_t *)(uintptr_t)(dst + 1024), 16, 0, 0);
     };
-    auto stage_a0 = [&](int kt) { if constexpr (kTN) stage_tn(kSlotA0, tn_a, tn_a_tile, tn_voff_a, kt); else stage(kSlotA0, a_base, a_voff, kt); };
-    auto stage_a1 = [&](int kt) { if constexpr (kTN) stage_tn(kSlotA1, tn_a + 256, tn_a_tile, tn_voff_a, kt); else stage(kSlotA1, a_base + a_half, a_voff, kt); };
+    auto stage_tn_a = [&](int slot, const char *base, int kt) {       // (the LDS parity follows kt, the source tile may be an aliased earlier one)
+        const unsigned dst = st_lds + (kt & 1) * kParity + slot;
+        const int src_kt = (p.a_alias_tiles && kt >= p.a_alias_tiles) ? kt - p.a_alias_tiles : kt;
+        const char *s = base + (int64_t)src_kt * tn_a_tile;
+        __builtin_amdgcn_global_load_lds((glb_void_t *)(s + tn_voff_a[0]), (lds_void_t *)(uintptr_t)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void_t *)(s + tn_voff_a[1]), (lds_void_t *)(uintptr_t)(dst + 1024), 16, 0, 0);
+    };
+    auto stage_a0 = [&](int kt) { if constexpr (kTN) stage_tn_a(kSlotA0, tn_a, kt); else stage(kSlotA0, a_base, a_voff, kt); };
+    auto stage_a1 = [&](int kt) { if constexpr (kTN) stage_tn_a(kSlotA1, tn_a + 256, kt); else stage(kSlotA1, a_base + a_half, a_voff, kt); };
     auto stage_b0 = [&](int kt) { if constexpr (kTN) stage_tn(kSlotB0, tn_b, tn_b_tile, tn_voff_b, kt); else stage(kSlotB0, b_base[0], b_voff[0], kt); };
     auto stage_b1 = [&](int kt) { if constexpr (kTN) stage_tn(kSlotB1, tn_b + 256, tn_b_tile, tn_voff_b, kt); else stage(kSlotB1, b_base[1], b_voff[1], kt); };
 

@@ -21,6 +21,21 @@ __global__ __launch_bounds__(256) void split3_kernel(const float *src, int64_t r
     }
 }
 
+// weight (N, K) fp32 -> the ROW stack [hi; lo; hi] (3 K, N) bf16 of its transpose: the right operand of dimsum_gemm_tn when the left one is
+// a d-major activation (out_proj: y = out_z^T W^T with out_z (d_inner, tokens)). One thread per (k, 2 n): the matrix is small and
+// L2-resident, the transposing reads cost nothing next to a launch.
+__global__ __launch_bounds__(256) void split3_t_kernel(const float *src, int64_t N, int64_t K, int64_t src_row_stride, unsigned short *dst) {
+    const int64_t half = N / 2, total = K * half;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t k = i / half, n = (i - k * half) * 2;
+        unsigned hi, lo;
+        split2(src[n * src_row_stride + k], src[(n + 1) * src_row_stride + k], hi, lo);
+        *reinterpret_cast<unsigned *>(dst + k * N + n) = hi;
+        *reinterpret_cast<unsigned *>(dst + (K + k) * N + n) = lo;
+        *reinterpret_cast<unsigned *>(dst + (2 * K + k) * N + n) = hi;
+    }
+}
+
 // scaled-fp16 image of fp32 rows (common.hpp, f16s): one wave per row, exact row maximum. Converts what has no producer kernel of its
 // own: the weights (whose largest row L1 norm -- the bound sum_k |w_nk| on |x W^T| / max|x| -- the gated epilogue of the GEMM needs).
 template <int kPieces>      // kPieces * 256 >= cols: the row lives in registers (one pass); 0: two passes over a row of any length
@@ -120,5 +135,18 @@ extern "C" int dimsum_split3(const void *src, int64_t rows, int64_t cols, int64_
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (left) hipLaunchKernelGGL(split3_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float *>(src), rows, cols, src_row_stride, reinterpret_cast<unsigned short *>(dst));
     else hipLaunchKernelGGL(split3_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float *>(src), rows, cols, src_row_stride, reinterpret_cast<unsigned short *>(dst));
+    return launch_status();
+}
+
+extern "C" int dimsum_split3_t(const void *src, int64_t rows, int64_t cols, int64_t src_row_stride, void *dst, void *stream) {
+    using namespace dimsum;
+    if (!src || !dst) return DIMSUM_ERR_NULL;
+    if (rows <= 0 || cols <= 0 || rows % 2 != 0) return DIMSUM_ERR_SHAPE;
+    if (src_row_stride < cols || !aligned_to<char>(dst, 4)) return DIMSUM_ERR_STRIDE;
+    const int64_t total = cols * (rows / 2);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(split3_t_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const float *>(src), rows, cols,
+                       src_row_stride, reinterpret_cast<unsigned short *>(dst));
     return launch_status();
 }

@@ -64,7 +64,8 @@ static int launch_fwd(const dimsum_ssm_params_t &p, hipStream_t stream) {
               (p.z_d_stride % 4 == 0) && (p.out_z_batch_stride % 4 == 0) && (p.out_z_d_stride % 4 == 0);
     if (p.out_z_lo_offset != 0) {      // out_z as its split-bf16 pair of planes: float32 I/O, vector path, 8-byte aligned 4-element stores
         if (!std::is_same<T, float>::value || !p.z_ptr) return DIMSUM_ERR_UNSUPPORTED;
-        if (!vec || !aligned_to<char>(p.out_z_ptr, 8) || p.out_z_lo_offset % 4 != 0) return DIMSUM_ERR_STRIDE;
+        if (p.seqlen % 8 != 0) return DIMSUM_ERR_SHAPE;
+        if (!vec || !aligned_to<char>(p.out_z_ptr, 16) || p.out_z_lo_offset % 8 != 0 || p.out_z_batch_stride % 8 != 0 || p.out_z_d_stride % 8 != 0) return DIMSUM_ERR_STRIDE;
     }
     if (p.x_ptr && !aligned_to<float>(p.x_ptr, 16)) return DIMSUM_ERR_STRIDE;
     // In-tile offsets are 32-bit BYTE offsets (saddr + voffset addressing): the farthest element of a tile is

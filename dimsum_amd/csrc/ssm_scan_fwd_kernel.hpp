@@ -98,19 +98,25 @@ template <typename T> __device__ __forceinline__ T *at(T *base, unsigned elem_of
     return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + (unsigned)(elem_off * (unsigned)sizeof(T)));
 }
 
-// out_z either as a `T` tensor or (planes != nullptr) as its split-bf16 pair: hi plane at `planes`, lo plane lo_off elements behind it
+// out_z either as a `T` tensor or (planes != nullptr) as its split-bf16 pair: hi plane at `planes`, lo plane lo_off elements behind it.
+// Adjacent lanes hold adjacent 4-step groups of one row (all three kernels' epilogue layouts), so a lane pair trades halves (one quad_perm
+// DPP each way) and the even lane stores 8 steps of hi, the odd lane 8 steps of lo: ONE 16-byte store per lane like the fp32 form (two
+// 8-byte stores per lane cost the 64-channel kernel 12 % -- store issue, not bytes). seqlen % 8 == 0: a pair is live or dead together.
 template <typename T> __device__ __forceinline__ void st4_out_z(T *base, unsigned short *planes, int64_t lo_off, unsigned elem_off, const f32x4 &y) {
     if (planes) {
         unsigned h0, l0, h1, l1;
         split2(y.v[0], y.v[1], h0, l0);
         split2(y.v[2], y.v[3], h1, l1);
-        *reinterpret_cast<uint2 *>(at(planes, elem_off)) = make_uint2(h0, h1);
-        *reinterpret_cast<uint2 *>(at(planes + lo_off, elem_off)) = make_uint2(l0, l1);
+        const bool odd = (threadIdx.x & 1) != 0;
+        const unsigned r0 = __float_as_uint(dpp_mov<0xB1>(__uint_as_float(odd ? h0 : l0)));      // quad_perm [1, 0, 3, 2]: the neighbour's word
+        const unsigned r1 = __float_as_uint(dpp_mov<0xB1>(__uint_as_float(odd ? h1 : l1)));
+        const uint4 v = odd ? make_uint4(r0, r1, l0, l1) : make_uint4(h0, h1, r0, r1);
+        unsigned short *dst = odd ? planes + lo_off : planes;
+        *reinterpret_cast<uint4 *>(at(dst, odd ? elem_off - 4u : elem_off)) = v;
     } else {
         st4<T>(at(base, elem_off), y);
     }
 }
-
 
 // kVec : every row base is 4-element aligned and L % 4 == 0 -> 16-byte (fp32) vector I/O, register-staged prefetch.
 // kFull: dim/n_groups % 64 == 0 -> all 64 lanes own a live channel, no row masks anywhere (needs kVec).

@@ -88,6 +88,32 @@ def weight_image(weight):
     return _cached("w3", weight, lambda: native.split3_rows(weight.detach(), left=False))
 
 
+def out_proj_planes_enabled(xz, weight, rows, scan_kernel=1):
+    """whether MambaInnerFn's out_proj runs as gemm_tn over the scan's split-bf16 out_z planes (inference, fp32 under allow_tf32: the products
+    the library's fp32 GEMM spends there too, without its conversion of the d-major operand): `rows` tokens of a (d_model, d_inner) weight.
+    DIMSUM_OUT_PROJ_PLANES = auto (default): where the scan runs one of its state-split kernels (scan_kernel != 1, underfilled launches:
+    DiM-XL/2 at 512 px 320.5 -> 315.7 ms per forward, the scan +1.5 %); the 64-channel kernel of a full chip is VALU-bound and pays +5 %
+    for the conversion in its epilogue (0.338 -> 0.356 ms) against -0.06 ms in out_proj: -0.7 % per DiM-L/2 forward, but the headline
+    kernel's roofline fraction 0.51 -> 0.49 -- left to `1` (always); `0` = never. tools/scratch/ab_planes.sh."""
+    import os
+    mode = os.environ.get("DIMSUM_OUT_PROJ_PLANES", "auto")
+    if mode == "0" or (mode != "1" and scan_kernel == 1):
+        return False
+    return (_policy in ("default", "f16s") and torch.backends.cuda.matmul.allow_tf32 and os.environ.get("DIMSUM_SPLIT3", "1") != "0"
+            and own_gemm_enabled() and xz.is_cuda and xz.dtype == torch.float32 and weight.dtype == torch.float32
+            and weight.stride(1) == 1 and rows % 256 == 0 and weight.shape[0] % 256 == 0 and weight.shape[1] % 64 == 0
+            and rows >= int(os.environ.get("DIMSUM_SPLIT3_MIN_ROWS", "8192")))
+
+
+def out_proj_planes(planes, weight):
+    """planes (2 D, M) bfloat16 [hi; lo] of the d-major out_z, weight (N, D) -> out_z^T weight^T (M, N) float32: hi.hi + hi.lo + lo.hi on the
+    kernel's transposing-read variant; the plane pair is read as the row stack [hi; hi; lo]"""
+    from . import native
+    D = weight.shape[1]
+    wt = _cached("w3t", weight, lambda: native.split3_rows_t(weight.detach()))
+    return native.gemm_tn(planes, wt, alias_rows=D)
+
+
 def set_policy(policy):
     global _policy
     if policy not in ("default", "fp16", "f16s"):

@@ -56,6 +56,15 @@ def scan_fwd_variant(v):
         _scan_fwd_variant = old
 
 
+def scan_fwd_kernel_for(batch, dim, seqlen, dstate, n_groups=1):
+    """which forward scan kernel the library runs for this launch shape, as lanes per channel (dimsum_ssm_scan_fwd_variant): 1 = the
+    64-channel kernel (a full chip), 2 / 4 / 16 = the state-split kernels of underfilled launches"""
+    P = _lib.SsmParams()
+    P.batch, P.dim, P.seqlen, P.dstate, P.n_groups, P.n_chunks = batch, dim, seqlen, dstate, n_groups, (seqlen + 2047) // 2048
+    P.kernel_variant = _scan_fwd_variant
+    return int(_lib.load().dimsum_ssm_scan_fwd_variant(P))
+
+
 def _fill_ssm(P, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, x, out_z, ckpt=None):
     P.kernel_variant = _scan_fwd_variant
     batch, dim, seqlen = u.shape
@@ -110,26 +119,36 @@ def scan_ckpt_shape(batch, dim, seqlen, dstate):
     return (batch, (seqlen + 7) // 8, dstate, dim)
 
 
-def selective_scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus, need_out=True, need_x=True, need_ckpt=False):
+def selective_scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus, need_out=True, need_x=True, need_ckpt=False, out_z_planes=False):
     """-> [out, x, (out_z)]   exactly like selective_scan_cuda.fwd.
     `need_out=False` / `need_x=False` are inference extras: the corresponding store is skipped and None returned.
-    `need_ckpt=True` (training extra) appends the tile-boundary states the backward kernel consumes."""
+    `need_ckpt=True` (training extra) appends the tile-boundary states the backward kernel consumes.
+    `out_z_planes=True` (inference extra, float32): out_z comes back as its split-bf16 pair of d-major planes, a (2 dim, batch seqlen)
+    bfloat16 matrix [hi; lo] -- the operand image of out_proj's GEMM (gemm_tn(..., alias_rows=dim)), the same 4 bytes per element."""
     _check_ssm(u, delta, A, B, C, D, z, delta_bias)
     batch, dim, seqlen = u.shape
     dstate = A.shape[1]
     n_chunks = (seqlen + 2047) // 2048
     out = torch.empty_like(delta) if need_out else None          # HBL layout like delta (selective_scan.cpp:310-311)
     x = torch.empty((batch, dim, n_chunks, dstate * 2), device=u.device, dtype=torch.float32) if need_x else None
-    out_z = torch.empty_like(z) if z is not None else None
+    planes = None
+    if out_z_planes:
+        _check(z is not None and u.dtype == torch.float32 and seqlen % 8 == 0, "selective_scan_fwd: out_z_planes needs z, float32 I/O and seqlen % 8 == 0")
+        planes = torch.empty((2 * dim, batch * seqlen), device=u.device, dtype=torch.bfloat16)
+        out_z = planes[:dim].view(dim, batch, seqlen).permute(1, 0, 2)           # the hi plane as a (batch, dim, seqlen) view
+    else:
+        out_z = torch.empty_like(z) if z is not None else None
     ckpt = torch.empty(scan_ckpt_shape(batch, dim, seqlen, dstate), device=u.device, dtype=torch.float32) if need_ckpt else None
     if u.numel() > 0:
         P = _lib.SsmParams()
         _fill_ssm(P, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, x, out_z, ckpt)
+        if planes is not None:
+            P.out_z_lo_offset = dim * batch * seqlen
         with torch.cuda.device(u.device):
             _lib.check(_lib.load().dimsum_ssm_scan_fwd(P, _stream(u)), "selective_scan_fwd")
     res = [out, x]
     if z is not None:
-        res.append(out_z)
+        res.append(out_z if planes is None else planes)
     if need_ckpt:
         res.append(ckpt)
     return res
@@ -473,6 +492,18 @@ def split3_rows(x, left):
     return out
 
 
+def split3_rows_t(w):
+    """weight (N, K) float32 (rows contiguous) -> (3 K, N) bfloat16: the row stack [hi; lo; hi] of w^T (csrc/operand_split.hip), the right
+    operand of gemm_tn(planes, ., alias_rows=K)"""
+    _gpu(w)
+    _check(w.dim() == 2 and w.dtype == torch.float32 and w.stride(1) == 1 and w.shape[0] % 2 == 0, "split3_rows_t: w must be (N, K) float32 rows, N even")
+    N, K = w.shape
+    out = torch.empty((3 * K, N), device=w.device, dtype=torch.bfloat16)
+    with torch.cuda.device(w.device):
+        _lib.check(_lib.load().dimsum_split3_t(_ptr(w), N, K, w.stride(0), _ptr(out), _stream(w)), "split3_rows_t")
+    return out
+
+
 class F16Image:
     """scaled-fp16 operand image (csrc/common.hpp, f16s): data (..., K) float16 = fp16(x * 2^s), one s per row, inv (...) float32 = 2^-s.
     Quacks like the tensor it replaces where the host layer only reshapes it and hands it to the next GEMM."""
@@ -553,12 +584,19 @@ def gemm_tn_splits(R, P, Q):
     return s
 
 
-def gemm_tn(a, b, splits=None, events=None):
+def gemm_tn(a, b, splits=None, events=None, alias_rows=0):
     """a (R, P)^T @ b (R, Q) -> (P, Q) float32 on the hand-written MFMA kernel's TN variant: the weight-gradient product of a Linear
-    (reduction over the rows). The reduction is cut into `splits` ranges whose partial results are added in a fixed order."""
+    (reduction over the rows). The reduction is cut into `splits` ranges whose partial results are added in a fixed order.
+    alias_rows = D: a is a (2 D, P) pair of planes [hi; lo] read as the row stack [hi; hi; lo] (b: (3 D, Q)); one range."""
     _gpu(a, b)
-    _check(gemm_tn_supported(a, b), "gemm_tn: unsupported operands (R % 64, P % 256, Q % 256, 16-bit rows, 16-byte aligned)")
-    R, P = a.shape
+    if alias_rows:
+        _check(a.dim() == 2 and a.shape[0] == 2 * alias_rows and b.shape[0] == 3 * alias_rows and alias_rows % 64 == 0 and gemm_tn_supported(a[:alias_rows], b[:alias_rows]),
+               "gemm_tn: alias_rows = D takes a (2 D, P) plane pair and a (3 D, Q) row stack, D % 64 == 0")
+        R, P = 3 * alias_rows, a.shape[1]
+        splits = 1
+    else:
+        _check(gemm_tn_supported(a, b), "gemm_tn: unsupported operands (R % 64, P % 256, Q % 256, 16-bit rows, 16-byte aligned)")
+        R, P = a.shape
     Q = b.shape[1]
     if splits is None:
         splits = gemm_tn_splits(R, P, Q)
@@ -571,6 +609,7 @@ def gemm_tn(a, b, splits=None, events=None):
     G.out_scale = 1.0
     G.lda, G.ldb, G.ldc = a.stride(0), b.stride(0), Q
     G.a_ptr, G.b_ptr, G.c_ptr = _ptr(a), _ptr(b), _ptr(out)
+    G.a_alias_rows = alias_rows
     if events is not None:
         G.timing_start_event, G.timing_stop_event = events
     with torch.cuda.device(a.device):

@@ -147,8 +147,15 @@ class _MambaInner(torch.autograd.Function):
         # DIMSUM_SCAN_INFER_STORES=0 skips both at inference (1.082 instead of 1.384 GB per launch at DiM-L/2, batch 256:
         # measured 0.320 -> 0.298 ms in the model, i.e. -22 % bytes buy -7 % time: the kernel is not bound by HBM alone).
         keep = need or os.environ.get("DIMSUM_SCAN_INFER_STORES", "1") != "0"
+        # inference under allow_tf32: out_z leaves the scan as its split-bf16 pair of planes (the same 4 bytes per element) and out_proj runs
+        # on the hand-written kernel's transposing-read variant straight from them (0.26 -> 0.17 ms per mixer at 65536 tokens)
+        planes = (has_out_proj and not need and out_proj_bias is None and L % 8 == 0
+                  and d_inner % 64 == 0 and xz.is_cuda
+                  and gemm.out_proj_planes_enabled(xz, out_proj_weight, bsz * L, native.scan_fwd_kernel_for(bsz, d_inner, L, N, Bm.shape[1])))
         out, scan_x, out_z, *rest = native.selective_scan_fwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus,
-                                                              need_out=keep, need_x=keep, need_ckpt=need)
+                                                              need_out=keep, need_x=keep, need_ckpt=need, out_z_planes=planes)
+        if planes:
+            return gemm.out_proj_planes(out_z, out_proj_weight).view(bsz, L, out_proj_weight.shape[0])
         ckpt = rest[0] if need else None
         ctx.delta_softplus, ctx.has_out_proj, ctx.checkpoint_lvl = delta_softplus, has_out_proj, checkpoint_lvl
         ctx.flags = (conv1d_bias is not None, D is not None, delta_bias is not None, B_proj_bias is not None,

@@ -101,7 +101,7 @@ typedef struct {
     int64_t out_z_lo_offset;  /* forward, float32 I/O only; 0 = out_z is a `dtype` tensor (the reference's interface). != 0: out_z is written as
                                  its split-bf16 pair -- out_z_ptr = the bfloat16 `hi` plane (out_z_*_stride in bfloat16 elements), the `lo`
                                  plane lies out_z_lo_offset elements behind it; hi = bf16(x), lo = bf16(x - hi): the same 4 bytes per
-                                 element, already the operand image of out_proj's GEMM (dimsum_gemm_tn with a_alias_rows), which then
+                                 element (seqlen % 8 == 0), already the operand image of out_proj's GEMM (dimsum_gemm_tn with a_alias_rows), which then
                                  needs no conversion pass (mamba_simple.py:352-354 out_proj under allow_tf32). */
 } dimsum_ssm_params_t;
 
@@ -229,6 +229,9 @@ int dimsum_norm_bwd(const dimsum_norm_bwd_params_t *p, void *stream);
  * cols % 4 == 0, src rows 16-byte aligned (src_row_stride % 4 == 0), dst contiguous and 8-byte aligned.
  * ------------------------------------------------------------------------------------------------------------- */
 int dimsum_split3(const void *src, int64_t rows, int64_t cols, int64_t src_row_stride, void *dst, int32_t left, void *stream);
+/* weight (rows = N, cols = K) float32 -> (3 K, N) bfloat16: the ROW stack [hi; lo; hi] of its transpose -- the b operand of dimsum_gemm_tn when
+   the a operand is a d-major activation pair of planes (out_proj behind the scan's out_z_lo_offset output). rows % 2 == 0. */
+int dimsum_split3_t(const void *src, int64_t rows, int64_t cols, int64_t src_row_stride, void *dst, void *stream);
 
 /* Scaled-fp16 operand image ("f16s") -- the single-product carrier of the same policy: TF32 keeps 10 mantissa bits of each operand and
  * accumulates in fp32; fp16 has exactly that mantissa, and its narrow exponent is taken out of the picture by an exact power-of-two

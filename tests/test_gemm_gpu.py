@@ -189,3 +189,37 @@ def test_gemm_tn_rejects_what_it_cannot_take():
     assert not native.gemm_tn_supported(_rnd((96, 256), torch.bfloat16, 1), _rnd((96, 256), torch.bfloat16, 2))
     with pytest.raises(RuntimeError):
         native.gemm_tn(_rnd((256, 256), torch.bfloat16, 1), _rnd((256, 256), torch.bfloat16, 2), splits=3)
+
+
+def test_out_proj_from_the_scan_planes():
+    """MambaInnerFn's out_proj at inference: the scan writes out_z as its split-bf16 pair of d-major planes (bit for bit the split of the
+    fp32 out_z it writes otherwise), split3_rows_t stacks the transposed weight as [hi; lo; hi], and gemm_tn(alias_rows = d_inner) reads
+    the pair as [hi; hi; lo]: the product is the fp32-class out_z^T W^T (3 bf16 products), against float64"""
+    from dimsum_amd import native
+    B, D, L, N, Q = 4, 192, 256, 16, 256
+    g = torch.Generator(device="cuda").manual_seed(3)
+    rn = lambda *s: torch.randn(s, device="cuda", generator=g)
+    xz = rn(2 * D, B * L)                                            # d-major like the in_proj output
+    u, z = (t.view(D, B, L).permute(1, 0, 2) for t in (xz[:D], xz[D:]))
+    delta = (rn(D, B * L) * 0.5).view(D, B, L).permute(1, 0, 2)
+    A = -torch.rand(D, N, device="cuda", generator=g) - 0.5
+    Bm, Cm = rn(B, 1, N, L), rn(B, 1, N, L)
+    Dv, bias = rn(D), rn(D) * 0.1
+    _, _, out_z = native.selective_scan_fwd(u, delta, A, Bm, Cm, Dv, z, bias, True)
+    _, _, planes = native.selective_scan_fwd(u, delta, A, Bm, Cm, Dv, z, bias, True, out_z_planes=True)
+    assert planes.shape == (2 * D, B * L) and planes.dtype == torch.bfloat16
+    ref_rows = out_z.permute(1, 0, 2).reshape(D, B * L)             # (d, tokens) fp32
+    hi = ref_rows.to(torch.bfloat16)
+    lo = (ref_rows - hi.float()).to(torch.bfloat16)
+    assert torch.equal(planes[:D], hi) and torch.equal(planes[D:], lo)
+    w = rn(Q, D) * D ** -0.5
+    wt = native.split3_rows_t(w)
+    whi = w.t().contiguous().to(torch.bfloat16)
+    wlo = (w.t().contiguous() - whi.float()).to(torch.bfloat16)
+    assert torch.equal(wt, torch.cat([whi, wlo, whi], 0))
+    y = native.gemm_tn(planes, wt, alias_rows=D)
+    ref = ref_rows.double().t() @ w.double().t()
+    assert y.shape == (B * L, Q)
+    assert (y.double() - ref).abs().max().item() / ref.abs().max().item() < 2e-5
+    lib = torch.nn.functional.linear(out_z.transpose(1, 2).reshape(B * L, D), w)        # what the host layer called before (fp32 operands)
+    assert (y - lib).abs().max().item() / ref.abs().max().item() < 2e-5

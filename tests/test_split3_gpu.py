@@ -372,3 +372,37 @@ def test_sample_batch_builds_each_weight_image_once(monkeypatch):
         torch.backends.cuda.matmul.allow_tf32 = old
     assert per_batch > 0 and calls["w"] == 3 * per_batch, (per_batch, calls["w"])
     assert torch.equal(a, b)
+
+
+def test_mamba_out_proj_from_the_scan_planes_matches_the_fp32_operand_path(monkeypatch):
+    """Mamba inference under allow_tf32 with out_proj on the scan's split-bf16 out_z planes (DIMSUM_OUT_PROJ_PLANES=1: the scan epilogue
+    writes the operand image, gemm_tn reads it transposed) against the library's fp32 GEMM on the fp32 out_z: both are 3-product
+    results (2e-5 of max|y|); the default (auto) takes the planes only where the scan runs a state-split kernel"""
+    from dimsum_amd import native
+    from dimsum_amd.modules.mamba_simple import Mamba
+    torch.manual_seed(0)
+    m = Mamba(256, d_state=16, expand=2).cuda().eval()
+    x = torch.randn(4, 256, 256, device="cuda")
+    old = torch.backends.cuda.matmul.allow_tf32
+    outs = {}
+    calls = []
+    real = native.gemm_tn
+    monkeypatch.setattr(native, "gemm_tn", lambda *a, **k: (calls.append(k.get("alias_rows", 0)), real(*a, **k))[1])
+    try:
+        torch.backends.cuda.matmul.allow_tf32 = True
+        monkeypatch.setenv("DIMSUM_SPLIT3_MIN_ROWS", "0")
+        for flag in ("1", "0", "auto"):
+            monkeypatch.setenv("DIMSUM_OUT_PROJ_PLANES", flag)
+            n = len(calls)
+            with torch.no_grad():
+                outs[flag] = m(x)
+            took = len(calls) > n
+            assert took == (flag == "1" or (flag == "auto" and native.scan_fwd_kernel_for(4, 512, 256, 16) != 1)), (flag, took)
+        y = m(x)                                   # under autograd: never the planes
+        assert y.requires_grad
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = old
+    assert calls and all(c == 512 for c in calls)
+    ref = outs["0"]
+    assert not torch.equal(outs["1"], ref)
+    assert (outs["1"] - ref).abs().max().item() / ref.abs().max().item() < 2e-5
