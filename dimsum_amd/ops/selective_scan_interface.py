@@ -153,7 +153,7 @@ class _MambaInner(torch.autograd.Function):
                   and d_inner % 64 == 0 and xz.is_cuda
                   and gemm.out_proj_planes_enabled(xz, out_proj_weight, bsz * L, native.scan_fwd_kernel_for(bsz, d_inner, L, N, Bm.shape[1])))
         out, scan_x, out_z, *rest = native.selective_scan_fwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus,
-                                                              need_out=keep, need_x=keep, need_ckpt=need, out_z_planes=planes)
+                                                              need_out=keep, need_x=keep, need_ckpt=need, **({"out_z_planes": True} if planes else {}))
         if planes:
             return gemm.out_proj_planes(out_z, out_proj_weight).view(bsz, L, out_proj_weight.shape[0])
         ckpt = rest[0] if need else None
