@@ -279,7 +279,8 @@ class Bench:
         _lib.load()                                   # fail loudly if the HIP library is missing
         self.timer = ScanTimer()
         self.timer.install()
-        box_probe(self.dev)
+        if not getattr(args, "no_box_probe", False):
+            box_probe(self.dev)
 
     @staticmethod
     def set_matmul(policy):
@@ -562,6 +563,7 @@ def main():
     ap.add_argument("--hip-graph", action="store_true", help="fwd / sample: replay the denoiser forward from a captured hipGraph "
                                                              "(dimsum_amd/hip_graph.py): for per-GPU batches below ~32, where eager is launch-bound")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-box-probe", action="store_true", help="skip the 1-GiB copy / add bandwidth probe at process start (kernel-trace runs: keeps its rows out of the stats)")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the extra exact-fp32 / fp16-operand timings (for profiling runs)")
     ap.add_argument("--matmul", choices=["tf32", "fp32", "fp16", "f16s"], default="tf32",
                     help="library-GEMM policy. tf32 = the reference's own setting (torch.backends.cuda.matmul.allow_tf32 = "

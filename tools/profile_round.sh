@@ -36,14 +36,14 @@ for r in rows:
 P
   tail -1 $out/${name}.log | cut -c1-300
 }
-stats fwd2s --mode fwd --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg
+stats fwd2s --mode fwd --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg --no-box-probe
 export DIMSUM_BRANCH_STREAMS=0
-stats fwd --mode fwd --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg
-stats block --mode block --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg
-stats xl512 --mode xl512 --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg
-stats fwd_f16s --mode fwd --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg --matmul f16s
+stats fwd --mode fwd --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg --no-box-probe
+stats block --mode block --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg --no-box-probe
+stats xl512 --mode xl512 --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg --no-box-probe
+stats fwd_f16s --mode fwd --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg --no-box-probe --matmul f16s
 unset DIMSUM_BRANCH_STREAMS
-stats all --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg --nfe 10
+stats all --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg --no-box-probe --nfe 10
 # PMC: forward (inference), forward + saved states, backward (as dimsum_amd.ops calls it: no out_z recompute; and with it), config-5 forward,
 # the long-sequence stress shape (one lane per state)
 bash tools/pmc_scan.sh $out/pmc_fwd --dmajor > $out/${tag}_scan_fwd_pmc.txt 2>&1
