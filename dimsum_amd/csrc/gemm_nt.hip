@@ -21,7 +21,10 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
     if (!p || !p->a_ptr || !p->b_ptr || !p->c_ptr) return DIMSUM_ERR_NULL;
     if (p->operand_dtype != DIMSUM_F16 && p->operand_dtype != DIMSUM_BF16) return DIMSUM_ERR_DTYPE;
     if (p->m <= 0 || p->n <= 0 || p->k < 2 * kBK || p->m % kBM != 0 || p->k % kBK != 0 || p->n % 4 != 0) return DIMSUM_ERR_SHAPE;
-    if (p->lda % 8 != 0 || p->ldb % 8 != 0 || p->lda < p->k || p->ldb < p->k || !aligned_to<char>(p->a_ptr, 16) || !aligned_to<char>(p->b_ptr, 16))
+    // a_alias_rows = C: the A rows are [hi | lo] pairs (2 C columns) read as the left image [hi | hi | lo] over k = 3 C
+    if (p->a_alias_rows != 0 && (p->a_alias_rows < 0 || p->a_alias_rows % kBK != 0 || p->k != 3 * p->a_alias_rows)) return DIMSUM_ERR_SHAPE;
+    if (p->lda % 8 != 0 || p->ldb % 8 != 0 || p->lda < (p->a_alias_rows ? 2 * p->a_alias_rows : p->k) || p->ldb < p->k || !aligned_to<char>(p->a_ptr, 16) ||
+        !aligned_to<char>(p->b_ptr, 16))
         return DIMSUM_ERR_STRIDE;
     // one 32-bit byte offset per lane inside a 256-row panel
     if ((int64_t)256 * p->lda * 2 >= ((int64_t)1 << 31) || (int64_t)256 * p->ldb * 2 >= ((int64_t)1 << 31) || (int64_t)257 * p->ldc * 4 >= ((int64_t)1 << 31))
@@ -33,6 +36,7 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
     a.M = p->m; a.K = p->k;
     a.tiles_m = p->m / kBM;
     a.out_scale = p->out_scale;
+    a.a_alias_tiles = (int)(p->a_alias_rows / kBK);
     // tile order: groups of 4 tile rows; a matrix of few tile rows (in_proj's d-major product: the weight is the left operand) walks whole tile
     // columns, so that every streamed right-operand panel is loaded once (tools/scratch/gm_sweep.py: 187 -> 178 us at 2048 x 65536 x 512)
     a.group_m = p->tune_group_m > 0 ? p->tune_group_m : (a.tiles_m <= 16 ? a.tiles_m : 4);
@@ -94,7 +98,9 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
         if (p->n % 16 != 0) return DIMSUM_ERR_SHAPE;
         const int F = p->n / 2;
         const bool img = p->epilogue == DIMSUM_GEMM_EPI_GATED_GELU_SPLIT3;
-        if (p->ldc % 8 != 0 || p->ldc < (img ? 3 : 1) * (int64_t)F || !aligned_to<char>(p->c_ptr, 16) || (int64_t)257 * p->ldc * 2 + 6 * (int64_t)F >= ((int64_t)1 << 31))
+        if (p->c_image_pieces != 0 && p->c_image_pieces != 3 && !(img && p->c_image_pieces == 2)) return DIMSUM_ERR_UNSUPPORTED;
+        a.c_pieces2 = p->c_image_pieces == 2;
+        if (p->ldc % 8 != 0 || p->ldc < (img ? (a.c_pieces2 ? 2 : 3) : 1) * (int64_t)F || !aligned_to<char>(p->c_ptr, 16) || (int64_t)257 * p->ldc * 2 + 6 * (int64_t)F >= ((int64_t)1 << 31))
             return DIMSUM_ERR_STRIDE;
         if (p->bias_ptr && !aligned_to<char>(p->bias_ptr, 16)) return DIMSUM_ERR_STRIDE;
         a.B0 = reinterpret_cast<const char *>(p->b_ptr);

@@ -78,7 +78,8 @@ struct Args {
     int64_t ldx;
     int splits;                    // kVarTN: the reduction is cut into `splits` ranges of K rows each (K = rows per range)
     int64_t c_split_stride;        // elements between the partial results
-    int a_alias_tiles;             // kVarTN: != 0 = K tiles kt >= a_alias_tiles of A are the tiles kt - a_alias_tiles (a [hi; lo] pair read as [hi; hi; lo])
+    int a_alias_tiles;             // != 0 = K tiles kt >= a_alias_tiles of A are the tiles kt - a_alias_tiles: a [hi | lo] pair read as the image [hi | hi | lo]
+    int c_pieces2;                 // kEpiGatedSplit3: the h image is written as the pair [hi | lo] (ldc >= 2 F) for a consumer that reads it with a_alias_tiles
 };
 // tuning variants (bit mask; 0 = the shipped schedule)
 enum { kVarLgkmAfterBarrier = 1, kVarNoEpilogue = 2, kVarNtStores = 4, kVarFullLineStores = 8, kVarNoSetprio = 16, kVarSc1Stores = 32, kVarSc0Stores = 64, kVarKeepX12 = 128, kVarTN = 256 };
@@ -184,9 +185,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
     }
     // stage(kind, kt): the two DMA pieces (k halves) of this wave's row block of half tile `kind` of K tile kt
     const unsigned st_lds = lds0 + w * 2048;
-    auto stage = [&](int slot, const char *base, unsigned voff, int kt) {      // base: wave-uniform (SGPR pair), voff: this lane's byte offset
+    auto stage = [&](int slot, const char *base, unsigned voff, int kt, int alias = 0) {      // base: wave-uniform (SGPR pair), voff: this lane's byte offset
         const unsigned dst = st_lds + (kt & 1) * kParity + slot;
-        const char *s = base + (int64_t)kt * (kBK * 2);
+        const int src_kt = (alias && kt >= alias) ? kt - alias : kt;      // (the LDS parity follows kt, the source tile may be an aliased earlier one)
+        const char *s = base + (int64_t)src_kt * (kBK * 2);
         __builtin_amdgcn_global_load_lds((glb_void_t *)(s + voff), (lds_void_t *)(uintptr_t)dst, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((glb_void_t *)(s + 64 + voff), (lds_void_t *)(uintptr_t)(dst + 1024), 16, 0, 0);
     };
@@ -203,8 +205,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
         __builtin_amdgcn_global_load_lds((glb_void_t *)(s + tn_voff_a[0]), (lds_void_t *)(uintptr_t)dst, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((glb_void_t *)(s + tn_voff_a[1]), (lds_void_t *)(uintptr_t)(dst + 1024), 16, 0, 0);
     };
-    auto stage_a0 = [&](int kt) { if constexpr (kTN) stage_tn_a(kSlotA0, tn_a, kt); else stage(kSlotA0, a_base, a_voff, kt); };
-    auto stage_a1 = [&](int kt) { if constexpr (kTN) stage_tn_a(kSlotA1, tn_a + 256, kt); else stage(kSlotA1, a_base + a_half, a_voff, kt); };
+    auto stage_a0 = [&](int kt) { if constexpr (kTN) stage_tn_a(kSlotA0, tn_a, kt); else stage(kSlotA0, a_base, a_voff, kt, p.a_alias_tiles); };
+    auto stage_a1 = [&](int kt) { if constexpr (kTN) stage_tn_a(kSlotA1, tn_a + 256, kt); else stage(kSlotA1, a_base + a_half, a_voff, kt, p.a_alias_tiles); };
     auto stage_b0 = [&](int kt) { if constexpr (kTN) stage_tn(kSlotB0, tn_b, tn_b_tile, tn_voff_b, kt); else stage(kSlotB0, b_base[0], b_voff[0], kt); };
     auto stage_b1 = [&](int kt) { if constexpr (kTN) stage_tn(kSlotB1, tn_b + 256, tn_b_tile, tn_voff_b, kt); else stage(kSlotB1, b_base[1], b_voff[1], kt); };
 
@@ -591,12 +593,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
             v = odd ? u32x4{v[2], v[3], v[0], v[1]} : v;
             if (live) {
                 __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, 2);
-                if constexpr (kImg) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff + (unsigned)(p.N * 2), 0, 2);
+                if constexpr (kImg) {
+                    if (!p.c_pieces2) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff + (unsigned)(p.N * 2), 0, 2);
+                }
             }
             if constexpr (kImg) {
                 u32x4 l = *reinterpret_cast<const u32x4 *>(src + 65536);
                 l = odd ? u32x4{l[2], l[3], l[0], l[1]} : l;
-                if (live) __builtin_amdgcn_raw_buffer_store_b128(l, rsrc, voff + (unsigned)(p.N * 4), 0, 2);
+                if (live) __builtin_amdgcn_raw_buffer_store_b128(l, rsrc, voff + (unsigned)(p.N * (p.c_pieces2 ? 2 : 4)), 0, 2);
             }
         }
     }

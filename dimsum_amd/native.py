@@ -504,6 +504,30 @@ def split3_rows_t(w):
     return out
 
 
+class PairImage:
+    """split-bf16 left operand image stored as the PAIR [hi | lo]: data (M, 2K) bfloat16. The GEMM kernel reads it as [hi | hi | lo]
+    (a_alias_rows = K: K tiles past the first piece re-read the tiles one piece earlier) -- a third less image traffic than the three-piece
+    form the library GEMM needs; .image3() expands it for a consumer without the kernel."""
+    __slots__ = ("data",)
+
+    def __init__(self, data):
+        self.data = data
+
+    @property
+    def k(self):
+        return self.data.shape[-1] // 2
+
+    def image3(self):
+        K = self.k
+        return torch.cat([self.data[..., :K], self.data[..., :K], self.data[..., K:]], dim=-1)
+
+    def reshape(self, *shape):
+        return PairImage(self.data.reshape(*shape))
+
+    def view(self, *shape):
+        return PairImage(self.data.view(*shape))
+
+
 class F16Image:
     """scaled-fp16 operand image (csrc/common.hpp, f16s): data (..., K) float16 = fp16(x * 2^s), one s per row, inv (...) float32 = 2^-s.
     Quacks like the tensor it replaces where the host layer only reshapes it and hands it to the next GEMM."""
@@ -548,11 +572,18 @@ def rows_f16s(x, want_l1=False):
     return (img, l1) if want_l1 else img
 
 
-def gemm_nt_supported(a, b, gated=False):
-    """shapes the hand-written NT GEMM takes (csrc/gemm_nt_kernel.hpp): 256-row panels of 16-bit rows, 64-deep K tiles"""
+def gemm_nt_supported(a, b, gated=False, pair=False):
+    """shapes the hand-written NT GEMM takes (csrc/gemm_nt_kernel.hpp): 256-row panels of 16-bit rows, 64-deep K tiles.
+    pair: a is the [hi | lo] pair (M, 2C) of a left image over K = 3C (C % 64 == 0)"""
+    if isinstance(a, PairImage):
+        a, pair = a.data, True
     if not (a.is_cuda and a.dim() == 2 and b.dim() == 2 and a.dtype == b.dtype and a.dtype in (torch.bfloat16, torch.float16)):
         return False
     M, K = a.shape
+    if pair:
+        if K % 128 != 0 or a.dtype != torch.bfloat16:
+            return False
+        K = K // 2 * 3
     N = b.shape[0]
     return (b.shape[1] == K and M > 0 and M % 256 == 0 and K % 64 == 0 and K >= 128 and N % (16 if gated else 4) == 0
             and a.stride(1) == 1 and b.stride(1) == 1 and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0
@@ -618,7 +649,7 @@ def gemm_tn(a, b, splits=None, events=None, alias_rows=0):
 
 
 def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=None, tune=None, scales=None, gate_bound=None, residual=None,
-            gate=None, rows_per_batch=None, keep_x12=False):
+            gate=None, rows_per_batch=None, keep_x12=False, pair_out=False):
     """a (M, K) @ b (N, K)^T on the hand-written MFMA kernel, 16-bit operands (bfloat16: split-bf16 images over 3 K; float16: scaled rows),
     fp32 accumulation.
       epilogue "f32"          -> (M, N) float32 (+ bias[N])
@@ -632,13 +663,18 @@ def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=Non
     gate_bound ("gated_f16" over scaled operands): 2-element float32 device tensor {max_n sum_k |w_nk|, max |bias|}: the h image gets a
     per-row power-of-two scale derived from it and the call returns (h16, h_inv).
     events: optional (start, stop) raw hipEvent_t handles recorded at the kernel's dispatch boundaries (bench.py)."""
+    pair_in = isinstance(a, PairImage)         # a: the pair [hi | lo] of a left image, read as [hi | hi | lo]
+    if pair_in:
+        a = a.data
     _gpu(a, b, bias)
     gated = epilogue != "f32"
-    _check(gemm_nt_supported(a, b, gated), "gemm_nt: unsupported operands (M % 256, K % 64, K >= 128, 16-bit K-contiguous rows, 16-byte aligned)")
-    M, K = a.shape
+    _check(gemm_nt_supported(a, b, gated, pair=pair_in), "gemm_nt: unsupported operands (M % 256, K % 64, K >= 128, 16-bit K-contiguous rows, 16-byte aligned)")
+    M, K = a.shape[0], b.shape[1]
     N = b.shape[0]
     P = _lib.GemmParams()
     P.m, P.n, P.k = M, N, K
+    if pair_in:
+        P.a_alias_rows = K // 3
     P.operand_dtype = _DT[a.dtype]
     P.out_scale = float(out_scale)
     P.lda, P.ldb = a.stride(0), b.stride(0)
@@ -660,9 +696,12 @@ def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=Non
                 P.gate_ptr, P.gate_ld, P.rows_per_batch = _ptr(gate), gate.stride(0), rows_per_batch
     elif epilogue == "gated_split3":
         P.epilogue = _lib.GEMM_EPI_GATED_GELU_SPLIT3
+        pieces = 2 if pair_out else 3
+        _check(not (pair_out and keep_x12), "gemm_nt: pair_out is the inference form")
+        P.c_image_pieces = pieces
         if out is None:
-            out = torch.empty((M, 3 * (N // 2)), device=a.device, dtype=torch.bfloat16)
-        _check(out.dtype == torch.bfloat16 and out.shape == (M, 3 * (N // 2)) and out.stride(1) == 1, "gemm_nt: out must be (M, 3F) bfloat16 rows")
+            out = torch.empty((M, pieces * (N // 2)), device=a.device, dtype=torch.bfloat16)
+        _check(out.dtype == torch.bfloat16 and out.shape == (M, pieces * (N // 2)) and out.stride(1) == 1, "gemm_nt: out must be (M, 3F) / (M, 2F) bfloat16 rows")
     elif epilogue == "gated_f16":
         P.epilogue = _lib.GEMM_EPI_GATED_GELU_F16
         if out is None:
@@ -698,6 +737,8 @@ def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=Non
         _lib.check(_lib.load().dimsum_gemm_nt(P, _stream(a)), "gemm_nt")
     if x12 is not None:
         return out, x12
+    if pair_out:
+        return PairImage(out)
     return out if h_inv is None else F16Image(out, h_inv)
 
 

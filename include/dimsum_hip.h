@@ -405,11 +405,13 @@ typedef struct {
     int32_t rows_per_batch;
     /* GATED_GELU_SPLIT3, training forward (mlp.py:66-70 under autograd): when non-NULL the bias-free accumulators [x1 | x2] are ALSO stored
        as float32 (m, n) rows with stride x12_ld -- what the gated-GeLU adjoint of the backward reads; bf16 images only. */
-    int32_t reserved0;
+    int32_t c_image_pieces;       /* GATED_GELU_SPLIT3: 0 / 3 = the image [hi | hi | lo] (ldc >= 3 F); 2 = the pair [hi | lo] (ldc >= 2 F), for a consumer that
+                                     reads it with a_alias_rows: a third less image traffic, the same three products */
     void *x12_ptr;
     int64_t x12_ld;
-    /* dimsum_gemm_tn only: != 0 = the A operand's reduction rows r >= a_alias_rows are the rows r - a_alias_rows of a_ptr (k = 3 a_alias_rows):
-       a [hi; lo] pair of planes serves as the row stack [hi; hi; lo] of a left operand image without storing hi twice. % 64 == 0. */
+    /* != 0 = the A operand's reduction indices r >= a_alias_rows are the indices r - a_alias_rows of a_ptr (k = 3 a_alias_rows, % 64 == 0): a
+       [hi | lo] pair (dimsum_gemm_nt: 2 C columns per row; dimsum_gemm_tn: a [hi; lo] pair of planes) serves as the left operand image
+       [hi | hi | lo] without storing hi twice. */
     int64_t a_alias_rows;
 } dimsum_gemm_params_t;
 

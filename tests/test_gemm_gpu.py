@@ -223,3 +223,27 @@ def test_out_proj_from_the_scan_planes():
     assert (y.double() - ref).abs().max().item() / ref.abs().max().item() < 2e-5
     lib = torch.nn.functional.linear(out_z.transpose(1, 2).reshape(B * L, D), w)        # what the host layer called before (fp32 operands)
     assert (y - lib).abs().max().item() / ref.abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("M,F,H", [(512, 256, 128), (256, 1536, 384)])
+def test_pair_image_is_the_same_product_bit_for_bit(M, F, H):
+    """the gated epilogue's h image as the pair [hi | lo] (a third less to store) and the w3 GEMM reading it as [hi | hi | lo]
+    (a_alias_rows): the same tiles in the same order -- the result equals the three-piece path bit for bit; a consumer without the
+    kernel expands the pair"""
+    from dimsum_amd import native
+    x = _rnd((M, H), torch.float32, 4)
+    w12 = _rnd((2 * F, H), torch.float32, 5, scale=H ** -0.5)
+    w3 = _rnd((H, F), torch.float32, 7, scale=F ** -0.5)
+    bias = _rnd((2 * F,), torch.float32, 6, scale=0.1)
+    x3, w12i, w3i = native.split3_rows(x, left=True), native.split3_rows(w12, left=False), native.split3_rows(w3, left=False)
+    h3 = native.gemm_nt(x3, w12i, bias=bias, epilogue="gated_split3")
+    hp = native.gemm_nt(x3, w12i, bias=bias, epilogue="gated_split3", pair_out=True)
+    assert isinstance(hp, native.PairImage) and hp.data.shape == (M, 2 * F)
+    assert torch.equal(hp.data[:, :F], h3[:, :F]) and torch.equal(hp.data[:, F:], h3[:, 2 * F:])
+    assert torch.equal(hp.image3(), h3)
+    y3 = native.gemm_nt(h3, w3i)
+    yp = native.gemm_nt(hp, w3i)
+    assert torch.equal(yp, y3)
+    res, gate = _rnd((M, H), torch.float32, 8), _rnd((M // 256, H), torch.float32, 9)
+    assert torch.equal(native.gemm_nt(hp, w3i, residual=res, gate=gate, rows_per_batch=256), native.gemm_nt(h3, w3i, residual=res, gate=gate, rows_per_batch=256))
+    assert not native.gemm_nt_supported(native.PairImage(hp.data[:, :F + 32]), w3i)
