@@ -88,7 +88,8 @@ class CrossAttentionFusion(nn.Module):
                                              f16s=(x1.inv.reshape(B, N), x2.inv.reshape(B, N), gemm.attn_kv_bound(self.qkv1.weight, b1, self.qkv2.weight, b2)))
             else:
                 f3 = native.xattn_fusion_fwd(qkv1, qkv2, self.num_heads, bias1=None if b1 is None else b1.float().contiguous(),
-                                             bias2=None if b2 is None else b2.float().contiguous(), split_bf16=True, split3=True)
+                                             bias2=None if b2 is None else b2.float().contiguous(), split_bf16=True,
+                                             split3="pair" if isinstance(x1, native.PairImage) else True)
             if residual is not None:
                 pb = None if self.proj.bias is None else self.proj.bias.float()
                 y = gemm.linear_split3(f3.reshape(B * N, -1), self.proj.weight, bias=pb, residual=residual.reshape(B * N, -1))

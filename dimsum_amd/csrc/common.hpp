@@ -93,6 +93,21 @@ template <bool kLeft> __device__ __forceinline__ void st_split3(unsigned short *
     *reinterpret_cast<uint2 *>(row + 2 * N + c) = kLeft ? make_uint2(l0, l1) : make_uint2(h0, h1);
 }
 
+// the left image of 4 consecutive columns, either as the three pieces [hi | hi | lo] (row: 3 N) or as the pair [hi | lo] (row: 2 N) that the
+// hand-written GEMM reads as [hi | hi | lo] (dimsum_gemm_params_t.a_alias_rows): the producers' y_split3 / out_split3 == 3
+__device__ __forceinline__ void st_split_left(unsigned short *row, int64_t c, int64_t N, const f32x4 &v, bool pair) {
+    unsigned h0, l0, h1, l1;
+    split2(v.v[0], v.v[1], h0, l0);
+    split2(v.v[2], v.v[3], h1, l1);
+    *reinterpret_cast<uint2 *>(row + c) = make_uint2(h0, h1);
+    if (pair) {
+        *reinterpret_cast<uint2 *>(row + N + c) = make_uint2(l0, l1);
+    } else {
+        *reinterpret_cast<uint2 *>(row + N + c) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2 *>(row + 2 * N + c) = make_uint2(l0, l1);
+    }
+}
+
 // ---- scaled-fp16 operand images ("f16s") ------------------------------------------------------------------------------
 // The reference multiplies under TF32 (train.py:20-21): operands rounded to 10 mantissa bits, fp32 accumulation. fp16 has exactly that
 // mantissa; what it lacks is range, so a row travels as fp16(row * 2^s) plus the exact power of two 2^-s that the consuming GEMM's

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const dimsum_norm_params_
                     r[i] = o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ymax = fmaxf(ymax, fabsf(o.v[e]));
-                } else if (p.y_split3) st_split3<true>(reinterpret_cast<unsigned short *>(p.y_ptr) + row * p.y_row_stride, c, N, o);
+                } else if (p.y_split3) st_split_left(reinterpret_cast<unsigned short *>(p.y_ptr) + row * p.y_row_stride, c, N, o, p.y_split3 == 3);
                 else st_cols<TY>(y, c, N, vec, o);
             }
         }
@@ -278,7 +278,7 @@ extern "C" int dimsum_norm_fwd(const dimsum_norm_params_t *p, void *stream) {
             return DIMSUM_ERR_STRIDE;
     } else
     // split3 output: bf16 rows of 3 N, written 8 bytes at a time
-    if (p->y_split3 && (p->out_dtype != DIMSUM_BF16 || p->cols % 4 != 0 || p->y_row_stride % 4 != 0 || p->y_row_stride < 3 * (int64_t)p->cols ||
+    if (p->y_split3 && (p->out_dtype != DIMSUM_BF16 || p->cols % 4 != 0 || p->y_row_stride % 4 != 0 || p->y_row_stride < (p->y_split3 == 3 ? 2 : 3) * (int64_t)p->cols ||
                         !dimsum::aligned_to<char>(p->y_ptr, 8)))
         return DIMSUM_ERR_STRIDE;
     if (p->rows == 0) return DIMSUM_OK;

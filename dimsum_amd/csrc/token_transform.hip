@@ -181,8 +181,8 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
         }
         if constexpr (VEC == 4) {
             if (p.y_split3) {       // split-bf16 operand image of the Linear that consumes y: rows of 3 C bf16, strides in bf16 elements
-                st_split3<true>(reinterpret_cast<unsigned short *>(p.y_ptr) + (int64_t)b * p.y_batch_stride + (int64_t)tok * p.y_token_stride, c, C,
-                                f32x4{{o[0], o[1], o[2], o[3]}});
+                st_split_left(reinterpret_cast<unsigned short *>(p.y_ptr) + (int64_t)b * p.y_batch_stride + (int64_t)tok * p.y_token_stride, c, C,
+                              f32x4{{o[0], o[1], o[2], o[3]}}, p.y_split3 == 3);
                 return;
             }
         }
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void token_rows_kernel(const dimsum_tt_params_
 #pragma unroll
             for (int i = 0; i < kPieces; ++i) {
                 const int c = (i * 64 + lane) * 4;
-                if (c < C) st_split3<true>(y, c, C, v[i]);
+                if (c < C) st_split_left(y, c, C, v[i], p.y_split3 == 3);
             }
         } else {
             float *y = reinterpret_cast<float *>(p.y_ptr) + (int64_t)b * p.y_batch_stride + (int64_t)dst * p.y_token_stride;
@@ -563,7 +563,7 @@ extern "C" int dimsum_token_transform(const dimsum_tt_params_t *p, void *stream)
         if (!vec || p->y_token_stride < p->channels || p->channels > (p->kind == DIMSUM_TT_NONE ? 2048 : 4 * kTTThreads) || p->w_ptr || p->tsum_ptr)
             return DIMSUM_ERR_STRIDE;
     } else
-    if (p->y_split3 && (!vec || !p->y_ptr || p->y_token_stride < 3 * (int64_t)p->channels)) return DIMSUM_ERR_STRIDE;   // image rows: 8-byte pieces
+    if (p->y_split3 && (!vec || !p->y_ptr || p->y_token_stride < (p->y_split3 == 3 ? 2 : 3) * (int64_t)p->channels)) return DIMSUM_ERR_STRIDE;   // image rows: 8-byte pieces
     return vec ? launch_tt<4>(*p, s) : launch_tt<1>(*p, s);
 }
 

@@ -444,8 +444,12 @@ __global__ __launch_bounds__(256, (QT == 2 && HD <= 64) ? 3 : (QT == 2 ? 2 : 1))
                         const uint4 hv = make_uint4(hw[4 * hlf], hw[4 * hlf + 1], hw[4 * hlf + 2], hw[4 * hlf + 3]);
                         const uint4 lv = make_uint4(lw[4 * hlf], lw[4 * hlf + 1], lw[4 * hlf + 2], lw[4 * hlf + 3]);
                         *reinterpret_cast<uint4 *>(d0 + 8 * hlf) = hv;
-                        *reinterpret_cast<uint4 *>(d0 + N + 8 * hlf) = hv;
-                        *reinterpret_cast<uint4 *>(d0 + 2 * N + 8 * hlf) = lv;
+                        if (p.out_split3 == 3) {           // the pair [hi | lo]
+                            *reinterpret_cast<uint4 *>(d0 + N + 8 * hlf) = lv;
+                        } else {
+                            *reinterpret_cast<uint4 *>(d0 + N + 8 * hlf) = hv;
+                            *reinterpret_cast<uint4 *>(d0 + 2 * N + 8 * hlf) = lv;
+                        }
                     }
                 }
             }
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(256, (QT == 2 && HD <= 64) ? 3 : (QT == 2 ? 2 : 1))
 #pragma unroll
                 for (int e = kTr; e < ET; ++e) {
                     const int e0 = e * 16 + kg * 4;
-                    if (e0 < HD) st_split3<true>(img, col0 + e0, N, f32x4{{o[t][e][0] * inv, o[t][e][1] * inv, o[t][e][2] * inv, o[t][e][3] * inv}});
+                    if (e0 < HD) st_split_left(img, col0 + e0, N, f32x4{{o[t][e][0] * inv, o[t][e][1] * inv, o[t][e][2] * inv, o[t][e][3] * inv}}, p.out_split3 == 3);
                 }
             }
         } else if (valid) {
@@ -499,7 +503,8 @@ extern "C" int dimsum_xattn_fusion_fwd(const dimsum_xattn_params_t *p, void *str
     }
     if (p->precision != 0 && p->precision != 1) return DIMSUM_ERR_SHAPE;
     // the operand image is written in 16-byte pieces (8 bf16): its base and both strides must keep that alignment
-    if (p->out_split3 && (p->precision != 1 || p->out_token_stride < 3 * (int64_t)(self_attn ? 1 : 2) * p->heads * p->head_dim ||
+    if (p->out_split3 != 0 && p->out_split3 != 1 && p->out_split3 != 3) return DIMSUM_ERR_SHAPE;
+    if (p->out_split3 && (p->precision != 1 || p->out_token_stride < (p->out_split3 == 3 ? 2 : 3) * (int64_t)(self_attn ? 1 : 2) * p->heads * p->head_dim ||
                           reinterpret_cast<uintptr_t>(p->out_ptr) % 16 != 0 || p->out_batch_stride % 8 != 0 || p->out_token_stride % 8 != 0))
         return DIMSUM_ERR_STRIDE;
     if (p->precision == 1) {

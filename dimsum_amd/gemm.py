@@ -253,9 +253,10 @@ def matmul_wx(weight, xt):
     return torch.mm(_w16(weight), xt.to(torch.float16), out_dtype=torch.float32)
 
 
-def split3_enabled(x, weight, producer="token"):
+def split3_enabled(x, weight, producer="token", left=True):
     """the operand-image carriers serve exactly the launches the library would run as split-bf16 fp32 GEMMs: inference, fp32, allow_tf32.
-    -> False, True (split-bf16 images: three bf16 products per fp32 product) or "f16s" (policy "f16s": scaled-fp16 images, ONE product):
+    -> False, True (split-bf16 images: three bf16 products per fp32 product), "pair" (the same image stored as [hi | lo], `left` consumers
+    on the hand-written GEMM) or "f16s" (policy "f16s": scaled-fp16 images, ONE product):
     the value is what the producer kernels take as their `split3` argument. producer: which kernel family writes the image ("token":
     csrc/token_transform.hip, "norm": csrc/norm.hip) -- their scaled-fp16 variants hold rows of different width."""
     import os
@@ -269,7 +270,14 @@ def split3_enabled(x, weight, producer="token"):
         return False
     # the weight image is rebuilt per call (one ~14 us launch): it pays from a few thousand rows on, and in the launch-bound
     # small-batch regime every extra launch costs wall time -- fp32 operands below DIMSUM_SPLIT3_MIN_ROWS (default 8192) rows
-    return mode if x.numel() // x.shape[-1] >= int(os.environ.get("DIMSUM_SPLIT3_MIN_ROWS", "8192")) else False
+    if x.numel() // x.shape[-1] < int(os.environ.get("DIMSUM_SPLIT3_MIN_ROWS", "8192")):
+        return False
+    # "pair": the image as [hi | lo] where its consumer is the LEFT operand of the hand-written GEMM, which reads it as [hi | hi | lo]
+    # (a_alias_rows): the producer writes a third less. (in_proj takes its image as the right operand: three pieces.)
+    if (mode is True and left and own_gemm_enabled() and x.shape[-1] % 64 == 0 and (x.numel() // x.shape[-1]) % 256 == 0
+            and os.environ.get("DIMSUM_PAIR_IMAGES", "1") != "0"):
+        return "pair"
+    return mode
 
 
 def weight_f16s(weight, want_l1=False):
@@ -372,6 +380,8 @@ def gated_mlp_hidden_split3(x3, w12, b12):
         # stores a third less (1.6 -> 1.07 GB per MLP at 65536 x 4096)
         pair = (w12.shape[0] // 2) % 64 == 0 and os.environ.get("DIMSUM_PAIR_IMAGES", "1") != "0"
         return native.gemm_nt(x3, w3i, bias=b12, epilogue="gated_split3", pair_out=pair)
+    if isinstance(x3, native.PairImage):
+        x3 = x3.image3()
     return native.gated_gelu_fwd(torch.mm(x3, w3i.t(), out_dtype=torch.float32), b12, split3=True)
 
 

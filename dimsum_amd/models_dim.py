@@ -213,7 +213,7 @@ class Attention(nn.Module):
                     o3 = native.xattn_fusion_fwd(qkv, None, self.num_heads, bias1=qb, split3="f16s",
                                                  f16s=(x3.inv.reshape(B, N), None, gemm.attn_kv_bound(self.qkv.weight, self.qkv.bias)))
                 else:
-                    o3 = native.xattn_fusion_fwd(qkv, None, self.num_heads, bias1=qb, split_bf16=True, split3=True)
+                    o3 = native.xattn_fusion_fwd(qkv, None, self.num_heads, bias1=qb, split_bf16=True, split3="pair" if isinstance(x3, native.PairImage) else True)
                 if residual is not None:
                     pb = None if self.proj.bias is None else self.proj.bias.float()
                     y = gemm.linear_split3(o3.reshape(B * N, -1), self.proj.weight, bias=pb, residual=residual.reshape(B * N, C), gate=gate, rows_per_batch=N)
@@ -292,9 +292,9 @@ def _mlp_tail(mlp, x, normed, shift, scale, gate):
 def _mix_through_images(mixer, hidden_states, kind, table, shift, scale, c):
     """mixer(pre_mixer(hidden_states)); at inference under allow_tf32 the pre-mixer pass writes the in_proj operand as a
     split-bf16 image (gemm.py, split3) instead of fp32"""
-    if getattr(mixer, "takes_image", lambda: False)() and gemm.split3_enabled(hidden_states, mixer.in_proj.weight):
+    if getattr(mixer, "takes_image", lambda: False)() and gemm.split3_enabled(hidden_states, mixer.in_proj.weight, left=False):
         return mixer(None, c, x3=token_ops.pre_mixer(hidden_states, kind, table, shift, scale,
-                                                     split3=gemm.split3_enabled(hidden_states, mixer.in_proj.weight)))
+                                                     split3=gemm.split3_enabled(hidden_states, mixer.in_proj.weight, left=False)))
     return mixer(token_ops.pre_mixer(hidden_states, kind, table, shift, scale), c)
 
 

@@ -41,6 +41,8 @@ def _ptr(t):
 # ---------------------------------------------------------------------------------------------------------------------
 # selective_scan_cuda.fwd / .bwd   (mamba/csrc/selective_scan/selective_scan.cpp:226-492)
 # ---------------------------------------------------------------------------------------------------------------------
+# the producers' image modes (dimsum_*_params_t.y_split3 / out_split3): True = three pieces [hi | hi | lo], "f16s" = scaled fp16, "pair" = [hi | lo]
+_SPLIT_MODE = {"f16s": 2, "pair": 3}
 _scan_fwd_variant = 0     # dimsum_ssm_params_t.kernel_variant of the calls made from here: 0 = the library's own choice
 
 
@@ -252,7 +254,7 @@ def layer_norm_fwd(x, weight, bias, eps, residual=None, out_dtype=None, residual
         y_inv = torch.empty((M,), device=x.device, dtype=torch.float32)
     elif split3:
         _check(N % 4 == 0 and out_dtype in (None, torch.bfloat16), "layer_norm_fwd: split3 needs N % 4 == 0 (bfloat16 output)")
-        y = torch.empty((M, 3 * N), device=x.device, dtype=torch.bfloat16)
+        y = torch.empty((M, (2 if split3 == "pair" else 3) * N), device=x.device, dtype=torch.bfloat16)
     else:
         y = torch.empty((M, N), device=x.device, dtype=x.dtype if out_dtype is None else out_dtype)
     need_res_out = residual is not None or x_bias is not None or (residual_dtype is not None and residual_dtype != x.dtype)
@@ -264,7 +266,7 @@ def layer_norm_fwd(x, weight, bias, eps, residual=None, out_dtype=None, residual
     if M > 0:
         P = _lib.NormParams()
         P.rows, P.cols, P.is_rms_norm, P.eps = M, N, int(is_rms_norm), float(eps)
-        P.x_dtype, P.out_dtype, P.y_split3 = _DT[x.dtype], _DT[y.dtype], (2 if split3 == "f16s" else int(bool(split3)))
+        P.x_dtype, P.out_dtype, P.y_split3 = _DT[x.dtype], _DT[y.dtype], _SPLIT_MODE.get(split3, int(bool(split3)))
         P.y_inv_scale_ptr = _ptr(y_inv)
         P.residual_dtype = _DT[residual_out.dtype] if residual_out is not None else _DT[x.dtype]
         P.x_row_stride, P.y_row_stride = x.stride(0), y.stride(0)
@@ -292,6 +294,8 @@ def layer_norm_fwd(x, weight, bias, eps, residual=None, out_dtype=None, residual
             _lib.check(_lib.load().dimsum_norm_fwd(P, _stream(x)), "layer_norm_fwd")
     if y_inv is not None:
         y = F16Image(y, y_inv)
+    elif split3 == "pair":
+        y = PairImage(y)
     return y, mean, rstd, residual_out if residual_out is not None else x
 
 
@@ -413,7 +417,7 @@ def token_transform(x, kind, forward, in_index=None, out_index=None, gate=None, 
         y_inv = torch.empty((B, L), device=x.device, dtype=torch.float32)
     elif split3:
         _check(want_y and C % 4 == 0, "token_transform: split3 needs an output and channels % 4 == 0")
-        y = torch.empty((B, L, 3 * C), device=x.device, dtype=torch.bfloat16)
+        y = torch.empty((B, L, (2 if split3 == "pair" else 3) * C), device=x.device, dtype=torch.bfloat16)
     else:
         y = torch.empty((B, L, C), device=x.device, dtype=torch.float32) if want_y else None
     mods = [m for m in (gate, scale, shift) if m is not None]
@@ -437,7 +441,7 @@ def token_transform(x, kind, forward, in_index=None, out_index=None, gate=None, 
     if B > 0:
         P = _lib.TtParams()
         P.batch, P.tokens, P.channels, P.grid, P.kind = B, L, C, grid, _TT_KIND[(kind, bool(forward))]
-        P.y_split3 = 2 if split3 == "f16s" else int(bool(split3))
+        P.y_split3 = _SPLIT_MODE.get(split3, int(bool(split3)))
         P.y_inv_scale_ptr = _ptr(y_inv)
         P.x_batch_stride, P.x_token_stride = x.stride(0), x.stride(1)
         if y is not None:
@@ -455,6 +459,8 @@ def token_transform(x, kind, forward, in_index=None, out_index=None, gate=None, 
             _lib.check(_lib.load().dimsum_token_transform(P, _stream(x)), "token_transform")
     if y_inv is not None:
         return F16Image(y, y_inv)
+    if split3 == "pair":
+        y = PairImage(y)
     if want_tsum:
         return (y, wdot, wsum, tsum)
     return y if w is None else (y, wdot, wsum)
@@ -521,11 +527,17 @@ class PairImage:
         K = self.k
         return torch.cat([self.data[..., :K], self.data[..., :K], self.data[..., K:]], dim=-1)
 
+    @property
+    def shape(self):
+        return self.data.shape
+
     def reshape(self, *shape):
         return PairImage(self.data.reshape(*shape))
 
-    def view(self, *shape):
-        return PairImage(self.data.view(*shape))
+    view = reshape
+
+    def record_stream(self, stream):
+        self.data.record_stream(stream)
 
 
 class F16Image:
@@ -802,7 +814,7 @@ def xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=False, bias1=None, bias2=None, 
         out_inv = torch.empty((B, L), device=qkv1.device, dtype=torch.float32)
     elif split3:
         _check(split_bf16, "xattn_fusion: the operand image output exists for the split-bf16 kernel only")
-        out = torch.empty((B, L, 3 * nd * heads * hd), device=qkv1.device, dtype=torch.bfloat16)
+        out = torch.empty((B, L, (2 if split3 == "pair" else 3) * nd * heads * hd), device=qkv1.device, dtype=torch.bfloat16)
     else:
         out = torch.empty((B, L, nd * heads * hd), device=qkv1.device, dtype=torch.float32)
     lse = torch.empty((B, nd, heads, L), device=qkv1.device, dtype=torch.float32) if need_lse else None
@@ -814,7 +826,7 @@ def xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=False, bias1=None, bias2=None, 
         P.qkv1_ptr, P.qkv2_ptr, P.out_ptr, P.lse_ptr = _ptr(qkv1), _ptr(qkv2), _ptr(out), _ptr(lse)
         P.bias1_ptr, P.bias2_ptr = _ptr(bias1), _ptr(bias2)
         P.precision = 1 if split_bf16 else 0
-        P.out_split3 = 2 if split3 == "f16s" else int(bool(split3))
+        P.out_split3 = _SPLIT_MODE.get(split3, int(bool(split3)))
         if f16s is not None:
             P.precision = 2
             P.x1_inv_ptr, P.x2_inv_ptr, P.kv_bound_ptr, P.out_inv_ptr = _ptr(x1_inv), _ptr(x2_inv), _ptr(kv_bound), _ptr(out_inv)
@@ -822,6 +834,8 @@ def xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=False, bias1=None, bias2=None, 
             _lib.check(_lib.load().dimsum_xattn_fusion_fwd(P, _stream(qkv1)), "xattn_fusion_fwd")
     if out_inv is not None:
         out = F16Image(out, out_inv)
+    elif split3 == "pair":
+        out = PairImage(out)
     return (out, lse) if need_lse else out
 
 

@@ -406,3 +406,37 @@ def test_mamba_out_proj_from_the_scan_planes_matches_the_fp32_operand_path(monke
     ref = outs["0"]
     assert not torch.equal(outs["1"], ref)
     assert (outs["1"] - ref).abs().max().item() / ref.abs().max().item() < 2e-5
+
+
+def test_producers_write_the_pair_image_as_hi_lo_of_their_three_piece_image():
+    """split3="pair": every producer of a LEFT operand image (norm pass, token passes with and without a transform, attention fusion) writes
+    [hi | lo] -- the first and the last third of the [hi | hi | lo] image it writes otherwise, bit for bit; PairImage.image3() restores it"""
+    from dimsum_amd import native
+    g = torch.Generator(device="cuda").manual_seed(11)
+    rn = lambda *s: torch.randn(s, device="cuda", generator=g)
+
+    def check(pair, three, C):
+        assert isinstance(pair, native.PairImage) and pair.data.shape[-1] == 2 * C and three.shape[-1] == 3 * C
+        assert torch.equal(pair.data[..., :C], three[..., :C]) and torch.equal(pair.data[..., C:], three[..., 2 * C:])
+        assert torch.equal(pair.image3(), three)
+
+    M, N, L = 96, 384, 16
+    x, res, w, xb = rn(M, N), rn(M, N), torch.rand(N, device="cuda", generator=g) + 0.5, rn(N)
+    kw = dict(residual=res, is_rms_norm=True, x_bias=xb, mod_scale=0.1 * rn(M // L, N), mod_shift=rn(M // L, N), rows_per_batch=L)
+    check(native.layer_norm_fwd(x, w, None, 1e-5, split3="pair", **kw)[0], native.layer_norm_fwd(x, w, None, 1e-5, split3=True, **kw)[0], N)
+    B, L, C = 3, 64, 40
+    wide = rn(B, L, 2 * C)
+    xt, rest = wide[:, :, :C], wide[:, :, C:]
+    sc, sh = 0.1 * rn(B, C), rn(B, C)
+    perm = torch.randperm(L, device="cuda", generator=g).to(torch.int32)
+    for kind in ("none", "haar"):
+        for fwd, kw in ((True, dict(out_index=perm, scale=sc, shift=sh)), (False, dict(in_index=perm, gate=sc, residual=rest))):
+            check(native.token_transform(xt, kind, fwd, split3="pair", **kw), native.token_transform(xt, kind, fwd, split3=True, **kw), C)
+    for hd, self_attn in ((64, False), (72, False), (24, True)):
+        H = 4
+        q1 = rn(2, 200, 3 * H * hd)
+        q2 = None if self_attn else rn(2, 200, 3 * H * hd)
+        b1 = rn(3 * H * hd)
+        b2 = None if self_attn else rn(3 * H * hd)
+        three = native.xattn_fusion_fwd(q1, q2, H, bias1=b1, bias2=b2, split_bf16=True, split3=True)
+        check(native.xattn_fusion_fwd(q1, q2, H, bias1=b1, bias2=b2, split_bf16=True, split3="pair"), three, three.shape[-1] // 3)
