@@ -23,7 +23,9 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
     if (p->m <= 0 || p->n <= 0 || p->k < 2 * kBK || p->m % kBM != 0 || p->k % kBK != 0 || p->n % 4 != 0) return DIMSUM_ERR_SHAPE;
     // a_alias_rows = C: the A rows are [hi | lo] pairs (2 C columns) read as the left image [hi | hi | lo] over k = 3 C
     if (p->a_alias_rows != 0 && (p->a_alias_rows < 0 || p->a_alias_rows % kBK != 0 || p->k != 3 * p->a_alias_rows)) return DIMSUM_ERR_SHAPE;
-    if (p->lda % 8 != 0 || p->ldb % 8 != 0 || p->lda < (p->a_alias_rows ? 2 * p->a_alias_rows : p->k) || p->ldb < p->k || !aligned_to<char>(p->a_ptr, 16) ||
+    if (p->b_alias_rows != 0 && (p->b_alias_rows < 0 || p->b_alias_rows % kBK != 0 || p->k != 3 * p->b_alias_rows || p->epilogue != DIMSUM_GEMM_EPI_F32)) return DIMSUM_ERR_SHAPE;
+    if (p->lda % 8 != 0 || p->ldb % 8 != 0 || p->lda < (p->a_alias_rows ? 2 * p->a_alias_rows : p->k) || p->ldb < (p->b_alias_rows ? 2 * p->b_alias_rows : p->k) ||
+        !aligned_to<char>(p->a_ptr, 16) ||
         !aligned_to<char>(p->b_ptr, 16))
         return DIMSUM_ERR_STRIDE;
     // one 32-bit byte offset per lane inside a 256-row panel
@@ -37,6 +39,7 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
     a.tiles_m = p->m / kBM;
     a.out_scale = p->out_scale;
     a.a_alias_tiles = (int)(p->a_alias_rows / kBK);
+    a.b_alias_tiles = (int)(p->b_alias_rows / kBK);
     // tile order: groups of 4 tile rows; a matrix of few tile rows (in_proj's d-major product: the weight is the left operand) walks whole tile
     // columns, so that every streamed right-operand panel is loaded once (tools/scratch/gm_sweep.py: 187 -> 178 us at 2048 x 65536 x 512)
     a.group_m = p->tune_group_m > 0 ? p->tune_group_m : (a.tiles_m <= 16 ? a.tiles_m : 4);
@@ -152,6 +155,7 @@ extern "C" int dimsum_gemm_tn(const dimsum_gemm_params_t *p, int32_t splits, int
     a.tiles_m = p->m / kBM;
     a.tiles_n = p->n / kBN;
     a.group_m = p->tune_group_m > 0 ? p->tune_group_m : (a.tiles_m <= 16 ? a.tiles_m : 4);
+    if (p->b_alias_rows != 0) return DIMSUM_ERR_UNSUPPORTED;
     if (p->a_alias_rows != 0) {
         if (splits != 1 || p->a_alias_rows < 0 || p->a_alias_rows % kBK != 0 || p->k != 3 * p->a_alias_rows) return DIMSUM_ERR_SHAPE;
         a.a_alias_tiles = (int)(p->a_alias_rows / kBK);

@@ -79,6 +79,7 @@ struct Args {
     int splits;                    // kVarTN: the reduction is cut into `splits` ranges of K rows each (K = rows per range)
     int64_t c_split_stride;        // elements between the partial results
     int a_alias_tiles;             // != 0 = K tiles kt >= a_alias_tiles of A are the tiles kt - a_alias_tiles: a [hi | lo] pair read as the image [hi | hi | lo]
+    int b_alias_tiles;             // the same for the B rows (NT only: in_proj, whose activation image is the right operand)
     int c_pieces2;                 // kEpiGatedSplit3: the h image is written as the pair [hi | lo] (ldc >= 2 F) for a consumer that reads it with a_alias_tiles
 };
 // tuning variants (bit mask; 0 = the shipped schedule)
@@ -207,8 +208,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
     };
     auto stage_a0 = [&](int kt) { if constexpr (kTN) stage_tn_a(kSlotA0, tn_a, kt); else stage(kSlotA0, a_base, a_voff, kt, p.a_alias_tiles); };
     auto stage_a1 = [&](int kt) { if constexpr (kTN) stage_tn_a(kSlotA1, tn_a + 256, kt); else stage(kSlotA1, a_base + a_half, a_voff, kt, p.a_alias_tiles); };
-    auto stage_b0 = [&](int kt) { if constexpr (kTN) stage_tn(kSlotB0, tn_b, tn_b_tile, tn_voff_b, kt); else stage(kSlotB0, b_base[0], b_voff[0], kt); };
-    auto stage_b1 = [&](int kt) { if constexpr (kTN) stage_tn(kSlotB1, tn_b + 256, tn_b_tile, tn_voff_b, kt); else stage(kSlotB1, b_base[1], b_voff[1], kt); };
+    auto stage_b0 = [&](int kt) { if constexpr (kTN) stage_tn(kSlotB0, tn_b, tn_b_tile, tn_voff_b, kt); else stage(kSlotB0, b_base[0], b_voff[0], kt, p.b_alias_tiles); };
+    auto stage_b1 = [&](int kt) { if constexpr (kTN) stage_tn(kSlotB1, tn_b + 256, tn_b_tile, tn_voff_b, kt); else stage(kSlotB1, b_base[1], b_voff[1], kt, p.b_alias_tiles); };
 
     // ---- operand read addresses: lane l reads row l & 15, k chunk l >> 4 of a subtile (swizzled: rows 8-15 swap chunk pairs)
     const unsigned rd = (unsigned)((lane & 15) * 64 + (((lane >> 4) ^ (((lane >> 3) & 1) << 1)) * 16));

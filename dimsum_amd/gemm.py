@@ -272,9 +272,9 @@ def split3_enabled(x, weight, producer="token", left=True):
     # small-batch regime every extra launch costs wall time -- fp32 operands below DIMSUM_SPLIT3_MIN_ROWS (default 8192) rows
     if x.numel() // x.shape[-1] < int(os.environ.get("DIMSUM_SPLIT3_MIN_ROWS", "8192")):
         return False
-    # "pair": the image as [hi | lo] where its consumer is the LEFT operand of the hand-written GEMM, which reads it as [hi | hi | lo]
-    # (a_alias_rows): the producer writes a third less. (in_proj takes its image as the right operand: three pieces.)
-    if (mode is True and left and own_gemm_enabled() and x.shape[-1] % 64 == 0 and (x.numel() // x.shape[-1]) % 256 == 0
+    # "pair": the image as [hi | lo] where its consumer is the hand-written GEMM, which reads it as [hi | hi | lo] (a_alias_rows; b_alias_rows
+    # for in_proj, whose activation image is the RIGHT operand: left=False): the producer writes a third less.
+    if (mode is True and own_gemm_enabled() and x.shape[-1] % 64 == 0 and (x.numel() // x.shape[-1] if left else weight.shape[0]) % 256 == 0
             and os.environ.get("DIMSUM_PAIR_IMAGES", "1") != "0"):
         return "pair"
     return mode
@@ -356,7 +356,10 @@ def matmul_wx_split3(weight, x3):
     from . import native
     if isinstance(x3, native.F16Image):
         return _nt_f16s(weight_f16s(weight), x3)
-    return _nt(weight_image(weight), x3)
+    w3i = weight_image(weight)
+    if isinstance(x3, native.PairImage) and not (own_gemm_enabled() and native.gemm_nt_supported(w3i, x3)):
+        x3 = x3.image3()
+    return _nt(w3i, x3)
 
 
 def gated_mlp_hidden_split3(x3, w12, b12):

@@ -584,20 +584,26 @@ def rows_f16s(x, want_l1=False):
     return (img, l1) if want_l1 else img
 
 
-def gemm_nt_supported(a, b, gated=False, pair=False):
+def gemm_nt_supported(a, b, gated=False, pair=False, pair_b=False):
     """shapes the hand-written NT GEMM takes (csrc/gemm_nt_kernel.hpp): 256-row panels of 16-bit rows, 64-deep K tiles.
-    pair: a is the [hi | lo] pair (M, 2C) of a left image over K = 3C (C % 64 == 0)"""
+    pair / pair_b (or a PairImage operand): that operand is the [hi | lo] pair (rows of 2C) of a split-bf16 image over K = 3C (C % 64 == 0)"""
     if isinstance(a, PairImage):
         a, pair = a.data, True
+    if isinstance(b, PairImage):
+        b, pair_b = b.data, True
     if not (a.is_cuda and a.dim() == 2 and b.dim() == 2 and a.dtype == b.dtype and a.dtype in (torch.bfloat16, torch.float16)):
         return False
     M, K = a.shape
+    N, Kb = b.shape
     if pair:
         if K % 128 != 0 or a.dtype != torch.bfloat16:
             return False
         K = K // 2 * 3
-    N = b.shape[0]
-    return (b.shape[1] == K and M > 0 and M % 256 == 0 and K % 64 == 0 and K >= 128 and N % (16 if gated else 4) == 0
+    if pair_b:
+        if pair or gated or Kb % 128 != 0 or b.dtype != torch.bfloat16:
+            return False
+        Kb = Kb // 2 * 3
+    return (Kb == K and M > 0 and M % 256 == 0 and K % 64 == 0 and K >= 128 and N % (16 if gated else 4) == 0
             and a.stride(1) == 1 and b.stride(1) == 1 and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0
             and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and 512 * max(a.stride(0), b.stride(0)) < 2 ** 31)
 
@@ -676,17 +682,23 @@ def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=Non
     per-row power-of-two scale derived from it and the call returns (h16, h_inv).
     events: optional (start, stop) raw hipEvent_t handles recorded at the kernel's dispatch boundaries (bench.py)."""
     pair_in = isinstance(a, PairImage)         # a: the pair [hi | lo] of a left image, read as [hi | hi | lo]
+    pair_b = isinstance(b, PairImage)          # b: the same on the right (in_proj: weight image x activation pair -> d-major output)
     if pair_in:
         a = a.data
+    if pair_b:
+        b = b.data
     _gpu(a, b, bias)
     gated = epilogue != "f32"
-    _check(gemm_nt_supported(a, b, gated, pair=pair_in), "gemm_nt: unsupported operands (M % 256, K % 64, K >= 128, 16-bit K-contiguous rows, 16-byte aligned)")
-    M, K = a.shape[0], b.shape[1]
+    _check(not (pair_in and pair_b) and not (pair_b and (gated or residual is not None or bias is not None)), "gemm_nt: a right-hand pair goes with the plain fp32 epilogue")
+    _check(gemm_nt_supported(a, b, gated, pair=pair_in, pair_b=pair_b), "gemm_nt: unsupported operands (M % 256, K % 64, K >= 128, 16-bit K-contiguous rows, 16-byte aligned)")
+    M, K = a.shape[0], (a.shape[1] if pair_b else b.shape[1])
     N = b.shape[0]
     P = _lib.GemmParams()
     P.m, P.n, P.k = M, N, K
     if pair_in:
         P.a_alias_rows = K // 3
+    if pair_b:
+        P.b_alias_rows = K // 3
     P.operand_dtype = _DT[a.dtype]
     P.out_scale = float(out_scale)
     P.lda, P.ldb = a.stride(0), b.stride(0)

@@ -413,6 +413,7 @@ typedef struct {
        [hi | lo] pair (dimsum_gemm_nt: 2 C columns per row; dimsum_gemm_tn: a [hi; lo] pair of planes) serves as the left operand image
        [hi | hi | lo] without storing hi twice. */
     int64_t a_alias_rows;
+    int64_t b_alias_rows;         /* dimsum_gemm_nt, F32 epilogue: the same for the B rows (in_proj: the activation image is the right operand) */
 } dimsum_gemm_params_t;
 
 int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream);

@@ -247,3 +247,6 @@ def test_pair_image_is_the_same_product_bit_for_bit(M, F, H):
     res, gate = _rnd((M, H), torch.float32, 8), _rnd((M // 256, H), torch.float32, 9)
     assert torch.equal(native.gemm_nt(hp, w3i, residual=res, gate=gate, rows_per_batch=256), native.gemm_nt(h3, w3i, residual=res, gate=gate, rows_per_batch=256))
     assert not native.gemm_nt_supported(native.PairImage(hp.data[:, :F + 32]), w3i)
+    # the pair on the right (in_proj: weight image x activation pair -> d-major output)
+    wl = native.split3_rows(_rnd((256, F), torch.float32, 10, scale=F ** -0.5), left=False)        # (256, 3F) as the LEFT operand
+    assert torch.equal(native.gemm_nt(wl, hp), native.gemm_nt(wl, h3))
