@@ -199,7 +199,9 @@ typedef struct {
     int32_t rows_per_batch;
     int32_t y_split3;   /* 1: y is a split-bf16 left operand image, rows of 3 N bf16 [hi | hi | lo] (out_dtype BF16, N % 4 == 0,
                          * y_row_stride >= 3 N): see dimsum_split3.  2: y is a scaled-fp16 operand image (out_dtype F16, N % 4 == 0):
-                         * row r = fp16(y_r * 2^s_r) with 2^-s_r written to y_inv_scale_ptr[r]: see dimsum_rows_f16s */
+                         * row r = fp16(y_r * 2^s_r) with 2^-s_r written to y_inv_scale_ptr[r]: see dimsum_rows_f16s.
+                         * 3: like 1 but as the PAIR [hi | lo], rows of 2 N bf16 (y_row_stride >= 2 N), for a consumer that reads it as
+                         * [hi | hi | lo] (dimsum_gemm_params_t.a_alias_rows / b_alias_rows): a third less image traffic */
     void *y_inv_scale_ptr;                      /* (M) f32, y_split3 == 2 only */
 } dimsum_norm_params_t;
 
@@ -272,7 +274,8 @@ typedef struct {
     int32_t y_split3;                      /* 1: y is the split-bf16 left operand image of the Linear that consumes it: rows of
                                               3 C bf16 [hi | hi | lo] (dimsum_split3); y strides in bf16 elements, channels % 4 == 0.
                                               2: y is the scaled-fp16 image (dimsum_rows_f16s): fp16 rows of C (strides in fp16 elements,
-                                              channels % 4 == 0, channels <= 1024), y_inv_scale_ptr[b * tokens + token] = 2^-s */
+                                              channels % 4 == 0, channels <= 1024), y_inv_scale_ptr[b * tokens + token] = 2^-s.
+                                              3: like 1 as the pair [hi | lo], rows of 2 C bf16 (see dimsum_norm_params_t.y_split3) */
     int64_t x_batch_stride, x_token_stride;           /* channel stride 1 everywhere */
     int64_t res_batch_stride, res_token_stride;
     int64_t y_batch_stride, y_token_stride;
@@ -316,7 +319,8 @@ typedef struct {
                            accumulation, ~1e-5 relative: the same arithmetic hipBLASLt uses for the reference's
                            torch.backends.cuda.matmul.allow_tf32 = True policy (train.py:20-21) on gfx950 */
     int32_t out_split3; /* forward, precision 1 only. != 0: out rows are the split-bf16 operand image of the proj Linear:
-                           3 x (n_dirs' x heads x hd) bf16 [hi | hi | lo] (dimsum_split3); out strides in bf16 elements.
+                           3 x (n_dirs' x heads x hd) bf16 [hi | hi | lo] (dimsum_split3); out strides in bf16 elements. 3 = the pair
+                           [hi | lo] (2 x ...), see dimsum_norm_params_t.y_split3.
                            precision 2: 0 (fp32 out) or 2 = the scaled-fp16 image (dimsum_rows_f16s): fp16 rows of n_dirs' x heads x hd
                            (strides in fp16 elements) + out_inv_ptr[b * L + token] */
     /* precision 2 (forward only): ONE fp16 MFMA product per element, the TF32-equivalent arithmetic (10-bit mantissas, fp32
