@@ -79,17 +79,17 @@ class CrossAttentionFusion(nn.Module):
             b1, b2 = self.qkv1.bias, self.qkv2.bias
             if (b1 is None) != (b2 is None):
                 raise RuntimeError("CrossAttentionFusion: qkv1 / qkv2 must both have a bias or none")
-            qkv1 = gemm.linear_split3(x1.reshape(B * N, C3), self.qkv1.weight).view(B, N, -1)
-            qkv2 = gemm.linear_split3(x2.reshape(B * N, C3), self.qkv2.weight).view(B, N, -1)
+            # the qkv biases ride in the GEMMs' epilogues: the attention kernel then stages K / V without the adds
+            bk1 = {} if b1 is None else {"bias": b1.float().contiguous()}
+            bk2 = {} if b2 is None else {"bias": b2.float().contiguous()}
+            qkv1 = gemm.linear_split3(x1.reshape(B * N, C3), self.qkv1.weight, **bk1).view(B, N, -1)
+            qkv2 = gemm.linear_split3(x2.reshape(B * N, C3), self.qkv2.weight, **bk2).view(B, N, -1)
             if isinstance(x1, native.F16Image) and (self.num_heads * self.head_dim) % 8 == 0:
                 # scaled-fp16 policy: ONE fp16 product per element in QK^T / PV too, proj's operand image written with the same kind of scale
-                f3 = native.xattn_fusion_fwd(qkv1, qkv2, self.num_heads, bias1=None if b1 is None else b1.float().contiguous(),
-                                             bias2=None if b2 is None else b2.float().contiguous(), split3="f16s",
+                f3 = native.xattn_fusion_fwd(qkv1, qkv2, self.num_heads, split3="f16s",
                                              f16s=(x1.inv.reshape(B, N), x2.inv.reshape(B, N), gemm.attn_kv_bound(self.qkv1.weight, b1, self.qkv2.weight, b2)))
             else:
-                f3 = native.xattn_fusion_fwd(qkv1, qkv2, self.num_heads, bias1=None if b1 is None else b1.float().contiguous(),
-                                             bias2=None if b2 is None else b2.float().contiguous(), split_bf16=True,
-                                             split3="pair" if isinstance(x1, native.PairImage) else True)
+                f3 = native.xattn_fusion_fwd(qkv1, qkv2, self.num_heads, split_bf16=True, split3="pair" if isinstance(x1, native.PairImage) else True)
             if residual is not None:
                 pb = None if self.proj.bias is None else self.proj.bias.float()
                 y = gemm.linear_split3(f3.reshape(B * N, -1), self.proj.weight, bias=pb, residual=residual.reshape(B * N, -1))

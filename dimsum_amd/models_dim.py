@@ -205,10 +205,14 @@ class Attention(nn.Module):
         from .attention_fusion import _XattnCoreFn
         B, N, C = x.shape
         if x3 is not None:
-            qkv = gemm.linear_split3(x3, self.qkv.weight).view(B, N, 3 * C)
+            # (the qkv bias rides in the GEMM's epilogue where the MFMA attention kernels follow: they then stage K / V without the adds)
+            qb = None if self.qkv.bias is None else self.qkv.bias.float().contiguous()
+            in_gemm = qb is not None and native.xattn_supported(x, self.head_dim)
+            qkv = gemm.linear_split3(x3, self.qkv.weight, **({"bias": qb} if in_gemm else {})).view(B, N, 3 * C)
             if native.xattn_supported(qkv, self.head_dim):
                 # the attention kernel writes the operand image of proj directly
-                qb = None if self.qkv.bias is None else self.qkv.bias.float().contiguous()
+                if in_gemm:
+                    qb = None
                 if isinstance(x3, native.F16Image) and C % 8 == 0:         # scaled-fp16 policy: the single-product attention kernel
                     o3 = native.xattn_fusion_fwd(qkv, None, self.num_heads, bias1=qb, split3="f16s",
                                                  f16s=(x3.inv.reshape(B, N), None, gemm.attn_kv_bound(self.qkv.weight, self.qkv.bias)))
