@@ -91,7 +91,8 @@ class GemmParams(C.Structure):
                 + [(n, vp) for n in ("a_ptr", "b_ptr", "bias_ptr", "c_ptr", "timing_start_event", "timing_stop_event")]
                 + [(n, i32) for n in ("tune_variant", "tune_group_m", "tune_reserved")]
                 + [(n, vp) for n in ("a_inv_scale_ptr", "b_inv_scale_ptr", "gate_bound_ptr", "h_inv_scale_ptr", "residual_ptr", "gate_ptr")]
-                + [("residual_ld", i64), ("gate_ld", i64), ("rows_per_batch", i32), ("c_image_pieces", i32), ("x12_ptr", vp), ("x12_ld", i64), ("a_alias_rows", i64), ("b_alias_rows", i64)])
+                + [("residual_ld", i64), ("gate_ld", i64), ("rows_per_batch", i32), ("c_image_pieces", i32), ("x12_ptr", vp), ("x12_ld", i64), ("a_alias_rows", i64), ("b_alias_rows", i64), ("a_alias_weight_order", i32), ("reserved1", i32),
+                   ("tn_pair_a_cols", i64), ("tn_pair_b_cols", i64)])
 
 
 GEMM_EPI_F32, GEMM_EPI_GATED_GELU_SPLIT3, GEMM_EPI_GATED_GELU_F16, GEMM_EPI_F32_BIAS, GEMM_EPI_F32_GATE_RESIDUAL = 0, 1, 2, 3, 4
@@ -103,7 +104,7 @@ EXPORTS = (
     "dimsum_ssm_scan_fwd", "dimsum_ssm_scan_bwd", "dimsum_ssm_scan_bwd_workspace_bytes", "dimsum_ssm_scan_fwd_variant",
     "dimsum_causal_conv1d_fwd", "dimsum_causal_conv1d_bwd",
     "dimsum_norm_fwd", "dimsum_norm_bwd", "dimsum_token_transform", "dimsum_xattn_fusion_fwd", "dimsum_xattn_fusion_bwd",
-    "dimsum_gated_gelu_fwd", "dimsum_gated_gelu_bwd", "dimsum_gated_gelu_fwd_split3", "dimsum_gated_gelu_bwd_split3", "dimsum_split3", "dimsum_split3_t",
+    "dimsum_gated_gelu_fwd", "dimsum_gated_gelu_bwd", "dimsum_gated_gelu_fwd_split3", "dimsum_gated_gelu_bwd_split3", "dimsum_gated_gelu_bwd_pair", "dimsum_split3", "dimsum_split3_t",
     "dimsum_gemm_nt", "dimsum_gemm_tn", "dimsum_rows_f16s",
 )
 
@@ -137,7 +138,7 @@ def load():
             fn.restype = C.c_int
             fn.argtypes = [C.POINTER(ptype), vp]
     for name, nptr in (("dimsum_gated_gelu_fwd", 3), ("dimsum_gated_gelu_bwd", 5), ("dimsum_gated_gelu_fwd_split3", 3),
-                       ("dimsum_gated_gelu_bwd_split3", 5)):
+                       ("dimsum_gated_gelu_bwd_split3", 5), ("dimsum_gated_gelu_bwd_pair", 5)):
         if hasattr(lib, name):
             fn = getattr(lib, name)
             fn.restype = C.c_int

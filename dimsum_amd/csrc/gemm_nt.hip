@@ -39,6 +39,12 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
     a.tiles_m = p->m / kBM;
     a.out_scale = p->out_scale;
     a.a_alias_tiles = (int)(p->a_alias_rows / kBK);
+    a.a_alias_from = a.a_alias_tiles;
+    if (p->a_alias_weight_order) {       // the pair read as [hi | lo | hi]: the third piece re-reads the first (shift = two pieces)
+        if (!p->a_alias_rows) return DIMSUM_ERR_SHAPE;
+        a.a_alias_tiles *= 2;
+        a.a_alias_from = a.a_alias_tiles;
+    }
     a.b_alias_tiles = (int)(p->b_alias_rows / kBK);
     // tile order: groups of 4 tile rows; a matrix of few tile rows (in_proj's d-major product: the weight is the left operand) walks whole tile
     // columns, so that every streamed right-operand panel is loaded once (tools/scratch/gm_sweep.py: 187 -> 178 us at 2048 x 65536 x 512)
@@ -138,7 +144,9 @@ extern "C" int dimsum_gemm_tn(const dimsum_gemm_params_t *p, int32_t splits, int
     if (!p || !p->a_ptr || !p->b_ptr || !p->c_ptr) return DIMSUM_ERR_NULL;
     if (p->operand_dtype != DIMSUM_F16 && p->operand_dtype != DIMSUM_BF16) return DIMSUM_ERR_DTYPE;
     if (p->epilogue != DIMSUM_GEMM_EPI_F32 || p->a_inv_scale_ptr || p->b_inv_scale_ptr || p->bias_ptr) return DIMSUM_ERR_UNSUPPORTED;
-    if (splits < 1 || p->m <= 0 || p->n <= 0 || p->m % kBM != 0 || p->n % kBN != 0 || p->k % ((int64_t)splits * kBK) != 0 || p->k / splits < 2 * kBK)
+    const int row_splits = (p->tn_pair_a_cols != 0) ? splits / 3 : splits;       // (pairs: the three pieces share the row ranges)
+    if (splits < 1 || row_splits < 1 || p->m <= 0 || p->n <= 0 || p->m % kBM != 0 || p->n % kBN != 0 || p->k % ((int64_t)row_splits * kBK) != 0 ||
+        p->k / row_splits < 2 * kBK)
         return DIMSUM_ERR_SHAPE;
     if (p->lda % 8 != 0 || p->ldb % 8 != 0 || p->lda < p->m || p->ldb < p->n || !aligned_to<char>(p->a_ptr, 16) || !aligned_to<char>(p->b_ptr, 16) ||
         p->ldc % 4 != 0 || p->ldc < p->n || !aligned_to<char>(p->c_ptr, 16) || (splits > 1 && (c_split_stride % 4 != 0 || c_split_stride < (int64_t)p->m * p->ldc)))
@@ -151,11 +159,20 @@ extern "C" int dimsum_gemm_tn(const dimsum_gemm_params_t *p, int32_t splits, int
     a.B0 = a.B1 = reinterpret_cast<const char *>(p->b_ptr);
     a.C = p->c_ptr;
     a.lda = p->lda; a.ldb = p->ldb; a.ldc = p->ldc;
-    a.M = p->m; a.N = p->n; a.K = p->k / splits;
+    a.M = p->m; a.N = p->n; a.K = p->k / row_splits;
     a.tiles_m = p->m / kBM;
     a.tiles_n = p->n / kBN;
     a.group_m = p->tune_group_m > 0 ? p->tune_group_m : (a.tiles_m <= 16 ? a.tiles_m : 4);
-    if (p->b_alias_rows != 0) return DIMSUM_ERR_UNSUPPORTED;
+    if (p->b_alias_rows != 0 || p->a_alias_weight_order) return DIMSUM_ERR_UNSUPPORTED;
+    if (p->tn_pair_a_cols != 0 || p->tn_pair_b_cols != 0) {
+        // both operands as [hi | lo] pairs: k = the rows of ONE piece, splits = 3 x (row ranges); lda >= 2 m-ish is the caller's business
+        if (p->tn_pair_a_cols <= 0 || p->tn_pair_b_cols <= 0 || splits % 3 != 0 || p->a_alias_rows != 0 || p->tn_pair_a_cols % 8 != 0 || p->tn_pair_b_cols % 8 != 0)
+            return DIMSUM_ERR_SHAPE;
+        if (p->lda < p->tn_pair_a_cols + p->m || p->ldb < p->tn_pair_b_cols + p->n) return DIMSUM_ERR_STRIDE;
+        a.tn_pieces = 1;
+        a.a_pair_cols = p->tn_pair_a_cols;
+        a.b_pair_cols = p->tn_pair_b_cols;
+    }
     if (p->a_alias_rows != 0) {
         if (splits != 1 || p->a_alias_rows < 0 || p->a_alias_rows % kBK != 0 || p->k != 3 * p->a_alias_rows) return DIMSUM_ERR_SHAPE;
         a.a_alias_tiles = (int)(p->a_alias_rows / kBK);

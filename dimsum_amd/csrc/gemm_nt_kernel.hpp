@@ -79,6 +79,10 @@ struct Args {
     int splits;                    // kVarTN: the reduction is cut into `splits` ranges of K rows each (K = rows per range)
     int64_t c_split_stride;        // elements between the partial results
     int a_alias_tiles;             // != 0 = K tiles kt >= a_alias_tiles of A are the tiles kt - a_alias_tiles: a [hi | lo] pair read as the image [hi | hi | lo]
+    int a_alias_from;              // K tiles kt >= a_alias_from are aliased (left order [hi | hi | lo]: = a_alias_tiles; weight order [hi | lo | hi]: 2 a_alias_tiles,
+                                   // with a_alias_tiles = twice the piece width: the third piece re-reads the first)
+    int tn_pieces;                 // kVarTN: both operands are [hi | lo] pairs: `splits` = 3 x splits_per_piece, split -> (piece, row range); the pieces pair
+    int64_t a_pair_cols, b_pair_cols;   //         A (weight order) columns [0, lo, 0] with B (left order) columns [0, 0, lo]
     int b_alias_tiles;             // the same for the B rows (NT only: in_proj, whose activation image is the right operand)
     int c_pieces2;                 // kEpiGatedSplit3: the h image is written as the pair [hi | lo] (ldc >= 2 F) for a consumer that reads it with a_alias_tiles
 };
@@ -179,8 +183,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
             tn_voff_a[pc] = (unsigned)(row * p.lda * 2 + chunk * 16);
             tn_voff_b[pc] = (unsigned)(row * p.ldb * 2 + chunk * 16);
         }
-        tn_a = p.A + ((int64_t)split * p.K * p.lda + m0) * 2;
-        tn_b = p.B0 + ((int64_t)split * p.K * p.ldb + n0) * 2;
+        int row_split = split;
+        int64_t a_col = 0, b_col = 0;
+        if (p.tn_pieces) {          // split = piece * splits_per_piece + row range
+            const int spp = p.splits / 3, piece = split / spp;
+            row_split = split - piece * spp;
+            a_col = piece == 1 ? p.a_pair_cols : 0;
+            b_col = piece == 2 ? p.b_pair_cols : 0;
+        }
+        tn_a = p.A + ((int64_t)row_split * p.K * p.lda + m0 + a_col) * 2;
+        tn_b = p.B0 + ((int64_t)row_split * p.K * p.ldb + n0 + b_col) * 2;
         tn_a_tile = (int64_t)kBK * p.lda * 2;
         tn_b_tile = (int64_t)kBK * p.ldb * 2;
     }
@@ -188,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
     const unsigned st_lds = lds0 + w * 2048;
     auto stage = [&](int slot, const char *base, unsigned voff, int kt, int alias = 0) {      // base: wave-uniform (SGPR pair), voff: this lane's byte offset
         const unsigned dst = st_lds + (kt & 1) * kParity + slot;
-        const int src_kt = (alias && kt >= alias) ? kt - alias : kt;      // (the LDS parity follows kt, the source tile may be an aliased earlier one)
+        const int src_kt = (alias && kt >= (slot < kSlotB0 ? p.a_alias_from : alias)) ? kt - alias : kt;      // (the LDS parity follows kt, the source tile may be an aliased earlier one)
         const char *s = base + (int64_t)src_kt * (kBK * 2);
         __builtin_amdgcn_global_load_lds((glb_void_t *)(s + voff), (lds_void_t *)(uintptr_t)dst, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((glb_void_t *)(s + 64 + voff), (lds_void_t *)(uintptr_t)(dst + 1024), 16, 0, 0);

@@ -21,6 +21,16 @@ __global__ __launch_bounds__(256) void split3_kernel(const float *src, int64_t r
     }
 }
 
+// the pair [hi | lo] (rows of 2 cols bf16): what the hand-written GEMM reads as [hi | hi | lo] or [hi | lo | hi] by aliasing K tiles
+__global__ __launch_bounds__(256) void split_pair_kernel(const float *src, int64_t rows, int64_t cols, int64_t src_row_stride, unsigned short *dst) {
+    const int64_t q = cols / 4, total = rows * q;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / q, c = (i - r * q) * 4;
+        const float4 v = *reinterpret_cast<const float4 *>(src + r * src_row_stride + c);
+        st_split_left(dst + r * 2 * cols, c, cols, f32x4{{v.x, v.y, v.z, v.w}}, true);
+    }
+}
+
 // weight (N, K) fp32 -> the ROW stack [hi; lo; hi] (3 K, N) bf16 of its transpose: the right operand of dimsum_gemm_tn when the left one is
 // a d-major activation (out_proj: y = out_z^T W^T with out_z (d_inner, tokens)). One thread per (k, 2 n): the matrix is small and
 // L2-resident, the transposing reads cost nothing next to a launch.
@@ -133,7 +143,8 @@ extern "C" int dimsum_split3(const void *src, int64_t rows, int64_t cols, int64_
     int64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (left) hipLaunchKernelGGL(split3_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float *>(src), rows, cols, src_row_stride, reinterpret_cast<unsigned short *>(dst));
+    if (left == 2) hipLaunchKernelGGL(split_pair_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float *>(src), rows, cols, src_row_stride, reinterpret_cast<unsigned short *>(dst));
+    else if (left) hipLaunchKernelGGL(split3_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float *>(src), rows, cols, src_row_stride, reinterpret_cast<unsigned short *>(dst));
     else hipLaunchKernelGGL(split3_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const float *>(src), rows, cols, src_row_stride, reinterpret_cast<unsigned short *>(dst));
     return launch_status();
 }

@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void gated_gelu_fwd_kernel(const float *x12, c
 }
 // kSplit: dx12 is written as the split-bf16 operand image of the two GEMMs that consume it (d input = dx12 W12, d weight = dx12^T h):
 // rows of 3 x 2H bf16 in WEIGHT order [hi | lo | hi] (common.hpp), to be paired with left-order images of W12^T and of h
-template <bool kSplit>
+template <int kSplit>        // 0: fp32 dx12, 1: the weight-order image [hi | lo | hi], 2: the pair [hi | lo]
 __global__ __launch_bounds__(256) void gated_gelu_bwd_kernel(const float *x12, const float *bias, const float *dh, void *dx12v, float *dbias,
                                                              int64_t rows, int64_t H) {
     float *dx12 = reinterpret_cast<float *>(dx12v);
@@ -524,7 +524,11 @@ __global__ __launch_bounds__(256) void gated_gelu_bwd_kernel(const float *x12, c
         g.x += bg.x; g.y += bg.y; g.z += bg.z; g.w += bg.w;
         const float4 da = make_float4(d.x * g.x * gelu_tanh_grad(a.x), d.y * g.y * gelu_tanh_grad(a.y), d.z * g.z * gelu_tanh_grad(a.z), d.w * g.w * gelu_tanh_grad(a.w));
         const float4 dg = make_float4(d.x * gelu_tanh(a.x), d.y * gelu_tanh(a.y), d.z * gelu_tanh(a.z), d.w * gelu_tanh(a.w));
-        if constexpr (kSplit) {
+        if constexpr (kSplit == 2) {
+            unsigned short *row = reinterpret_cast<unsigned short *>(dx12v) + r * 4 * H;
+            st_split_left(row, c, 2 * H, f32x4{{da.x, da.y, da.z, da.w}}, true);
+            st_split_left(row, H + c, 2 * H, f32x4{{dg.x, dg.y, dg.z, dg.w}}, true);
+        } else if constexpr (kSplit == 1) {
             unsigned short *row = reinterpret_cast<unsigned short *>(dx12v) + r * 6 * H;
             st_split3<false>(row, c, 2 * H, f32x4{{da.x, da.y, da.z, da.w}});
             st_split3<false>(row, H + c, 2 * H, f32x4{{dg.x, dg.y, dg.z, dg.w}});
@@ -592,7 +596,7 @@ extern "C" int dimsum_gated_gelu_fwd_split3(const void *x12, const void *bias, v
     return launch_gated_gelu_fwd<true>(x12, bias, h3, rows, hidden, stream);
 }
 
-template <bool kSplit>
+template <int kSplit>
 static int launch_gated_gelu_bwd(const void *x12, const void *bias, const void *dh, void *dx12, void *dbias, int64_t rows, int64_t hidden, void *stream) {
     using namespace dimsum;
     if (!x12 || !dh || !dx12) return DIMSUM_ERR_NULL;
@@ -609,10 +613,15 @@ static int launch_gated_gelu_bwd(const void *x12, const void *bias, const void *
 
 extern "C" int dimsum_gated_gelu_bwd(const void *x12, const void *bias, const void *dh, void *dx12, void *dbias, int64_t rows,
                                      int64_t hidden, void *stream) {
-    return launch_gated_gelu_bwd<false>(x12, bias, dh, dx12, dbias, rows, hidden, stream);
+    return launch_gated_gelu_bwd<0>(x12, bias, dh, dx12, dbias, rows, hidden, stream);
 }
 
 extern "C" int dimsum_gated_gelu_bwd_split3(const void *x12, const void *bias, const void *dh, void *dx12_image, void *dbias, int64_t rows,
                                             int64_t hidden, void *stream) {
-    return launch_gated_gelu_bwd<true>(x12, bias, dh, dx12_image, dbias, rows, hidden, stream);
+    return launch_gated_gelu_bwd<1>(x12, bias, dh, dx12_image, dbias, rows, hidden, stream);
+}
+
+extern "C" int dimsum_gated_gelu_bwd_pair(const void *x12, const void *bias, const void *dh, void *dx12_pair, void *dbias, int64_t rows,
+                                          int64_t hidden, void *stream) {
+    return launch_gated_gelu_bwd<2>(x12, bias, dh, dx12_pair, dbias, rows, hidden, stream);
 }

@@ -150,6 +150,9 @@ def _slices(rows, n_out, k_out):
 def mm_tn(a, b, out_dtype=None):
     """a (R, N), b (R, K) -> a^T b (N, K): the weight-gradient shape (reduction over the R rows), split over row slices when the
     output is small"""
+    from . import native as _nat
+    if isinstance(a, _nat.PairImage):        # both operands as [hi | lo] pairs of (M, .) matrices (training images, mlp.py)
+        return _nat.gemm_tn_pairs(a, b)
     R, N = a.shape
     K = b.shape[1]
     if a.is_cuda and a.dtype in (torch.bfloat16, torch.float16) and out_dtype in (None, torch.float32) and own_gemm_enabled():
@@ -388,6 +391,13 @@ def gated_mlp_hidden_split3(x3, w12, b12):
     return native.gated_gelu_fwd(torch.mm(x3, w3i.t(), out_dtype=torch.float32), b12, split3=True)
 
 
+def train_pairs_enabled(M, *widths):
+    """the training images of the gated MLP as [hi | lo] pairs (every consumer is the hand-written kernel: NT with K-tile aliasing, TN over
+    piece ranges): a third less image traffic (gated-GeLU adjoint 3.2 -> 2.1 GB, h image 1.6 -> 1.07 GB at 65536 x 4096)"""
+    return (own_gemm_enabled() and os.environ.get("DIMSUM_PAIR_IMAGES", "1") != "0" and M % 256 == 0 and M >= 2048
+            and all(w % 256 == 0 for w in widths))
+
+
 def gated_mlp_hidden_split3_train(x3, w12, b12):
     """the training forward of the same product: -> (h image (M, 3F), x12 (M, 2F) float32 without the bias): the backward's gated-GeLU
     adjoint reads x12, so the GEMM's gate epilogue stores its accumulators next to the image (one kernel) instead of a plain GEMM
@@ -395,7 +405,9 @@ def gated_mlp_hidden_split3_train(x3, w12, b12):
     from . import native
     w3i = weight_image(w12)
     if own_gemm_enabled() and native.gemm_nt_supported(x3, w3i, gated=True):
-        return native.gemm_nt(x3, w3i, bias=b12, epilogue="gated_split3", keep_x12=True)
+        return native.gemm_nt(x3, w3i, bias=b12, epilogue="gated_split3", keep_x12=True, pair_out=isinstance(x3, native.PairImage))
+    if isinstance(x3, native.PairImage):
+        x3 = x3.image3()
     x12 = _nt(x3, w3i)
     return native.gated_gelu_fwd(x12, b12, split3=True), x12
 

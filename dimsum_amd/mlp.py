@@ -48,11 +48,16 @@ class _ModGatedMlpImagesFn(torch.autograd.Function):
         B, L, H = normed.shape
         M = B * L
         normed = normed if normed.stride(-1) == 1 else normed.contiguous()
-        h3 = native.token_transform(normed, "none", True, scale=scale, shift=shift, split3=True)          # (B, L, 3H)
+        # every image as the pair [hi | lo] where all its consumers are the hand-written kernel (gemm.train_pairs_enabled)
+        pairs = gemm.train_pairs_enabled(M, H, w12.shape[0] // 2, w3.shape[0])
+        h3 = native.token_transform(normed, "none", True, scale=scale, shift=shift, split3="pair" if pairs else True)   # (B, L, 3H) / pair
         b12f = None if b12 is None else b12.float()
-        g3, x12 = gemm.gated_mlp_hidden_split3_train(h3.view(M, 3 * H), w12, b12f)                         # (M, 3F) image, (M, 2F) fp32
+        g3, x12 = gemm.gated_mlp_hidden_split3_train(h3.reshape(M, -1), w12, b12f)                        # (M, 3F) image / pair, (M, 2F) fp32
         m = gemm.linear_split3(g3, w3)                                                                     # (M, H)
-        ctx.save_for_backward(normed, scale, h3, x12, g3, w12, b12f, w3)
+        ctx.pairs = pairs and isinstance(g3, native.PairImage)
+        ctx.save_for_backward(normed, scale, h3.data if pairs else h3, x12, g3.data if ctx.pairs else g3, w12, b12f, w3)
+        if pairs and not ctx.pairs:
+            raise RuntimeError("mlp: the pair images need the hand-written GEMM for every product of the MLP")
         return m.view(B, L, w3.shape[0])
 
     @staticmethod
@@ -62,12 +67,21 @@ class _ModGatedMlpImagesFn(torch.autograd.Function):
         M, F2 = x12.shape
         Fh = F2 // 2
         Ho = w3.shape[0]
-        dm_w = native.split3_rows(dm.reshape(M, Ho).contiguous(), left=False)                              # (M, 3Ho), weight order
-        dg = gemm._nt(dm_w, native.split3_rows(w3.detach().t().contiguous(), left=True))                    # (M, F)
-        dw3 = gemm.mm_tn(dm_w.view(3 * M, Ho), g3.view(3 * M, Fh), out_dtype=torch.float32) if ctx.needs_input_grad[5] else None   # (Ho, F)
-        dx12_w, db12 = native.gated_gelu_bwd(x12, b12f, dg, need_dbias=b12f is not None and ctx.needs_input_grad[4], split3=True)
-        dh = gemm._nt(dx12_w, native.split3_rows(w12.detach().t().contiguous(), left=True))                 # (M, H)
-        dw12 = gemm.mm_tn(dx12_w.view(3 * M, F2), h3.view(3 * M, H), out_dtype=torch.float32) if ctx.needs_input_grad[3] else None   # (2F, H)
+        if ctx.pairs:
+            P = native.PairImage
+            dm_w = native.split3_rows(dm.reshape(M, Ho).contiguous(), left="pair")                         # (M, 2Ho) pair, read in weight order below
+            dg = native.gemm_nt(dm_w, native.split3_rows(w3.detach().t().contiguous(), left=True), weight_order=True)            # (M, F)
+            dw3 = gemm.mm_tn(dm_w, P(g3)) if ctx.needs_input_grad[5] else None                              # (Ho, F)
+            dx12_w, db12 = native.gated_gelu_bwd(x12, b12f, dg, need_dbias=b12f is not None and ctx.needs_input_grad[4], split3="pair")
+            dh = native.gemm_nt(dx12_w, native.split3_rows(w12.detach().t().contiguous(), left=True), weight_order=True)          # (M, H)
+            dw12 = gemm.mm_tn(dx12_w, P(h3.view(M, 2 * H))) if ctx.needs_input_grad[3] else None           # (2F, H)
+        else:
+            dm_w = native.split3_rows(dm.reshape(M, Ho).contiguous(), left=False)                              # (M, 3Ho), weight order
+            dg = gemm._nt(dm_w, native.split3_rows(w3.detach().t().contiguous(), left=True))                    # (M, F)
+            dw3 = gemm.mm_tn(dm_w.view(3 * M, Ho), g3.view(3 * M, Fh), out_dtype=torch.float32) if ctx.needs_input_grad[5] else None   # (Ho, F)
+            dx12_w, db12 = native.gated_gelu_bwd(x12, b12f, dg, need_dbias=b12f is not None and ctx.needs_input_grad[4], split3=True)
+            dh = gemm._nt(dx12_w, native.split3_rows(w12.detach().t().contiguous(), left=True))                 # (M, H)
+            dw12 = gemm.mm_tn(dx12_w.view(3 * M, F2), h3.view(3 * M, H), out_dtype=torch.float32) if ctx.needs_input_grad[3] else None   # (2F, H)
         dh = dh.view(B, L, H)
         dnormed = dshift = dscale = None
         if ctx.needs_input_grad[0]:

@@ -491,11 +491,12 @@ def split3_rows(x, left):
     _check(x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1 and x.shape[1] % 4 == 0 and x.stride(0) % 4 == 0,
            "split3_rows: x must be (R, K) float32 with contiguous rows, K % 4 == 0 and a row stride % 4 == 0")
     R, K = x.shape
-    out = torch.empty((R, 3 * K), device=x.device, dtype=torch.bfloat16)
+    pair = isinstance(left, str) and left == "pair"          # the pair [hi | lo] (PairImage): the consumer chooses the reading order
+    out = torch.empty((R, (2 if pair else 3) * K), device=x.device, dtype=torch.bfloat16)
     if R > 0:
         with torch.cuda.device(x.device):
-            _lib.check(_lib.load().dimsum_split3(_ptr(x), R, K, x.stride(0), _ptr(out), int(bool(left)), _stream(x)), "split3_rows")
-    return out
+            _lib.check(_lib.load().dimsum_split3(_ptr(x), R, K, x.stride(0), _ptr(out), 2 if pair else int(bool(left)), _stream(x)), "split3_rows")
+    return PairImage(out) if pair else out
 
 
 def split3_rows_t(w):
@@ -633,6 +634,33 @@ def gemm_tn_splits(R, P, Q):
     return s
 
 
+def gemm_tn_pairs(a, b, splits=None):
+    """a, b PairImages (M, 2P) / (M, 2Q): dW = a^T b with a read in weight order [hi | lo | hi] and b in left order [hi | hi | lo] (the three
+    products of the split-bf16 policy) -> (P, Q) float32. The reduction runs over 3 pieces x `splits` row ranges of M."""
+    ad, bd = a.data, b.data
+    _gpu(ad, bd)
+    M, P2 = ad.shape
+    P, Q = P2 // 2, bd.shape[1] // 2
+    _check(bd.shape[0] == M and gemm_tn_supported(ad[:, :P], bd[:, :Q]), "gemm_tn_pairs: unsupported operands")
+    if splits is None:
+        tiles = (P // 256) * (Q // 256)
+        # whole rounds of the 256 CUs: 3 x splits x tiles workgroups of equal length (128 tiles x 3 = 384 would be one and a half)
+        splits = 1
+        while (tiles * 3 * splits) % 256 != 0 and tiles * 3 * splits < 1024 and M % (2 * splits * 64) == 0 and M // (2 * splits) >= 2048:
+            splits *= 2
+    _check(M % (splits * 64) == 0 and M // splits >= 128, "gemm_tn_pairs: splits must cut M into ranges of whole 64-row tiles")
+    out = torch.empty((3 * splits, P, Q), device=ad.device, dtype=torch.float32)
+    G = _lib.GemmParams()
+    G.m, G.n, G.k = P, Q, M
+    G.operand_dtype, G.epilogue, G.out_scale = _DT[ad.dtype], _lib.GEMM_EPI_F32, 1.0
+    G.lda, G.ldb, G.ldc = ad.stride(0), bd.stride(0), Q
+    G.a_ptr, G.b_ptr, G.c_ptr = _ptr(ad), _ptr(bd), _ptr(out)
+    G.tn_pair_a_cols, G.tn_pair_b_cols = P, Q
+    with torch.cuda.device(ad.device):
+        _lib.check(_lib.load().dimsum_gemm_tn(G, 3 * splits, P * Q, _stream(ad)), "gemm_tn_pairs")
+    return out.sum(0)
+
+
 def gemm_tn(a, b, splits=None, events=None, alias_rows=0):
     """a (R, P)^T @ b (R, Q) -> (P, Q) float32 on the hand-written MFMA kernel's TN variant: the weight-gradient product of a Linear
     (reduction over the rows). The reduction is cut into `splits` ranges whose partial results are added in a fixed order.
@@ -667,7 +695,7 @@ def gemm_tn(a, b, splits=None, events=None, alias_rows=0):
 
 
 def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=None, tune=None, scales=None, gate_bound=None, residual=None,
-            gate=None, rows_per_batch=None, keep_x12=False, pair_out=False):
+            gate=None, rows_per_batch=None, keep_x12=False, pair_out=False, weight_order=False):
     """a (M, K) @ b (N, K)^T on the hand-written MFMA kernel, 16-bit operands (bfloat16: split-bf16 images over 3 K; float16: scaled rows),
     fp32 accumulation.
       epilogue "f32"          -> (M, N) float32 (+ bias[N])
@@ -697,6 +725,7 @@ def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=Non
     P.m, P.n, P.k = M, N, K
     if pair_in:
         P.a_alias_rows = K // 3
+        P.a_alias_weight_order = int(bool(weight_order))       # the pair read as [hi | lo | hi] (a gradient image x a left-order weight image)
     if pair_b:
         P.b_alias_rows = K // 3
     P.operand_dtype = _DT[a.dtype]
@@ -721,7 +750,6 @@ def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=Non
     elif epilogue == "gated_split3":
         P.epilogue = _lib.GEMM_EPI_GATED_GELU_SPLIT3
         pieces = 2 if pair_out else 3
-        _check(not (pair_out and keep_x12), "gemm_nt: pair_out is the inference form")
         P.c_image_pieces = pieces
         if out is None:
             out = torch.empty((M, pieces * (N // 2)), device=a.device, dtype=torch.bfloat16)
@@ -760,7 +788,7 @@ def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=Non
     with torch.cuda.device(a.device):
         _lib.check(_lib.load().dimsum_gemm_nt(P, _stream(a)), "gemm_nt")
     if x12 is not None:
-        return out, x12
+        return (PairImage(out) if pair_out else out), x12
     if pair_out:
         return PairImage(out)
     return out if h_inv is None else F16Image(out, h_inv)
@@ -771,13 +799,15 @@ def gated_gelu_bwd(x12, bias, dh, need_dbias=True, split3=False):
     _gpu(x12, bias, dh)
     dh = dh.contiguous()
     H = x12.shape[-1] // 2
-    dx12 = torch.empty(x12.shape[:-1] + (6 * H,), device=x12.device, dtype=torch.bfloat16) if split3 else torch.empty_like(x12)
+    pair = split3 == "pair"        # (..., 2 * 2H) bfloat16 [hi | lo] (PairImage)
+    dx12 = torch.empty(x12.shape[:-1] + ((4 if pair else 6) * H,), device=x12.device, dtype=torch.bfloat16) if split3 else torch.empty_like(x12)
     dbias = torch.zeros(2 * H, device=x12.device, dtype=torch.float32) if (bias is not None and need_dbias) else None
     rows = x12.numel() // (2 * H)
     with torch.cuda.device(x12.device):
-        fn = _lib.load().dimsum_gated_gelu_bwd_split3 if split3 else _lib.load().dimsum_gated_gelu_bwd
+        lib = _lib.load()
+        fn = lib.dimsum_gated_gelu_bwd_pair if pair else (lib.dimsum_gated_gelu_bwd_split3 if split3 else lib.dimsum_gated_gelu_bwd)
         _lib.check(fn(_ptr(x12), _ptr(bias), _ptr(dh), _ptr(dx12), _ptr(dbias), rows, H, _stream(x12)), "gated_gelu_bwd")
-    return dx12, dbias
+    return (PairImage(dx12) if pair else dx12), dbias
 
 
 # ---------------------------------------------------------------------------------------------------------------------

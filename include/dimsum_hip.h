@@ -228,6 +228,7 @@ int dimsum_norm_bwd(const dimsum_norm_bwd_params_t *p, void *stream);
  * (rows, 3 cols) bf16:  left != 0: [hi | hi | lo]  (activations),  left == 0: [hi | lo | hi]  (weights), so that
  *     left_image (M, 3K) . weight_image (N, 3K)^T  =  hi.hi + hi.lo + lo.hi   accumulated in f32 by ONE bf16 GEMM.
  * Producer kernels write the left image directly (dimsum_norm_params_t.y_split3, dimsum_gated_gelu_fwd_split3).
+ * left == 2: the PAIR [hi | lo] ((rows, 2 cols) bf16) for dimsum_gemm_params_t.a_alias_rows / tn_pair_*_cols.
  * cols % 4 == 0, src rows 16-byte aligned (src_row_stride % 4 == 0), dst contiguous and 8-byte aligned.
  * ------------------------------------------------------------------------------------------------------------- */
 int dimsum_split3(const void *src, int64_t rows, int64_t cols, int64_t src_row_stride, void *dst, int32_t left, void *stream);
@@ -361,6 +362,8 @@ int dimsum_gated_gelu_bwd(const void *x12, const void *bias, const void *dh, voi
  * paired with left-order images of W12^T (input gradient) and, through the (3 rows, .) view of both, of the MLP input (weight gradient) */
 int dimsum_gated_gelu_bwd_split3(const void *x12, const void *bias, const void *dh, void *dx12_image, void *dbias, int64_t rows,
                                  int64_t hidden, void *stream);
+/* the same with dx12 as the PAIR [hi | lo] (rows of 2 x 2 hidden bf16): see dimsum_gemm_params_t.a_alias_weight_order / tn_pair_a_cols */
+int dimsum_gated_gelu_bwd_pair(const void *x12, const void *bias, const void *dh, void *dx12_pair, void *dbias, int64_t rows, int64_t hidden, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * NT GEMM with a fused Linear epilogue: C (m, n) = A (m, k) . B (n, k)^T, 16-bit operands (bf16 or fp16 rows, k contiguous), fp32
@@ -418,6 +421,13 @@ typedef struct {
        [hi | hi | lo] without storing hi twice. */
     int64_t a_alias_rows;
     int64_t b_alias_rows;         /* dimsum_gemm_nt, F32 epilogue: the same for the B rows (in_proj: the activation image is the right operand) */
+    /* training (dimsum/mlp.py:66-70 under autograd): the gradient images as pairs too.
+       a_alias_weight_order (dimsum_gemm_nt, with a_alias_rows = C): the pair is read in WEIGHT order [hi | lo | hi] (dx = dy_w . (W^T)image).
+       tn_pair_a_cols / tn_pair_b_cols (dimsum_gemm_tn): both operands are pairs -- a_ptr rows [hi | lo] with lo at column tn_pair_a_cols (read
+       in weight order), b_ptr rows [hi | lo] with lo at column tn_pair_b_cols (read in left order); k = the rows of one piece, splits = 3 x the
+       number of row ranges: partial result (piece, range) pairs A's piece with B's piece over that range. */
+    int32_t a_alias_weight_order, reserved1;
+    int64_t tn_pair_a_cols, tn_pair_b_cols;
 } dimsum_gemm_params_t;
 
 int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream);

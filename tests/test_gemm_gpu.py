@@ -250,3 +250,30 @@ def test_pair_image_is_the_same_product_bit_for_bit(M, F, H):
     # the pair on the right (in_proj: weight image x activation pair -> d-major output)
     wl = native.split3_rows(_rnd((256, F), torch.float32, 10, scale=F ** -0.5), left=False)        # (256, 3F) as the LEFT operand
     assert torch.equal(native.gemm_nt(wl, hp), native.gemm_nt(wl, h3))
+
+
+def test_training_pair_images_are_the_same_products():
+    """the gradient-side pair forms: a pair read in WEIGHT order [hi | lo | hi] by the NT kernel (dx = dy_w . (W^T)image) and two pairs as the
+    operands of the TN kernel (dW = dy_w^T x3, three piece ranges) -- against the three-piece images they replace: the NT product bit for
+    bit (same tiles, same order), the TN product to fp32 summation order"""
+    from dimsum_amd import native
+    M, N, K = 2048, 512, 256
+    dy, x = _rnd((M, N), torch.float32, 21), _rnd((M, K), torch.float32, 22)
+    wt = native.split3_rows(_rnd((K, N), torch.float32, 23, scale=N ** -0.5), left=True)          # (K, 3N): the left-order image of W^T
+    dy3, dyp = native.split3_rows(dy, left=False), native.split3_rows(dy, left="pair")
+    assert isinstance(dyp, native.PairImage) and torch.equal(dyp.data[:, :N], dy3[:, :N]) and torch.equal(dyp.data[:, N:], dy3[:, N:2 * N])
+    assert torch.equal(native.gemm_nt(dyp, wt, weight_order=True), native.gemm_nt(dy3, wt))
+    x3, xp = native.split3_rows(x, left=True), native.split3_rows(x, left="pair")
+    ref = native.gemm_tn(dy3.view(3 * M, N), x3.view(3 * M, K))
+    for splits in (None, 1, 2):
+        got = native.gemm_tn_pairs(dyp, xp, splits=splits)
+        assert got.shape == (N, K)
+        assert (got - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    f64 = dy.double().t() @ x.double()
+    assert (native.gemm_tn_pairs(dyp, xp).double() - f64).abs().max().item() / f64.abs().max().item() < 2e-5
+    # the gated-GeLU adjoint's pair output = hi | lo of its three-piece image
+    H = 256
+    x12, dh, b = _rnd((M, 2 * H), torch.float32, 24), _rnd((M, H), torch.float32, 25), _rnd((2 * H,), torch.float32, 26, scale=0.1)
+    d3, db3 = native.gated_gelu_bwd(x12, b, dh, split3=True)
+    dp, dbp = native.gated_gelu_bwd(x12, b, dh, split3="pair")
+    assert torch.equal(dp.data[:, :2 * H], d3[:, :2 * H]) and torch.equal(dp.data[:, 2 * H:], d3[:, 2 * H:4 * H]) and torch.allclose(db3, dbp, rtol=1e-4, atol=1e-4)
