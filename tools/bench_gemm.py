@@ -169,6 +169,7 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--tune", action="store_true")
     ap.add_argument("--pmc-run", action="store_true", help="a few launches of the w12-shape kernels (under rocprofv3 --pmc)")
+    ap.add_argument("--pmc-run-tn", action="store_true", help="a few launches of the dW12-shape TN kernels (three-piece row stacks, pairs) and of the library's batched TN GEMM")
     args = ap.parse_args()
     ok = True
     if args.check:
@@ -191,6 +192,15 @@ def main():
             native.gemm_nt(a, b, epilogue="gated_split3", out=h3)
             native.gemm_nt(a, b, out=c, tune=(2, 8, 0))
             torch.mm(a, b.t(), out_dtype=torch.float32)
+        torch.cuda.synchronize()
+    if args.pmc_run_tn:
+        M = 65536
+        dy3, x3 = rnd((3 * M, 8192), torch.bfloat16, 1), rnd((3 * M, 1024), torch.bfloat16, 2, scale=0.01)
+        dyp, xp = native.PairImage(rnd((M, 2 * 8192), torch.bfloat16, 3)), native.PairImage(rnd((M, 2 * 1024), torch.bfloat16, 4, scale=0.01))
+        for _ in range(3):
+            native.gemm_tn(dy3, x3)
+            native.gemm_tn_pairs(dyp, xp)
+            torch.bmm(dy3.view(2, 3 * M // 2, 8192).transpose(1, 2), x3.view(2, 3 * M // 2, 1024), out_dtype=torch.float32).sum(0)
         torch.cuda.synchronize()
     if args.tune:
         tune(65536, 8192, 3072, torch.bfloat16, args.rounds, args.inner)
