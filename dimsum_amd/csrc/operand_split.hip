@@ -119,7 +119,8 @@ extern "C" int dimsum_rows_f16s(const void *src, int64_t rows, int64_t cols, int
         return DIMSUM_ERR_STRIDE;
     if (rows == 0) return DIMSUM_OK;
     int64_t blocks = (rows + 3) / 4;
-    if (blocks > 256 * 8) blocks = 256 * 8;
+    const int64_t cap = l1max ? 512 : 256 * 8;      // (with the L1 maximum every workgroup ends in an atomic on ONE address: ~35 ns each, serialised)
+    if (blocks > cap) blocks = cap;
 #define DIMSUM_F16S(P)                                                                                                                             \
     hipLaunchKernelGGL(rows_f16s_kernel<P>, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const float *>(src), \
                        rows, cols, src_row_stride, reinterpret_cast<__half *>(dst), dst_row_stride, reinterpret_cast<float *>(inv_scale),                  \
