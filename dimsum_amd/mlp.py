@@ -84,9 +84,13 @@ class _ModGatedMlpImagesFn(torch.autograd.Function):
             dw12 = gemm.mm_tn(dx12_w.view(3 * M, F2), h3.view(3 * M, H), out_dtype=torch.float32) if ctx.needs_input_grad[3] else None   # (2F, H)
         dh = dh.view(B, L, H)
         dnormed = dshift = dscale = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            # one pass over (dh, normed): d normed = dh (1 + scale), d scale = sum_t dh normed, d shift = sum_t dh (the reductions see the
+            # un-modulated dh, like the gate / bias sums of token_ops._GateResidual)
+            dnormed, dscale, _, dshift = native.token_transform(dh, "none", True, scale=scale, w=normed, want_y=True, want_tsum=True)
+        elif ctx.needs_input_grad[0]:
             dnormed = native.token_transform(dh, "none", False, gate=1.0 + scale)
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+        elif ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             _, dscale, dshift = native.token_transform(normed, "none", True, w=dh, want_y=False, want_wsum=True)
         if db12 is not None and b12f is not None:
             db12 = db12.to(b12f.dtype)
