@@ -277,3 +277,32 @@ def test_training_pair_images_are_the_same_products():
     d3, db3 = native.gated_gelu_bwd(x12, b, dh, split3=True)
     dp, dbp = native.gated_gelu_bwd(x12, b, dh, split3="pair")
     assert torch.equal(dp.data[:, :2 * H], d3[:, :2 * H]) and torch.equal(dp.data[:, 2 * H:], d3[:, 2 * H:4 * H]) and torch.allclose(db3, dbp, rtol=1e-4, atol=1e-4)
+
+
+def test_alias_parameters_are_checked_at_the_c_abi():
+    """dimsum_gemm_nt / dimsum_gemm_tn reject alias / pair parameters that do not describe a [hi | lo] pair of whole 64-column pieces"""
+    import ctypes
+    from dimsum_amd import _lib, native
+    lib = _lib.load()
+    a, b = _rnd((256, 2 * 192), torch.bfloat16, 1), _rnd((256, 3 * 192), torch.bfloat16, 2)
+    c = torch.empty((256, 256), device="cuda", dtype=torch.float32)
+
+    def params(**kw):
+        P = _lib.GemmParams()
+        P.m, P.n, P.k = 256, 256, 3 * 192
+        P.operand_dtype, P.epilogue, P.out_scale = native._DT[torch.bfloat16], _lib.GEMM_EPI_F32, 1.0
+        P.lda, P.ldb, P.ldc = a.stride(0), b.stride(0), 256
+        P.a_ptr, P.b_ptr, P.c_ptr = a.data_ptr(), b.data_ptr(), c.data_ptr()
+        for k, v in kw.items():
+            setattr(P, k, v)
+        return P
+
+    s = torch.cuda.current_stream().cuda_stream
+    assert lib.dimsum_gemm_nt(ctypes.byref(params(a_alias_rows=192)), s) == 0
+    assert lib.dimsum_gemm_nt(ctypes.byref(params(a_alias_rows=128)), s) != 0                 # k != 3 x alias
+    assert lib.dimsum_gemm_nt(ctypes.byref(params(a_alias_rows=192, k=3 * 192 - 64)), s) != 0
+    assert lib.dimsum_gemm_nt(ctypes.byref(params(a_alias_weight_order=1)), s) != 0            # weight order without an alias
+    assert lib.dimsum_gemm_nt(ctypes.byref(params(b_alias_rows=192, epilogue=_lib.GEMM_EPI_F32_BIAS)), s) != 0
+    assert lib.dimsum_gemm_tn(ctypes.byref(params(b_alias_rows=192)), 1, 0, s) != 0
+    assert lib.dimsum_gemm_tn(ctypes.byref(params(m=256, n=256, k=256, lda=2 * 256, ldb=2 * 256, tn_pair_a_cols=256, tn_pair_b_cols=256)), 2, 256 * 256, s) != 0   # splits % 3
+    torch.cuda.synchronize()
