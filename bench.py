@@ -577,7 +577,7 @@ def main():
     b = Bench(args)
     world, rank = b.world, b.rank
     policy = {"tf32": "allow_tf32=True like the reference (train.py:20-21); gfx950 split-bf16 path (3 bf16 products per fp32 product), 4e-6 rms rel err"
-                      + ("; the inference GEMMs in_proj / qkv / proj / w12 / w3 take their left operands as split images written by the producer kernels, the training GEMMs of qkv / proj / w12 / w3 run forward and backward on such images (dimsum_amd/gemm.py, split3)"
+                      + ("; the inference GEMMs in_proj / qkv / proj / w12 / w3 take their left operands as split images written by the producer kernels, the training GEMMs of qkv / proj / w12 / w3 run forward and backward on such images (dimsum_amd/gemm.py, split3); on this package's MFMA kernel (dimsum_gemm_nt / dimsum_gemm_tn) the images travel as [hi | lo] pairs read as [hi | hi | lo] by K-tile aliasing: the same three products"
                          if os.environ.get("DIMSUM_SPLIT3", "1") != "0" else "; DIMSUM_SPLIT3=0: fp32 operands everywhere"),
               "fp32": "exact fp32",
               "f16s": "TF32-equivalent single product: the large Linears on scaled-fp16 operand images (10-bit mantissas like TF32, exact power-of-two row "
