@@ -321,12 +321,17 @@ class Bench:
             elapsed = tmax.item()
         return elapsed
 
-    def scan_roofline_pass(self, step, n=2):
+    def scan_roofline_pass(self, step, n=2, full_interface=False):
         """Inference runs the two branches of every block on two HIP streams (dimsum_amd/models_dim.py, the default): the scan of
         one branch overlaps the GEMMs of the other and its launch-to-launch time is no longer its own. The roofline of the scan
         kernel is therefore measured in a short pass of `n` more steps of the SAME step function on ONE stream
-        (DIMSUM_BRANCH_STREAMS=0), right after the timed region, with one HIP-event pair per launch; the line says so."""
+        (DIMSUM_BRANCH_STREAMS=0), right after the timed region, with one HIP-event pair per launch; the line says so.
+        full_interface: the same pass with DIMSUM_SCAN_INFER_STORES=1, i.e. the launch with the reference interface's `out` / `x`
+        stores that an inference call skips by default (SURVEY 8(d)'s full-interface pricing: the figure the 0.5 target is quoted on)."""
         from dimsum_amd.models_dim import branch_streams
+        old = os.environ.get("DIMSUM_SCAN_INFER_STORES")
+        if full_interface:
+            os.environ["DIMSUM_SCAN_INFER_STORES"] = "1"
         try:
             with branch_streams(False):
                 step()
@@ -338,11 +343,32 @@ class Bench:
                 torch.cuda.synchronize()
         finally:
             self.timer.enabled = False
+            if full_interface:
+                if old is None:
+                    del os.environ["DIMSUM_SCAN_INFER_STORES"]
+                else:
+                    os.environ["DIMSUM_SCAN_INFER_STORES"] = old
         rf = self.timer.roofline("fwd")
         if rf is not None:
             rf["timed_in"] = (f"single-stream pass of {n} steps right after the timed region ({rf['launches_timed']} launches, HIP events at the "
-                              "kernels' own begin / end); the timed region itself runs the two branches of every block on two HIP streams")
+                              "kernels' own begin / end); the timed region itself runs the two branches of every block on two HIP streams"
+                              + ("; THIS pass with DIMSUM_SCAN_INFER_STORES=1: the launch keeps the reference interface's `out` / `x` stores, "
+                                 "which the timed region's inference launches skip" if full_interface else ""))
         return rf
+
+    def scan_rooflines(self, step, out):
+        """`roofline`: the scan launch as the timed region runs it (inference: no `out` / `x` stores, priced with the bytes it moves =
+        SURVEY 8(d)'s inference-only lower bound); `roofline_full_interface`: the same kernel with the reference interface's stores on
+        (8(d)'s full formula), from a second single-stream pass -- the figure comparable across rounds and with the 0.5 target."""
+        rf = self.scan_roofline_pass(step)
+        if rf is not None:
+            out["roofline"] = rf
+            if "no out / x stores" in rf["kernel"]:
+                rf["pricing"] = "SURVEY 8(d) inference-only lower bound: the launch skips the `out` / `x` stores nothing reads, and is priced without them"
+                full = self.scan_roofline_pass(step, full_interface=True)
+                if full is not None:
+                    full["pricing"] = "SURVEY 8(d) full interface (reads u, delta, z, B, C, A, D, delta_bias; writes out, out_z, x)"
+                    out["roofline_full_interface"] = full
 
     @staticmethod
     def streams_note():
@@ -385,53 +411,69 @@ class Bench:
                "branch_streams": "one stream (captured graph)" if a.hip_graph else self.streams_note()}
         if self.ranks:
             out["ranks"] = self.ranks
-        rf = None if a.hip_graph else self.scan_roofline_pass(step)          # (a replayed graph makes no library calls to time)
-        if rf is not None:
-            out["roofline"] = rf
-        if extra_precisions and self.world == 1 and a.matmul == "tf32" and not a.hip_graph:      # (extras: the shipped policy is the reference line)
-            # the same step with exact-fp32 library GEMMs, and with the opt-in fp16-operand policy (never the headline).
+        if not a.hip_graph:                                                   # (a replayed graph makes no library calls to time)
+            self.scan_rooflines(step, out)
+        if extra_precisions and self.world == 1 and a.matmul in ("tf32", "f16s") and not a.hip_graph:
+            # the same step under the other carrier of the reference's allow_tf32 policy, with exact-fp32 library GEMMs, under the emulated
+            # TF32 arithmetic of the reference's own hardware path, and with the opt-in fp16-operand policy (never the headline).
             # (skipped under --hip-graph: a captured graph has the policy of its capture baked in)
             def dev(got, ref):
                 d = (got.double() - ref.double()).abs()
                 return {"max_over_max_abs": (d.max() / ref.abs().max()).item(), "rms_over_max_abs": (d.pow(2).mean().sqrt() / ref.abs().max()).item()}
-            three = step()
+            outs = {a.matmul: step()}
             self.set_matmul("fp32")
             dt = self.timed(step, 2, 2, time_scans=False) / 2
             out["fp32_exact_matmul"] = {"value_per_gpu": batch / dt, "ms_per_step": 1e3 * dt}
             ref = step()
             # the reference's own arithmetic, emulated: every torch matmul with operands rounded to TF32 (10 mantissa bits), fp32 sums
+            # (the attention core and the patch-embedding conv stay exact fp32 in this run: it UNDERSTATES a real TF32 run's deviation)
             from dimsum_amd.utils.tf32_emulation import emulated_tf32
             with emulated_tf32():
                 tf = step()
-            self.set_matmul("f16s")
-            one = step()
+            other = "tf32" if a.matmul == "f16s" else "f16s"
+            self.set_matmul(other)
+            outs[other] = step()
             n1 = max(3, steps // 2)
             dt = self.timed(step, n1, 2, time_scans=False) / n1
-            out["tf32_single_product_f16s"] = {
-                "what": "the large Linears (in_proj, qkv, w12 + gate, w3) on scaled-fp16 operand images: ONE v_mfma_f32_16x16x32_f16 product per "
-                        "element, fp32 accumulation, exact power-of-two row scales undone in the GEMM epilogue (dimsum_amd.gemm policy 'f16s'); "
-                        "NOT the headline value this round",
-                "value_per_gpu": batch / dt, "ms_per_step": 1e3 * dt, "steps": n1, "deviation_vs_exact_fp32": dev(one, ref),
-                "emulated_tf32_deviation_vs_exact_fp32": dev(tf, ref), "headline_three_product_deviation_vs_exact_fp32": dev(three, ref)}
+            devs = {"f16s_single_product": dev(outs["f16s"], ref), "three_product_split_bf16": dev(outs["tf32"], ref),
+                    "emulated_tf32_matmul_operands": dev(tf, ref)}
+            what = {"f16s": "the large Linears (in_proj, qkv, proj, w12 + gate, w3) on scaled-fp16 operand images: ONE v_mfma_f32_16x16x32_f16 product per "
+                            "element, fp32 accumulation, exact power-of-two row scales undone in the GEMM epilogue (dimsum_amd.gemm policy 'f16s'), the "
+                            "attention fusion on its single-product fp16 kernel",
+                    "tf32": "the same Linears on split-bf16 operand images: THREE bf16 MFMA products per element (hi.hi + hi.lo + lo.hi), fp32-class "
+                            "(4e-6 rms): what `--matmul tf32` makes the headline (rounds 1-4)"}
+            key = {"f16s": "tf32_single_product_f16s", "tf32": "tf32_three_product_split_bf16"}[other]
+            out[key] = {"what": what[other] + "; NOT the headline value of this line", "value_per_gpu": batch / dt, "ms_per_step": 1e3 * dt, "steps": n1}
+            out["deviation_vs_exact_fp32"] = dict(devs, headline=("f16s_single_product" if a.matmul == "f16s" else "three_product_split_bf16"),
+                                                  what="max / rms |out - out_fp32| over max|out_fp32| of the denoiser output on the bench batch; exact fp32 = "
+                                                       "allow_tf32 off (fp32 MFMA GEMMs, fp32 attention); emulated TF32 = the reference's hardware arithmetic "
+                                                       "for every torch matmul (10-bit operand mantissas, fp32 sums), attention / conv left exact")
             self.set_matmul("fp16")
             got = step()
             dt = self.timed(step, 3, 1, time_scans=False) / 3
             out["fp16_operand_matmul_optin"] = {"value_per_gpu": batch / dt, "ms_per_step": 1e3 * dt,
                                                 "max_abs_dev_over_max_abs_vs_exact_fp32": ((got - ref).abs().max() / ref.abs().max()).item()}
-            self.set_matmul("tf32")
-        elif self.world == 1 and a.matmul == "tf32" and not a.hip_graph and not a.no_fp32_leg:
-            # (legs without the full extras: only the single-product timing, 3 steps)
-            self.set_matmul("f16s")
+            self.set_matmul(a.matmul)
+        elif self.world == 1 and a.matmul in ("tf32", "f16s") and not a.hip_graph and not a.no_fp32_leg:
+            # (legs without the full extras: only the other carrier's timing, 3 steps)
+            other = "tf32" if a.matmul == "f16s" else "f16s"
+            self.set_matmul(other)
             dt = self.timed(step, 3, 2, time_scans=False) / 3
-            out["tf32_single_product_f16s"] = {"value_per_gpu": batch / dt, "ms_per_step": 1e3 * dt, "steps": 3,
-                                               "what": "dimsum_amd.gemm policy 'f16s' (see the headline leg's key of the same name); NOT this leg's value"}
-            self.set_matmul("tf32")
+            out[{"f16s": "tf32_single_product_f16s", "tf32": "tf32_three_product_split_bf16"}[other]] = {
+                "value_per_gpu": batch / dt, "ms_per_step": 1e3 * dt, "steps": 3,
+                "what": f"dimsum_amd.gemm policy of `--matmul {other}` (see the headline leg's key of the same name); NOT this leg's value"}
+            self.set_matmul(a.matmul)
         del model
         self.free()
         return out
 
+    TRAIN_MATMUL = ("allow_tf32=True served by the three-product split-bf16 images (fp32-class): the scaled-fp16 single-product carrier of "
+                    "`--matmul f16s` is an inference carrier")
+
     def leg_block(self, model_name, image_size, batch, steps, warmup):
         r = image_size // 8
+        if self.args.matmul == "f16s":
+            self.set_matmul("tf32")
         model, hidden = build_block(model_name, self.dev)
         _, _, _, gen = self.inputs(1, r)
         ntok = (r // 2) ** 2
@@ -454,6 +496,9 @@ class Bench:
             rf = self.timer.roofline(which)
             if rf is not None:
                 out[key] = rf
+        if self.args.matmul == "f16s":
+            out["matmul"] = self.TRAIN_MATMUL
+            self.set_matmul("f16s")
         del model, hs, res, cond, dy
         self.free()
         return out
@@ -491,9 +536,7 @@ class Bench:
             def one_nfe():
                 with torch.no_grad():
                     return model(x, tt, y)
-            rf = self.scan_roofline_pass(one_nfe)
-            if rf is not None:
-                out["roofline"] = rf
+            self.scan_rooflines(one_nfe, out)
         del model
         self.free()
         return out
@@ -502,6 +545,8 @@ class Bench:
         from dimsum_amd.train import build_training, train_step
         from dimsum_amd.transport import create_transport
         r = image_size // 8
+        if self.args.matmul == "f16s":
+            self.set_matmul("tf32")
         model = build_model(model_name, self.dev, image_size)
         x, _, y, _ = self.inputs(batch, r)
         ddp, ema, opt = build_training(model.train(), self.dev, 1e-4, self.world, [self.local_rank])
@@ -513,6 +558,9 @@ class Bench:
         rb = self.timer.roofline("bwd")
         if rb is not None:
             out["roofline_bwd"] = rb
+        if self.args.matmul == "f16s":
+            out["matmul"] = self.TRAIN_MATMUL
+            self.set_matmul("f16s")
         del ddp, ema, opt, model
         self.free()
         return out
@@ -565,12 +613,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-box-probe", action="store_true", help="skip the 1-GiB copy / add bandwidth probe at process start (kernel-trace runs: keeps its rows out of the stats)")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the extra exact-fp32 / fp16-operand timings (for profiling runs)")
-    ap.add_argument("--matmul", choices=["tf32", "fp32", "fp16", "f16s"], default="tf32",
-                    help="library-GEMM policy. tf32 = the reference's own setting (torch.backends.cuda.matmul.allow_tf32 = "
-                         "True, dimsum/train.py:20-21, sample_ddp.py:56); on gfx950 hipBLASLt serves it with a split-bf16 "
-                         "MFMA path measured at 4e-6 rms relative error (real TF32: ~5e-4). fp32 = exact fp32 MFMA. "
-                         "fp16 = opt-in, inference only: fp16 operands (TF32's 10 mantissa bits, NOT its exponent range) with "
-                         "fp32 accumulation for the large Linears (dimsum_amd/gemm.py); never the headline.")
+    ap.add_argument("--matmul", choices=["tf32", "fp32", "fp16", "f16s"], default="f16s",
+                    help="how the reference's matmul policy (torch.backends.cuda.matmul.allow_tf32 = True, dimsum/train.py:20-21, "
+                         "sample_ddp.py:56) is served. f16s (default, the headline since round 5) = TF32's own arithmetic -- 10-bit operand "
+                         "mantissas, fp32 accumulation -- as ONE fp16 MFMA product per element over scaled-fp16 operand images (exact "
+                         "power-of-two row scales restore TF32's exponent range; deviation from exact fp32 below an emulated-TF32 run's); "
+                         "inference only: training legs run the three-product images. tf32 = three bf16 products per element (split-bf16, "
+                         "4e-6 rms: fp32-class, the headline of rounds 1-4). fp32 = exact fp32 MFMA. fp16 = opt-in: plain fp16 operands "
+                         "(TF32's mantissa, NOT its exponent range); never the headline.")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))           # before anything touches the GPU
@@ -580,8 +630,12 @@ def main():
                       + ("; the inference GEMMs in_proj / qkv / proj / w12 / w3 take their left operands as split images written by the producer kernels, the training GEMMs of qkv / proj / w12 / w3 run forward and backward on such images (dimsum_amd/gemm.py, split3); on this package's MFMA kernel (dimsum_gemm_nt / dimsum_gemm_tn) the images travel as [hi | lo] pairs read as [hi | hi | lo] by K-tile aliasing: the same three products"
                          if os.environ.get("DIMSUM_SPLIT3", "1") != "0" else "; DIMSUM_SPLIT3=0: fp32 operands everywhere"),
               "fp32": "exact fp32",
-              "f16s": "TF32-equivalent single product: the large Linears on scaled-fp16 operand images (10-bit mantissas like TF32, exact power-of-two row "
-                      "scales: no range loss), fp32 accumulation; split-bf16 (3 products) elsewhere",
+              "f16s": "allow_tf32=True like the reference (train.py:20-21), served as the TF32-equivalent SINGLE product: the large Linears (in_proj, qkv, proj, "
+                      "w12 + gate, w3) and the attention fusion's QK^T / PV on scaled-fp16 operand images (10-bit mantissas like TF32, exact power-of-two "
+                      "row scales: no range loss; one v_mfma_f32_16x16x32_f16 per element, fp32 accumulation); split-bf16 (3 products, fp32-class) for "
+                      "out_proj / x_proj / dt_proj and every training GEMM; deviation from exact fp32 on this line under `deviation_vs_exact_fp32`, "
+                      "next to the emulated-TF32 run's and the three-product carrier's (`--matmul tf32`, the headline of rounds 1-4, timed as "
+                      "`tf32_three_product_split_bf16`)",
               "fp16": "OPT-IN: fp16 operands (TF32 mantissa, fp16 exponent range) + fp32 accumulation for the large Linears, split-bf16 elsewhere"}[args.matmul]
 
     extras = {}
@@ -619,7 +673,8 @@ def main():
                 "box": dict(_BOX),
                 "dist": {"world_size": dist.get_world_size() if world > 1 else 1,
                          "backend": (dist.get_backend() + " (RCCL)") if world > 1 else "none (single process)"}}
-        for k in ("roofline", "roofline_bwd", "fp32_exact_matmul", "tf32_single_product_f16s", "fp16_operand_matmul_optin", "nfe", "s_per_batch", "gathered_shape", "finite"):
+        for k in ("roofline", "roofline_full_interface", "roofline_bwd", "deviation_vs_exact_fp32", "fp32_exact_matmul", "tf32_single_product_f16s",
+                  "tf32_three_product_split_bf16", "fp16_operand_matmul_optin", "nfe", "s_per_batch", "gathered_shape", "finite"):
             if k in head:
                 line[k] = head[k]
         if "sample_250nfe" in extras:

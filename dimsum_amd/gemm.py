@@ -416,7 +416,8 @@ def split3_train_enabled(x, weight):
     """the operand-image carrier under autograd (mlp.py: forward AND backward GEMMs of the gated MLP): fp32 CUDA training under
     allow_tf32, outside autocast; DIMSUM_SPLIT3_TRAIN=0 / DIMSUM_SPLIT3=0 switch it off; same row threshold as inference"""
     import os
-    if not (_policy == "default" and torch.backends.cuda.matmul.allow_tf32 and os.environ.get("DIMSUM_SPLIT3", "1") != "0"
+    # (policy "f16s" is an inference carrier: under autograd it runs the same three-product images as "default")
+    if not (_policy in ("default", "f16s") and torch.backends.cuda.matmul.allow_tf32 and os.environ.get("DIMSUM_SPLIT3", "1") != "0"
             and os.environ.get("DIMSUM_SPLIT3_TRAIN", "1") != "0" and x.is_cuda and x.dtype == torch.float32
             and weight.dtype == torch.float32 and x.shape[-1] % 4 == 0 and torch.is_grad_enabled()
             and not torch.is_autocast_enabled("cuda")):

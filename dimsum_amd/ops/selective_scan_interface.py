@@ -143,10 +143,11 @@ class _MambaInner(torch.autograd.Function):
         # its own to rebuild them. They depend on (conv_out, delta, A, B) only, which the backward recomputes identically.
         need = need_ckpt        # decided by the caller (grad mode is off in here)
         # `out` (ungated) and the chunk states `x` only serve the backward. The reference's kernel always stores them
-        # (selective_scan_fwd_kernel.cuh:239-254) and so does this call by default -- SURVEY 8(d) prices the launch with them.
-        # DIMSUM_SCAN_INFER_STORES=0 skips both at inference (1.082 instead of 1.384 GB per launch at DiM-L/2, batch 256:
-        # measured 0.320 -> 0.298 ms in the model, i.e. -22 % bytes buy -7 % time: the kernel is not bound by HBM alone).
-        keep = need or os.environ.get("DIMSUM_SCAN_INFER_STORES", "1") != "0"
+        # (selective_scan_fwd_kernel.cuh:239-254); here an inference call (nothing to differentiate) passes NULL out_ptr / x_ptr and the
+        # kernel skips both stores: 1.082 instead of 1.384 GB per launch at DiM-L/2, batch 256 (SURVEY 8(d)'s "inference-only lower bound"),
+        # same arithmetic, bit-identical out_z. DIMSUM_SCAN_INFER_STORES=1 restores the reference interface's stores (bench.py prices
+        # that launch too, as `roofline_full_interface`).
+        keep = need or os.environ.get("DIMSUM_SCAN_INFER_STORES", "0") == "1"
         # inference under allow_tf32: out_z leaves the scan as its split-bf16 pair of planes (the same 4 bytes per element) and out_proj runs
         # on the hand-written kernel's transposing-read variant straight from them (0.26 -> 0.17 ms per mixer at 65536 tokens)
         planes = (has_out_proj and not need and out_proj_bias is None and L % 8 == 0

@@ -109,6 +109,62 @@ def test_product_is_never_less_accurate_than_tf32(M, K, N, adversarial):
         assert not torch.isfinite(plain).all() or ((plain.double() - ref).abs() / row).max().item() > 10 * e_got.max().item()
 
 
+@pytest.mark.parametrize("M,K,N", [(512, 256, 384), (1024, 1024, 2048)])
+def test_product_with_wide_ranges_inside_a_row_vs_tf32(M, K, N):
+    """the per-row scale cannot help WITHIN a row: an element below 2^-28 of its row's maximum lands in fp16's subnormal range (absolute
+    error <= 2^-39 of the row maximum instead of TF32's 2^-11 of the element). Element magnitudes log-uniform over 2^-30 .. 1 inside every
+    row of x AND of w (independent draws), plus: a row of x at 1e-38 (fp32's own subnormal edge: the scale clamp), a row with one 2^32
+    outlier over O(1) entries (every other element subnormal after scaling), an all-zero row. The product against float64, judged per
+    output row like above: still <= 1.05 x the emulated-TF32 error -- the lost elements carry 2^-28 of the row's largest term."""
+    from dimsum_amd.utils.tf32_emulation import round_tf32
+    from dimsum_amd import gemm, native
+    g = torch.Generator(device="cuda").manual_seed(11)
+    def wide(R, C, s):
+        mag = torch.exp2(-30.0 * torch.rand(R, C, device="cuda", generator=g))
+        return torch.randn(R, C, device="cuda", generator=g).sign() * mag * (1.0 + torch.rand(R, C, device="cuda", generator=g)) * s
+    x, w = wide(M, K, 1.0), wide(N, K, K ** -0.5)
+    x[3] = torch.randn(K, device="cuda", generator=g) * 1e-38
+    x[4] = torch.randn(K, device="cuda", generator=g)
+    x[4, 7] = 2.0 ** 32
+    x[5] = 0.0
+    ref = x.double() @ w.double().t()
+    row = ref.abs().amax(-1, keepdim=True).clamp_min(1e-300)
+    xi = native.rows_f16s(x)
+    assert xi.data[4].float().abs().max().item() >= 2.0 ** 14                                                      # the outlier owns the row's scale
+    assert (xi.data[4, 8:].float().abs() < 2.0 ** -14).all()                                                       # ... everything else is subnormal fp16
+    got = gemm._nt_f16s(xi, native.rows_f16s(w))
+    tf = (round_tf32(x).double() @ round_tf32(w).double().t()).float()
+    assert torch.isfinite(got).all() and (got[5] == 0).all()
+    e_got, e_tf = (got.double() - ref).abs() / row, (tf.double() - ref).abs() / row
+    keep = torch.ones(M, dtype=torch.bool, device="cuda")
+    keep[3] = False          # (the 1e-38 row: its fp32 OUTPUT is subnormal -- judged on its own below)
+    assert e_got[keep].max().item() <= 1.05 * e_tf[keep].max().item() + 1e-6, (e_got[keep].max().item(), e_tf[keep].max().item())
+    assert e_got[keep].pow(2).mean().sqrt().item() <= 1.05 * e_tf[keep].pow(2).mean().sqrt().item() + 1e-7
+    # per row too: no single row is worse than 1.5 x the TF32 error of the worst row of its own kind
+    assert (e_got[keep].amax(-1) <= 1.5 * e_tf[keep].amax(-1).max() + 1e-6).all()
+    # the tiny row: 1e-38 inputs, outputs ~1e-38 (fp32 subnormal steps of 1.4e-45 = 1e-7 relative): TF32-class relative to the row's own size
+    assert e_got[3].max().item() <= 2.0 ** -9, e_got[3].max().item()
+
+
+def test_where_the_row_scale_ends():
+    """the documented limit of the construction: if the weights cancel a row's large elements EXACTLY (here: zero columns
+    where x is large), the output is made of elements that sit below 2^-28 of the row maximum, whose image keeps an ABSOLUTE error
+    <= 2^-39 max|x_r| per element -- the product's error is then bounded by K 2^-39 max|x_r| max|w|, not by TF32's relative bound.
+    Activations out of RMSNorm / modulate / Haar / DCT passes have row-internal ranges of 2^10 .. 2^15 (measured on DiM-L/2: the model
+    tests), 13 octaves short of this regime."""
+    from dimsum_amd import gemm, native
+    g = torch.Generator(device="cuda").manual_seed(12)
+    M, K, N = 256, 256, 256
+    x = torch.randn(M, K, device="cuda", generator=g) * 2.0 ** -31
+    x[:, :8] = torch.randn(M, 8, device="cuda", generator=g)            # 8 large columns ...
+    w = torch.randn(N, K, device="cuda", generator=g)
+    w[:, :8] = 0.0                                                      # ... that the weights ignore
+    ref = x.double() @ w.double().t()
+    got = gemm._nt_f16s(native.rows_f16s(x), native.rows_f16s(w))
+    bound = K * 2.0 ** -39 * x.abs().amax(-1, keepdim=True).double() * w.abs().max().item() + 2.0 ** -10 * (x.abs().double() @ w.abs().double().t())
+    assert ((got.double() - ref).abs() <= bound).all()
+
+
 def test_gated_mlp_on_scaled_images_vs_tf32():
     """w12 + bias + gelu_tanh * gate -> h image (per-row scale from the bound, no row reduction) -> w3: against float64 next to the
     emulated-TF32 evaluation of the same MLP; with rows of very different magnitude and outliers"""

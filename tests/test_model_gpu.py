@@ -122,6 +122,87 @@ def test_zoo_forward_under_the_reference_matmul_policy(name, tag, B, R, over):
     assert_close(out.cpu().numpy(), g["out"], 1e-3, 0, "out (allow_tf32 policy)", scale_atol=1e-4)
 
 
+# ---- the scaled-fp16 single-product policy ("f16s", bench.py's headline arithmetic since round 5) against the REFERENCE goldens ----------
+@pytest.fixture
+def f16s_policy(monkeypatch):
+    """policy "f16s" with its image carriers forced on (the golden batches have 512 / 1024 rows, below the 8192-row default threshold):
+    exactly the kernels bench.py's headline runs at batch 256 -- scaled-fp16 images out of the norm / token / attention producers,
+    ONE fp16 MFMA product per element in in_proj / qkv / proj / w12 + gate / w3 and in the attention's QK^T / PV"""
+    from dimsum_amd import gemm
+    monkeypatch.setenv("DIMSUM_SPLIT3_MIN_ROWS", "0")
+    monkeypatch.setattr(torch.backends.cuda.matmul, "allow_tf32", True)
+    gemm.set_policy("f16s")
+    yield
+    gemm.set_policy("default")
+
+
+def _count_f16s_products(monkeypatch):
+    """spy: how many GEMM launches took scaled-fp16 operands (scales=...) -- the policy must really be the path under test"""
+    from dimsum_amd import native
+    seen = {"f16s": 0, "other": 0}
+    real = native.gemm_nt
+
+    def spy(a, b, **kw):
+        seen["f16s" if kw.get("scales") is not None else "other"] += 1
+        return real(a, b, **kw)
+    monkeypatch.setattr(native, "gemm_nt", spy)
+    return seen
+
+
+@pytest.mark.parametrize("name,tag,B,R,over", [("DiM-L/2", "model_L2", 2, 32, {}), ("DiM-XL/2", "model_XL2_512", 1, 64, {}),
+                                               ("DiM-XL/2", "model_XL2_512_zigma8", 1, 64, dict(scan_type="zigma_8"))])
+def test_zoo_forward_under_the_f16s_policy_vs_reference_goldens(name, tag, B, R, over, f16s_policy, monkeypatch):
+    """the headline arithmetic (TF32-equivalent single product, dimsum/train.py:20-21 is what it stands for) against the goldens the
+    REFERENCE model produced in exact fp32 on the CPU, at the tolerance of the exact-fp32 and 3-product runs (north star: 1e-3)"""
+    from dimsum_amd.models_dim import DiM_models
+    g = golden(tag)
+    m = DiM_models[name](**_published(img_resolution=R, **over))
+    procedural_fill(m, seed=3)
+    m = m.cuda().eval()
+    seen = _count_f16s_products(monkeypatch)
+    with torch.no_grad():
+        out = m(T(seeded((B, 4, R, R), 71)).cuda(), T(g["t"]).cuda(), T(g["y"]).cuda())
+    depth = len(m.blocks)
+    assert seen["f16s"] >= 4 * depth, seen             # in_proj x 2, w12, w3 per block (+ qkv x 2, proj in every block with a fusion)
+    assert_close(out.cpu().numpy(), g["out"], 1e-3, 0, "out (f16s policy)", scale_atol=1e-4)
+
+
+def test_block_combined_1024_forward_under_the_f16s_policy_vs_reference_golden(f16s_policy, monkeypatch):
+    """configs[2]'s block at DiM-L/2's width against the reference block golden, inference forward under the headline policy. Tolerance:
+    the north star's 1e-3 of max|ref| -- ONE block under any 10-bit-mantissa arithmetic sits at 4-5e-4 (the emulated-TF32 run of this
+    block: tests/test_f16s_gpu.py), which the 2e-5 of the fp32-class rows cannot hold; the residual stream stays bit-exact."""
+    from dimsum_amd import utils
+    from dimsum_amd.models_dim import create_block
+    from dimsum_amd.utils.tf32_emulation import emulated_tf32
+    g = golden("block_combined_1024")
+    blk = create_block(1024, norm_epsilon=1e-5, rms_norm=True, residual_in_fp32=True, fused_add_norm=True, layer_idx=1,
+                       scan_type="none", block_type="combined", reverse=True, transpose=True, cond_mamba=True,
+                       scanning_continuity=False, use_gated_mlp=True)
+    procedural_fill(blk, seed=9)
+    blk = blk.cuda().eval()
+    sh = (2, 256, 1024)
+    x, res, cc = (T(seeded(s_, sd)).cuda() for s_, sd in ((sh, 91), (sh, 92), ((2, 1024), 93)))
+    before = utils.torch_path_counts()
+    seen = _count_f16s_products(monkeypatch)
+    with torch.no_grad():
+        y, ro = blk(x, res, cc)
+    assert seen["f16s"] >= 7 and utils.torch_path_counts() == before, seen
+    assert np.array_equal(ro.cpu().numpy(), g["res_out"])
+    assert_close(y.cpu().numpy(), g["y"], 1e-3, 0, "y (f16s policy)", scale_atol=1e-3)
+    # ... and not further from the reference golden than the emulated-TF32 run of the same block (the reference's own arithmetic)
+    from dimsum_amd import gemm
+    gemm.set_policy("default")
+    torch.backends.cuda.matmul.allow_tf32 = False
+    with torch.no_grad(), emulated_tf32():
+        y_tf = blk(x, res, cc)[0]
+    ref = T(g["y"]).cuda().double()
+    e1, et = (y.double() - ref).abs(), (y_tf.double() - ref).abs()
+    print(f"block_1024 vs reference golden, max / rms over max|y|: f16s {e1.max().item() / ref.abs().max().item():.2e} / "
+          f"{e1.pow(2).mean().sqrt().item() / ref.abs().max().item():.2e}, emulated TF32 {et.max().item() / ref.abs().max().item():.2e} / "
+          f"{et.pow(2).mean().sqrt().item() / ref.abs().max().item():.2e}")
+    assert e1.max().item() <= 1.25 * et.max().item() and e1.pow(2).mean().sqrt().item() <= 1.1 * et.pow(2).mean().sqrt().item()
+
+
 # ---- forward + backward through autograd on the GPU (BASELINE config 3 path) ---------------------------------------------
 def test_mamba_inner_fn_fwd_bwd_gpu():
     from dimsum_amd.ops import mamba_inner_fn
@@ -393,9 +474,9 @@ def test_two_stream_branches_are_bit_identical():
 
 @pytest.mark.gpu
 def test_inference_without_out_and_x_stores_is_bit_identical(monkeypatch):
-    """DIMSUM_SCAN_INFER_STORES=0 (opt-in): the mixers' inference scans skip the stores of the ungated `out` and of the chunk
-    states `x` (NULL out_ptr / x_ptr in the C ABI) -- only a backward reads them. Same kernel, same arithmetic: the model output
-    is bit-identical; and under autograd the switch changes nothing (the backward needs both)."""
+    """the mixers' inference scans skip the stores of the ungated `out` and of the chunk states `x` (NULL out_ptr / x_ptr in the C ABI:
+    only a backward reads them; the default since round 5), DIMSUM_SCAN_INFER_STORES=1 keeps the reference interface's stores. Same
+    kernel, same arithmetic: the model output is bit-identical; and under autograd the switch changes nothing (the backward needs both)."""
     from dimsum_amd import native
     from dimsum_amd.models_dim import DiM
     m = DiM(depth=4, hidden_size=384, patch_size=2, **_published())
@@ -413,12 +494,13 @@ def test_inference_without_out_and_x_stores_is_bit_identical(monkeypatch):
 
     monkeypatch.setattr(native, "selective_scan_fwd", spy)
     with torch.no_grad():
+        monkeypatch.setenv("DIMSUM_SCAN_INFER_STORES", "1")
         ref = m(x, t, y)
-        assert seen and all(s == (True, True) for s in seen)          # the default keeps the reference interface's stores
+        assert seen and all(s == (True, True) for s in seen)          # the reference interface's stores
         seen.clear()
-        monkeypatch.setenv("DIMSUM_SCAN_INFER_STORES", "0")
+        monkeypatch.delenv("DIMSUM_SCAN_INFER_STORES")
         got = m(x, t, y)
-        assert seen and all(s == (False, False) for s in seen)
+        assert seen and all(s == (False, False) for s in seen)        # the default: nothing reads them at inference
     assert torch.equal(got, ref)
     seen.clear()
     xg = x.clone().requires_grad_()

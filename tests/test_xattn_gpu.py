@@ -55,6 +55,51 @@ def test_module_vs_golden(name, dim, monkeypatch):
     assert_close(x2r.grad.cpu().numpy(), g["dx2"], 5e-4, 0, "dx2", scale_atol=5e-5)
 
 
+def test_module_on_scaled_fp16_images_vs_reference_golden(monkeypatch):
+    """CrossAttentionFusion the way a block calls it under the headline policy "f16s" (forward_deferred(images=True): scaled-fp16 images of
+    x1 / x2 in, qkv GEMMs + the single-product fp16 attention kernel + proj, all with ONE fp16 MFMA product per element) against the
+    REFERENCE module's output (golden fusion_hd24, head_dim 24). Tolerance: 1e-3 of max|ref| (north star); the emulated-TF32 evaluation
+    of the same module (operands of every matmul and of QK^T / PV rounded to 10 mantissa bits) is measured next to it and must not be
+    beaten by more than 1.25 x."""
+    from dimsum_amd import gemm, native
+    from dimsum_amd.attention_fusion import CrossAttentionFusion
+    from dimsum_amd.utils.tf32_emulation import round_tf32
+    g = golden("fusion_hd24")
+    m = CrossAttentionFusion(384, num_heads=8, qkv_bias=True, swap_k=False)
+    procedural_fill(m, seed=5)
+    m = m.cuda().eval()
+    x1, x2 = torch.from_numpy(g["x1"]).cuda(), torch.from_numpy(g["x2"]).cuda()
+    B, N, C = x1.shape
+    monkeypatch.setattr(torch.backends.cuda.matmul, "allow_tf32", True)
+    gemm.set_policy("f16s")
+    try:
+        with torch.no_grad():
+            i1, i2 = (native.rows_f16s(x.reshape(B * N, C)).reshape(B, N, C) for x in (x1, x2))
+            assert m.takes_images(x1)
+            y, b = m.forward_deferred(i1, i2, images=True)
+            y = y + b
+    finally:
+        gemm.set_policy("default")
+    ref = torch.from_numpy(g["y"]).cuda().double()
+    assert_close(y.cpu().numpy(), g["y"], 1e-3, 0, "y (f16s images)", scale_atol=1e-3)
+    # emulated TF32 of the same module in float64 arithmetic over rounded operands
+    r = lambda t: round_tf32(t.float()).double()
+    H, hd = m.num_heads, m.head_dim
+    def qkv(x, lin):
+        return (r(x) @ r(lin.weight).t() + lin.bias.double()).reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4).unbind(0)
+    (q1, k1, v1), (q2, k2, v2) = qkv(x1, m.qkv1), qkv(x2, m.qkv2)
+    def sdpa(q, k, v):
+        p = torch.softmax((r(q) @ r(k).transpose(-1, -2)) * hd ** -0.5, -1)
+        return (r(p) @ r(v)).transpose(1, 2).reshape(B, N, H * hd)
+    fused = torch.cat([sdpa(q1, k2, v2), sdpa(q2, k1, v1)], -1)
+    y_tf = r(fused) @ r(m.proj.weight).t() + m.proj.bias.double()
+    e1, et = (y.double() - ref).abs(), (y_tf - ref).abs()
+    scale = ref.abs().max().item()
+    print(f"fusion_hd24 vs reference golden, max / rms over max|y|: f16s {e1.max().item() / scale:.2e} / {e1.pow(2).mean().sqrt().item() / scale:.2e}, "
+          f"emulated TF32 {et.max().item() / scale:.2e} / {et.pow(2).mean().sqrt().item() / scale:.2e}")
+    assert e1.max().item() <= 1.5 * et.max().item() and e1.pow(2).mean().sqrt().item() <= 1.25 * et.pow(2).mean().sqrt().item()
+
+
 @pytest.mark.parametrize("L,heads,hd", [(256, 8, 64), (100, 4, 24), (64, 8, 72)])
 def test_in_kernel_qkv_bias(L, heads, hd):
     """the qkv Linear biases added inside the kernel == attention on (qkv + bias): the adds are the same fp32 operations,
