@@ -152,19 +152,34 @@ def _count_f16s_products(monkeypatch):
 @pytest.mark.parametrize("name,tag,B,R,over", [("DiM-L/2", "model_L2", 2, 32, {}), ("DiM-XL/2", "model_XL2_512", 1, 64, {}),
                                                ("DiM-XL/2", "model_XL2_512_zigma8", 1, 64, dict(scan_type="zigma_8"))])
 def test_zoo_forward_under_the_f16s_policy_vs_reference_goldens(name, tag, B, R, over, f16s_policy, monkeypatch):
-    """the headline arithmetic (TF32-equivalent single product, dimsum/train.py:20-21 is what it stands for) against the goldens the
-    REFERENCE model produced in exact fp32 on the CPU, at the tolerance of the exact-fp32 and 3-product runs (north star: 1e-3)"""
+    """the headline arithmetic (TF32-equivalent single product; dimsum/train.py:20-21 is what it stands for) against the goldens the
+    REFERENCE model produced in exact fp32 on the CPU. Tolerance: |err| <= 1e-3 |ref| + 5e-4 max|ref| -- half the north star's 1e-3.
+    The fp32-class rows above hold 1e-4 max|ref|; 16-28 layers of 10-bit-mantissa products cannot (measured here: f16s 2.2e-4 / 3.0e-4 /
+    3.6e-4 of max|ref| for the three models), and neither can the reference's own TF32 arithmetic: the emulated-TF32 forward of the same
+    model (every torch matmul on operands rounded to 10 mantissa bits, attention exact) is run against the same golden and the f16s
+    error must not exceed 1.25 x its maximum / 1.1 x its rms."""
+    from dimsum_amd import gemm
     from dimsum_amd.models_dim import DiM_models
+    from dimsum_amd.utils.tf32_emulation import emulated_tf32
     g = golden(tag)
     m = DiM_models[name](**_published(img_resolution=R, **over))
     procedural_fill(m, seed=3)
     m = m.cuda().eval()
     seen = _count_f16s_products(monkeypatch)
+    args = (T(seeded((B, 4, R, R), 71)).cuda(), T(g["t"]).cuda(), T(g["y"]).cuda())
     with torch.no_grad():
-        out = m(T(seeded((B, 4, R, R), 71)).cuda(), T(g["t"]).cuda(), T(g["y"]).cuda())
+        out = m(*args)
     depth = len(m.blocks)
     assert seen["f16s"] >= 4 * depth, seen             # in_proj x 2, w12, w3 per block (+ qkv x 2, proj in every block with a fusion)
-    assert_close(out.cpu().numpy(), g["out"], 1e-3, 0, "out (f16s policy)", scale_atol=1e-4)
+    assert_close(out.cpu().numpy(), g["out"], 1e-3, 0, "out (f16s policy)", scale_atol=5e-4)
+    gemm.set_policy("default")
+    with torch.no_grad(), emulated_tf32():
+        out_tf = m(*args)
+    ref = T(g["out"]).cuda().double()
+    e1, et, scale = (out.double() - ref).abs(), (out_tf.double() - ref).abs(), ref.abs().max().item()
+    print(f"{tag} vs reference golden, max / rms over max|out|: f16s {e1.max().item() / scale:.2e} / {e1.pow(2).mean().sqrt().item() / scale:.2e}, "
+          f"emulated TF32 {et.max().item() / scale:.2e} / {et.pow(2).mean().sqrt().item() / scale:.2e}")
+    assert e1.max().item() <= 1.25 * et.max().item() and e1.pow(2).mean().sqrt().item() <= 1.1 * et.pow(2).mean().sqrt().item()
 
 
 def test_block_combined_1024_forward_under_the_f16s_policy_vs_reference_golden(f16s_policy, monkeypatch):
