@@ -12,6 +12,22 @@ template <int kOp, int kEpi, int kVar = 0> int launch(const Args &a, hipStream_t
     return launch_status();
 }
 
+// the 128 x 256-tile variant (4-wave workgroups, two per CU): launches whose epilogue is a large share of a tile's time (short K)
+template <int kOp, int kEpi, int kVar = 0> int launch_m128(const Args &a0, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    Args a = a0;
+    a.tiles_m = a.M / 128;
+    a.group_m = a.tiles_m <= 32 ? a.tiles_m : 2 * a0.group_m;     // the same L2 patch in rows
+    const dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(256);
+    if (e0 || e1) hipExtLaunchKernelGGL((gemm_nt_m128_kernel<kOp, kEpi, kVar>), grid, block, 0, s, e0, e1, 0, a);
+    else hipLaunchKernelGGL((gemm_nt_m128_kernel<kOp, kEpi, kVar>), grid, block, 0, s, a);
+    return launch_status();
+}
+
+// scaled-fp16 operands (one product per element): both tile shapes are built
+template <int kEpi, int kVar = 0> int launch_f16(const Args &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1, bool m128) {
+    return m128 ? launch_m128<kOpF16, kEpi, kVar>(a, s, e0, e1) : launch<kOpF16, kEpi, kVar>(a, s, e0, e1);
+}
+
 }  // namespace gemm_nt
 }  // namespace dimsum
 
@@ -56,6 +72,13 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t e0 = reinterpret_cast<hipEvent_t>(p->timing_start_event), e1 = reinterpret_cast<hipEvent_t>(p->timing_stop_event);
     const bool bf = p->operand_dtype == DIMSUM_BF16;
+    // tile shape: tune_variant 512 / 513 force the 128-row / 256-row tiles (A / B runs, tools/bench_gemm.py); 0 = by shape: scaled-fp16
+    // operands (one product per element) with K <= 1024 spend a third to a half of a 256 x 256 tile's time in its epilogue
+    const bool m128 = p->tune_variant == 512 || (p->tune_variant == 0 && !bf && p->k <= 576 && (p->epilogue == DIMSUM_GEMM_EPI_F32 || p->epilogue == DIMSUM_GEMM_EPI_F32_BIAS));
+#ifndef DIMSUM_GEMM_TUNE
+    if (p->tune_variant != 0 && p->tune_variant != 512 && p->tune_variant != 513) return DIMSUM_ERR_UNSUPPORTED;
+#endif
+    if (p->tune_variant == 512 && bf) return DIMSUM_ERR_UNSUPPORTED;       // (the 128-row tiles are built for the fp16 operands only)
     if (p->epilogue == DIMSUM_GEMM_EPI_F32_GATE_RESIDUAL) {
         if (!p->residual_ptr) return DIMSUM_ERR_NULL;
         if (p->ldc % 4 != 0 || p->ldc < p->n || !aligned_to<char>(p->c_ptr, 16) || p->residual_ld % 4 != 0 || p->residual_ld < p->n ||
@@ -72,7 +95,7 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
         a.N = p->n;
         a.tiles_n = (p->n + kBN - 1) / kBN;
         constexpr int kShipR = kVarFullLineStores | kVarNtStores;
-        return bf ? launch<kOpBf16, kEpiF32GateRes, kShipR>(a, s, e0, e1) : launch<kOpF16, kEpiF32GateRes, kShipR>(a, s, e0, e1);
+        return bf ? launch<kOpBf16, kEpiF32GateRes, kShipR>(a, s, e0, e1) : launch_f16<kEpiF32GateRes, kShipR>(a, s, e0, e1, m128);
     }
     if (p->epilogue == DIMSUM_GEMM_EPI_F32 || p->epilogue == DIMSUM_GEMM_EPI_F32_BIAS) {
         if (p->ldc % 4 != 0 || p->ldc < p->n || !aligned_to<char>(p->c_ptr, 16)) return DIMSUM_ERR_STRIDE;
@@ -83,9 +106,10 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
         a.N = p->n;
         a.tiles_n = (p->n + kBN - 1) / kBN;
         constexpr int kShip = kVarFullLineStores | kVarNtStores;      // 128-byte row segments, streaming stores (tools/bench_gemm.py --tune)
-        if (bias) return bf ? launch<kOpBf16, kEpiF32Bias, kShip>(a, s, e0, e1) : launch<kOpF16, kEpiF32Bias, kShip>(a, s, e0, e1);
-        if (bf) switch (p->tune_variant) {       // tuning builds only
-            case 0: break;
+        if (bias) return bf ? launch<kOpBf16, kEpiF32Bias, kShip>(a, s, e0, e1) : launch_f16<kEpiF32Bias, kShip>(a, s, e0, e1, m128);
+#ifdef DIMSUM_GEMM_TUNE      // tuning builds only (tools/scratch/build_variant.sh ... -DDIMSUM_GEMM_TUNE): schedule / store-policy variants of the plain kernel
+        if (bf) switch (p->tune_variant) {
+            case 0: case 512: case 513: break;
             case 100: return launch<kOpBf16, kEpiF32, 0>(a, s, e0, e1);
             case 1: return launch<kOpBf16, kEpiF32, 1>(a, s, e0, e1);
             case 2: return launch<kOpBf16, kEpiF32, 2>(a, s, e0, e1);
@@ -100,7 +124,8 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
             case 104: return launch<kOpBf16, kEpiF32, 104>(a, s, e0, e1);
             default: return DIMSUM_ERR_UNSUPPORTED;
         }
-        return bf ? launch<kOpBf16, kEpiF32, kShip>(a, s, e0, e1) : launch<kOpF16, kEpiF32, kShip>(a, s, e0, e1);
+#endif
+        return bf ? launch<kOpBf16, kEpiF32, kShip>(a, s, e0, e1) : launch_f16<kEpiF32, kShip>(a, s, e0, e1, m128);
     }
     if (p->epilogue == DIMSUM_GEMM_EPI_GATED_GELU_SPLIT3 || p->epilogue == DIMSUM_GEMM_EPI_GATED_GELU_F16) {
         // b_ptr: the (2 F, K) weight of w12; n = 2 F; output: (M, 3 F) bf16 left image [hi | hi | lo] or (M, F) fp16
@@ -132,7 +157,7 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
             return launch<kOpBf16, kEpiGatedSplit3, kVarKeepX12>(a, s, e0, e1);
         }
         if (img) return bf ? launch<kOpBf16, kEpiGatedSplit3>(a, s, e0, e1) : launch<kOpF16, kEpiGatedSplit3>(a, s, e0, e1);
-        return bf ? launch<kOpBf16, kEpiGatedF16>(a, s, e0, e1) : launch<kOpF16, kEpiGatedF16>(a, s, e0, e1);
+        return bf ? launch<kOpBf16, kEpiGatedF16>(a, s, e0, e1) : launch_f16<kEpiGatedF16>(a, s, e0, e1, m128);
     }
     return DIMSUM_ERR_UNSUPPORTED;
 }

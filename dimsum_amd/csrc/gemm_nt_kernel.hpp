@@ -87,7 +87,7 @@ struct Args {
     int c_pieces2;                 // kEpiGatedSplit3: the h image is written as the pair [hi | lo] (ldc >= 2 F) for a consumer that reads it with a_alias_tiles
 };
 // tuning variants (bit mask; 0 = the shipped schedule)
-enum { kVarLgkmAfterBarrier = 1, kVarNoEpilogue = 2, kVarNtStores = 4, kVarFullLineStores = 8, kVarNoSetprio = 16, kVarSc1Stores = 32, kVarSc0Stores = 64, kVarKeepX12 = 128, kVarTN = 256 };
+enum { kVarLgkmAfterBarrier = 1, kVarNoEpilogue = 2, kVarNtStores = 4, kVarFullLineStores = 8, kVarNoSetprio = 16, kVarSc1Stores = 32, kVarSc0Stores = 64, kVarKeepX12 = 128, kVarTN = 256, kVarM128 = 512 };
 
 __device__ __forceinline__ float dpp_row_ror8(float x) {      // lane l <- lane l ^ 8 (rotation by 8 inside each row of 16 lanes)
     const int v = __builtin_bit_cast(int, x);                  // (old = the source: with a constant `old` hipcc 7.2 merges the calls of an unrolled loop)
@@ -113,19 +113,34 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
     return x * fast_rcp(1.0f + fast_exp2(-2.0f * kLog2e * u));
 }
 
-template <int kOp, int kEpi, int kVar = 0>
-__global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
-    __shared__ __attribute__((aligned(1024))) char lds[2 * kParity];
+// M128 variant (kVarM128): 128 x 256 output tiles by 4-wave workgroups with an 80-KB ring, TWO workgroups per CU. A 256 x 256 tile's
+// epilogue (fp32 stores at the ~12 B/clk a CU can push, or the gated GeLU's VALU work) runs with the matrix pipe idle, and with one
+// workgroup per CU nothing else is resident to use it: a third of a K = 1024 launch, half of a K = 512 one (scaled-fp16 operands: one
+// product per element, short K). Two independent workgroups per CU overlap one's epilogue with the other's K loop. Same wave tile
+// (a wave owns all 128 rows x 64 columns: acc[mi][ni][4][2], mi = row half), same 16-MFMA phases and operand registers; the two A
+// halves A_lo / A_hi are 64-row entries (8 KB), B0 / B1 128-row entries (16 KB), consumed in the order
+//   A_lo(0) | B0(t) B1(t) A_hi(t) A_lo(t+1) | ...
+// out of a ring of ten 8-KB units (positions advance by the entry size, the first entry sits at unit 1 so that a B entry always starts
+// at an even unit and never straddles the wrap): while phase p reads entry p + 1 the DMA of entry p + 6 is issued into the units the
+// entries <= p have left -- every window of 6 consecutive entries is <= 10 units -- and `s_waitcnt vmcnt(12)` (the DMA pieces of 4
+// entries: A 2, B 4 per wave) retires entry p + 2. ONE barrier per phase (lgkmcnt(0) before it frees the slot read, the counted vmcnt
+// before it publishes the entry read next); the ping-pong partner of a wave is the other workgroup's wave on its SIMD.
+template <int kOp, int kEpi, int kVar>
+__device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wr = w >> 2, wc = w & 3;
+    constexpr bool kM1 = (kVar & kVarM128) != 0;
+    constexpr int kTileM = kM1 ? 128 : kBM;        // rows of an output tile
+    constexpr int kMiRows = kM1 ? 64 : 128;        // rows between the two A halves (mi)
+    const int wr = kM1 ? 0 : (w >> 2), wc = w & 3;
 
     // ---- block -> tile: every XCD (block b runs on XCD b % 8) walks a contiguous range of the tile list, ordered in groups of 8 tile
     // rows (consecutive tiles walk down the rows of a group, then to the next tile column): the 32 workgroups an XCD runs at a time
     // form an 8 x 4 patch that shares its A and B panels through that XCD's L2.
     constexpr bool kTN = (kVar & kVarTN) != 0;
     static_assert(!kTN || kEpi == kEpiF32, "the TN variant has the plain fp32 epilogue");
+    static_assert(!(kTN && kM1), "the TN variant has 256 x 256 tiles only");
     int tile_m, tile_n, split = 0;
     {
         const int nwg = gridDim.x, bid = blockIdx.x;
@@ -144,7 +159,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
         tile_n = within / gsz;
         tile_m = first_m + (within - tile_n * gsz);
     }
-    const int m0 = tile_m * kBM, n0 = tile_n * (kEpi == kEpiGatedSplit3 || kEpi == kEpiGatedF16 ? 128 : kBN);
+    const int m0 = tile_m * kTileM, n0 = tile_n * (kEpi == kEpiGatedSplit3 || kEpi == kEpiGatedF16 ? 128 : kBN);
 
     // ---- staging addresses: wave w fills row block w (16 rows) of every half tile; lane l -> LDS byte 16 l of a subtile = logical row l >> 2,
     // k chunk (l & 3) ^ (2 if l >= 32)
@@ -168,7 +183,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
         }
     }
     const char *a_base = p.A + (int64_t)m0 * p.lda * 2;
-    const int64_t a_half = (int64_t)128 * p.lda * 2;
+    const int64_t a_half = (int64_t)kMiRows * p.lda * 2;
+    unsigned b_voff2[2][2];        // M128: a B entry (128 weight rows) is two 64-row pieces per wave pass: rows st_row, st_row + 64
+    if constexpr (kM1) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int first = (kEpi == kEpiGatedSplit3 || kEpi == kEpiGatedF16) ? 0 : ni * 128;
+                const int row = min(first + h * 64 + st_row, p.N - 1 - n0);
+                b_voff2[ni][h] = (unsigned)((row * p.ldb + st_kc * 8) * 2);
+            }
+    }
 
     // TN: wave w fills rows 8 w .. 8 w + 7 of every half tile (two pieces of 4 rows x 256 B); lane l -> row l >> 4 of the piece, 16-byte
     // slot l & 15, which holds the source chunk whose 32-byte pair index is (slot >> 1) ^ (row & 7)
@@ -320,6 +346,70 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
 
     const int nk = p.K / kBK;      // >= 2
 
+    if constexpr (kM1) {
+        constexpr unsigned kU = 8192, kRing = 10 * kU;
+        unsigned spos = kU, rpos = kU;          // stage / read positions in the ring (wave-uniform)
+        auto adv = [&](unsigned &pos, unsigned sz) { pos += sz; pos = pos >= kRing ? pos - kRing : pos; };
+        auto dma = [&](unsigned dst, const char *base, unsigned voff, int kt, int alias, int alias_from) {
+            const int src_kt = (alias && kt >= alias_from) ? kt - alias : kt;
+            const char *s = base + (int64_t)src_kt * (kBK * 2);
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(s + voff), (lds_void_t *)(uintptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(s + 64 + voff), (lds_void_t *)(uintptr_t)(dst + 1024), 16, 0, 0);
+        };
+        auto st_a = [&](int half, int kt) {      // 64 rows of A: row block w of the entry
+            dma(st_lds + spos, a_base + half * a_half, a_voff, kt, p.a_alias_tiles, p.a_alias_from);
+            adv(spos, kU);
+        };
+        auto st_b = [&](int ni, int kt) {        // 128 weight rows: row blocks w and w + 4
+            dma(st_lds + spos, b_base[ni], b_voff2[ni][0], kt, p.b_alias_tiles, p.b_alias_tiles);
+            dma(st_lds + spos + 4 * 2048, b_base[ni], b_voff2[ni][1], kt, p.b_alias_tiles, p.b_alias_tiles);
+            adv(spos, 2 * kU);
+        };
+#define DIMSUM_M1_SYNC()                                                                   \
+    do {                                                                                   \
+        DIMSUM_WAIT_LGKM0();                                                               \
+        __builtin_amdgcn_s_barrier();                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+    } while (0)
+        // one phase: read the entry at rpos into FRAG (A: 64 rows = 8 reads, B: 4 reads), stage (STAGE), counted wait, barrier, 16 MFMA
+#define DIMSUM_M1_PHASE(READ, SIZE, STAGE, VM, MI, NI, AF, BF)                              \
+    do {                                                                                   \
+        READ;                                                                              \
+        adv(rpos, SIZE);                                                                   \
+        STAGE;                                                                             \
+        DIMSUM_WAIT_VM(VM);                                                                \
+        DIMSUM_M1_SYNC();                                                                  \
+        DIMSUM_QUADRANT(MI, NI, AF, BF);                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+    } while (0)
+        // prologue: entries 0 .. 5 = A_lo(0) B0(0) B1(0) A_hi(0) A_lo(1) B0(1) (18 DMA pieces per wave); the first two must have landed
+        st_a(0, 0); st_b(0, 0); st_b(1, 0); st_a(1, 0); st_a(0, 1); st_b(0, 1);
+        DIMSUM_WAIT_VM(12);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        DIMSUM_READ_A(a0, 0, rpos);               // "phase -1": A_lo(0), retired in every wave before phase 0 stages over its unit
+        adv(rpos, kU);
+        DIMSUM_M1_SYNC();
+        int kt = 0;
+        for (; kt < nk - 2; ++kt) {
+            DIMSUM_M1_PHASE(DIMSUM_READ_B(b0, 0, rpos), 2 * kU, st_b(1, kt + 1), 12, 0, 0, a0, b0);
+            DIMSUM_M1_PHASE(DIMSUM_READ_B(b1, 0, rpos), 2 * kU, st_a(1, kt + 1), 12, 0, 1, a0, b1);
+            DIMSUM_M1_PHASE(DIMSUM_READ_A(a1, 0, rpos), kU, st_a(0, kt + 2), 12, 1, 1, a1, b1);
+            DIMSUM_M1_PHASE(DIMSUM_READ_A(a0, 0, rpos), kU, st_b(0, kt + 2), 12, 1, 0, a1, b0);
+        }
+        // K tile nk - 2: its first two phases stage the last two entries, then the counted waits run down
+        DIMSUM_M1_PHASE(DIMSUM_READ_B(b0, 0, rpos), 2 * kU, st_b(1, kt + 1), 12, 0, 0, a0, b0);
+        DIMSUM_M1_PHASE(DIMSUM_READ_B(b1, 0, rpos), 2 * kU, st_a(1, kt + 1), 12, 0, 1, a0, b1);
+        DIMSUM_M1_PHASE(DIMSUM_READ_A(a1, 0, rpos), kU, (void)0, 10, 1, 1, a1, b1);
+        DIMSUM_M1_PHASE(DIMSUM_READ_A(a0, 0, rpos), kU, (void)0, 6, 1, 0, a1, b0);
+        // K tile nk - 1
+        DIMSUM_M1_PHASE(DIMSUM_READ_B(b0, 0, rpos), 2 * kU, (void)0, 2, 0, 0, a0, b0);
+        DIMSUM_M1_PHASE(DIMSUM_READ_B(b1, 0, rpos), 2 * kU, (void)0, 0, 0, 1, a0, b1);
+        DIMSUM_M1_PHASE(DIMSUM_READ_A(a1, 0, rpos), kU, (void)0, 0, 1, 1, a1, b1);
+        DIMSUM_QUADRANT(1, 0, a1, b0);
+#undef DIMSUM_M1_PHASE
+#undef DIMSUM_M1_SYNC
+    } else {
     // ---- prologue: the 8 half tiles of K tiles 0 and 1 in read order; A0(0) and B0(0) must have landed before the first reads
     stage_a0(0); stage_b0(0); stage_b1(0); stage_a1(0);
     stage_a0(1); stage_b0(1); stage_b1(1); stage_a1(1);
@@ -404,6 +494,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
         DIMSUM_QUADRANT(1, 0, a1, b0);
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();       // matches the second wave row's extra barrier
+    }
 
     // ---- epilogue: acc[mi][ni][i][j] = rows m0 + mi * 128 + wr * 64 + i * 16 + (lane & 15), 4 columns from ni * 128 + wc * 32 + j * 16 + (lane >> 4) * 4
     const int ecol = wc * 32 + (lane >> 4) * 4;
@@ -452,7 +543,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
                             s0[e] = up ? r1 : x0[e];
                             s1[e] = up ? x1[e] : r0;
                         }
-                        const int lrow = frow + mi * 128 + i * 16;
+                        const int lrow = frow + mi * kMiRows + i * 16;
                         const unsigned voff = (unsigned)((lrow * p.ldc + col) * 4);
                         if (p.sa) {             // scaled-fp16 operands: exact powers of two
                             s0 = s0 * (sbv * p.sa[m0 + lrow]);
@@ -485,7 +576,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
                         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                             for (int i = 0; i < 4; ++i)
-                                store_f4<kAux>(rsrc, (unsigned)(((frow + mi * 128 + i * 16) * p.ldc + col) * 4), acc[mi][ni][i][j] + bv);
+                                store_f4<kAux>(rsrc, (unsigned)(((frow + mi * kMiRows + i * 16) * p.ldc + col) * 4), acc[mi][ni][i][j] + bv);
                     }
                 }
         }
@@ -505,7 +596,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int r = mi * 128 + wr * 64 + i * 16 + (lane & 15);
+                const int r = mi * kMiRows + wr * 64 + i * 16 + (lane & 15);
                 row_sa[mi][i] = p.sa ? p.sa[m0 + r] : 1.0f;
                 row_hs[mi][i] = p.out_scale;
                 if constexpr (!kImg) {
@@ -540,7 +631,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
                             s0[e] = up ? r1 : x0[e];
                             s1[e] = up ? x1[e] : r0;
                         }
-                        const int lrow = frow + mi * 128 + i * 16;
+                        const int lrow = frow + mi * kMiRows + i * 16;
                         const unsigned voff = (unsigned)((lrow * p.ldx + ni * p.N + fcol) * 4);
                         if (xlive) {
                             store_f4<2>(xrsrc, voff, s0);
@@ -565,7 +656,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int r = mi * 128 + wr * 64 + i * 16 + (lane & 15);
+                    const int r = mi * kMiRows + wr * 64 + i * 16 + (lane & 15);
                     f4 x1 = acc[mi][0][i][j], x2 = acc[mi][1][i][j];
                     const float hs = row_hs[mi][i];
                     if (p.sa) {
@@ -583,7 +674,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
                         split2(h[0], h[1], h0, l0);
                         split2(h[2], h[3], h1, l1);
                         *reinterpret_cast<uint2 *>(dst) = make_uint2(h0, h1);
-                        *reinterpret_cast<uint2 *>(dst + 65536) = make_uint2(l0, l1);
+                        *reinterpret_cast<uint2 *>(dst + kTileM * 256) = make_uint2(l0, l1);
                     } else {
                         const __half2 a = __floats2half2_rn(h[0] * hs, h[1] * hs), b = __floats2half2_rn(h[2] * hs, h[3] * hs);
                         *reinterpret_cast<uint2 *>(dst) = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
@@ -611,12 +702,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
                 }
             }
             if constexpr (kImg) {
-                u32x4 l = *reinterpret_cast<const u32x4 *>(src + 65536);
+                u32x4 l = *reinterpret_cast<const u32x4 *>(src + kTileM * 256);
                 l = odd ? u32x4{l[2], l[3], l[0], l[1]} : l;
                 if (live) __builtin_amdgcn_raw_buffer_store_b128(l, rsrc, voff + (unsigned)(p.N * (p.c_pieces2 ? 2 : 4)), 0, 2);
             }
         }
     }
+}
+
+template <int kOp, int kEpi, int kVar = 0>
+__global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
+    __shared__ __attribute__((aligned(1024))) char lds[2 * kParity];
+    gemm_body<kOp, kEpi, kVar>(p, lds);
+}
+
+// 4 waves, 80 KB: two workgroups per CU (2 waves per SIMD: the same 256-VGPR budget)
+template <int kOp, int kEpi, int kVar = 0>
+__global__ __launch_bounds__(256, 2) void gemm_nt_m128_kernel(const Args p) {
+    __shared__ __attribute__((aligned(1024))) char lds[10 * 8192];
+    gemm_body<kOp, kEpi, kVar | kVarM128>(p, lds);
 }
 
 #undef DIMSUM_READ_A

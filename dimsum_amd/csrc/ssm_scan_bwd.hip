@@ -40,7 +40,10 @@
 
 namespace dimsum {
 
-constexpr int kBW = 4;    // waves per workgroup
+#ifndef DIMSUM_SCAN_BWD_WAVES
+#define DIMSUM_SCAN_BWD_WAVES 4
+#endif
+constexpr int kBW = DIMSUM_SCAN_BWD_WAVES;    // waves per workgroup
 constexpr int kBC = 16;   // channels per wave (one DPP row per state quarter)
 constexpr int kBQ = 4;    // lanes per channel
 constexpr int kBT = 32;   // time steps per LDS tile (128 B per row and tensor: whole HBM lines)
@@ -130,15 +133,15 @@ template <typename Gen> __device__ __forceinline__ void transposed_reduce_row32_
     r[1] = v[1];
 }
 
-// The same for values that are PRODUCTS y[i & 7] * h[i] (dC): the partner's product dpp(y h) = dpp(y) * dpp(h), and dpp(y) is
-// one of only 8 values per lane (yp), so the first level is  v = fma(dpp(h[i + 16]), yp[i & 7], y[i & 7] * h[i])  -- a v_mul
-// and a v_fmac with a DPP source instead of two v_mul, a v_mov_dpp and a v_add per output.
+// The same for values that are PRODUCTS y[i & 7] * h[i] (dC). First level: both products of a pair are formed by their owner, then ONE
+// v_add_f32 with a DPP source: v_mul, v_mul, v_add_dpp = 4 issue slots per output (a DPP operand costs a second slot). The round-3 form
+// fma(dpp(h[i + 16]), dpp(y), y h[i]) looked shorter on paper, but v_fma has no DPP encoding on gfx9: it became v_mul + v_mov_dpp + v_fma
+// (4 slots) plus 8 v_mov_dpp for the partner's y (16 slots per half). Contraction is off here: y h[i] + dpp(..) must stay an add.
 __device__ __forceinline__ void transposed_reduce_row32_perm_prod(const float (&y)[8], const float (&h)[32], int lane, float (&r)[2]) {
-    float yp[8], v[16];
+#pragma clang fp contract(off)
+    float v[16];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) yp[t] = dpp<0x128>(y[t]);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = fmaf(dpp<0x128>(h[i + 16]), yp[i & 7], y[i & 7] * h[i]);
+    for (int i = 0; i < 16; ++i) v[i] = y[i & 7] * h[i] + dpp<0x128>(y[i & 7] * h[i + 16]);      // v_mul, v_mul, v_add_f32_dpp
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] += dpp<0x141>(v[i + 8]);
     reduce_level<0x4E, 8>(v, lane & 2);
@@ -147,13 +150,19 @@ __device__ __forceinline__ void transposed_reduce_row32_perm_prod(const float (&
     r[1] = v[1];
 }
 
-// sigmoid(x) for dt = softplus(x) = log(1 + e^x):  sigmoid(x) = 1 - exp(-dt)  (for x > 20 the reference takes dt = x and
-// a derivative of 1: 1 - exp(-20) rounds to 1). Small dt: alternating series (the direct form cancels).
-__device__ __forceinline__ float dsoftplus_from_dt(float dt) {
-    const float ser = dt * (1.0f - dt * (0.5f - dt * (1.0f / 6 - dt * (1.0f / 24 - dt * (1.0f / 120 - dt * (1.0f / 720))))));
-    float big = 1.0f - fast_exp(-dt);
-    asm volatile("" : "+v"(big));          // both forms in straight-line code: no per-element branch around the v_exp_f32
-    return dt < 0.25f ? ser : big;
+// dt = softplus(x) (the reference's threshold form, common.hpp softplus_ref) AND its slope sigmoid(x) = e^x / (1 + e^x) from the same
+// exponential: one v_rcp_f32 next to the softplus instead of a second exponential + a series per step in the per-step epilogue
+// (selective_scan_bwd_kernel.cuh:439-452 recomputes the softplus derivative there too). Without softplus: dt = x, slope 1.
+// Straight-line code (the empty asm pins both forms: no per-element branch around the transcendentals).
+__device__ __forceinline__ void softplus_and_slope(float x, bool flag, float &dt, float &slope) {
+    const float e = fast_exp(x);
+    const float w = 1.0f + e;
+    float sp = fmaf(e - (w - 1.0f), fmaxf(2.0f - w, 0.0f), fast_log(w));
+    float sg = e * fast_rcp(w);
+    asm volatile("" : "+v"(sp), "+v"(sg));
+    const bool big = x > 20.0f;             // the reference takes dt = x there, slope 1 (e / (1 + e) rounds to 1 from x = 17 on; e overflows at 88)
+    dt = flag ? (big ? x : sp) : x;
+    slope = flag ? (big ? 1.0f : sg) : 1.0f;
 }
 
 // kVec : every row base 4-element aligned and L % 4 == 0 -> 16-byte vector I/O.   kFull: all 64 channel slots are live.
@@ -170,15 +179,15 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
     // The sweeps address it with byte offsets: the same per-lane offset serves u, dt and dy (constant distances = immediate offsets of
     // the ds instructions), and the 16-byte slot index of a half tile enters by one XOR (btile_off: the row bases have no bits below 128).
     constexpr int kTile = kBC * kBT, kSums = kN * kDS;
-    constexpr unsigned kOffD = 4u * kBW * kTile, kOffY = 8u * kBW * kTile;                      // dt, dy tiles relative to the u tile (bytes)
-    constexpr unsigned kOffB = 4u * (3 * kBW * kTile + 2 * kBW * kSums), kOffC = kOffB + 4u * kN * kBCS;   // B, C tiles (bytes)
-    __shared__ __attribute__((aligned(16))) float smem[3 * kBW * kTile + 2 * kBW * kSums + 2 * kN * kBCS];
-    float(*const sdB)[kSums] = reinterpret_cast<float(*)[kSums]>(smem + 3 * kBW * kTile);
-    float(*const sdC)[kSums] = reinterpret_cast<float(*)[kSums]>(smem + 3 * kBW * kTile + kBW * kSums);
+    constexpr unsigned kOffD = 4u * kBW * kTile, kOffY = 8u * kBW * kTile, kOffS = 12u * kBW * kTile;   // dt, dy, sigmoid tiles relative to the u tile (bytes)
+    constexpr unsigned kOffB = 4u * (4 * kBW * kTile + 2 * kBW * kSums), kOffC = kOffB + 4u * kN * kBCS;   // B, C tiles (bytes)
+    __shared__ __attribute__((aligned(16))) float smem[4 * kBW * kTile + 2 * kBW * kSums + 2 * kN * kBCS];
+    float(*const sdB)[kSums] = reinterpret_cast<float(*)[kSums]>(smem + 4 * kBW * kTile);
+    float(*const sdC)[kSums] = reinterpret_cast<float(*)[kSums]>(smem + 4 * kBW * kTile + kBW * kSums);
     float *const tB = smem + kOffB / 4, *const tC = smem + kOffC / 4;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & (kBC - 1), sh = lane >> 4;
-    float *tU = smem + wave * kTile, *tD = tU + kBW * kTile, *tY = tD + kBW * kTile, *tdB = sdB[wave], *tdC = sdC[wave];
+    float *tU = smem + wave * kTile, *tD = tU + kBW * kTile, *tY = tD + kBW * kTile, *tS = tY + kBW * kTile, *tdB = sdB[wave], *tdC = sdC[wave];
     auto lds4 = [&](unsigned off) -> const f32x4 & { return *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(smem) + off); };
     const unsigned ubase = 4u * (unsigned)(wave * kTile + btile_off(c, 0));       // u4 of 4-step slot j of this lane's row: ubase ^ (j << 4)
     const int ns0 = sh * kNL;                     // first state of this lane
@@ -230,7 +239,7 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
     for (int k = 0; k < kNL; ++k) bbyte[k] = kOffB + 4u * (unsigned)brow[k];
     // this lane's 2 steps of a half in the per-(d, t) epilogue: columns 2 q, 2 q + 1 of the half (q = sh)
     const unsigned ebase = ubase ^ ((unsigned)(sh >> 1) << 4) ^ ((unsigned)(sh & 1) << 3);
-    const unsigned sums_base = 4u * (unsigned)((3 * kBW * kTile) + wave * kSums + (ns0 + (c >> 2)) * kDS + 2 * (c & 3));   // NV == 32 layout
+    const unsigned sums_base = 4u * (unsigned)((4 * kBW * kTile) + wave * kSums + (ns0 + (c >> 2)) * kDS + 2 * (c & 3));   // NV == 32 layout
     // per-lane constants and carries, all in registers (only ever indexed with compile-time constants)
     float A2[kNL], re[kNL], rdA[kNL];             // A log2 e; e = a_{t+1} dh_{t+1} carried across halves; dA accumulators
     {
@@ -310,15 +319,16 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
 #pragma unroll
                 for (int i = 0; i < kNPc; ++i) {
                     const int row = i * 8 + lrow;
-                    f32x4 vu = {{0.f, 0.f, 0.f, 0.f}}, vd = {{0.f, 0.f, 0.f, 0.f}};
+                    f32x4 vu = {{0.f, 0.f, 0.f, 0.f}}, vd = {{0.f, 0.f, 0.f, 0.f}}, vs = {{0.f, 0.f, 0.f, 0.f}};
                     if ((kFull || row < nd) && t0 + lcol < L) {
                         vu = widen(pu[i]);
                         vd = widen(pd[i]);
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) vd.v[s] = softplus_if(vd.v[s] + bias_row[i], softplus);
+                        for (int s = 0; s < 4; ++s) softplus_and_slope(vd.v[s] + bias_row[i], softplus, vd.v[s], vs.v[s]);
                     }
                     *reinterpret_cast<f32x4 *>(&tU[btile_off(row, lc4)]) = vu;
                     *reinterpret_cast<f32x4 *>(&tD[btile_off(row, lc4)]) = vd;
+                    *reinterpret_cast<f32x4 *>(&tS[btile_off(row, lc4)]) = vs;
                 }
                 // ---- dy = dout * silu(z), dz, optional out_z -- in the coalesced layout; only dy goes to LDS ---------------
 #pragma unroll
@@ -351,10 +361,10 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
             } else {
                 for (int i = 0; i < kBC * kBT / kWave; ++i) {
                     const int idx = i * kWave + lane, row = idx / kBT, col = idx & (kBT - 1), t = t0 + col;
-                    float vu = 0.f, vd = 0.f, dy = 0.f;
+                    float vu = 0.f, vd = 0.f, dy = 0.f, vs = 0.f;
                     if (row < nd && t < L) {
                         vu = to_f32<T>(u_base[(unsigned)(row * u_ds + t)]);
-                        vd = softplus_if(to_f32<T>(dl_base[(unsigned)(row * dl_ds + t)]) + (bias_p ? bias_p[d0 + row] : 0.f), softplus);
+                        softplus_and_slope(to_f32<T>(dl_base[(unsigned)(row * dl_ds + t)]) + (bias_p ? bias_p[d0 + row] : 0.f), softplus, vd, vs);
                         const float go = to_f32<T>(do_base[(unsigned)(row * do_ds + t)]);
                         if constexpr (kHasZ) {
                             const float zv = to_f32<T>(z_base[(unsigned)(row * z_ds + t)]), yv = to_f32<T>(y_base[(unsigned)(row * y_ds + t)]);
@@ -369,6 +379,7 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
                     tU[btile_off(row, col >> 2) + (col & 3)] = vu;
                     tD[btile_off(row, col >> 2) + (col & 3)] = vd;
                     tY[btile_off(row, col >> 2) + (col & 3)] = dy;
+                    tS[btile_off(row, col >> 2) + (col & 3)] = vs;
                 }
             }
         }
@@ -546,11 +557,11 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
                     const float2 u2 = *reinterpret_cast<const float2 *>(eo);
                     const float2 d2 = *reinterpret_cast<const float2 *>(eo + kOffD);
                     const float2 y2 = *reinterpret_cast<const float2 *>(eo + kOffY);
-                    // dead steps (t >= L) have dt = 0 -> factor 0 with softplus; without it they carry u = dy = 0 -> ddt = 0
-                    float dsp0 = dsoftplus_from_dt(d2.x), dsp1 = dsoftplus_from_dt(d2.y);
-                    asm volatile("" : "+v"(dsp0), "+v"(dsp1));
+                    // d softplus / d delta = sigmoid(delta + bias), formed where the softplus was (staging: its exp is at hand there); 1 without
+                    // softplus; dead steps (t >= L) and dead rows carry 0 (they have u = dy = 0 -> ddt = 0 anyway)
+                    const float2 sg2 = *reinterpret_cast<const float2 *>(eo + kOffS);
                     const float du0 = fmaf(d2.x, z4[0], Dval * y2.x), du1 = fmaf(d2.y, z4[2], Dval * y2.y);
-                    const float dd0 = softplus ? z4[1] * dsp0 : z4[1], dd1 = softplus ? z4[3] * dsp1 : z4[3];
+                    const float dd0 = z4[1] * sg2.x, dd1 = z4[3] * sg2.y;
                     dD = fmaf(y2.x, u2.x, fmaf(y2.y, u2.y, dD));
                     dbias += dd0 + dd1;
                     *reinterpret_cast<float2 *>(eo) = make_float2(du0, du1);

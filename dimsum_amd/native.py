@@ -785,6 +785,7 @@ def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=Non
         P.timing_start_event, P.timing_stop_event = events
     if tune is not None:
         P.tune_variant, P.tune_group_m = tune[:2]
+        P.tune_reserved = tune[2] if len(tune) > 2 else 0
     with torch.cuda.device(a.device):
         _lib.check(_lib.load().dimsum_gemm_nt(P, _stream(a)), "gemm_nt")
     if x12 is not None:

@@ -306,3 +306,72 @@ def test_alias_parameters_are_checked_at_the_c_abi():
     assert lib.dimsum_gemm_tn(ctypes.byref(params(b_alias_rows=192)), 1, 0, s) != 0
     assert lib.dimsum_gemm_tn(ctypes.byref(params(m=256, n=256, k=256, lda=2 * 256, ldb=2 * 256, tn_pair_a_cols=256, tn_pair_b_cols=256)), 2, 256 * 256, s) != 0   # splits % 3
     torch.cuda.synchronize()
+
+
+# ---- the 128 x 256-tile variant (kVarM128: 4-wave workgroups, two per CU, 80-KB ring; scaled-fp16 operands with short K) ----------------
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (256, 256, 192), (512, 384, 320), (768, 1152, 512), (256, 132, 256), (512, 4, 128),
+                                    (1024, 2048, 1024), (2048, 512, 2048)])
+def test_m128_tiles_are_bit_identical_to_the_256_row_tiles(M, N, K):
+    """the tile shape changes which workgroup owns an output element, not the order in which its products are accumulated (K tiles in
+    order, the same MFMA shape): fp16 products on 128-row tiles (tune 512) == on 256-row tiles (tune 513), bit for bit, for every ring
+    phase count (K / 64 = 2, 3, 5, 8, 16, 32: prologue-only, run-down and steady loops), ragged N, with and without row scales and bias;
+    both against float64; repeated launches identical (a race in the ring would show as run-to-run differences)"""
+    from dimsum_amd import native
+    a, b = _rnd((M, K), torch.float16, 1), _rnd((N, K), torch.float16, 2)
+    ref = a.double() @ b.double().t()
+    small, big = native.gemm_nt(a, b, tune=(512, 0, 0)), native.gemm_nt(a, b, tune=(513, 0, 0))
+    assert torch.equal(small, big)
+    assert (small.double() - ref).abs().max().item() / ref.abs().max().item() < 2e-6 * max(1.0, (K / 1024) ** 0.5) + 1e-7
+    for _ in range(3):
+        assert torch.equal(native.gemm_nt(a, b, tune=(512, 0, 0)), small)
+    sa = torch.exp2(torch.randint(-20, 20, (M,), device="cuda").float())
+    sb = torch.exp2(torch.randint(-20, 20, (N,), device="cuda").float())
+    bias = _rnd((N,), torch.float32, 3)
+    s1 = native.gemm_nt(a, b, bias=bias, scales=(sa, sb), tune=(512, 0, 0))
+    s2 = native.gemm_nt(a, b, bias=bias, scales=(sa, sb), tune=(513, 0, 0))
+    assert torch.equal(s1, s2)
+    want = ref * sa.double()[:, None] * sb.double()[None, :] + bias.double()
+    assert ((s1.double() - want).abs() <= 3e-6 * (ref.abs().max().item() * sa.double()[:, None] * sb.double()[None, :]) + 1e-6 * bias.abs().max().item()).all()
+
+
+def test_m128_one_hot_rows_land_where_they_belong():
+    """A = one-hot rows against an asymmetric B on the 128-row tiles: C must be exactly the selected rows of B^T"""
+    from dimsum_amd import native
+    M, N, K = 768, 512, 256
+    a = torch.zeros((M, K), device="cuda", dtype=torch.float16)
+    idx = (torch.arange(M, device="cuda") * 7 + 3) % K
+    a[torch.arange(M, device="cuda"), idx] = 1.0
+    b = ((torch.arange(N, device="cuda")[:, None] * 3 + torch.arange(K, device="cuda")[None, :] * 5) % 251).to(torch.float16)
+    got = native.gemm_nt(a, b, tune=(512, 0, 0))
+    assert torch.equal(got, b.float()[:, idx].t().contiguous())
+
+
+@pytest.mark.parametrize("with_gate", [True, False])
+def test_m128_epilogues_match_the_256_row_tiles(with_gate):
+    """the residual tail and the gated-GeLU fp16 epilogue (bound-derived per-row scales) on both tile shapes: identical bits"""
+    from dimsum_amd import native
+    B, L, N, K = 3, 256, 392, 320
+    M = B * L
+    a, b = _rnd((M, K), torch.float16, 1), _rnd((N, K), torch.float16, 2, scale=K ** -0.5)
+    sa, sb = torch.exp2(torch.randint(-6, 6, (M,), device="cuda").float()), torch.exp2(torch.randint(-6, 6, (N,), device="cuda").float())
+    res, bias = _rnd((M, N), torch.float32, 3), _rnd((N,), torch.float32, 4)
+    gate = _rnd((B, N), torch.float32, 5) if with_gate else None
+    kw = dict(bias=bias, residual=res, gate=gate, rows_per_batch=L if with_gate else None, scales=(sa, sb))
+    o1, o2 = native.gemm_nt(a, b, tune=(512, 0, 0), **kw), native.gemm_nt(a, b, tune=(513, 0, 0), **kw)
+    assert torch.equal(o1, o2)
+    y = (a.double() @ b.double().t()) * sa.double()[:, None] * sb.double()[None, :] + bias.double()
+    ref = res.double() + (y if gate is None else (y.view(B, L, N) * gate.double()[:, None, :]).view(M, N))
+    assert (o1.double() - ref).abs().max().item() / ref.abs().max().item() < 3e-6
+    # gated GeLU -> scaled-fp16 h image
+    F, H = 384, 256
+    x = native.rows_f16s(_rnd((M, H), torch.float32, 6) * torch.logspace(-2, 2, M, device="cuda")[:, None])
+    w12 = _rnd((2 * F, H), torch.float32, 7, scale=H ** -0.5)
+    b12 = _rnd((2 * F,), torch.float32, 8, scale=0.1)
+    w16, l1 = native.rows_f16s(w12, want_l1=True)
+    bound = torch.cat([l1 * (1.0 + 2.0 ** -10), b12.abs().max().reshape(1)]).contiguous()
+    kw = dict(bias=b12, epilogue="gated_f16", scales=(x.inv, w16.inv), gate_bound=bound)
+    h1, h2 = native.gemm_nt(x.data, w16.data, tune=(512, 0, 0), **kw), native.gemm_nt(x.data, w16.data, tune=(513, 0, 0), **kw)
+    assert torch.equal(h1.data.view(torch.int16), h2.data.view(torch.int16)) and torch.equal(h1.inv, h2.inv)
+    x12 = x.float().double() @ w16.float().double().t() + b12.double()
+    href = torch.nn.functional.gelu(x12[:, :F], approximate="tanh") * x12[:, F:]
+    assert ((h1.float().double() - href).abs() / href.abs().amax(-1, keepdim=True)).max().item() < 2e-3

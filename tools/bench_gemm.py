@@ -160,6 +160,50 @@ def tune(M, N, K, dtype, rounds, inner, check=True):
         print(f"  {k:22s} median {med:7.4f} ms  min {v[0]:7.4f}  {fl / med / 1e9:7.1f} TF", flush=True)
 
 
+def tiles_ab(rounds, inner):
+    """the scaled-fp16 launches of one DiM-L/2 forward at batch 256 on 256-row tiles (tune 513) against 128-row tiles (tune 512: two
+    4-wave workgroups per CU, csrc/gemm_nt_kernel.hpp kVarM128), interleaved rounds on one box; epilogues as the model runs them"""
+    M = 65536
+    def f16(shape, seed, scale=1.0):
+        return native.rows_f16s(rnd(shape, torch.float32, seed, scale))
+    shapes = [("in_proj (d-major out)", 2048, M, 512, "f32"), ("qkv + bias", M, 1536, 512, "bias"), ("proj + residual", M, 1024, 1024, "res"),
+              ("w12 + gate -> f16", M, 8192, 1024, "gated"), ("w3 + gate residual", M, 1024, 4096, "gres"), ("xl512 w12 + gate", M, 9216, 1152, "gated"),
+              ("xl512 in_proj", 2304, M, 576, "f32")]
+    for name, m, n, k, kind in shapes:
+        a, b = f16((m, k), 1), f16((n, k), 2, k ** -0.5)
+        kw = dict(scales=(a.inv, b.inv))
+        if kind == "bias":
+            kw["bias"] = rnd((n,), torch.float32, 3)
+        if kind in ("res", "gres"):
+            kw.update(bias=rnd((n,), torch.float32, 3), residual=rnd((m, n), torch.float32, 4))
+        if kind == "gres":
+            kw.update(gate=rnd((m // 256, n), torch.float32, 5), rows_per_batch=256)
+        if kind == "gated":
+            w, l1 = native.rows_f16s(rnd((n, k), torch.float32, 2, k ** -0.5), want_l1=True)
+            b12 = rnd((n,), torch.float32, 6, 0.1)
+            kw.update(bias=b12, epilogue="gated_f16", gate_bound=torch.cat([l1 * (1 + 2.0 ** -10), b12.abs().max().reshape(1)]).contiguous())
+        if kind == "gated":
+            out = None
+        else:
+            out = torch.empty((m, n), device="cuda", dtype=torch.float32)
+        arms = {"256-row tiles": lambda: native.gemm_nt(a.data, b.data, out=out, tune=(513, 0, 0), **kw),
+                "128-row tiles": lambda: native.gemm_nt(a.data, b.data, out=out, tune=(512, 0, 0), **kw)}
+        r0, r1 = arms["256-row tiles"](), arms["128-row tiles"]()
+        same = torch.equal(r0.data, r1.data) if kind == "gated" else torch.equal(r0, r1)
+        torch.cuda.synchronize()
+        res = {k_: [] for k_ in arms}
+        for _ in range(rounds):
+            for k_, f in arms.items():
+                res[k_].append(timed(f, inner))
+        row = {"shape": name, "M": m, "N": n, "K": k, "bit_identical": same}
+        for k_, v in res.items():
+            v.sort()
+            row[k_] = {"ms_median": round(v[len(v) // 2], 4), "ms_min": round(v[0], 4), "TF_median": round(2.0 * m * n * k / v[len(v) // 2] / 1e9, 1)}
+        print(json.dumps(row), flush=True)
+        del a, b, out, kw, r0, r1
+        torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
@@ -168,6 +212,7 @@ def main():
     ap.add_argument("--inner", type=int, default=10)
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--tune", action="store_true")
+    ap.add_argument("--tiles", action="store_true", help="A / B of the 256-row against the 128-row tile variant on the scaled-fp16 launch shapes")
     ap.add_argument("--pmc-run", action="store_true", help="a few launches of the w12-shape kernels (under rocprofv3 --pmc)")
     ap.add_argument("--pmc-run-tn", action="store_true", help="a few launches of the dW12-shape TN kernels (three-piece row stacks, pairs) and of the library's batched TN GEMM")
     args = ap.parse_args()
@@ -206,6 +251,8 @@ def main():
         tune(65536, 8192, 3072, torch.bfloat16, args.rounds, args.inner)
         tune(65536, 8192, 1024, torch.bfloat16, args.rounds, args.inner)
         tune(65536, 1024, 12288, torch.bfloat16, args.rounds, args.inner)
+    if args.tiles:
+        tiles_ab(args.rounds, args.inner)
     if args.perf:
         shapes = [("w12 split3", 65536, 8192, 3072, torch.bfloat16),
                   ("w3 split3", 65536, 1024, 12288, torch.bfloat16),
