@@ -95,6 +95,11 @@ class GemmParams(C.Structure):
                    ("tn_pair_a_cols", i64), ("tn_pair_b_cols", i64)])
 
 
+class F16sJob(C.Structure):
+    _fields_ = ([(n, vp) for n in ("src", "dst", "inv_scale_ptr", "l1max_ptr", "absmax_ptr")]
+                + [(n, i64) for n in ("rows", "cols", "src_row_stride", "dst_row_stride")] + [("l1_factor", f32), ("reserved", i32)])
+
+
 GEMM_EPI_F32, GEMM_EPI_GATED_GELU_SPLIT3, GEMM_EPI_GATED_GELU_F16, GEMM_EPI_F32_BIAS, GEMM_EPI_F32_GATE_RESIDUAL = 0, 1, 2, 3, 4
 
 # every symbol include/dimsum_hip.h declares (tests check the library exports all of them)
@@ -105,7 +110,7 @@ EXPORTS = (
     "dimsum_causal_conv1d_fwd", "dimsum_causal_conv1d_bwd",
     "dimsum_norm_fwd", "dimsum_norm_bwd", "dimsum_token_transform", "dimsum_xattn_fusion_fwd", "dimsum_xattn_fusion_bwd",
     "dimsum_gated_gelu_fwd", "dimsum_gated_gelu_bwd", "dimsum_gated_gelu_fwd_split3", "dimsum_gated_gelu_bwd_split3", "dimsum_gated_gelu_bwd_pair", "dimsum_split3", "dimsum_split3_t",
-    "dimsum_gemm_nt", "dimsum_gemm_tn", "dimsum_rows_f16s",
+    "dimsum_gemm_nt", "dimsum_gemm_tn", "dimsum_rows_f16s", "dimsum_rows_f16s_multi",
 )
 
 _lib = None
@@ -155,13 +160,16 @@ def load():
     if hasattr(lib, "dimsum_rows_f16s"):
         lib.dimsum_rows_f16s.restype = C.c_int
         lib.dimsum_rows_f16s.argtypes = [vp, i64, i64, i64, vp, i64, vp, vp, vp]
+    if hasattr(lib, "dimsum_rows_f16s_multi"):
+        lib.dimsum_rows_f16s_multi.restype = C.c_int
+        lib.dimsum_rows_f16s_multi.argtypes = [C.POINTER(F16sJob), i32, vp]
     if hasattr(lib, "dimsum_ssm_scan_bwd_workspace_bytes"):
         lib.dimsum_ssm_scan_bwd_workspace_bytes.restype = i64
         lib.dimsum_ssm_scan_bwd_workspace_bytes.argtypes = [i32] * 5
     if hasattr(lib, "dimsum_ssm_scan_fwd_variant"):
         lib.dimsum_ssm_scan_fwd_variant.restype = C.c_int
         lib.dimsum_ssm_scan_fwd_variant.argtypes = [C.POINTER(SsmParams)]
-    if lib.dimsum_abi_version() != 12:
+    if lib.dimsum_abi_version() != 13:
         raise RuntimeError("dimsum_amd: libdimsum_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -107,7 +107,109 @@ __global__ __launch_bounds__(256) void rows_f16s_kernel(const float *src, int64_
     }
 }
 
+// Many conversions in ONE launch (dimsum_rows_f16s_multi): what a denoiser forward under the scaled-fp16 policy needs of its weights --
+// the images of every large Linear (7 per DiMBlockCombined), their largest row L1 norms and the bias maxima of the bound-derived scales
+// -- used to be ~150 launches of 5-30 us per DiM-L/2 forward (2.2 ms of small grids + ~1 ms of torch reductions between the big kernels);
+// the job table travels in the kernel arguments, a workgroup finds its job by its block index. Rows of any length: two passes over a row
+// (the second read hits the cache); a job without `dst` only reduces (bias vectors: rows = 1).
+constexpr int kMultiJobs = 24;
+struct F16sJob {
+    const float *src;
+    __half *dst;
+    float *inv_scale, *l1max, *absmax;
+    int64_t rows, cols, src_stride, dst_stride;
+    float l1_factor;
+    int first_block;            // blocks [first_block, next job's first_block) work on this job
+};
+struct F16sJobs {
+    F16sJob job[kMultiJobs];
+    int n;
+};
+__global__ __launch_bounds__(256) void rows_f16s_multi_kernel(const F16sJobs t) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int j = 0;
+#pragma unroll 1
+    for (int i = 1; i < t.n; ++i) j = ((int)blockIdx.x >= t.job[i].first_block) ? i : j;
+    const F16sJob &q = t.job[j];
+    const int nblocks = (j + 1 < t.n ? t.job[j + 1].first_block : (int)gridDim.x) - q.first_block;
+    float l1top = 0.f, mtop = 0.f;
+    for (int64_t row = (int64_t)((int)blockIdx.x - q.first_block) * 4 + wave; row < q.rows; row += (int64_t)nblocks * 4) {
+        const float *x = q.src + row * q.src_stride;
+        float m = 0.f, l1 = 0.f;
+        for (int64_t c = lane * 4; c < q.cols; c += 256) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + c);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            l1 += (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
+        }
+        m = wave_allmax(m);
+        mtop = fmaxf(mtop, m);
+        if (q.dst) {
+            float sc, inv;
+            f16s_scales(m, sc, inv);
+            for (int64_t c = lane * 4; c < q.cols; c += 256) {
+                const float4 v = *reinterpret_cast<const float4 *>(x + c);
+                *reinterpret_cast<uint2 *>(q.dst + row * q.dst_stride + c) = f16s_pack4(f32x4{{v.x, v.y, v.z, v.w}}, sc);
+            }
+            if (lane == 0) q.inv_scale[row] = inv;
+        }
+        if (q.l1max) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) l1 += __shfl_xor(l1, o, kWave);
+            l1top = fmaxf(l1top, l1);
+        }
+    }
+    if (q.l1max || q.absmax) {          // (wave-uniform per workgroup: every wave of a workgroup works on the same job)
+        __shared__ float top[2][4];
+        if (lane == 0) { top[0][wave] = l1top; top[1][wave] = mtop; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float a = fmaxf(fmaxf(top[0][0], top[0][1]), fmaxf(top[0][2], top[0][3])) * q.l1_factor;
+            const float b = fmaxf(fmaxf(top[1][0], top[1][1]), fmaxf(top[1][2], top[1][3]));
+            if (q.l1max && a > __builtin_nontemporal_load(q.l1max)) atomicMax(reinterpret_cast<int *>(q.l1max), __float_as_int(a));
+            if (q.absmax && b > __builtin_nontemporal_load(q.absmax)) atomicMax(reinterpret_cast<int *>(q.absmax), __float_as_int(b));
+        }
+    }
+}
+
 }  // namespace dimsum
+
+extern "C" int dimsum_rows_f16s_multi(const dimsum_f16s_job_t *jobs, int32_t n_jobs, void *stream) {
+    using namespace dimsum;
+    if (n_jobs < 0 || (n_jobs > 0 && !jobs)) return DIMSUM_ERR_NULL;
+    for (int32_t i = 0; i < n_jobs; ++i) {
+        const dimsum_f16s_job_t &q = jobs[i];
+        if (!q.src || (q.dst && !q.inv_scale_ptr) || (!q.dst && !q.l1max_ptr && !q.absmax_ptr)) return DIMSUM_ERR_NULL;
+        if (q.rows <= 0 || q.cols <= 0 || q.cols % 4 != 0) return DIMSUM_ERR_SHAPE;
+        if (q.src_row_stride % 4 != 0 || q.src_row_stride < q.cols || !aligned_to<float>(q.src, 16) ||
+            (q.dst && (q.dst_row_stride % 4 != 0 || q.dst_row_stride < q.cols || !aligned_to<char>(q.dst, 8))))
+            return DIMSUM_ERR_STRIDE;
+    }
+    for (int32_t base = 0; base < n_jobs; base += kMultiJobs) {
+        F16sJobs t{};
+        t.n = n_jobs - base < kMultiJobs ? n_jobs - base : kMultiJobs;
+        int blocks = 0;
+        for (int i = 0; i < t.n; ++i) {
+            const dimsum_f16s_job_t &q = jobs[base + i];
+            F16sJob &o = t.job[i];
+            o.src = reinterpret_cast<const float *>(q.src);
+            o.dst = reinterpret_cast<__half *>(q.dst);
+            o.inv_scale = reinterpret_cast<float *>(q.inv_scale_ptr);
+            o.l1max = reinterpret_cast<float *>(q.l1max_ptr);
+            o.absmax = reinterpret_cast<float *>(q.absmax_ptr);
+            o.rows = q.rows; o.cols = q.cols; o.src_stride = q.src_row_stride; o.dst_stride = q.dst_row_stride;
+            o.l1_factor = q.l1_factor != 0.f ? q.l1_factor : 1.0f;
+            o.first_block = blocks;
+            // enough workgroups to stream the job at the chip's rate, few enough that the per-workgroup atomics on ONE address stay short
+            const int64_t by_rows = (q.rows + 3) / 4, by_bytes = (q.rows * q.cols * 4 + 65535) / 65536;
+            int64_t nb = by_rows < by_bytes ? by_rows : by_bytes;
+            nb = nb < 1 ? 1 : (nb > 512 ? 512 : nb);
+            blocks += (int)nb;
+        }
+        hipLaunchKernelGGL(rows_f16s_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), t);
+        if (launch_status() != DIMSUM_OK) return DIMSUM_ERR_LAUNCH;
+    }
+    return DIMSUM_OK;
+}
 
 extern "C" int dimsum_rows_f16s(const void *src, int64_t rows, int64_t cols, int64_t src_row_stride, void *dst, int64_t dst_row_stride,
                                 void *inv_scale, void *l1max, void *stream) {

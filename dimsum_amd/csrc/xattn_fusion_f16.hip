@@ -107,7 +107,8 @@ __global__ __launch_bounds__(256, (QT == 2 && HD <= 64) ? 3 : 2) void xattn_fusi
             }
         float qs, qinv;
         f16s_scales(quad_max(qm), qs, qinv);
-        cq[t] = p.scale * kLog2e * qinv * kv_inv;
+        // (never 0: a masked score is -inf, and -inf * 0 would be NaN for the whole row -- an all-zero query row with a tiny kv_inv underflows here)
+        cq[t] = fmaxf(p.scale * kLog2e * qinv * kv_inv, 1.17549435e-38f);
 #pragma unroll
         for (int c = 0; c < EC; ++c)
 #pragma unroll

@@ -101,9 +101,15 @@ def out_proj_planes_enabled(xz, weight, rows, scan_kernel=1):
     mode = os.environ.get("DIMSUM_OUT_PROJ_PLANES", "auto")
     if mode == "0" or (mode != "1" and scan_kernel == 1):
         return False
+    # ... and only where BOTH kernels take the operands (else the fp32 out_z + library GEMM, never an error): the TN GEMM wants whole
+    # 64-row reduction tiles with at least two of them per piece (d_inner % 64, d_inner >= 128), 256-column panels on both sides and
+    # 32-bit in-tile offsets of the (2 d_inner, rows) plane pair (native.gemm_tn_supported); the scan's plane epilogue is part of its
+    # 16-byte vector path (ssm_scan_fwd.hip: every xz row base 4-element aligned; seqlen % 8 is checked by the caller)
+    D = weight.shape[1]
     return (_policy in ("default", "f16s") and torch.backends.cuda.matmul.allow_tf32 and os.environ.get("DIMSUM_SPLIT3", "1") != "0"
             and own_gemm_enabled() and xz.is_cuda and xz.dtype == torch.float32 and weight.dtype == torch.float32
-            and weight.stride(1) == 1 and rows % 256 == 0 and weight.shape[0] % 256 == 0 and weight.shape[1] % 64 == 0
+            and weight.stride(1) == 1 and rows % 256 == 0 and weight.shape[0] % 256 == 0 and D % 64 == 0 and D >= 128
+            and 128 * rows + 512 < 2 ** 31 and xz.data_ptr() % 16 == 0 and all(st % 4 == 0 for st in xz.stride()[:-1]) and xz.stride(-1) == 1
             and rows >= int(os.environ.get("DIMSUM_SPLIT3_MIN_ROWS", "8192")))
 
 
@@ -283,23 +289,124 @@ def split3_enabled(x, weight, producer="token", left=True):
     return mode
 
 
+_K10 = 1.0 + 2.0 ** -10          # covers the fp16 rounding of the operands in the bound-derived scales
+
+
 def weight_f16s(weight, want_l1=False):
     """weight (N, K) float32 -> F16Image (N, K) [, l1]: its scaled-fp16 image (one exact power-of-two scale per row); want_l1: and
-    max_n sum_k |w_nk| as a 1-element device tensor (the gated epilogue's bound). Built once per frozen_weights() scope."""
+    max_n sum_k |w_nk| as a 1-element device tensor (the bound-derived scales need it). ONE cache entry per weight (image, l1): built
+    once per frozen_weights() scope -- or, for a whole model in one launch, by forward_scope()."""
     from . import native
-    if want_l1:
-        return _cached("w16s_l1", weight, lambda: native.rows_f16s(weight.detach(), want_l1=True))
-    return _cached("w16s", weight, lambda: native.rows_f16s(weight.detach()))
+    img, l1 = _cached("w16s", weight, lambda: native.rows_f16s(weight.detach(), want_l1=True))
+    if not want_l1:
+        return img
+    return img, (l1() if callable(l1) else l1)          # (forward_scope keeps the bound-scaled value and divides on demand)
+
+
+def _absmax(b, like):
+    return b.detach().float().abs().max().reshape(1) if b is not None else torch.zeros(1, device=like.device)
+
+
+def gated_bound(w12, b12):
+    """the 2-element bound tensor of the gated GEMM epilogue's h image: {max_n sum_k |w_nk| (1 + 2^-10), max |b|}"""
+    return _cached("w16s_bound", w12, lambda: torch.cat([weight_f16s(w12, want_l1=True)[1] * _K10, _absmax(b12, w12)]).contiguous())
 
 
 def attn_kv_bound(w1, b1, w2=None, b2=None):
-    """the 4-element bound tensor of the fp16 attention kernel (native.xattn_fusion_fwd(f16s=...)): {max_n sum_c |W1_nc|, max|b1|, the same
-    for the second qkv Linear (self-attention: the first again)}; the weight sums come with the weights' scaled-fp16 images (cached in a
-    frozen_weights() scope), the 2^-10 covers the fp16 rounding of the operands"""
+    """the 4-element bound tensor of the fp16 attention kernel (native.xattn_fusion_fwd(f16s=...)): {max_n sum_c |W1_nc| (1 + 2^-10), max|b1|,
+    the same for the second qkv Linear (self-attention: the first again)}; the weight sums come with the weights' scaled-fp16 images"""
     def one(w, b):
-        l1 = weight_f16s(w, want_l1=True)[1] * (1.0 + 2.0 ** -10)
-        return [l1, b.detach().float().abs().max().reshape(1) if b is not None else torch.zeros(1, device=w.device)]
+        return [weight_f16s(w, want_l1=True)[1] * _K10, _absmax(b, w)]
     return _cached("kvbound", w1, lambda: torch.cat(one(w1, b1) + (one(w2, b2) if w2 is not None else one(w1, b1))).contiguous())
+
+
+def f16s_plan(model):
+    """what a forward of `model` under the scaled-fp16 policy converts: [(weight, kind, bias, partner)] over its large bias-free-GEMM
+    Linears -- the mixers' in_proj, the fusion's qkv1 / qkv2 / proj, the shared attention's qkv / proj, the gated MLP's w12 / w3
+    (dimsum/models_dim.py:974-1117, mlp.py:49-70, attention_fusion.py:44-79). kind: "plain" (image), "gated" (image + the gate epilogue's
+    bound with `bias`), "kv" (image + its half of the attention kernel's bound; `partner` = the other qkv Linear's weight or None)."""
+    from .attention_fusion import CrossAttentionFusion
+    from .mlp import GatedMLP
+    plan = []
+    for m in model.modules():
+        if hasattr(m, "in_proj") and hasattr(m, "x_proj") and hasattr(m, "dt_proj"):
+            plan.append((m.in_proj.weight, "plain", None, None))
+        elif isinstance(m, CrossAttentionFusion):
+            plan += [(m.qkv1.weight, "kv", m.qkv1.bias, m.qkv2), (m.proj.weight, "plain", None, None)]
+        elif isinstance(m, GatedMLP):
+            plan += [(m.w12.weight, "gated", m.w12.bias, None), (m.w3.weight, "plain", None, None)]
+        elif type(m).__name__ == "Attention" and hasattr(m, "qkv") and hasattr(m, "proj"):
+            plan += [(m.qkv.weight, "kv", m.qkv.bias, None), (m.proj.weight, "plain", None, None)]
+    return plan
+
+
+@contextlib.contextmanager
+def forward_scope(model, rows):
+    """ONE inference forward of `model` over `rows` tokens under the scaled-fp16 policy: every weight image, weight L1 bound and bias maximum
+    the forward will ask for is built up front by ONE multi-job launch per 24 jobs (native.rows_f16s_multi) instead of ~150 small launches
+    and ~250 small torch reductions between the big kernels (3 ms of a 90-ms DiM-L/2 forward at batch 256), and lives exactly as long as
+    the forward -- weights cannot change inside one. Everything is still rebuilt on EVERY forward (`.data` updates between forwards are
+    seen); inside a frozen_weights() scope, under hipGraph capture (the conversion kernels must be part of the graph and their outputs
+    live in its pool: _cached bypasses the cache there), under autograd or another policy this is a no-op."""
+    import os
+    from . import native
+    first = next(model.parameters(), None)
+    if (_policy != "f16s" or _tls.frozen is not None or torch.is_grad_enabled() or not torch.backends.cuda.matmul.allow_tf32 or first is None
+            or not first.is_cuda or torch.cuda.is_current_stream_capturing() or not own_gemm_enabled() or os.environ.get("DIMSUM_SPLIT3", "1") == "0"
+            or rows < int(os.environ.get("DIMSUM_SPLIT3_MIN_ROWS", "8192")) or os.environ.get("DIMSUM_FORWARD_SCOPE", "1") == "0"):
+        yield
+        return
+    plan = getattr(model, "_f16s_plan", None)
+    if plan is None:
+        plan = model._f16s_plan = f16s_plan(model)
+    jobs, slot = [], 0
+    layout = []                     # per plan entry: (first job index, slot of its l1 [, ...])
+    for w, kind, bias, partner in plan:
+        ok = w.dtype == torch.float32 and w.is_cuda and w.stride(1) == 1 and w.shape[1] % 4 == 0 and w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0
+        if not ok:
+            layout.append(None)
+            continue
+        layout.append((len(jobs), slot))
+        if kind == "plain":
+            jobs.append((w.detach(), True, slot, None, 1.0))            # (the L1 norm rides along: one cache entry kind per weight)
+            slot += 1
+        elif kind == "gated":                                            # slots: l1 (1 + 2^-10), max |b| -- the bound tensor itself; then the plain l1
+            jobs.append((w.detach(), True, slot, None, _K10))
+            if bias is not None:
+                jobs.append((bias.detach().float(), False, None, slot + 1, 1.0))
+            slot += 2
+        else:                                                            # kv: slots l1_1 K10, max|b1|, l1_2 K10, max|b2| (self-attention: the pair twice)
+            ws = [(w, bias)] + ([(partner.weight, partner.bias)] if partner is not None else [])
+            for i, (wi, bi) in enumerate(ws):
+                jobs.append((wi.detach(), True, slot + 2 * i, None, _K10))
+                if bi is not None:
+                    jobs.append((bi.detach().float(), False, None, slot + 2 * i + 1, 1.0))
+            slot += 4
+    images, scal = native.rows_f16s_multi(jobs)
+    cache = {}
+    key = lambda kind, w: (kind, w.data_ptr(), tuple(w.shape), tuple(w.stride()), w.dtype)
+    for (w, kind, bias, partner), lay in zip(plan, layout):
+        if lay is None:
+            continue
+        j, sl = lay
+        if kind == "plain":
+            cache[key("w16s", w)] = ((images[j], scal[sl:sl + 1]), w)
+        elif kind == "gated":
+            cache[key("w16s", w)] = ((images[j], lambda i=sl: scal[i:i + 1] / _K10), w)          # (only evaluated if someone asks for the raw l1)
+            cache[key("w16s_bound", w)] = (scal[sl:sl + 2], w)
+        else:
+            cache[key("w16s", w)] = ((images[j], lambda i=sl: scal[i:i + 1] / _K10), w)
+            if partner is not None:
+                j2 = j + (2 if bias is not None else 1)
+                cache[key("w16s", partner.weight)] = ((images[j2], lambda i=sl + 2: scal[i:i + 1] / _K10), partner.weight)
+                cache[key("kvbound", w)] = (scal[sl:sl + 4], w)
+            else:
+                cache[key("kvbound", w)] = (torch.cat([scal[sl:sl + 2], scal[sl:sl + 2]]), w)
+    _tls.frozen = cache
+    try:
+        yield
+    finally:
+        _tls.frozen = None
 
 
 def own_gemm_enabled():
@@ -371,13 +478,11 @@ def gated_mlp_hidden_split3(x3, w12, b12):
     gated-GeLU pass (csrc/token_transform.hip) when the shape does not fit the kernel's tiling."""
     from . import native
     if isinstance(x3, native.F16Image):
-        w16, l1 = weight_f16s(w12, want_l1=True)
+        w16 = weight_f16s(w12)
         if own_gemm_enabled() and native.gemm_nt_supported(x3.data, w16.data, gated=True):
-            # the h image's per-row scale comes from the bound |x1|, |x2| <= max|x_r| * max_n sum_k |w_nk| + max|b| -- no row reduction.
-            # (the 2^-10 on the weight bound covers the fp16 rounding of the operands)
-            bmax = b12.abs().max().reshape(1) if b12 is not None else torch.zeros(1, device=l1.device)
-            bound = _cached("w16s_bound", w12, lambda: torch.cat([l1 * (1.0 + 2.0 ** -10), bmax]).contiguous())
-            return native.gemm_nt(x3.data, w16.data, bias=b12, epilogue="gated_f16", scales=(x3.inv, w16.inv), gate_bound=bound)
+            # the h image's per-row scale comes from the bound |x1|, |x2| <= max|x_r| * max_n sum_k |w_nk| + max|b| -- no row reduction
+            # (gated_bound: the 2^-10 on the weight bound covers the fp16 rounding of the operands)
+            return native.gemm_nt(x3.data, w16.data, bias=b12, epilogue="gated_f16", scales=(x3.inv, w16.inv), gate_bound=gated_bound(w12, b12))
         x12 = _nt_f16s(x3, w16)
         return native.rows_f16s(native.gated_gelu_fwd(x12, b12))
     w3i = weight_image(w12)

@@ -728,6 +728,10 @@ class DiM(nn.Module):
             t = torch.randint(0, 1000, (x.shape[0],), device=x.device)
         if y is None:
             y = torch.ones(x.size(0), dtype=torch.long, device=x.device) * (self.y_embedder.get_in_channels() - 1)
+        with gemm.forward_scope(self, x.shape[0] * self.x_embedder.num_patches):     # (inference under the scaled-fp16 policy: one weight-image launch)
+            return self._forward(x, t, y, inference_params)
+
+    def _forward(self, x, t, y, inference_params):
         c = self.t_embedder(t) + self.y_embedder(y, self.training)
         x = self.x_embedder(x) + self.pos_embed
         residual = None

@@ -585,6 +585,42 @@ def rows_f16s(x, want_l1=False):
     return (img, l1) if want_l1 else img
 
 
+def rows_f16s_multi(jobs):
+    """ONE launch per 24 jobs (csrc/operand_split.hip, dimsum_rows_f16s_multi). jobs: list of (x, image, l1_slot, absmax_slot, l1_factor):
+    x (R, K) float32 rows (or a (K,) vector: one row); image: build the F16Image; l1_slot / absmax_slot: index into the returned float32
+    scalar buffer that receives l1_factor * max_r sum_k |x_rk| / max |x| (None: not wanted; several jobs may NOT share a slot's meaning but
+    may share a slot: the maximum over them lands there). -> ([F16Image or None per job], scalars)"""
+    if not jobs:
+        return [], None
+    dev = jobs[0][0].device
+    n_slots = 1 + max([-1] + [s_ for j in jobs for s_ in j[2:4] if s_ is not None])
+    scal = torch.zeros(max(n_slots, 1), device=dev, dtype=torch.float32)
+    arr = (_lib.F16sJob * len(jobs))()
+    images, keep = [], []
+    for q, (x, image, l1_slot, abs_slot, factor) in zip(arr, jobs):
+        _gpu(x)
+        x2 = x if x.dim() == 2 else x.reshape(1, -1)
+        _check(x2.dtype == torch.float32 and x2.dim() == 2 and x2.stride(1) == 1 and x2.shape[1] % 4 == 0 and (x2.shape[0] == 1 or x2.stride(0) % 4 == 0),
+               "rows_f16s_multi: operands must be float32 rows with K % 4 == 0 and a row stride % 4 == 0")
+        R, K = x2.shape
+        q.src, q.rows, q.cols, q.src_row_stride = _ptr(x2), R, K, (x2.stride(0) if R > 1 else K)
+        if image:
+            out, inv = torch.empty((R, K), device=dev, dtype=torch.float16), torch.empty((R,), device=dev, dtype=torch.float32)
+            q.dst, q.inv_scale_ptr, q.dst_row_stride = _ptr(out), _ptr(inv), K
+            images.append(F16Image(out, inv))
+        else:
+            images.append(None)
+        if l1_slot is not None:
+            q.l1max_ptr = scal.data_ptr() + 4 * l1_slot
+        if abs_slot is not None:
+            q.absmax_ptr = scal.data_ptr() + 4 * abs_slot
+        q.l1_factor = float(factor)
+        keep.append(x2)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().dimsum_rows_f16s_multi(arr, len(jobs), _stream(jobs[0][0])), "rows_f16s_multi")
+    return images, scal
+
+
 def gemm_nt_supported(a, b, gated=False, pair=False, pair_b=False):
     """shapes the hand-written NT GEMM takes (csrc/gemm_nt_kernel.hpp): 256-row panels of 16-bit rows, 64-deep K tiles.
     pair / pair_b (or a PairImage operand): that operand is the [hi | lo] pair (rows of 2C) of a split-bf16 image over K = 3C (C % 64 == 0)"""

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DIMSUM_ABI_VERSION 12
+#define DIMSUM_ABI_VERSION 13
 
 typedef enum {
     DIMSUM_OK = 0,
@@ -245,6 +245,21 @@ int dimsum_split3_t(const void *src, int64_t rows, int64_t cols, int64_t src_row
  * Producer kernels write the image directly (dimsum_norm_params_t.y_split3 == 2, dimsum_tt_params_t.y_split3 == 2, GATED_GELU_F16). */
 int dimsum_rows_f16s(const void *src, int64_t rows, int64_t cols, int64_t src_row_stride, void *dst, int64_t dst_row_stride,
                      void *inv_scale, void *l1max, void *stream);
+
+/* Many scaled-fp16 conversions in ONE launch (per 24 jobs): the weight images, largest row L1 norms and bias maxima a whole denoiser forward
+ * needs under the scaled-fp16 policy (host: dimsum_amd/gemm.py forward_scope). No reference counterpart: the reference's cuBLAS TF32 GEMMs
+ * read the fp32 weights directly (dimsum/train.py:20-21). Same image as dimsum_rows_f16s, bit for bit. */
+typedef struct {
+    const void *src;            /* (rows, cols) f32 rows, 16-byte aligned, cols % 4 == 0, src_row_stride % 4 == 0 */
+    void *dst;                  /* (rows, cols) f16 image, or NULL: reduce only (a bias vector: rows = 1) */
+    void *inv_scale_ptr;        /* (rows) f32, required with dst */
+    void *l1max_ptr;            /* 1 f32, ZERO-FILLED by the caller, or NULL: l1_factor * max_r sum_k |x_rk| */
+    void *absmax_ptr;           /* 1 f32, ZERO-FILLED by the caller, or NULL: max |x| over the matrix */
+    int64_t rows, cols, src_row_stride, dst_row_stride;
+    float l1_factor;            /* 0 = 1 */
+    int32_t reserved;
+} dimsum_f16s_job_t;
+int dimsum_rows_f16s_multi(const dimsum_f16s_job_t *jobs, int32_t n_jobs, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Token-space transforms on (batch, L = grid*grid tokens, channels) f32 tensors: ONE pass that fuses

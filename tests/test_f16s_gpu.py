@@ -329,3 +329,62 @@ def test_attention_single_product_vs_tf32(hd, heads, L, self_attn):
     # the split-bf16 kernel on the same inputs agrees to the TF32 class
     three = native.xattn_fusion_fwd(args[0], args[1], heads, bias1=bs[0], bias2=None if self_attn else bs[1], split_bf16=True)
     assert ((out - three).abs() / row.float()).max().item() <= 3 * etf.max().item() + 1e-6
+
+
+def test_multi_job_conversion_is_the_single_conversion_bit_for_bit():
+    """dimsum_rows_f16s_multi (one launch for many weights: gemm.forward_scope) against dimsum_rows_f16s job by job: images, inverse
+    scales, L1 bounds (with their factor) and the reduce-only jobs of bias vectors; more jobs than one launch holds (24)"""
+    from dimsum_amd import native
+    g = torch.Generator(device="cuda").manual_seed(3)
+    shapes = [(2048, 512), (1536, 512), (1024, 1024), (8192, 1024), (1024, 4096), (48, 1024), (7, 260), (300, 72)] * 4      # 32 jobs
+    ws = [torch.randn(r, c, device="cuda", generator=g) * (10.0 ** (i % 5 - 2)) for i, (r, c) in enumerate(shapes)]
+    buf = torch.randn(64, 520, device="cuda", generator=g)
+    ws.append(buf[:, 4:516])                                            # a strided view (16-byte aligned rows)
+    bias = torch.randn(8192, device="cuda", generator=g)
+    jobs = [(w, True, 2 * i, 2 * i + 1, 1.0 + 2.0 ** -10) for i, w in enumerate(ws)] + [(bias, False, None, 2 * len(ws), 1.0)]
+    images, scal = native.rows_f16s_multi(jobs)
+    for i, w in enumerate(ws):
+        ref, l1 = native.rows_f16s(w, want_l1=True)
+        assert torch.equal(images[i].data.view(torch.int16), ref.data.view(torch.int16)) and torch.equal(images[i].inv, ref.inv), i
+        assert scal[2 * i].item() == (l1 * (1.0 + 2.0 ** -10)).item() and scal[2 * i + 1].item() == w.abs().max().item(), i
+    assert images[-1] is None and scal[2 * len(ws)].item() == bias.abs().max().item()
+
+
+def test_forward_scope_changes_launch_counts_not_bits(monkeypatch):
+    """DiM under the headline policy: with the per-forward weight scope (one multi-job launch for all images and bounds) the output is
+    bit-identical to per-call conversions, no single conversion is left, and the images are rebuilt on the next forward (a `.data` update
+    in between is seen)"""
+    from dimsum_amd import gemm, native
+    from dimsum_amd.create_model import create_model, published_config
+    from dimsum_amd.utils import rerandomize_zeros
+    torch.manual_seed(0)
+    m = create_model(published_config(model="DiM-L/2", image_size=256))
+    rerandomize_zeros(m, std=0.02, seed=0)
+    m = m.cuda().eval()
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    x, t = torch.randn(32, 4, 32, 32, device="cuda", generator=gen), torch.rand(32, device="cuda", generator=gen)
+    y = torch.randint(0, 1000, (32,), device="cuda", generator=gen)
+    singles, multis = [], []
+    real1, realm = native.rows_f16s, native.rows_f16s_multi
+    monkeypatch.setattr(native, "rows_f16s", lambda *a, **k: (singles.append(1), real1(*a, **k))[1])
+    monkeypatch.setattr(native, "rows_f16s_multi", lambda jobs: (multis.append(len(jobs)), realm(jobs))[1])
+    monkeypatch.setattr(torch.backends.cuda.matmul, "allow_tf32", True)
+    gemm.set_policy("f16s")
+    try:
+        with torch.no_grad():
+            monkeypatch.setenv("DIMSUM_FORWARD_SCOPE", "0")
+            ref = m(x, t, y)
+            n_single = len(singles)
+            assert n_single > 100 and not multis
+            monkeypatch.delenv("DIMSUM_FORWARD_SCOPE")
+            got = m(x, t, y)
+            assert len(singles) == n_single and len(multis) == 1 and multis[0] >= 7 * 16, (len(singles) - n_single, multis)
+            assert torch.equal(got, ref)
+            w = m.blocks[3].mlp.w3.weight
+            w.data.mul_(1.5)                                   # (no version bump: exactly what a cached image would miss)
+            changed = m(x, t, y)
+            assert len(multis) == 2 and not torch.equal(changed, ref)
+            w.data.div_(1.5)
+            assert torch.equal(m(x, t, y), ref)
+    finally:
+        gemm.set_policy("default")

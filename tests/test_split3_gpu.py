@@ -440,3 +440,33 @@ def test_producers_write_the_pair_image_as_hi_lo_of_their_three_piece_image():
         b2 = None if self_attn else rn(3 * H * hd)
         three = native.xattn_fusion_fwd(q1, q2, H, bias1=b1, bias2=b2, split_bf16=True, split3=True)
         check(native.xattn_fusion_fwd(q1, q2, H, bias1=b1, bias2=b2, split_bf16=True, split3="pair"), three, three.shape[-1] // 3)
+
+
+def test_out_proj_planes_predicate_never_raises_on_shapes_the_kernels_refuse(monkeypatch):
+    """DIMSUM_OUT_PROJ_PLANES=1 on a mixer whose d_inner is 64 (the TN GEMM needs two 64-row reduction tiles per piece: d_inner >= 128):
+    the predicate must send it down the fp32 out_z + library GEMM path instead of raising from native.gemm_tn's checks"""
+    from dimsum_amd import native
+    from dimsum_amd.modules.mamba_simple import Mamba
+    torch.manual_seed(0)
+    small = Mamba(32, d_state=16, expand=2).cuda().eval()          # d_inner 64; out_proj (32, 64): also no 256-row panel
+    x = torch.randn(4, 256, 32, device="cuda")
+    calls = []
+    real = native.gemm_tn
+    monkeypatch.setattr(native, "gemm_tn", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    monkeypatch.setattr(torch.backends.cuda.matmul, "allow_tf32", True)
+    monkeypatch.setenv("DIMSUM_SPLIT3_MIN_ROWS", "0")
+    monkeypatch.setenv("DIMSUM_OUT_PROJ_PLANES", "1")
+    with torch.no_grad():
+        y1 = small(x)
+    assert not calls
+    monkeypatch.setenv("DIMSUM_OUT_PROJ_PLANES", "0")
+    with torch.no_grad():
+        y0 = small(x)
+    assert torch.equal(y0, y1)
+    from dimsum_amd import gemm
+    monkeypatch.setenv("DIMSUM_OUT_PROJ_PLANES", "1")
+    w64 = torch.randn(256, 64, device="cuda")                       # the advisor's case proper: out_proj (256, 64) with 8192 rows
+    assert not gemm.out_proj_planes_enabled(torch.randn(4, 128, 2048, device="cuda"), w64, 8192, scan_kernel=4)
+    w128 = torch.randn(256, 128, device="cuda")
+    assert gemm.out_proj_planes_enabled(torch.randn(4, 256, 2048, device="cuda"), w128, 8192, scan_kernel=4)
+    assert not gemm.out_proj_planes_enabled(torch.randn(4, 256, 2050, device="cuda")[:, :, 1:2049], w128, 8192, scan_kernel=4)   # misaligned rows

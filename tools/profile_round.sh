@@ -6,20 +6,6 @@
 tag=${1:-rXX}
 out=$GRAFT_REPO_ROOT/gpurun_out/profiles_$tag; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-stats() {   # stats <name> <bench args...>
-  name=$1; shift
-  rm -rf /tmp/prof_$name
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python3 bench.py "$@" > $out/${name}.log 2>&1
-  f=$(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1)
-  [ -n "$f" ] && python3 - "$f" "$out/${tag}_${name}_kernel_stats.csv" <<'P'
-import csv, sys
-rows = list(csv.reader(open(sys.argv[1])))
-w = csv.writer(open(sys.argv[2], "w"))
-for r in rows:
-    w.writerow([c[:200] for c in r])          # kernel names truncated to 200 chars
-P
-  tail -1 $out/${name}.log | cut -c1-300
-}
 # the headline forward twice: as shipped (two HIP streams per block: overlapped kernels, the wall time) and on ONE stream
 # (DIMSUM_BRANCH_STREAMS=0: per-kernel durations that mean something -- this is what bench.py's single-stream roofline pass times)
 stats() {   # (every profiled run is bounded: a hung profiler must not eat the round's GPU minutes)
