@@ -77,7 +77,7 @@ class XattnParams(C.Structure):
                 + [(n, i64) for n in ("qkv_batch_stride", "qkv_token_stride", "out_batch_stride", "out_token_stride")]
                 + [(n, vp) for n in ("qkv1_ptr", "qkv2_ptr", "out_ptr", "lse_ptr", "bias1_ptr", "bias2_ptr")]
                 + [("precision", i32), ("out_split3", i32)]
-                + [(n, vp) for n in ("x1_inv_ptr", "x2_inv_ptr", "kv_bound_ptr", "out_inv_ptr")])
+                + [(n, vp) for n in ("x1_inv_ptr", "x2_inv_ptr", "kv_bound_ptr", "out_inv_ptr")] + [("qkv_f16", i32), ("reserved2", i32)])
 
 
 class XattnBwdParams(C.Structure):
@@ -91,7 +91,7 @@ class GemmParams(C.Structure):
                 + [(n, vp) for n in ("a_ptr", "b_ptr", "bias_ptr", "c_ptr", "timing_start_event", "timing_stop_event")]
                 + [(n, i32) for n in ("tune_variant", "tune_group_m", "tune_reserved")]
                 + [(n, vp) for n in ("a_inv_scale_ptr", "b_inv_scale_ptr", "gate_bound_ptr", "h_inv_scale_ptr", "residual_ptr", "gate_ptr")]
-                + [("residual_ld", i64), ("gate_ld", i64), ("rows_per_batch", i32), ("c_image_pieces", i32), ("x12_ptr", vp), ("x12_ld", i64), ("a_alias_rows", i64), ("b_alias_rows", i64), ("a_alias_weight_order", i32), ("reserved1", i32),
+                + [("residual_ld", i64), ("gate_ld", i64), ("rows_per_batch", i32), ("c_image_pieces", i32), ("x12_ptr", vp), ("x12_ld", i64), ("a_alias_rows", i64), ("b_alias_rows", i64), ("a_alias_weight_order", i32), ("qkv_q_cols", i32),
                    ("tn_pair_a_cols", i64), ("tn_pair_b_cols", i64)])
 
 
@@ -100,7 +100,7 @@ class F16sJob(C.Structure):
                 + [(n, i64) for n in ("rows", "cols", "src_row_stride", "dst_row_stride")] + [("l1_factor", f32), ("reserved", i32)])
 
 
-GEMM_EPI_F32, GEMM_EPI_GATED_GELU_SPLIT3, GEMM_EPI_GATED_GELU_F16, GEMM_EPI_F32_BIAS, GEMM_EPI_F32_GATE_RESIDUAL = 0, 1, 2, 3, 4
+GEMM_EPI_F32, GEMM_EPI_GATED_GELU_SPLIT3, GEMM_EPI_GATED_GELU_F16, GEMM_EPI_F32_BIAS, GEMM_EPI_F32_GATE_RESIDUAL, GEMM_EPI_F16_QKV = 0, 1, 2, 3, 4, 5
 
 # every symbol include/dimsum_hip.h declares (tests check the library exports all of them)
 EXPORTS = (

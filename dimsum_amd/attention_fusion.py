@@ -82,12 +82,20 @@ class CrossAttentionFusion(nn.Module):
             # the qkv biases ride in the GEMMs' epilogues: the attention kernel then stages K / V without the adds
             bk1 = {} if b1 is None else {"bias": b1.float().contiguous()}
             bk2 = {} if b2 is None else {"bias": b2.float().contiguous()}
-            qkv1 = gemm.linear_split3(x1.reshape(B * N, C3), self.qkv1.weight, **bk1).view(B, N, -1)
-            qkv2 = gemm.linear_split3(x2.reshape(B * N, C3), self.qkv2.weight, **bk2).view(B, N, -1)
-            if isinstance(x1, native.F16Image) and (self.num_heads * self.head_dim) % 8 == 0:
-                # scaled-fp16 policy: ONE fp16 product per element in QK^T / PV too, proj's operand image written with the same kind of scale
-                f3 = native.xattn_fusion_fwd(qkv1, qkv2, self.num_heads, split3="f16s",
-                                             f16s=(x1.inv.reshape(B, N), x2.inv.reshape(B, N), gemm.attn_kv_bound(self.qkv1.weight, b1, self.qkv2.weight, b2)))
+            f16 = isinstance(x1, native.F16Image) and (self.num_heads * self.head_dim) % 8 == 0
+            qkv1 = qkv2 = None
+            if f16:
+                # scaled-fp16 policy: q | k | v leave the qkv GEMMs as scaled fp16 (the F16_QKV epilogue: no fp32 qkv tensors) where the shape allows
+                kvb = gemm.attn_kv_bound(self.qkv1.weight, b1, self.qkv2.weight, b2)
+                qkv1 = gemm.qkv_f16s(x1.reshape(B * N, C3), self.qkv1.weight, b1, N, kvb[0:2])
+                qkv2 = gemm.qkv_f16s(x2.reshape(B * N, C3), self.qkv2.weight, b2, N, kvb[2:4]) if qkv1 is not None else None
+            if qkv2 is None:
+                qkv1 = gemm.linear_split3(x1.reshape(B * N, C3), self.qkv1.weight, **bk1)
+                qkv2 = gemm.linear_split3(x2.reshape(B * N, C3), self.qkv2.weight, **bk2)
+            qkv1, qkv2 = qkv1.view(B, N, -1), qkv2.view(B, N, -1)
+            if f16:
+                # ONE fp16 product per element in QK^T / PV too, proj's operand image written with the same kind of scale
+                f3 = native.xattn_fusion_fwd(qkv1, qkv2, self.num_heads, split3="f16s", f16s=(x1.inv.reshape(B, N), x2.inv.reshape(B, N), kvb))
             else:
                 f3 = native.xattn_fusion_fwd(qkv1, qkv2, self.num_heads, split_bf16=True, split3="pair" if isinstance(x1, native.PairImage) else True)
             if residual is not None:

@@ -97,6 +97,23 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
         constexpr int kShipR = kVarFullLineStores | kVarNtStores;
         return bf ? launch<kOpBf16, kEpiF32GateRes, kShipR>(a, s, e0, e1) : launch_f16<kEpiF32GateRes, kShipR>(a, s, e0, e1, m128);
     }
+    if (p->epilogue == DIMSUM_GEMM_EPI_F16_QKV) {
+        if (bf || !a.sa || !p->gate_bound_ptr) return DIMSUM_ERR_NULL;
+        if (p->rows_per_batch <= 0 || p->rows_per_batch % kBM != 0 || p->m % p->rows_per_batch != 0 || p->qkv_q_cols <= 0 || p->qkv_q_cols % 16 != 0 ||
+            p->qkv_q_cols > p->n || p->n % 8 != 0)
+            return DIMSUM_ERR_SHAPE;
+        if (p->ldc % 8 != 0 || p->ldc < p->n || !aligned_to<char>(p->c_ptr, 16) || (p->bias_ptr && !aligned_to<char>(p->bias_ptr, 16)) ||
+            (int64_t)257 * p->ldc * 2 >= ((int64_t)1 << 31))
+            return DIMSUM_ERR_STRIDE;
+        a.B0 = a.B1 = reinterpret_cast<const char *>(p->b_ptr);
+        a.bias0 = reinterpret_cast<const float *>(p->bias_ptr);
+        a.gate_bound = reinterpret_cast<const float *>(p->gate_bound_ptr);
+        a.rows_per_batch = p->rows_per_batch;
+        a.q_cols = p->qkv_q_cols;
+        a.N = p->n;
+        a.tiles_n = (p->n + kBN - 1) / kBN;
+        return launch_f16<kEpiF16Qkv>(a, s, e0, e1, p->tune_variant == 512 || (p->tune_variant == 0 && p->k <= 576));
+    }
     if (p->epilogue == DIMSUM_GEMM_EPI_F32 || p->epilogue == DIMSUM_GEMM_EPI_F32_BIAS) {
         if (p->ldc % 4 != 0 || p->ldc < p->n || !aligned_to<char>(p->c_ptr, 16)) return DIMSUM_ERR_STRIDE;
         const bool bias = p->epilogue == DIMSUM_GEMM_EPI_F32_BIAS;

@@ -57,7 +57,7 @@ constexpr int kParity = 4 * kHalf;         // bytes of one K tile in LDS
 constexpr int kSlotA0 = 0, kSlotA1 = kHalf, kSlotB0 = 2 * kHalf, kSlotB1 = 3 * kHalf;
 
 enum { kOpBf16 = 0, kOpF16 = 1 };
-enum { kEpiF32 = 0, kEpiGatedSplit3 = 1, kEpiGatedF16 = 2, kEpiF32Bias = 3, kEpiF32GateRes = 4 };
+enum { kEpiF32 = 0, kEpiGatedSplit3 = 1, kEpiGatedF16 = 2, kEpiF32Bias = 3, kEpiF32GateRes = 4, kEpiF16Qkv = 5 };
 
 struct Args {
     const char *A, *B0, *B1;       // B0 / B1: first weight row of the two 128-row halves' matrices (B1 = B0 + 128 rows for a plain GEMM)
@@ -84,6 +84,7 @@ struct Args {
     int tn_pieces;                 // kVarTN: both operands are [hi | lo] pairs: `splits` = 3 x splits_per_piece, split -> (piece, row range); the pieces pair
     int64_t a_pair_cols, b_pair_cols;   //         A (weight order) columns [0, lo, 0] with B (left order) columns [0, 0, lo]
     int b_alias_tiles;             // the same for the B rows (NT only: in_proj, whose activation image is the right operand)
+    int q_cols;                    // kEpiF16Qkv: columns [0, q_cols) take the per-row scale, the others the per-batch-element one
     int c_pieces2;                 // kEpiGatedSplit3: the h image is written as the pair [hi | lo] (ldc >= 2 F) for a consumer that reads it with a_alias_tiles
 };
 // tuning variants (bit mask; 0 = the shipped schedule)
@@ -579,6 +580,75 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
                                 store_f4<kAux>(rsrc, (unsigned)(((frow + mi * kMiRows + i * 16) * p.ldc + col) * 4), acc[mi][ni][i][j] + bv);
                     }
                 }
+        }
+    } else if constexpr (kEpi == kEpiF16Qkv) {
+        // q | k | v of the attention fusion as scaled fp16 (include/dimsum_hip.h, DIMSUM_GEMM_EPI_F16_QKV): the attention kernel reads half the
+        // bytes and stages K / V without a conversion. Scales from the bound |x W^T + b| <= 2^15 a_inv wl1 + bmax: q per row, k / v per
+        // batch element (the maximum of a_inv over the element's rows: a tile lies inside one element).
+        constexpr int kNW = kM1 ? 4 : 8;
+        float *red = reinterpret_cast<float *>(lds);              // (the ring is free: no DMA pending, every operand read retired)
+        {
+            const float *sab = p.sa + (int64_t)(m0 / p.rows_per_batch) * p.rows_per_batch;
+            float mloc = 0.f;
+            for (int t = threadIdx.x; t < p.rows_per_batch; t += kNW * 64) mloc = fmaxf(mloc, sab[t]);
+            mloc = wave_allmax(mloc);
+            if (lane == 0) red[w] = mloc;
+        }
+        __syncthreads();
+        float mb = red[0];
+#pragma unroll
+        for (int i = 1; i < kNW; ++i) mb = fmaxf(mb, red[i]);
+        __syncthreads();                                            // (the staging below overwrites `red`)
+        const float wl1 = p.gate_bound[0], bmax = p.gate_bound[1];
+        float kv_scale, kv_inv;
+        f16s_scales(2.0f * (32768.0f * mb * wl1 + bmax), kv_scale, kv_inv);
+        float row_sa[2][4], row_qs[2][4];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = mi * kMiRows + wr * 64 + i * 16 + (lane & 15);
+                row_sa[mi][i] = p.sa[m0 + r];
+                float qinv;
+                f16s_scales(2.0f * (32768.0f * row_sa[mi][i] * wl1 + bmax), row_qs[mi][i], qinv);
+            }
+        // the tile through LDS: [kTileM rows][256 cols] fp16, 512 B per row; the 8-byte unit u (4 columns) of row r sits at u ^ (r & 15)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int tcol = ni * 128 + ecol + j * 16, col = n0 + tcol;
+                f4 bv = f4{0.f, 0.f, 0.f, 0.f}, sbv = f4{1.f, 1.f, 1.f, 1.f};
+                if (col < p.N) {
+                    if (p.bias0) bv = *reinterpret_cast<const f4 *>(p.bias0 + col);
+                    sbv = *reinterpret_cast<const f4 *>(p.sb + col);
+                }
+                const bool is_q = col < p.q_cols;
+                const int unit = tcol >> 2;
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = mi * kMiRows + wr * 64 + i * 16 + (lane & 15);
+                        const f4 x = acc[mi][ni][i][j] * (sbv * row_sa[mi][i]) + bv;
+                        const float sc = is_q ? row_qs[mi][i] : kv_scale;
+                        const __half2 a = __floats2half2_rn(x[0] * sc, x[1] * sc), b = __floats2half2_rn(x[2] * sc, x[3] * sc);
+                        *reinterpret_cast<uint2 *>(lds + r * 512 + ((unit ^ (lane & 15)) << 3)) = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+                    }
+            }
+        __syncthreads();
+        // wave w stores rows 32 w .. 32 w + 31, two rows (512 B each) per instruction
+        char *Ct = reinterpret_cast<char *>(p.C) + ((int64_t)m0 * p.ldc + n0) * 2;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(Ct, 0, 0x7fffffff, 0x00020000);
+        const int piece = lane & 31;
+        const bool live = n0 + piece * 8 < p.N;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int r = w * 32 + it * 2 + (lane >> 5);
+            const char *src = lds + r * 512 + ((piece ^ ((r & 15) >> 1)) << 4);
+            u32x4 v = *reinterpret_cast<const u32x4 *>(src);
+            v = (r & 1) ? u32x4{v[2], v[3], v[0], v[1]} : v;
+            if (live) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (unsigned)((r * p.ldc + piece * 8) * 2), 0, 2);
         }
     } else {
         // gated GeLU: h = gelu_tanh(x1 + b1) (x2 + b2) with x1 = acc[mi][0], x2 = acc[mi][1] of the same hidden column. The 256 x 128 tile of h

@@ -495,6 +495,7 @@ extern "C" int dimsum_xattn_fusion_fwd(const dimsum_xattn_params_t *p, void *str
     const dim3 grid((unsigned)nblk), block(256);
     if (p->precision == 2) {
         if (!p->x1_inv_ptr || (!self_attn && !p->x2_inv_ptr) || !p->kv_bound_ptr) return DIMSUM_ERR_NULL;
+        if (p->qkv_f16 && (p->qkv_batch_stride % 8 != 0 || p->qkv_token_stride % 8 != 0 || p->head_dim % 8 != 0)) return DIMSUM_ERR_STRIDE;   // 16-byte fp16 loads
         if (p->out_split3 != 0 && p->out_split3 != 2) return DIMSUM_ERR_SHAPE;
         if (p->out_split3 == 2 && (!p->out_inv_ptr || p->out_token_stride < (int64_t)(self_attn ? 1 : 2) * p->heads * p->head_dim ||
                                    p->out_batch_stride % 8 != 0 || p->out_token_stride % 8 != 0 || (p->heads * p->head_dim) % 8 != 0))

@@ -15,6 +15,8 @@
 // Same transposed formulation, LDS layout (rows 4-11 of a fragment keep their 16-byte slot pairs swapped) and workgroup shape as the
 // split-bf16 kernel: S^T = K Q^T, O^T = V^T P^T, a lane works for one query per 16-query tile; 1 MFMA where that kernel issues 3, no
 // hi / lo splits anywhere (they were ~half of its VALU work).
+#include <type_traits>
+
 #include "xattn_common.hpp"
 
 namespace dimsum {
@@ -29,7 +31,10 @@ __device__ __forceinline__ unsigned pack_h2(float a, float b) {
 constexpr int kKT16 = 64;        // keys per tile
 constexpr int kQW16 = 16;        // queries per 16-query tile
 
-template <int HD, int QT>
+// kIn16: q | k | v arrive as the scaled fp16 the qkv GEMM's F16_QKV epilogue wrote (include/dimsum_hip.h: q scaled per row, k / v per batch
+// element, from the same bound and the same x_inv this kernel holds; biases included) -- half the bytes to read (the fp32 qkv tensors
+// made this kernel HBM-bound: 0.94 GB in 0.22 ms at DiM-L/2, batch 256), K goes to LDS as it is, V^T by byte permutes.
+template <int HD, int QT, bool kIn16>
 __global__ __launch_bounds__(256, (QT == 2 && HD <= 64) ? 3 : 2) void xattn_fusion_fwd_f16_kernel(const dimsum_xattn_params_t p) {
     constexpr int EP = (HD + 31) / 32 * 32;  // reduction length of QK^T, padded with zeros to whole 32-deep chunks
     constexpr int EC = EP / 32;
@@ -53,9 +58,10 @@ __global__ __launch_bounds__(256, (QT == 2 && HD <= 64) ? 3 : 2) void xattn_fusi
     const int b = idx / H;
     const int C = H * HD;
     const bool kv_from_1 = dir == 1 || ndir == 1;
-    const float *qsrc = reinterpret_cast<const float *>(dir == 0 ? p.qkv1_ptr : p.qkv2_ptr) + (int64_t)b * p.qkv_batch_stride + h * HD;
-    const float *kvsrc = reinterpret_cast<const float *>(kv_from_1 ? p.qkv1_ptr : p.qkv2_ptr) + (int64_t)b * p.qkv_batch_stride + h * HD;
-    const float *ksrc = kvsrc + C, *vsrc = kvsrc + 2 * C;
+    using In = typename std::conditional<kIn16, __half, float>::type;
+    const In *qsrc = reinterpret_cast<const In *>(dir == 0 ? p.qkv1_ptr : p.qkv2_ptr) + (int64_t)b * p.qkv_batch_stride + h * HD;
+    const In *kvsrc = reinterpret_cast<const In *>(kv_from_1 ? p.qkv1_ptr : p.qkv2_ptr) + (int64_t)b * p.qkv_batch_stride + h * HD;
+    const In *ksrc = kvsrc + C, *vsrc = kvsrc + 2 * C;
     const int64_t ts = p.qkv_token_stride;
     const float *qbv = reinterpret_cast<const float *>(dir == 0 ? p.bias1_ptr : p.bias2_ptr);
     const float *kvb = reinterpret_cast<const float *>(kv_from_1 ? p.bias1_ptr : p.bias2_ptr);
@@ -64,11 +70,11 @@ __global__ __launch_bounds__(256, (QT == 2 && HD <= 64) ? 3 : 2) void xattn_fusi
 
     // ---- the K / V (and output) scales of this batch element: max_t inv[b, t] of both qkv inputs, then the bound ----------------------
     float kv_scale, kv_inv, o_scale = 1.f, o_inv = 1.f;
+    const float *bnd = reinterpret_cast<const float *>(p.kv_bound_ptr);       // {wl1_1, bmax_1, wl1_2, bmax_2}
+    const float *i1 = reinterpret_cast<const float *>(p.x1_inv_ptr) + (int64_t)b * L;
+    const float *i2 = ndir == 2 ? reinterpret_cast<const float *>(p.x2_inv_ptr) + (int64_t)b * L : i1;
     {
-        const float *bnd = reinterpret_cast<const float *>(p.kv_bound_ptr);       // {wl1_1, bmax_1, wl1_2, bmax_2}
         float m1 = 0.f, m2 = 0.f;
-        const float *i1 = reinterpret_cast<const float *>(p.x1_inv_ptr) + (int64_t)b * L;
-        const float *i2 = ndir == 2 ? reinterpret_cast<const float *>(p.x2_inv_ptr) + (int64_t)b * L : i1;
         for (int t = tid; t < L; t += 256) { m1 = fmaxf(m1, i1[t]); m2 = fmaxf(m2, i2[t]); }
         m1 = wave_allmax(m1); m2 = wave_allmax(m2);
         if (lane == 0) { red[wave] = m1; red[4 + wave] = m2; }
@@ -91,6 +97,20 @@ __global__ __launch_bounds__(256, (QT == 2 && HD <= 64) ? 3 : 2) void xattn_fusi
     for (int t = 0; t < QT; ++t) {
         q_tok[t] = qb * (64 * QT) + (wave * QT + t) * kQW16 + qi;
         const int q_ld = min(q_tok[t], L - 1);
+        if constexpr (kIn16) {
+            // already fp16(q 2^sq) with sq from the row's bound: the same expression as in the GEMM epilogue that wrote it
+            float qs, qinv;
+            const float xinv = (dir == 0 ? i1 : i2)[q_ld];
+            f16s_scales(2.0f * (32768.0f * xinv * bnd[dir == 0 ? 0 : 2] + bnd[dir == 0 ? 1 : 3]), qs, qinv);
+            cq[t] = fmaxf(p.scale * kLog2e * qinv * kv_inv, 1.17549435e-38f);
+#pragma unroll
+            for (int c = 0; c < EC; ++c) {
+                const int e0 = 32 * c + 8 * kg;
+                qh[t][c] = u4v{{0u, 0u, 0u, 0u}};
+                if (e0 < HD) qh[t][c] = *reinterpret_cast<const u4v *>(qsrc + (int64_t)q_ld * ts + e0);
+            }
+            continue;
+        }
         float v[EC][8], qm = 0.f;
 #pragma unroll
         for (int c = 0; c < EC; ++c)
@@ -99,7 +119,7 @@ __global__ __launch_bounds__(256, (QT == 2 && HD <= 64) ? 3 : 2) void xattn_fusi
                 const int e0 = 32 * c + 8 * kg + 4 * half;
                 float4 tq = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (e0 < HD) {
-                    tq = *reinterpret_cast<const float4 *>(qsrc + (int64_t)q_ld * ts + e0);
+                    tq = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(qsrc) + (int64_t)q_ld * ts + e0);
                     if (qbias) { const float4 bq = *reinterpret_cast<const float4 *>(qbias + e0); tq.x += bq.x; tq.y += bq.y; tq.z += bq.z; tq.w += bq.w; }
                 }
                 v[c][4 * half + 0] = tq.x; v[c][4 * half + 1] = tq.y; v[c][4 * half + 2] = tq.z; v[c][4 * half + 3] = tq.w;
@@ -132,8 +152,30 @@ __global__ __launch_bounds__(256, (QT == 2 && HD <= 64) ? 3 : 2) void xattn_fusi
     }
 
     constexpr int kItems = (kKT16 / 2) * (HD / 4), kIters = (kItems + 255) / 256;
+    constexpr int kItems16 = (kKT16 / 2) * (HD / 8), kIters16 = (kItems16 + 255) / 256;
     for (int k0 = 0; k0 < L; k0 += kKT16) {
         __syncthreads();
+        if constexpr (kIn16) {
+            // ---- K [key][e] copied as it is, V^T [e][pi(key)] by byte permutes; one thread = 2 keys x 8 e (16 bytes per key and tensor) -------
+#pragma unroll
+            for (int it = 0; it < kIters16; ++it) {
+                const int i = tid + it * 256;
+                if (kItems16 % 256 != 0 && i >= kItems16) continue;
+                const int kp = i / (HD / 8), e8 = i - kp * (HD / 8), key = 2 * kp;
+                const int tok0 = min(k0 + key, L - 1), tok1 = min(k0 + key + 1, L - 1);
+                const u4v ka = *reinterpret_cast<const u4v *>(ksrc + (int64_t)tok0 * ts + e8 * 8), kb = *reinterpret_cast<const u4v *>(ksrc + (int64_t)tok1 * ts + e8 * 8);
+                const u4v va = *reinterpret_cast<const u4v *>(vsrc + (int64_t)tok0 * ts + e8 * 8), vb = *reinterpret_cast<const u4v *>(vsrc + (int64_t)tok1 * ts + e8 * 8);
+                const int ke = (e8 * 8) ^ flip(key);
+                *reinterpret_cast<u4v *>(&Kh[key * KS + ke]) = ka;
+                *reinterpret_cast<u4v *>(&Kh[(key + 1) * KS + ke]) = kb;
+                const int kap = key & 31, pos = (key & ~31) + 8 * ((kap & 15) >> 2) + (kap & 3) + 4 * (kap >> 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {          // e = 8 e8 + 2 j, + 1: (key, key + 1) pairs out of the low / high halves of word j
+                    *reinterpret_cast<unsigned *>(&Vh[(e8 * 8 + 2 * j) * VS + (pos ^ flip(e8 * 8 + 2 * j))]) = __builtin_amdgcn_perm(vb.w[j], va.w[j], 0x05040100u);
+                    *reinterpret_cast<unsigned *>(&Vh[(e8 * 8 + 2 * j + 1) * VS + (pos ^ flip(e8 * 8 + 2 * j + 1))]) = __builtin_amdgcn_perm(vb.w[j], va.w[j], 0x07060302u);
+                }
+            }
+        } else {
         // ---- stage K [key][e] and V^T [e][pi(key)] as fp16(x * kv_scale) for keys k0 .. k0+63; one thread = 2 keys x 4 e -----------------
 #pragma unroll
         for (int it = 0; it < kIters; ++it) {
@@ -141,8 +183,9 @@ __global__ __launch_bounds__(256, (QT == 2 && HD <= 64) ? 3 : 2) void xattn_fusi
             if (kItems % 256 != 0 && i >= kItems) continue;
             const int kp = i / (HD / 4), e4 = i - kp * (HD / 4), key = 2 * kp;
             const int tok0 = min(k0 + key, L - 1), tok1 = min(k0 + key + 1, L - 1);
-            float4 ka = *reinterpret_cast<const float4 *>(ksrc + (int64_t)tok0 * ts + e4 * 4), kb = *reinterpret_cast<const float4 *>(ksrc + (int64_t)tok1 * ts + e4 * 4);
-            float4 va = *reinterpret_cast<const float4 *>(vsrc + (int64_t)tok0 * ts + e4 * 4), vb = *reinterpret_cast<const float4 *>(vsrc + (int64_t)tok1 * ts + e4 * 4);
+            const float *kf = reinterpret_cast<const float *>(ksrc), *vf = reinterpret_cast<const float *>(vsrc);
+            float4 ka = *reinterpret_cast<const float4 *>(kf + (int64_t)tok0 * ts + e4 * 4), kb = *reinterpret_cast<const float4 *>(kf + (int64_t)tok1 * ts + e4 * 4);
+            float4 va = *reinterpret_cast<const float4 *>(vf + (int64_t)tok0 * ts + e4 * 4), vb = *reinterpret_cast<const float4 *>(vf + (int64_t)tok1 * ts + e4 * 4);
             if (kbias) {
                 const float4 bk = *reinterpret_cast<const float4 *>(kbias + e4 * 4), bv = *reinterpret_cast<const float4 *>(vbias + e4 * 4);
                 ka.x += bk.x; ka.y += bk.y; ka.z += bk.z; ka.w += bk.w; kb.x += bk.x; kb.y += bk.y; kb.z += bk.z; kb.w += bk.w;
@@ -157,6 +200,7 @@ __global__ __launch_bounds__(256, (QT == 2 && HD <= 64) ? 3 : 2) void xattn_fusi
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 *reinterpret_cast<unsigned *>(&Vh[(e4 * 4 + e) * VS + (pos ^ flip(e4 * 4))]) = pack_h2(a4[e] * kv_scale, b4[e] * kv_scale);
+        }
         }
         __syncthreads();
 
@@ -285,8 +329,11 @@ int launch_xattn_f16(const dimsum_xattn_params_t &p, hipStream_t s) {
     if (nblk > 0x7fffffff) return DIMSUM_ERR_SHAPE;
     const dim3 grid((unsigned)nblk), block(256);
 #define DIMSUM_XF16(HDV)                                                                                \
-    if (two) hipLaunchKernelGGL((xattn_fusion_fwd_f16_kernel<HDV, 2>), grid, block, 0, s, p);           \
-    else hipLaunchKernelGGL((xattn_fusion_fwd_f16_kernel<HDV, 1>), grid, block, 0, s, p)
+    if (p.qkv_f16) {                                                                                    \
+        if (two) hipLaunchKernelGGL((xattn_fusion_fwd_f16_kernel<HDV, 2, true>), grid, block, 0, s, p); \
+        else hipLaunchKernelGGL((xattn_fusion_fwd_f16_kernel<HDV, 1, true>), grid, block, 0, s, p);     \
+    } else if (two) hipLaunchKernelGGL((xattn_fusion_fwd_f16_kernel<HDV, 2, false>), grid, block, 0, s, p); \
+    else hipLaunchKernelGGL((xattn_fusion_fwd_f16_kernel<HDV, 1, false>), grid, block, 0, s, p)
     switch (p.head_dim) {
         case 24: DIMSUM_XF16(24); break;
         case 32: DIMSUM_XF16(32); break;

@@ -320,6 +320,22 @@ def attn_kv_bound(w1, b1, w2=None, b2=None):
     return _cached("kvbound", w1, lambda: torch.cat(one(w1, b1) + (one(w2, b2) if w2 is not None else one(w1, b1))).contiguous())
 
 
+def qkv_f16s(x, weight, bias, rows_per_batch, bound2):
+    """the qkv Linear of an attention under the scaled-fp16 policy with q | k | v written as scaled fp16 by the GEMM's epilogue (F16_QKV: q per
+    row, k / v per batch element, from bound2 = this Linear's half {wl1 (1 + 2^-10), max|b|} of attn_kv_bound): x F16Image (M, K) ->
+    (M, 3 C) float16, or None where the kernel does not take the shape (the caller then runs the fp32-output GEMM). The attention kernel
+    reads half the bytes (it was HBM-bound on the fp32 qkv tensors) and the GEMM writes half. DIMSUM_QKV_F16=0 switches it off."""
+    from . import native
+    w16 = weight_f16s(weight)
+    N = weight.shape[0]
+    if not (os.environ.get("DIMSUM_QKV_F16", "1") != "0" and own_gemm_enabled() and native.gemm_nt_supported(x.data, w16.data) and rows_per_batch % 256 == 0
+            and x.data.shape[0] % rows_per_batch == 0 and N % 3 == 0 and (N // 3) % 16 == 0):
+        return None
+    b = None if bias is None else bias.detach().float().contiguous()
+    return native.gemm_nt(x.data, w16.data, bias=b, epilogue="f16_qkv", scales=(x.inv, w16.inv), gate_bound=bound2, rows_per_batch=rows_per_batch,
+                          q_cols=N // 3)
+
+
 def f16s_plan(model):
     """what a forward of `model` under the scaled-fp16 policy converts: [(weight, kind, bias, partner)] over its large bias-free-GEMM
     Linears -- the mixers' in_proj, the fusion's qkv1 / qkv2 / proj, the shared attention's qkv / proj, the gated MLP's w12 / w3

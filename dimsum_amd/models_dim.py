@@ -208,14 +208,21 @@ class Attention(nn.Module):
             # (the qkv bias rides in the GEMM's epilogue where the MFMA attention kernels follow: they then stage K / V without the adds)
             qb = None if self.qkv.bias is None else self.qkv.bias.float().contiguous()
             in_gemm = qb is not None and native.xattn_supported(x, self.head_dim)
-            qkv = gemm.linear_split3(x3, self.qkv.weight, **({"bias": qb} if in_gemm else {})).view(B, N, 3 * C)
-            if native.xattn_supported(qkv, self.head_dim):
+            f16 = isinstance(x3, native.F16Image) and C % 8 == 0 and native.xattn_supported(x, self.head_dim)
+            qkv = None
+            if f16:     # scaled-fp16 policy: q | k | v as scaled fp16 out of the GEMM's epilogue (gemm.qkv_f16s) where the shape allows
+                kvb = gemm.attn_kv_bound(self.qkv.weight, self.qkv.bias)
+                qkv = gemm.qkv_f16s(x3.reshape(B * N, -1), self.qkv.weight, self.qkv.bias, N, kvb[0:2])
+                if qkv is not None:
+                    qkv, in_gemm = qkv.view(B, N, 3 * C), True
+            if qkv is None:
+                qkv = gemm.linear_split3(x3, self.qkv.weight, **({"bias": qb} if in_gemm else {})).view(B, N, 3 * C)
+            if native.xattn_supported(x, self.head_dim):
                 # the attention kernel writes the operand image of proj directly
                 if in_gemm:
                     qb = None
-                if isinstance(x3, native.F16Image) and C % 8 == 0:         # scaled-fp16 policy: the single-product attention kernel
-                    o3 = native.xattn_fusion_fwd(qkv, None, self.num_heads, bias1=qb, split3="f16s",
-                                                 f16s=(x3.inv.reshape(B, N), None, gemm.attn_kv_bound(self.qkv.weight, self.qkv.bias)))
+                if f16:                                                     # the single-product attention kernel
+                    o3 = native.xattn_fusion_fwd(qkv, None, self.num_heads, bias1=qb, split3="f16s", f16s=(x3.inv.reshape(B, N), None, kvb))
                 else:
                     o3 = native.xattn_fusion_fwd(qkv, None, self.num_heads, bias1=qb, split_bf16=True, split3="pair" if isinstance(x3, native.PairImage) else True)
                 if residual is not None:

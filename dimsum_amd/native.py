@@ -731,7 +731,7 @@ def gemm_tn(a, b, splits=None, events=None, alias_rows=0):
 
 
 def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=None, tune=None, scales=None, gate_bound=None, residual=None,
-            gate=None, rows_per_batch=None, keep_x12=False, pair_out=False, weight_order=False):
+            gate=None, rows_per_batch=None, keep_x12=False, pair_out=False, weight_order=False, q_cols=None):
     """a (M, K) @ b (N, K)^T on the hand-written MFMA kernel, 16-bit operands (bfloat16: split-bf16 images over 3 K; float16: scaled rows),
     fp32 accumulation.
       epilogue "f32"          -> (M, N) float32 (+ bias[N])
@@ -752,7 +752,7 @@ def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=Non
     if pair_b:
         b = b.data
     _gpu(a, b, bias)
-    gated = epilogue != "f32"
+    gated = epilogue in ("gated_split3", "gated_f16")
     _check(not (pair_in and pair_b) and not (pair_b and (gated or residual is not None or bias is not None)), "gemm_nt: a right-hand pair goes with the plain fp32 epilogue")
     _check(gemm_nt_supported(a, b, gated, pair=pair_in, pair_b=pair_b), "gemm_nt: unsupported operands (M % 256, K % 64, K >= 128, 16-bit K-contiguous rows, 16-byte aligned)")
     M, K = a.shape[0], (a.shape[1] if pair_b else b.shape[1])
@@ -790,6 +790,15 @@ def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=Non
         if out is None:
             out = torch.empty((M, pieces * (N // 2)), device=a.device, dtype=torch.bfloat16)
         _check(out.dtype == torch.bfloat16 and out.shape == (M, pieces * (N // 2)) and out.stride(1) == 1, "gemm_nt: out must be (M, 3F) / (M, 2F) bfloat16 rows")
+    elif epilogue == "f16_qkv":
+        # the qkv Linear of the attention fusion as scaled fp16 (include/dimsum_hip.h, DIMSUM_GEMM_EPI_F16_QKV): q_cols = the width of q
+        P.epilogue = _lib.GEMM_EPI_F16_QKV
+        _check(scales is not None and gate_bound is not None and rows_per_batch and rows_per_batch % 256 == 0 and M % rows_per_batch == 0
+               and q_cols and q_cols % 16 == 0 and N % 8 == 0, "gemm_nt: f16_qkv needs scales, gate_bound = {wl1, bmax}, rows_per_batch % 256 == 0, q_cols % 16 == 0")
+        P.rows_per_batch, P.qkv_q_cols = rows_per_batch, q_cols
+        if out is None:
+            out = torch.empty((M, N), device=a.device, dtype=torch.float16)
+        _check(out.dtype == torch.float16 and out.shape == (M, N) and out.stride(1) == 1, "gemm_nt: out must be (M, N) float16 rows")
     elif epilogue == "gated_f16":
         P.epilogue = _lib.GEMM_EPI_GATED_GELU_F16
         if out is None:
@@ -807,10 +816,12 @@ def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=Non
         P.a_inv_scale_ptr, P.b_inv_scale_ptr = _ptr(sa), _ptr(sb)
         if gate_bound is not None:
             _gpu(gate_bound)
-            _check(epilogue == "gated_f16" and gate_bound.dtype == torch.float32 and gate_bound.numel() == 2 and gate_bound.is_contiguous(),
-                   "gemm_nt: gate_bound is a 2-element float32 tensor for the gated_f16 epilogue")
-            h_inv = torch.empty((M,), device=a.device, dtype=torch.float32)
-            P.gate_bound_ptr, P.h_inv_scale_ptr = _ptr(gate_bound), _ptr(h_inv)
+            _check(epilogue in ("gated_f16", "f16_qkv") and gate_bound.dtype == torch.float32 and gate_bound.numel() == 2 and gate_bound.is_contiguous(),
+                   "gemm_nt: gate_bound is a 2-element float32 tensor for the gated_f16 / f16_qkv epilogues")
+            P.gate_bound_ptr = _ptr(gate_bound)
+            if epilogue == "gated_f16":
+                h_inv = torch.empty((M,), device=a.device, dtype=torch.float32)
+                P.h_inv_scale_ptr = _ptr(h_inv)
     P.a_ptr, P.b_ptr, P.bias_ptr, P.c_ptr = _ptr(a), _ptr(b), _ptr(bias), _ptr(out)
     x12 = None
     if keep_x12:
@@ -875,9 +886,10 @@ def xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=False, bias1=None, bias2=None, 
             _check(bb.dtype == torch.float32 and bb.numel() == qkv1.shape[2] and bb.is_contiguous(), "xattn_fusion: bad bias")
     B, L, W = qkv1.shape
     hd = W // (3 * heads)
-    _check(qkv1.dtype == torch.float32 and qkv1.stride(2) == 1, "xattn_fusion: bad qkv")
+    qkv_f16 = qkv1.dtype == torch.float16          # the F16_QKV epilogue's output (gemm_nt(epilogue="f16_qkv")): the fp16 kernel's own scaling
+    _check((qkv1.dtype == torch.float32 or (qkv_f16 and f16s is not None and bias1 is None and bias2 is None)) and qkv1.stride(2) == 1, "xattn_fusion: bad qkv")
     if not self_attn:
-        _check(qkv1.shape == qkv2.shape and qkv2.dtype == torch.float32 and qkv1.stride() == qkv2.stride(), "xattn_fusion: qkv1/qkv2 must share shape and strides")
+        _check(qkv1.shape == qkv2.shape and qkv2.dtype == qkv1.dtype and qkv1.stride() == qkv2.stride(), "xattn_fusion: qkv1/qkv2 must share shape, dtype and strides")
     nd = 1 if self_attn else 2
     out_inv = None
     if f16s is not None:
@@ -908,6 +920,7 @@ def xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=False, bias1=None, bias2=None, 
         P.out_split3 = _SPLIT_MODE.get(split3, int(bool(split3)))
         if f16s is not None:
             P.precision = 2
+            P.qkv_f16 = int(qkv_f16)
             P.x1_inv_ptr, P.x2_inv_ptr, P.kv_bound_ptr, P.out_inv_ptr = _ptr(x1_inv), _ptr(x2_inv), _ptr(kv_bound), _ptr(out_inv)
         with torch.cuda.device(qkv1.device):
             _lib.check(_lib.load().dimsum_xattn_fusion_fwd(P, _stream(qkv1)), "xattn_fusion_fwd")

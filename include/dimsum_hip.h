@@ -345,6 +345,9 @@ typedef struct {
      * where x*_inv are the inverse row scales (batch, L) of the scaled-fp16 images the qkv GEMMs consumed (wl1 = max_n sum_c |W_nc|). */
     const void *x1_inv_ptr, *x2_inv_ptr, *kv_bound_ptr;
     void *out_inv_ptr;  /* (batch, L) f32, out_split3 == 2 */
+    int32_t qkv_f16;    /* precision 2 only. 1: qkv1 / qkv2 are the fp16 outputs of dimsum_gemm_nt's F16_QKV epilogue (biases included, scaled as
+                           described there; qkv strides in fp16 elements, bias pointers unused): half the bytes of the fp32 qkv tensors */
+    int32_t reserved2;
 } dimsum_xattn_params_t;
 
 int dimsum_xattn_fusion_fwd(const dimsum_xattn_params_t *p, void *stream);
@@ -400,7 +403,14 @@ int dimsum_gated_gelu_bwd_pair(const void *x12, const void *bias, const void *dh
  * ------------------------------------------------------------------------------------------------------------- */
 typedef enum {
     DIMSUM_GEMM_EPI_F32 = 0, DIMSUM_GEMM_EPI_GATED_GELU_SPLIT3 = 1, DIMSUM_GEMM_EPI_GATED_GELU_F16 = 2, DIMSUM_GEMM_EPI_F32_BIAS = 3,
-    DIMSUM_GEMM_EPI_F32_GATE_RESIDUAL = 4
+    DIMSUM_GEMM_EPI_F32_GATE_RESIDUAL = 4,
+    DIMSUM_GEMM_EPI_F16_QKV = 5     /* the qkv Linear of the attention fusion under the scaled-fp16 policy (attention_fusion.py:52-60, models_dim.py:1470):
+                                       C (m, n = 3 C') fp16 = fp16((A B^T + bias) 2^s), scaled-fp16 operands (a / b_inv_scale_ptr required). Columns
+                                       [0, qkv_q_cols) (q) take one power-of-two scale per ROW, the rest (k, v) one per BATCH ELEMENT (rows_per_batch rows,
+                                       a multiple of 256), both from the bound |x W^T + b| <= 2^15 a_inv * wl1 + bmax with gate_bound_ptr = {wl1, bmax}:
+                                           s_row = scale(2 (2^15 a_inv[row] wl1 + bmax)),  s_batch = scale(2 (2^15 max_t a_inv[b, t] wl1 + bmax))
+                                       -- exactly what dimsum_xattn_fusion_fwd (precision 2, qkv_f16 = 1) assumes of its fp16 inputs: it recomputes the
+                                       same scales from the same a_inv and bound. Halves the bytes between the two kernels (no fp32 qkv tensor). */
 } dimsum_gemm_epilogue_t;
 
 typedef struct {
@@ -441,7 +451,7 @@ typedef struct {
        tn_pair_a_cols / tn_pair_b_cols (dimsum_gemm_tn): both operands are pairs -- a_ptr rows [hi | lo] with lo at column tn_pair_a_cols (read
        in weight order), b_ptr rows [hi | lo] with lo at column tn_pair_b_cols (read in left order); k = the rows of one piece, splits = 3 x the
        number of row ranges: partial result (piece, range) pairs A's piece with B's piece over that range. */
-    int32_t a_alias_weight_order, reserved1;
+    int32_t a_alias_weight_order, qkv_q_cols;      /* qkv_q_cols: F16_QKV only (% 16 == 0) */
     int64_t tn_pair_a_cols, tn_pair_b_cols;
 } dimsum_gemm_params_t;
 

@@ -277,8 +277,10 @@ def test_model_under_f16s_policy_vs_emulated_tf32(name, image_size, B):
     assert m1 / scale < 1e-3
 
 
-@pytest.mark.parametrize("hd,heads,L,self_attn", [(64, 8, 256, False), (64, 4, 200, False), (72, 4, 320, False), (24, 4, 256, True), (64, 16, 256, True)])
-def test_attention_single_product_vs_tf32(hd, heads, L, self_attn):
+@pytest.mark.parametrize("hd,heads,L,self_attn,fp16_qkv", [(64, 8, 256, False, False), (64, 4, 200, False, False), (72, 4, 320, False, False), (24, 4, 256, True, False),
+                                                            (64, 16, 256, True, False), (64, 8, 256, False, True), (72, 8, 512, False, True), (48, 8, 256, True, True),
+                                                            (64, 16, 256, True, True), (48, 8, 256, False, True)])
+def test_attention_single_product_vs_tf32(hd, heads, L, self_attn, fp16_qkv):
     """the fp16 single-product attention kernel (csrc/xattn_fusion_f16.hip) against float64 SDPA math, next to the emulated-TF32
     evaluation (q, k, v and p rounded to 10 mantissa bits, fp32 products): the deviation is of the same size; the scaled-fp16 image
     output decodes to the fp32 output within fp16's significand; rows of very different magnitude (10^-3 .. 10^3) per token"""
@@ -300,6 +302,25 @@ def test_attention_single_product_vs_tf32(hd, heads, L, self_attn):
         bound = gemm.attn_kv_bound(ws[0], bs[0], ws[1], bs[1])
         args = (qkvs[0], qkvs[1], heads)
         kw = dict(bias1=bs[0], bias2=bs[1], f16s=(imgs[0].inv.reshape(B, L), imgs[1].inv.reshape(B, L), bound))
+    if fp16_qkv:
+        # q | k | v as the scaled fp16 the qkv GEMM's F16_QKV epilogue writes (biases included): the attention kernel's fp16-input variant
+        q16 = [gemm.qkv_f16s(i, w, b_, L, bound[2 * n:2 * n + 2]) for n, (i, w, b_) in enumerate(zip(imgs, ws, bs)) if n == 0 or not self_attn]
+        assert all(q is not None and q.dtype == torch.float16 for q in q16)
+        # the epilogue's numbers: fp16((x W^T + b) 2^s) with s from the row's (q) / the batch element's (k, v) bound -- decoded, they are the
+        # fp32 GEMM output within fp16's significand, and no element overflows
+        for n, q in enumerate(q16):
+            full = (qkvs[n].reshape(B * L, 3 * C) + bs[n]).double()
+            xinv = imgs[n].inv.double()
+            def sc(bnd):                        # the power of two f16s_scales derives from a bound (csrc/common.hpp)
+                return torch.exp2(14 - torch.floor(torch.log2(bnd)))
+            row = sc(2.0 * (32768.0 * xinv * bound[2 * n].double() + bound[2 * n + 1].double()))
+            per_b = sc(2.0 * (32768.0 * xinv.reshape(B, L).amax(1) * bound[2 * n].double() + bound[2 * n + 1].double())).repeat_interleave(L)
+            dec = torch.cat([q[:, :C].double() / row[:, None], q[:, C:].double() / per_b[:, None]], 1)
+            assert torch.isfinite(q).all() and q.float().abs().max().item() < 2.0 ** 15
+            big = full.abs() > full.abs().amax(-1, keepdim=True) * 2.0 ** -12
+            assert ((dec - full).abs()[big] <= full.abs()[big] * 2.0 ** -10).all()
+        args = (q16[0].view(B, L, 3 * C), None if self_attn else q16[1].view(B, L, 3 * C), heads)
+        kw = dict(f16s=kw["f16s"])
     out = native.xattn_fusion_fwd(*args, **kw)
     img = native.xattn_fusion_fwd(*args, split3="f16s", **kw)
 
@@ -322,12 +343,14 @@ def test_attention_single_product_vs_tf32(hd, heads, L, self_attn):
     row = r64.abs().amax(-1, keepdim=True)
     e, etf = (out.double() - r64).abs() / row, (rtf - r64).abs() / row
     assert torch.isfinite(out).all()
+    print(f"attention hd {hd} heads {heads} L {L} self {self_attn} fp16_qkv {fp16_qkv}: max / rms error over the row maximum {e.max().item():.2e} / "
+          f"{e.pow(2).mean().sqrt().item():.2e}, emulated TF32 {etf.max().item():.2e} / {etf.pow(2).mean().sqrt().item():.2e}")
     assert e.max().item() <= 1.5 * etf.max().item() + 1e-6, (e.max().item(), etf.max().item())
     assert e.pow(2).mean().sqrt().item() <= 1.25 * etf.pow(2).mean().sqrt().item() + 1e-7, (e.pow(2).mean().sqrt().item(), etf.pow(2).mean().sqrt().item())
     assert isinstance(img, native.F16Image) and torch.isfinite(img.data).all() and img.data.float().abs().max().item() < 2.0 ** 15
     assert ((img.float().double() - out.double()).abs() / row).max().item() <= 2.0 ** -10
     # the split-bf16 kernel on the same inputs agrees to the TF32 class
-    three = native.xattn_fusion_fwd(args[0], args[1], heads, bias1=bs[0], bias2=None if self_attn else bs[1], split_bf16=True)
+    three = native.xattn_fusion_fwd(qkvs[0], None if self_attn else qkvs[1], heads, bias1=bs[0], bias2=None if self_attn else bs[1], split_bf16=True)
     assert ((out - three).abs() / row.float()).max().item() <= 3 * etf.max().item() + 1e-6
 
 
