@@ -59,12 +59,14 @@ def usable_cores():
     return n
 
 
-def scan_bytes(B, D, L, N, G=1, s=4, has_out=True, has_x=True):
+def scan_bytes(B, D, L, N, G=1, s=4, has_out=True, has_x=True, dt_rank=0):
     """5 B D L s + 2 B G N L s + B D ceil(L/2048) 2N 4 + (D N + 2 D) 4 for the full interface (reads u, delta, z,
     B, C, A, D, delta_bias; writes out, out_z, x). A launch that skips the `out` / `x` stores (inference: out_ptr / x_ptr NULL)
-    is priced with what it moves: one B D L s term / the chunk-state term less -- 8(d)'s "inference-only lower bound" 1.082 GB."""
-    return ((5 if has_out else 4) * B * D * L * s + 2 * B * G * N * L * s + (B * D * ((L + 2047) // 2048) * 2 * N * 4 if has_x else 0)
-            + (D * N + 2 * D) * 4)
+    is priced with what it moves: one B D L s term / the chunk-state term less -- 8(d)'s "inference-only lower bound" 1.082 GB; a launch
+    with the fused dt_proj (dt_rank > 0: delta = W_dt x_dbl[:R] formed inside the kernel) reads x_dbl[:R] and W_dt instead of delta."""
+    terms = (5 if has_out else 4) - (1 if dt_rank else 0)      # fused dt_proj: `delta` is not read; the launch reads x_dbl[:R] and W_dt instead
+    return (terms * B * D * L * s + 2 * B * G * N * L * s + (B * D * ((L + 2047) // 2048) * 2 * N * 4 if has_x else 0)
+            + (D * N + 2 * D) * 4 + (B * L * dt_rank + D * dt_rank) * 4)
 
 
 def scan_bwd_bytes(B, D, L, N, G=1, s=4, recompute_out_z=True):
@@ -111,7 +113,8 @@ class ScanTimer:
                 p = P.fwd if which == "bwd" else P
                 if which == "fwd":
                     kernel = (_lib.SCAN_FWD_KERNELS[lib.dimsum_ssm_scan_fwd_variant(p)] + (" (+ saved states)" if p.ckpt_ptr else "")
-                              + ("" if (p.out_ptr and p.x_ptr) else " (inference: no out / x stores)"))
+                              + ("" if (p.out_ptr and p.x_ptr) else " (inference: no out / x stores)")
+                              + (" (+ fused dt_proj: delta formed in the kernel, not read)" if p.dt_w_ptr else ""))
                 else:
                     kernel = "ssm_scan_bwd_kernel (+ ssm_scan_bwd_reduce_kernel)" + ("" if p.out_z_ptr else ", no out_z recompute")
                 # HIP events recorded at the begin of the call's first kernel and the end of its last one (the per-call
@@ -131,7 +134,7 @@ class ScanTimer:
                 s = {_lib.F32: 4}.get(p.dtype, 2)
                 shape = (p.batch, p.dim, p.seqlen, p.dstate)
                 nbytes = (scan_bwd_bytes(*shape, p.n_groups, s, recompute_out_z=bool(p.out_z_ptr)) if which == "bwd"
-                          else scan_bytes(*shape, p.n_groups, s, has_out=bool(p.out_ptr), has_x=bool(p.x_ptr)))
+                          else scan_bytes(*shape, p.n_groups, s, has_out=bool(p.out_ptr), has_x=bool(p.x_ptr), dt_rank=p.dt_rank if p.dt_w_ptr else 0))
                 timer.records[which].append((e0, e1, nbytes, shape, kernel))
                 return rc
 
@@ -364,7 +367,9 @@ class Bench:
         if rf is not None:
             out["roofline"] = rf
             if "no out / x stores" in rf["kernel"]:
-                rf["pricing"] = "SURVEY 8(d) inference-only lower bound: the launch skips the `out` / `x` stores nothing reads, and is priced without them"
+                rf["pricing"] = ("SURVEY 8(d) inference-only lower bound: the launch skips the `out` / `x` stores nothing reads, and is priced without them"
+                                 + ("; dt_proj runs inside it on the matrix cores (delta = W_dt x_dbl[:R] per tile): no B D L delta read either -- priced with "
+                                    "the x_dbl[:R] / W_dt bytes it reads instead" if "fused dt_proj" in rf["kernel"] else ""))
                 full = self.scan_roofline_pass(step, full_interface=True)
                 if full is not None:
                     full["pricing"] = "SURVEY 8(d) full interface (reads u, delta, z, B, C, A, D, delta_bias; writes out, out_z, x)"

@@ -18,7 +18,8 @@ class SsmParams(C.Structure):
                                       "out_z_batch_stride", "out_z_d_stride")]
                 + [(n, vp) for n in ("A_ptr", "B_ptr", "C_ptr", "D_ptr", "u_ptr", "delta_ptr", "delta_bias_ptr",
                                      "z_ptr", "out_ptr", "x_ptr", "out_z_ptr", "ckpt_ptr")]
-                + [("kernel_variant", i32), ("timing_start_event", vp), ("timing_stop_event", vp), ("out_z_lo_offset", i64)])
+                + [("kernel_variant", i32), ("timing_start_event", vp), ("timing_stop_event", vp), ("out_z_lo_offset", i64)]
+                + [("dt_w_ptr", vp), ("dt_x_ptr", vp), ("dt_w_row_stride", i64), ("dt_x_row_stride", i64), ("dt_rank", i32), ("reserved3", i32)])
 
 
 class SsmBwdParams(C.Structure):
@@ -169,7 +170,7 @@ def load():
     if hasattr(lib, "dimsum_ssm_scan_fwd_variant"):
         lib.dimsum_ssm_scan_fwd_variant.restype = C.c_int
         lib.dimsum_ssm_scan_fwd_variant.argtypes = [C.POINTER(SsmParams)]
-    if lib.dimsum_abi_version() != 13:
+    if lib.dimsum_abi_version() != 14:
         raise RuntimeError("dimsum_amd: libdimsum_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -12,7 +12,16 @@ template <typename T, int kN, int kSP> void ssm_scan_fwd_launch_split(const dims
 template <typename T> void ssm_scan_fwd_launch_lanes(const dimsum_ssm_params_t &p, hipStream_t stream, int tiles, bool vec, bool full);
 
 int ssm_check(const dimsum_ssm_params_t *p, bool forward) {
-    if (!p || !p->A_ptr || !p->B_ptr || !p->C_ptr || !p->u_ptr || !p->delta_ptr) return DIMSUM_ERR_NULL;
+    if (!p || !p->A_ptr || !p->B_ptr || !p->C_ptr || !p->u_ptr || (!p->delta_ptr && !(forward && p->dt_w_ptr))) return DIMSUM_ERR_NULL;
+    if (p->dt_w_ptr) {          // fused dt_proj (forward only)
+        if (!forward) return DIMSUM_ERR_UNSUPPORTED;
+        if (!p->dt_x_ptr) return DIMSUM_ERR_NULL;
+        if (p->dt_rank <= 0 || p->dt_rank > 32 || p->dt_rank % 4 != 0) return DIMSUM_ERR_SHAPE;
+        if (p->dt_w_row_stride % 4 != 0 || p->dt_w_row_stride < p->dt_rank || p->dt_x_row_stride < (int64_t)p->batch * p->seqlen ||
+            reinterpret_cast<uintptr_t>(p->dt_w_ptr) % 16 != 0 || reinterpret_cast<uintptr_t>(p->dt_x_ptr) % 4 != 0 ||
+            (int64_t)8 * p->dt_x_row_stride * 4 >= ((int64_t)1 << 31))           // (32-bit byte offsets of the 8 r rows a lane reads)
+            return DIMSUM_ERR_STRIDE;
+    }
     if (forward && p->z_ptr && !p->out_z_ptr) return DIMSUM_ERR_NULL;   // in the backward out_z is the optional recompute
     if (p->batch <= 0 || p->dim <= 0 || p->seqlen <= 0 || p->n_groups <= 0 || p->dim % p->n_groups != 0) return DIMSUM_ERR_SHAPE;
     if (p->dstate > 256) return DIMSUM_ERR_SHAPE;  // selective_scan.cpp:262
@@ -75,6 +84,8 @@ static int launch_fwd(const dimsum_ssm_params_t &p, hipStream_t stream) {
         !offsets_fit_32bit<T>(p.seqlen, p.dstate, {p.B_dstate_stride, p.C_dstate_stride}))
         return DIMSUM_ERR_STRIDE;
     const bool full = vec && (dpg % cpw == 0);
+    if (p.dt_w_ptr && !(sp == 1 && full && p.z_ptr && !p.ckpt_ptr && std::is_same<T, float>::value && kN == 16 && p.seqlen % 4 == 0))
+        return DIMSUM_ERR_UNSUPPORTED;        // the fused dt_proj rides on the 64-channel kernel's full fp32 inference path only
     if (sp == 16) {
         if constexpr (kN == 16) ssm_scan_fwd_launch_lanes<T>(p, stream, tiles, vec, full);
     } else if (sp == 4) {

@@ -31,6 +31,8 @@
 //
 // Algorithmic HBM bytes: 5*B*D*L*s + 2*B*G*N*L*s + B*D*ceil(L/2048)*2N*4 (+ A, D, bias).
 #pragma once
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace dimsum {
@@ -120,9 +122,21 @@ template <typename T> __device__ __forceinline__ void st4_out_z(T *base, unsigne
 
 // kVec : every row base is 4-element aligned and L % 4 == 0 -> 16-byte (fp32) vector I/O, register-staged prefetch.
 // kFull: dim/n_groups % 64 == 0 -> all 64 lanes own a live channel, no row masks anywhere (needs kVec).
-template <typename T, int kN, bool kHasZ, bool kVec, bool kFull, bool kCkpt = false>
+// kDt  : fused dt_proj (include/dimsum_hip.h, dt_w_ptr): the tile's delta = x_dbl[:, :R] W_dt^T is formed on the matrix cores instead of being
+//        read from HBM. Transposed product D[step][channel] (A = 16 steps x 32 r of x_dbl, B = 32 r x 16 channels of W_dt^T): a lane ends up with
+//        4 consecutive STEPS of one channel = one 16-byte slot of the delta tile's row. Both operands as bf16 hi / lo pairs, three
+//        v_mfma_f32_16x16x32_bf16 per output tile (hi.hi + hi.lo + lo.hi: fp32-class, what the library's GEMM spends on it under
+//        allow_tf32); 2 x 4 output tiles = 24 MFMAs per 32-step tile against ~7k cycles of VALU work, issued while the tile is staged (the
+//        matrix pipe is otherwise idle and the SIMD's other wave keeps the VALU busy). The x_dbl rows of the next tile are requested a
+//        tile ahead (16 VGPRs instead of the 32 of the delta pieces).
+typedef __bf16 scan_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float scan_f4 __attribute__((ext_vector_type(4)));
+struct alignas(16) ScanU4 { unsigned w[4]; };
+
+template <typename T, int kN, bool kHasZ, bool kVec, bool kFull, bool kCkpt = false, bool kDt = false>
 __global__ __launch_bounds__(kWave, kScanWaves) void ssm_scan_fwd_kernel(const dimsum_ssm_params_t p) {
     static_assert(!kFull || kVec, "kFull implies kVec");
+    static_assert(!kDt || (kFull && kHasZ && !kCkpt && std::is_same<T, float>::value), "the fused dt_proj rides on the full fp32 inference path");
     __shared__ __attribute__((aligned(16))) float tileU[kWave * kLdsStride];
     __shared__ __attribute__((aligned(16))) float tileD[kWave * kLdsStride];
     __shared__ __attribute__((aligned(16))) float tileB[kN * kTC];   // [n][t] of the current 32 steps (wave-uniform data,
@@ -146,7 +160,7 @@ __global__ __launch_bounds__(kWave, kScanWaves) void ssm_scan_fwd_kernel(const d
 
     // Wave-uniform tile bases. In-tile offsets are 32-bit (the host checks 64 * d_stride + L < 2^31).
     const T *u_base = reinterpret_cast<const T *>(p.u_ptr) + (int64_t)b * p.u_batch_stride + (int64_t)d0 * p.u_d_stride;
-    const T *dl_base = reinterpret_cast<const T *>(p.delta_ptr) + (int64_t)b * p.delta_batch_stride + (int64_t)d0 * p.delta_d_stride;
+    const T *dl_base = kDt ? nullptr : reinterpret_cast<const T *>(p.delta_ptr) + (int64_t)b * p.delta_batch_stride + (int64_t)d0 * p.delta_d_stride;
     const T *z_base = kHasZ ? reinterpret_cast<const T *>(p.z_ptr) + (int64_t)b * p.z_batch_stride + (int64_t)d0 * p.z_d_stride : nullptr;
     T *out_base = p.out_ptr ? reinterpret_cast<T *>(p.out_ptr) + (int64_t)b * p.out_batch_stride + (int64_t)d0 * p.out_d_stride : nullptr;
     T *oz_base = kHasZ ? reinterpret_cast<T *>(p.out_z_ptr) + (int64_t)b * p.out_z_batch_stride + (int64_t)d0 * p.out_z_d_stride : nullptr;
@@ -189,13 +203,70 @@ __global__ __launch_bounds__(kWave, kScanWaves) void ssm_scan_fwd_kernel(const d
         if constexpr (kFull) return at(base + i * kRPP * ds, (unsigned)(lrow * ds + col));
         else return at(base, (unsigned)(min(i * kRPP + lrow, nd - 1) * ds + col));   // clamped row: never negative
     };
+    // ---- fused dt_proj state: W_dt fragments of this wave's 4 channel blocks (B operand: lane -> channel lane & 15, r = 8 (lane >> 4) .. + 7),
+    //      the next tile's x_dbl rows (A operand: lane -> step lane & 15, the same 8 r) and the delta accumulators [step block][channel block]
+    ScanU4 wh[kDt ? 4 : 1], wl[kDt ? 4 : 1];
+    float xr[2][8];            // [step block][r = 8 fkg + e] of step lane & 15
+    scan_f4 dacc[2][4];
+    const int fq = lane & 15, fkg = lane >> 4;
+    const float *dtx = nullptr;
+    int dtx_rs = 0;
+    bool r_lo = false, r_hi = false;
+    auto split8 = [](const float4 &a, const float4 &c, ScanU4 &hi, ScanU4 &lo) {
+        split2(a.x, a.y, hi.w[0], lo.w[0]);
+        split2(a.z, a.w, hi.w[1], lo.w[1]);
+        split2(c.x, c.y, hi.w[2], lo.w[2]);
+        split2(c.z, c.w, hi.w[3], lo.w[3]);
+    };
+    if constexpr (kDt) {
+        r_lo = 8 * fkg < p.dt_rank; r_hi = 8 * fkg + 4 < p.dt_rank;          // (dt_rank % 4 == 0: r beyond it are zeros on both sides)
+        dtx = reinterpret_cast<const float *>(p.dt_x_ptr) + (int64_t)(8 * fkg) * p.dt_x_row_stride + (int64_t)b * L;    // row r = 8 fkg of this batch element
+        dtx_rs = (int)p.dt_x_row_stride;
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const float *w = reinterpret_cast<const float *>(p.dt_w_ptr) + (int64_t)(d0 + 16 * nb + fq) * p.dt_w_row_stride + 8 * fkg;
+            split8(r_lo ? *reinterpret_cast<const float4 *>(w) : zero, r_hi ? *reinterpret_cast<const float4 *>(w + 4) : zero, wh[nb], wl[nb]);
+        }
+    }
+    auto issue_x = [&](int t0) {                   // x_dbl^T (r-major, as the inference x_proj writes it) of the tile at t0: 16 consecutive steps per
+#pragma unroll                                     // 16 lanes and r row (steps beyond L: the last one; they are never taken)
+        for (int mt = 0; mt < 2; ++mt) {
+            const float *x = dtx + min(t0 + 16 * mt + fq, L - 1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xr[mt][e] = (e < 4 ? r_lo : r_hi) ? x[(unsigned)(e * dtx_rs)] : 0.f;
+        }
+    };
+    auto mma_delta = [&]() {                       // dacc = the delta tile of the rows in xr
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            ScanU4 ah, al;
+            split8(make_float4(xr[mt][0], xr[mt][1], xr[mt][2], xr[mt][3]), make_float4(xr[mt][4], xr[mt][5], xr[mt][6], xr[mt][7]), ah, al);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                scan_f4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(scan_bf16x8, al), __builtin_bit_cast(scan_bf16x8, wh[nb]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(scan_bf16x8, ah), __builtin_bit_cast(scan_bf16x8, wl[nb]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(scan_bf16x8, ah), __builtin_bit_cast(scan_bf16x8, wh[nb]), acc, 0, 0, 0);
+                dacc[mt][nb] = acc;
+            }
+        }
+    };
+    auto store_delta = [&]() {                     // lane: channel 16 nb + fq, steps 16 mt + 4 fkg .. + 3 = 16-byte slot 4 mt + fkg of its row
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+                *reinterpret_cast<scan_f4 *>(&tileD[tile_off(16 * nb + fq, 4 * mt + fkg)]) = dacc[mt][nb];
+    };
     auto issue_loads = [&](int t0) {
         const int col = col_of(t0);
 #pragma unroll
         for (int i = 0; i < kNP; ++i) {
             ru[i] = ld4<T>(piece(u_base, u_ds, i, col));
-            rd[i] = ld4<T>(piece(dl_base, dl_ds, i, col));
+            if constexpr (!kDt) rd[i] = ld4<T>(piece(dl_base, dl_ds, i, col));
         }
+        if constexpr (kDt) issue_x(t0);
 #pragma unroll
         for (int i = 0; i < kBCPieces; ++i) {
             const int n = min(i * kRPP + lrow, kN - 1);
@@ -215,7 +286,11 @@ __global__ __launch_bounds__(kWave, kScanWaves) void ssm_scan_fwd_kernel(const d
             for (int i = 0; i < kNP; ++i) {
                 const int row = i * kRPP + lrow;
                 *reinterpret_cast<f32x4 *>(&tileU[tile_off(row, lc4)]) = widen(ru[i]);
-                *reinterpret_cast<f32x4 *>(&tileD[tile_off(row, lc4)]) = widen(rd[i]);
+                if constexpr (!kDt) *reinterpret_cast<f32x4 *>(&tileD[tile_off(row, lc4)]) = widen(rd[i]);
+            }
+            if constexpr (kDt) {                   // this tile's delta from its x_dbl rows (requested a tile ahead), then the next tile's rows
+                mma_delta();
+                store_delta();
             }
 #pragma unroll
             for (int i = 0; i < kBCPieces; ++i) {
@@ -361,6 +436,12 @@ void ssm_scan_fwd_launch_v0(const dimsum_ssm_params_t &p, hipStream_t stream, in
         if (p.ckpt_ptr) DIMSUM_LAUNCH_EV((ssm_scan_fwd_kernel<T, kN, HASZ, VEC, FULL, true>), grid, block, stream, ev0, ev1, p); \
         else DIMSUM_LAUNCH_EV((ssm_scan_fwd_kernel<T, kN, HASZ, VEC, FULL, false>), grid, block, stream, ev0, ev1, p);          \
     } while (0)
+    if constexpr (std::is_same<T, float>::value && kN == 16) {
+        if (p.dt_w_ptr) {       // fused dt_proj (the caller checked: full vector path, z, no saved states)
+            DIMSUM_LAUNCH_EV((ssm_scan_fwd_kernel<T, kN, true, true, true, false, true>), grid, block, stream, ev0, ev1, p);
+            return;
+        }
+    }
     if (p.z_ptr) {
         if (full) DIMSUM_LAUNCH(true, true, true);
         else if (vec) DIMSUM_LAUNCH(true, true, false);

@@ -121,12 +121,33 @@ def scan_ckpt_shape(batch, dim, seqlen, dstate):
     return (batch, (seqlen + 7) // 8, dstate, dim)
 
 
-def selective_scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus, need_out=True, need_x=True, need_ckpt=False, out_z_planes=False):
+def scan_dt_proj_supported(u, z, A, dt_w, dt_xt, n_groups=1):
+    """whether selective_scan_fwd(dt_proj=(dt_w, dt_xt)) is served (csrc/ssm_scan_fwd_kernel.hpp, kDt): the 64-channels-per-wave kernel on
+    its full fp32 vector path -- float32, dstate 16, dim / n_groups % 64 == 0, seqlen % 4 == 0, 16-byte aligned rows, dt_rank % 4 == 0 and
+    <= 32, dt_xt (dt_rank, batch seqlen) r-major -- and only where that kernel is the one a launch of this shape gets"""
+    batch, dim, seqlen = u.shape
+    R = dt_w.shape[1]
+    return (u.is_cuda and u.dtype == torch.float32 and z is not None and A.shape[1] == 16 and (dim // n_groups) % 64 == 0 and seqlen % 4 == 0
+            and dt_w.dtype == torch.float32 and dt_xt.dtype == torch.float32 and dt_w.dim() == 2 and dt_w.shape[0] == dim and R % 4 == 0 and 0 < R <= 32
+            and dt_w.stride(1) == 1 and dt_w.stride(0) % 4 == 0 and dt_w.data_ptr() % 16 == 0
+            and dt_xt.dim() == 2 and dt_xt.shape == (R, batch * seqlen) and dt_xt.stride(1) == 1 and 32 * dt_xt.stride(0) < 2 ** 31
+            and u.stride(2) == 1 and z.stride(2) == 1 and all(st % 4 == 0 for st in (*u.stride()[:2], *z.stride()[:2])) and u.data_ptr() % 16 == 0
+            and z.data_ptr() % 16 == 0 and scan_fwd_kernel_for(batch, dim, seqlen, A.shape[1], n_groups) == 1)
+
+
+def selective_scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus, need_out=True, need_x=True, need_ckpt=False, out_z_planes=False, dt_proj=None):
     """-> [out, x, (out_z)]   exactly like selective_scan_cuda.fwd.
     `need_out=False` / `need_x=False` are inference extras: the corresponding store is skipped and None returned.
     `need_ckpt=True` (training extra) appends the tile-boundary states the backward kernel consumes.
     `out_z_planes=True` (inference extra, float32): out_z comes back as its split-bf16 pair of d-major planes, a (2 dim, batch seqlen)
     bfloat16 matrix [hi; lo] -- the operand image of out_proj's GEMM (gemm_tn(..., alias_rows=dim)), the same 4 bytes per element."""
+    if dt_proj is not None:
+        # fused dt_proj (inference extra): delta = dt_w @ dt_xt is formed inside the scan (scan_dt_proj_supported); `delta` only lends its layout
+        dt_w, dt_xt = dt_proj
+        _gpu(dt_w, dt_xt)
+        _check(delta is None and not need_ckpt and not need_out and scan_dt_proj_supported(u, z, A, dt_w, dt_xt, B.shape[1]),
+               "selective_scan_fwd: dt_proj = (dt_w, dt_xt) needs delta = None, no saved states, no `out` and a shape scan_dt_proj_supported takes")
+        delta = u                  # (argument checks and the out_z layout below; the kernel never reads it)
     _check_ssm(u, delta, A, B, C, D, z, delta_bias)
     batch, dim, seqlen = u.shape
     dstate = A.shape[1]
@@ -146,6 +167,9 @@ def selective_scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus, need
         _fill_ssm(P, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, x, out_z, ckpt)
         if planes is not None:
             P.out_z_lo_offset = dim * batch * seqlen
+        if dt_proj is not None:
+            P.delta_ptr = None
+            P.dt_w_ptr, P.dt_x_ptr, P.dt_w_row_stride, P.dt_x_row_stride, P.dt_rank = _ptr(dt_w), _ptr(dt_xt), dt_w.stride(0), dt_xt.stride(0), dt_w.shape[1]
         with torch.cuda.device(u.device):
             _lib.check(_lib.load().dimsum_ssm_scan_fwd(P, _stream(u)), "selective_scan_fwd")
     res = [out, x]

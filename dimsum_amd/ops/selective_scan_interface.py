@@ -117,6 +117,7 @@ class _MambaInner(torch.autograd.Function):
         else:
             conv_out = native.causal_conv1d_fwd(x, conv_w, conv_b, True)
         bsz, d_inner = conv_out.shape[0], conv_out.shape[1]
+        keep_stores = need_ckpt or os.environ.get("DIMSUM_SCAN_INFER_STORES", "0") == "1"      # (see `keep` below)
         # layouts chosen like the reference (:622-626): the GEMM writes delta d-major so that it needs no transpose
         conv_rows = _rows(conv_out)
         if not need_ckpt and B_proj_bias is None and C_proj_bias is None and conv_rows.stride(1) == 1:
@@ -124,7 +125,12 @@ class _MambaInner(torch.autograd.Function):
             # them -- (b, 1, N, l) views with strides (l, ., b l, 1) -- without the two transposing copies per mixer
             x_dbl_t = x_proj_weight @ conv_rows                                                          # (R + 2N, b l)
             x_dbl = None
-            delta = (delta_proj_weight @ x_dbl_t[:R]).view(d_inner, bsz, L).permute(1, 0, 2)
+            # dt_proj inside the scan (csrc/ssm_scan_fwd_kernel.hpp, kDt): where the 64-channel kernel serves the launch, delta = W_dt x_dbl[:R] is
+            # formed tile by tile on the matrix cores and the (b, d, l) tensor never exists: one GEMM launch and 2 b d l 4 bytes less per mixer.
+            # The launch keeps no `out` / `x` stores then (DIMSUM_SCAN_INFER_STORES=1, the reference interface's launch, takes the GEMM).
+            dt_fused = (not keep_stores and not torch.is_autocast_enabled("cuda") and os.environ.get("DIMSUM_SCAN_DT_PROJ", "1") != "0"
+                        and native.scan_dt_proj_supported(conv_out, z, A, delta_proj_weight, x_dbl_t[:R]))
+            delta = None if dt_fused else (delta_proj_weight @ x_dbl_t[:R]).view(d_inner, bsz, L).permute(1, 0, 2)
             Bm = x_dbl_t[R:R + N].view(N, bsz, L).permute(1, 0, 2).unsqueeze(1)
             Cm = x_dbl_t[R + N:].view(N, bsz, L).permute(1, 0, 2).unsqueeze(1)
         else:
@@ -147,14 +153,15 @@ class _MambaInner(torch.autograd.Function):
         # kernel skips both stores: 1.082 instead of 1.384 GB per launch at DiM-L/2, batch 256 (SURVEY 8(d)'s "inference-only lower bound"),
         # same arithmetic, bit-identical out_z. DIMSUM_SCAN_INFER_STORES=1 restores the reference interface's stores (bench.py prices
         # that launch too, as `roofline_full_interface`).
-        keep = need or os.environ.get("DIMSUM_SCAN_INFER_STORES", "0") == "1"
+        keep = need or keep_stores
         # inference under allow_tf32: out_z leaves the scan as its split-bf16 pair of planes (the same 4 bytes per element) and out_proj runs
         # on the hand-written kernel's transposing-read variant straight from them (0.26 -> 0.17 ms per mixer at 65536 tokens)
         planes = (has_out_proj and not need and out_proj_bias is None and L % 8 == 0
                   and d_inner % 64 == 0 and xz.is_cuda
                   and gemm.out_proj_planes_enabled(xz, out_proj_weight, bsz * L, native.scan_fwd_kernel_for(bsz, d_inner, L, N, Bm.shape[1])))
         out, scan_x, out_z, *rest = native.selective_scan_fwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus,
-                                                              need_out=keep, need_x=keep, need_ckpt=need, **({"out_z_planes": True} if planes else {}))
+                                                              need_out=keep, need_x=keep, need_ckpt=need, **({"out_z_planes": True} if planes else {}),
+                                                              **({"dt_proj": (delta_proj_weight, x_dbl_t[:R])} if delta is None else {}))
         if planes:
             return gemm.out_proj_planes(out_z, out_proj_weight).view(bsz, L, out_proj_weight.shape[0])
         ckpt = rest[0] if need else None

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DIMSUM_ABI_VERSION 13
+#define DIMSUM_ABI_VERSION 14
 
 typedef enum {
     DIMSUM_OK = 0,
@@ -103,6 +103,18 @@ typedef struct {
                                  plane lies out_z_lo_offset elements behind it; hi = bf16(x), lo = bf16(x - hi): the same 4 bytes per
                                  element (seqlen % 8 == 0), already the operand image of out_proj's GEMM (dimsum_gemm_tn with a_alias_rows), which then
                                  needs no conversion pass (mamba_simple.py:352-354 out_proj under allow_tf32). */
+    /* Fused dt_proj (forward, inference, float32 I/O; no reference counterpart as a kernel: selective_scan_interface.py:840-841 computes
+     * delta = dt_proj.weight @ x_dbl[:, :R]^T as a TF32 GEMM of its own and hands the (batch, dim, seqlen) result to the scan). With
+     * dt_w_ptr != NULL the scan forms delta[b, d, t] = sum_r dt_w[d, r] * dt_x[r, b * seqlen + t] itself, tile by tile on the matrix
+     * cores (three bf16 products per fp32 product: the arithmetic of the library GEMM it replaces), delta_ptr is NOT read (it may be
+     * NULL) and the (batch, dim, seqlen) delta tensor never exists: one launch and 2 B D L 4 bytes of traffic less per mixer.
+     * Served by the 64-channels-per-wave kernel on its full vector path (dim / n_groups % 64 == 0, z given, no ckpt_ptr); any other
+     * call with dt_w_ptr set is DIMSUM_ERR_UNSUPPORTED (dimsum_ssm_scan_fwd_variant() == 1 tells the host beforehand). */
+    const void *dt_w_ptr;     /* (dim, dt_rank) f32, 16-byte aligned rows, dt_rank % 4 == 0, dt_rank <= 32 */
+    const void *dt_x_ptr;     /* (dt_rank, batch * seqlen) f32: the first dt_rank rows of x_proj's output written r-major (x_proj.weight @ conv_out
+                                 as a (R + 2N, batch seqlen) matrix, the layout whose B / C rows the scan reads without a transposing copy) */
+    int64_t dt_w_row_stride, dt_x_row_stride;     /* in elements; dt_w_row_stride % 4 == 0 */
+    int32_t dt_rank, reserved3;
 } dimsum_ssm_params_t;
 
 typedef struct {

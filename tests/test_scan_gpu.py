@@ -395,3 +395,42 @@ def test_timing_events_bracket_the_whole_backward_call(monkeypatch):
         assert len(timer.records["bwd"]) == 5 and not timer.records["fwd"]     # the internal sweep is not a second record
         ms[name] = timer.roofline("bwd")["avg_launch_ms"]
     assert ms["saved"] > 0 and ms["rebuilt"] > 1.15 * ms["saved"], ms
+
+
+@pytest.mark.parametrize("B,D,L,R", [(2, 128, 256, 32), (3, 192, 100, 8), (1, 64, 36, 12), (2, 256, 1024, 32)])
+def test_fused_dt_proj_matches_the_scan_fed_with_the_gemm_result(B, D, L, R):
+    """dimsum_ssm_params_t.dt_w_ptr (inference extra, csrc/ssm_scan_fwd_kernel.hpp kDt): delta = W_dt x_dbl[:R] formed per tile on the matrix
+    cores inside the 64-channel kernel (3 bf16 products per fp32 product, fp32-class like the library GEMM it replaces,
+    selective_scan_interface.py:840-841) against the same kernel fed with the float64 product rounded to fp32, and against the C oracle;
+    dt_rank below 32 (zero-padded K), ragged last tile, several tiles"""
+    from dimsum_amd import native
+    from oracle import c_ops
+    g = torch.Generator().manual_seed(B * L + R)
+    N = 16
+    u, z = torch.randn(B, D, L, generator=g), torch.randn(B, D, L, generator=g)
+    A = -0.5 * torch.rand(D, N, generator=g) - 0.05
+    Bm, Cm = torch.randn(B, 1, N, L, generator=g), torch.randn(B, 1, N, L, generator=g)
+    Dv, bias = torch.randn(D, generator=g), 0.5 * torch.rand(D, generator=g)
+    w = torch.randn(D, R, generator=g) * R ** -0.5
+    xt = torch.randn(R + 5, B * L, generator=g)[:R]                       # a row block of a taller matrix, like x_dbl_t[:R]
+    delta = (w.double() @ xt.double()).float().view(D, B, L).permute(1, 0, 2).contiguous()
+    cu = lambda t: t.cuda()
+    old = native._scan_fwd_variant
+    native._scan_fwd_variant = 1                                           # the 64-channel kernel, whatever the launch size
+    try:
+        assert native.scan_dt_proj_supported(cu(u), cu(z), cu(A), cu(w), cu(xt))
+        _, _, ref = native.selective_scan_fwd(cu(u), cu(delta), cu(A), cu(Bm), cu(Cm), cu(Dv), cu(z), cu(bias), True, need_out=False, need_x=False)
+        _, _, got = native.selective_scan_fwd(cu(u), None, cu(A), cu(Bm), cu(Cm), cu(Dv), cu(z), cu(bias), True, need_out=False, need_x=False,
+                                              dt_proj=(cu(w), cu(xt)))
+        _, _, again = native.selective_scan_fwd(cu(u), None, cu(A), cu(Bm), cu(Cm), cu(Dv), cu(z), cu(bias), True, need_out=False, need_x=False,
+                                                dt_proj=(cu(w), cu(xt)))
+    finally:
+        native._scan_fwd_variant = old
+    assert torch.equal(got, again)
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 2e-5 * scale, (got - ref).abs().max().item() / scale
+    _, oz, _ = c_ops.selective_scan_fwd(u.numpy(), delta.numpy(), A.numpy(), Bm.numpy(), Cm.numpy(), Dv.numpy(), z.numpy(), bias.numpy(), True)
+    assert np.abs(got.cpu().numpy() - oz).max() <= 1e-4 * np.abs(oz).max()
+    # what the kernel does not take is refused up front, not computed wrongly
+    assert not native.scan_dt_proj_supported(cu(u), cu(z), cu(A), cu(torch.randn(D, 36)), cu(torch.randn(36, B * L)))          # dt_rank > 32
+    assert not native.scan_dt_proj_supported(cu(u)[:, :D - 32], cu(z)[:, :D - 32], cu(A)[:D - 32], cu(w)[:D - 32], cu(xt)) or (D - 32) % 64 == 0
