@@ -133,9 +133,13 @@ class ScanTimer:
                     p.timing_start_event = p.timing_stop_event = None
                 s = {_lib.F32: 4}.get(p.dtype, 2)
                 shape = (p.batch, p.dim, p.seqlen, p.dstate)
+                # algorithmic bytes = SURVEY 8(d)'s formula for the scan this launch performs (full interface, or its inference-only lower bound
+                # when the `out` / `x` stores are skipped); `moved`: what the launch itself reads and writes -- less than that when dt_proj runs
+                # inside it (delta is formed on the matrix cores instead of being read)
                 nbytes = (scan_bwd_bytes(*shape, p.n_groups, s, recompute_out_z=bool(p.out_z_ptr)) if which == "bwd"
-                          else scan_bytes(*shape, p.n_groups, s, has_out=bool(p.out_ptr), has_x=bool(p.x_ptr), dt_rank=p.dt_rank if p.dt_w_ptr else 0))
-                timer.records[which].append((e0, e1, nbytes, shape, kernel))
+                          else scan_bytes(*shape, p.n_groups, s, has_out=bool(p.out_ptr), has_x=bool(p.x_ptr)))
+                moved = nbytes if (which == "bwd" or not p.dt_w_ptr) else scan_bytes(*shape, p.n_groups, s, has_out=bool(p.out_ptr), has_x=bool(p.x_ptr), dt_rank=p.dt_rank)
+                timer.records[which].append((e0, e1, nbytes, shape, kernel, moved))
                 return rc
 
             def dimsum_ssm_scan_fwd(self, P, stream):
@@ -159,7 +163,7 @@ class ScanTimer:
         from dimsum_amd import _lib
         lib = _lib.load()
         ms = lambda a, b: a.elapsed_time(b) if isinstance(a, torch.cuda.Event) else float(lib.dimsum_event_elapsed_ms(a, b))
-        avg_ms = sum(ms(a, b) for a, b, *_ in rs) / len(rs)
+        avg_ms = sum(ms(r[0], r[1]) for r in rs) / len(rs)
         nbytes = rs[0][2]
         achieved = nbytes / (avg_ms * 1e-3) / 1e9
         traffic = None
@@ -171,6 +175,10 @@ class ScanTimer:
         rf = {"kernel": kernel, "shape_BDLN": list(shape), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
               "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": avg_ms,
               "launches_timed": len(rs)}
+        moved = rs[0][5]
+        if moved != nbytes:
+            rf["bytes_moved_by_this_launch"] = moved
+            rf["frac_of_bytes_moved"] = moved / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
         if _BOX:
             rf["frac_of_box_copy"] = achieved / _BOX["copy_GBps"]
         return rf
@@ -368,8 +376,9 @@ class Bench:
             out["roofline"] = rf
             if "no out / x stores" in rf["kernel"]:
                 rf["pricing"] = ("SURVEY 8(d) inference-only lower bound: the launch skips the `out` / `x` stores nothing reads, and is priced without them"
-                                 + ("; dt_proj runs inside it on the matrix cores (delta = W_dt x_dbl[:R] per tile): no B D L delta read either -- priced with "
-                                    "the x_dbl[:R] / W_dt bytes it reads instead" if "fused dt_proj" in rf["kernel"] else ""))
+                                 + ("; dt_proj ALSO runs inside this launch on the matrix cores (delta = W_dt x_dbl[:R] per tile: one GEMM launch less per "
+                                    "mixer), so the launch does not even read delta: `achieved` / `frac` keep 8(d)'s algorithmic bytes of the scan it "
+                                    "performs, `bytes_moved_by_this_launch` / `frac_of_bytes_moved` price only what crosses HBM" if "fused dt_proj" in rf["kernel"] else ""))
                 full = self.scan_roofline_pass(step, full_interface=True)
                 if full is not None:
                     full["pricing"] = "SURVEY 8(d) full interface (reads u, delta, z, B, C, A, D, delta_bias; writes out, out_z, x)"

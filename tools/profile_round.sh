@@ -22,25 +22,34 @@ for r in rows:
 P
   tail -1 $out/${name}.log | cut -c1-300
 }
+# (bench.py's default policy is the headline's: --matmul f16s; the three-product carrier of rounds 1-4 is --matmul tf32)
 stats fwd2s --mode fwd --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg --no-box-probe
 export DIMSUM_BRANCH_STREAMS=0
 stats fwd --mode fwd --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg --no-box-probe
+stats fwd_tf32 --mode fwd --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg --no-box-probe --matmul tf32
 stats block --mode block --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg --no-box-probe
 stats xl512 --mode xl512 --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg --no-box-probe
-stats fwd_f16s --mode fwd --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg --no-box-probe --matmul f16s
 unset DIMSUM_BRANCH_STREAMS
 stats all --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg --no-box-probe --nfe 10
-# PMC: forward (inference), forward + saved states, backward (as dimsum_amd.ops calls it: no out_z recompute; and with it), config-5 forward,
-# the long-sequence stress shape (one lane per state)
+# PMC: forward as the headline runs it (inference: no out / x stores, dt_proj fused), the same without the fusion, the full reference
+# interface, forward + saved states, backward (as dimsum_amd.ops calls it: no out_z recompute; and with it; at the training leg's batch 64
+# and the block leg's 256), config-5 forward (inference / full interface), the long-sequence stress shape (one lane per state)
+bash tools/pmc_scan.sh $out/pmc_fwd_dt --dmajor --dt-fused > $out/${tag}_scan_fwd_dtfused_pmc.txt 2>&1
+bash tools/pmc_scan.sh $out/pmc_fwd_inf --dmajor --infer > $out/${tag}_scan_fwd_infer_pmc.txt 2>&1
 bash tools/pmc_scan.sh $out/pmc_fwd --dmajor > $out/${tag}_scan_fwd_pmc.txt 2>&1
 bash tools/pmc_scan.sh $out/pmc_fwd_train --dmajor --train-fwd > $out/${tag}_scan_fwd_train_pmc.txt 2>&1
 bash tools/pmc_scan.sh $out/pmc_bwd --dmajor --bwd --no-out-z > $out/${tag}_scan_bwd_pmc.txt 2>&1
 bash tools/pmc_scan.sh $out/pmc_bwd_oz --dmajor --bwd > $out/${tag}_scan_bwd_outz_pmc.txt 2>&1
+bash tools/pmc_scan.sh $out/pmc_bwd_b64 --dmajor --bwd --no-out-z --B 64 > $out/${tag}_scan_bwd_b64_pmc.txt 2>&1
+bash tools/pmc_scan.sh $out/pmc_fwd_train_b64 --dmajor --train-fwd --B 64 > $out/${tag}_scan_fwd_train_b64_pmc.txt 2>&1
+bash tools/pmc_scan.sh $out/pmc_fwd_inf_b128 --dmajor --dt-fused --B 128 > $out/${tag}_scan_fwd_dtfused_b128_pmc.txt 2>&1
 bash tools/pmc_scan.sh $out/pmc_fwd_xl --dmajor --B 64 --D 1152 --L 1024 > $out/${tag}_scan_fwd_xl512_pmc.txt 2>&1
+bash tools/pmc_scan.sh $out/pmc_fwd_xl_inf --dmajor --infer --B 64 --D 1152 --L 1024 > $out/${tag}_scan_fwd_xl512_infer_pmc.txt 2>&1
 bash tools/pmc_scan.sh $out/pmc_fwd_stress --dmajor --B 16 --D 1152 --L 4096 > $out/${tag}_scan_fwd_stress_pmc.txt 2>&1
 timeout 600 bash tools/scratch/gemm_pmc.sh $tag > /dev/null 2>&1; cp gpurun_out/gemm/pmc_${tag}.txt $out/${tag}_gemm_gated_pmc.txt; rm -rf gpurun_out/gemm/pmc_${tag}
 timeout 300 python3 tools/bench_gemm.py --perf --rounds 5 2>/dev/null | grep -v amdgpu > $out/${tag}_gemm_perf.jsonl
+timeout 300 python3 tools/bench_gemm.py --tiles --rounds 5 2>/dev/null | grep -v amdgpu > $out/${tag}_gemm_tiles.jsonl
 bash tools/scratch/xattn_pmc.sh fwd > $out/${tag}_xattn_fwd_pmc.txt 2>&1
 bash tools/scratch/xattn_pmc.sh bwd > $out/${tag}_xattn_bwd_pmc.txt 2>&1
-rm -rf $out/pmc_fwd $out/pmc_fwd_train $out/pmc_bwd $out/pmc_bwd_oz $out/pmc_fwd_xl $out/pmc_fwd_stress     # raw csv trees: only the summaries travel back
+rm -rf $out/pmc_*     # raw csv trees: only the summaries travel back
 ls -la $out
