@@ -92,7 +92,7 @@ class GemmParams(C.Structure):
                 + [(n, vp) for n in ("a_ptr", "b_ptr", "bias_ptr", "c_ptr", "timing_start_event", "timing_stop_event")]
                 + [(n, i32) for n in ("tune_variant", "tune_group_m", "tune_reserved")]
                 + [(n, vp) for n in ("a_inv_scale_ptr", "b_inv_scale_ptr", "gate_bound_ptr", "h_inv_scale_ptr", "residual_ptr", "gate_ptr")]
-                + [("residual_ld", i64), ("gate_ld", i64), ("rows_per_batch", i32), ("c_image_pieces", i32), ("x12_ptr", vp), ("x12_ld", i64), ("a_alias_rows", i64), ("b_alias_rows", i64), ("a_alias_weight_order", i32), ("qkv_q_cols", i32),
+                + [("residual_ld", i64), ("gate_ld", i64), ("rows_per_batch", i32), ("c_image_pieces", i32), ("x12_ptr", vp), ("x12_ld", i64), ("a_alias_rows", i64), ("b_alias_rows", i64), ("a_alias_weight_order", i32), ("qkv_q_cols", i32), ("conv_weight_ptr", vp), ("conv_bias_ptr", vp), ("conv_rows", i32), ("conv_width", i32), ("conv_seq", i32), ("conv_weight_ld", i32),
                    ("tn_pair_a_cols", i64), ("tn_pair_b_cols", i64)])
 
 
@@ -101,7 +101,7 @@ class F16sJob(C.Structure):
                 + [(n, i64) for n in ("rows", "cols", "src_row_stride", "dst_row_stride")] + [("l1_factor", f32), ("reserved", i32)])
 
 
-GEMM_EPI_F32, GEMM_EPI_GATED_GELU_SPLIT3, GEMM_EPI_GATED_GELU_F16, GEMM_EPI_F32_BIAS, GEMM_EPI_F32_GATE_RESIDUAL, GEMM_EPI_F16_QKV = 0, 1, 2, 3, 4, 5
+GEMM_EPI_F32, GEMM_EPI_GATED_GELU_SPLIT3, GEMM_EPI_GATED_GELU_F16, GEMM_EPI_F32_BIAS, GEMM_EPI_F32_GATE_RESIDUAL, GEMM_EPI_F16_QKV, GEMM_EPI_F32_CONV = 0, 1, 2, 3, 4, 5, 6
 
 # every symbol include/dimsum_hip.h declares (tests check the library exports all of them)
 EXPORTS = (
@@ -170,7 +170,7 @@ def load():
     if hasattr(lib, "dimsum_ssm_scan_fwd_variant"):
         lib.dimsum_ssm_scan_fwd_variant.restype = C.c_int
         lib.dimsum_ssm_scan_fwd_variant.argtypes = [C.POINTER(SsmParams)]
-    if lib.dimsum_abi_version() != 14:
+    if lib.dimsum_abi_version() != 15:
         raise RuntimeError("dimsum_amd: libdimsum_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

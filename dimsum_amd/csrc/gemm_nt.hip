@@ -39,7 +39,7 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
     if (p->m <= 0 || p->n <= 0 || p->k < 2 * kBK || p->m % kBM != 0 || p->k % kBK != 0 || p->n % 4 != 0) return DIMSUM_ERR_SHAPE;
     // a_alias_rows = C: the A rows are [hi | lo] pairs (2 C columns) read as the left image [hi | hi | lo] over k = 3 C
     if (p->a_alias_rows != 0 && (p->a_alias_rows < 0 || p->a_alias_rows % kBK != 0 || p->k != 3 * p->a_alias_rows)) return DIMSUM_ERR_SHAPE;
-    if (p->b_alias_rows != 0 && (p->b_alias_rows < 0 || p->b_alias_rows % kBK != 0 || p->k != 3 * p->b_alias_rows || p->epilogue != DIMSUM_GEMM_EPI_F32)) return DIMSUM_ERR_SHAPE;
+    if (p->b_alias_rows != 0 && (p->b_alias_rows < 0 || p->b_alias_rows % kBK != 0 || p->k != 3 * p->b_alias_rows || (p->epilogue != DIMSUM_GEMM_EPI_F32 && p->epilogue != DIMSUM_GEMM_EPI_F32_CONV))) return DIMSUM_ERR_SHAPE;
     if (p->lda % 8 != 0 || p->ldb % 8 != 0 || p->lda < (p->a_alias_rows ? 2 * p->a_alias_rows : p->k) || p->ldb < (p->b_alias_rows ? 2 * p->b_alias_rows : p->k) ||
         !aligned_to<char>(p->a_ptr, 16) ||
         !aligned_to<char>(p->b_ptr, 16))
@@ -113,6 +113,21 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
         a.N = p->n;
         a.tiles_n = (p->n + kBN - 1) / kBN;
         return launch_f16<kEpiF16Qkv>(a, s, e0, e1, p->tune_variant == 512 || (p->tune_variant == 0 && p->k <= 576));
+    }
+    if (p->epilogue == DIMSUM_GEMM_EPI_F32_CONV) {
+        if (!p->conv_weight_ptr) return DIMSUM_ERR_NULL;
+        if (p->conv_rows <= 0 || p->conv_rows % kBM != 0 || p->conv_rows > p->m || p->conv_width < 2 || p->conv_width > 4 || p->conv_seq <= 0 || 256 % p->conv_seq != 0 ||
+            p->conv_seq % 4 != 0 || p->n % p->conv_seq != 0 || p->conv_weight_ld < p->conv_width)
+            return DIMSUM_ERR_SHAPE;
+        if (p->ldc % 4 != 0 || p->ldc < p->n || !aligned_to<char>(p->c_ptr, 16)) return DIMSUM_ERR_STRIDE;
+        a.B0 = a.B1 = reinterpret_cast<const char *>(p->b_ptr);
+        a.conv_w = reinterpret_cast<const float *>(p->conv_weight_ptr);
+        a.conv_b = reinterpret_cast<const float *>(p->conv_bias_ptr);
+        a.conv_rows = p->conv_rows; a.conv_width = p->conv_width; a.conv_seq = p->conv_seq; a.conv_w_ld = p->conv_weight_ld;
+        a.N = p->n;
+        a.tiles_n = (p->n + kBN - 1) / kBN;
+        constexpr int kShipC = kVarFullLineStores | kVarNtStores;
+        return bf ? launch<kOpBf16, kEpiF32Conv, kShipC>(a, s, e0, e1) : launch_f16<kEpiF32Conv, kShipC>(a, s, e0, e1, p->tune_variant == 512 || (p->tune_variant == 0 && p->k <= 576));
     }
     if (p->epilogue == DIMSUM_GEMM_EPI_F32 || p->epilogue == DIMSUM_GEMM_EPI_F32_BIAS) {
         if (p->ldc % 4 != 0 || p->ldc < p->n || !aligned_to<char>(p->c_ptr, 16)) return DIMSUM_ERR_STRIDE;

@@ -57,7 +57,7 @@ constexpr int kParity = 4 * kHalf;         // bytes of one K tile in LDS
 constexpr int kSlotA0 = 0, kSlotA1 = kHalf, kSlotB0 = 2 * kHalf, kSlotB1 = 3 * kHalf;
 
 enum { kOpBf16 = 0, kOpF16 = 1 };
-enum { kEpiF32 = 0, kEpiGatedSplit3 = 1, kEpiGatedF16 = 2, kEpiF32Bias = 3, kEpiF32GateRes = 4, kEpiF16Qkv = 5 };
+enum { kEpiF32 = 0, kEpiGatedSplit3 = 1, kEpiGatedF16 = 2, kEpiF32Bias = 3, kEpiF32GateRes = 4, kEpiF16Qkv = 5, kEpiF32Conv = 6 };
 
 struct Args {
     const char *A, *B0, *B1;       // B0 / B1: first weight row of the two 128-row halves' matrices (B1 = B0 + 128 rows for a plain GEMM)
@@ -84,6 +84,8 @@ struct Args {
     int tn_pieces;                 // kVarTN: both operands are [hi | lo] pairs: `splits` = 3 x splits_per_piece, split -> (piece, row range); the pieces pair
     int64_t a_pair_cols, b_pair_cols;   //         A (weight order) columns [0, lo, 0] with B (left order) columns [0, 0, lo]
     int b_alias_tiles;             // the same for the B rows (NT only: in_proj, whose activation image is the right operand)
+    const float *conv_w, *conv_b;  // kEpiF32Conv: (conv_rows, conv_width) taps (row stride conv_w_ld), (conv_rows) bias or NULL
+    int conv_rows, conv_width, conv_seq, conv_w_ld;     //   output rows [0, conv_rows) get conv + SiLU along the columns, sequences of conv_seq columns (256 % conv_seq == 0)
     int q_cols;                    // kEpiF16Qkv: columns [0, q_cols) take the per-row scale, the others the per-batch-element one
     int c_pieces2;                 // kEpiGatedSplit3: the h image is written as the pair [hi | lo] (ldc >= 2 F) for a consumer that reads it with a_alias_tiles
 };
@@ -508,7 +510,68 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[mi][ni][i][j]));
-    } else if constexpr (kEpi == kEpiF32 || kEpi == kEpiF32Bias || kEpi == kEpiF32GateRes) {
+    } else if constexpr (kEpi == kEpiF32 || kEpi == kEpiF32Bias || kEpi == kEpiF32GateRes || kEpi == kEpiF32Conv) {
+        if constexpr (kEpi == kEpiF32Conv) {
+            // in_proj of a Mamba mixer with the depthwise causal conv1d + bias + SiLU of its x half in the epilogue (mamba_simple.py in_proj,
+            // then causal_conv1d_fn inside mamba_inner_fn: selective_scan_interface.py:616): the product is d-major (rows = channels, columns =
+            // tokens), a tile's 256 columns are whole sequences (256 % conv_seq == 0), so the conv runs along a tile row with zero history at
+            // every sequence start. A half tile (kMiRows.. rows x 256 tokens, fp32) goes through the ring (free now): accumulators -> LDS
+            // (16-byte slot s of row r at s ^ (r & 7): the 8 rows a ds_write_b128 group touches land in 8 bank groups), then one wave per row:
+            // 16 bytes per lane along the sequence, the 3-element halo from the neighbouring lane, 1-KB coalesced stores. The conv kernel's
+            // pass over x (read + write of B D L 4 bytes and one launch per mixer) is gone; rows >= conv_rows (the z half) take the plain path.
+            if (m0 < p.conv_rows) {
+                constexpr int kNW = kM1 ? 4 : 8;
+                constexpr int kHalfRows = kM1 ? 64 : 128;              // rows of one mi half of the tile
+                float *Ct = reinterpret_cast<float *>(p.C) + (int64_t)m0 * p.ldc + n0;
+                const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(Ct, 0, 0x7fffffff, 0x00020000);
+                const int W = p.conv_width;
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    if (mi) __syncthreads();                            // the first half's rows have been read
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int tcol = ni * 128 + ecol + j * 16, col = n0 + tcol;
+                            f4 sbv = f4{1.f, 1.f, 1.f, 1.f};
+                            if (p.sb && col < p.N) sbv = *reinterpret_cast<const f4 *>(p.sb + col);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int rl = wr * 64 + i * 16 + (lane & 15);             // row inside the half
+                                f4 x = acc[mi][ni][i][j];
+                                if (p.sa) x = x * (sbv * p.sa[m0 + mi * kMiRows + rl]);
+                                *reinterpret_cast<f4 *>(lds + rl * 1024 + (((tcol >> 2) ^ (rl & 7)) << 4)) = x;
+                            }
+                        }
+                    __syncthreads();
+                    // wave w: rows 16 w .. 16 w + 15 of the half (kHalfRows / kNW = 16), lane l: tokens 4 l .. 4 l + 3
+#pragma unroll 4
+                    for (int it = 0; it < kHalfRows / kNW; ++it) {
+                        const int rl = w * (kHalfRows / kNW) + it, row = m0 + mi * kMiRows + rl;
+                        const f4 v = *reinterpret_cast<const f4 *>(lds + rl * 1024 + ((lane ^ (rl & 7)) << 4));
+                        float w4[4];                                    // taps right-aligned into 4 slots (w4[3] multiplies x[t]): wave-uniform loads
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) w4[k] = (k >= 4 - W) ? p.conv_w[(int64_t)row * p.conv_w_ld + (k - (4 - W))] : 0.f;
+                        const float cbias = p.conv_b ? p.conv_b[row] : 0.f;
+                        // x[t-1], x[t-2], x[t-3] of the lane's first token: the neighbouring lane's last three, zeros at a sequence start
+                        const bool start = ((4 * lane) % p.conv_seq) == 0;
+                        // (ds_bpermute: the three wave_shr:1 DPP moves this wants were merged into ONE move of the wrong register by hipcc 7.2 --
+                        // ISA checked -- whatever their `old` operand)
+                        float p1 = __shfl_up(v[3], 1, 64), p2 = __shfl_up(v[2], 1, 64), p3 = __shfl_up(v[1], 1, 64);
+                        p1 = start ? 0.f : p1; p2 = start ? 0.f : p2; p3 = start ? 0.f : p3;
+                        f4 y;
+                        y[0] = fmaf(w4[0], p3, fmaf(w4[1], p2, fmaf(w4[2], p1, fmaf(w4[3], v[0], cbias))));
+                        y[1] = fmaf(w4[0], p2, fmaf(w4[1], p1, fmaf(w4[2], v[0], fmaf(w4[3], v[1], cbias))));
+                        y[2] = fmaf(w4[0], p1, fmaf(w4[1], v[0], fmaf(w4[2], v[1], fmaf(w4[3], v[2], cbias))));
+                        y[3] = fmaf(w4[0], v[0], fmaf(w4[1], v[1], fmaf(w4[2], v[2], fmaf(w4[3], v[3], cbias))));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] = y[e] * fast_rcp(1.0f + fast_exp(-y[e]));          // SiLU (the conv kernel's sigmoidf_fast)
+                        if (n0 + 4 * lane < p.N) store_f4<2>(crsrc, (unsigned)(((mi * kMiRows + rl) * p.ldc + 4 * lane) * 4), y);
+                    }
+                }
+                return;
+            }
+        }
         // one buffer descriptor per tile (base = the tile's first element: wave-uniform), a 32-bit byte offset per lane
         constexpr int kAux = ((kVar & kVarNtStores) ? 2 : 0) | ((kVar & kVarSc1Stores) ? 16 : 0) | ((kVar & kVarSc0Stores) ? 1 : 0);
         float *Ct = reinterpret_cast<float *>(p.C) + (int64_t)m0 * p.ldc + n0 + (kTN ? (int64_t)split * p.c_split_stride : (int64_t)0);

@@ -477,9 +477,25 @@ def linear_split3(x3, weight, bias=None, residual=None, gate=None, rows_per_batc
     return _tail(torch.mm(x3, w3i.t(), out_dtype=torch.float32), bias, residual, gate, rows_per_batch)
 
 
-def matmul_wx_split3(weight, x3):
-    """weight (N, K) @ x^T -> (N, M) float32 with x given as its left image x3 (M, 3K) / F16Image: the in_proj site (d-major output)"""
+def matmul_wx_split3(weight, x3, conv=None):
+    """weight (N, K) @ x^T -> (N, M) float32 with x given as its left image x3 (M, 3K) / F16Image: the in_proj site (d-major output).
+    conv = (conv_weight (D, width), conv_bias (D) or None, seq): ask for the mixer's causal conv1d + SiLU over the first D output rows in the
+    GEMM's epilogue (native.gemm_nt(conv=...): sequences of `seq` tokens, 256 % seq == 0) -> (product, True) when the kernel took it, else
+    (plain product, False): the caller then runs the conv kernel as before. DIMSUM_INPROJ_CONV=0 switches the fusion off."""
     from . import native
+    if conv is not None:
+        cw, cb, seq = conv
+        a = weight_f16s(weight) if isinstance(x3, native.F16Image) else weight_image(weight)
+        ad, bd = (a.data, x3.data) if isinstance(x3, native.F16Image) else (a, x3)
+        ok = (os.environ.get("DIMSUM_INPROJ_CONV", "1") != "0" and own_gemm_enabled() and native.gemm_nt_supported(ad, bd)
+              and cw.dtype == torch.float32 and cw.dim() == 2 and cw.stride(1) == 1 and cw.shape[0] % 256 == 0 and 2 <= cw.shape[1] <= 4
+              and seq % 4 == 0 and 256 % seq == 0 and x3.shape[0] % seq == 0)
+        if ok:
+            cbf = None if cb is None else cb.detach().float().contiguous()
+            if isinstance(x3, native.F16Image):
+                return native.gemm_nt(ad, bd, scales=(a.inv, x3.inv), conv=(cw.detach(), cbf, seq)), True
+            return native.gemm_nt(a, x3, conv=(cw.detach(), cbf, seq)), True
+        return matmul_wx_split3(weight, x3), False
     if isinstance(x3, native.F16Image):
         return _nt_f16s(weight_f16s(weight), x3)
     w3i = weight_image(weight)

@@ -98,8 +98,19 @@ class _MambaBase(nn.Module):
             # xz[..., j] = xz[..., perm[j]]: permuting the columns of xz == permuting the tokens before in_proj
             hidden_states = hidden_states.index_select(1, self.zigzag_paths[self.layer_idx])
         # in_proj with the transpose fused: (2D, d_model) @ (d_model, B*L) viewed as (B, 2D, L) -- d-major, no copy
+        conv_done = False
         if x3 is not None:
-            xz = gemm.matmul_wx_split3(self.in_proj.weight, x3.reshape(bsz * L, -1)).view(2 * self.d_inner, bsz, L).permute(1, 0, 2)
+            # inference on operand images: where a 256-token tile of the GEMM holds whole sequences, the mixer's causal conv1d + SiLU runs in
+            # in_proj's epilogue (csrc/gemm_nt_kernel.hpp, kEpiF32Conv): xz[:, :d_inner] then already IS the conv output and
+            # mamba_inner_fn skips the conv kernel (one launch and a read + write of (b, d_inner, l) fp32 less per mixer)
+            cw = self.conv1d.weight
+            if (self.scan_type != "v2" and self.in_proj.bias is None and not torch.is_grad_enabled() and cond is None and cw.dtype == torch.float32
+                    and self.d_inner % 256 == 0 and 256 % L == 0 and L % 4 == 0):
+                xz, conv_done = gemm.matmul_wx_split3(self.in_proj.weight, x3.reshape(bsz * L, -1),
+                                                      conv=(cw.reshape(cw.shape[0], cw.shape[-1]), self.conv1d.bias, L))
+            else:
+                xz = gemm.matmul_wx_split3(self.in_proj.weight, x3.reshape(bsz * L, -1))
+            xz = xz.view(2 * self.d_inner, bsz, L).permute(1, 0, 2)
         else:
             xz = gemm.matmul_wx(self.in_proj.weight, hidden_states.reshape(bsz * L, -1).t()).view(2 * self.d_inner, bsz, L).permute(1, 0, 2)
         if self.in_proj.bias is not None:
@@ -120,7 +131,7 @@ class _MambaBase(nn.Module):
             return nn.functional.linear(y, self.out_proj.weight, self.out_proj.bias)
         out = mamba_inner_fn_cond(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight, self.dt_proj.weight,
                                   self.out_proj.weight, self.out_proj.bias, A, None, None, self.D.float(),
-                                  delta_bias=self.dt_proj.bias.float(), delta_softplus=True, init_states=cond)
+                                  delta_bias=self.dt_proj.bias.float(), delta_softplus=True, init_states=cond, conv_done=conv_done)
         if own_gather:
             out = out.index_select(1, self.zigzag_paths_reverse[self.layer_idx])
         return out

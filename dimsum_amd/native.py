@@ -755,7 +755,7 @@ def gemm_tn(a, b, splits=None, events=None, alias_rows=0):
 
 
 def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=None, tune=None, scales=None, gate_bound=None, residual=None,
-            gate=None, rows_per_batch=None, keep_x12=False, pair_out=False, weight_order=False, q_cols=None):
+            gate=None, rows_per_batch=None, keep_x12=False, pair_out=False, weight_order=False, q_cols=None, conv=None):
     """a (M, K) @ b (N, K)^T on the hand-written MFMA kernel, 16-bit operands (bfloat16: split-bf16 images over 3 K; float16: scaled rows),
     fp32 accumulation.
       epilogue "f32"          -> (M, N) float32 (+ bias[N])
@@ -798,6 +798,18 @@ def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=Non
         if out is None:
             out = torch.empty((M, N), device=a.device, dtype=torch.float32)
         _check(out.dtype == torch.float32 and out.shape == (M, N) and out.stride(1) == 1, "gemm_nt: out must be (M, N) float32 rows")
+        if conv is not None:
+            # conv = (weight (rows, width) f32, bias (rows) f32 or None, seq): rows [0, rows) of the d-major product get the causal conv1d + SiLU
+            # along their columns (sequences of `seq` columns) in the epilogue -- in_proj + causal_conv1d_fn of a Mamba mixer in one kernel
+            cw, cb, seq = conv
+            _gpu(cw, cb)
+            _check(bias is None and residual is None and cw.dtype == torch.float32 and cw.dim() == 2 and cw.stride(1) == 1 and cw.shape[0] % 256 == 0
+                   and cw.shape[0] <= M and 2 <= cw.shape[1] <= 4 and 256 % seq == 0 and seq % 4 == 0 and N % seq == 0
+                   and (cb is None or (cb.dtype == torch.float32 and cb.is_contiguous() and cb.numel() == cw.shape[0])),
+                   "gemm_nt: conv = (weight (rows % 256 == 0, width 2..4) f32, bias or None, seq with 256 % seq == 0)")
+            P.epilogue = _lib.GEMM_EPI_F32_CONV
+            P.conv_weight_ptr, P.conv_bias_ptr = _ptr(cw), _ptr(cb)
+            P.conv_rows, P.conv_width, P.conv_seq, P.conv_weight_ld = cw.shape[0], cw.shape[1], seq, cw.stride(0)
         if residual is not None:
             _gpu(residual, gate)
             _check(residual.dtype == torch.float32 and residual.shape == (M, N) and residual.stride(1) == 1, "gemm_nt: residual must be (M, N) float32 rows")

@@ -90,8 +90,11 @@ class _MambaInner(torch.autograd.Function):
     @custom_fwd(device_type="cuda")
     def forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
                 A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, init_states, has_out_proj, checkpoint_lvl,
-                need_ckpt=False):
+                need_ckpt=False, conv_done=False):
+        # conv_done (inference extra, not in the reference's signature): xz[:, :d_inner] already holds the causal conv1d + SiLU of the in_proj
+        # output (the GEMM's epilogue formed it, modules/mamba_simple.py) -- the conv kernel is skipped
         assert checkpoint_lvl in (0, 1)
+        assert not (conv_done and need_ckpt), "conv_done is an inference extra"
         if A.is_complex():
             raise NotImplementedError("mamba_inner_fn: complex A is outside this build's scope")
         if B is not None or C is not None:
@@ -112,7 +115,9 @@ class _MambaInner(torch.autograd.Function):
         # `init_states` is numerically dead in the reference (its buffer is overwritten with the plain conv result,
         # causal_conv1d.cpp:326-329). A full-size buffer is honoured as the output buffer; anything else (e.g. the
         # (batch, d_inner) cond_proj output CondMamba passes) only keeps the autograd edge.
-        if init_states is not None and init_states.shape == x.shape and init_states.dtype == x.dtype and init_states.stride(-1) == 1:
+        if conv_done:
+            conv_out = x
+        elif init_states is not None and init_states.shape == x.shape and init_states.dtype == x.dtype and init_states.stride(-1) == 1:
             conv_out = native.causal_conv1d_fwd_cond(x, conv_w, conv_b, True, init_states)
         else:
             conv_out = native.causal_conv1d_fwd(x, conv_w, conv_b, True)
@@ -228,7 +233,7 @@ class _MambaInner(torch.autograd.Function):
         _, dconv_w, dconv_b = native.causal_conv1d_bwd(x, conv_w, conv_b, dconv_out, dx, True)
         return (dxz, dconv_w.unsqueeze(1), dconv_b if has_conv_b else None, dx_proj_weight, ddelta_proj_weight,
                 dout_proj_weight, dout_proj_bias, dA, None, None, dD if has_D else None,
-                ddelta_bias if has_dbias else None, dB_proj_bias, dC_proj_bias, None, None, None, None, None)
+                ddelta_bias if has_dbias else None, dB_proj_bias, dC_proj_bias, None, None, None, None, None, None)
 
 
 def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias, A,
@@ -241,11 +246,11 @@ def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_wei
 
 def mamba_inner_fn_cond(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
                         A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None,
-                        delta_softplus=True, init_states=None):
+                        delta_softplus=True, init_states=None, conv_done=False):
     return _MambaInner.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
                              out_proj_bias, A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, init_states,
                              True, 1, _will_backprop(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias, A, B, C, D, delta_bias,
-                                            B_proj_bias, C_proj_bias, init_states))
+                                            B_proj_bias, C_proj_bias, init_states), conv_done)
 
 
 def mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B=None, C=None,

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DIMSUM_ABI_VERSION 14
+#define DIMSUM_ABI_VERSION 15
 
 typedef enum {
     DIMSUM_OK = 0,
@@ -416,6 +416,11 @@ int dimsum_gated_gelu_bwd_pair(const void *x12, const void *bias, const void *dh
 typedef enum {
     DIMSUM_GEMM_EPI_F32 = 0, DIMSUM_GEMM_EPI_GATED_GELU_SPLIT3 = 1, DIMSUM_GEMM_EPI_GATED_GELU_F16 = 2, DIMSUM_GEMM_EPI_F32_BIAS = 3,
     DIMSUM_GEMM_EPI_F32_GATE_RESIDUAL = 4,
+    DIMSUM_GEMM_EPI_F32_CONV = 6,   /* in_proj of a Mamba mixer with the causal conv1d + bias + SiLU of its x half in the epilogue (mamba_simple.py in_proj followed
+                                       by causal_conv1d_fn, selective_scan_interface.py:616): C (m, n) f32 d-major (rows = channels, columns = tokens); rows
+                                       [0, conv_rows) hold silu(conv(A B^T) + conv_bias) along the columns, in sequences of conv_seq columns (256 % conv_seq == 0,
+                                       n % conv_seq == 0: zero history at every sequence start), the other rows the plain product. conv_weight (conv_rows,
+                                       conv_width 2..4) f32 row stride conv_weight_ld, conv_bias (conv_rows) f32 or NULL. conv_rows % 128 == 0. */
     DIMSUM_GEMM_EPI_F16_QKV = 5     /* the qkv Linear of the attention fusion under the scaled-fp16 policy (attention_fusion.py:52-60, models_dim.py:1470):
                                        C (m, n = 3 C') fp16 = fp16((A B^T + bias) 2^s), scaled-fp16 operands (a / b_inv_scale_ptr required). Columns
                                        [0, qkv_q_cols) (q) take one power-of-two scale per ROW, the rest (k, v) one per BATCH ELEMENT (rows_per_batch rows,
@@ -464,6 +469,8 @@ typedef struct {
        in weight order), b_ptr rows [hi | lo] with lo at column tn_pair_b_cols (read in left order); k = the rows of one piece, splits = 3 x the
        number of row ranges: partial result (piece, range) pairs A's piece with B's piece over that range. */
     int32_t a_alias_weight_order, qkv_q_cols;      /* qkv_q_cols: F16_QKV only (% 16 == 0) */
+    const void *conv_weight_ptr, *conv_bias_ptr;   /* F32_CONV only */
+    int32_t conv_rows, conv_width, conv_seq, conv_weight_ld;
     int64_t tn_pair_a_cols, tn_pair_b_cols;
 } dimsum_gemm_params_t;
 

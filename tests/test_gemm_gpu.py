@@ -375,3 +375,26 @@ def test_m128_epilogues_match_the_256_row_tiles(with_gate):
     x12 = x.float().double() @ w16.float().double().t() + b12.double()
     href = torch.nn.functional.gelu(x12[:, :F], approximate="tanh") * x12[:, F:]
     assert ((h1.float().double() - href).abs() / href.abs().amax(-1, keepdim=True)).max().item() < 2e-3
+
+
+@pytest.mark.parametrize("dtype,tune", [("float16", 512), ("float16", 513), ("bfloat16", 513)])
+@pytest.mark.parametrize("M,D,N,K,seq,width,with_bias", [(512, 256, 512, 128, 256, 4, True), (1024, 512, 768, 256, 128, 3, False), (512, 512, 1024, 512, 64, 2, True)])
+def test_conv_epilogue_is_the_gemm_followed_by_the_conv_kernel(dtype, tune, M, D, N, K, seq, width, with_bias):
+    """DIMSUM_GEMM_EPI_F32_CONV (in_proj + causal_conv1d_fn of a Mamba mixer, mamba_simple.py / selective_scan_interface.py:616): rows [0, D) of
+    the d-major product carry silu(conv + bias) along their columns in sequences of `seq` tokens, the other rows the plain product -- against
+    the plain GEMM followed by the stand-alone conv kernel on the (batch, D, seq) view of those rows (the same fp32 formula: differences at the
+    level of the fused multiply-adds' order); both tile shapes, scaled-fp16 and bf16 operands, widths 2-4, several sequences per tile"""
+    from dimsum_amd import native
+    dt = getattr(torch, dtype)
+    a, b = _rnd((M, K), dt, 1, K ** -0.5), _rnd((N, K), dt, 2)
+    cw, cb = _rnd((D, width), torch.float32, 3), (_rnd((D,), torch.float32, 4) if with_bias else None)
+    kw = {}
+    if dtype == "float16":
+        kw["scales"] = (torch.exp2(torch.randint(-4, 4, (M,), device="cuda").float()), torch.exp2(torch.randint(-4, 4, (N,), device="cuda").float()))
+    plain = native.gemm_nt(a, b, tune=(tune, 0, 0), **kw)
+    got = native.gemm_nt(a, b, tune=(tune, 0, 0), conv=(cw, cb, seq), **kw)
+    assert torch.equal(got[D:], plain[D:])
+    x = plain[:D].view(D, N // seq, seq).permute(1, 0, 2)                       # (batch, D, seq) d-major view, like MambaInnerFn's x
+    ref = native.causal_conv1d_fwd(x, cw, cb, True).permute(1, 0, 2).reshape(D, N)
+    assert (got[:D] - ref).abs().max().item() <= 2e-6 * ref.abs().max().item() + 1e-7
+    assert torch.equal(native.gemm_nt(a, b, tune=(tune, 0, 0), conv=(cw, cb, seq), **kw), got)
