@@ -86,11 +86,13 @@ struct Args {
     int b_alias_tiles;             // the same for the B rows (NT only: in_proj, whose activation image is the right operand)
     const float *conv_w, *conv_b;  // kEpiF32Conv: (conv_rows, conv_width) taps (row stride conv_w_ld), (conv_rows) bias or NULL
     int conv_rows, conv_width, conv_seq, conv_w_ld;     //   output rows [0, conv_rows) get conv + SiLU along the columns, sequences of conv_seq columns (256 % conv_seq == 0)
+    const _Float16 *a_rebase;      // kVarRebase (TN, fp16): (M / 32, a_rebase_ld >= K / 64) powers of two <= 1: the A values of token group g = m / 32 in K tile kt were stored with
+    int a_rebase_ld;               //   their own scale; multiplying them by a_rebase[g][kt] puts the whole row group on ONE scale (undone by sa[m] in the epilogue)
     int q_cols;                    // kEpiF16Qkv: columns [0, q_cols) take the per-row scale, the others the per-batch-element one
     int c_pieces2;                 // kEpiGatedSplit3: the h image is written as the pair [hi | lo] (ldc >= 2 F) for a consumer that reads it with a_alias_tiles
 };
 // tuning variants (bit mask; 0 = the shipped schedule)
-enum { kVarLgkmAfterBarrier = 1, kVarNoEpilogue = 2, kVarNtStores = 4, kVarFullLineStores = 8, kVarNoSetprio = 16, kVarSc1Stores = 32, kVarSc0Stores = 64, kVarKeepX12 = 128, kVarTN = 256, kVarM128 = 512 };
+enum { kVarLgkmAfterBarrier = 1, kVarNoEpilogue = 2, kVarNtStores = 4, kVarFullLineStores = 8, kVarNoSetprio = 16, kVarSc1Stores = 32, kVarSc0Stores = 64, kVarKeepX12 = 128, kVarTN = 256, kVarM128 = 512, kVarRebase = 1024 };
 
 __device__ __forceinline__ float dpp_row_ror8(float x) {      // lane l <- lane l ^ 8 (rotation by 8 inside each row of 16 lanes)
     const int v = __builtin_bit_cast(int, x);                  // (old = the source: with a constant `old` hipcc 7.2 merges the calls of an unrolled loop)
@@ -347,6 +349,31 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
         __builtin_amdgcn_sched_barrier(0);                                                 \
     } while (0)
 
+    // kVarRebase: block-scaled fp16 A (the scan's out_z: one power-of-two scale per 32 tokens x 64 channels, section 3.5 of DESIGN.md): a fragment
+    // (16 tokens x 32 reduction rows of one K tile) is multiplied by its block's factor right after it was read -- exact (a power of two <= 1)
+    // unless the value drops below fp16's normal range, i.e. below 2^-29 of its row group's maximum. 32 v_pk_mul_f16 per fragment set, under the MFMAs.
+    constexpr bool kRebase = (kVar & kVarRebase) != 0;
+    static_assert(!kRebase || (kTN && kOp == kOpF16), "the rebase serves the fp16 TN variant");
+    auto rebase = [&](u32x4 (&frag)[4][2], int mi, int kt_) {
+        if constexpr (kRebase) {
+            const int g0 = (m0 + mi * 128 + wr * 64) >> 5;
+            const _Float16 f0 = p.a_rebase[(int64_t)g0 * p.a_rebase_ld + kt_], f1 = p.a_rebase[(int64_t)(g0 + 1) * p.a_rebase_ld + kt_];
+            // (the fragments are outputs of asynchronous ds_read asm statements: the empty asm pins every one of them to its registers HERE, after the
+            // phase's lgkmcnt(0), so that whatever copies the multiplies need are made of landed data -- without it the compiler copied the asm outputs
+            // right behind the reads, before the wait)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh) asm volatile("" : "+v"(frag[i][kh]));
+            typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+            const h8_t s0 = {f0, f0, f0, f0, f0, f0, f0, f0}, s1 = {f1, f1, f1, f1, f1, f1, f1, f1};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh) frag[i][kh] = __builtin_bit_cast(u32x4, __builtin_bit_cast(h8_t, frag[i][kh]) * (i < 2 ? s0 : s1));
+        }
+    };
+
     const int nk = p.K / kBK;      // >= 2
 
     if constexpr (kM1) {
@@ -422,6 +449,7 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
     __builtin_amdgcn_sched_barrier(0);
     DIMSUM_READ_A(a0, kSlotA0, 0);                    // "phase -1": A0(0), retired in every wave before anything re-stages its slot
     DIMSUM_PHASE_SYNC();
+    rebase(a0, 0, 0);
     DIMSUM_PHASE_END();
 
     // ---- main loop: K tile kt is computed while K tile kt + 2 is staged into the slots kt frees
@@ -447,6 +475,7 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
         stage_b1(kt + 2);
         DIMSUM_WAIT_VM(12);
         DIMSUM_PHASE_SYNC();
+        rebase(a1, 1, kt);
         DIMSUM_QUADRANT(1, 1, a1, b1);
         DIMSUM_PHASE_END();
         // P4
@@ -455,6 +484,7 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
         DIMSUM_WAIT_VM(12);
         DIMSUM_PHASE_SYNC();
         DIMSUM_QUADRANT(1, 0, a1, b0);
+        rebase(a0, 0, kt + 1);                        // (under the MFMAs just issued: a0 is next used in P1 of K tile kt + 1)
         DIMSUM_PHASE_END();
     }
     // ---- the last two K tiles: nothing left to stage, the counted waits run down (5, 4, 3, 2, 1, 0 half tiles behind the one needed next)
@@ -473,12 +503,14 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
         DIMSUM_READ_A(a1, kSlotA1, par);
         DIMSUM_WAIT_VM(6);
         DIMSUM_PHASE_SYNC();
+        rebase(a1, 1, kt);
         DIMSUM_QUADRANT(1, 1, a1, b1);
         DIMSUM_PHASE_END();
         DIMSUM_READ_A(a0, kSlotA0, par_next);
         DIMSUM_WAIT_VM(4);
         DIMSUM_PHASE_SYNC();
         DIMSUM_QUADRANT(1, 0, a1, b0);
+        rebase(a0, 0, kt + 1);
         DIMSUM_PHASE_END();
         DIMSUM_READ_B(b0, kSlotB0, par_next);
         DIMSUM_WAIT_VM(2);
@@ -492,6 +524,7 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
         DIMSUM_PHASE_END();
         DIMSUM_READ_A(a1, kSlotA1, par_next);
         DIMSUM_PHASE_SYNC();
+        rebase(a1, 1, kt + 1);
         DIMSUM_QUADRANT(1, 1, a1, b1);
         DIMSUM_PHASE_END();
         DIMSUM_QUADRANT(1, 0, a1, b0);

@@ -721,11 +721,21 @@ def gemm_tn_pairs(a, b, splits=None):
     return out.sum(0)
 
 
-def gemm_tn(a, b, splits=None, events=None, alias_rows=0):
+def gemm_tn(a, b, splits=None, events=None, alias_rows=0, scales=None, rebase=None):
     """a (R, P)^T @ b (R, Q) -> (P, Q) float32 on the hand-written MFMA kernel's TN variant: the weight-gradient product of a Linear
     (reduction over the rows). The reduction is cut into `splits` ranges whose partial results are added in a fixed order.
-    alias_rows = D: a is a (2 D, P) pair of planes [hi; lo] read as the row stack [hi; hi; lo] (b: (3 D, Q)); one range."""
+    alias_rows = D: a is a (2 D, P) pair of planes [hi; lo] read as the row stack [hi; hi; lo] (b: (3 D, Q)); one range.
+    scales = (a_inv (P,), b_inv (Q,)) [, rebase (P / 32, R / 64) float16]: float16 operands carrying power-of-two scales (one range): the result is
+    multiplied by a_inv[p] b_inv[q]; with `rebase` a's values of tokens [32 g, 32 g + 32) x reduction rows [64 t, 64 t + 64) are multiplied by
+    rebase[g][t] as they are read (the scan's block-scaled fp16 out_z: out_proj of a Mamba mixer as ONE fp16 product per element)."""
     _gpu(a, b)
+    if scales is not None:
+        _gpu(*scales, rebase)
+        _check(a.dtype == torch.float16 and not alias_rows and scales[0].dtype == torch.float32 and scales[1].dtype == torch.float32 and scales[0].numel() == a.shape[1]
+               and scales[1].numel() == b.shape[1] and scales[0].is_contiguous() and scales[1].is_contiguous(), "gemm_tn: scales = (a_inv (P,), b_inv (Q,)) float32 with float16 operands")
+        _check(rebase is None or (rebase.dtype == torch.float16 and rebase.dim() == 2 and rebase.shape[0] == a.shape[1] // 32 and rebase.shape[1] >= a.shape[0] // 64
+                                  and rebase.stride(1) == 1), "gemm_tn: rebase must be (P / 32, R / 64) float16")
+        splits = 1
     if alias_rows:
         _check(a.dim() == 2 and a.shape[0] == 2 * alias_rows and b.shape[0] == 3 * alias_rows and alias_rows % 64 == 0 and gemm_tn_supported(a[:alias_rows], b[:alias_rows]),
                "gemm_tn: alias_rows = D takes a (2 D, P) plane pair and a (3 D, Q) row stack, D % 64 == 0")
@@ -747,6 +757,10 @@ def gemm_tn(a, b, splits=None, events=None, alias_rows=0):
     G.lda, G.ldb, G.ldc = a.stride(0), b.stride(0), Q
     G.a_ptr, G.b_ptr, G.c_ptr = _ptr(a), _ptr(b), _ptr(out)
     G.a_alias_rows = alias_rows
+    if scales is not None:
+        G.a_inv_scale_ptr, G.b_inv_scale_ptr = _ptr(scales[0]), _ptr(scales[1])
+        if rebase is not None:
+            G.a_rebase_ptr, G.a_rebase_ld = _ptr(rebase), rebase.stride(0)
     if events is not None:
         G.timing_start_event, G.timing_stop_event = events
     with torch.cuda.device(a.device):

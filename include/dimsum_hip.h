@@ -471,6 +471,11 @@ typedef struct {
     int32_t a_alias_weight_order, qkv_q_cols;      /* qkv_q_cols: F16_QKV only (% 16 == 0) */
     const void *conv_weight_ptr, *conv_bias_ptr;   /* F32_CONV only */
     int32_t conv_rows, conv_width, conv_seq, conv_weight_ld;
+    /* dimsum_gemm_tn, float16 operands, splits == 1: block-scaled A (the scan's fp16 out_z, dimsum_ssm_params_t.out_z_f16): a_rebase_ptr is a
+     * (m / 32, a_rebase_ld >= k / 64) float16 table of powers of two <= 1; the A values of tokens [32 g, 32 g + 32) in reduction rows [64 t, 64 t + 64)
+     * are multiplied by a_rebase[g][t] as they are read, which puts a row group on one scale (undone by a_inv_scale_ptr[m]). */
+    const void *a_rebase_ptr;
+    int64_t a_rebase_ld;
     int64_t tn_pair_a_cols, tn_pair_b_cols;
 } dimsum_gemm_params_t;
 

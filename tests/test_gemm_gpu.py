@@ -398,3 +398,37 @@ def test_conv_epilogue_is_the_gemm_followed_by_the_conv_kernel(dtype, tune, M, D
     ref = native.causal_conv1d_fwd(x, cw, cb, True).permute(1, 0, 2).reshape(D, N)
     assert (got[:D] - ref).abs().max().item() <= 2e-6 * ref.abs().max().item() + 1e-7
     assert torch.equal(native.gemm_nt(a, b, tune=(tune, 0, 0), conv=(cw, cb, seq), **kw), got)
+
+
+@pytest.mark.parametrize("K,M,N", [(128, 256, 256), (1024, 2048, 512), (320, 512, 256)])
+def test_tn_product_of_block_scaled_fp16_rows(K, M, N):
+    """dimsum_gemm_tn with a_rebase_ptr: A (K, M) float16 whose (64-row, 32-column) blocks carry their own power-of-two scales (what the scan's
+    fp16 out_z is), rebased to one scale per 32-column group as it is read, times a per-column-scaled B (K, N): against the float64 product of
+    the decoded operands (exact: every factor is a power of two and nothing leaves fp16's normal range here), and against the float64 product of
+    the ORIGINAL fp32 data at the TF32 class (10-bit mantissas); block magnitudes spread over 2^-12 .. 2^12"""
+    from dimsum_amd import native
+    from dimsum_amd.utils.tf32_emulation import round_tf32
+    g = torch.Generator(device="cuda").manual_seed(K + M)
+    x = torch.randn(K, M, device="cuda", generator=g)
+    mag = torch.exp2(torch.randint(-12, 13, (K // 64, M // 32), device="cuda", generator=g).float())
+    x = x * mag.repeat_interleave(64, 0).repeat_interleave(32, 1)
+    w = torch.randn(N, K, device="cuda", generator=g) * K ** -0.5
+    # the producer's side: one scale per block from the block's maximum (f16s_scales: the maximum lands in [2^14, 2^15))
+    bmax = x.view(K // 64, 64, M // 32, 32).abs().amax((1, 3))
+    sc = torch.exp2(14 - torch.floor(torch.log2(bmax)))
+    a16 = (x * sc.repeat_interleave(64, 0).repeat_interleave(32, 1)).half()
+    inv = (1.0 / sc).t().contiguous()                                   # (M / 32, K / 64)
+    sa_g = inv.amax(1)
+    rebase = (inv / sa_g[:, None]).half()
+    wimg = native.rows_f16s(w)
+    b16 = wimg.data.t().contiguous()                                    # (K, N) float16, column n scaled by 2^s_n
+    got = native.gemm_tn(a16, b16, scales=(sa_g.repeat_interleave(32).contiguous(), wimg.inv), rebase=rebase)
+    a_dec = a16.double() * rebase.double().t().repeat_interleave(64, 0).repeat_interleave(32, 1)
+    exact = (a_dec.t() @ b16.double()) * sa_g.repeat_interleave(32).double()[:, None] * wimg.inv.double()[None, :]
+    row = exact.abs().amax(1, keepdim=True)
+    assert ((got.double() - exact).abs() / row).max().item() < 3e-6
+    ref = x.double().t() @ w.double().t()
+    tf = round_tf32(x).double().t() @ round_tf32(w).double().t()
+    e, et = (got.double() - ref).abs() / ref.abs().amax(1, keepdim=True), (tf - ref).abs() / ref.abs().amax(1, keepdim=True)
+    assert e.max().item() <= 1.1 * et.max().item() + 1e-6 and e.pow(2).mean().sqrt().item() <= 1.1 * et.pow(2).mean().sqrt().item() + 1e-7, (e.max().item(), et.max().item())
+    assert torch.equal(native.gemm_tn(a16, b16, scales=(sa_g.repeat_interleave(32).contiguous(), wimg.inv), rebase=rebase), got)
