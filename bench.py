@@ -59,14 +59,15 @@ def usable_cores():
     return n
 
 
-def scan_bytes(B, D, L, N, G=1, s=4, has_out=True, has_x=True, dt_rank=0):
+def scan_bytes(B, D, L, N, G=1, s=4, has_out=True, has_x=True, dt_rank=0, out_z_f16=False):
     """5 B D L s + 2 B G N L s + B D ceil(L/2048) 2N 4 + (D N + 2 D) 4 for the full interface (reads u, delta, z,
     B, C, A, D, delta_bias; writes out, out_z, x). A launch that skips the `out` / `x` stores (inference: out_ptr / x_ptr NULL)
     is priced with what it moves: one B D L s term / the chunk-state term less -- 8(d)'s "inference-only lower bound" 1.082 GB; a launch
-    with the fused dt_proj (dt_rank > 0: delta = W_dt x_dbl[:R] formed inside the kernel) reads x_dbl[:R] and W_dt instead of delta."""
+    with the fused dt_proj (dt_rank > 0: delta = W_dt x_dbl[:R] formed inside the kernel) reads x_dbl[:R] and W_dt instead of delta; one that
+    writes out_z as block-scaled fp16 (out_z_f16) writes 2 bytes per element + one scale per 64 x 32 block."""
     terms = (5 if has_out else 4) - (1 if dt_rank else 0)      # fused dt_proj: `delta` is not read; the launch reads x_dbl[:R] and W_dt instead
     return (terms * B * D * L * s + 2 * B * G * N * L * s + (B * D * ((L + 2047) // 2048) * 2 * N * 4 if has_x else 0)
-            + (D * N + 2 * D) * 4 + (B * L * dt_rank + D * dt_rank) * 4)
+            + (D * N + 2 * D) * 4 + (B * L * dt_rank + D * dt_rank) * 4 - ((B * D * L * (s - 2) - B * D * L // 2048 * 4) if out_z_f16 else 0))
 
 
 def scan_bwd_bytes(B, D, L, N, G=1, s=4, recompute_out_z=True):
@@ -114,7 +115,8 @@ class ScanTimer:
                 if which == "fwd":
                     kernel = (_lib.SCAN_FWD_KERNELS[lib.dimsum_ssm_scan_fwd_variant(p)] + (" (+ saved states)" if p.ckpt_ptr else "")
                               + ("" if (p.out_ptr and p.x_ptr) else " (inference: no out / x stores)")
-                              + (" (+ fused dt_proj: delta formed in the kernel, not read)" if p.dt_w_ptr else ""))
+                              + (" (+ fused dt_proj: delta formed in the kernel, not read)" if p.dt_w_ptr else "")
+                              + (" (out_z as block-scaled fp16)" if p.out_z_f16 else ""))
                 else:
                     kernel = "ssm_scan_bwd_kernel (+ ssm_scan_bwd_reduce_kernel)" + ("" if p.out_z_ptr else ", no out_z recompute")
                 # HIP events recorded at the begin of the call's first kernel and the end of its last one (the per-call
@@ -138,7 +140,8 @@ class ScanTimer:
                 # inside it (delta is formed on the matrix cores instead of being read)
                 nbytes = (scan_bwd_bytes(*shape, p.n_groups, s, recompute_out_z=bool(p.out_z_ptr)) if which == "bwd"
                           else scan_bytes(*shape, p.n_groups, s, has_out=bool(p.out_ptr), has_x=bool(p.x_ptr)))
-                moved = nbytes if (which == "bwd" or not p.dt_w_ptr) else scan_bytes(*shape, p.n_groups, s, has_out=bool(p.out_ptr), has_x=bool(p.x_ptr), dt_rank=p.dt_rank)
+                moved = nbytes if (which == "bwd" or not (p.dt_w_ptr or p.out_z_f16)) else scan_bytes(*shape, p.n_groups, s, has_out=bool(p.out_ptr), has_x=bool(p.x_ptr),
+                                                                                                      dt_rank=p.dt_rank if p.dt_w_ptr else 0, out_z_f16=bool(p.out_z_f16))
                 timer.records[which].append((e0, e1, nbytes, shape, kernel, moved))
                 return rc
 
@@ -378,7 +381,9 @@ class Bench:
                 rf["pricing"] = ("SURVEY 8(d) inference-only lower bound: the launch skips the `out` / `x` stores nothing reads, and is priced without them"
                                  + ("; dt_proj ALSO runs inside this launch on the matrix cores (delta = W_dt x_dbl[:R] per tile: one GEMM launch less per "
                                     "mixer), so the launch does not even read delta: `achieved` / `frac` keep 8(d)'s algorithmic bytes of the scan it "
-                                    "performs, `bytes_moved_by_this_launch` / `frac_of_bytes_moved` price only what crosses HBM" if "fused dt_proj" in rf["kernel"] else ""))
+                                    "performs, `bytes_moved_by_this_launch` / `frac_of_bytes_moved` price only what crosses HBM" if "fused dt_proj" in rf["kernel"] else "")
+                                 + ("; out_z leaves as block-scaled fp16 (2 bytes per element + one scale per 64 x 32 block: the operand of out_proj's single "
+                                    "fp16 product), counted in `bytes_moved_by_this_launch` only" if "block-scaled fp16" in rf["kernel"] else ""))
                 full = self.scan_roofline_pass(step, full_interface=True)
                 if full is not None:
                     full["pricing"] = "SURVEY 8(d) full interface (reads u, delta, z, B, C, A, D, delta_bias; writes out, out_z, x)"

@@ -19,7 +19,8 @@ class SsmParams(C.Structure):
                 + [(n, vp) for n in ("A_ptr", "B_ptr", "C_ptr", "D_ptr", "u_ptr", "delta_ptr", "delta_bias_ptr",
                                      "z_ptr", "out_ptr", "x_ptr", "out_z_ptr", "ckpt_ptr")]
                 + [("kernel_variant", i32), ("timing_start_event", vp), ("timing_stop_event", vp), ("out_z_lo_offset", i64)]
-                + [("dt_w_ptr", vp), ("dt_x_ptr", vp), ("dt_w_row_stride", i64), ("dt_x_row_stride", i64), ("dt_rank", i32), ("reserved3", i32)])
+                + [("dt_w_ptr", vp), ("dt_x_ptr", vp), ("dt_w_row_stride", i64), ("dt_x_row_stride", i64), ("dt_rank", i32), ("out_z_f16", i32),
+                   ("out_z_scale_ptr", vp), ("out_z_scale_ld", i64)])
 
 
 class SsmBwdParams(C.Structure):

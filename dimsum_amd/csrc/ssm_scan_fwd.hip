@@ -84,8 +84,13 @@ static int launch_fwd(const dimsum_ssm_params_t &p, hipStream_t stream) {
         !offsets_fit_32bit<T>(p.seqlen, p.dstate, {p.B_dstate_stride, p.C_dstate_stride}))
         return DIMSUM_ERR_STRIDE;
     const bool full = vec && (dpg % cpw == 0);
-    if (p.dt_w_ptr && !(sp == 1 && full && p.z_ptr && !p.ckpt_ptr && std::is_same<T, float>::value && kN == 16 && p.seqlen % 4 == 0))
-        return DIMSUM_ERR_UNSUPPORTED;        // the fused dt_proj rides on the 64-channel kernel's full fp32 inference path only
+    if ((p.dt_w_ptr || p.out_z_f16) && !(sp == 1 && full && p.z_ptr && !p.ckpt_ptr && std::is_same<T, float>::value && kN == 16 && p.seqlen % 4 == 0))
+        return DIMSUM_ERR_UNSUPPORTED;        // the fused dt_proj / fp16 out_z ride on the 64-channel kernel's full fp32 inference path only
+    if (p.out_z_f16) {
+        if (!p.out_z_scale_ptr) return DIMSUM_ERR_NULL;
+        if (p.seqlen % 32 != 0 || p.out_z_lo_offset != 0) return DIMSUM_ERR_UNSUPPORTED;
+        if (!aligned_to<char>(p.out_z_ptr, 16) || p.out_z_batch_stride % 8 != 0 || p.out_z_d_stride % 8 != 0 || p.out_z_scale_ld < p.dim / 64) return DIMSUM_ERR_STRIDE;
+    }
     if (sp == 16) {
         if constexpr (kN == 16) ssm_scan_fwd_launch_lanes<T>(p, stream, tiles, vec, full);
     } else if (sp == 4) {

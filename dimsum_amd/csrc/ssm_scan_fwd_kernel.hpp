@@ -133,9 +133,16 @@ typedef __bf16 scan_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float scan_f4 __attribute__((ext_vector_type(4)));
 struct alignas(16) ScanU4 { unsigned w[4]; };
 
-template <typename T, int kN, bool kHasZ, bool kVec, bool kFull, bool kCkpt = false, bool kDt = false>
+// kZ16 : out_z leaves as BLOCK-SCALED fp16 (include/dimsum_hip.h, out_z_f16): the wave's 64 channels x 32 steps of a tile share one power-of-two
+//        scale from the tile's own maximum (the values are all in registers in the epilogue; one wave_allmax), written as fp16(out_z 2^s) with
+//        2^-s in a (tokens / 32, channels / 64) table. out_proj then multiplies ONE fp16 product per element (dimsum_gemm_tn, a_rebase_ptr: the
+//        GEMM puts a 32-token group on one scale as it reads the blocks) instead of the library's three bf16 products over fp32 operands, and
+//        the scan writes half the bytes. A lane pair trades halves (one quad_perm DPP each way) so that every lane issues ONE 16-byte store
+//        for two pieces. The reference feeds out_proj under TF32 (selective_scan_interface.py:954-981 under train.py:20-21): 10-bit mantissas.
+template <typename T, int kN, bool kHasZ, bool kVec, bool kFull, bool kCkpt = false, bool kDt = false, bool kZ16 = false>
 __global__ __launch_bounds__(kWave, kScanWaves) void ssm_scan_fwd_kernel(const dimsum_ssm_params_t p) {
     static_assert(!kFull || kVec, "kFull implies kVec");
+    static_assert(!kZ16 || (kFull && kHasZ && !kCkpt && std::is_same<T, float>::value), "the fp16 out_z rides on the full fp32 inference path");
     static_assert(!kDt || (kFull && kHasZ && !kCkpt && std::is_same<T, float>::value), "the fused dt_proj rides on the full fp32 inference path");
     __shared__ __attribute__((aligned(16))) float tileU[kWave * kLdsStride];
     __shared__ __attribute__((aligned(16))) float tileD[kWave * kLdsStride];
@@ -392,7 +399,37 @@ __global__ __launch_bounds__(kWave, kScanWaves) void ssm_scan_fwd_kernel(const d
         }
 
         // ---- epilogue: re-read y in the coalesced layout, gate, store -------------------------------------------
-        if constexpr (kVec) {
+        if constexpr (kZ16) {
+            f32x4 yz[kNP];
+            float mx = 0.f;
+#pragma unroll
+            for (int i = 0; i < kNP; ++i) {
+                yz[i] = *reinterpret_cast<const f32x4 *>(&tileU[tile_off(i * kRPP + lrow, lc4)]);
+                const f32x4 z4 = widen(rz[i]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { yz[i].v[e] *= z4.v[e] * sigmoidf_fast(z4.v[e]); mx = fmaxf(mx, fabsf(yz[i].v[e])); }
+            }
+            float sc, inv;
+            f16s_scales(wave_allmax(mx), sc, inv);
+            if (lane == 0) reinterpret_cast<float *>(p.out_z_scale_ptr)[(int64_t)(((int64_t)b * L + t0) >> 5) * p.out_z_scale_ld + (d0 >> 6)] = inv;
+            __half *z16 = reinterpret_cast<__half *>(p.out_z_ptr) + (int64_t)b * p.out_z_batch_stride + (int64_t)d0 * p.out_z_d_stride + t0;
+            const bool odd = (lane & 1) != 0;
+#pragma unroll
+            for (int i = 0; i < kNP; i += 2) {          // pieces i (even lanes) and i + 1 (odd lanes): 8 steps = 16 bytes per lane
+                unsigned w[2][2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const __half2 a = __floats2half2_rn(yz[i + k].v[0] * sc, yz[i + k].v[1] * sc), c = __floats2half2_rn(yz[i + k].v[2] * sc, yz[i + k].v[3] * sc);
+                    w[k][0] = __builtin_bit_cast(unsigned, a); w[k][1] = __builtin_bit_cast(unsigned, c);
+                }
+                // the neighbour needs: (even lane) the odd lane's piece-i words, (odd lane) the even lane's piece-(i + 1) words
+                const unsigned r0 = __float_as_uint(dpp_mov<0xB1>(__uint_as_float(odd ? w[0][0] : w[1][0])));
+                const unsigned r1 = __float_as_uint(dpp_mov<0xB1>(__uint_as_float(odd ? w[0][1] : w[1][1])));
+                const uint4 v = odd ? make_uint4(r0, r1, w[1][0], w[1][1]) : make_uint4(w[0][0], w[0][1], r0, r1);
+                const int row = (i + (odd ? 1 : 0)) * kRPP + lrow, col = (lc4 & ~1) * 4;
+                *reinterpret_cast<uint4 *>(z16 + (int64_t)row * p.out_z_d_stride + col) = v;
+            }
+        } else if constexpr (kVec) {
             if (t0 + lcol < L) {
 #pragma unroll
                 for (int i = 0; i < kNP; ++i) {
@@ -437,8 +474,10 @@ void ssm_scan_fwd_launch_v0(const dimsum_ssm_params_t &p, hipStream_t stream, in
         else DIMSUM_LAUNCH_EV((ssm_scan_fwd_kernel<T, kN, HASZ, VEC, FULL, false>), grid, block, stream, ev0, ev1, p);          \
     } while (0)
     if constexpr (std::is_same<T, float>::value && kN == 16) {
-        if (p.dt_w_ptr) {       // fused dt_proj (the caller checked: full vector path, z, no saved states)
-            DIMSUM_LAUNCH_EV((ssm_scan_fwd_kernel<T, kN, true, true, true, false, true>), grid, block, stream, ev0, ev1, p);
+        if (p.dt_w_ptr || p.out_z_f16) {       // fused dt_proj / block-scaled fp16 out_z (the caller checked: full vector path, z, no saved states)
+            if (p.dt_w_ptr && p.out_z_f16) DIMSUM_LAUNCH_EV((ssm_scan_fwd_kernel<T, kN, true, true, true, false, true, true>), grid, block, stream, ev0, ev1, p);
+            else if (p.dt_w_ptr) DIMSUM_LAUNCH_EV((ssm_scan_fwd_kernel<T, kN, true, true, true, false, true, false>), grid, block, stream, ev0, ev1, p);
+            else DIMSUM_LAUNCH_EV((ssm_scan_fwd_kernel<T, kN, true, true, true, false, false, true>), grid, block, stream, ev0, ev1, p);
             return;
         }
     }

@@ -122,6 +122,39 @@ def out_proj_planes(planes, weight):
     return native.gemm_tn(planes, wt, alias_rows=D)
 
 
+def out_proj_f16_enabled(xz, weight, rows, seqlen, scan_kernel=1):
+    """whether MambaInnerFn's out_proj runs as ONE fp16 product per element over the scan's block-scaled fp16 out_z (inference under the
+    scaled-fp16 policy; native.selective_scan_fwd(out_z_f16=True) + native.gemm_tn(scales, rebase)): the 64-channel scan kernel only
+    (scan_kernel == 1), whole 32-step tiles, the TN GEMM's shapes. DIMSUM_OUT_PROJ_F16=0 hands out_proj back to the library's fp32 GEMM."""
+    import os
+    D = weight.shape[1]
+    return (_policy == "f16s" and scan_kernel == 1 and os.environ.get("DIMSUM_OUT_PROJ_F16", "1") != "0" and torch.backends.cuda.matmul.allow_tf32
+            and os.environ.get("DIMSUM_SPLIT3", "1") != "0" and own_gemm_enabled() and xz.is_cuda and xz.dtype == torch.float32
+            and weight.dtype == torch.float32 and weight.stride(1) == 1 and rows % 256 == 0 and seqlen % 32 == 0 and weight.shape[0] % 256 == 0
+            and D % 64 == 0 and D >= 128 and 128 * rows + 512 < 2 ** 31 and xz.data_ptr() % 16 == 0
+            and all(st % 4 == 0 for st in xz.stride()[:-1]) and xz.stride(-1) == 1 and rows >= int(os.environ.get("DIMSUM_SPLIT3_MIN_ROWS", "8192")))
+
+
+def weight_f16s_t(weight):
+    """weight (N, K) float32 -> (image^T (K, N) float16, inv (N,)): the scaled-fp16 rows of the weight as the right operand of a TN product
+    (columns carry the scales)"""
+    def make():
+        img = weight_f16s(weight)
+        return img.data.t().contiguous(), img.inv
+    return _cached("w16t", weight, make)
+
+
+def out_proj_f16(image, inv, weight):
+    """image (D, M) float16, inv (M / 32, D / 64) float32: the scan's block-scaled out_z (include/dimsum_hip.h, out_z_f16); weight (N, D)
+    -> out_z^T weight^T (M, N) float32, one fp16 product per element. A 32-token group goes onto ONE scale (its largest block's) inside
+    the GEMM: the blocks are multiplied by exact powers of two <= 1 as they are read (a value more than 2^29 below its group's maximum
+    loses bits there: 2^-40 of the maximum)."""
+    from . import native
+    wt, w_inv = weight_f16s_t(weight)
+    top = inv.amax(1, keepdim=True)
+    return native.gemm_tn(image, wt, scales=(top.expand(-1, 32).reshape(-1), w_inv), rebase=(inv / top).to(torch.float16))
+
+
 def set_policy(policy):
     global _policy
     if policy not in ("default", "fp16", "f16s"):

@@ -135,12 +135,20 @@ def scan_dt_proj_supported(u, z, A, dt_w, dt_xt, n_groups=1):
             and z.data_ptr() % 16 == 0 and scan_fwd_kernel_for(batch, dim, seqlen, A.shape[1], n_groups) == 1)
 
 
-def selective_scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus, need_out=True, need_x=True, need_ckpt=False, out_z_planes=False, dt_proj=None):
+def scan_out_z_f16_supported(u, z, A, n_groups):
+    """whether selective_scan_fwd(out_z_f16=True) is served: the 64-channel kernel's full fp32 inference path on whole 32-step tiles"""
+    return (z is not None and u.dtype == torch.float32 and z.dtype == torch.float32 and A.shape[1] == 16 and not A.is_complex() and n_groups == 1
+            and u.shape[1] % 64 == 0 and u.shape[2] % 32 == 0 and u.numel() > 0)
+
+
+def selective_scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus, need_out=True, need_x=True, need_ckpt=False, out_z_planes=False, dt_proj=None, out_z_f16=False):
     """-> [out, x, (out_z)]   exactly like selective_scan_cuda.fwd.
     `need_out=False` / `need_x=False` are inference extras: the corresponding store is skipped and None returned.
     `need_ckpt=True` (training extra) appends the tile-boundary states the backward kernel consumes.
     `out_z_planes=True` (inference extra, float32): out_z comes back as its split-bf16 pair of d-major planes, a (2 dim, batch seqlen)
-    bfloat16 matrix [hi; lo] -- the operand image of out_proj's GEMM (gemm_tn(..., alias_rows=dim)), the same 4 bytes per element."""
+    bfloat16 matrix [hi; lo] -- the operand image of out_proj's GEMM (gemm_tn(..., alias_rows=dim)), the same 4 bytes per element.
+    `out_z_f16=True` (inference extra, see scan_out_z_f16_supported): out_z comes back as (image, inv): a (dim, batch seqlen) float16 matrix of
+    block-scaled values and the (batch seqlen / 32, dim / 64) float32 table of the blocks' inverse scales (include/dimsum_hip.h, out_z_f16)."""
     if dt_proj is not None:
         # fused dt_proj (inference extra): delta = dt_w @ dt_xt is formed inside the scan (scan_dt_proj_supported); `delta` only lends its layout
         dt_w, dt_xt = dt_proj
@@ -154,8 +162,13 @@ def selective_scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus, need
     n_chunks = (seqlen + 2047) // 2048
     out = torch.empty_like(delta) if need_out else None          # HBL layout like delta (selective_scan.cpp:310-311)
     x = torch.empty((batch, dim, n_chunks, dstate * 2), device=u.device, dtype=torch.float32) if need_x else None
-    planes = None
-    if out_z_planes:
+    planes = z16 = None
+    if out_z_f16:
+        _check(not out_z_planes and not need_ckpt and not need_out and scan_out_z_f16_supported(u, z, A, B.shape[1]),
+               "selective_scan_fwd: out_z_f16 needs no saved states, no `out`, no planes and a shape scan_out_z_f16_supported takes")
+        z16 = (torch.empty((dim, batch * seqlen), device=u.device, dtype=torch.float16), torch.empty((batch * seqlen // 32, dim // 64), device=u.device, dtype=torch.float32))
+        out_z = z16[0].view(dim, batch, seqlen).permute(1, 0, 2)
+    elif out_z_planes:
         _check(z is not None and u.dtype == torch.float32 and seqlen % 8 == 0, "selective_scan_fwd: out_z_planes needs z, float32 I/O and seqlen % 8 == 0")
         planes = torch.empty((2 * dim, batch * seqlen), device=u.device, dtype=torch.bfloat16)
         out_z = planes[:dim].view(dim, batch, seqlen).permute(1, 0, 2)           # the hi plane as a (batch, dim, seqlen) view
@@ -167,6 +180,8 @@ def selective_scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus, need
         _fill_ssm(P, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, x, out_z, ckpt)
         if planes is not None:
             P.out_z_lo_offset = dim * batch * seqlen
+        if z16 is not None:
+            P.out_z_f16, P.out_z_scale_ptr, P.out_z_scale_ld = 1, _ptr(z16[1]), z16[1].stride(0)
         if dt_proj is not None:
             P.delta_ptr = None
             P.dt_w_ptr, P.dt_x_ptr, P.dt_w_row_stride, P.dt_x_row_stride, P.dt_rank = _ptr(dt_w), _ptr(dt_xt), dt_w.stride(0), dt_xt.stride(0), dt_w.shape[1]
@@ -174,7 +189,7 @@ def selective_scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus, need
             _lib.check(_lib.load().dimsum_ssm_scan_fwd(P, _stream(u)), "selective_scan_fwd")
     res = [out, x]
     if z is not None:
-        res.append(out_z if planes is None else planes)
+        res.append(z16 if z16 is not None else out_z if planes is None else planes)
     if need_ckpt:
         res.append(ckpt)
     return res

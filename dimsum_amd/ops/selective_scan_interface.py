@@ -164,9 +164,17 @@ class _MambaInner(torch.autograd.Function):
         planes = (has_out_proj and not need and out_proj_bias is None and L % 8 == 0
                   and d_inner % 64 == 0 and xz.is_cuda
                   and gemm.out_proj_planes_enabled(xz, out_proj_weight, bsz * L, native.scan_fwd_kernel_for(bsz, d_inner, L, N, Bm.shape[1])))
+        # inference under the scaled-fp16 policy on the 64-channel kernel: out_z leaves the scan as block-scaled fp16 (half the bytes) and
+        # out_proj is ONE fp16 product per element on the hand-written TN GEMM (gemm.out_proj_f16) instead of the library's fp32 GEMM
+        z16 = (has_out_proj and not keep and not planes and out_proj_bias is None and xz.is_cuda and not torch.is_autocast_enabled("cuda")
+               and native.scan_out_z_f16_supported(conv_out, z, A, Bm.shape[1])
+               and gemm.out_proj_f16_enabled(xz, out_proj_weight, bsz * L, L, native.scan_fwd_kernel_for(bsz, d_inner, L, N, Bm.shape[1])))
         out, scan_x, out_z, *rest = native.selective_scan_fwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus,
                                                               need_out=keep, need_x=keep, need_ckpt=need, **({"out_z_planes": True} if planes else {}),
+                                                              **({"out_z_f16": True} if z16 else {}),
                                                               **({"dt_proj": (delta_proj_weight, x_dbl_t[:R])} if delta is None else {}))
+        if z16:
+            return gemm.out_proj_f16(out_z[0], out_z[1], out_proj_weight).view(bsz, L, out_proj_weight.shape[0])
         if planes:
             return gemm.out_proj_planes(out_z, out_proj_weight).view(bsz, L, out_proj_weight.shape[0])
         ckpt = rest[0] if need else None

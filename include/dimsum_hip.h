@@ -114,7 +114,15 @@ typedef struct {
     const void *dt_x_ptr;     /* (dt_rank, batch * seqlen) f32: the first dt_rank rows of x_proj's output written r-major (x_proj.weight @ conv_out
                                  as a (R + 2N, batch seqlen) matrix, the layout whose B / C rows the scan reads without a transposing copy) */
     int64_t dt_w_row_stride, dt_x_row_stride;     /* in elements; dt_w_row_stride % 4 == 0 */
-    int32_t dt_rank, reserved3;
+    int32_t dt_rank;
+    /* Block-scaled fp16 out_z (forward, inference, float32 I/O; same kernel path as dt_w_ptr): out_z_f16 != 0 -> out_z_ptr is a float16 buffer
+     * (out_z_*_stride in float16 elements, rows 16-byte aligned, seqlen % 32 == 0): the 64 channels x 32 steps a wave finishes at a time are
+     * stored as fp16(out_z * 2^s) with 2^-s (f32) at out_z_scale_ptr[((b * seqlen + t) / 32) * out_z_scale_ld + d / 64] -- the A operand of
+     * out_proj as ONE fp16 product per element (dimsum_gemm_tn with a_rebase_ptr): the reference multiplies out_z under TF32
+     * (selective_scan_interface.py:954-981 under train.py:20-21), i.e. with 10-bit mantissas. */
+    int32_t out_z_f16;
+    void *out_z_scale_ptr;
+    int64_t out_z_scale_ld;
 } dimsum_ssm_params_t;
 
 typedef struct {

@@ -411,3 +411,52 @@ def test_forward_scope_changes_launch_counts_not_bits(monkeypatch):
             assert torch.equal(m(x, t, y), ref)
     finally:
         gemm.set_policy("default")
+
+
+@pytest.mark.parametrize("B,L,d_model,d_inner", [(4, 256, 256, 512), (2, 1024, 512, 1024)])
+def test_mamba_inner_out_proj_as_one_fp16_product_vs_tf32(B, L, d_model, d_inner, monkeypatch):
+    """MambaInnerFn's inference forward under the scaled-fp16 policy with out_proj on the scan's block-scaled fp16 out_z (gemm.out_proj_f16:
+    selective_scan_fwd(out_z_f16) + gemm_tn(scales, rebase)) against the same call with out_proj on the library's fp32 GEMM
+    (DIMSUM_OUT_PROJ_F16=0) and against the float64 product of the fp32 kernel's out_z: no further from it than 1.1 x what rounding both
+    operands to TF32 costs (the reference's arithmetic for this Linear, selective_scan_interface.py:954-981 under train.py:20-21)"""
+    from dimsum_amd import gemm, native
+    from dimsum_amd.ops import selective_scan_interface as ssi
+    g = torch.Generator().manual_seed(L + d_inner)
+    N, R = 16, 32
+    dev = "cuda"
+    r = lambda *s, k=1.0: (torch.randn(*s, generator=g) * k).to(dev)
+    xz = r(B, 2 * d_inner, L)
+    xz[:, d_inner:, : L // 2] *= 30.0                                  # token groups of very different magnitude
+    conv_w, conv_b = r(d_inner, 1, 4, k=0.5), r(d_inner, k=0.1)
+    x_w, dt_w, out_w = r(R + 2 * N, d_inner, k=d_inner ** -0.5), r(d_inner, R, k=R ** -0.5), r(d_model, d_inner, k=d_inner ** -0.5)
+    A = (-0.5 * torch.rand(d_inner, N, generator=g) - 0.05).to(dev)
+    Dv, dt_b = r(d_inner), (0.5 * torch.rand(d_inner, generator=g)).to(dev)
+    monkeypatch.setenv("DIMSUM_SPLIT3_MIN_ROWS", "256")
+    old_tf32, old_policy, old_var = torch.backends.cuda.matmul.allow_tf32, gemm.get_policy(), native._scan_fwd_variant
+    torch.backends.cuda.matmul.allow_tf32 = True
+    gemm.set_policy("f16s")
+    native._scan_fwd_variant = 1
+    try:
+        with torch.no_grad():
+            run = lambda: ssi.mamba_inner_fn(xz, conv_w, conv_b, x_w, dt_w, out_w, None, A, None, None, Dv, dt_b, delta_softplus=True)
+            calls = []
+            real = native.gemm_tn
+            monkeypatch.setattr(native, "gemm_tn", lambda *a, **k: (calls.append(k), real(*a, **k))[1])
+            got = run()
+            assert len(calls) == 1 and calls[0].get("rebase") is not None, "out_proj did not take the fp16 path"
+            monkeypatch.setenv("DIMSUM_OUT_PROJ_F16", "0")
+            lib = run()
+            assert len(calls) == 1
+            out_z = ssi.mamba_inner_fn_no_out_proj(xz, conv_w, conv_b, x_w, dt_w, A, None, None, Dv, dt_b, delta_softplus=True)     # (B, d_inner, L) fp32
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = old_tf32
+        gemm.set_policy(old_policy)
+        native._scan_fwd_variant = old_var
+    a = out_z.transpose(1, 2).reshape(B * L, d_inner)
+    exact = (a.double() @ out_w.double().t()).view(B, L, d_model)
+    tf = lambda t: ((t.view(torch.int32) + 0x1000) & ~0x1FFF).view(torch.float32)
+    tf32 = (tf(a.contiguous()).double() @ tf(out_w).double().t()).view(B, L, d_model)
+    e16, e32 = (got.double() - exact), (tf32 - exact)
+    assert e16.abs().max() <= 1.1 * e32.abs().max() and e16.pow(2).mean().sqrt() <= 1.1 * e32.pow(2).mean().sqrt(), \
+        (e16.abs().max().item(), e32.abs().max().item(), e16.pow(2).mean().sqrt().item(), e32.pow(2).mean().sqrt().item())
+    assert (lib.double() - exact).abs().max() <= 1.1 * e32.abs().max()

@@ -434,3 +434,52 @@ def test_fused_dt_proj_matches_the_scan_fed_with_the_gemm_result(B, D, L, R):
     # what the kernel does not take is refused up front, not computed wrongly
     assert not native.scan_dt_proj_supported(cu(u), cu(z), cu(A), cu(torch.randn(D, 36)), cu(torch.randn(36, B * L)))          # dt_rank > 32
     assert not native.scan_dt_proj_supported(cu(u)[:, :D - 32], cu(z)[:, :D - 32], cu(A)[:D - 32], cu(w)[:D - 32], cu(xt)) or (D - 32) % 64 == 0
+
+
+@pytest.mark.parametrize("B,D,L,fused", [(2, 128, 256, False), (3, 192, 96, True), (1, 64, 32, False), (2, 256, 1024, True)])
+def test_block_scaled_fp16_out_z_decodes_to_the_fp32_out_z(B, D, L, fused):
+    """dimsum_ssm_params_t.out_z_f16 (inference extra, kZ16): every 64-channel x 32-step block of out_z as fp16(value 2^s) with 2^-s in the
+    table: decoded, it is the fp32 kernel's out_z to half an fp16 ulp of the block's own maximum (2^-11 relative to at most 2 x the maximum),
+    the scales are exact powers of two that put the block maximum in [2^14, 2^15]; with and without the fused dt_proj; blocks of very
+    different magnitudes (z = 0 on one block: an all-zero block decodes to zeros)"""
+    from dimsum_amd import native
+    g = torch.Generator().manual_seed(B * L + D)
+    N, R = 16, 16
+    u, z = torch.randn(B, D, L, generator=g), torch.randn(B, D, L, generator=g)
+    z[0, :64, :32] = 0.0
+    z[-1, -64:, -32:] *= 1e-12
+    u[0, :64, 32 * (L > 32):] *= 1e6
+    A = -0.5 * torch.rand(D, N, generator=g) - 0.05
+    Bm, Cm = torch.randn(B, 1, N, L, generator=g), torch.randn(B, 1, N, L, generator=g)
+    Dv, bias = torch.randn(D, generator=g), 0.5 * torch.rand(D, generator=g)
+    w = torch.randn(D, R, generator=g) * R ** -0.5
+    xt = torch.randn(R, B * L, generator=g)
+    delta = (w.double() @ xt.double()).float().view(D, B, L).permute(1, 0, 2).contiguous()
+    cu = lambda t: t.cuda()
+    old = native._scan_fwd_variant
+    native._scan_fwd_variant = 1
+    try:
+        kw = {"dt_proj": (cu(w), cu(xt))} if fused else {}
+        args = (cu(u), None if fused else cu(delta), cu(A), cu(Bm), cu(Cm), cu(Dv), cu(z), cu(bias), True)
+        assert native.scan_out_z_f16_supported(cu(u), cu(z), cu(A), 1)
+        _, _, ref = native.selective_scan_fwd(*args, need_out=False, need_x=False, **kw)
+        _, _, (img, inv) = native.selective_scan_fwd(*args, need_out=False, need_x=False, out_z_f16=True, **kw)
+        _, _, (img2, inv2) = native.selective_scan_fwd(*args, need_out=False, need_x=False, out_z_f16=True, **kw)
+    finally:
+        native._scan_fwd_variant = old
+    assert torch.equal(img, img2) and torch.equal(inv, inv2)
+    assert img.shape == (D, B * L) and img.dtype == torch.float16 and inv.shape == (B * L // 32, D // 64)
+    m, e = torch.frexp(inv)
+    assert torch.all(m == 0.5), "the block scales are powers of two"
+    blocks = lambda t: t.reshape(D // 64, 64, B * L // 32, 32).permute(2, 0, 1, 3)                # (token group, channel block, 64, 32)
+    dec = blocks(img.float()) * inv[:, :, None, None]
+    want = blocks(ref.permute(1, 0, 2).reshape(D, B * L))
+    bmax = want.abs().amax((2, 3))
+    err = (dec - want).abs().amax((2, 3))
+    assert torch.all(err <= 2.0 ** -10 * bmax), (err / bmax.clamp_min(1e-30)).max().item()
+    top = blocks(img.float()).abs().amax((2, 3))
+    live = bmax > 1e-30
+    assert torch.all(top[live] >= 2.0 ** 13) and torch.all(top <= 2.0 ** 15)
+    assert torch.all(dec[0, 0] == 0)
+    # refused up front where the kernel does not take it
+    assert not native.scan_out_z_f16_supported(cu(u)[:, :, :L - 4], cu(z)[:, :, :L - 4], cu(A), 1)
