@@ -93,7 +93,7 @@ class GemmParams(C.Structure):
                 + [(n, vp) for n in ("a_ptr", "b_ptr", "bias_ptr", "c_ptr", "timing_start_event", "timing_stop_event")]
                 + [(n, i32) for n in ("tune_variant", "tune_group_m", "tune_reserved")]
                 + [(n, vp) for n in ("a_inv_scale_ptr", "b_inv_scale_ptr", "gate_bound_ptr", "h_inv_scale_ptr", "residual_ptr", "gate_ptr")]
-                + [("residual_ld", i64), ("gate_ld", i64), ("rows_per_batch", i32), ("c_image_pieces", i32), ("x12_ptr", vp), ("x12_ld", i64), ("a_alias_rows", i64), ("b_alias_rows", i64), ("a_alias_weight_order", i32), ("qkv_q_cols", i32), ("conv_weight_ptr", vp), ("conv_bias_ptr", vp), ("conv_rows", i32), ("conv_width", i32), ("conv_seq", i32), ("conv_weight_ld", i32), ("a_rebase_ptr", vp), ("a_rebase_ld", i64),
+                + [("residual_ld", i64), ("gate_ld", i64), ("rows_per_batch", i32), ("c_image_pieces", i32), ("x12_ptr", vp), ("x12_ld", i64), ("a_alias_rows", i64), ("b_alias_rows", i64), ("a_alias_weight_order", i32), ("qkv_q_cols", i32), ("conv_weight_ptr", vp), ("conv_bias_ptr", vp), ("conv_rows", i32), ("conv_width", i32), ("conv_seq", i32), ("conv_weight_ld", i32), ("a_block_inv_ptr", vp), ("a_block_inv_ld", i64),
                    ("tn_pair_a_cols", i64), ("tn_pair_b_cols", i64)])
 
 

@@ -201,9 +201,9 @@ extern "C" int dimsum_gemm_tn(const dimsum_gemm_params_t *p, int32_t splits, int
     if (!p || !p->a_ptr || !p->b_ptr || !p->c_ptr) return DIMSUM_ERR_NULL;
     if (p->operand_dtype != DIMSUM_F16 && p->operand_dtype != DIMSUM_BF16) return DIMSUM_ERR_DTYPE;
     if (p->epilogue != DIMSUM_GEMM_EPI_F32 || p->bias_ptr) return DIMSUM_ERR_UNSUPPORTED;
-    if ((p->a_inv_scale_ptr == nullptr) != (p->b_inv_scale_ptr == nullptr)) return DIMSUM_ERR_NULL;
-    if ((p->a_inv_scale_ptr || p->a_rebase_ptr) && (p->operand_dtype != DIMSUM_F16 || splits != 1 || p->tn_pair_a_cols != 0 || p->a_alias_rows != 0)) return DIMSUM_ERR_UNSUPPORTED;
-    if (p->a_rebase_ptr && (!p->a_inv_scale_ptr || p->a_rebase_ld < p->k / kBK)) return DIMSUM_ERR_SHAPE;
+    if (((p->a_inv_scale_ptr || p->a_block_inv_ptr) == 0) != (p->b_inv_scale_ptr == nullptr)) return DIMSUM_ERR_NULL;
+    if ((p->a_inv_scale_ptr || p->a_block_inv_ptr) && (p->operand_dtype != DIMSUM_F16 || splits != 1 || p->tn_pair_a_cols != 0 || p->a_alias_rows != 0)) return DIMSUM_ERR_UNSUPPORTED;
+    if (p->a_block_inv_ptr && (p->a_inv_scale_ptr || p->a_block_inv_ld < p->k / kBK || p->k > 64 * kBK)) return DIMSUM_ERR_SHAPE;
     if (p->b_inv_scale_ptr && !aligned_to<char>(p->b_inv_scale_ptr, 16)) return DIMSUM_ERR_STRIDE;
     const int row_splits = (p->tn_pair_a_cols != 0) ? splits / 3 : splits;       // (pairs: the three pieces share the row ranges)
     if (splits < 1 || row_splits < 1 || p->m <= 0 || p->n <= 0 || p->m % kBM != 0 || p->n % kBN != 0 || p->k % ((int64_t)row_splits * kBK) != 0 ||
@@ -243,8 +243,8 @@ extern "C" int dimsum_gemm_tn(const dimsum_gemm_params_t *p, int32_t splits, int
     a.out_scale = 1.0f;
     a.sa = reinterpret_cast<const float *>(p->a_inv_scale_ptr);
     a.sb = reinterpret_cast<const float *>(p->b_inv_scale_ptr);
-    a.a_rebase = reinterpret_cast<const _Float16 *>(p->a_rebase_ptr);
-    a.a_rebase_ld = (int)p->a_rebase_ld;
+    a.a_block_inv = reinterpret_cast<const float *>(p->a_block_inv_ptr);
+    a.a_block_inv_ld = (int)p->a_block_inv_ld;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t e0 = reinterpret_cast<hipEvent_t>(p->timing_start_event), e1 = reinterpret_cast<hipEvent_t>(p->timing_stop_event);
     constexpr int kShipT = kVarFullLineStores | kVarNtStores | kVarTN;
@@ -252,7 +252,7 @@ extern "C" int dimsum_gemm_tn(const dimsum_gemm_params_t *p, int32_t splits, int
     if (p->operand_dtype == DIMSUM_BF16) {
         if (e0 || e1) hipExtLaunchKernelGGL((gemm_nt_kernel<kOpBf16, kEpiF32, kShipT>), grid, block, 0, s, e0, e1, 0, a);
         else hipLaunchKernelGGL((gemm_nt_kernel<kOpBf16, kEpiF32, kShipT>), grid, block, 0, s, a);
-    } else if (a.a_rebase) {
+    } else if (a.a_block_inv) {
         if (e0 || e1) hipExtLaunchKernelGGL((gemm_nt_kernel<kOpF16, kEpiF32, kShipT | kVarRebase>), grid, block, 0, s, e0, e1, 0, a);
         else hipLaunchKernelGGL((gemm_nt_kernel<kOpF16, kEpiF32, kShipT | kVarRebase>), grid, block, 0, s, a);
     } else {

@@ -86,8 +86,8 @@ struct Args {
     int b_alias_tiles;             // the same for the B rows (NT only: in_proj, whose activation image is the right operand)
     const float *conv_w, *conv_b;  // kEpiF32Conv: (conv_rows, conv_width) taps (row stride conv_w_ld), (conv_rows) bias or NULL
     int conv_rows, conv_width, conv_seq, conv_w_ld;     //   output rows [0, conv_rows) get conv + SiLU along the columns, sequences of conv_seq columns (256 % conv_seq == 0)
-    const _Float16 *a_rebase;      // kVarRebase (TN, fp16): (M / 32, a_rebase_ld >= K / 64) powers of two <= 1: the A values of token group g = m / 32 in K tile kt were stored with
-    int a_rebase_ld;               //   their own scale; multiplying them by a_rebase[g][kt] puts the whole row group on ONE scale (undone by sa[m] in the epilogue)
+    const float *a_block_inv;      // kVarRebase (TN, fp16): (M / 32, a_block_inv_ld >= K / 64) inverse scales (powers of two): the A values of token group g = m / 32 in K tile kt were
+    int a_block_inv_ld;            //   stored with their own scale 1 / a_block_inv[g][kt]; the kernel puts a group on ONE scale (the largest inverse of its row of the table, K <= 4096)
     int q_cols;                    // kEpiF16Qkv: columns [0, q_cols) take the per-row scale, the others the per-batch-element one
     int c_pieces2;                 // kEpiGatedSplit3: the h image is written as the pair [hi | lo] (ldc >= 2 F) for a consumer that reads it with a_alias_tiles
 };
@@ -354,10 +354,23 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
     // unless the value drops below fp16's normal range, i.e. below 2^-29 of its row group's maximum. 32 v_pk_mul_f16 per fragment set, under the MFMAs.
     constexpr bool kRebase = (kVar & kVarRebase) != 0;
     static_assert(!kRebase || (kTN && kOp == kOpF16), "the rebase serves the fp16 TN variant");
+    // The factors: a wave owns 4 token groups (2 per 128-row half); lane t of rb[q] holds group q's factor for K tile t = table[g][t] / top[q], with
+    // top[q] = the row's maximum (one load + one wave maximum per group, before the main loop) -- the per-tile factor is then a v_readlane, no memory
+    // operation inside the loop (scalar loads would share lgkmcnt with the counted ds_read waits). top[q] is the epilogue's row scale.
+    float rb[4] = {1.f, 1.f, 1.f, 1.f}, top[4] = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (kRebase) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int g = (m0 + (q >> 1) * 128 + wr * 64 + (q & 1) * 32) >> 5;
+            const float v = lane < p.K / kBK ? p.a_block_inv[(int64_t)g * p.a_block_inv_ld + lane] : 0.f;
+            top[q] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wave_allmax(v))));
+            rb[q] = v * __builtin_amdgcn_rcpf(top[q]);                          // (powers of two: exact)
+        }
+    }
     auto rebase = [&](u32x4 (&frag)[4][2], int mi, int kt_) {
         if constexpr (kRebase) {
-            const int g0 = (m0 + mi * 128 + wr * 64) >> 5;
-            const _Float16 f0 = p.a_rebase[(int64_t)g0 * p.a_rebase_ld + kt_], f1 = p.a_rebase[(int64_t)(g0 + 1) * p.a_rebase_ld + kt_];
+            const _Float16 f0 = (_Float16)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rb[mi * 2]), kt_));
+            const _Float16 f1 = (_Float16)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rb[mi * 2 + 1]), kt_));
             // (the fragments are outputs of asynchronous ds_read asm statements: the empty asm pins every one of them to its registers HERE, after the
             // phase's lgkmcnt(0), so that whatever copies the multiplies need are made of landed data -- without it the compiler copied the asm outputs
             // right behind the reads, before the wait)
@@ -642,7 +655,10 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
                         }
                         const int lrow = frow + mi * kMiRows + i * 16;
                         const unsigned voff = (unsigned)((lrow * p.ldc + col) * 4);
-                        if (p.sa) {             // scaled-fp16 operands: exact powers of two
+                        if constexpr (kRebase) {
+                            s0 = s0 * (sbv * top[mi * 2 + (i >> 1)]);
+                            s1 = s1 * (sbv * top[mi * 2 + (i >> 1)]);
+                        } else if (p.sa) {      // scaled-fp16 operands: exact powers of two
                             s0 = s0 * (sbv * p.sa[m0 + lrow]);
                             s1 = s1 * (sbv * p.sa[m0 + lrow + 8]);
                         }

@@ -124,7 +124,7 @@ def out_proj_planes(planes, weight):
 
 def out_proj_f16_enabled(xz, weight, rows, seqlen, scan_kernel=1):
     """whether MambaInnerFn's out_proj runs as ONE fp16 product per element over the scan's block-scaled fp16 out_z (inference under the
-    scaled-fp16 policy; native.selective_scan_fwd(out_z_f16=True) + native.gemm_tn(scales, rebase)): the 64-channel scan kernel only
+    scaled-fp16 policy; native.selective_scan_fwd(out_z_f16=True) + native.gemm_tn(scales = (table, ..))): the 64-channel scan kernel only
     (scan_kernel == 1), whole 32-step tiles, the TN GEMM's shapes. DIMSUM_OUT_PROJ_F16=0 hands out_proj back to the library's fp32 GEMM."""
     import os
     D = weight.shape[1]
@@ -151,8 +151,7 @@ def out_proj_f16(image, inv, weight):
     loses bits there: 2^-40 of the maximum)."""
     from . import native
     wt, w_inv = weight_f16s_t(weight)
-    top = inv.amax(1, keepdim=True)
-    return native.gemm_tn(image, wt, scales=(top.expand(-1, 32).reshape(-1), w_inv), rebase=(inv / top).to(torch.float16))
+    return native.gemm_tn(image, wt, scales=(inv, w_inv))
 
 
 def set_policy(policy):

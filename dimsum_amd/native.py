@@ -736,20 +736,27 @@ def gemm_tn_pairs(a, b, splits=None):
     return out.sum(0)
 
 
-def gemm_tn(a, b, splits=None, events=None, alias_rows=0, scales=None, rebase=None):
+def gemm_tn(a, b, splits=None, events=None, alias_rows=0, scales=None):
     """a (R, P)^T @ b (R, Q) -> (P, Q) float32 on the hand-written MFMA kernel's TN variant: the weight-gradient product of a Linear
     (reduction over the rows). The reduction is cut into `splits` ranges whose partial results are added in a fixed order.
     alias_rows = D: a is a (2 D, P) pair of planes [hi; lo] read as the row stack [hi; hi; lo] (b: (3 D, Q)); one range.
-    scales = (a_inv (P,), b_inv (Q,)) [, rebase (P / 32, R / 64) float16]: float16 operands carrying power-of-two scales (one range): the result is
-    multiplied by a_inv[p] b_inv[q]; with `rebase` a's values of tokens [32 g, 32 g + 32) x reduction rows [64 t, 64 t + 64) are multiplied by
-    rebase[g][t] as they are read (the scan's block-scaled fp16 out_z: out_proj of a Mamba mixer as ONE fp16 product per element)."""
+    scales = (a_inv, b_inv (Q,)): float16 operands carrying power-of-two scales (one range): a_inv (P,) -> the result is multiplied by
+    a_inv[p] b_inv[q]; a_inv (P / 32, R / 64) -> block-scaled a (the scan's fp16 out_z with its table, selective_scan_fwd(out_z_f16=True)):
+    the values of tokens [32 g, 32 g + 32) x reduction rows [64 t, 64 t + 64) stand for value * a_inv[g][t]; R <= 4096 (out_proj of a
+    Mamba mixer as ONE fp16 product per element)."""
     _gpu(a, b)
+    blocks = None
     if scales is not None:
-        _gpu(*scales, rebase)
-        _check(a.dtype == torch.float16 and not alias_rows and scales[0].dtype == torch.float32 and scales[1].dtype == torch.float32 and scales[0].numel() == a.shape[1]
-               and scales[1].numel() == b.shape[1] and scales[0].is_contiguous() and scales[1].is_contiguous(), "gemm_tn: scales = (a_inv (P,), b_inv (Q,)) float32 with float16 operands")
-        _check(rebase is None or (rebase.dtype == torch.float16 and rebase.dim() == 2 and rebase.shape[0] == a.shape[1] // 32 and rebase.shape[1] >= a.shape[0] // 64
-                                  and rebase.stride(1) == 1), "gemm_tn: rebase must be (P / 32, R / 64) float16")
+        _gpu(*scales)
+        sa, sb = scales
+        _check(a.dtype == torch.float16 and not alias_rows and sa.dtype == torch.float32 and sb.dtype == torch.float32 and sb.numel() == b.shape[1] and sb.is_contiguous(),
+               "gemm_tn: scales = (a_inv, b_inv (Q,)) float32 with float16 operands")
+        if sa.dim() == 2:
+            _check(sa.shape[0] == a.shape[1] // 32 and sa.shape[1] >= a.shape[0] // 64 and sa.stride(1) == 1 and a.shape[0] <= 4096 and a.shape[1] % 32 == 0,
+                   "gemm_tn: a block table must be (P / 32, R / 64) float32, R <= 4096")
+            blocks = sa
+        else:
+            _check(sa.numel() == a.shape[1] and sa.is_contiguous(), "gemm_tn: a_inv must be (P,)")
         splits = 1
     if alias_rows:
         _check(a.dim() == 2 and a.shape[0] == 2 * alias_rows and b.shape[0] == 3 * alias_rows and alias_rows % 64 == 0 and gemm_tn_supported(a[:alias_rows], b[:alias_rows]),
@@ -773,9 +780,11 @@ def gemm_tn(a, b, splits=None, events=None, alias_rows=0, scales=None, rebase=No
     G.a_ptr, G.b_ptr, G.c_ptr = _ptr(a), _ptr(b), _ptr(out)
     G.a_alias_rows = alias_rows
     if scales is not None:
-        G.a_inv_scale_ptr, G.b_inv_scale_ptr = _ptr(scales[0]), _ptr(scales[1])
-        if rebase is not None:
-            G.a_rebase_ptr, G.a_rebase_ld = _ptr(rebase), rebase.stride(0)
+        G.b_inv_scale_ptr = _ptr(scales[1])
+        if blocks is not None:
+            G.a_block_inv_ptr, G.a_block_inv_ld = _ptr(blocks), blocks.stride(0)
+        else:
+            G.a_inv_scale_ptr = _ptr(scales[0])
     if events is not None:
         G.timing_start_event, G.timing_stop_event = events
     with torch.cuda.device(a.device):

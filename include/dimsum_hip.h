@@ -118,7 +118,7 @@ typedef struct {
     /* Block-scaled fp16 out_z (forward, inference, float32 I/O; same kernel path as dt_w_ptr): out_z_f16 != 0 -> out_z_ptr is a float16 buffer
      * (out_z_*_stride in float16 elements, rows 16-byte aligned, seqlen % 32 == 0): the 64 channels x 32 steps a wave finishes at a time are
      * stored as fp16(out_z * 2^s) with 2^-s (f32) at out_z_scale_ptr[((b * seqlen + t) / 32) * out_z_scale_ld + d / 64] -- the A operand of
-     * out_proj as ONE fp16 product per element (dimsum_gemm_tn with a_rebase_ptr): the reference multiplies out_z under TF32
+     * out_proj as ONE fp16 product per element (dimsum_gemm_tn with a_block_inv_ptr): the reference multiplies out_z under TF32
      * (selective_scan_interface.py:954-981 under train.py:20-21), i.e. with 10-bit mantissas. */
     int32_t out_z_f16;
     void *out_z_scale_ptr;
@@ -479,11 +479,13 @@ typedef struct {
     int32_t a_alias_weight_order, qkv_q_cols;      /* qkv_q_cols: F16_QKV only (% 16 == 0) */
     const void *conv_weight_ptr, *conv_bias_ptr;   /* F32_CONV only */
     int32_t conv_rows, conv_width, conv_seq, conv_weight_ld;
-    /* dimsum_gemm_tn, float16 operands, splits == 1: block-scaled A (the scan's fp16 out_z, dimsum_ssm_params_t.out_z_f16): a_rebase_ptr is a
-     * (m / 32, a_rebase_ld >= k / 64) float16 table of powers of two <= 1; the A values of tokens [32 g, 32 g + 32) in reduction rows [64 t, 64 t + 64)
-     * are multiplied by a_rebase[g][t] as they are read, which puts a row group on one scale (undone by a_inv_scale_ptr[m]). */
-    const void *a_rebase_ptr;
-    int64_t a_rebase_ld;
+    /* dimsum_gemm_tn, float16 operands, splits == 1, k <= 4096: block-scaled A (the scan's fp16 out_z, dimsum_ssm_params_t.out_z_f16, with its
+     * table as it is): a_block_inv_ptr is a (m / 32, a_block_inv_ld >= k / 64) float32 table of inverse scales (powers of two): the A values of
+     * tokens [32 g, 32 g + 32) in reduction rows [64 t, 64 t + 64) stand for value * a_block_inv[g][t]. The kernel puts a token group on ONE
+     * scale -- its row's largest inverse -- by multiplying the blocks by exact powers of two <= 1 as it reads them, and multiplies the result by
+     * that scale and b_inv_scale_ptr[n]; a_inv_scale_ptr must be NULL. */
+    const void *a_block_inv_ptr;
+    int64_t a_block_inv_ld;
     int64_t tn_pair_a_cols, tn_pair_b_cols;
 } dimsum_gemm_params_t;
 

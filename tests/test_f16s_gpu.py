@@ -416,7 +416,7 @@ def test_forward_scope_changes_launch_counts_not_bits(monkeypatch):
 @pytest.mark.parametrize("B,L,d_model,d_inner", [(4, 256, 256, 512), (2, 1024, 512, 1024)])
 def test_mamba_inner_out_proj_as_one_fp16_product_vs_tf32(B, L, d_model, d_inner, monkeypatch):
     """MambaInnerFn's inference forward under the scaled-fp16 policy with out_proj on the scan's block-scaled fp16 out_z (gemm.out_proj_f16:
-    selective_scan_fwd(out_z_f16) + gemm_tn(scales, rebase)) against the same call with out_proj on the library's fp32 GEMM
+    selective_scan_fwd(out_z_f16) + gemm_tn(scales = (block table, ..))) against the same call with out_proj on the library's fp32 GEMM
     (DIMSUM_OUT_PROJ_F16=0) and against the float64 product of the fp32 kernel's out_z: no further from it than 1.1 x what rounding both
     operands to TF32 costs (the reference's arithmetic for this Linear, selective_scan_interface.py:954-981 under train.py:20-21)"""
     from dimsum_amd import gemm, native
@@ -443,7 +443,7 @@ def test_mamba_inner_out_proj_as_one_fp16_product_vs_tf32(B, L, d_model, d_inner
             real = native.gemm_tn
             monkeypatch.setattr(native, "gemm_tn", lambda *a, **k: (calls.append(k), real(*a, **k))[1])
             got = run()
-            assert len(calls) == 1 and calls[0].get("rebase") is not None, "out_proj did not take the fp16 path"
+            assert len(calls) == 1 and calls[0]["scales"][0].dim() == 2, "out_proj did not take the fp16 path"
             monkeypatch.setenv("DIMSUM_OUT_PROJ_F16", "0")
             lib = run()
             assert len(calls) == 1

@@ -402,7 +402,7 @@ def test_conv_epilogue_is_the_gemm_followed_by_the_conv_kernel(dtype, tune, M, D
 
 @pytest.mark.parametrize("K,M,N", [(128, 256, 256), (1024, 2048, 512), (320, 512, 256)])
 def test_tn_product_of_block_scaled_fp16_rows(K, M, N):
-    """dimsum_gemm_tn with a_rebase_ptr: A (K, M) float16 whose (64-row, 32-column) blocks carry their own power-of-two scales (what the scan's
+    """dimsum_gemm_tn with a_block_inv_ptr: A (K, M) float16 whose (64-row, 32-column) blocks carry their own power-of-two scales (what the scan's
     fp16 out_z is), rebased to one scale per 32-column group as it is read, times a per-column-scaled B (K, N): against the float64 product of
     the decoded operands (exact: every factor is a power of two and nothing leaves fp16's normal range here), and against the float64 product of
     the ORIGINAL fp32 data at the TF32 class (10-bit mantissas); block magnitudes spread over 2^-12 .. 2^12"""
@@ -422,7 +422,7 @@ def test_tn_product_of_block_scaled_fp16_rows(K, M, N):
     rebase = (inv / sa_g[:, None]).half()
     wimg = native.rows_f16s(w)
     b16 = wimg.data.t().contiguous()                                    # (K, N) float16, column n scaled by 2^s_n
-    got = native.gemm_tn(a16, b16, scales=(sa_g.repeat_interleave(32).contiguous(), wimg.inv), rebase=rebase)
+    got = native.gemm_tn(a16, b16, scales=(inv, wimg.inv))
     a_dec = a16.double() * rebase.double().t().repeat_interleave(64, 0).repeat_interleave(32, 1)
     exact = (a_dec.t() @ b16.double()) * sa_g.repeat_interleave(32).double()[:, None] * wimg.inv.double()[None, :]
     row = exact.abs().amax(1, keepdim=True)
@@ -431,4 +431,6 @@ def test_tn_product_of_block_scaled_fp16_rows(K, M, N):
     tf = round_tf32(x).double().t() @ round_tf32(w).double().t()
     e, et = (got.double() - ref).abs() / ref.abs().amax(1, keepdim=True), (tf - ref).abs() / ref.abs().amax(1, keepdim=True)
     assert e.max().item() <= 1.1 * et.max().item() + 1e-6 and e.pow(2).mean().sqrt().item() <= 1.1 * et.pow(2).mean().sqrt().item() + 1e-7, (e.max().item(), et.max().item())
-    assert torch.equal(native.gemm_tn(a16, b16, scales=(sa_g.repeat_interleave(32).contiguous(), wimg.inv), rebase=rebase), got)
+    assert torch.equal(native.gemm_tn(a16, b16, scales=(inv, wimg.inv)), got)
+    with pytest.raises(Exception):
+        native.gemm_tn(a16, b16, scales=(inv[:, :-1].contiguous(), wimg.inv))
