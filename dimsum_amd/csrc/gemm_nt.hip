@@ -65,6 +65,7 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
     // tile order: groups of 4 tile rows; a matrix of few tile rows (in_proj's d-major product: the weight is the left operand) walks whole tile
     // columns, so that every streamed right-operand panel is loaded once (tools/scratch/gm_sweep.py: 187 -> 178 us at 2048 x 65536 x 512)
     a.group_m = p->tune_group_m > 0 ? p->tune_group_m : (a.tiles_m <= 16 ? a.tiles_m : 4);
+    a.stagger = p->tune_reserved > 0 ? p->tune_reserved : 0;
     if ((p->a_inv_scale_ptr == nullptr) != (p->b_inv_scale_ptr == nullptr)) return DIMSUM_ERR_NULL;
     a.sa = reinterpret_cast<const float *>(p->a_inv_scale_ptr);
     a.sb = reinterpret_cast<const float *>(p->b_inv_scale_ptr);

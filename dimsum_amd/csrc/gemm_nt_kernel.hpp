@@ -74,6 +74,7 @@ struct Args {
     int tiles_m, tiles_n;
     float out_scale;               // kEpiGatedF16: h is stored as fp16(h * out_scale)
     int group_m;                   // tile rows per group of the tile order (L2 patch shape)
+    int stagger;                   // > 0: the first-round workgroups on odd CUs start `stagger` x 1024 cycles late (see cu_stagger)
     float *x12;                    // kVarKeepX12 (gated epilogues, training): the bias-free fp32 (M, 2 F) [x1 | x2] is stored as well
     int64_t ldx;
     int splits;                    // kVarTN: the reduction is cut into `splits` ranges of K rows each (K = rows per range)
@@ -107,9 +108,37 @@ template <int kOp> __device__ __forceinline__ f4 mma(const u32x4 &a, const u32x4
     else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
 }
 
+// c ? a : b on the bits, with the mask hidden from the optimiser: a plain select whose `a` is a load is turned into a branch around the load
+// (CodeGenPrepare), and hipcc then waits vmcnt(0) at every later use of anything loaded -- inside a store sequence that drains the queue
+__device__ __forceinline__ unsigned pick_mask(bool c) {
+    unsigned m = c ? 0xffffffffu : 0u;
+    asm volatile("" : "+v"(m));
+    return m;
+}
+__device__ __forceinline__ unsigned pick_mask_lanes(bool c) {          // (a per-lane condition)
+    unsigned m = c ? 0xffffffffu : 0u;
+    asm volatile("" : "+v"(m));
+    return m;
+}
+__device__ __forceinline__ float pick(unsigned m, float a, float b) {
+    return __uint_as_float((__float_as_uint(a) & m) | (__float_as_uint(b) & ~m));
+}
+__device__ __forceinline__ f4 pick(unsigned m, const f4 &a, const f4 &b) {
+    return f4{pick(m, a[0], b[0]), pick(m, a[1], b[1]), pick(m, a[2], b[2]), pick(m, a[3], b[3])};
+}
+
 #define DIMSUM_DS_READ_B128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
 #define DIMSUM_DS_READ_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
 #define DIMSUM_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+// Two workgroups share a CU under kVarM128: while one is in its epilogue the other's LDS-DMA loads go through the same in-order vector-memory
+// path, behind whatever stores are queued there. The epilogue therefore keeps at most DIMSUM_EPI_PACE of its own stores in flight
+// (tools/bench_gemm.py --tiles: unpaced, in_proj 180 -> 214 us); the 8-wave kernel has the CU to itself and does not pace.
+#ifndef DIMSUM_EPI_PACE
+#define DIMSUM_EPI_PACE 0
+#endif
+#define DIMSUM_STR2(x) #x
+#define DIMSUM_STR(x) DIMSUM_STR2(x)
+#define DIMSUM_PACE_STORES() do { if constexpr (kM1 && DIMSUM_EPI_PACE >= 0) asm volatile("s_waitcnt vmcnt(" DIMSUM_STR(DIMSUM_EPI_PACE) ")" ::: "memory"); } while (0)
 #define DIMSUM_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 __device__ __forceinline__ float gelu_tanh_f(float x) {
@@ -571,6 +600,34 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
                 float *Ct = reinterpret_cast<float *>(p.C) + (int64_t)m0 * p.ldc + n0;
                 const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(Ct, 0, 0x7fffffff, 0x00020000);
                 const int W = p.conv_width;
+                // all scale loads before the first store, unconditional (see the plain path below): 8 row scales, 4 column vectors per lane
+                const bool has_s = p.sa != nullptr;
+                const unsigned ms = pick_mask(has_s);
+                const float *sap = has_s ? p.sa + m0 : reinterpret_cast<const float *>(p.A), *sbp = has_s ? p.sb : reinterpret_cast<const float *>(p.B0);
+                float csa[2][4];
+                f4 csb[2][2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        csa[mi][i] = pick(ms, sap[mi * kMiRows + wr * 64 + i * 16 + (lane & 15)], 1.0f);
+                    }
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int col = n0 + ni * 128 + ecol + j * 16;
+                        csb[ni][j] = pick(ms, *reinterpret_cast<const f4 *>(sbp + (col < p.N ? col : 0)), f4{1.f, 1.f, 1.f, 1.f});
+                    }
+                // the taps and the bias of the wave's 16 rows of each half: lane l holds tap l / 16 of row l % 16 (one load per half, before the first
+                // store); the row loop below reads them with v_readlane -- loads inside it would each wait behind the previous row's store
+                float ctap[2], cbia[2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    const int row = m0 + mi * kMiRows + w * (kHalfRows / kNW) + (lane & 15);
+                    ctap[mi] = pick(pick_mask_lanes((lane >> 4) < W), p.conv_w[(int64_t)row * p.conv_w_ld + ((lane >> 4) < W ? (lane >> 4) : 0)], 0.f);
+                    cbia[mi] = pick(pick_mask(p.conv_b != nullptr), (p.conv_b ? p.conv_b : reinterpret_cast<const float *>(p.B0))[row], 0.f);
+                }
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) {
                     if (mi) __syncthreads();                            // the first half's rows have been read
@@ -578,14 +635,11 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
                     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
-                            const int tcol = ni * 128 + ecol + j * 16, col = n0 + tcol;
-                            f4 sbv = f4{1.f, 1.f, 1.f, 1.f};
-                            if (p.sb && col < p.N) sbv = *reinterpret_cast<const f4 *>(p.sb + col);
+                            const int tcol = ni * 128 + ecol + j * 16;
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
                                 const int rl = wr * 64 + i * 16 + (lane & 15);             // row inside the half
-                                f4 x = acc[mi][ni][i][j];
-                                if (p.sa) x = x * (sbv * p.sa[m0 + mi * kMiRows + rl]);
+                                const f4 x = acc[mi][ni][i][j] * (csb[ni][j] * csa[mi][i]);
                                 *reinterpret_cast<f4 *>(lds + rl * 1024 + (((tcol >> 2) ^ (rl & 7)) << 4)) = x;
                             }
                         }
@@ -595,10 +649,11 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
                     for (int it = 0; it < kHalfRows / kNW; ++it) {
                         const int rl = w * (kHalfRows / kNW) + it, row = m0 + mi * kMiRows + rl;
                         const f4 v = *reinterpret_cast<const f4 *>(lds + rl * 1024 + ((lane ^ (rl & 7)) << 4));
-                        float w4[4];                                    // taps right-aligned into 4 slots (w4[3] multiplies x[t]): wave-uniform loads
+                        float w4[4];                                    // taps right-aligned into 4 slots (w4[3] multiplies x[t])
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) w4[k] = (k >= 4 - W) ? p.conv_w[(int64_t)row * p.conv_w_ld + (k - (4 - W))] : 0.f;
-                        const float cbias = p.conv_b ? p.conv_b[row] : 0.f;
+                        for (int k = 0; k < 4; ++k)
+                            w4[k] = (k >= 4 - W) ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ctap[mi]), it + 16 * (k - (4 - W)))) : 0.f;
+                        const float cbias = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cbia[mi]), it));
                         // x[t-1], x[t-2], x[t-3] of the lane's first token: the neighbouring lane's last three, zeros at a sequence start
                         const bool start = ((4 * lane) % p.conv_seq) == 0;
                         // (ds_bpermute: the three wave_shr:1 DPP moves this wants were merged into ONE move of the wrong register by hipcc 7.2 --
@@ -613,6 +668,7 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) y[e] = y[e] * fast_rcp(1.0f + fast_exp(-y[e]));          // SiLU (the conv kernel's sigmoidf_fast)
                         if (n0 + 4 * lane < p.N) store_f4<2>(crsrc, (unsigned)(((mi * kMiRows + rl) * p.ldc + 4 * lane) * 4), y);
+                        DIMSUM_PACE_STORES();
                     }
                 }
                 return;
@@ -628,52 +684,89 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
             const bool up = (lane & 8) != 0;
             const int frow = wr * 64 + (lane & 7);
             const int fcol = wc * 32 + (lane >> 4) * 4 + (up ? 16 : 0);
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
+            // Every load of the epilogue is issued BEFORE the stores it could otherwise queue behind: loads and stores share vmcnt, so a load issued
+            // after a store is waited for with vmcnt(0) -- the round-4 form (two row-scale loads per 16-row step, between the stores) drained
+            // the store queue 16 times per tile, ~2 us each with the matrix pipe idle. The per-column vectors and the 16 row scales are
+            // loaded up front; the residual rows (kEpiF32GateRes) run one group of four 16-row steps ahead of the stores.
+            // (scale loads are unconditional -- without scales they read a valid address and the value is replaced by 1: a branch around a load
+            // makes hipcc wait vmcnt(0) at every later use)
+            const bool has_s = kRebase || p.sa != nullptr;
+            const unsigned ms = pick_mask(has_s);
+            const float *sap = p.sa ? p.sa + m0 : reinterpret_cast<const float *>(p.A), *sbp = has_s ? p.sb : reinterpret_cast<const float *>(p.B0);
+            bool live[2];
+            f4 bv[2], sbv[2], gv[2];
+            auto load_cols = [&](int ni) {                 // (ni = 1's vectors are loaded under group 1, before its stores: 12 registers less at the peak)
                 const int col = ni * 128 + fcol;
-                const bool live = n0 + col < p.N;          // (the lane exchange below runs in every lane: only the stores are predicated)
-                f4 bv = f4{0.f, 0.f, 0.f, 0.f}, sbv = f4{1.f, 1.f, 1.f, 1.f}, gv = sbv;
-                if constexpr (kEpi == kEpiF32Bias) {
-                    if (live) bv = *reinterpret_cast<const f4 *>(p.bias0 + n0 + col);
-                }
+                live[ni] = n0 + col < p.N;                 // (the lane exchange below runs in every lane: only the stores are predicated)
+                const int lc = live[ni] ? n0 + col : 0;    // dead lanes load a valid column (no branch around the loads)
+                bv[ni] = f4{0.f, 0.f, 0.f, 0.f}; sbv[ni] = gv[ni] = f4{1.f, 1.f, 1.f, 1.f};
+                if constexpr (kEpi == kEpiF32Bias) bv[ni] = *reinterpret_cast<const f4 *>(p.bias0 + lc);
                 if constexpr (kEpi == kEpiF32GateRes) {    // the residual tail of a block: out = res + gate * (x W^T + b), one pass less
-                    if (live && p.bias0) bv = *reinterpret_cast<const f4 *>(p.bias0 + n0 + col);
-                    if (live && p.gate) gv = *reinterpret_cast<const f4 *>(p.gate + (int64_t)(m0 / p.rows_per_batch) * p.ldg + n0 + col);
+                    bv[ni] = pick(pick_mask(p.bias0 != nullptr), *reinterpret_cast<const f4 *>((p.bias0 ? p.bias0 : reinterpret_cast<const float *>(p.B0)) + lc), bv[ni]);
+                    gv[ni] = pick(pick_mask(p.gate != nullptr),
+                                  *reinterpret_cast<const f4 *>((p.gate ? p.gate + (int64_t)(m0 / p.rows_per_batch) * p.ldg : reinterpret_cast<const float *>(p.B0)) + lc), gv[ni]);
                 }
-                if (p.sb && live) sbv = *reinterpret_cast<const f4 *>(p.sb + n0 + col);
+                sbv[ni] = pick(ms, *reinterpret_cast<const f4 *>(sbp + lc), sbv[ni]);
+            };
+            load_cols(0);
+            live[1] = n0 + 128 + fcol < p.N;
+            float rs[2][4][2];
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int lrow = frow + mi * kMiRows + i * 16;
+                    if constexpr (kRebase) rs[mi][i][0] = rs[mi][i][1] = top[mi * 2 + (i >> 1)];
+                    else {                                  // scaled-fp16 operands: exact powers of two
+                        rs[mi][i][0] = pick(ms, sap[lrow], 1.0f); rs[mi][i][1] = pick(ms, sap[lrow + 8], 1.0f);
+                    }
+                }
+            f4 rr[2][4][2];                                // kEpiF32GateRes: residual rows of group g = 2 ni + mi in rr[g & 1]
+            auto load_res = [&](int g) {
+                if constexpr (kEpi == kEpiF32GateRes) {
+                    const int ni = g >> 1, mi = g & 1;
+                    const float *rp = p.res + (int64_t)(m0 + frow + mi * kMiRows) * p.ldr + (live[ni] ? n0 + ni * 128 + fcol : 0);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const f4 x0 = acc[mi][ni][i][0], x1 = acc[mi][ni][i][1];
-                        f4 s0, s1;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float r0 = dpp_row_ror8(x0[e]), r1 = dpp_row_ror8(x1[e]);
-                            s0[e] = up ? r1 : x0[e];
-                            s1[e] = up ? x1[e] : r0;
-                        }
-                        const int lrow = frow + mi * kMiRows + i * 16;
-                        const unsigned voff = (unsigned)((lrow * p.ldc + col) * 4);
-                        if constexpr (kRebase) {
-                            s0 = s0 * (sbv * top[mi * 2 + (i >> 1)]);
-                            s1 = s1 * (sbv * top[mi * 2 + (i >> 1)]);
-                        } else if (p.sa) {      // scaled-fp16 operands: exact powers of two
-                            s0 = s0 * (sbv * p.sa[m0 + lrow]);
-                            s1 = s1 * (sbv * p.sa[m0 + lrow + 8]);
-                        }
-                        if constexpr (kEpi == kEpiF32GateRes) {
-                            if (live) {
-                                const float *rp = p.res + (int64_t)(m0 + lrow) * p.ldr + n0 + col;
-                                const f4 r0 = *reinterpret_cast<const f4 *>(rp), r1 = *reinterpret_cast<const f4 *>(rp + 8 * p.ldr);
-                                store_f4<kAux>(rsrc, voff, r0 + gv * (s0 + bv));
-                                store_f4<kAux>(rsrc, voff + (unsigned)(8 * p.ldc * 4), r1 + gv * (s1 + bv));
-                            }
-                        } else if (live) {
-                            store_f4<kAux>(rsrc, voff, s0 + bv);
-                            store_f4<kAux>(rsrc, voff + (unsigned)(8 * p.ldc * 4), s1 + bv);
-                        }
+                        rr[g & 1][i][0] = *reinterpret_cast<const f4 *>(rp + (int64_t)(i * 16) * p.ldr);
+                        rr[g & 1][i][1] = *reinterpret_cast<const f4 *>(rp + (int64_t)(i * 16 + 8) * p.ldr);
                     }
+                }
+            };
+            load_res(0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ni = g >> 1, mi = g & 1;
+                if (g + 1 < 4) load_res(g + 1);
+                if (g == 1) load_cols(1);
+                const int col = ni * 128 + fcol;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f4 x0 = acc[mi][ni][i][0], x1 = acc[mi][ni][i][1];
+                    f4 s0, s1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float r0 = dpp_row_ror8(x0[e]), r1 = dpp_row_ror8(x1[e]);
+                        s0[e] = up ? r1 : x0[e];
+                        s1[e] = up ? x1[e] : r0;
+                    }
+                    const int lrow = frow + mi * kMiRows + i * 16;
+                    const unsigned voff = (unsigned)((lrow * p.ldc + col) * 4);
+                    s0 = s0 * (sbv[ni] * rs[mi][i][0]);           // (without scales: 1 x 1, exact -- a branch here made hipcc wait vmcnt(0) in every step)
+                    s1 = s1 * (sbv[ni] * rs[mi][i][1]);
+                    if constexpr (kEpi == kEpiF32GateRes) {
+                        s0 = rr[g & 1][i][0] + gv[ni] * (s0 + bv[ni]);
+                        s1 = rr[g & 1][i][1] + gv[ni] * (s1 + bv[ni]);
+                    } else {
+                        s0 = s0 + bv[ni];
+                        s1 = s1 + bv[ni];
+                    }
+                    if (live[ni]) {
+                        store_f4<kAux>(rsrc, voff, s0);
+                        store_f4<kAux>(rsrc, voff + (unsigned)(8 * p.ldc * 4), s1);
+                    }
+                    if constexpr (kEpi != kEpiF32GateRes) DIMSUM_PACE_STORES();
+                }
             }
         } else {
             const int frow = wr * 64 + (lane & 15);
@@ -892,9 +985,23 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
     }
 }
 
+// Every workgroup of a launch runs the same loop and the same epilogue: started together, all CUs reach their epilogues together and the chip's
+// store path (6-7 TB/s) is idle during the K loops and the bound during the epilogues. Delaying the first round on every other CU by part
+// of a tile period lets one half of the chip store while the other half multiplies; later rounds inherit the phase (a workgroup starts when
+// one ends on its CU). Workgroups sharing a CU get the same delay (their waves pair up on the SIMDs: section 3.5 of DESIGN.md).
+__device__ __forceinline__ void cu_stagger(const Args &p, int first_round) {
+    if (p.stagger > 0 && (int)blockIdx.x < first_round) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        if ((hw >> 8) & 1u)                              // CU_ID bit 0
+            for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+    }
+}
+
 template <int kOp, int kEpi, int kVar = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
     __shared__ __attribute__((aligned(1024))) char lds[2 * kParity];
+    cu_stagger(p, 256);
     gemm_body<kOp, kEpi, kVar>(p, lds);
 }
 
@@ -902,6 +1009,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
 template <int kOp, int kEpi, int kVar = 0>
 __global__ __launch_bounds__(256, 2) void gemm_nt_m128_kernel(const Args p) {
     __shared__ __attribute__((aligned(1024))) char lds[10 * 8192];
+    cu_stagger(p, 512);
     gemm_body<kOp, kEpi, kVar | kVarM128>(p, lds);
 }
 

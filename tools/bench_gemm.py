@@ -160,7 +160,7 @@ def tune(M, N, K, dtype, rounds, inner, check=True):
         print(f"  {k:22s} median {med:7.4f} ms  min {v[0]:7.4f}  {fl / med / 1e9:7.1f} TF", flush=True)
 
 
-def tiles_ab(rounds, inner):
+def tiles_ab(rounds, inner, stagger=()):
     """the scaled-fp16 launches of one DiM-L/2 forward at batch 256 on 256-row tiles (tune 513) against 128-row tiles (tune 512: two
     4-wave workgroups per CU, csrc/gemm_nt_kernel.hpp kVarM128), interleaved rounds on one box; epilogues as the model runs them"""
     M = 65536
@@ -188,6 +188,9 @@ def tiles_ab(rounds, inner):
             out = torch.empty((m, n), device="cuda", dtype=torch.float32)
         arms = {"256-row tiles": lambda: native.gemm_nt(a.data, b.data, out=out, tune=(513, 0, 0), **kw),
                 "128-row tiles": lambda: native.gemm_nt(a.data, b.data, out=out, tune=(512, 0, 0), **kw)}
+        for st in stagger:          # first round of the odd CUs `st` x 1024 cycles late (gemm_nt_kernel.hpp cu_stagger)
+            arms[f"256 stagger {st}"] = lambda st=st: native.gemm_nt(a.data, b.data, out=out, tune=(513, 0, st), **kw)
+            arms[f"128 stagger {st}"] = lambda st=st: native.gemm_nt(a.data, b.data, out=out, tune=(512, 0, st), **kw)
         r0, r1 = arms["256-row tiles"](), arms["128-row tiles"]()
         same = torch.equal(r0.data, r1.data) if kind == "gated" else torch.equal(r0, r1)
         torch.cuda.synchronize()
@@ -212,6 +215,7 @@ def main():
     ap.add_argument("--inner", type=int, default=10)
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--tune", action="store_true")
+    ap.add_argument("--stagger", default="", help="--tiles: also time these start delays of the odd CUs (x 1024 cycles), e.g. 4,8,16")
     ap.add_argument("--tiles", action="store_true", help="A / B of the 256-row against the 128-row tile variant on the scaled-fp16 launch shapes")
     ap.add_argument("--pmc-run", action="store_true", help="a few launches of the w12-shape kernels (under rocprofv3 --pmc)")
     ap.add_argument("--pmc-run-tn", action="store_true", help="a few launches of the dW12-shape TN kernels (three-piece row stacks, pairs) and of the library's batched TN GEMM")
@@ -252,7 +256,7 @@ def main():
         tune(65536, 8192, 1024, torch.bfloat16, args.rounds, args.inner)
         tune(65536, 1024, 12288, torch.bfloat16, args.rounds, args.inner)
     if args.tiles:
-        tiles_ab(args.rounds, args.inner)
+        tiles_ab(args.rounds, args.inner, [int(v) for v in args.stagger.split(",") if v])
     if args.perf:
         shapes = [("w12 split3", 65536, 8192, 3072, torch.bfloat16),
                   ("w3 split3", 65536, 1024, 12288, torch.bfloat16),
