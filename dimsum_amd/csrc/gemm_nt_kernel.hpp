@@ -792,6 +792,27 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
         // batch element (the maximum of a_inv over the element's rows: a tile lies inside one element).
         constexpr int kNW = kM1 ? 4 : 8;
         float *red = reinterpret_cast<float *>(lds);              // (the ring is free: no DMA pending, every operand read retired)
+        // every load of the epilogue is issued here, in one batch (the round-4 form paid a memory round trip for the batch maximum, one for the
+        // row scales and one per column vector: 6 in a row)
+        const float wl1 = p.gate_bound[0], bmax = p.gate_bound[1];
+        float row_sa[2][4], row_qs[2][4];
+        f4 cbv[2][2], csb[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) row_sa[mi][i] = p.sa[m0 + mi * kMiRows + wr * 64 + i * 16 + (lane & 15)];
+        {
+            const unsigned mbias = pick_mask(p.bias0 != nullptr);
+            const float *b0p = p.bias0 ? p.bias0 : p.sb;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = n0 + ni * 128 + ecol + j * 16, lc = col < p.N ? col : 0;
+                    cbv[ni][j] = pick(mbias, *reinterpret_cast<const f4 *>(b0p + lc), f4{0.f, 0.f, 0.f, 0.f});
+                    csb[ni][j] = *reinterpret_cast<const f4 *>(p.sb + lc);
+                }
+        }
         {
             const float *sab = p.sa + (int64_t)(m0 / p.rows_per_batch) * p.rows_per_batch;
             float mloc = 0.f;
@@ -804,16 +825,12 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
 #pragma unroll
         for (int i = 1; i < kNW; ++i) mb = fmaxf(mb, red[i]);
         __syncthreads();                                            // (the staging below overwrites `red`)
-        const float wl1 = p.gate_bound[0], bmax = p.gate_bound[1];
         float kv_scale, kv_inv;
         f16s_scales(2.0f * (32768.0f * mb * wl1 + bmax), kv_scale, kv_inv);
-        float row_sa[2][4], row_qs[2][4];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int r = mi * kMiRows + wr * 64 + i * 16 + (lane & 15);
-                row_sa[mi][i] = p.sa[m0 + r];
                 float qinv;
                 f16s_scales(2.0f * (32768.0f * row_sa[mi][i] * wl1 + bmax), row_qs[mi][i], qinv);
             }
@@ -823,11 +840,7 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int tcol = ni * 128 + ecol + j * 16, col = n0 + tcol;
-                f4 bv = f4{0.f, 0.f, 0.f, 0.f}, sbv = f4{1.f, 1.f, 1.f, 1.f};
-                if (col < p.N) {
-                    if (p.bias0) bv = *reinterpret_cast<const f4 *>(p.bias0 + col);
-                    sbv = *reinterpret_cast<const f4 *>(p.sb + col);
-                }
+                const f4 bv = cbv[ni][j], sbv = csb[ni][j];       // (columns past N hold column 0's values: computed, never stored)
                 const bool is_q = col < p.q_cols;
                 const int unit = tcol >> 2;
 #pragma unroll
@@ -866,17 +879,40 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
         //   |x1|, |x2| <= max|a_r| * max_n sum_k |w_nk| + max|b|   (max|a_r| < 2^15 sa[r] by the image's construction), |gelu(x)| <= |x|:
         // no reduction over the row -- every column tile derives the same power of two. The factor 4 covers the fp16 rounding of the
         // operands and the fp32 accumulation many times over.
+        // ALL loads of the epilogue in one batch, unconditional (dead columns / absent operands read a valid address and the value is replaced:
+        // see pick()), before the first store: the round-4 form went to memory 8 times in a row for the row scales (load, wait, store inv_out,
+        // load, ..) and twice more for the column vectors -- ten serial round trips per tile with the matrix pipe idle
+        const bool has_s = p.sa != nullptr, has_b = p.bias0 != nullptr;
+        const unsigned ms = pick_mask(has_s), mb = pick_mask(has_b);
+        const float *sap = has_s ? p.sa + m0 : reinterpret_cast<const float *>(p.A);
+        const float *sbp = has_s ? p.sb : reinterpret_cast<const float *>(p.B0), *b0p = has_b ? p.bias0 : reinterpret_cast<const float *>(p.B0), *b1p = has_b ? p.bias1 : b0p;
+        const int sb2_off = has_s ? p.N : 0;
         float row_sa[2][4], row_hs[2][4];
+        f4 cbv1[2], cbv2[2], csb1[2], csb2[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) row_sa[mi][i] = pick(ms, sap[mi * kMiRows + wr * 64 + i * 16 + (lane & 15)], 1.0f);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + ecol + j * 16, lc = col < p.N ? col : 0;
+            const f4 zero = f4{0.f, 0.f, 0.f, 0.f}, one = f4{1.f, 1.f, 1.f, 1.f};
+            cbv1[j] = pick(mb, *reinterpret_cast<const f4 *>(b0p + lc), zero);
+            cbv2[j] = pick(mb, *reinterpret_cast<const f4 *>(b1p + lc), zero);
+            csb1[j] = pick(ms, *reinterpret_cast<const f4 *>(sbp + lc), one);
+            csb2[j] = pick(ms, *reinterpret_cast<const f4 *>(sbp + sb2_off + lc), one);
+        }
+        const bool bound = !kImg && has_s && p.gate_bound != nullptr;
+        const float gb0 = bound ? p.gate_bound[0] : 0.f, gb1 = bound ? p.gate_bound[1] : 0.f;        // (wave-uniform: scalar loads)
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = mi * kMiRows + wr * 64 + i * 16 + (lane & 15);
-                row_sa[mi][i] = p.sa ? p.sa[m0 + r] : 1.0f;
                 row_hs[mi][i] = p.out_scale;
                 if constexpr (!kImg) {
-                    if (p.sa && p.gate_bound) {
-                        const float xb = 32768.0f * row_sa[mi][i] * p.gate_bound[0] + p.gate_bound[1];
+                    if (bound) {
+                        const float xb = 32768.0f * row_sa[mi][i] * gb0 + gb1;
                         float inv;
                         f16s_scales(4.0f * xb * xb, row_hs[mi][i], inv);
                         if (tile_n == 0 && wc == 0 && lane < 16) p.inv_out[m0 + r] = inv;
@@ -916,16 +952,7 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int col = n0 + ecol + j * 16;
-            f4 bv1 = f4{0.f, 0.f, 0.f, 0.f}, bv2 = bv1, sb1 = f4{1.f, 1.f, 1.f, 1.f}, sb2 = sb1;
-            if (p.bias0 && col < p.N) {
-                bv1 = *reinterpret_cast<const f4 *>(p.bias0 + col);
-                bv2 = *reinterpret_cast<const f4 *>(p.bias1 + col);
-            }
-            if (p.sb && col < p.N) {
-                sb1 = *reinterpret_cast<const f4 *>(p.sb + col);
-                sb2 = *reinterpret_cast<const f4 *>(p.sb + p.N + col);
-            }
+            const f4 bv1 = cbv1[j], bv2 = cbv2[j], sb1 = csb1[j], sb2 = csb2[j];
             const int unit = (ecol + j * 16) >> 2;
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
@@ -934,10 +961,8 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
                     const int r = mi * kMiRows + wr * 64 + i * 16 + (lane & 15);
                     f4 x1 = acc[mi][0][i][j], x2 = acc[mi][1][i][j];
                     const float hs = row_hs[mi][i];
-                    if (p.sa) {
-                        x1 = x1 * (sb1 * row_sa[mi][i]);
-                        x2 = x2 * (sb2 * row_sa[mi][i]);
-                    }
+                    x1 = x1 * (sb1 * row_sa[mi][i]);           // (without scales: 1 x 1, exact)
+                    x2 = x2 * (sb2 * row_sa[mi][i]);
                     x1 = x1 + bv1;
                     x2 = x2 + bv2;
                     float h[4];
