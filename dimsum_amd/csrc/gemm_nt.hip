@@ -23,6 +23,27 @@ template <int kOp, int kEpi, int kVar = 0> int launch_m128(const Args &a0, hipSt
     return launch_status();
 }
 
+// persistent workgroups (kVarPersist): one per CU (a multiple of 8: the tile walk's XCD ranges), each walking the tile list as one K stream
+inline int persist_grid() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        n = cus >= 8 ? cus / 8 * 8 : 8;
+    }
+    return n;
+}
+inline bool persist_ok(const Args &a, int tune_variant) {       // 514 forces it, 513 forbids it (A / B runs)
+    const int nk = a.K / kBK;
+    return tune_variant != 513 && tune_variant != 512 && nk >= 4 && nk % 2 == 0 && a.tiles_m * a.tiles_n > persist_grid() && a.a_alias_tiles == 0 && a.b_alias_tiles == 0;
+}
+template <int kOp, int kEpi, int kVar = 0> int launch_persist(const Args &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    const dim3 grid((unsigned)persist_grid()), block(512);
+    if (e0 || e1) hipExtLaunchKernelGGL((gemm_nt_persist_kernel<kOp, kEpi, kVar>), grid, block, 0, s, e0, e1, 0, a);
+    else hipLaunchKernelGGL((gemm_nt_persist_kernel<kOp, kEpi, kVar>), grid, block, 0, s, a);
+    return launch_status();
+}
+
 // scaled-fp16 operands (one product per element): both tile shapes are built
 template <int kEpi, int kVar = 0> int launch_f16(const Args &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1, bool m128) {
     return m128 ? launch_m128<kOpF16, kEpi, kVar>(a, s, e0, e1) : launch<kOpF16, kEpi, kVar>(a, s, e0, e1);
@@ -77,7 +98,7 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
     // operands (one product per element) with K <= 1024 spend a third to a half of a 256 x 256 tile's time in its epilogue
     const bool m128 = p->tune_variant == 512 || (p->tune_variant == 0 && !bf && p->k <= 576 && (p->epilogue == DIMSUM_GEMM_EPI_F32 || p->epilogue == DIMSUM_GEMM_EPI_F32_BIAS));
 #ifndef DIMSUM_GEMM_TUNE
-    if (p->tune_variant != 0 && p->tune_variant != 512 && p->tune_variant != 513) return DIMSUM_ERR_UNSUPPORTED;
+    if (p->tune_variant != 0 && p->tune_variant != 512 && p->tune_variant != 513 && p->tune_variant != 514) return DIMSUM_ERR_UNSUPPORTED;
 #endif
     if (p->tune_variant == 512 && bf) return DIMSUM_ERR_UNSUPPORTED;       // (the 128-row tiles are built for the fp16 operands only)
     if (p->epilogue == DIMSUM_GEMM_EPI_F32_GATE_RESIDUAL) {
@@ -96,6 +117,7 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
         a.N = p->n;
         a.tiles_n = (p->n + kBN - 1) / kBN;
         constexpr int kShipR = kVarFullLineStores | kVarNtStores;
+        if (!bf && !m128 && p->tune_variant == 514 && p->n % kBN == 0 && persist_ok(a, p->tune_variant)) return launch_persist<kOpF16, kEpiF32GateRes, kShipR>(a, s, e0, e1);     // (A / B only: see DESIGN 3.5)
         return bf ? launch<kOpBf16, kEpiF32GateRes, kShipR>(a, s, e0, e1) : launch_f16<kEpiF32GateRes, kShipR>(a, s, e0, e1, m128);
     }
     if (p->epilogue == DIMSUM_GEMM_EPI_F16_QKV) {
@@ -190,6 +212,7 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
             return launch<kOpBf16, kEpiGatedSplit3, kVarKeepX12>(a, s, e0, e1);
         }
         if (img) return bf ? launch<kOpBf16, kEpiGatedSplit3>(a, s, e0, e1) : launch<kOpF16, kEpiGatedSplit3>(a, s, e0, e1);
+        if (!bf && !m128 && F % 128 == 0 && persist_ok(a, p->tune_variant)) return launch_persist<kOpF16, kEpiGatedF16>(a, s, e0, e1);
         return bf ? launch<kOpBf16, kEpiGatedF16>(a, s, e0, e1) : launch_f16<kEpiGatedF16>(a, s, e0, e1, m128);
     }
     return DIMSUM_ERR_UNSUPPORTED;

@@ -93,7 +93,7 @@ struct Args {
     int c_pieces2;                 // kEpiGatedSplit3: the h image is written as the pair [hi | lo] (ldc >= 2 F) for a consumer that reads it with a_alias_tiles
 };
 // tuning variants (bit mask; 0 = the shipped schedule)
-enum { kVarLgkmAfterBarrier = 1, kVarNoEpilogue = 2, kVarNtStores = 4, kVarFullLineStores = 8, kVarNoSetprio = 16, kVarSc1Stores = 32, kVarSc0Stores = 64, kVarKeepX12 = 128, kVarTN = 256, kVarM128 = 512, kVarRebase = 1024 };
+enum { kVarLgkmAfterBarrier = 1, kVarNoEpilogue = 2, kVarNtStores = 4, kVarFullLineStores = 8, kVarNoSetprio = 16, kVarSc1Stores = 32, kVarSc0Stores = 64, kVarKeepX12 = 128, kVarTN = 256, kVarM128 = 512, kVarRebase = 1024, kVarPersist = 2048 };
 
 __device__ __forceinline__ float dpp_row_ror8(float x) {      // lane l <- lane l ^ 8 (rotation by 8 inside each row of 16 lanes)
     const int v = __builtin_bit_cast(int, x);                  // (old = the source: with a constant `old` hipcc 7.2 merges the calls of an unrolled loop)
@@ -106,6 +106,13 @@ template <int kAux> __device__ __forceinline__ void store_f4(__amdgpu_buffer_rsr
 template <int kOp> __device__ __forceinline__ f4 mma(const u32x4 &a, const u32x4 &b, f4 c) {
     if constexpr (kOp == kOpBf16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+// a wave-uniform pointer the compiler lost track of (it went through a struct copy behind a branch): back into SGPRs
+__device__ __forceinline__ const char *uniform_ptr(const char *q) {
+    const uint64_t v = reinterpret_cast<uint64_t>(q);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const char *>(((uint64_t)hi << 32) | lo);
 }
 
 // c ? a : b on the bits, with the mask hidden from the optimiser: a plain select whose `a` is a load is turned into a branch around the load
@@ -133,6 +140,9 @@ __device__ __forceinline__ f4 pick(unsigned m, const f4 &a, const f4 &b) {
 // Two workgroups share a CU under kVarM128: while one is in its epilogue the other's LDS-DMA loads go through the same in-order vector-memory
 // path, behind whatever stores are queued there. The epilogue therefore keeps at most DIMSUM_EPI_PACE of its own stores in flight
 // (tools/bench_gemm.py --tiles: unpaced, in_proj 180 -> 214 us); the 8-wave kernel has the CU to itself and does not pace.
+#ifndef DIMSUM_PERSIST_GS
+#define DIMSUM_PERSIST_GS 2
+#endif
 #ifndef DIMSUM_EPI_PACE
 #define DIMSUM_EPI_PACE 0
 #endif
@@ -175,9 +185,15 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
     constexpr bool kTN = (kVar & kVarTN) != 0;
     static_assert(!kTN || kEpi == kEpiF32, "the TN variant has the plain fp32 epilogue");
     static_assert(!(kTN && kM1), "the TN variant has 256 x 256 tiles only");
+    // kVarPersist: gridDim.x (a multiple of 8, <= the tile count) workgroups walk the tile list, workgroup b taking the list positions b,
+    // b + gridDim.x, .. -- the positions the hardware dispatcher would hand to the CU one after the other -- as ONE stream of K tiles: the
+    // last two K tiles of an output tile stage the first two of the next one, the epilogue runs with those DMAs in flight, and the K loop
+    // resumes on landed data (no pipeline fill, no workgroup launch between tiles). K / 64 must be even (the ring parity follows the stream).
+    constexpr bool kPersist = (kVar & kVarPersist) != 0;
+    static_assert(!kPersist || (!kTN && !kM1 && (kEpi == kEpiF32 || kEpi == kEpiF32Bias || kEpi == kEpiF32GateRes || kEpi == kEpiGatedF16)), "persistent: the 256-row NT kernel");
     int tile_m, tile_n, split = 0;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x;
+    auto map_tile = [&](int bid, int &tile_m, int &tile_n) {
+        const int nwg = kPersist ? p.tiles_m * p.tiles_n : (int)gridDim.x;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
         if constexpr (kTN) {       // (the splits of one tile are `tiles` apart in the list: they run at the same time on different XCDs' ranges)
@@ -192,8 +208,11 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
         const int gsz = min(p.tiles_m - first_m, GM);
         tile_n = within / gsz;
         tile_m = first_m + (within - tile_n * gsz);
-    }
-    const int m0 = tile_m * kTileM, n0 = tile_n * (kEpi == kEpiGatedSplit3 || kEpi == kEpiGatedF16 ? 128 : kBN);
+    };
+    int bid = blockIdx.x;
+    map_tile(bid, tile_m, tile_n);
+    constexpr int kTileN = (kEpi == kEpiGatedSplit3 || kEpi == kEpiGatedF16) ? 128 : kBN;
+    int m0 = tile_m * kTileM, n0 = tile_n * kTileN;
 
     // ---- staging addresses: wave w fills row block w (16 rows) of every half tile; lane l -> LDS byte 16 l of a subtile = logical row l >> 2,
     // k chunk (l & 3) ^ (2 if l >= 32)
@@ -201,22 +220,29 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
     const int st_kc = (lane & 3) ^ ((lane >> 5) << 1);
     const unsigned a_voff = (unsigned)((st_row * p.lda + st_kc * 8) * 2);
     // weight rows beyond N are clamped to the last row (their products land in columns the epilogue masks)
-    unsigned b_voff[2];
-    const char *b_base[2];
-    if constexpr (kEpi == kEpiGatedSplit3 || kEpi == kEpiGatedF16) {
-        b_base[0] = p.B0 + (int64_t)n0 * p.ldb * 2;
-        b_base[1] = p.B1 + (int64_t)n0 * p.ldb * 2;
-        const int row = min(st_row, p.N - 1 - n0);
-        b_voff[0] = b_voff[1] = (unsigned)((row * p.ldb + st_kc * 8) * 2);
-    } else {
-        b_base[0] = b_base[1] = p.B0 + (int64_t)n0 * p.ldb * 2;
+    struct Src { const char *a_base, *b_base[2]; unsigned b_voff[2]; };          // the operand panels of one output tile
+    auto make_src = [&](int m0_, int n0_) {
+        Src s_;
+        if constexpr (kEpi == kEpiGatedSplit3 || kEpi == kEpiGatedF16) {
+            s_.b_base[0] = p.B0 + (int64_t)n0_ * p.ldb * 2;
+            s_.b_base[1] = p.B1 + (int64_t)n0_ * p.ldb * 2;
+            const int row = min(st_row, p.N - 1 - n0_);
+            s_.b_voff[0] = s_.b_voff[1] = (unsigned)((row * p.ldb + st_kc * 8) * 2);
+        } else {
+            s_.b_base[0] = s_.b_base[1] = p.B0 + (int64_t)n0_ * p.ldb * 2;
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int row = min(ni * 128 + st_row, p.N - 1 - n0);
-            b_voff[ni] = (unsigned)((row * p.ldb + st_kc * 8) * 2);
+            for (int ni = 0; ni < 2; ++ni) {
+                const int row = min(ni * 128 + st_row, p.N - 1 - n0_);
+                s_.b_voff[ni] = (unsigned)((row * p.ldb + st_kc * 8) * 2);
+            }
         }
-    }
-    const char *a_base = p.A + (int64_t)m0 * p.lda * 2;
+        s_.a_base = p.A + (int64_t)m0_ * p.lda * 2;
+        return s_;
+    };
+    Src cur = make_src(m0, n0);
+    const char *(&b_base)[2] = cur.b_base;
+    unsigned (&b_voff)[2] = cur.b_voff;
+    const char *&a_base = cur.a_base;
     const int64_t a_half = (int64_t)kMiRows * p.lda * 2;
     unsigned b_voff2[2][2];        // M128: a B entry (128 weight rows) is two 64-row pieces per wave pass: rows st_row, st_row + 64
     if constexpr (kM1) {
@@ -282,6 +308,13 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
     auto stage_a1 = [&](int kt) { if constexpr (kTN) stage_tn_a(kSlotA1, tn_a + 256, kt); else stage(kSlotA1, a_base + a_half, a_voff, kt, p.a_alias_tiles); };
     auto stage_b0 = [&](int kt) { if constexpr (kTN) stage_tn(kSlotB0, tn_b, tn_b_tile, tn_voff_b, kt); else stage(kSlotB0, b_base[0], b_voff[0], kt, p.b_alias_tiles); };
     auto stage_b1 = [&](int kt) { if constexpr (kTN) stage_tn(kSlotB1, tn_b + 256, tn_b_tile, tn_voff_b, kt); else stage(kSlotB1, b_base[1], b_voff[1], kt, p.b_alias_tiles); };
+    // (persistent: half tile `which` of K tile kt of the tile whose panels are s_)
+    auto stage_of = [&](const Src &s_, int which, int kt) {
+        if (which == 0) stage(kSlotA0, s_.a_base, a_voff, kt, p.a_alias_tiles);
+        else if (which == 1) stage(kSlotB0, s_.b_base[0], s_.b_voff[0], kt, p.b_alias_tiles);
+        else if (which == 2) stage(kSlotB1, s_.b_base[1], s_.b_voff[1], kt, p.b_alias_tiles);
+        else stage(kSlotA1, s_.a_base + a_half, a_voff, kt, p.a_alias_tiles);
+    };
 
     // ---- operand read addresses: lane l reads row l & 15, k chunk l >> 4 of a subtile (swizzled: rows 8-15 swap chunk pairs)
     const unsigned rd = (unsigned)((lane & 15) * 64 + (((lane >> 4) ^ (((lane >> 3) & 1) << 1)) * 16));
@@ -494,41 +527,61 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
     rebase(a0, 0, 0);
     DIMSUM_PHASE_END();
 
+    }
+    // one K tile = four phases; ST_* stage the four half tiles two K tiles ahead; NEXT_A0: whether P4 reads the next K tile's A0
+    // W12 / W34: whether the first / last two phases wait for the steady state's vmcnt(12) (the DMA pieces of 6 half tiles in flight)
+#define DIMSUM_KTILE(KT, ST_A0, ST_B0, ST_B1, ST_A1, W12, W34)                                                                  \
+    do {                                                                                                                        \
+        const unsigned par = ((KT) & 1) * kParity, par_next = kParity - par;                                                    \
+        DIMSUM_READ_B(b0, kSlotB0, par); ST_A0; if (W12) DIMSUM_WAIT_VM(12); DIMSUM_PHASE_SYNC();                               \
+        DIMSUM_QUADRANT(0, 0, a0, b0); DIMSUM_PHASE_END();                                                                      \
+        DIMSUM_READ_B(b1, kSlotB1, par); ST_B0; if (W12) DIMSUM_WAIT_VM(12); DIMSUM_PHASE_SYNC();                               \
+        DIMSUM_QUADRANT(0, 1, a0, b1); DIMSUM_PHASE_END();                                                                      \
+        DIMSUM_READ_A(a1, kSlotA1, par); ST_B1; if (W34) DIMSUM_WAIT_VM(12); DIMSUM_PHASE_SYNC();                               \
+        rebase(a1, 1, KT); DIMSUM_QUADRANT(1, 1, a1, b1); DIMSUM_PHASE_END();                                                   \
+        DIMSUM_READ_A(a0, kSlotA0, par_next);                                                                                   \
+        ST_A1; if (W34) DIMSUM_WAIT_VM(12); DIMSUM_PHASE_SYNC();                                                                \
+        DIMSUM_QUADRANT(1, 0, a1, b0);                                                                                          \
+        rebase(a0, 0, (KT) + 1);     /* (under the MFMAs just issued: a0 is next used in P1 of K tile KT + 1) */                \
+        DIMSUM_PHASE_END();                                                                                                     \
+    } while (0)
+    bool resumed = false;      // persistent: this tile's K loop follows an epilogue whose stores may still be in flight
+    for (;;) {                 // (one pass unless kPersist)
+    bool has_next = false;
+    int nbid = 0, ntile_m = 0, ntile_n = 0;
+    Src nxt = cur;             // (the last tile of a persistent workgroup streams its own first K tiles again: valid addresses, never read)
+    if constexpr (kPersist) {
+        nbid = bid + (int)gridDim.x;
+        has_next = nbid < p.tiles_m * p.tiles_n;
+        if (has_next) {
+            map_tile(nbid, ntile_m, ntile_n);
+            nxt = make_src(ntile_m * kTileM, ntile_n * kTileN);
+        }
+    }
+    if constexpr (kPersist) {
+        // ONE loop body for the whole stream (a second copy of the phases behind a branch -- a drained tail for the last tile, a peeled first K
+        // tile -- made hipcc spill ~300 registers at the merges). The last two K tiles of an output tile stage K tiles 0 and 1 of the next
+        // one (K / 64 is even: the ring parity of the next tile's K tile j is j & 1). After an epilogue its stores (<= 32 per wave, OLDER
+        // than every DMA issued from here on: vmcnt retires in order) may drain under the first six phases, whose operands landed before
+        // the epilogue: those phases do not wait at all; P3 of K tile 1 is the first that needs a piece issued after the stores.
+        // P4 of the last K tile reads the next tile's A0 like every other (discarded: the epilogue comes first, the read is re-issued after it).
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool own = kt + 2 < nk;
+            const int skt = own ? kt + 2 : kt + 2 - nk;
+            Src ss;
+            ss.a_base = uniform_ptr(own ? cur.a_base : nxt.a_base);
+            ss.b_base[0] = uniform_ptr(own ? cur.b_base[0] : nxt.b_base[0]);
+            ss.b_base[1] = uniform_ptr(own ? cur.b_base[1] : nxt.b_base[1]);
+            ss.b_voff[0] = cur.b_voff[0];          // (N is a whole number of tiles: no clamped weight rows, the lane offsets are the same in every tile)
+            ss.b_voff[1] = cur.b_voff[1];
+            const bool w12 = !(resumed && kt < 2), w34 = !(resumed && kt < 1);
+            DIMSUM_KTILE(kt, stage_of(ss, 0, skt), stage_of(ss, 1, skt), stage_of(ss, 2, skt), stage_of(ss, 3, skt), w12, w34);
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();       // the two wave rows meet
+    } else if constexpr (!kM1) {
     // ---- main loop: K tile kt is computed while K tile kt + 2 is staged into the slots kt frees
     int kt = 0;
-    for (; kt < nk - 2; ++kt) {
-        const unsigned par = (kt & 1) * kParity, par_next = kParity - par;
-        // P1
-        DIMSUM_READ_B(b0, kSlotB0, par);
-        stage_a0(kt + 2);
-        DIMSUM_WAIT_VM(12);
-        DIMSUM_PHASE_SYNC();
-        DIMSUM_QUADRANT(0, 0, a0, b0);
-        DIMSUM_PHASE_END();
-        // P2
-        DIMSUM_READ_B(b1, kSlotB1, par);
-        stage_b0(kt + 2);
-        DIMSUM_WAIT_VM(12);
-        DIMSUM_PHASE_SYNC();
-        DIMSUM_QUADRANT(0, 1, a0, b1);
-        DIMSUM_PHASE_END();
-        // P3
-        DIMSUM_READ_A(a1, kSlotA1, par);
-        stage_b1(kt + 2);
-        DIMSUM_WAIT_VM(12);
-        DIMSUM_PHASE_SYNC();
-        rebase(a1, 1, kt);
-        DIMSUM_QUADRANT(1, 1, a1, b1);
-        DIMSUM_PHASE_END();
-        // P4
-        DIMSUM_READ_A(a0, kSlotA0, par_next);
-        stage_a1(kt + 2);
-        DIMSUM_WAIT_VM(12);
-        DIMSUM_PHASE_SYNC();
-        DIMSUM_QUADRANT(1, 0, a1, b0);
-        rebase(a0, 0, kt + 1);                        // (under the MFMAs just issued: a0 is next used in P1 of K tile kt + 1)
-        DIMSUM_PHASE_END();
-    }
+    for (; kt < nk - 2; ++kt) DIMSUM_KTILE(kt, stage_a0(kt + 2), stage_b0(kt + 2), stage_b1(kt + 2), stage_a1(kt + 2), true, true);
     // ---- the last two K tiles: nothing left to stage, the counted waits run down (5, 4, 3, 2, 1, 0 half tiles behind the one needed next)
     {
         const unsigned par = (kt & 1) * kParity, par_next = kParity - par;
@@ -575,6 +628,12 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
     }
 
     // ---- epilogue: acc[mi][ni][i][j] = rows m0 + mi * 128 + wr * 64 + i * 16 + (lane & 15), 4 columns from ni * 128 + wc * 32 + j * 16 + (lane >> 4) * 4
+    // (persistent: the epilogue's lane-derived indices must not be hoisted out of the tile loop -- they would live in registers through the K
+    // loop, which has ~10 to spare: everything below derives them from a lane id the optimiser cannot see through)
+    int lane_e = lane;
+    if constexpr (kPersist) asm volatile("" : "+v"(lane_e));
+    {
+    const int lane = lane_e;
     const int ecol = wc * 32 + (lane >> 4) * 4;
     if constexpr (kVar & kVarNoEpilogue) {
 #pragma unroll
@@ -711,6 +770,7 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
             load_cols(0);
             live[1] = n0 + 128 + fcol < p.N;
             float rs[2][4][2];
+            if constexpr (!kPersist || kRebase || kEpi != kEpiF32GateRes)          // (persistent + residual: the row scales ride with the residual groups)
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -721,27 +781,39 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
                         rs[mi][i][0] = pick(ms, sap[lrow], 1.0f); rs[mi][i][1] = pick(ms, sap[lrow + 8], 1.0f);
                     }
                 }
-            f4 rr[2][4][2];                                // kEpiF32GateRes: residual rows of group g = 2 ni + mi in rr[g & 1]
+            // kEpiF32GateRes: the residual rows run one group of kGS 16-row steps ahead of the stores (step t = (2 ni + mi) 4 + i; the persistent kernel
+            // keeps its loop state in registers through the epilogue and affords 2 steps = 32 registers, the plain one 4)
+            constexpr int kGS = kPersist ? DIMSUM_PERSIST_GS : 4, kNG = 16 / kGS;
+            f4 rr[2][kGS][2];
+            float rg[2][kGS][2];
             auto load_res = [&](int g) {
                 if constexpr (kEpi == kEpiF32GateRes) {
-                    const int ni = g >> 1, mi = g & 1;
+                    const int t0 = g * kGS, ni = t0 >> 3, mi = (t0 >> 2) & 1;          // (a group lies inside one (ni, mi) quadrant)
+                    if constexpr (kPersist) {
+#pragma unroll
+                        for (int k = 0; k < kGS; ++k) {
+                            const int lrow = frow + mi * kMiRows + ((t0 + k) & 3) * 16;
+                            rg[g & 1][k][0] = pick(ms, sap[lrow], 1.0f); rg[g & 1][k][1] = pick(ms, sap[lrow + 8], 1.0f);
+                        }
+                    }
                     const float *rp = p.res + (int64_t)(m0 + frow + mi * kMiRows) * p.ldr + (live[ni] ? n0 + ni * 128 + fcol : 0);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        rr[g & 1][i][0] = *reinterpret_cast<const f4 *>(rp + (int64_t)(i * 16) * p.ldr);
-                        rr[g & 1][i][1] = *reinterpret_cast<const f4 *>(rp + (int64_t)(i * 16 + 8) * p.ldr);
+                    for (int k = 0; k < kGS; ++k) {
+                        const int i = (t0 + k) & 3;
+                        rr[g & 1][k][0] = *reinterpret_cast<const f4 *>(rp + (int64_t)(i * 16) * p.ldr);
+                        rr[g & 1][k][1] = *reinterpret_cast<const f4 *>(rp + (int64_t)(i * 16 + 8) * p.ldr);
                     }
                 }
             };
             load_res(0);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ni = g >> 1, mi = g & 1;
-                if (g + 1 < 4) load_res(g + 1);
-                if (g == 1) load_cols(1);
-                const int col = ni * 128 + fcol;
+            for (int g = 0; g < kNG; ++g) {
+                if (g + 1 < kNG) load_res(g + 1);
+                if (g * kGS == 4) load_cols(1);                // (under ni = 0's second half, before its stores: ahead of its first use)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int k = 0; k < kGS; ++k) {
+                    const int t = g * kGS + k, ni = t >> 3, mi = (t >> 2) & 1, i = t & 3;
+                    const int col = ni * 128 + fcol;
                     const f4 x0 = acc[mi][ni][i][0], x1 = acc[mi][ni][i][1];
                     f4 s0, s1;
 #pragma unroll
@@ -752,11 +824,12 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
                     }
                     const int lrow = frow + mi * kMiRows + i * 16;
                     const unsigned voff = (unsigned)((lrow * p.ldc + col) * 4);
-                    s0 = s0 * (sbv[ni] * rs[mi][i][0]);           // (without scales: 1 x 1, exact -- a branch here made hipcc wait vmcnt(0) in every step)
-                    s1 = s1 * (sbv[ni] * rs[mi][i][1]);
+                    constexpr bool kRowsInGroup = kPersist && kEpi == kEpiF32GateRes;
+                    s0 = s0 * (sbv[ni] * (kRowsInGroup ? rg[g & 1][k][0] : rs[mi][i][0]));           // (without scales: 1 x 1, exact -- a branch here made hipcc wait vmcnt(0) in every step)
+                    s1 = s1 * (sbv[ni] * (kRowsInGroup ? rg[g & 1][k][1] : rs[mi][i][1]));
                     if constexpr (kEpi == kEpiF32GateRes) {
-                        s0 = rr[g & 1][i][0] + gv[ni] * (s0 + bv[ni]);
-                        s1 = rr[g & 1][i][1] + gv[ni] * (s1 + bv[ni]);
+                        s0 = rr[g & 1][k][0] + gv[ni] * (s0 + bv[ni]);
+                        s1 = rr[g & 1][k][1] + gv[ni] * (s1 + bv[ni]);
                     } else {
                         s0 = s0 + bv[ni];
                         s1 = s1 + bv[ni];
@@ -950,64 +1023,98 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
                         }
                     }
         }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const f4 bv1 = cbv1[j], bv2 = cbv2[j], sb1 = csb1[j], sb2 = csb2[j];
-            const int unit = (ecol + j * 16) >> 2;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = mi * kMiRows + wr * 64 + i * 16 + (lane & 15);
-                    f4 x1 = acc[mi][0][i][j], x2 = acc[mi][1][i][j];
-                    const float hs = row_hs[mi][i];
-                    x1 = x1 * (sb1 * row_sa[mi][i]);           // (without scales: 1 x 1, exact)
-                    x2 = x2 * (sb2 * row_sa[mi][i]);
-                    x1 = x1 + bv1;
-                    x2 = x2 + bv2;
-                    float h[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) h[e] = gelu_tanh_f(x1[e]) * x2[e];
-                    char *dst = lds + r * 256 + ((unit ^ (lane & 15)) << 3);
-                    if constexpr (kImg) {
-                        unsigned h0, l0, h1, l1;
-                        split2(h[0], h[1], h0, l0);
-                        split2(h[2], h[3], h1, l1);
-                        *reinterpret_cast<uint2 *>(dst) = make_uint2(h0, h1);
-                        *reinterpret_cast<uint2 *>(dst + kTileM * 256) = make_uint2(l0, l1);
-                    } else {
-                        const __half2 a = __floats2half2_rn(h[0] * hs, h[1] * hs), b = __floats2half2_rn(h[2] * hs, h[3] * hs);
-                        *reinterpret_cast<uint2 *>(dst) = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
-                    }
-                }
-        }
-        __syncthreads();
-        // wave w stores rows 32 w .. 32 w + 31, four rows (256 B of one plane each) per instruction
+        // persistent kernel: the ring holds the next tile's first K tiles -- the h tile goes through the 32 KB behind the ring instead, one 128-row
+        // half (mi) at a time: gate, barrier, store, barrier. The plain kernel stages both halves in the (free) ring and stores once.
+        static_assert(!(kPersist && kImg), "persistent: the fp16 image of h only");
+        constexpr int kPasses = kPersist ? 2 : 1, kPassRows = kTileM / kPasses;
+        char *stg = kPersist ? lds + 2 * kParity : lds;
         char *Ct = reinterpret_cast<char *>(p.C) + ((int64_t)m0 * p.ldc + n0) * 2;
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(Ct, 0, 0x7fffffff, 0x00020000);
         const int piece = lane & 15;
         const bool live = n0 + piece * 8 < p.N;
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int r = w * 32 + it * 4 + (lane >> 4);
-            const char *src = lds + r * 256 + ((piece ^ ((r & 15) >> 1)) << 4);
-            const bool odd = (r & 1) != 0;
-            const unsigned voff = (unsigned)((r * p.ldc + piece * 8) * 2);
-            u32x4 v = *reinterpret_cast<const u32x4 *>(src);
-            v = odd ? u32x4{v[2], v[3], v[0], v[1]} : v;
-            if (live) {
-                __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, 2);
-                if constexpr (kImg) {
-                    if (!p.c_pieces2) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff + (unsigned)(p.N * 2), 0, 2);
-                }
+        for (int pass = 0; pass < kPasses; ++pass) {
+            if (pass) __syncthreads();                     // (the first half's rows have been read)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f4 bv1 = cbv1[j], bv2 = cbv2[j], sb1 = csb1[j], sb2 = csb2[j];
+                const int unit = (ecol + j * 16) >> 2;
+#pragma unroll
+                for (int mi = kPersist ? pass : 0; mi < (kPersist ? pass + 1 : 2); ++mi)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = (kPersist ? 0 : mi * kMiRows) + wr * 64 + i * 16 + (lane & 15);       // row inside the staged rows
+                        f4 x1 = acc[mi][0][i][j], x2 = acc[mi][1][i][j];
+                        const float hs = row_hs[mi][i];
+                        x1 = x1 * (sb1 * row_sa[mi][i]);           // (without scales: 1 x 1, exact)
+                        x2 = x2 * (sb2 * row_sa[mi][i]);
+                        x1 = x1 + bv1;
+                        x2 = x2 + bv2;
+                        float h[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) h[e] = gelu_tanh_f(x1[e]) * x2[e];
+                        char *dst = stg + r * 256 + ((unit ^ (lane & 15)) << 3);
+                        if constexpr (kImg) {
+                            unsigned h0, l0, h1, l1;
+                            split2(h[0], h[1], h0, l0);
+                            split2(h[2], h[3], h1, l1);
+                            *reinterpret_cast<uint2 *>(dst) = make_uint2(h0, h1);
+                            *reinterpret_cast<uint2 *>(dst + kTileM * 256) = make_uint2(l0, l1);
+                        } else {
+                            const __half2 a = __floats2half2_rn(h[0] * hs, h[1] * hs), b = __floats2half2_rn(h[2] * hs, h[3] * hs);
+                            *reinterpret_cast<uint2 *>(dst) = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+                        }
+                    }
             }
-            if constexpr (kImg) {
-                u32x4 l = *reinterpret_cast<const u32x4 *>(src + kTileM * 256);
-                l = odd ? u32x4{l[2], l[3], l[0], l[1]} : l;
-                if (live) __builtin_amdgcn_raw_buffer_store_b128(l, rsrc, voff + (unsigned)(p.N * (p.c_pieces2 ? 2 : 4)), 0, 2);
+            __syncthreads();
+            // wave w stores its share (kPassRows / number of waves) of the staged rows, four rows (256 B of one plane each) per instruction
+#pragma unroll
+            for (int it = 0; it < kPassRows / (kM1 ? 4 : 8) / 4; ++it) {
+                const int rl = w * (kPassRows / (kM1 ? 4 : 8)) + it * 4 + (lane >> 4), r = pass * kPassRows + rl;
+                const char *src = stg + rl * 256 + ((piece ^ ((rl & 15) >> 1)) << 4);
+                const bool odd = (rl & 1) != 0;
+                const unsigned voff = (unsigned)((r * p.ldc + piece * 8) * 2);
+                u32x4 v = *reinterpret_cast<const u32x4 *>(src);
+                v = odd ? u32x4{v[2], v[3], v[0], v[1]} : v;
+                if (live) {
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, 2);
+                    if constexpr (kImg) {
+                        if (!p.c_pieces2) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff + (unsigned)(p.N * 2), 0, 2);
+                    }
+                }
+                if constexpr (kImg) {
+                    u32x4 l = *reinterpret_cast<const u32x4 *>(src + kTileM * 256);
+                    l = odd ? u32x4{l[2], l[3], l[0], l[1]} : l;
+                    if (live) __builtin_amdgcn_raw_buffer_store_b128(l, rsrc, voff + (unsigned)(p.N * (p.c_pieces2 ? 2 : 4)), 0, 2);
+                }
             }
         }
     }
+    }      // (the epilogue's scope)
+    if constexpr (!kPersist) break;
+    else {
+        if (!has_next) {
+            DIMSUM_WAIT_VM(0);                            // (the streamed-ahead K tiles nobody reads must have landed before the LDS is released)
+            break;
+        }
+        // the next output tile: its K tiles 0 and 1 are in the ring (the epilogue above did not touch LDS)
+        bid = nbid; tile_m = ntile_m; tile_n = ntile_n; m0 = tile_m * kTileM; n0 = tile_n * kTileN; cur = nxt;
+        resumed = true;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[mi][ni][i][j] = f4{0.f, 0.f, 0.f, 0.f};
+        if (wr == 1) __builtin_amdgcn_s_barrier();       // the second wave row falls one barrier behind again
+        __builtin_amdgcn_sched_barrier(0);
+        DIMSUM_READ_A(a0, kSlotA0, 0);
+        DIMSUM_PHASE_SYNC();
+        DIMSUM_PHASE_END();
+    }
+    }      // for (;;)
 }
 
 // Every workgroup of a launch runs the same loop and the same epilogue: started together, all CUs reach their epilogues together and the chip's
@@ -1030,6 +1137,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const Args p) {
     gemm_body<kOp, kEpi, kVar>(p, lds);
 }
 
+// persistent (kVarPersist): the whole LDS of a CU -- the 128-KB ring and 32 KB behind it for the epilogues that stage their tile
+template <int kOp, int kEpi, int kVar = 0>
+__global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(const Args p) {
+    __shared__ __attribute__((aligned(1024))) char lds[2 * kParity + 32768];
+    gemm_body<kOp, kEpi, kVar | kVarPersist>(p, lds);
+}
+
 // 4 waves, 80 KB: two workgroups per CU (2 waves per SIMD: the same 256-VGPR budget)
 template <int kOp, int kEpi, int kVar = 0>
 __global__ __launch_bounds__(256, 2) void gemm_nt_m128_kernel(const Args p) {
@@ -1038,6 +1152,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_m128_kernel(const Args p) {
     gemm_body<kOp, kEpi, kVar | kVarM128>(p, lds);
 }
 
+#undef DIMSUM_KTILE
 #undef DIMSUM_READ_A
 #undef DIMSUM_READ_TN1
 #undef DIMSUM_DS_READ_TR

@@ -11,6 +11,8 @@ There is no CPU path: a non-GPU tensor or a missing library is an error.
 """
 import contextlib
 
+import os
+
 import torch
 
 from . import _lib
@@ -907,6 +909,8 @@ def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=Non
     if tune is not None:
         P.tune_variant, P.tune_group_m = tune[:2]
         P.tune_reserved = tune[2] if len(tune) > 2 else 0
+    elif epilogue == "gated_f16" and os.environ.get("DIMSUM_GEMM_PERSIST", "1") == "0":
+        P.tune_variant = 513          # A / B switch: the gated GEMM one workgroup per tile instead of the persistent stream (csrc/gemm_nt_kernel.hpp, kVarPersist)
     with torch.cuda.device(a.device):
         _lib.check(_lib.load().dimsum_gemm_nt(P, _stream(a)), "gemm_nt")
     if x12 is not None:

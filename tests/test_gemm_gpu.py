@@ -434,3 +434,31 @@ def test_tn_product_of_block_scaled_fp16_rows(K, M, N):
     assert torch.equal(native.gemm_tn(a16, b16, scales=(inv, wimg.inv)), got)
     with pytest.raises(Exception):
         native.gemm_tn(a16, b16, scales=(inv[:, :-1].contiguous(), wimg.inv))
+
+
+@pytest.mark.parametrize("M,F,K", [(16384, 1024, 256), (12800, 768, 512), (33280, 256, 1024)])
+def test_persistent_stream_is_the_one_tile_per_workgroup_kernel_bit_for_bit(M, F, K):
+    """kVarPersist (csrc/gemm_nt_kernel.hpp): one workgroup per CU walks the tile list as ONE stream of K tiles -- the last two K tiles of an
+    output tile stage the first two of the next, the gated epilogue stages h in the 32 KB behind the ring while those DMAs are in flight.
+    Same arithmetic in the same order as the one-tile-per-workgroup kernel (tune 513): identical bits, for the launch heuristics' own choice
+    (tune None) and the forced one (514); 512 / 300 / 260 tiles (whole rounds, a partial second round, four workgroups with a second tile),
+    K / 64 = 4, 8, 16; the residual-tail epilogue's persistent build (A / B only) too."""
+    from dimsum_amd import native
+    x = native.rows_f16s(_rnd((M, K), torch.float32, 1) * torch.logspace(-1, 1, M, device="cuda")[:, None])
+    w16, l1 = native.rows_f16s(_rnd((2 * F, K), torch.float32, 2, scale=K ** -0.5), want_l1=True)
+    b12 = _rnd((2 * F,), torch.float32, 3, scale=0.1)
+    bound = torch.cat([l1 * (1.0 + 2.0 ** -10), b12.abs().max().reshape(1)]).contiguous()
+    kw = dict(bias=b12, epilogue="gated_f16", scales=(x.inv, w16.inv), gate_bound=bound)
+    plain = native.gemm_nt(x.data, w16.data, tune=(513, 0, 0), **kw)
+    for tune in (None, (514, 0, 0)):
+        got = native.gemm_nt(x.data, w16.data, tune=tune, **kw)
+        assert torch.equal(got.data.view(torch.int16), plain.data.view(torch.int16)) and torch.equal(got.inv, plain.inv)
+    x12 = x.float().double() @ w16.float().double().t() + b12.double()
+    href = torch.nn.functional.gelu(x12[:, :F], approximate="tanh") * x12[:, F:]
+    assert ((plain.float().double() - href).abs() / href.abs().amax(-1, keepdim=True)).max().item() < 2e-3
+    # residual tail: out = res + gate * (x w^T + b) with N = 2 F columns
+    N = 2 * F
+    if N % 256 == 0:
+        res, gate = _rnd((M, N), torch.float32, 4), _rnd((M // 256, N), torch.float32, 5)
+        kw = dict(bias=b12, residual=res, gate=gate, rows_per_batch=256, scales=(x.inv, w16.inv))
+        assert torch.equal(native.gemm_nt(x.data, w16.data, tune=(514, 0, 0), **kw), native.gemm_nt(x.data, w16.data, tune=(513, 0, 0), **kw))

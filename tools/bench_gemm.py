@@ -188,11 +188,12 @@ def tiles_ab(rounds, inner, stagger=()):
             out = torch.empty((m, n), device="cuda", dtype=torch.float32)
         arms = {"256-row tiles": lambda: native.gemm_nt(a.data, b.data, out=out, tune=(513, 0, 0), **kw),
                 "128-row tiles": lambda: native.gemm_nt(a.data, b.data, out=out, tune=(512, 0, 0), **kw)}
+        arms["persistent"] = lambda: native.gemm_nt(a.data, b.data, out=out, tune=(514, 0, 0), **kw)       # (where built: else the launch heuristics' choice)
         for st in stagger:          # first round of the odd CUs `st` x 1024 cycles late (gemm_nt_kernel.hpp cu_stagger)
             arms[f"256 stagger {st}"] = lambda st=st: native.gemm_nt(a.data, b.data, out=out, tune=(513, 0, st), **kw)
             arms[f"128 stagger {st}"] = lambda st=st: native.gemm_nt(a.data, b.data, out=out, tune=(512, 0, st), **kw)
-        r0, r1 = arms["256-row tiles"](), arms["128-row tiles"]()
-        same = torch.equal(r0.data, r1.data) if kind == "gated" else torch.equal(r0, r1)
+        r0, r1, r2 = arms["256-row tiles"](), arms["128-row tiles"](), arms["persistent"]()
+        same = (torch.equal(r0.data, r1.data) and torch.equal(r0.data, r2.data)) if kind == "gated" else (torch.equal(r0, r1) and torch.equal(r0, r2))
         torch.cuda.synchronize()
         res = {k_: [] for k_ in arms}
         for _ in range(rounds):
