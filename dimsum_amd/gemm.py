@@ -372,13 +372,16 @@ def f16s_plan(model):
     """what a forward of `model` under the scaled-fp16 policy converts: [(weight, kind, bias, partner)] over its large bias-free-GEMM
     Linears -- the mixers' in_proj, the fusion's qkv1 / qkv2 / proj, the shared attention's qkv / proj, the gated MLP's w12 / w3
     (dimsum/models_dim.py:974-1117, mlp.py:49-70, attention_fusion.py:44-79). kind: "plain" (image), "gated" (image + the gate epilogue's
-    bound with `bias`), "kv" (image + its half of the attention kernel's bound; `partner` = the other qkv Linear's weight or None)."""
+    bound with `bias`), "kv" (image + its half of the attention kernel's bound; `partner` = the other qkv Linear's weight or None),
+    "plain_t" (the mixers' out_proj: the image transposed, the right operand of out_proj_f16's TN product)."""
     from .attention_fusion import CrossAttentionFusion
     from .mlp import GatedMLP
     plan = []
     for m in model.modules():
         if hasattr(m, "in_proj") and hasattr(m, "x_proj") and hasattr(m, "dt_proj"):
             plan.append((m.in_proj.weight, "plain", None, None))
+            if getattr(m, "out_proj", None) is not None and getattr(m.out_proj, "bias", None) is None:
+                plan.append((m.out_proj.weight, "plain_t", None, None))
         elif isinstance(m, CrossAttentionFusion):
             plan += [(m.qkv1.weight, "kv", m.qkv1.bias, m.qkv2), (m.proj.weight, "plain", None, None)]
         elif isinstance(m, GatedMLP):
@@ -408,6 +411,7 @@ def forward_scope(model, rows):
     if plan is None:
         plan = model._f16s_plan = f16s_plan(model)
     jobs, slot = [], 0
+    tbufs = {}                      # "plain_t": weight shape -> job indices
     layout = []                     # per plan entry: (first job index, slot of its l1 [, ...])
     for w, kind, bias, partner in plan:
         ok = w.dtype == torch.float32 and w.is_cuda and w.stride(1) == 1 and w.shape[1] % 4 == 0 and w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0
@@ -417,6 +421,14 @@ def forward_scope(model, rows):
         layout.append((len(jobs), slot))
         if kind == "plain":
             jobs.append((w.detach(), True, slot, None, 1.0))            # (the L1 norm rides along: one cache entry kind per weight)
+            slot += 1
+        elif kind == "plain_t" and os.environ.get("DIMSUM_OUT_PROJ_F16", "1") == "0":
+            layout[-1] = None
+        elif kind == "plain_t":
+            # all transposed images of one shape share ONE buffer: one transposing copy per shape after the launch instead of one per weight
+            buf = tbufs.setdefault(tuple(w.shape), [])
+            buf.append(len(jobs))
+            jobs.append((w.detach(), True, slot, None, 1.0, None))
             slot += 1
         elif kind == "gated":                                            # slots: l1 (1 + 2^-10), max |b| -- the bound tensor itself; then the plain l1
             jobs.append((w.detach(), True, slot, None, _K10))
@@ -430,7 +442,16 @@ def forward_scope(model, rows):
                 if bi is not None:
                     jobs.append((bi.detach().float(), False, None, slot + 2 * i + 1, 1.0))
             slot += 4
+    tdata = {}
+    for shape, idx in tbufs.items():
+        data = torch.empty((len(idx),) + shape, device=first.device, dtype=torch.float16)
+        inv = torch.empty((len(idx), shape[0]), device=first.device, dtype=torch.float32)
+        for n, j in enumerate(idx):
+            jobs[j] = jobs[j][:5] + ((data[n], inv[n]),)
+            tdata[j] = (shape, n)
+        tbufs[shape] = (data, inv)
     images, scal = native.rows_f16s_multi(jobs)
+    tbufs = {shape: (data.transpose(1, 2).contiguous(), inv) for shape, (data, inv) in tbufs.items()}
     cache = {}
     key = lambda kind, w: (kind, w.data_ptr(), tuple(w.shape), tuple(w.stride()), w.dtype)
     for (w, kind, bias, partner), lay in zip(plan, layout):
@@ -439,6 +460,9 @@ def forward_scope(model, rows):
         j, sl = lay
         if kind == "plain":
             cache[key("w16s", w)] = ((images[j], scal[sl:sl + 1]), w)
+        elif kind == "plain_t":
+            shape, n = tdata[j]
+            cache[key("w16t", w)] = ((tbufs[shape][0][n], tbufs[shape][1][n]), w)
         elif kind == "gated":
             cache[key("w16s", w)] = ((images[j], lambda i=sl: scal[i:i + 1] / _K10), w)          # (only evaluated if someone asks for the raw l1)
             cache[key("w16s_bound", w)] = (scal[sl:sl + 2], w)

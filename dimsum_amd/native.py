@@ -630,7 +630,8 @@ def rows_f16s_multi(jobs):
     """ONE launch per 24 jobs (csrc/operand_split.hip, dimsum_rows_f16s_multi). jobs: list of (x, image, l1_slot, absmax_slot, l1_factor):
     x (R, K) float32 rows (or a (K,) vector: one row); image: build the F16Image; l1_slot / absmax_slot: index into the returned float32
     scalar buffer that receives l1_factor * max_r sum_k |x_rk| / max |x| (None: not wanted; several jobs may NOT share a slot's meaning but
-    may share a slot: the maximum over them lands there). -> ([F16Image or None per job], scalars)"""
+    may share a slot: the maximum over them lands there); an optional 6th element (data (R, K) float16, inv (R,) float32) makes the job
+    write its image there (e.g. slices of one buffer). -> ([F16Image or None per job], scalars)"""
     if not jobs:
         return [], None
     dev = jobs[0][0].device
@@ -638,7 +639,8 @@ def rows_f16s_multi(jobs):
     scal = torch.zeros(max(n_slots, 1), device=dev, dtype=torch.float32)
     arr = (_lib.F16sJob * len(jobs))()
     images, keep = [], []
-    for q, (x, image, l1_slot, abs_slot, factor) in zip(arr, jobs):
+    for q, job in zip(arr, jobs):
+        x, image, l1_slot, abs_slot, factor = job[:5]
         _gpu(x)
         x2 = x if x.dim() == 2 else x.reshape(1, -1)
         _check(x2.dtype == torch.float32 and x2.dim() == 2 and x2.stride(1) == 1 and x2.shape[1] % 4 == 0 and (x2.shape[0] == 1 or x2.stride(0) % 4 == 0),
@@ -646,7 +648,12 @@ def rows_f16s_multi(jobs):
         R, K = x2.shape
         q.src, q.rows, q.cols, q.src_row_stride = _ptr(x2), R, K, (x2.stride(0) if R > 1 else K)
         if image:
-            out, inv = torch.empty((R, K), device=dev, dtype=torch.float16), torch.empty((R,), device=dev, dtype=torch.float32)
+            if len(job) > 5:
+                out, inv = job[5]
+                _check(out.shape == (R, K) and out.dtype == torch.float16 and out.is_contiguous() and inv.shape == (R,) and inv.dtype == torch.float32 and inv.is_contiguous(),
+                       "rows_f16s_multi: a job's own destination must be a contiguous (R, K) float16 / (R,) float32 pair")
+            else:
+                out, inv = torch.empty((R, K), device=dev, dtype=torch.float16), torch.empty((R,), device=dev, dtype=torch.float32)
             q.dst, q.inv_scale_ptr, q.dst_row_stride = _ptr(out), _ptr(inv), K
             images.append(F16Image(out, inv))
         else:
