@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--variant", type=int, default=-1, help="ask for a forward kernel: lanes per channel 1 (64 channels per wave) / 2 / 4 / 16 (0 or -1: automatic)")
     ap.add_argument("--infer", action="store_true", help="forward as the model calls it at inference: no `out` / `x` stores (1.082 GB at the default shape)")
     ap.add_argument("--train-fwd", action="store_true", help="time the forward's training variant (also stores the states the backward consumes)")
+    ap.add_argument("--z16", action="store_true", help="--dt-fused with out_z as block-scaled fp16 (the launch of the headline forward: out_proj's operand image)")
     ap.add_argument("--dt-fused", action="store_true", help="forward with dt_proj inside the kernel (implies --infer): delta = W_dt x_dbl[:32] per tile on the matrix cores")
     a = ap.parse_args()
     from dimsum_amd import _lib
@@ -78,13 +79,13 @@ def main():
             return native.selective_scan_bwd(u, delta, A, Bm, Cm, Dv, z, bias, dout, x, out, dz, True, not a.no_out_z, ckpt=ck)
         s_ = u.element_size()       # (8 + out_z recompute) B D L s + 2 B N L (s + 4) + x
         nbytes = (8 if a.no_out_z else 9) * B * D * L * s_ + 2 * B * N * L * (s_ + 4) + B * D * ((L + 2047) // 2048) * 2 * N * 4 + (D * N + 2 * D) * 4
-    elif a.dt_fused:
+    elif a.dt_fused or a.z16:
         R = 32
         dt_w, dt_xt = torch.randn(D, R, device=dev) * 0.1, torch.randn(R + 2 * N, B * L, device=dev)[:R]
 
         def call():
-            return native.selective_scan_fwd(u, None, A, Bm, Cm, Dv, z, bias, True, need_out=False, need_x=False, dt_proj=(dt_w, dt_xt))
-        nbytes = 3 * B * D * L * 4 + 2 * B * N * L * 4 + (D * N + 2 * D) * 4 + (B * L * R + D * R) * 4
+            return native.selective_scan_fwd(u, None, A, Bm, Cm, Dv, z, bias, True, need_out=False, need_x=False, dt_proj=(dt_w, dt_xt), **({"out_z_f16": True} if a.z16 else {}))
+        nbytes = 3 * B * D * L * 4 + 2 * B * N * L * 4 + (D * N + 2 * D) * 4 + (B * L * R + D * R) * 4 - ((B * D * L * 2 - B * D * L // 2048 * 4) if a.z16 else 0)
     else:
         def call():
             return native.selective_scan_fwd(u, delta, A, Bm, Cm, Dv, z, bias, True, need_out=not a.infer, need_x=not a.infer, need_ckpt=a.train_fwd)

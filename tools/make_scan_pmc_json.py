@@ -10,10 +10,12 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
-INF, DT = " (inference: no out / x stores)", " (+ fused dt_proj: delta formed in the kernel, not read)"
+INF, DT, Z16 = " (inference: no out / x stores)", " (+ fused dt_proj: delta formed in the kernel, not read)", " (out_z as block-scaled fp16)"
 BWD = "ssm_scan_bwd_kernel (+ ssm_scan_bwd_reduce_kernel)"
 SPLIT4 = "ssm_scan_fwd_split_kernel<4 lanes per channel>"
 FILES = [   # (file suffix, bench kernel name, shape, which rocprof kernels to add up)
+    ("scan_fwd_z16", "ssm_scan_fwd_kernel" + INF + DT + Z16, (256, 1024, 256, 16), ["scan_fwd_kernel"]),
+    ("scan_fwd_z16_b128", "ssm_scan_fwd_kernel" + INF + DT + Z16, (128, 1024, 256, 16), ["scan_fwd_kernel"]),
     ("scan_fwd_dtfused", "ssm_scan_fwd_kernel" + INF + DT, (256, 1024, 256, 16), ["scan_fwd_kernel"]),
     ("scan_fwd_dtfused_b128", "ssm_scan_fwd_kernel" + INF + DT, (128, 1024, 256, 16), ["scan_fwd_kernel"]),
     ("scan_fwd_infer", "ssm_scan_fwd_kernel" + INF, (256, 1024, 256, 16), ["scan_fwd_kernel"]),

@@ -34,6 +34,8 @@ stats all --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg --no-box-probe --
 # PMC: forward as the headline runs it (inference: no out / x stores, dt_proj fused), the same without the fusion, the full reference
 # interface, forward + saved states, backward (as dimsum_amd.ops calls it: no out_z recompute; and with it; at the training leg's batch 64
 # and the block leg's 256), config-5 forward (inference / full interface), the long-sequence stress shape (one lane per state)
+bash tools/pmc_scan.sh $out/pmc_fwd_z16 --dmajor --z16 > $out/${tag}_scan_fwd_z16_pmc.txt 2>&1
+bash tools/pmc_scan.sh $out/pmc_fwd_z16_b128 --dmajor --z16 --B 128 > $out/${tag}_scan_fwd_z16_b128_pmc.txt 2>&1
 bash tools/pmc_scan.sh $out/pmc_fwd_dt --dmajor --dt-fused > $out/${tag}_scan_fwd_dtfused_pmc.txt 2>&1
 bash tools/pmc_scan.sh $out/pmc_fwd_inf --dmajor --infer > $out/${tag}_scan_fwd_infer_pmc.txt 2>&1
 bash tools/pmc_scan.sh $out/pmc_fwd --dmajor > $out/${tag}_scan_fwd_pmc.txt 2>&1
