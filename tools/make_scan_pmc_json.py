@@ -14,14 +14,14 @@ INF, DT, Z16 = " (inference: no out / x stores)", " (+ fused dt_proj: delta form
 BWD = "ssm_scan_bwd_kernel (+ ssm_scan_bwd_reduce_kernel)"
 SPLIT4 = "ssm_scan_fwd_split_kernel<4 lanes per channel>"
 FILES = [   # (file suffix, bench kernel name, shape, which rocprof kernels to add up)
-    ("scan_fwd_z16", "ssm_scan_fwd_kernel" + INF + DT + Z16, (256, 1024, 256, 16), ["_fwd_kernel<"]),
-    ("scan_fwd_z16_b128", "ssm_scan_fwd_kernel" + INF + DT + Z16, (128, 1024, 256, 16), ["_fwd_kernel<"]),
-    ("scan_fwd_dtfused", "ssm_scan_fwd_kernel" + INF + DT, (256, 1024, 256, 16), ["_fwd_kernel<"]),
-    ("scan_fwd_dtfused_b128", "ssm_scan_fwd_kernel" + INF + DT, (128, 1024, 256, 16), ["_fwd_kernel<"]),
-    ("scan_fwd_infer", "ssm_scan_fwd_kernel" + INF, (256, 1024, 256, 16), ["_fwd_kernel<"]),
-    ("scan_fwd", "ssm_scan_fwd_kernel", (256, 1024, 256, 16), ["_fwd_kernel<"]),
-    ("scan_fwd_train", "ssm_scan_fwd_kernel (+ saved states)", (256, 1024, 256, 16), ["_fwd_kernel<"]),
-    ("scan_fwd_train_b64", "ssm_scan_fwd_kernel (+ saved states)", (64, 1024, 256, 16), ["_fwd_kernel<"]),
+    ("scan_fwd_z16", "ssm_scan_fwd_kernel" + INF + DT + Z16, (256, 1024, 256, 16), ["fwd_kernel<"]),
+    ("scan_fwd_z16_b128", "ssm_scan_fwd_kernel" + INF + DT + Z16, (128, 1024, 256, 16), ["fwd_kernel<"]),
+    ("scan_fwd_dtfused", "ssm_scan_fwd_kernel" + INF + DT, (256, 1024, 256, 16), ["fwd_kernel<"]),
+    ("scan_fwd_dtfused_b128", "ssm_scan_fwd_kernel" + INF + DT, (128, 1024, 256, 16), ["fwd_kernel<"]),
+    ("scan_fwd_infer", "ssm_scan_fwd_kernel" + INF, (256, 1024, 256, 16), ["fwd_kernel<"]),
+    ("scan_fwd", "ssm_scan_fwd_kernel", (256, 1024, 256, 16), ["fwd_kernel<"]),
+    ("scan_fwd_train", "ssm_scan_fwd_kernel (+ saved states)", (256, 1024, 256, 16), ["fwd_kernel<"]),
+    ("scan_fwd_train_b64", "ssm_scan_fwd_kernel (+ saved states)", (64, 1024, 256, 16), ["fwd_kernel<"]),
     ("scan_bwd", BWD + ", no out_z recompute", (256, 1024, 256, 16), ["scan_bwd_kernel", "scan_bwd_reduce_kernel"]),
     ("scan_bwd_outz", BWD, (256, 1024, 256, 16), ["scan_bwd_kernel", "scan_bwd_reduce_kernel"]),
     ("scan_bwd_b64", BWD + ", no out_z recompute", (64, 1024, 256, 16), ["scan_bwd_kernel", "scan_bwd_reduce_kernel"]),
