@@ -1122,12 +1122,14 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
 // of a tile period lets one half of the chip store while the other half multiplies; later rounds inherit the phase (a workgroup starts when
 // one ends on its CU). Workgroups sharing a CU get the same delay (their waves pair up on the SIMDs: section 3.5 of DESIGN.md).
 __device__ __forceinline__ void cu_stagger(const Args &p, int first_round) {
+#ifdef DIMSUM_GEMM_TUNE      // (tuning builds only, like the other schedule variants: measured 0 .. +4 %, section 3.5 of DESIGN.md)
     if (p.stagger > 0 && (int)blockIdx.x < first_round) {
         unsigned hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         if ((hw >> 8) & 1u)                              // CU_ID bit 0
             for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(16);
     }
+#endif
 }
 
 template <int kOp, int kEpi, int kVar = 0>

@@ -216,7 +216,7 @@ def main():
     ap.add_argument("--inner", type=int, default=10)
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--tune", action="store_true")
-    ap.add_argument("--stagger", default="", help="--tiles: also time these start delays of the odd CUs (x 1024 cycles), e.g. 4,8,16")
+    ap.add_argument("--stagger", default="", help="--tiles: also time these start delays of the odd CUs (x 1024 cycles), e.g. 4,8,16 (a library built with -DDIMSUM_GEMM_TUNE: tools/scratch/build_variant.sh)")
     ap.add_argument("--tiles", action="store_true", help="A / B of the 256-row against the 128-row tile variant on the scaled-fp16 launch shapes")
     ap.add_argument("--pmc-run", action="store_true", help="a few launches of the w12-shape kernels (under rocprofv3 --pmc)")
     ap.add_argument("--pmc-run-tn", action="store_true", help="a few launches of the dW12-shape TN kernels (three-piece row stacks, pairs) and of the library's batched TN GEMM")
