@@ -158,7 +158,7 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
 }
 
 // M128 variant (kVarM128): 128 x 256 output tiles by 4-wave workgroups with an 80-KB ring, TWO workgroups per CU. A 256 x 256 tile's
-// epilogue (fp32 stores at the ~12 B/clk a CU can push, or the gated GeLU's VALU work) runs with the matrix pipe idle, and with one
+// epilogue (fp32 stores at the chip's ~5 TB/s shared by all CUs storing at once, or the gated GeLU's VALU work) runs with the matrix pipe idle, and with one
 // workgroup per CU nothing else is resident to use it: a third of a K = 1024 launch, half of a K = 512 one (scaled-fp16 operands: one
 // product per element, short K). Two independent workgroups per CU overlap one's epilogue with the other's K loop. Same wave tile
 // (a wave owns all 128 rows x 64 columns: acc[mi][ni][4][2], mi = row half), same 16-MFMA phases and operand registers; the two A
