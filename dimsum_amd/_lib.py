@@ -171,7 +171,7 @@ def load():
     if hasattr(lib, "dimsum_ssm_scan_fwd_variant"):
         lib.dimsum_ssm_scan_fwd_variant.restype = C.c_int
         lib.dimsum_ssm_scan_fwd_variant.argtypes = [C.POINTER(SsmParams)]
-    if lib.dimsum_abi_version() != 15:
+    if lib.dimsum_abi_version() != 16:
         raise RuntimeError("dimsum_amd: libdimsum_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

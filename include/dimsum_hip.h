@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DIMSUM_ABI_VERSION 15
+#define DIMSUM_ABI_VERSION 16
 
 typedef enum {
     DIMSUM_OK = 0,
