@@ -79,6 +79,31 @@ def test_struct_sizes_match_header():
     assert sizes == [ctypes.sizeof(m) for m in mirrors]
 
 
+def test_field_offsets_of_the_round5_fields_match_header():
+    """the fields added in round 5 sit where the header puts them (a swap of two equally sized fields would pass the sizeof test)"""
+    import subprocess
+    import tempfile
+    from dimsum_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fields = [("dimsum_ssm_params_t", _lib.SsmParams, ["dt_w_ptr", "dt_x_ptr", "dt_w_row_stride", "dt_x_row_stride", "dt_rank", "out_z_f16", "out_z_scale_ptr", "out_z_scale_ld"]),
+              ("dimsum_xattn_params_t", _lib.XattnParams, ["qkv_f16"]),
+              ("dimsum_gemm_params_t", _lib.GemmParams, ["qkv_q_cols", "conv_weight_ptr", "conv_bias_ptr", "conv_rows", "conv_width", "conv_seq", "conv_weight_ld",
+                                                         "a_block_inv_ptr", "a_block_inv_ld", "tn_pair_a_cols", "tune_variant", "tune_reserved"])]
+    body = "".join(f'printf("%zu ", offsetof({st}, {f}));' for st, _, fs in fields for f in fs)
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "dimsum_hip.h"\nint main(){' + body + 'return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "o.c"), "w").write(src)
+        subprocess.run(["gcc", "-I", os.path.join(root, "include"), os.path.join(d, "o.c"), "-o", os.path.join(d, "o")], check=True)
+        offs = [int(v) for v in subprocess.run([os.path.join(d, "o")], capture_output=True, text=True, check=True).stdout.split()]
+    assert offs == [getattr(m, f).offset for _, m, fs in fields for f in fs]
+    # the job table of dimsum_rows_f16s_multi
+    src = '#include <stdio.h>\n#include "dimsum_hip.h"\nint main(){printf("%zu", sizeof(dimsum_f16s_job_t));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "j.c"), "w").write(src)
+        subprocess.run(["gcc", "-I", os.path.join(root, "include"), os.path.join(d, "j.c"), "-o", os.path.join(d, "j")], check=True)
+        assert int(subprocess.run([os.path.join(d, "j")], capture_output=True, text=True, check=True).stdout) == ctypes.sizeof(_lib.F16sJob)
+
+
 def test_ops_fail_loudly_without_gpu():
     from dimsum_amd import native
     from dimsum_amd.ops import causal_conv1d_fn, rms_norm_fn, selective_scan_fn
