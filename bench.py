@@ -112,11 +112,12 @@ class ScanTimer:
                 if not timer.enabled:
                     return fn(P, stream)
                 p = P.fwd if which == "bwd" else P
+                x = p.ext.contents if p.ext else _lib.attach_ext(p, _lib.SsmExt)       # dimsum_ssm_ext_t: what the call uses beyond the reference interface
                 if which == "fwd":
-                    kernel = (_lib.SCAN_FWD_KERNELS[lib.dimsum_ssm_scan_fwd_variant(p)] + (" (+ saved states)" if p.ckpt_ptr else "")
+                    kernel = (_lib.SCAN_FWD_KERNELS[lib.dimsum_ssm_scan_fwd_variant(p)] + (" (+ saved states)" if x.ckpt_ptr else "")
                               + ("" if (p.out_ptr and p.x_ptr) else " (inference: no out / x stores)")
-                              + (" (+ fused dt_proj: delta formed in the kernel, not read)" if p.dt_w_ptr else "")
-                              + (" (out_z as block-scaled fp16)" if p.out_z_f16 else ""))
+                              + (" (+ fused dt_proj: delta formed in the kernel, not read)" if x.dt_w_ptr else "")
+                              + (" (out_z as block-scaled fp16)" if x.out_z_f16 else ""))
                 else:
                     kernel = "ssm_scan_bwd_kernel (+ ssm_scan_bwd_reduce_kernel)" + ("" if p.out_z_ptr else ", no out_z recompute")
                 # HIP events recorded at the begin of the call's first kernel and the end of its last one (the per-call
@@ -130,9 +131,9 @@ class ScanTimer:
                     e1.record()
                 else:
                     e0, e1 = timer.pool_event(lib), timer.pool_event(lib)
-                    p.timing_start_event, p.timing_stop_event = e0, e1
+                    x.timing_start_event, x.timing_stop_event = e0, e1
                     rc = fn(P, stream)
-                    p.timing_start_event = p.timing_stop_event = None
+                    x.timing_start_event = x.timing_stop_event = None
                 s = {_lib.F32: 4}.get(p.dtype, 2)
                 shape = (p.batch, p.dim, p.seqlen, p.dstate)
                 # algorithmic bytes = SURVEY 8(d)'s formula for the scan this launch performs (full interface, or its inference-only lower bound
@@ -140,8 +141,8 @@ class ScanTimer:
                 # inside it (delta is formed on the matrix cores instead of being read)
                 nbytes = (scan_bwd_bytes(*shape, p.n_groups, s, recompute_out_z=bool(p.out_z_ptr)) if which == "bwd"
                           else scan_bytes(*shape, p.n_groups, s, has_out=bool(p.out_ptr), has_x=bool(p.x_ptr)))
-                moved = nbytes if (which == "bwd" or not (p.dt_w_ptr or p.out_z_f16)) else scan_bytes(*shape, p.n_groups, s, has_out=bool(p.out_ptr), has_x=bool(p.x_ptr),
-                                                                                                      dt_rank=p.dt_rank if p.dt_w_ptr else 0, out_z_f16=bool(p.out_z_f16))
+                moved = nbytes if (which == "bwd" or not (x.dt_w_ptr or x.out_z_f16)) else scan_bytes(*shape, p.n_groups, s, has_out=bool(p.out_ptr), has_x=bool(p.x_ptr),
+                                                                                                      dt_rank=x.dt_rank if x.dt_w_ptr else 0, out_z_f16=bool(x.out_z_f16))
                 timer.records[which].append((e0, e1, nbytes, shape, kernel, moved))
                 return rc
 

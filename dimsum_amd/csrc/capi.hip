@@ -10,6 +10,7 @@ extern "C" const char *dimsum_status_string(int status) {
         case DIMSUM_ERR_STRIDE: return "unsupported stride or alignment (innermost stride must be 1; in-tile offsets must fit 31 bits)";
         case DIMSUM_ERR_UNSUPPORTED: return "valid in the reference but out of scope here (complex A, constant B/C)";
         case DIMSUM_ERR_LAUNCH: return "HIP kernel launch failed";
+        case DIMSUM_ERR_ABI: return "struct_size of a parameter struct (or of its extension) does not match this library: the caller was built against another include/dimsum_hip.h";
         default: return "unknown status";
     }
 }

@@ -217,7 +217,9 @@ template <typename T> static int launch_conv_bwd(const dimsum_conv_bwd_params_t 
 
 extern "C" int dimsum_causal_conv1d_fwd(const dimsum_conv_params_t *p, void *stream) {
     using namespace dimsum;
-    if (!p || !p->out_ptr) return DIMSUM_ERR_NULL;
+    if (!p) return DIMSUM_ERR_NULL;
+    if (p->struct_size != sizeof(dimsum_conv_params_t)) return DIMSUM_ERR_ABI;
+    if (!p->out_ptr) return DIMSUM_ERR_NULL;
     const int rc = conv_check(*p);
     if (rc != DIMSUM_OK) return rc;
     if (p->batch == 0) return DIMSUM_OK;
@@ -231,7 +233,9 @@ extern "C" int dimsum_causal_conv1d_fwd(const dimsum_conv_params_t *p, void *str
 
 extern "C" int dimsum_causal_conv1d_bwd(const dimsum_conv_bwd_params_t *q, void *stream) {
     using namespace dimsum;
-    if (!q || !q->dout_ptr || !q->dx_ptr || !q->dweight_ptr) return DIMSUM_ERR_NULL;
+    if (!q) return DIMSUM_ERR_NULL;
+    if (q->struct_size != sizeof(dimsum_conv_bwd_params_t)) return DIMSUM_ERR_ABI;
+    if (!q->dout_ptr || !q->dx_ptr || !q->dweight_ptr) return DIMSUM_ERR_NULL;
     const int rc = conv_check(q->fwd);
     if (rc != DIMSUM_OK) return rc;
     if (q->fwd.batch == 0) return DIMSUM_OK;

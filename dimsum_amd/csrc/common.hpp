@@ -5,6 +5,7 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
+#include <string.h>
 
 #include <initializer_list>
 
@@ -171,10 +172,91 @@ __device__ __forceinline__ float softplus_if(float x, bool flag) {
     return flag ? sp : x;
 }
 
+// ---- internal parameter blocks -----------------------------------------------------------------------------------------
+// The kernels take ONE flat parameter block by value. The public structs (include/dimsum_hip.h) are versioned: a reference-shaped base
+// struct + an optional extension behind `ext`. The entry points validate the sizes and flatten base + extension into these blocks
+// (args_from below); fields of an extension the caller's struct_size does not cover read as 0 / NULL.
+struct ssm_args_t {
+    int32_t batch, dim, seqlen, dstate, n_groups, n_chunks;
+    int32_t delta_softplus, dtype;
+    int64_t A_d_stride, A_dstate_stride;
+    int64_t B_batch_stride, B_group_stride, B_dstate_stride;
+    int64_t C_batch_stride, C_group_stride, C_dstate_stride;
+    int64_t u_batch_stride, u_d_stride;
+    int64_t delta_batch_stride, delta_d_stride;
+    int64_t z_batch_stride, z_d_stride;
+    int64_t out_batch_stride, out_d_stride;
+    int64_t out_z_batch_stride, out_z_d_stride;
+    const void *A_ptr, *B_ptr, *C_ptr, *D_ptr, *u_ptr, *delta_ptr, *delta_bias_ptr, *z_ptr;
+    void *out_ptr, *x_ptr, *out_z_ptr, *ckpt_ptr;
+    int32_t kernel_variant;
+    void *timing_start_event, *timing_stop_event;
+    int64_t out_z_lo_offset;
+    const void *dt_w_ptr, *dt_x_ptr;
+    int64_t dt_w_row_stride, dt_x_row_stride;
+    int32_t dt_rank, out_z_f16;
+    void *out_z_scale_ptr;
+    int64_t out_z_scale_ld;
+};
+
+struct ssm_bwd_args_t {
+    ssm_args_t fwd;
+    int64_t dout_batch_stride, dout_d_stride;
+    int64_t dA_d_stride, dA_dstate_stride;
+    int64_t dB_batch_stride, dB_group_stride, dB_dstate_stride;
+    int64_t dC_batch_stride, dC_group_stride, dC_dstate_stride;
+    int64_t du_batch_stride, du_d_stride;
+    int64_t dz_batch_stride, dz_d_stride;
+    int64_t ddelta_batch_stride, ddelta_d_stride;
+    const void *dout_ptr;
+    void *dA_ptr, *dB_ptr, *dC_ptr, *dD_ptr, *du_ptr, *dz_ptr, *ddelta_ptr, *ddelta_bias_ptr, *workspace_ptr;
+    int64_t workspace_bytes;
+};
+
+// a caller's extension struct copied into a zero-filled one of the library's size: DIMSUM_ERR_ABI when it is larger than the library knows
+// (or too small to hold its own struct_size); NULL = all zeros
+template <typename Ext> inline int ext_from(const Ext *e, Ext &out) {
+    memset(&out, 0, sizeof(Ext));
+    if (!e) return DIMSUM_OK;
+    const uint32_t n = e->struct_size;
+    if (n < sizeof(uint32_t) || n > sizeof(Ext)) return DIMSUM_ERR_ABI;
+    memcpy(&out, e, n);
+    return DIMSUM_OK;
+}
+
+// base (+ ext) -> flat block. check_size: the entry points of the forward check p->struct_size; inside a backward struct only the outer
+// struct's size is checked (include/dimsum_hip.h, "Versioning")
+inline int ssm_args_from(const dimsum_ssm_params_t *p, ssm_args_t &a, bool check_size) {
+    if (!p) return DIMSUM_ERR_NULL;
+    if (check_size && p->struct_size != sizeof(dimsum_ssm_params_t)) return DIMSUM_ERR_ABI;
+    dimsum_ssm_ext_t e;
+    const int rc = ext_from(p->ext, e);
+    if (rc != DIMSUM_OK) return rc;
+    a.batch = p->batch; a.dim = p->dim; a.seqlen = p->seqlen; a.dstate = p->dstate; a.n_groups = p->n_groups; a.n_chunks = p->n_chunks;
+    a.delta_softplus = p->delta_softplus; a.dtype = p->dtype;
+    a.A_d_stride = p->A_d_stride; a.A_dstate_stride = p->A_dstate_stride;
+    a.B_batch_stride = p->B_batch_stride; a.B_group_stride = p->B_group_stride; a.B_dstate_stride = p->B_dstate_stride;
+    a.C_batch_stride = p->C_batch_stride; a.C_group_stride = p->C_group_stride; a.C_dstate_stride = p->C_dstate_stride;
+    a.u_batch_stride = p->u_batch_stride; a.u_d_stride = p->u_d_stride;
+    a.delta_batch_stride = p->delta_batch_stride; a.delta_d_stride = p->delta_d_stride;
+    a.z_batch_stride = p->z_batch_stride; a.z_d_stride = p->z_d_stride;
+    a.out_batch_stride = p->out_batch_stride; a.out_d_stride = p->out_d_stride;
+    a.out_z_batch_stride = p->out_z_batch_stride; a.out_z_d_stride = p->out_z_d_stride;
+    a.A_ptr = p->A_ptr; a.B_ptr = p->B_ptr; a.C_ptr = p->C_ptr; a.D_ptr = p->D_ptr; a.u_ptr = p->u_ptr; a.delta_ptr = p->delta_ptr;
+    a.delta_bias_ptr = p->delta_bias_ptr; a.z_ptr = p->z_ptr;
+    a.out_ptr = p->out_ptr; a.x_ptr = p->x_ptr; a.out_z_ptr = p->out_z_ptr;
+    a.ckpt_ptr = e.ckpt_ptr; a.kernel_variant = e.kernel_variant;
+    a.timing_start_event = e.timing_start_event; a.timing_stop_event = e.timing_stop_event;
+    a.out_z_lo_offset = e.out_z_lo_offset;
+    a.dt_w_ptr = e.dt_w_ptr; a.dt_x_ptr = e.dt_x_ptr; a.dt_w_row_stride = e.dt_w_row_stride; a.dt_x_row_stride = e.dt_x_row_stride;
+    a.dt_rank = e.dt_rank; a.out_z_f16 = e.out_z_f16; a.out_z_scale_ptr = e.out_z_scale_ptr; a.out_z_scale_ld = e.out_z_scale_ld;
+    return DIMSUM_OK;
+}
+
 // ---- host ----------------------------------------------------------------------------------------------------------
 inline int launch_status() { return hipGetLastError() == hipSuccess ? DIMSUM_OK : DIMSUM_ERR_LAUNCH; }
 
-// Kernel-boundary timing (dimsum_ssm_params_t.timing_start_event / timing_stop_event): hipExtLaunchKernelGGL records the events
+// Kernel-boundary timing (dimsum_ssm_ext_t.timing_start_event / timing_stop_event): hipExtLaunchKernelGGL records the events
 // at the begin / end of the kernel's own dispatch packet -- what rocprofv3 reports -- instead of as separate commands around it.
 #define DIMSUM_LAUNCH_EV(KERNEL, GRID, BLOCK, STREAM, EV0, EV1, ...)                                              \
     do {                                                                                                          \

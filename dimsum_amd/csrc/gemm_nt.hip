@@ -5,7 +5,8 @@
 namespace dimsum {
 namespace gemm_nt {
 
-template <int kOp, int kEpi, int kVar = 0> int launch(const Args &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+template <int kOp, int kEpi, int kVar = 0> int launch(const Args &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1, int *probe) {
+    if (probe) { *probe = 0; return DIMSUM_OK; }
     const dim3 grid((unsigned)(a.tiles_m * a.tiles_n)), block(512);
     if (e0 || e1) hipExtLaunchKernelGGL((gemm_nt_kernel<kOp, kEpi, kVar>), grid, block, 0, s, e0, e1, 0, a);
     else hipLaunchKernelGGL((gemm_nt_kernel<kOp, kEpi, kVar>), grid, block, 0, s, a);
@@ -13,7 +14,8 @@ template <int kOp, int kEpi, int kVar = 0> int launch(const Args &a, hipStream_t
 }
 
 // the 128 x 256-tile variant (4-wave workgroups, two per CU): launches whose epilogue is a large share of a tile's time (short K)
-template <int kOp, int kEpi, int kVar = 0> int launch_m128(const Args &a0, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+template <int kOp, int kEpi, int kVar = 0> int launch_m128(const Args &a0, hipStream_t s, hipEvent_t e0, hipEvent_t e1, int *probe) {
+    if (probe) { *probe = 1; return DIMSUM_OK; }
     Args a = a0;
     a.tiles_m = a.M / 128;
     a.group_m = a.tiles_m <= 32 ? a.tiles_m : 2 * a0.group_m;     // the same L2 patch in rows
@@ -24,20 +26,19 @@ template <int kOp, int kEpi, int kVar = 0> int launch_m128(const Args &a0, hipSt
 }
 
 // persistent workgroups (kVarPersist): one per CU (a multiple of 8: the tile walk's XCD ranges), each walking the tile list as one K stream
-inline int persist_grid() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        n = cus >= 8 ? cus / 8 * 8 : 8;
-    }
-    return n;
+inline int persist_grid() {        // queried per call for the CURRENT device (no cached state: several devices per process, any thread)
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus >= 8 ? cus / 8 * 8 : 8;
 }
-inline bool persist_ok(const Args &a, int tune_variant) {       // 514 forces it, 513 forbids it (A / B runs)
+// the persistent stream needs an even number (>= 4) of K tiles, more tiles than workgroups and plain (un-aliased) operands; tune_variant 512 / 513
+// forbid it (A / B runs), 514 asks for it where a launch would not take it by default (the fp32 gate + residual epilogue) -- under the same conditions
+inline bool persist_ok(const Args &a, int tune_variant) {
     const int nk = a.K / kBK;
     return tune_variant != 513 && tune_variant != 512 && nk >= 4 && nk % 2 == 0 && a.tiles_m * a.tiles_n > persist_grid() && a.a_alias_tiles == 0 && a.b_alias_tiles == 0;
 }
-template <int kOp, int kEpi, int kVar = 0> int launch_persist(const Args &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+template <int kOp, int kEpi, int kVar = 0> int launch_persist(const Args &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1, int *probe) {
+    if (probe) { *probe = 2; return DIMSUM_OK; }
     const dim3 grid((unsigned)persist_grid()), block(512);
     if (e0 || e1) hipExtLaunchKernelGGL((gemm_nt_persist_kernel<kOp, kEpi, kVar>), grid, block, 0, s, e0, e1, 0, a);
     else hipLaunchKernelGGL((gemm_nt_persist_kernel<kOp, kEpi, kVar>), grid, block, 0, s, a);
@@ -45,17 +46,45 @@ template <int kOp, int kEpi, int kVar = 0> int launch_persist(const Args &a, hip
 }
 
 // scaled-fp16 operands (one product per element): both tile shapes are built
-template <int kEpi, int kVar = 0> int launch_f16(const Args &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1, bool m128) {
-    return m128 ? launch_m128<kOpF16, kEpi, kVar>(a, s, e0, e1) : launch<kOpF16, kEpi, kVar>(a, s, e0, e1);
+template <int kEpi, int kVar = 0> int launch_f16(const Args &a, hipStream_t s, hipEvent_t e0, hipEvent_t e1, bool m128, int *probe) {
+    return m128 ? launch_m128<kOpF16, kEpi, kVar>(a, s, e0, e1, probe) : launch<kOpF16, kEpi, kVar>(a, s, e0, e1, probe);
+}
+
+// base + extension of the public parameter struct, flattened (include/dimsum_hip.h "Versioning"): what the entry points below read
+struct gemm_flat_t : dimsum_gemm_ext_t {
+    int32_t m, n, k, operand_dtype, epilogue;
+    float out_scale;
+    int64_t lda, ldb, ldc;
+    const void *a_ptr, *b_ptr, *bias_ptr;
+    void *c_ptr;
+    const void *a_inv_scale_ptr, *b_inv_scale_ptr;
+};
+static int gemm_flat_from(const dimsum_gemm_params_t *p, gemm_flat_t &f) {
+    if (!p) return DIMSUM_ERR_NULL;
+    if (p->struct_size != sizeof(dimsum_gemm_params_t)) return DIMSUM_ERR_ABI;
+    const int rc = ext_from<dimsum_gemm_ext_t>(p->ext, f);
+    if (rc != DIMSUM_OK) return rc;
+    f.m = p->m; f.n = p->n; f.k = p->k; f.operand_dtype = p->operand_dtype; f.epilogue = p->epilogue; f.out_scale = p->out_scale;
+    f.lda = p->lda; f.ldb = p->ldb; f.ldc = p->ldc;
+    f.a_ptr = p->a_ptr; f.b_ptr = p->b_ptr; f.bias_ptr = p->bias_ptr; f.c_ptr = p->c_ptr;
+    f.a_inv_scale_ptr = p->a_inv_scale_ptr; f.b_inv_scale_ptr = p->b_inv_scale_ptr;
+    return DIMSUM_OK;
 }
 
 }  // namespace gemm_nt
 }  // namespace dimsum
 
-extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
+// `probe` != NULL: nothing is launched, *probe receives the kernel family (0 = 256-row tiles, 1 = 128-row tiles, 2 = persistent stream)
+static int gemm_nt_run(const dimsum_gemm_params_t *pub, void *stream, int *probe) {
     using namespace dimsum;
     using namespace dimsum::gemm_nt;
-    if (!p || !p->a_ptr || !p->b_ptr || !p->c_ptr) return DIMSUM_ERR_NULL;
+    gemm_flat_t flat;
+    {
+        const int frc = gemm_flat_from(pub, flat);
+        if (frc != DIMSUM_OK) return frc;
+    }
+    const gemm_flat_t *p = &flat;
+    if (!p->a_ptr || !p->b_ptr || !p->c_ptr) return DIMSUM_ERR_NULL;
     if (p->operand_dtype != DIMSUM_F16 && p->operand_dtype != DIMSUM_BF16) return DIMSUM_ERR_DTYPE;
     if (p->m <= 0 || p->n <= 0 || p->k < 2 * kBK || p->m % kBM != 0 || p->k % kBK != 0 || p->n % 4 != 0) return DIMSUM_ERR_SHAPE;
     // a_alias_rows = C: the A rows are [hi | lo] pairs (2 C columns) read as the left image [hi | hi | lo] over k = 3 C
@@ -117,8 +146,8 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
         a.N = p->n;
         a.tiles_n = (p->n + kBN - 1) / kBN;
         constexpr int kShipR = kVarFullLineStores | kVarNtStores;
-        if (!bf && !m128 && p->tune_variant == 514 && p->n % kBN == 0 && persist_ok(a, p->tune_variant)) return launch_persist<kOpF16, kEpiF32GateRes, kShipR>(a, s, e0, e1);     // (A / B only: see DESIGN 3.5)
-        return bf ? launch<kOpBf16, kEpiF32GateRes, kShipR>(a, s, e0, e1) : launch_f16<kEpiF32GateRes, kShipR>(a, s, e0, e1, m128);
+        if (!bf && !m128 && p->tune_variant == 514 && p->n % kBN == 0 && persist_ok(a, p->tune_variant)) return launch_persist<kOpF16, kEpiF32GateRes, kShipR>(a, s, e0, e1, probe);     // (A / B only: see DESIGN 3.5)
+        return bf ? launch<kOpBf16, kEpiF32GateRes, kShipR>(a, s, e0, e1, probe) : launch_f16<kEpiF32GateRes, kShipR>(a, s, e0, e1, m128, probe);
     }
     if (p->epilogue == DIMSUM_GEMM_EPI_F16_QKV) {
         if (bf || !a.sa || !p->gate_bound_ptr) return DIMSUM_ERR_NULL;
@@ -135,7 +164,7 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
         a.q_cols = p->qkv_q_cols;
         a.N = p->n;
         a.tiles_n = (p->n + kBN - 1) / kBN;
-        return launch_f16<kEpiF16Qkv>(a, s, e0, e1, p->tune_variant == 512 || (p->tune_variant == 0 && p->k <= 576));
+        return launch_f16<kEpiF16Qkv>(a, s, e0, e1, p->tune_variant == 512 || (p->tune_variant == 0 && p->k <= 576), probe);
     }
     if (p->epilogue == DIMSUM_GEMM_EPI_F32_CONV) {
         if (!p->conv_weight_ptr) return DIMSUM_ERR_NULL;
@@ -150,7 +179,7 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
         a.N = p->n;
         a.tiles_n = (p->n + kBN - 1) / kBN;
         constexpr int kShipC = kVarFullLineStores | kVarNtStores;
-        return bf ? launch<kOpBf16, kEpiF32Conv, kShipC>(a, s, e0, e1) : launch_f16<kEpiF32Conv, kShipC>(a, s, e0, e1, p->tune_variant == 512 || (p->tune_variant == 0 && p->k <= 576));
+        return bf ? launch<kOpBf16, kEpiF32Conv, kShipC>(a, s, e0, e1, probe) : launch_f16<kEpiF32Conv, kShipC>(a, s, e0, e1, p->tune_variant == 512 || (p->tune_variant == 0 && p->k <= 576), probe);
     }
     if (p->epilogue == DIMSUM_GEMM_EPI_F32 || p->epilogue == DIMSUM_GEMM_EPI_F32_BIAS) {
         if (p->ldc % 4 != 0 || p->ldc < p->n || !aligned_to<char>(p->c_ptr, 16)) return DIMSUM_ERR_STRIDE;
@@ -161,26 +190,26 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
         a.N = p->n;
         a.tiles_n = (p->n + kBN - 1) / kBN;
         constexpr int kShip = kVarFullLineStores | kVarNtStores;      // 128-byte row segments, streaming stores (tools/bench_gemm.py --tune)
-        if (bias) return bf ? launch<kOpBf16, kEpiF32Bias, kShip>(a, s, e0, e1) : launch_f16<kEpiF32Bias, kShip>(a, s, e0, e1, m128);
+        if (bias) return bf ? launch<kOpBf16, kEpiF32Bias, kShip>(a, s, e0, e1, probe) : launch_f16<kEpiF32Bias, kShip>(a, s, e0, e1, m128, probe);
 #ifdef DIMSUM_GEMM_TUNE      // tuning builds only (tools/scratch/build_variant.sh ... -DDIMSUM_GEMM_TUNE): schedule / store-policy variants of the plain kernel
         if (bf) switch (p->tune_variant) {
             case 0: case 512: case 513: break;
-            case 100: return launch<kOpBf16, kEpiF32, 0>(a, s, e0, e1);
-            case 1: return launch<kOpBf16, kEpiF32, 1>(a, s, e0, e1);
-            case 2: return launch<kOpBf16, kEpiF32, 2>(a, s, e0, e1);
-            case 4: return launch<kOpBf16, kEpiF32, 4>(a, s, e0, e1);
-            case 8: return launch<kOpBf16, kEpiF32, 8>(a, s, e0, e1);
-            case 12: return launch<kOpBf16, kEpiF32, 12>(a, s, e0, e1);
-            case 16: return launch<kOpBf16, kEpiF32, 16>(a, s, e0, e1);
-            case 3: return launch<kOpBf16, kEpiF32, 3>(a, s, e0, e1);
-            case 40: return launch<kOpBf16, kEpiF32, 40>(a, s, e0, e1);
-            case 44: return launch<kOpBf16, kEpiF32, 44>(a, s, e0, e1);
-            case 72: return launch<kOpBf16, kEpiF32, 72>(a, s, e0, e1);
-            case 104: return launch<kOpBf16, kEpiF32, 104>(a, s, e0, e1);
+            case 100: return launch<kOpBf16, kEpiF32, 0>(a, s, e0, e1, probe);
+            case 1: return launch<kOpBf16, kEpiF32, 1>(a, s, e0, e1, probe);
+            case 2: return launch<kOpBf16, kEpiF32, 2>(a, s, e0, e1, probe);
+            case 4: return launch<kOpBf16, kEpiF32, 4>(a, s, e0, e1, probe);
+            case 8: return launch<kOpBf16, kEpiF32, 8>(a, s, e0, e1, probe);
+            case 12: return launch<kOpBf16, kEpiF32, 12>(a, s, e0, e1, probe);
+            case 16: return launch<kOpBf16, kEpiF32, 16>(a, s, e0, e1, probe);
+            case 3: return launch<kOpBf16, kEpiF32, 3>(a, s, e0, e1, probe);
+            case 40: return launch<kOpBf16, kEpiF32, 40>(a, s, e0, e1, probe);
+            case 44: return launch<kOpBf16, kEpiF32, 44>(a, s, e0, e1, probe);
+            case 72: return launch<kOpBf16, kEpiF32, 72>(a, s, e0, e1, probe);
+            case 104: return launch<kOpBf16, kEpiF32, 104>(a, s, e0, e1, probe);
             default: return DIMSUM_ERR_UNSUPPORTED;
         }
 #endif
-        return bf ? launch<kOpBf16, kEpiF32, kShip>(a, s, e0, e1) : launch_f16<kEpiF32, kShip>(a, s, e0, e1, m128);
+        return bf ? launch<kOpBf16, kEpiF32, kShip>(a, s, e0, e1, probe) : launch_f16<kEpiF32, kShip>(a, s, e0, e1, m128, probe);
     }
     if (p->epilogue == DIMSUM_GEMM_EPI_GATED_GELU_SPLIT3 || p->epilogue == DIMSUM_GEMM_EPI_GATED_GELU_F16) {
         // b_ptr: the (2 F, K) weight of w12; n = 2 F; output: (M, 3 F) bf16 left image [hi | hi | lo] or (M, F) fp16
@@ -209,20 +238,34 @@ extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) {
                 return DIMSUM_ERR_STRIDE;
             a.x12 = reinterpret_cast<float *>(p->x12_ptr);
             a.ldx = p->x12_ld;
-            return launch<kOpBf16, kEpiGatedSplit3, kVarKeepX12>(a, s, e0, e1);
+            return launch<kOpBf16, kEpiGatedSplit3, kVarKeepX12>(a, s, e0, e1, probe);
         }
-        if (img) return bf ? launch<kOpBf16, kEpiGatedSplit3>(a, s, e0, e1) : launch<kOpF16, kEpiGatedSplit3>(a, s, e0, e1);
-        if (!bf && !m128 && F % 128 == 0 && persist_ok(a, p->tune_variant)) return launch_persist<kOpF16, kEpiGatedF16>(a, s, e0, e1);
-        return bf ? launch<kOpBf16, kEpiGatedF16>(a, s, e0, e1) : launch_f16<kEpiGatedF16>(a, s, e0, e1, m128);
+        if (img) return bf ? launch<kOpBf16, kEpiGatedSplit3>(a, s, e0, e1, probe) : launch<kOpF16, kEpiGatedSplit3>(a, s, e0, e1, probe);
+        if (!bf && !m128 && F % 128 == 0 && persist_ok(a, p->tune_variant)) return launch_persist<kOpF16, kEpiGatedF16>(a, s, e0, e1, probe);
+        return bf ? launch<kOpBf16, kEpiGatedF16>(a, s, e0, e1, probe) : launch_f16<kEpiGatedF16>(a, s, e0, e1, m128, probe);
     }
     return DIMSUM_ERR_UNSUPPORTED;
 }
 
+extern "C" int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream) { return gemm_nt_run(p, stream, nullptr); }
+
+extern "C" int dimsum_gemm_nt_kernel_for(const dimsum_gemm_params_t *p) {
+    int which = -1;
+    const int rc = gemm_nt_run(p, nullptr, &which);
+    return rc == DIMSUM_OK ? which : -rc;
+}
+
 // dW-shaped product: C[s] (m, n) = sum over rows r in split s of A[r, :m]^T B[r, :n]; A (k, m) and B (k, n) 16-bit rows over the reduction index
-extern "C" int dimsum_gemm_tn(const dimsum_gemm_params_t *p, int32_t splits, int64_t c_split_stride, void *stream) {
+extern "C" int dimsum_gemm_tn(const dimsum_gemm_params_t *pub, int32_t splits, int64_t c_split_stride, void *stream) {
     using namespace dimsum;
     using namespace dimsum::gemm_nt;
-    if (!p || !p->a_ptr || !p->b_ptr || !p->c_ptr) return DIMSUM_ERR_NULL;
+    gemm_flat_t flat;
+    {
+        const int frc = gemm_flat_from(pub, flat);
+        if (frc != DIMSUM_OK) return frc;
+    }
+    const gemm_flat_t *p = &flat;
+    if (!p->a_ptr || !p->b_ptr || !p->c_ptr) return DIMSUM_ERR_NULL;
     if (p->operand_dtype != DIMSUM_F16 && p->operand_dtype != DIMSUM_BF16) return DIMSUM_ERR_DTYPE;
     if (p->epilogue != DIMSUM_GEMM_EPI_F32 || p->bias_ptr) return DIMSUM_ERR_UNSUPPORTED;
     if (((p->a_inv_scale_ptr || p->a_block_inv_ptr) == 0) != (p->b_inv_scale_ptr == nullptr)) return DIMSUM_ERR_NULL;

@@ -267,7 +267,9 @@ static int dispatch_res(const dimsum_norm_params_t &p, hipStream_t s) {
 
 extern "C" int dimsum_norm_fwd(const dimsum_norm_params_t *p, void *stream) {
     using namespace dimsum;
-    if (!p || !p->x_ptr || !p->weight_ptr || !p->y_ptr) return DIMSUM_ERR_NULL;
+    if (!p) return DIMSUM_ERR_NULL;
+    if (p->struct_size != sizeof(dimsum_norm_params_t)) return DIMSUM_ERR_ABI;
+    if (!p->x_ptr || !p->weight_ptr || !p->y_ptr) return DIMSUM_ERR_NULL;
     if (p->rows < 0 || p->cols <= 0) return DIMSUM_ERR_SHAPE;
     if ((p->mod_scale_ptr == nullptr) != (p->mod_shift_ptr == nullptr)) return DIMSUM_ERR_NULL;
     if (p->mod_scale_ptr && p->rows_per_batch <= 0) return DIMSUM_ERR_SHAPE;
@@ -293,7 +295,9 @@ extern "C" int dimsum_norm_fwd(const dimsum_norm_params_t *p, void *stream) {
 
 extern "C" int dimsum_norm_bwd(const dimsum_norm_bwd_params_t *p, void *stream) {
     using namespace dimsum;
-    if (!p || !p->r_ptr || !p->weight_ptr || !p->rstd_ptr || !p->dy_ptr || !p->dx_ptr || !p->dweight_ptr) return DIMSUM_ERR_NULL;
+    if (!p) return DIMSUM_ERR_NULL;
+    if (p->struct_size != sizeof(dimsum_norm_bwd_params_t)) return DIMSUM_ERR_ABI;
+    if (!p->r_ptr || !p->weight_ptr || !p->rstd_ptr || !p->dy_ptr || !p->dx_ptr || !p->dweight_ptr) return DIMSUM_ERR_NULL;
     if (p->rows < 0 || p->cols <= 0) return DIMSUM_ERR_SHAPE;
     if (p->rows == 0) return DIMSUM_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -167,14 +167,14 @@ __device__ __forceinline__ void softplus_and_slope(float x, bool flag, float &dt
 
 // kVec : every row base 4-element aligned and L % 4 == 0 -> 16-byte vector I/O.   kFull: all 64 channel slots are live.
 template <typename T, int kN, bool kHasZ, bool kVec, bool kFull>
-__global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dimsum_ssm_bwd_params_t q, const float *__restrict__ ckpt, float *__restrict__ part) {
+__global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const ssm_bwd_args_t q, const float *__restrict__ ckpt, float *__restrict__ part) {
     constexpr int kNL = kN / kBQ;                 // states per lane
     constexpr int kBG = kNL < 4 ? kNL : 4;        // states per register sweep
     constexpr int NV = kBG * kBS;                 // (state, step) values per transposed reduction
     constexpr int kNG = kNL / kBG;                // register sweeps (state groups) per half tile: 1 up to dstate 16
     constexpr int kNPc = kBC / 8;                 // 16-byte pieces per lane of a 16 x 32 tile (a piece = 8 rows x 128 B)
     static_assert(kN % kBQ == 0 && kNL % kBG == 0 && (NV == 32 || NV == 16 || NV == 8), "dstate must be 4, 8, 16 or 32");
-    const dimsum_ssm_params_t &p = q.fwd;
+    const ssm_args_t &p = q.fwd;
     // ONE LDS block: [u | dt (softplus'ed) | dy] per wave, [a wave's dB | dC sums of the tile] per wave, [B | C] shared by the 4 waves.
     // The sweeps address it with byte offsets: the same per-lane offset serves u, dt and dy (constant distances = immediate offsets of
     // the ds instructions), and the 16-byte slot index of a half tile enters by one XOR (btile_off: the row bases have no bits below 128).
@@ -630,8 +630,8 @@ __global__ __launch_bounds__(kBW * kWave, 2) void ssm_scan_bwd_kernel(const dims
 // dB[b, g, n, t] = sum over the workgroups w of (b, g), in index order, of part[b, g, w][0][n][t]  (same for dC).
 // One thread owns 4 consecutive steps (16-byte loads when L % 4 == 0); the partial rows of a (b, g) are 2 N L floats apart.
 template <bool kVec4>
-__global__ __launch_bounds__(256) void ssm_scan_bwd_reduce_kernel(const float *__restrict__ part, const dimsum_ssm_bwd_params_t q, int waves_per_group) {
-    const dimsum_ssm_params_t &p = q.fwd;
+__global__ __launch_bounds__(256) void ssm_scan_bwd_reduce_kernel(const float *__restrict__ part, const ssm_bwd_args_t q, int waves_per_group) {
+    const ssm_args_t &p = q.fwd;
     const int L = p.seqlen, N = p.dstate, L4 = (L + 3) / 4;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // over (b, g, which, n, t / 4)
     const int64_t total = (int64_t)p.batch * p.n_groups * 2 * N * L4;
@@ -671,8 +671,8 @@ __global__ __launch_bounds__(256) void ssm_scan_bwd_reduce_kernel(const float *_
 
 // ev0: recorded at the begin of the main kernel unless the state-rebuild sweep of this call already took it (then null)
 template <typename T, int kN>
-static int launch_bwd(const dimsum_ssm_bwd_params_t &q, const float *ckpt, float *part, hipStream_t stream, hipEvent_t ev0) {
-    const dimsum_ssm_params_t &p = q.fwd;
+static int launch_bwd(const ssm_bwd_args_t &q, const float *ckpt, float *part, hipStream_t stream, hipEvent_t ev0) {
+    const ssm_args_t &p = q.fwd;
     const int dpg = p.dim / p.n_groups;
     constexpr int kWC = kBW * kBC;            // channels per workgroup
     const int tiles = p.batch * p.n_groups * ((dpg + kWC - 1) / kWC);
@@ -721,7 +721,7 @@ static int launch_bwd(const dimsum_ssm_bwd_params_t &q, const float *ckpt, float
 }
 
 template <typename T>
-static int dispatch_bwd(const dimsum_ssm_bwd_params_t &q, const float *ckpt, float *part, hipStream_t stream, hipEvent_t ev0) {
+static int dispatch_bwd(const ssm_bwd_args_t &q, const float *ckpt, float *part, hipStream_t stream, hipEvent_t ev0) {
     switch (q.fwd.dstate) {
         case 4: return launch_bwd<T, 4>(q, ckpt, part, stream, ev0);
         case 8: return launch_bwd<T, 8>(q, ckpt, part, stream, ev0);
@@ -731,7 +731,7 @@ static int dispatch_bwd(const dimsum_ssm_bwd_params_t &q, const float *ckpt, flo
     }
 }
 
-int ssm_check(const dimsum_ssm_params_t *p, bool forward);
+int ssm_check(const ssm_args_t *p, bool forward);
 
 }  // namespace dimsum
 
@@ -750,14 +750,33 @@ extern "C" int64_t dimsum_ssm_scan_bwd_workspace_bytes(int32_t batch, int32_t di
     return partial_bytes(batch, dim, seqlen, dstate, n_groups) + ckpt_bytes(batch, dim, seqlen, dstate);
 }
 
-extern "C" int dimsum_ssm_scan_bwd(const dimsum_ssm_bwd_params_t *q, void *stream) {
+namespace dimsum { int ssm_scan_fwd_run(const ssm_args_t &a, hipStream_t s); }
+
+extern "C" int dimsum_ssm_scan_bwd(const dimsum_ssm_bwd_params_t *pub, void *stream) {
     using namespace dimsum;
-    if (!q) return DIMSUM_ERR_NULL;
+    if (!pub) return DIMSUM_ERR_NULL;
+    if (pub->struct_size != sizeof(dimsum_ssm_bwd_params_t)) return DIMSUM_ERR_ABI;
+    ssm_bwd_args_t flat;
+    {
+        const int arc = ssm_args_from(&pub->fwd, flat.fwd, false);
+        if (arc != DIMSUM_OK) return arc;
+    }
+    flat.dout_batch_stride = pub->dout_batch_stride; flat.dout_d_stride = pub->dout_d_stride;
+    flat.dA_d_stride = pub->dA_d_stride; flat.dA_dstate_stride = pub->dA_dstate_stride;
+    flat.dB_batch_stride = pub->dB_batch_stride; flat.dB_group_stride = pub->dB_group_stride; flat.dB_dstate_stride = pub->dB_dstate_stride;
+    flat.dC_batch_stride = pub->dC_batch_stride; flat.dC_group_stride = pub->dC_group_stride; flat.dC_dstate_stride = pub->dC_dstate_stride;
+    flat.du_batch_stride = pub->du_batch_stride; flat.du_d_stride = pub->du_d_stride;
+    flat.dz_batch_stride = pub->dz_batch_stride; flat.dz_d_stride = pub->dz_d_stride;
+    flat.ddelta_batch_stride = pub->ddelta_batch_stride; flat.ddelta_d_stride = pub->ddelta_d_stride;
+    flat.dout_ptr = pub->dout_ptr; flat.dA_ptr = pub->dA_ptr; flat.dB_ptr = pub->dB_ptr; flat.dC_ptr = pub->dC_ptr; flat.dD_ptr = pub->dD_ptr;
+    flat.du_ptr = pub->du_ptr; flat.dz_ptr = pub->dz_ptr; flat.ddelta_ptr = pub->ddelta_ptr; flat.ddelta_bias_ptr = pub->ddelta_bias_ptr;
+    flat.workspace_ptr = pub->workspace_ptr; flat.workspace_bytes = pub->workspace_bytes;
+    const ssm_bwd_args_t *q = &flat;
     const int rc = ssm_check(&q->fwd, false);
     if (rc != DIMSUM_OK) return rc;
     if (!q->dout_ptr || !q->dA_ptr || !q->dB_ptr || !q->dC_ptr || !q->du_ptr || !q->ddelta_ptr || !q->workspace_ptr) return DIMSUM_ERR_NULL;
     if (q->fwd.z_ptr && (!q->dz_ptr || !q->fwd.out_ptr)) return DIMSUM_ERR_NULL;
-    const dimsum_ssm_params_t &p = q->fwd;
+    const ssm_args_t &p = q->fwd;
     if (!aligned_to<float>(q->workspace_ptr, 16)) return DIMSUM_ERR_STRIDE;
     // workspace = [per-wave partial dB / dC | saved states (only when the caller did not keep the forward's)]
     const int64_t pbytes = partial_bytes(p.batch, p.dim, p.seqlen, p.dstate, p.n_groups);
@@ -767,11 +786,11 @@ extern "C" int dimsum_ssm_scan_bwd(const dimsum_ssm_bwd_params_t *q, void *strea
     hipEvent_t ev0 = reinterpret_cast<hipEvent_t>(p.timing_start_event);     // begin of the call's FIRST kernel
     if (!ckpt) {
         // reference-shaped call (no saved states): one state-only forward sweep rebuilds them in the workspace
-        dimsum_ssm_params_t f = p;
+        ssm_args_t f = p;
         f.z_ptr = nullptr; f.out_ptr = nullptr; f.out_z_ptr = nullptr; f.x_ptr = nullptr; f.D_ptr = nullptr;
         f.ckpt_ptr = reinterpret_cast<char *>(q->workspace_ptr) + pbytes;
         f.timing_stop_event = nullptr;          // (the sweep's begin is the call's begin; its end is not the call's end)
-        const int frc = dimsum_ssm_scan_fwd(&f, stream);
+        const int frc = ssm_scan_fwd_run(f, reinterpret_cast<hipStream_t>(stream));
         if (frc != DIMSUM_OK) return frc;
         ev0 = nullptr;
         ckpt = reinterpret_cast<const float *>(f.ckpt_ptr);

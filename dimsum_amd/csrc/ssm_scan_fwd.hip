@@ -7,11 +7,11 @@
 namespace dimsum {
 
 // kernel launchers, instantiated in ssm_scan_fwd_{f32,f16,bf16}.hip / ssm_scan_fwd_split_{f32,f16,bf16}.hip
-template <typename T, int kN> void ssm_scan_fwd_launch_v0(const dimsum_ssm_params_t &p, hipStream_t stream, int tiles, bool vec, bool full);
-template <typename T, int kN, int kSP> void ssm_scan_fwd_launch_split(const dimsum_ssm_params_t &p, hipStream_t stream, int tiles, bool vec, bool full);
-template <typename T> void ssm_scan_fwd_launch_lanes(const dimsum_ssm_params_t &p, hipStream_t stream, int tiles, bool vec, bool full);
+template <typename T, int kN> void ssm_scan_fwd_launch_v0(const ssm_args_t &p, hipStream_t stream, int tiles, bool vec, bool full);
+template <typename T, int kN, int kSP> void ssm_scan_fwd_launch_split(const ssm_args_t &p, hipStream_t stream, int tiles, bool vec, bool full);
+template <typename T> void ssm_scan_fwd_launch_lanes(const ssm_args_t &p, hipStream_t stream, int tiles, bool vec, bool full);
 
-int ssm_check(const dimsum_ssm_params_t *p, bool forward) {
+int ssm_check(const ssm_args_t *p, bool forward) {
     if (!p || !p->A_ptr || !p->B_ptr || !p->C_ptr || !p->u_ptr || (!p->delta_ptr && !(forward && p->dt_w_ptr))) return DIMSUM_ERR_NULL;
     if (p->dt_w_ptr) {          // fused dt_proj (forward only)
         if (!forward) return DIMSUM_ERR_UNSUPPORTED;
@@ -34,11 +34,11 @@ int ssm_check(const dimsum_ssm_params_t *p, bool forward) {
 // for one of them (tests, tuning); a pure function of the parameters.
 constexpr int64_t kLanesBelowWaves = 2048;
 
-static bool variant_ok(const dimsum_ssm_params_t &p, int v) {
+static bool variant_ok(const ssm_args_t &p, int v) {
     return v == 1 || (v == 2 && p.dstate % 4 == 0) || (v == 4 && p.dstate % 8 == 0) || (v == 16 && p.dstate == 16);
 }
 
-int ssm_scan_fwd_variant(const dimsum_ssm_params_t &p) {
+int ssm_scan_fwd_variant(const ssm_args_t &p) {
     if (p.kernel_variant != 0) return variant_ok(p, p.kernel_variant) ? p.kernel_variant : 1;
     // The 64-channel kernel keeps 8 waves per CU resident (2048 on the chip) and is HBM-bound when they are all there.
     // A launch that does not fill those slots is latency-bound per wave: splitting the states over 2 or 4 lanes gives it
@@ -56,7 +56,7 @@ int ssm_scan_fwd_variant(const dimsum_ssm_params_t &p) {
 }
 
 template <typename T, int kN>
-static int launch_fwd(const dimsum_ssm_params_t &p, hipStream_t stream) {
+static int launch_fwd(const ssm_args_t &p, hipStream_t stream) {
     const int dpg = p.dim / p.n_groups;
     const int sp = ssm_scan_fwd_variant(p);                // lanes per channel: 1, 2, 4 or 16
     const int cpw = kWave / sp;                            // channels per wave
@@ -104,7 +104,7 @@ static int launch_fwd(const dimsum_ssm_params_t &p, hipStream_t stream) {
 }
 
 template <typename T>
-static int ssm_scan_fwd_dispatch(const dimsum_ssm_params_t &p, hipStream_t stream) {
+static int ssm_scan_fwd_dispatch(const ssm_args_t &p, hipStream_t stream) {
     switch (p.dstate) {
         case 4: return launch_fwd<T, 4>(p, stream);
         case 8: return launch_fwd<T, 8>(p, stream);
@@ -116,21 +116,30 @@ static int ssm_scan_fwd_dispatch(const dimsum_ssm_params_t &p, hipStream_t strea
 
 }  // namespace dimsum
 
+// flat block -> kernels (also the entry of the backward's state-rebuild sweep, ssm_scan_bwd.hip)
+namespace dimsum {
+int ssm_scan_fwd_run(const ssm_args_t &a, hipStream_t s) {
+    const int rc = ssm_check(&a, true);
+    if (rc != DIMSUM_OK) return rc;
+    if (a.batch == 0) return DIMSUM_OK;
+    switch (a.dtype) {
+        case DIMSUM_F32: return ssm_scan_fwd_dispatch<float>(a, s);
+        case DIMSUM_F16: return ssm_scan_fwd_dispatch<__half>(a, s);
+        case DIMSUM_BF16: return ssm_scan_fwd_dispatch<__hip_bfloat16>(a, s);
+        default: return DIMSUM_ERR_DTYPE;
+    }
+}
+}  // namespace dimsum
+
 extern "C" int dimsum_ssm_scan_fwd_variant(const dimsum_ssm_params_t *p) {
-    if (!p || p->n_groups <= 0) return -1;
-    return dimsum::ssm_scan_fwd_variant(*p);
+    dimsum::ssm_args_t a;
+    if (dimsum::ssm_args_from(p, a, true) != DIMSUM_OK || a.n_groups <= 0) return -1;
+    return dimsum::ssm_scan_fwd_variant(a);
 }
 
 extern "C" int dimsum_ssm_scan_fwd(const dimsum_ssm_params_t *p, void *stream) {
-    using namespace dimsum;
-    const int rc = ssm_check(p, true);
+    dimsum::ssm_args_t a;
+    const int rc = dimsum::ssm_args_from(p, a, true);
     if (rc != DIMSUM_OK) return rc;
-    if (p->batch == 0) return DIMSUM_OK;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    switch (p->dtype) {
-        case DIMSUM_F32: return ssm_scan_fwd_dispatch<float>(*p, s);
-        case DIMSUM_F16: return ssm_scan_fwd_dispatch<__half>(*p, s);
-        case DIMSUM_BF16: return ssm_scan_fwd_dispatch<__hip_bfloat16>(*p, s);
-        default: return DIMSUM_ERR_DTYPE;
-    }
+    return dimsum::ssm_scan_fwd_run(a, reinterpret_cast<hipStream_t>(stream));
 }

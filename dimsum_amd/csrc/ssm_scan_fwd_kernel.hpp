@@ -140,7 +140,7 @@ struct alignas(16) ScanU4 { unsigned w[4]; };
 //        the scan writes half the bytes. A lane pair trades halves (one quad_perm DPP each way) so that every lane issues ONE 16-byte store
 //        for two pieces. The reference feeds out_proj under TF32 (selective_scan_interface.py:954-981 under train.py:20-21): 10-bit mantissas.
 template <typename T, int kN, bool kHasZ, bool kVec, bool kFull, bool kCkpt = false, bool kDt = false, bool kZ16 = false>
-__global__ __launch_bounds__(kWave, kScanWaves) void ssm_scan_fwd_kernel(const dimsum_ssm_params_t p) {
+__global__ __launch_bounds__(kWave, kScanWaves) void ssm_scan_fwd_kernel(const ssm_args_t p) {
     static_assert(!kFull || kVec, "kFull implies kVec");
     static_assert(!kZ16 || (kFull && kHasZ && !kCkpt && std::is_same<T, float>::value), "the fp16 out_z rides on the full fp32 inference path");
     static_assert(!kDt || (kFull && kHasZ && !kCkpt && std::is_same<T, float>::value), "the fused dt_proj rides on the full fp32 inference path");
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(kWave, kScanWaves) void ssm_scan_fwd_kernel(const d
 // ---- launchers of this kernel: defined here, explicitly instantiated per I/O dtype in ssm_scan_fwd_{f32,f16,bf16}.hip, called
 // by the dispatch in ssm_scan_fwd.hip (the split kernels' launcher lives in ssm_scan_fwd_split.hpp the same way) -----------
 template <typename T, int kN>
-void ssm_scan_fwd_launch_v0(const dimsum_ssm_params_t &p, hipStream_t stream, int tiles, bool vec, bool full) {
+void ssm_scan_fwd_launch_v0(const ssm_args_t &p, hipStream_t stream, int tiles, bool vec, bool full) {
     const dim3 grid(tiles), block(kWave);
     const hipEvent_t ev0 = reinterpret_cast<hipEvent_t>(p.timing_start_event), ev1 = reinterpret_cast<hipEvent_t>(p.timing_stop_event);
 #define DIMSUM_LAUNCH(HASZ, VEC, FULL)                                                                                        \
@@ -494,9 +494,9 @@ void ssm_scan_fwd_launch_v0(const dimsum_ssm_params_t &p, hipStream_t stream, in
 }
 
 #define DIMSUM_INSTANTIATE_FWD_V0(T)                                                                                \
-    template void ssm_scan_fwd_launch_v0<T, 4>(const dimsum_ssm_params_t &, hipStream_t, int, bool, bool);           \
-    template void ssm_scan_fwd_launch_v0<T, 8>(const dimsum_ssm_params_t &, hipStream_t, int, bool, bool);           \
-    template void ssm_scan_fwd_launch_v0<T, 16>(const dimsum_ssm_params_t &, hipStream_t, int, bool, bool);          \
-    template void ssm_scan_fwd_launch_v0<T, 32>(const dimsum_ssm_params_t &, hipStream_t, int, bool, bool);
+    template void ssm_scan_fwd_launch_v0<T, 4>(const ssm_args_t &, hipStream_t, int, bool, bool);           \
+    template void ssm_scan_fwd_launch_v0<T, 8>(const ssm_args_t &, hipStream_t, int, bool, bool);           \
+    template void ssm_scan_fwd_launch_v0<T, 16>(const ssm_args_t &, hipStream_t, int, bool, bool);          \
+    template void ssm_scan_fwd_launch_v0<T, 32>(const ssm_args_t &, hipStream_t, int, bool, bool);
 
 }  // namespace dimsum

@@ -33,7 +33,7 @@ template <int CTRL> __device__ __forceinline__ float lanes_dpp(float v) {
 }
 
 template <typename T, bool kHasZ, bool kVec, bool kFull, bool kCkpt = false>
-__global__ __launch_bounds__(kWave, 4) void ssm_scan_fwd_lanes_kernel(const dimsum_ssm_params_t p) {
+__global__ __launch_bounds__(kWave, 4) void ssm_scan_fwd_lanes_kernel(const ssm_args_t p) {
     static_assert(!kFull || kVec, "kFull implies kVec");
     constexpr int kN = 16;
     // one LDS block [dt * u (then y in place) | dt | B | C]: the sequential loop addresses it with byte offsets formed by ONE
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(kWave, 4) void ssm_scan_fwd_lanes_kernel(const dims
 
 // ---- launcher: explicitly instantiated per I/O dtype in ssm_scan_fwd_split_{f32,f16,bf16}.hip ---------------------------------
 template <typename T>
-void ssm_scan_fwd_launch_lanes(const dimsum_ssm_params_t &p, hipStream_t stream, int tiles, bool vec, bool full) {
+void ssm_scan_fwd_launch_lanes(const ssm_args_t &p, hipStream_t stream, int tiles, bool vec, bool full) {
     const dim3 grid(tiles), block(kWave);
     const hipEvent_t ev0 = reinterpret_cast<hipEvent_t>(p.timing_start_event), ev1 = reinterpret_cast<hipEvent_t>(p.timing_stop_event);
 #define DIMSUM_LAUNCH(HASZ, VEC, FULL)                                                                                        \
@@ -285,6 +285,6 @@ void ssm_scan_fwd_launch_lanes(const dimsum_ssm_params_t &p, hipStream_t stream,
 }
 
 #define DIMSUM_INSTANTIATE_FWD_LANES(T) \
-    template void ssm_scan_fwd_launch_lanes<T>(const dimsum_ssm_params_t &, hipStream_t, int, bool, bool);
+    template void ssm_scan_fwd_launch_lanes<T>(const ssm_args_t &, hipStream_t, int, bool, bool);
 
 }  // namespace dimsum

@@ -35,7 +35,7 @@ __device__ __forceinline__ void swap_rows(float &x, float &y) {        // x.odd 
 }
 
 template <typename T, int kN, int kSP, bool kHasZ, bool kVec, bool kFull, bool kCkpt = false>
-__global__ __launch_bounds__(kWave, (kSP == 4 && kN <= 16) ? 5 : 3) void ssm_scan_fwd_split_kernel(const dimsum_ssm_params_t p) {
+__global__ __launch_bounds__(kWave, (kSP == 4 && kN <= 16) ? 5 : 3) void ssm_scan_fwd_split_kernel(const ssm_args_t p) {
     static_assert(!kFull || kVec, "kFull implies kVec");
     static_assert(kSP == 2 || kSP == 4, "2 or 4 lanes per channel");
     static_assert(kN % (2 * kSP) == 0, "dstate must be a multiple of 2 * kSP");
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(kWave, (kSP == 4 && kN <= 16) ? 5 : 3) void ssm_sca
 
 // ---- launcher: explicitly instantiated per I/O dtype in ssm_scan_fwd_split_{f32,f16,bf16}.hip ---------------------------------
 template <typename T, int kN, int kSP>
-void ssm_scan_fwd_launch_split(const dimsum_ssm_params_t &p, hipStream_t stream, int tiles, bool vec, bool full) {
+void ssm_scan_fwd_launch_split(const ssm_args_t &p, hipStream_t stream, int tiles, bool vec, bool full) {
     const dim3 grid(tiles), block(kWave);
     const hipEvent_t ev0 = reinterpret_cast<hipEvent_t>(p.timing_start_event), ev1 = reinterpret_cast<hipEvent_t>(p.timing_stop_event);
 #define DIMSUM_LAUNCH(HASZ, VEC, FULL)                                                                                               \
@@ -328,12 +328,12 @@ void ssm_scan_fwd_launch_split(const dimsum_ssm_params_t &p, hipStream_t stream,
 }
 
 #define DIMSUM_INSTANTIATE_FWD_SPLIT(T)                                                                                   \
-    template void ssm_scan_fwd_launch_split<T, 4, 2>(const dimsum_ssm_params_t &, hipStream_t, int, bool, bool);           \
-    template void ssm_scan_fwd_launch_split<T, 8, 2>(const dimsum_ssm_params_t &, hipStream_t, int, bool, bool);           \
-    template void ssm_scan_fwd_launch_split<T, 16, 2>(const dimsum_ssm_params_t &, hipStream_t, int, bool, bool);          \
-    template void ssm_scan_fwd_launch_split<T, 32, 2>(const dimsum_ssm_params_t &, hipStream_t, int, bool, bool);          \
-    template void ssm_scan_fwd_launch_split<T, 8, 4>(const dimsum_ssm_params_t &, hipStream_t, int, bool, bool);           \
-    template void ssm_scan_fwd_launch_split<T, 16, 4>(const dimsum_ssm_params_t &, hipStream_t, int, bool, bool);          \
-    template void ssm_scan_fwd_launch_split<T, 32, 4>(const dimsum_ssm_params_t &, hipStream_t, int, bool, bool);
+    template void ssm_scan_fwd_launch_split<T, 4, 2>(const ssm_args_t &, hipStream_t, int, bool, bool);           \
+    template void ssm_scan_fwd_launch_split<T, 8, 2>(const ssm_args_t &, hipStream_t, int, bool, bool);           \
+    template void ssm_scan_fwd_launch_split<T, 16, 2>(const ssm_args_t &, hipStream_t, int, bool, bool);          \
+    template void ssm_scan_fwd_launch_split<T, 32, 2>(const ssm_args_t &, hipStream_t, int, bool, bool);          \
+    template void ssm_scan_fwd_launch_split<T, 8, 4>(const ssm_args_t &, hipStream_t, int, bool, bool);           \
+    template void ssm_scan_fwd_launch_split<T, 16, 4>(const ssm_args_t &, hipStream_t, int, bool, bool);          \
+    template void ssm_scan_fwd_launch_split<T, 32, 4>(const ssm_args_t &, hipStream_t, int, bool, bool);
 
 }  // namespace dimsum

@@ -549,7 +549,9 @@ __global__ __launch_bounds__(256) void gated_gelu_bwd_kernel(const float *x12, c
 
 extern "C" int dimsum_token_transform(const dimsum_tt_params_t *p, void *stream) {
     using namespace dimsum;
-    if (!p || !p->x_ptr) return DIMSUM_ERR_NULL;
+    if (!p) return DIMSUM_ERR_NULL;
+    if (p->struct_size != sizeof(dimsum_tt_params_t)) return DIMSUM_ERR_ABI;
+    if (!p->x_ptr) return DIMSUM_ERR_NULL;
     if (!p->y_ptr && !p->tsum_ptr && !(p->w_ptr && (p->wdot_ptr || p->wsum_ptr))) return DIMSUM_ERR_NULL;   // nothing to produce
     if ((p->wdot_ptr || p->wsum_ptr) && !p->w_ptr) return DIMSUM_ERR_NULL;
     if (p->batch < 0 || p->tokens <= 0 || p->channels <= 0) return DIMSUM_ERR_SHAPE;

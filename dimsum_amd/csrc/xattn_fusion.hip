@@ -479,8 +479,10 @@ int launch_xattn_f16(const dimsum_xattn_params_t &p, hipStream_t s);      // xat
 
 extern "C" int dimsum_xattn_fusion_fwd(const dimsum_xattn_params_t *p, void *stream) {
     using namespace dimsum;
-    const bool self_attn = p && p->n_dirs == 1;
-    if (!p || !p->qkv1_ptr || (!self_attn && !p->qkv2_ptr) || !p->out_ptr) return DIMSUM_ERR_NULL;
+    if (!p) return DIMSUM_ERR_NULL;
+    if (p->struct_size != sizeof(dimsum_xattn_params_t)) return DIMSUM_ERR_ABI;
+    const bool self_attn = p->n_dirs == 1;
+    if (!p->qkv1_ptr || (!self_attn && !p->qkv2_ptr) || !p->out_ptr) return DIMSUM_ERR_NULL;
     if (p->n_dirs != 0 && p->n_dirs != 1 && p->n_dirs != 2) return DIMSUM_ERR_SHAPE;
     if (p->batch < 0 || p->seqlen <= 0 || p->heads <= 0) return DIMSUM_ERR_SHAPE;
     if (!self_attn && (p->bias1_ptr == nullptr) != (p->bias2_ptr == nullptr)) return DIMSUM_ERR_NULL;

@@ -706,8 +706,10 @@ static int launch_xbwd(const dimsum_xattn_bwd_params_t &p, hipStream_t s) {
 
 extern "C" int dimsum_xattn_fusion_bwd(const dimsum_xattn_bwd_params_t *p, void *stream) {
     using namespace dimsum;
-    const bool self_attn = p && p->fwd.n_dirs == 1;
-    if (!p || !p->fwd.qkv1_ptr || (!self_attn && !p->fwd.qkv2_ptr) || !p->fwd.out_ptr || !p->fwd.lse_ptr || !p->dout_ptr || !p->dqkv1_ptr ||
+    if (!p) return DIMSUM_ERR_NULL;
+    if (p->struct_size != sizeof(dimsum_xattn_bwd_params_t)) return DIMSUM_ERR_ABI;
+    const bool self_attn = p->fwd.n_dirs == 1;
+    if (!p->fwd.qkv1_ptr || (!self_attn && !p->fwd.qkv2_ptr) || !p->fwd.out_ptr || !p->fwd.lse_ptr || !p->dout_ptr || !p->dqkv1_ptr ||
         (!self_attn && !p->dqkv2_ptr) || !p->delta_ptr)
         return DIMSUM_ERR_NULL;
     const dimsum_xattn_params_t &f = p->fwd;

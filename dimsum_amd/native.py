@@ -65,12 +65,16 @@ def scan_fwd_kernel_for(batch, dim, seqlen, dstate, n_groups=1):
     64-channel kernel (a full chip), 2 / 4 / 16 = the state-split kernels of underfilled launches"""
     P = _lib.SsmParams()
     P.batch, P.dim, P.seqlen, P.dstate, P.n_groups, P.n_chunks = batch, dim, seqlen, dstate, n_groups, (seqlen + 2047) // 2048
-    P.kernel_variant = _scan_fwd_variant
+    if _scan_fwd_variant:
+        _lib.attach_ext(P, _lib.SsmExt).kernel_variant = _scan_fwd_variant
     return int(_lib.load().dimsum_ssm_scan_fwd_variant(P))
 
 
 def _fill_ssm(P, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, x, out_z, ckpt=None):
-    P.kernel_variant = _scan_fwd_variant
+    """fills the reference-shaped struct P (dimsum_ssm_params_t) and links a zeroed dimsum_ssm_ext_t to it -> the extension (the caller sets
+    what it uses beyond the reference interface: saved states, the inference fusions, timing events)"""
+    E = _lib.attach_ext(P, _lib.SsmExt)
+    E.kernel_variant, E.ckpt_ptr = _scan_fwd_variant, _ptr(ckpt)
     batch, dim, seqlen = u.shape
     P.batch, P.dim, P.seqlen, P.dstate = batch, dim, seqlen, A.shape[1]
     P.n_groups, P.n_chunks = B.shape[1], (seqlen + 2047) // 2048
@@ -88,7 +92,8 @@ def _fill_ssm(P, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, x, ou
         P.out_z_batch_stride, P.out_z_d_stride = out_z.stride(0), out_z.stride(1)
     P.A_ptr, P.B_ptr, P.C_ptr, P.D_ptr = _ptr(A), _ptr(B), _ptr(C), _ptr(D)
     P.u_ptr, P.delta_ptr, P.delta_bias_ptr, P.z_ptr = _ptr(u), _ptr(delta), _ptr(delta_bias), _ptr(z)
-    P.out_ptr, P.x_ptr, P.out_z_ptr, P.ckpt_ptr = _ptr(out), _ptr(x), _ptr(out_z), _ptr(ckpt)
+    P.out_ptr, P.x_ptr, P.out_z_ptr = _ptr(out), _ptr(x), _ptr(out_z)
+    return E
 
 
 def _check_ssm(u, delta, A, B, C, D, z, delta_bias):
@@ -179,14 +184,14 @@ def selective_scan_fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus, need
     ckpt = torch.empty(scan_ckpt_shape(batch, dim, seqlen, dstate), device=u.device, dtype=torch.float32) if need_ckpt else None
     if u.numel() > 0:
         P = _lib.SsmParams()
-        _fill_ssm(P, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, x, out_z, ckpt)
+        E = _fill_ssm(P, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, x, out_z, ckpt)
         if planes is not None:
-            P.out_z_lo_offset = dim * batch * seqlen
+            E.out_z_lo_offset = dim * batch * seqlen
         if z16 is not None:
-            P.out_z_f16, P.out_z_scale_ptr, P.out_z_scale_ld = 1, _ptr(z16[1]), z16[1].stride(0)
+            E.out_z_f16, E.out_z_scale_ptr, E.out_z_scale_ld = 1, _ptr(z16[1]), z16[1].stride(0)
         if dt_proj is not None:
             P.delta_ptr = None
-            P.dt_w_ptr, P.dt_x_ptr, P.dt_w_row_stride, P.dt_x_row_stride, P.dt_rank = _ptr(dt_w), _ptr(dt_xt), dt_w.stride(0), dt_xt.stride(0), dt_w.shape[1]
+            E.dt_w_ptr, E.dt_x_ptr, E.dt_w_row_stride, E.dt_x_row_stride, E.dt_rank = _ptr(dt_w), _ptr(dt_xt), dt_w.stride(0), dt_xt.stride(0), dt_w.shape[1]
         with torch.cuda.device(u.device):
             _lib.check(_lib.load().dimsum_ssm_scan_fwd(P, _stream(u)), "selective_scan_fwd")
     res = [out, x]
@@ -739,7 +744,8 @@ def gemm_tn_pairs(a, b, splits=None):
     G.operand_dtype, G.epilogue, G.out_scale = _DT[ad.dtype], _lib.GEMM_EPI_F32, 1.0
     G.lda, G.ldb, G.ldc = ad.stride(0), bd.stride(0), Q
     G.a_ptr, G.b_ptr, G.c_ptr = _ptr(ad), _ptr(bd), _ptr(out)
-    G.tn_pair_a_cols, G.tn_pair_b_cols = P, Q
+    X = _lib.attach_ext(G, _lib.GemmExt)
+    X.tn_pair_a_cols, X.tn_pair_b_cols = P, Q
     with torch.cuda.device(ad.device):
         _lib.check(_lib.load().dimsum_gemm_tn(G, 3 * splits, P * Q, _stream(ad)), "gemm_tn_pairs")
     return out.sum(0)
@@ -787,18 +793,34 @@ def gemm_tn(a, b, splits=None, events=None, alias_rows=0, scales=None):
     G.out_scale = 1.0
     G.lda, G.ldb, G.ldc = a.stride(0), b.stride(0), Q
     G.a_ptr, G.b_ptr, G.c_ptr = _ptr(a), _ptr(b), _ptr(out)
-    G.a_alias_rows = alias_rows
+    X = _lib.attach_ext(G, _lib.GemmExt)
+    X.a_alias_rows = alias_rows
     if scales is not None:
         G.b_inv_scale_ptr = _ptr(scales[1])
         if blocks is not None:
-            G.a_block_inv_ptr, G.a_block_inv_ld = _ptr(blocks), blocks.stride(0)
+            X.a_block_inv_ptr, X.a_block_inv_ld = _ptr(blocks), blocks.stride(0)
         else:
             G.a_inv_scale_ptr = _ptr(scales[0])
     if events is not None:
-        G.timing_start_event, G.timing_stop_event = events
+        X.timing_start_event, X.timing_stop_event = events
     with torch.cuda.device(a.device):
         _lib.check(_lib.load().dimsum_gemm_tn(G, splits, P * Q, _stream(a)), "gemm_tn")
     return out[0] if splits == 1 else out.sum(0)
+
+
+_gemm_kernel_log = None      # a list while gemm_kernel_log() is open: (epilogue, dimsum_gemm_nt_kernel_for) of every gemm_nt call
+
+
+@contextlib.contextmanager
+def gemm_kernel_log():
+    """tests / measurement: records, for every gemm_nt call made inside, which kernel family the library launches (_lib.GEMM_NT_KERNELS:
+    0 = 256-row tiles, 1 = 128-row tiles, 2 = the persistent K-tile stream). Host-side, not thread-safe."""
+    global _gemm_kernel_log
+    old, _gemm_kernel_log = _gemm_kernel_log, []
+    try:
+        yield _gemm_kernel_log
+    finally:
+        _gemm_kernel_log = old
 
 
 def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=None, tune=None, scales=None, gate_bound=None, residual=None,
@@ -829,12 +851,13 @@ def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=Non
     M, K = a.shape[0], (a.shape[1] if pair_b else b.shape[1])
     N = b.shape[0]
     P = _lib.GemmParams()
+    X = _lib.attach_ext(P, _lib.GemmExt)            # fused-epilogue operands, image read modes, timing, tuning (dimsum_gemm_ext_t)
     P.m, P.n, P.k = M, N, K
     if pair_in:
-        P.a_alias_rows = K // 3
-        P.a_alias_weight_order = int(bool(weight_order))       # the pair read as [hi | lo | hi] (a gradient image x a left-order weight image)
+        X.a_alias_rows = K // 3
+        X.a_alias_weight_order = int(bool(weight_order))       # the pair read as [hi | lo | hi] (a gradient image x a left-order weight image)
     if pair_b:
-        P.b_alias_rows = K // 3
+        X.b_alias_rows = K // 3
     P.operand_dtype = _DT[a.dtype]
     P.out_scale = float(out_scale)
     P.lda, P.ldb = a.stride(0), b.stride(0)
@@ -855,21 +878,21 @@ def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=Non
                    and (cb is None or (cb.dtype == torch.float32 and cb.is_contiguous() and cb.numel() == cw.shape[0])),
                    "gemm_nt: conv = (weight (rows % 256 == 0, width 2..4) f32, bias or None, seq with 256 % seq == 0)")
             P.epilogue = _lib.GEMM_EPI_F32_CONV
-            P.conv_weight_ptr, P.conv_bias_ptr = _ptr(cw), _ptr(cb)
-            P.conv_rows, P.conv_width, P.conv_seq, P.conv_weight_ld = cw.shape[0], cw.shape[1], seq, cw.stride(0)
+            X.conv_weight_ptr, X.conv_bias_ptr = _ptr(cw), _ptr(cb)
+            X.conv_rows, X.conv_width, X.conv_seq, X.conv_weight_ld = cw.shape[0], cw.shape[1], seq, cw.stride(0)
         if residual is not None:
             _gpu(residual, gate)
             _check(residual.dtype == torch.float32 and residual.shape == (M, N) and residual.stride(1) == 1, "gemm_nt: residual must be (M, N) float32 rows")
             P.epilogue = _lib.GEMM_EPI_F32_GATE_RESIDUAL
-            P.residual_ptr, P.residual_ld = _ptr(residual), residual.stride(0)
+            X.residual_ptr, X.residual_ld = _ptr(residual), residual.stride(0)
             if gate is not None:
                 _check(rows_per_batch and rows_per_batch % 256 == 0 and M % rows_per_batch == 0 and gate.dtype == torch.float32
                        and gate.shape == (M // rows_per_batch, N) and gate.stride(1) == 1, "gemm_nt: gate must be (M / rows_per_batch, N) float32, rows_per_batch % 256 == 0")
-                P.gate_ptr, P.gate_ld, P.rows_per_batch = _ptr(gate), gate.stride(0), rows_per_batch
+                X.gate_ptr, X.gate_ld, X.rows_per_batch = _ptr(gate), gate.stride(0), rows_per_batch
     elif epilogue == "gated_split3":
         P.epilogue = _lib.GEMM_EPI_GATED_GELU_SPLIT3
         pieces = 2 if pair_out else 3
-        P.c_image_pieces = pieces
+        X.c_image_pieces = pieces
         if out is None:
             out = torch.empty((M, pieces * (N // 2)), device=a.device, dtype=torch.bfloat16)
         _check(out.dtype == torch.bfloat16 and out.shape == (M, pieces * (N // 2)) and out.stride(1) == 1, "gemm_nt: out must be (M, 3F) / (M, 2F) bfloat16 rows")
@@ -878,7 +901,7 @@ def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=Non
         P.epilogue = _lib.GEMM_EPI_F16_QKV
         _check(scales is not None and gate_bound is not None and rows_per_batch and rows_per_batch % 256 == 0 and M % rows_per_batch == 0
                and q_cols and q_cols % 16 == 0 and N % 8 == 0, "gemm_nt: f16_qkv needs scales, gate_bound = {wl1, bmax}, rows_per_batch % 256 == 0, q_cols % 16 == 0")
-        P.rows_per_batch, P.qkv_q_cols = rows_per_batch, q_cols
+        X.rows_per_batch, X.qkv_q_cols = rows_per_batch, q_cols
         if out is None:
             out = torch.empty((M, N), device=a.device, dtype=torch.float16)
         _check(out.dtype == torch.float16 and out.shape == (M, N) and out.stride(1) == 1, "gemm_nt: out must be (M, N) float16 rows")
@@ -901,24 +924,26 @@ def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=Non
             _gpu(gate_bound)
             _check(epilogue in ("gated_f16", "f16_qkv") and gate_bound.dtype == torch.float32 and gate_bound.numel() == 2 and gate_bound.is_contiguous(),
                    "gemm_nt: gate_bound is a 2-element float32 tensor for the gated_f16 / f16_qkv epilogues")
-            P.gate_bound_ptr = _ptr(gate_bound)
+            X.gate_bound_ptr = _ptr(gate_bound)
             if epilogue == "gated_f16":
                 h_inv = torch.empty((M,), device=a.device, dtype=torch.float32)
-                P.h_inv_scale_ptr = _ptr(h_inv)
+                X.h_inv_scale_ptr = _ptr(h_inv)
     P.a_ptr, P.b_ptr, P.bias_ptr, P.c_ptr = _ptr(a), _ptr(b), _ptr(bias), _ptr(out)
     x12 = None
     if keep_x12:
         _check(epilogue == "gated_split3" and a.dtype == torch.bfloat16 and scales is None, "gemm_nt: keep_x12 goes with the gated_split3 epilogue over bf16 images")
         x12 = torch.empty((M, N), device=a.device, dtype=torch.float32)
-        P.x12_ptr, P.x12_ld = _ptr(x12), N
+        X.x12_ptr, X.x12_ld = _ptr(x12), N
     if events is not None:
-        P.timing_start_event, P.timing_stop_event = events
+        X.timing_start_event, X.timing_stop_event = events
     if tune is not None:
-        P.tune_variant, P.tune_group_m = tune[:2]
-        P.tune_reserved = tune[2] if len(tune) > 2 else 0
+        X.tune_variant, X.tune_group_m = tune[:2]
+        X.tune_reserved = tune[2] if len(tune) > 2 else 0
     elif epilogue == "gated_f16" and os.environ.get("DIMSUM_GEMM_PERSIST", "1") == "0":
-        P.tune_variant = 513          # A / B switch: the gated GEMM one workgroup per tile instead of the persistent stream (csrc/gemm_nt_kernel.hpp, kVarPersist)
+        X.tune_variant = 513          # A / B switch: the gated GEMM one workgroup per tile instead of the persistent stream (csrc/gemm_nt_kernel.hpp, kVarPersist)
     with torch.cuda.device(a.device):
+        if _gemm_kernel_log is not None:            # tests / bench: which kernel family the library picks for this call
+            _gemm_kernel_log.append((epilogue if conv is None else "f32_conv", int(_lib.load().dimsum_gemm_nt_kernel_for(P))))
         _lib.check(_lib.load().dimsum_gemm_nt(P, _stream(a)), "gemm_nt")
     if x12 is not None:
         return (PairImage(out) if pair_out else out), x12

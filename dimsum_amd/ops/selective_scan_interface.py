@@ -133,7 +133,11 @@ class _MambaInner(torch.autograd.Function):
             # dt_proj inside the scan (csrc/ssm_scan_fwd_kernel.hpp, kDt): where the 64-channel kernel serves the launch, delta = W_dt x_dbl[:R] is
             # formed tile by tile on the matrix cores and the (b, d, l) tensor never exists: one GEMM launch and 2 b d l 4 bytes less per mixer.
             # The launch keeps no `out` / `x` stores then (DIMSUM_SCAN_INFER_STORES=1, the reference interface's launch, takes the GEMM).
+            # Only under allow_tf32 (the reference's own setting, train.py:20-21): the in-scan product is three bf16 products per fp32 product
+            # (2e-5 relative, what the library's TF32-policy GEMM spends) -- with the flag off the reference multiplies in exact fp32 and so
+            # does this path (the library's fp32 GEMM), which also keeps bench.py's exact-fp32 reference leg exact.
             dt_fused = (not keep_stores and not torch.is_autocast_enabled("cuda") and os.environ.get("DIMSUM_SCAN_DT_PROJ", "1") != "0"
+                        and torch.backends.cuda.matmul.allow_tf32
                         and native.scan_dt_proj_supported(conv_out, z, A, delta_proj_weight, x_dbl_t[:R]))
             delta = None if dt_fused else (delta_proj_weight @ x_dbl_t[:R]).view(d_inner, bsz, L).permute(1, 0, 2)
             Bm = x_dbl_t[R:R + N].view(N, bsz, L).permute(1, 0, 2).unsqueeze(1)

@@ -23,6 +23,17 @@
  *   - return value: DIMSUM_OK or an error code; dimsum_status_string() gives the message the host layer raises
  *     (the reference raises RuntimeError from TORCH_CHECK at the same places).
  *   - innermost (sequence / feature) stride must be 1 for every activation tensor, like selective_scan.cpp:252-253.
+ *
+ * Versioning (ABI 17). Every parameter struct starts with `struct_size`: sizeof() of the struct AS THE CALLER COMPILED IT. An entry point
+ * whose struct_size differs from the library's own sizeof returns DIMSUM_ERR_ABI before it reads anything else -- a caller built against an
+ * older or newer header can never make a kernel read past its struct. (Inside the *_bwd_params_t structs only the outer struct_size is
+ * checked; `fwd.struct_size` is ignored, `fwd.ext` is honoured.)
+ * The two structs that mirror reference structs (dimsum_ssm_params_t <- SSMParamsBase, dimsum_gemm_params_t <- the arguments of F.linear)
+ * hold ONLY the reference interface; everything this library offers beyond it (inference fusions, saved states, timing events, tuning)
+ * lives behind `ext`, a pointer to a dimsum_*_ext_t that may be NULL (= the reference interface, nothing else). An ext struct carries its
+ * own struct_size and only ever grows at its end: the library accepts any struct_size up to its own sizeof and reads the fields past the
+ * caller's struct_size as 0 / NULL, so a new kernel option does not move the ABI version; an ext LARGER than the library's is
+ * DIMSUM_ERR_ABI (the caller asks for something this library does not know).
  */
 #ifndef DIMSUM_HIP_H
 #define DIMSUM_HIP_H
@@ -33,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DIMSUM_ABI_VERSION 16
+#define DIMSUM_ABI_VERSION 17
 
 typedef enum {
     DIMSUM_OK = 0,
@@ -42,7 +53,8 @@ typedef enum {
     DIMSUM_ERR_SHAPE = 3,         /* bad size (dstate, width, n_groups, ...) */
     DIMSUM_ERR_STRIDE = 4,        /* stride not supported (innermost != 1, overflow) */
     DIMSUM_ERR_UNSUPPORTED = 5,   /* valid in the reference but out of scope here (complex A, constant B/C) */
-    DIMSUM_ERR_LAUNCH = 6         /* hipGetLastError() after the launch */
+    DIMSUM_ERR_LAUNCH = 6,        /* hipGetLastError() after the launch */
+    DIMSUM_ERR_ABI = 7            /* struct_size of a parameter struct does not match this library (stale / foreign header) */
 } dimsum_status_t;
 
 typedef enum { DIMSUM_F32 = 0, DIMSUM_F16 = 1, DIMSUM_BF16 = 2 } dimsum_dtype_t;
@@ -51,7 +63,7 @@ const char *dimsum_status_string(int status);
 int dimsum_abi_version(void);
 
 /* Measurement helpers (benchmarks; no reference counterpart): HIP events (hipEvent_t behind void*) for the per-call
- * `timing_start_event` / `timing_stop_event` fields of dimsum_ssm_params_t. Stateless wrappers of hipEventCreate / Destroy / ElapsedTime. */
+ * `timing_start_event` / `timing_stop_event` fields of dimsum_ssm_ext_t. Stateless wrappers of hipEventCreate / Destroy / ElapsedTime. */
 void *dimsum_event_create(void);
 void dimsum_event_destroy(void *event);
 float dimsum_event_elapsed_ms(void *start_event, void *stop_event);   /* after the stream has been synchronised; < 0 on error */
@@ -68,32 +80,16 @@ const char *dimsum_target_arch(void);
  *       x[...,2n] = running product of exp(delta*A_n), x[...,2n+1] = state h_n at the end of each 2048-chunk
  *   out   = C.h + D*u          out_z = out * silu(z)  (written iff z_ptr != NULL)
  * ------------------------------------------------------------------------------------------------------------- */
+/* Everything beyond the reference interface (SSMParamsBase has none of it). All 0 / NULL by default; nothing here is process state. */
 typedef struct {
-    int32_t batch, dim, seqlen, dstate, n_groups, n_chunks;
-    int32_t delta_softplus;   /* bool */
-    int32_t dtype;            /* dimsum_dtype_t of u/delta/z/B/C/out/out_z */
-
-    int64_t A_d_stride, A_dstate_stride;
-    int64_t B_batch_stride, B_group_stride, B_dstate_stride;
-    int64_t C_batch_stride, C_group_stride, C_dstate_stride;
-    int64_t u_batch_stride, u_d_stride;
-    int64_t delta_batch_stride, delta_d_stride;
-    int64_t z_batch_stride, z_d_stride;
-    int64_t out_batch_stride, out_d_stride;
-    int64_t out_z_batch_stride, out_z_d_stride;
-
-    const void *A_ptr, *B_ptr, *C_ptr, *D_ptr, *u_ptr, *delta_ptr, *delta_bias_ptr, *z_ptr;
-    void *out_ptr;    /* may be NULL: inference-only callers that need just out_z skip the store */
-    void *x_ptr;      /* may be NULL: skip the chunk-state store */
-    void *out_z_ptr;  /* required iff z_ptr != NULL */
+    uint32_t struct_size;     /* sizeof(dimsum_ssm_ext_t) as the caller compiled it (see "Versioning" at the top) */
+    int32_t kernel_variant;   /* forward kernel: 0 = automatic (dimsum_ssm_scan_fwd_variant tells which), else lanes per channel:
+                                 1 (64 channels per wave), 2, 4, 16 (one lane per state; dstate 16). A variant the shape does
+                                 not support (dstate % 4, % 8, != 16) falls back to 1. For tests and tuning. */
     void *ckpt_ptr;   /* optional (batch, ceil(seqlen/8), dstate, dim) f32: the state h BEFORE every 8th step.
                          forward: written when non-NULL (training callers keep it for the backward);
                          backward: read when non-NULL, otherwise rebuilt into workspace_ptr by one extra sweep.
                          Not part of the reference interface (its backward re-scans whole rows instead). */
-    /* per-call extras, all 0 / NULL by default (no reference counterpart; nothing here is process state): */
-    int32_t kernel_variant;   /* forward kernel: 0 = automatic (dimsum_ssm_scan_fwd_variant tells which), else lanes per channel:
-                                 1 (64 channels per wave), 2, 4, 16 (one lane per state; dstate 16). A variant the shape does
-                                 not support (dstate % 4, % 8, != 16) falls back to 1. For tests and tuning. */
     void *timing_start_event, *timing_stop_event;   /* optional hipEvent_t pair: recorded at the begin of the call's first kernel
                                  and the end of its last one (hipExtLaunchKernel: the kernels' own dispatch timestamps, the
                                  durations rocprofv3 reports). In dimsum_ssm_bwd_params_t.fwd they bracket the whole backward
@@ -123,11 +119,38 @@ typedef struct {
     int32_t out_z_f16;
     void *out_z_scale_ptr;
     int64_t out_z_scale_ld;
+} dimsum_ssm_ext_t;
+
+/* The reference interface: field for field what set_ssm_params_fwd fills into SSMParamsBase (selective_scan.cpp:64-143;
+ * selective_scan.h:26-68), plus the dtype code ATen carries in the tensors. `ext` = NULL is exactly that interface. */
+typedef struct {
+    uint32_t struct_size;     /* sizeof(dimsum_ssm_params_t) as the caller compiled it; anything else -> DIMSUM_ERR_ABI */
+    int32_t batch, dim, seqlen, dstate, n_groups, n_chunks;
+    int32_t delta_softplus;   /* bool */
+    int32_t dtype;            /* dimsum_dtype_t of u/delta/z/B/C/out/out_z */
+    int32_t reserved;         /* 0 */
+
+    int64_t A_d_stride, A_dstate_stride;
+    int64_t B_batch_stride, B_group_stride, B_dstate_stride;
+    int64_t C_batch_stride, C_group_stride, C_dstate_stride;
+    int64_t u_batch_stride, u_d_stride;
+    int64_t delta_batch_stride, delta_d_stride;
+    int64_t z_batch_stride, z_d_stride;
+    int64_t out_batch_stride, out_d_stride;
+    int64_t out_z_batch_stride, out_z_d_stride;
+
+    const void *A_ptr, *B_ptr, *C_ptr, *D_ptr, *u_ptr, *delta_ptr, *delta_bias_ptr, *z_ptr;
+    void *out_ptr;    /* may be NULL: inference-only callers that need just out_z skip the store */
+    void *x_ptr;      /* may be NULL: skip the chunk-state store */
+    void *out_z_ptr;  /* required iff z_ptr != NULL */
+    const dimsum_ssm_ext_t *ext;   /* NULL = the reference interface */
 } dimsum_ssm_params_t;
 
 typedef struct {
+    uint32_t struct_size;      /* sizeof(dimsum_ssm_bwd_params_t) */
+    uint32_t reserved;         /* 0 */
     dimsum_ssm_params_t fwd;   /* forward operands (out_ptr = forward `out`, needed when z_ptr != NULL;
-                                  out_z_ptr != NULL => recompute_out_z, selective_scan.cpp:443-449) */
+                                  out_z_ptr != NULL => recompute_out_z, selective_scan.cpp:443-449); fwd.ext->ckpt_ptr = the saved states */
     int64_t dout_batch_stride, dout_d_stride;
     int64_t dA_d_stride, dA_dstate_stride;
     int64_t dB_batch_stride, dB_group_stride, dB_dstate_stride;
@@ -171,9 +194,11 @@ int dimsum_ssm_scan_fwd_variant(const dimsum_ssm_params_t *p);
  * (SURVEY finding 1): pass that buffer as out_ptr.
  * ------------------------------------------------------------------------------------------------------------- */
 typedef struct {
+    uint32_t struct_size;     /* sizeof(dimsum_conv_params_t) */
     int32_t batch, dim, seqlen, width;
     int32_t silu_activation;  /* bool */
     int32_t dtype;            /* of x/out */
+    int32_t reserved;         /* 0 */
     int64_t x_batch_stride, x_c_stride;
     int64_t weight_c_stride, weight_width_stride;
     int64_t out_batch_stride, out_c_stride;
@@ -182,6 +207,8 @@ typedef struct {
 } dimsum_conv_params_t;
 
 typedef struct {
+    uint32_t struct_size;     /* sizeof(dimsum_conv_bwd_params_t) */
+    uint32_t reserved;        /* 0 */
     dimsum_conv_params_t fwd; /* out_ptr unused */
     int64_t dout_batch_stride, dout_c_stride;
     int64_t dx_batch_stride, dx_c_stride;
@@ -206,6 +233,7 @@ int dimsum_causal_conv1d_bwd(const dimsum_conv_bwd_params_t *p, void *stream);
  * buffers (the Triton reference reduces per-SM partials on the host, layernorm.py:324-359).
  * ------------------------------------------------------------------------------------------------------------- */
 typedef struct {
+    uint32_t struct_size;     /* sizeof(dimsum_norm_params_t) */
     int32_t rows, cols;
     int32_t is_rms_norm;
     int32_t x_dtype, residual_dtype, out_dtype; /* dimsum_dtype_t; residual_dtype covers residual and residual_out */
@@ -221,14 +249,16 @@ typedef struct {
                          * y_row_stride >= 3 N): see dimsum_split3.  2: y is a scaled-fp16 operand image (out_dtype F16, N % 4 == 0):
                          * row r = fp16(y_r * 2^s_r) with 2^-s_r written to y_inv_scale_ptr[r]: see dimsum_rows_f16s.
                          * 3: like 1 but as the PAIR [hi | lo], rows of 2 N bf16 (y_row_stride >= 2 N), for a consumer that reads it as
-                         * [hi | hi | lo] (dimsum_gemm_params_t.a_alias_rows / b_alias_rows): a third less image traffic */
+                         * [hi | hi | lo] (dimsum_gemm_ext_t.a_alias_rows / b_alias_rows): a third less image traffic */
     void *y_inv_scale_ptr;                      /* (M) f32, y_split3 == 2 only */
 } dimsum_norm_params_t;
 
 typedef struct {
+    uint32_t struct_size;     /* sizeof(dimsum_norm_bwd_params_t) */
     int32_t rows, cols;
     int32_t is_rms_norm;
     float eps;
+    int32_t reserved;         /* 0 */
     int64_t r_row_stride, dy_row_stride, dres_row_stride, dx_row_stride;
     const void *r_ptr;       /* saved residual_out (f32) = the normalised input */
     const void *weight_ptr, *mean_ptr, *rstd_ptr;
@@ -248,7 +278,7 @@ int dimsum_norm_bwd(const dimsum_norm_bwd_params_t *p, void *stream);
  * (rows, 3 cols) bf16:  left != 0: [hi | hi | lo]  (activations),  left == 0: [hi | lo | hi]  (weights), so that
  *     left_image (M, 3K) . weight_image (N, 3K)^T  =  hi.hi + hi.lo + lo.hi   accumulated in f32 by ONE bf16 GEMM.
  * Producer kernels write the left image directly (dimsum_norm_params_t.y_split3, dimsum_gated_gelu_fwd_split3).
- * left == 2: the PAIR [hi | lo] ((rows, 2 cols) bf16) for dimsum_gemm_params_t.a_alias_rows / tn_pair_*_cols.
+ * left == 2: the PAIR [hi | lo] ((rows, 2 cols) bf16) for dimsum_gemm_ext_t.a_alias_rows / tn_pair_*_cols.
  * cols % 4 == 0, src rows 16-byte aligned (src_row_stride % 4 == 0), dst contiguous and 8-byte aligned.
  * ------------------------------------------------------------------------------------------------------------- */
 int dimsum_split3(const void *src, int64_t rows, int64_t cols, int64_t src_row_stride, void *dst, int32_t left, void *stream);
@@ -305,6 +335,7 @@ typedef enum {
 } dimsum_tt_kind_t;
 
 typedef struct {
+    uint32_t struct_size;                  /* sizeof(dimsum_tt_params_t) */
     int32_t batch, tokens, channels, grid; /* tokens = grid*grid, grid % 4 == 0 unless kind == NONE */
     int32_t kind;                          /* dimsum_tt_kind_t */
     int32_t y_split3;                      /* 1: y is the split-bf16 left operand image of the Linear that consumes it: rows of
@@ -327,6 +358,7 @@ typedef struct {
     void *tsum_ptr;                                   /* (batch, channels) f32: tsum[b, c] += sum_s T(v)[s, c], or NULL */
     void *y_inv_scale_ptr;                            /* (batch, tokens) f32, y_split3 == 2 only */
     int32_t y_f16s_lds_offset;                        /* internal (set by the library) */
+    int32_t reserved;                                 /* 0 */
 } dimsum_tt_params_t;
 
 int dimsum_token_transform(const dimsum_tt_params_t *p, void *stream);
@@ -339,6 +371,7 @@ int dimsum_token_transform(const dimsum_tt_params_t *p, void *stream);
  * lse (batch, 2, heads, L) f32 saved for the backward, or NULL.
  * ------------------------------------------------------------------------------------------------------------- */
 typedef struct {
+    uint32_t struct_size;   /* sizeof(dimsum_xattn_params_t) */
     int32_t batch, seqlen, heads, head_dim;
     float scale;
     int32_t n_dirs;   /* 0 or 2: the two swapped-KV directions above. 1: plain self-attention out = softmax(q1 k1^T) v1
@@ -378,6 +411,8 @@ int dimsum_xattn_fusion_fwd(const dimsum_xattn_params_t *p, void *stream);
  *   dqkv1/2  : (batch, L, 3*heads*hd) f32, fully overwritten (direction 0 -> dq1, dk2, dv2; direction 1 -> dq2, dk1, dv1)
  *   delta    : (batch, 2, heads, L) f32 scratch (row sums of dout o out) */
 typedef struct {
+    uint32_t struct_size;   /* sizeof(dimsum_xattn_bwd_params_t) */
+    uint32_t reserved;      /* 0 */
     dimsum_xattn_params_t fwd;
     int64_t dqkv_batch_stride, dqkv_token_stride;
     const void *dout_ptr;
@@ -400,7 +435,7 @@ int dimsum_gated_gelu_bwd(const void *x12, const void *bias, const void *dh, voi
  * paired with left-order images of W12^T (input gradient) and, through the (3 rows, .) view of both, of the MLP input (weight gradient) */
 int dimsum_gated_gelu_bwd_split3(const void *x12, const void *bias, const void *dh, void *dx12_image, void *dbias, int64_t rows,
                                  int64_t hidden, void *stream);
-/* the same with dx12 as the PAIR [hi | lo] (rows of 2 x 2 hidden bf16): see dimsum_gemm_params_t.a_alias_weight_order / tn_pair_a_cols */
+/* the same with dx12 as the PAIR [hi | lo] (rows of 2 x 2 hidden bf16): see dimsum_gemm_ext_t.a_alias_weight_order / tn_pair_a_cols */
 int dimsum_gated_gelu_bwd_pair(const void *x12, const void *bias, const void *dh, void *dx12_pair, void *dbias, int64_t rows, int64_t hidden, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -438,19 +473,19 @@ typedef enum {
                                        same scales from the same a_inv and bound. Halves the bytes between the two kernels (no fp32 qkv tensor). */
 } dimsum_gemm_epilogue_t;
 
+/* Everything beyond C = A B^T (+ bias): fused epilogue operands, operand-image read modes, timing, tuning. All 0 / NULL by default. */
 typedef struct {
-    int32_t m, n, k;
-    int32_t operand_dtype;        /* DIMSUM_BF16 or DIMSUM_F16 (both operands) */
-    int32_t epilogue;             /* dimsum_gemm_epilogue_t */
-    float out_scale;              /* GATED_GELU_F16 only */
-    int64_t lda, ldb, ldc;        /* row strides in elements of the respective dtype */
-    const void *a_ptr, *b_ptr, *bias_ptr;
-    void *c_ptr;
+    uint32_t struct_size;         /* sizeof(dimsum_gemm_ext_t) as the caller compiled it (see "Versioning" at the top) */
+    int32_t rows_per_batch;       /* F32_GATE_RESIDUAL with a gate, F16_QKV */
     void *timing_start_event, *timing_stop_event;   /* optional hipEvent_t pair recorded at the kernel's own dispatch boundaries */
-    int32_t tune_variant, tune_group_m, tune_reserved;      /* 0 = the shipped schedule and tile order (tools/bench_gemm.py --tune sweeps them) */
-    /* scaled-fp16 operand images (dimsum_rows_f16s): C[m, n] = acc * a_inv_scale[m] * b_inv_scale[n] (exact powers of two), both or none */
-    const void *a_inv_scale_ptr;  /* (m) f32 */
-    const void *b_inv_scale_ptr;  /* (n) f32 */
+    /* tune_variant: 0 = the library's choice of tile shape / schedule (dimsum_gemm_nt_kernel_for reports it). 512 = 128 x 256 tiles by 4-wave
+     * workgroups (scaled-fp16 operands only), 513 = 256 x 256 tiles, one workgroup per tile (never the persistent stream), 514 = the persistent
+     * K-tile stream (one workgroup per CU walking the tile list) where the shape allows it (k / 64 even and >= 4, more tiles than CUs, no
+     * aliased operand), else as 513. Other values: tuning builds only (-DDIMSUM_GEMM_TUNE), DIMSUM_ERR_UNSUPPORTED otherwise.
+     * tune_group_m: tile rows per L2 patch of the tile walk (0 = automatic). tune_reserved: start delay of the odd CUs (tuning builds). */
+    int32_t tune_variant, tune_group_m, tune_reserved;
+    int32_t c_image_pieces;       /* GATED_GELU_SPLIT3: 0 / 3 = the image [hi | hi | lo] (ldc >= 3 F); 2 = the pair [hi | lo] (ldc >= 2 F), for a consumer that
+                                     reads it with a_alias_rows: a third less image traffic, the same three products */
     /* GATED_GELU_F16 over scaled operands: the h image gets one power-of-two scale per row, derived WITHOUT a row reduction from the bound
      * |x1|, |x2| <= max|a_m| * gate_bound[0] + gate_bound[1]  (gate_bound = {max_n sum_k |w_nk|, max |bias|}, 2 f32 on the device);
      * its inverse goes to h_inv_scale[m] -- the a_inv_scale of the w3 GEMM. NULL: out_scale for every row. */
@@ -459,11 +494,8 @@ typedef struct {
     /* F32_GATE_RESIDUAL */
     const void *residual_ptr, *gate_ptr;
     int64_t residual_ld, gate_ld;
-    int32_t rows_per_batch;
     /* GATED_GELU_SPLIT3, training forward (mlp.py:66-70 under autograd): when non-NULL the bias-free accumulators [x1 | x2] are ALSO stored
        as float32 (m, n) rows with stride x12_ld -- what the gated-GeLU adjoint of the backward reads; bf16 images only. */
-    int32_t c_image_pieces;       /* GATED_GELU_SPLIT3: 0 / 3 = the image [hi | hi | lo] (ldc >= 3 F); 2 = the pair [hi | lo] (ldc >= 2 F), for a consumer that
-                                     reads it with a_alias_rows: a third less image traffic, the same three products */
     void *x12_ptr;
     int64_t x12_ld;
     /* != 0 = the A operand's reduction indices r >= a_alias_rows are the indices r - a_alias_rows of a_ptr (k = 3 a_alias_rows, % 64 == 0): a
@@ -479,7 +511,7 @@ typedef struct {
     int32_t a_alias_weight_order, qkv_q_cols;      /* qkv_q_cols: F16_QKV only (% 16 == 0) */
     const void *conv_weight_ptr, *conv_bias_ptr;   /* F32_CONV only */
     int32_t conv_rows, conv_width, conv_seq, conv_weight_ld;
-    /* dimsum_gemm_tn, float16 operands, splits == 1, k <= 4096: block-scaled A (the scan's fp16 out_z, dimsum_ssm_params_t.out_z_f16, with its
+    /* dimsum_gemm_tn, float16 operands, splits == 1, k <= 4096: block-scaled A (the scan's fp16 out_z, dimsum_ssm_ext_t.out_z_f16, with its
      * table as it is): a_block_inv_ptr is a (m / 32, a_block_inv_ld >= k / 64) float32 table of inverse scales (powers of two): the A values of
      * tokens [32 g, 32 g + 32) in reduction rows [64 t, 64 t + 64) stand for value * a_block_inv[g][t]. The kernel puts a token group on ONE
      * scale -- its row's largest inverse -- by multiplying the blocks by exact powers of two <= 1 as it reads them, and multiplies the result by
@@ -487,9 +519,33 @@ typedef struct {
     const void *a_block_inv_ptr;
     int64_t a_block_inv_ld;
     int64_t tn_pair_a_cols, tn_pair_b_cols;
+} dimsum_gemm_ext_t;
+
+/* The Linear itself: what F.linear(x, weight, bias) is given (plus the operand dtype and the power-of-two scales the scaled-fp16 operand
+ * images carry). `ext` = NULL: C = A B^T (+ bias), fp32 (or the gated epilogues with a constant out_scale). */
+typedef struct {
+    uint32_t struct_size;         /* sizeof(dimsum_gemm_params_t) as the caller compiled it; anything else -> DIMSUM_ERR_ABI */
+    int32_t m, n, k;
+    int32_t operand_dtype;        /* DIMSUM_BF16 or DIMSUM_F16 (both operands) */
+    int32_t epilogue;             /* dimsum_gemm_epilogue_t */
+    float out_scale;              /* GATED_GELU_F16 only */
+    int32_t reserved;             /* 0 */
+    int64_t lda, ldb, ldc;        /* row strides in elements of the respective dtype */
+    const void *a_ptr, *b_ptr, *bias_ptr;
+    void *c_ptr;
+    /* scaled-fp16 operand images (dimsum_rows_f16s): C[m, n] = acc * a_inv_scale[m] * b_inv_scale[n] (exact powers of two), both or none */
+    const void *a_inv_scale_ptr;  /* (m) f32 */
+    const void *b_inv_scale_ptr;  /* (n) f32 */
+    const dimsum_gemm_ext_t *ext; /* NULL = the plain Linear */
 } dimsum_gemm_params_t;
 
 int dimsum_gemm_nt(const dimsum_gemm_params_t *p, void *stream);
+/* Which kernel dimsum_gemm_nt launches for these parameters (a pure function of *p and of the current device's CU count; nothing is launched):
+ *   0 = gemm_nt_kernel         256 x 256 tiles, one 8-wave workgroup per tile
+ *   1 = gemm_nt_m128_kernel    128 x 256 tiles, 4-wave workgroups, two per CU (short-K launches with fp32-family epilogues)
+ *   2 = gemm_nt_persist_kernel one workgroup per CU walking the tile list as one K-tile stream (the gated w12 GEMM under the scaled-fp16 policy)
+ * or -(error status) for parameters dimsum_gemm_nt would refuse. Measurement / tests; no reference counterpart. */
+int dimsum_gemm_nt_kernel_for(const dimsum_gemm_params_t *p);
 
 /* The weight-gradient shape of the same Linears under autograd (torch.mm(dy.t(), x) in the reference's autograd graph; dimsum/mlp.py:66-70,
    attention_fusion.py:44-79): C[s] (m, n) float32 = sum over the rows r of reduction range s of A[r, 0..m)^T B[r, 0..n). a_ptr: (k, m) rows

@@ -66,6 +66,50 @@ def test_scan_fwd_bwd_rows_vs_oracle(B, D, L, N):
     assert_close(f(dC[r]), gr["dC"].reshape(f(dC[r]).shape), what="dC", **bt)
 
 
+@pytest.mark.parametrize("B", [256, 128])
+def test_headline_scan_launch_fused_dt_proj_fp16_out_z_rows_vs_oracle(B):
+    """The launch bench.py's headline times (DiM-L/2 inference under the scaled-fp16 policy, batch 256; 128 per GPU in the sampling leg):
+    dt_proj fused into the scan + block-scaled fp16 out_z, at the DISPATCH THE LIBRARY CHOOSES (no forced variant: 4096 / 2048 waves ->
+    the 64-channel kernel), operands in MambaInnerFn's layouts (x_proj written r-major: its first R rows feed the in-scan dt_proj, the
+    next 2N are B and C as (b, 1, N, l) views), decoded through the scale table and compared with the C oracle on three batch rows.
+    The oracle's delta is the float64 product W_dt x_dbl[:R] rounded to fp32 (selective_scan_interface.py:840-841)."""
+    from dimsum_amd import native
+    from oracle import c_ops
+    D, L, N, R = 1024, 256, 16, 32
+    g = torch.Generator(device="cuda").manual_seed(1000 + B)
+    u, z = dmajor(g, B, D, L), dmajor(g, B, D, L)
+    x_dbl_t = torch.randn(R + 2 * N, B * L, device="cuda", generator=g)
+    x_dbl_t[:R] *= 0.5
+    dt_w = (torch.rand(D, R, device="cuda", generator=g) * 2 - 1) * R ** -0.5           # dt_proj's own init range (mamba_simple.py:494-499)
+    A = -0.5 * torch.rand(D, N, device="cuda", generator=g) - 0.05
+    Bm = x_dbl_t[R:R + N].view(N, B, L).permute(1, 0, 2).unsqueeze(1)
+    Cm = x_dbl_t[R + N:].view(N, B, L).permute(1, 0, 2).unsqueeze(1)
+    Dv, bias = torch.randn(D, device="cuda", generator=g), 0.5 * torch.rand(D, device="cuda", generator=g)
+    assert native._scan_fwd_variant == 0 and native.scan_fwd_kernel_for(B, D, L, N) == 1
+    assert native.scan_dt_proj_supported(u, z, A, dt_w, x_dbl_t[:R]) and native.scan_out_z_f16_supported(u, z, A, 1)
+    out, x, (img, inv) = native.selective_scan_fwd(u, None, A, Bm, Cm, Dv, z, bias, True, need_out=False, need_x=False,
+                                                   dt_proj=(dt_w, x_dbl_t[:R]), out_z_f16=True)
+    assert out is None and x is None and img.shape == (D, B * L) and img.dtype == torch.float16 and inv.shape == (B * L // 32, D // 64)
+    r = rows_of(B)
+    delta = (dt_w.double() @ x_dbl_t[:R].double()).float().view(D, B, L).permute(1, 0, 2)
+    _, oz_ref, _ = c_ops.selective_scan_fwd(f(u[r]), f(delta[r]), f(A), f(Bm[r]), f(Cm[r]), f(Dv), f(z[r]), f(bias), True)
+    # decode: value = fp16 * table[token / 32, channel / 64]
+    scale = inv.repeat_interleave(32, 0).repeat_interleave(64, 1).t()                      # (D, B L)
+    dec = (img.float() * scale).view(D, B, L).permute(1, 0, 2)
+    # tolerance: the fp32 scan's (scan_tol) + the in-scan dt_proj's three bf16 products (2e-5 of |delta|, test_scan_gpu.py) + half an fp16
+    # ulp: 2^-11 relative for every element within 2^-14 of its block's maximum, 2^-25 of that maximum below
+    t = scan_tol(L)
+    got, want = f(dec[r]), oz_ref
+    bmax = np.abs(want.reshape(3, D // 64, 64, L // 32, 32)).max(axis=(2, 4), keepdims=True)
+    bmax = np.broadcast_to(bmax, (3, D // 64, 64, L // 32, 32)).reshape(3, D, L)
+    tol = (t["rtol"] + 2.0 ** -11) * np.abs(want) + t["scale_atol"] * np.abs(want).max() + 2.0 ** -24 * bmax
+    err = np.abs(got - want)
+    assert (err <= tol).all(), f"max violation {np.max(err - tol):.3e}; max err {err.max():.3e} of {np.abs(want).max():.3e}"
+    # and the same launch without the two fusions (GEMM-fed delta, fp32 out_z) agrees with the decoded image block by block
+    _, _, oz32 = native.selective_scan_fwd(u[r], delta[r].contiguous(), A, Bm[r].contiguous(), Cm[r].contiguous(), Dv, z[r], bias, True, need_out=False, need_x=False)
+    assert_close(got, f(oz32), rtol=2.0 ** -10, atol=0.0, what="fused launch vs the fp32 launch", scale_atol=2e-5)
+
+
 @pytest.mark.parametrize("B,D,L,N", SHAPES)
 def test_conv1d_fwd_bwd_rows_vs_oracle(B, D, L, N):
     from dimsum_amd import native

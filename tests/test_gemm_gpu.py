@@ -293,8 +293,9 @@ def test_alias_parameters_are_checked_at_the_c_abi():
         P.operand_dtype, P.epilogue, P.out_scale = native._DT[torch.bfloat16], _lib.GEMM_EPI_F32, 1.0
         P.lda, P.ldb, P.ldc = a.stride(0), b.stride(0), 256
         P.a_ptr, P.b_ptr, P.c_ptr = a.data_ptr(), b.data_ptr(), c.data_ptr()
+        X = _lib.attach_ext(P, _lib.GemmExt)
         for k, v in kw.items():
-            setattr(P, k, v)
+            setattr(X if hasattr(X, k) else P, k, v)
         return P
 
     s = torch.cuda.current_stream().cuda_stream

@@ -60,48 +60,117 @@ def test_library_exports_every_declared_symbol():
     assert lib.dimsum_status_string(3).decode().startswith("unsupported shape")
 
 
-def test_struct_sizes_match_header():
-    """ctypes mirrors must have the C layout: compile a tiny C program against the header and compare sizeof."""
+_STRUCTS = [("dimsum_ssm_params_t", "SsmParams"), ("dimsum_ssm_ext_t", "SsmExt"), ("dimsum_ssm_bwd_params_t", "SsmBwdParams"),
+            ("dimsum_conv_params_t", "ConvParams"), ("dimsum_conv_bwd_params_t", "ConvBwdParams"), ("dimsum_norm_params_t", "NormParams"),
+            ("dimsum_norm_bwd_params_t", "NormBwdParams"), ("dimsum_tt_params_t", "TtParams"), ("dimsum_xattn_params_t", "XattnParams"),
+            ("dimsum_xattn_bwd_params_t", "XattnBwdParams"), ("dimsum_gemm_params_t", "GemmParams"), ("dimsum_gemm_ext_t", "GemmExt"),
+            ("dimsum_f16s_job_t", "F16sJob")]
+
+
+def _header_layout(pairs):
+    """{c struct: (sizeof, {field: offset})} from a C program compiled against include/dimsum_hip.h; pairs: [(c struct, ctypes mirror)]"""
     import subprocess
     import tempfile
-    from dimsum_amd import _lib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = '#include <stdio.h>\n#include "dimsum_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",' \
-          'sizeof(dimsum_ssm_params_t),sizeof(dimsum_ssm_bwd_params_t),sizeof(dimsum_conv_params_t),' \
-          'sizeof(dimsum_conv_bwd_params_t),sizeof(dimsum_norm_params_t),sizeof(dimsum_norm_bwd_params_t),' \
-          'sizeof(dimsum_tt_params_t),sizeof(dimsum_xattn_params_t),sizeof(dimsum_xattn_bwd_params_t),sizeof(dimsum_gemm_params_t));return 0;}\n'
+    body = ""
+    for cname, mirror in pairs:
+        body += f'printf("{cname} %zu", sizeof({cname}));'
+        body += "".join(f'printf(" {f}=%zu", offsetof({cname}, {f}));' for f, _ in mirror._fields_)
+        body += 'printf("\\n");'
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "dimsum_hip.h"\nint main(){' + body + 'return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(src)
         subprocess.run(["gcc", "-I", os.path.join(root, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")], check=True)
-        sizes = [int(v) for v in subprocess.run([os.path.join(d, "s")], capture_output=True, text=True, check=True).stdout.split()]
-    mirrors = [_lib.SsmParams, _lib.SsmBwdParams, _lib.ConvParams, _lib.ConvBwdParams, _lib.NormParams, _lib.NormBwdParams,
-               _lib.TtParams, _lib.XattnParams, _lib.XattnBwdParams, _lib.GemmParams]
-    assert sizes == [ctypes.sizeof(m) for m in mirrors]
+        out = subprocess.run([os.path.join(d, "s")], capture_output=True, text=True, check=True).stdout
+    layout = {}
+    for line in out.strip().splitlines():
+        name, size, *fields = line.split()
+        layout[name] = (int(size), {f.split("=")[0]: int(f.split("=")[1]) for f in fields})
+    return layout
 
 
-def test_field_offsets_of_the_round5_fields_match_header():
-    """the fields added in round 5 sit where the header puts them (a swap of two equally sized fields would pass the sizeof test)"""
-    import subprocess
-    import tempfile
+def test_struct_layouts_match_header():
+    """ctypes mirrors must have the C layout: sizeof AND the offset of every field of every struct (a swap of two equally sized fields
+    would pass a sizeof test), from a C program compiled against the header; every struct starts with struct_size"""
     from dimsum_amd import _lib
+    pairs = [(c, getattr(_lib, m)) for c, m in _STRUCTS]
+    layout = _header_layout(pairs)
+    for cname, mirror in pairs:
+        size, offs = layout[cname]
+        assert size == ctypes.sizeof(mirror), cname
+        assert offs == {f: getattr(mirror, f).offset for f, _ in mirror._fields_}, cname
+        if cname != "dimsum_f16s_job_t":
+            assert mirror._fields_[0][0] == "struct_size" and getattr(mirror, "struct_size").offset == 0, cname
+            assert mirror().struct_size == size, cname                       # filled in on construction
+
+
+def test_documented_stub_matches_the_header():
+    """INTEGRATION.md section 2 shows the ctypes stub a maintainer of the reference would write. The block between its begin / end markers
+    is executed as it stands and its two structs are compared with the header: sizeof and every field offset. (Round 5 shipped a stub that
+    stopped 8 fields short of the struct it described.)"""
+    import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    fields = [("dimsum_ssm_params_t", _lib.SsmParams, ["dt_w_ptr", "dt_x_ptr", "dt_w_row_stride", "dt_x_row_stride", "dt_rank", "out_z_f16", "out_z_scale_ptr", "out_z_scale_ld"]),
-              ("dimsum_xattn_params_t", _lib.XattnParams, ["qkv_f16"]),
-              ("dimsum_gemm_params_t", _lib.GemmParams, ["qkv_q_cols", "conv_weight_ptr", "conv_bias_ptr", "conv_rows", "conv_width", "conv_seq", "conv_weight_ld",
-                                                         "a_block_inv_ptr", "a_block_inv_ld", "tn_pair_a_cols", "tune_variant", "tune_reserved"])]
-    body = "".join(f'printf("%zu ", offsetof({st}, {f}));' for st, _, fs in fields for f in fs)
-    src = '#include <stdio.h>\n#include <stddef.h>\n#include "dimsum_hip.h"\nint main(){' + body + 'return 0;}\n'
-    with tempfile.TemporaryDirectory() as d:
-        open(os.path.join(d, "o.c"), "w").write(src)
-        subprocess.run(["gcc", "-I", os.path.join(root, "include"), os.path.join(d, "o.c"), "-o", os.path.join(d, "o")], check=True)
-        offs = [int(v) for v in subprocess.run([os.path.join(d, "o")], capture_output=True, text=True, check=True).stdout.split()]
-    assert offs == [getattr(m, f).offset for _, m, fs in fields for f in fs]
-    # the job table of dimsum_rows_f16s_multi
-    src = '#include <stdio.h>\n#include "dimsum_hip.h"\nint main(){printf("%zu", sizeof(dimsum_f16s_job_t));return 0;}\n'
-    with tempfile.TemporaryDirectory() as d:
-        open(os.path.join(d, "j.c"), "w").write(src)
-        subprocess.run(["gcc", "-I", os.path.join(root, "include"), os.path.join(d, "j.c"), "-o", os.path.join(d, "j")], check=True)
-        assert int(subprocess.run([os.path.join(d, "j")], capture_output=True, text=True, check=True).stdout) == ctypes.sizeof(_lib.F16sJob)
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    m = re.search(r"# --- documented stub: begin ---\n(.*?)# --- documented stub: end ---", text, re.S)
+    assert m, "INTEGRATION.md lost its documented stub"
+    ns = {}
+    exec(m.group(1), ns)
+    pairs = [("dimsum_ssm_params_t", ns["SsmParams"]), ("dimsum_ssm_ext_t", ns["SsmExt"])]
+    layout = _header_layout(pairs)
+    for cname, mirror in pairs:
+        size, offs = layout[cname]
+        assert size == ctypes.sizeof(mirror), cname
+        assert offs == {f: getattr(mirror, f).offset for f, _ in mirror._fields_}, cname
+    # every field of the header's two structs is in the stub (the offsets above only cover what the stub names)
+    header = open(os.path.join(root, "include", "dimsum_hip.h")).read()
+    for cname, mirror in pairs:
+        body = re.search(r"typedef struct \{((?:(?!typedef struct).)*?)\} " + cname + ";", header, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if decl:
+                names += [re.sub(r"[\s\*]", "", part).split(" ")[-1] for part in re.sub(r"^(const\s+)?[A-Za-z_0-9]+\s+", "", decl).split(",")]
+        assert names == [f for f, _ in mirror._fields_], (cname, names)
+    # and the stub binds: the library loads without a GPU and a stale size is refused before anything is read (no device call is made)
+    lib = ns["bind"](os.path.join(root, "dimsum_amd", "lib", "libdimsum_hip.so"))
+    p = ns["SsmParams"]()
+    p.struct_size = ctypes.sizeof(ns["SsmParams"]) - 8                       # a caller built against an older, shorter header
+    assert lib.dimsum_ssm_scan_fwd(p, None) == 7
+    assert "struct_size" in lib.dimsum_status_string(7).decode()
+
+
+def test_stale_or_foreign_structs_are_refused_not_read():
+    """every entry point checks struct_size first (DIMSUM_ERR_ABI = 7): a zeroed struct of the wrong size never reaches a pointer check;
+    an extension larger than the library's is refused, a shorter one reads its missing tail as zeros. CPU-only: nothing is launched."""
+    from dimsum_amd import _lib
+    lib = _lib.load()
+    for fn, mirror in ((lib.dimsum_ssm_scan_fwd, _lib.SsmParams), (lib.dimsum_ssm_scan_bwd, _lib.SsmBwdParams),
+                       (lib.dimsum_causal_conv1d_fwd, _lib.ConvParams), (lib.dimsum_causal_conv1d_bwd, _lib.ConvBwdParams),
+                       (lib.dimsum_norm_fwd, _lib.NormParams), (lib.dimsum_norm_bwd, _lib.NormBwdParams),
+                       (lib.dimsum_token_transform, _lib.TtParams), (lib.dimsum_xattn_fusion_fwd, _lib.XattnParams),
+                       (lib.dimsum_xattn_fusion_bwd, _lib.XattnBwdParams), (lib.dimsum_gemm_nt, _lib.GemmParams)):
+        P = mirror()
+        assert fn(P, None) != 7, mirror                                      # the right size gets past the check (and fails on its NULL pointers)
+        for bad in (0, ctypes.sizeof(mirror) - 8, ctypes.sizeof(mirror) + 8):
+            P.struct_size = bad
+            assert fn(P, None) == 7, (mirror, bad)
+    P = _lib.GemmParams()
+    P.struct_size = 0
+    assert lib.dimsum_gemm_tn(P, 1, 0, None) == 7 and lib.dimsum_gemm_nt_kernel_for(P) == -7
+    # extensions: the dispatch query is a pure host function of (*p, *p->ext)
+    P = _lib.SsmParams()
+    P.batch, P.dim, P.seqlen, P.dstate, P.n_groups, P.n_chunks = 256, 1024, 256, 16, 1, 1
+    assert lib.dimsum_ssm_scan_fwd_variant(P) == 1                           # ext = NULL: the reference interface, automatic dispatch
+    E = _lib.attach_ext(P, _lib.SsmExt)
+    E.kernel_variant = 4
+    assert lib.dimsum_ssm_scan_fwd_variant(P) == 4
+    E.struct_size = 8                                                        # a caller whose dimsum_ssm_ext_t ends after kernel_variant
+    assert lib.dimsum_ssm_scan_fwd_variant(P) == 4
+    E.struct_size = 4                                                        # ... and one that only knows struct_size: the rest reads as 0
+    assert lib.dimsum_ssm_scan_fwd_variant(P) == 1
+    E.struct_size = ctypes.sizeof(_lib.SsmExt) + 8                           # a caller that knows MORE than this library
+    assert lib.dimsum_ssm_scan_fwd_variant(P) == -1 and lib.dimsum_ssm_scan_fwd(P, None) == 7
 
 
 def test_ops_fail_loudly_without_gpu():

@@ -182,6 +182,76 @@ def test_zoo_forward_under_the_f16s_policy_vs_reference_goldens(name, tag, B, R,
     assert e1.max().item() <= 1.25 * et.max().item() and e1.pow(2).mean().sqrt().item() <= 1.1 * et.pow(2).mean().sqrt().item()
 
 
+class _LaunchSpy:
+    """records which of the inference launch routes a forward took: the scan's fused options, the TN out_proj over a block-scale table,
+    the GEMM epilogues and the kernel family the library picked for each gemm_nt call (native.gemm_kernel_log)"""
+
+    def __init__(self, monkeypatch):
+        from dimsum_amd import native
+        self.scan, self.tn_tables, self.conv_done = [], 0, 0
+        real_scan, real_tn = native.selective_scan_fwd, native.gemm_tn
+
+        def scan(*a, **kw):
+            self.scan.append((kw.get("dt_proj") is not None, bool(kw.get("out_z_f16")), native.scan_fwd_kernel_for(*a[0].shape, a[2].shape[1], a[3].shape[1])))
+            return real_scan(*a, **kw)
+
+        def tn(a, b, **kw):
+            sc = kw.get("scales")
+            self.tn_tables += int(sc is not None and sc[0].dim() == 2)
+            return real_tn(a, b, **kw)
+        monkeypatch.setattr(native, "selective_scan_fwd", scan)
+        monkeypatch.setattr(native, "gemm_tn", tn)
+
+
+@pytest.mark.parametrize("name,tag,B,R,over", [("DiM-L/2", "model_L2", 128, 32, {}), ("DiM-XL/2", "model_XL2_512_zigma8", 64, 64, dict(scan_type="zigma_8"))])
+def test_as_run_launch_mix_at_bench_batch_sizes_vs_reference_goldens(name, tag, B, R, over, monkeypatch):
+    """The EXACT configuration bench.py times, against the reference goldens: policy "f16s" with its DEFAULT thresholds (no forced carriers,
+    no forced kernel variant) at the batch sizes of the sampling leg (128 latents per GPU of DiM-L/2) and of BASELINE's config 5 (64 latents
+    of DiM-XL/2 at 512 px with the 8-way zigzag orders). The golden latents (2 resp. 1, from the reference model in exact fp32) sit at the first
+    and last rows of the batch, random latents in between (every latent is independent through the denoiser). A spy asserts the launch mix:
+    at DiM-L/2 every mixer takes the 64-channel scan with dt_proj fused and block-scaled fp16 out_z, out_proj the TN product over that
+    table, in_proj carries the conv in its epilogue, qkv leaves as scaled fp16, w12 + gate runs as the persistent stream; at XL/2 (1152
+    waves: the 4-lanes-per-channel scan) the scan keeps the reference-shaped launch. Tolerance: the zoo's f16s bound."""
+    from dimsum_amd import _lib, gemm, native
+    from dimsum_amd.models_dim import DiM_models
+    monkeypatch.delenv("DIMSUM_SPLIT3_MIN_ROWS", raising=False)
+    monkeypatch.setattr(torch.backends.cuda.matmul, "allow_tf32", True)
+    g = golden(tag)
+    m = DiM_models[name](**_published(img_resolution=R, **over))
+    procedural_fill(m, seed=3)
+    m = m.cuda().eval()
+    n_gold = g["out"].shape[0]
+    gold_rows = [0, B - 1][:n_gold]
+    gen = torch.Generator().manual_seed(4242)
+    x = torch.randn(B, 4, R, R, generator=gen)
+    t, y = torch.rand(B, generator=gen), torch.randint(0, 1000, (B,), generator=gen)
+    x[gold_rows] = T(seeded((n_gold, 4, R, R), 71))
+    t[gold_rows], y[gold_rows] = T(g["t"]).to(t.dtype), T(g["y"]).to(y.dtype)
+    spy = _LaunchSpy(monkeypatch)
+    gemm.set_policy("f16s")
+    try:
+        assert native._scan_fwd_variant == 0
+        with torch.no_grad(), native.gemm_kernel_log() as log:
+            out = m(x.cuda(), t.cuda(), y.cuda())
+    finally:
+        gemm.set_policy("default")
+    depth = len(m.blocks)
+    mixers = sum(1 for mm in m.modules() if hasattr(mm, "x_proj") and hasattr(mm, "dt_proj"))
+    assert len(spy.scan) == mixers >= 2 * depth
+    by = {}
+    for epi, kern in log:
+        by.setdefault(epi, []).append(kern)
+    assert len(by.get("gated_f16", [])) >= depth and all(k == 2 for k in by["gated_f16"]), by.get("gated_f16")     # w12 + gate: persistent stream
+    assert len(by.get("f16_qkv", [])) >= 2 * depth, {k: len(v) for k, v in by.items()}
+    if name == "DiM-L/2":
+        assert all(s == (True, True, 1) for s in spy.scan), spy.scan
+        assert spy.tn_tables == mixers and len(by.get("f32_conv", [])) == mixers, {k: len(v) for k, v in by.items()}
+    else:
+        assert all(s == (False, False, 4) for s in spy.scan), spy.scan
+    assert_close(out[gold_rows].cpu().numpy(), g["out"], 1e-3, 0, f"{tag} rows {gold_rows} of a batch of {B} (f16s, default thresholds)", scale_atol=5e-4)
+    assert torch.isfinite(out).all()
+
+
 def test_block_combined_1024_forward_under_the_f16s_policy_vs_reference_golden(f16s_policy, monkeypatch):
     """configs[2]'s block at DiM-L/2's width against the reference block golden, inference forward under the headline policy. Tolerance:
     the north star's 1e-3 of max|ref| -- ONE block under any 10-bit-mantissa arithmetic sits at 4-5e-4 (the emulated-TF32 run of this

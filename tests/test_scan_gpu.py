@@ -137,11 +137,11 @@ def test_forward_kernel_variants_agree():
             out, x, oz, ck = native.selective_scan_fwd(u, dl, A, Bm, Cm, Dv, z, bias, True, need_ckpt=True)
             res[v] = [t.cpu().numpy() for t in (out, x, oz, ck)]
             P = _lib.SsmParams()
-            native._fill_ssm(P, u, dl, A, Bm, Cm, Dv, z, bias, True, out, x, oz)
-            assert P.kernel_variant == v and lib.dimsum_ssm_scan_fwd_variant(P) == v
+            E = native._fill_ssm(P, u, dl, A, Bm, Cm, Dv, z, bias, True, out, x, oz)
+            assert E.kernel_variant == v and lib.dimsum_ssm_scan_fwd_variant(P) == v
     P = _lib.SsmParams()
-    native._fill_ssm(P, u, dl, A, Bm, Cm, Dv, z, bias, True, out, x, oz)
-    assert P.kernel_variant == 0                # the request ends with its scope: nothing sticks in the library or the host layer
+    E = native._fill_ssm(P, u, dl, A, Bm, Cm, Dv, z, bias, True, out, x, oz)
+    assert E.kernel_variant == 0                # the request ends with its scope: nothing sticks in the library or the host layer
     for v in (2, 4, 16):
         for name, a, b in zip(("out", "x", "out_z", "saved states"), res[v], res[1]):
             assert_close(a, b, 2e-5, 0, f"{name} (variant {v})", scale_atol=2e-6)
@@ -357,7 +357,7 @@ def test_forward_variants_vs_oracle_on_ragged_shapes(variant, B, D, L, G, has_z,
 
 
 def test_timing_events_bracket_the_whole_backward_call(monkeypatch):
-    """dimsum_ssm_params_t.timing_start_event / timing_stop_event (per call, no process state): in a backward call they are
+    """dimsum_ssm_ext_t.timing_start_event / timing_stop_event (per call, no process state): in a backward call they are
     recorded at the begin of its FIRST kernel and the end of its LAST one -- with saved states that is main kernel .. reduce
     kernel; for a reference-shaped call (no saved states) the interval also contains the state-rebuild sweep, so it is longer by
     about a forward launch. A call without events records nothing."""
@@ -399,7 +399,7 @@ def test_timing_events_bracket_the_whole_backward_call(monkeypatch):
 
 @pytest.mark.parametrize("B,D,L,R", [(2, 128, 256, 32), (3, 192, 100, 8), (1, 64, 36, 12), (2, 256, 1024, 32)])
 def test_fused_dt_proj_matches_the_scan_fed_with_the_gemm_result(B, D, L, R):
-    """dimsum_ssm_params_t.dt_w_ptr (inference extra, csrc/ssm_scan_fwd_kernel.hpp kDt): delta = W_dt x_dbl[:R] formed per tile on the matrix
+    """dimsum_ssm_ext_t.dt_w_ptr (inference extra, csrc/ssm_scan_fwd_kernel.hpp kDt): delta = W_dt x_dbl[:R] formed per tile on the matrix
     cores inside the 64-channel kernel (3 bf16 products per fp32 product, fp32-class like the library GEMM it replaces,
     selective_scan_interface.py:840-841) against the same kernel fed with the float64 product rounded to fp32, and against the C oracle;
     dt_rank below 32 (zero-padded K), ragged last tile, several tiles"""
@@ -438,7 +438,7 @@ def test_fused_dt_proj_matches_the_scan_fed_with_the_gemm_result(B, D, L, R):
 
 @pytest.mark.parametrize("B,D,L,fused", [(2, 128, 256, False), (3, 192, 96, True), (1, 64, 32, False), (2, 256, 1024, True)])
 def test_block_scaled_fp16_out_z_decodes_to_the_fp32_out_z(B, D, L, fused):
-    """dimsum_ssm_params_t.out_z_f16 (inference extra, kZ16): every 64-channel x 32-step block of out_z as fp16(value 2^s) with 2^-s in the
+    """dimsum_ssm_ext_t.out_z_f16 (inference extra, kZ16): every 64-channel x 32-step block of out_z as fp16(value 2^s) with 2^-s in the
     table: decoded, it is the fp32 kernel's out_z to half an fp16 ulp of the block's own maximum (2^-11 relative to at most 2 x the maximum),
     the scales are exact powers of two that put the block maximum in [2^14, 2^15]; with and without the fused dt_proj; blocks of very
     different magnitudes (z = 0 on one block: an all-zero block decodes to zeros)"""

@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--dt-fused", action="store_true", help="forward with dt_proj inside the kernel (implies --infer): delta = W_dt x_dbl[:32] per tile on the matrix cores")
     a = ap.parse_args()
     from dimsum_amd import _lib
-    native._scan_fwd_variant = max(a.variant, 0)          # per-call field of the C ABI (dimsum_ssm_params_t.kernel_variant)
+    native._scan_fwd_variant = max(a.variant, 0)          # per-call field of the C ABI (dimsum_ssm_ext_t.kernel_variant)
     dt = getattr(torch, a.dtype)
     B, D, L, N = a.B, a.D, a.L, a.N
     dev = "cuda"
@@ -113,7 +113,7 @@ def main():
     copy_gbps = 5 * 2 * 4 * (1 << 28) / (c0.elapsed_time(c1) * 1e-3) / 1e9
     P = _lib.SsmParams()
     P.batch, P.dim, P.seqlen, P.dstate, P.n_groups, P.n_chunks = B, D, L, N, 1, (L + 2047) // 2048
-    P.kernel_variant = native._scan_fwd_variant
+    _lib.attach_ext(P, _lib.SsmExt).kernel_variant = native._scan_fwd_variant
     print(json.dumps({"kernel": "bwd" if a.bwd else "fwd", "fwd_variant": _lib.load().dimsum_ssm_scan_fwd_variant(P), "shape": [B, D, L, N], "dtype": a.dtype, "ms_median": med, "ms_min": ms[0], "algorithmic_GB": nbytes / 1e9,
                       "GBps": nbytes / med / 1e6, "frac_of_8TBps": nbytes / med / 1e6 / 8000,
                       "box_copy_GBps": copy_gbps, "frac_of_box_copy": nbytes / med / 1e6 / copy_gbps, "timed_by": "HIP events, this process"}))
