@@ -36,6 +36,7 @@ for suffix, bench, shape, kernels in FILES:
         continue
     fetch = write = 0.0
     found = []
+    ctr = {}
     for ln in open(path):
         m = re.match(r"(\S.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+avg=([0-9.e+]+)", ln)
         if m and any(k in m.group(1) for k in kernels):
@@ -44,9 +45,24 @@ for suffix, bench, shape, kernels in FILES:
             else:
                 write += float(m.group(3))
             found.append(m.group(1).strip())
+        m = re.match(r"(\S.*?)\s+(SQ_INSTS_VALU|SQ_ACTIVE_INST_VALU|SQ_WAVES|GRBM_GUI_ACTIVE)\s+avg=([0-9.e+]+)", ln)
+        if m and kernels[0] in m.group(1):            # the main kernel only (not the backward's small reduce kernel)
+            ctr[m.group(2)] = float(m.group(3))
     if fetch == 0 and write == 0:
         continue
-    entries.append({"bench_kernel": bench, "rocprof_kernels": sorted(set(found)), "shape_BDLN": list(shape), "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
+    valu = None
+    if all(k in ctr for k in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVES", "GRBM_GUI_ACTIVE")) and ctr["SQ_WAVES"] > 0:
+        # busy: SQ_ACTIVE_INST_VALU counts quad-cycles per SIMD: x 4 / 1024 SIMDs against the kernel's cycles (GRBM_GUI_ACTIVE / 8 XCDs).
+        # insts_per_tn: VALU instructions a wave issues per (time step, state) pair of one lane -- lanes per channel by kernel family
+        # (forward: 1 / 4 / 16 for the 64-channel / 4-lanes / one-lane-per-state kernels; backward: lane = (channel, 4 states))
+        B_, D_, L_, N_ = shape
+        lanes = 16 if "lanes_kernel" in kernels[0] else 4 if ("split" in kernels[0] or "bwd" in kernels[0]) else 1
+        valu = {"busy": round(ctr["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (ctr["GRBM_GUI_ACTIVE"] / 8), 3),
+                "insts_per_tn": round(ctr["SQ_INSTS_VALU"] / ctr["SQ_WAVES"] / (L_ * N_ / lanes), 2),
+                "floor_per_tn": 5.0 if "bwd" not in kernels[0] else None,
+                "what": "busy = SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8); insts_per_tn = SQ_INSTS_VALU / SQ_WAVES / ((steps x states) per lane); "
+                        "floor (forward): exp2, a = exp2(dt A), b = dt u B, h = a h + b, y += C h per (step, state)"}
+    entries.append({"valu": valu, "bench_kernel": bench, "rocprof_kernels": sorted(set(found)), "shape_BDLN": list(shape), "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
                     "source": f"profiles/{tag}_{suffix}_pmc.txt", "fetch_correction": 2.0, "hbm_bytes_per_launch": int((2 * fetch + write) * 1024)})
 out = {"note": __doc__.split(": ", 1)[1].replace("\n", " "), "entries": entries}
 json.dump(out, open(os.path.join(ROOT, "profiles", "scan_pmc.json"), "w"), indent=1)
