@@ -120,7 +120,8 @@ class GemmExt(_Sized):
                 + [("residual_ld", i64), ("gate_ld", i64), ("x12_ptr", vp), ("x12_ld", i64), ("a_alias_rows", i64), ("b_alias_rows", i64),
                    ("a_alias_weight_order", i32), ("qkv_q_cols", i32), ("conv_weight_ptr", vp), ("conv_bias_ptr", vp),
                    ("conv_rows", i32), ("conv_width", i32), ("conv_seq", i32), ("conv_weight_ld", i32),
-                   ("a_block_inv_ptr", vp), ("a_block_inv_ld", i64), ("tn_pair_a_cols", i64), ("tn_pair_b_cols", i64)])
+                   ("a_block_inv_ptr", vp), ("a_block_inv_ld", i64), ("tn_pair_a_cols", i64), ("tn_pair_b_cols", i64),
+                   ("k_scale_ptr", vp), ("c_scale_ptr", vp)])
 
 
 class GemmParams(_Sized):
@@ -144,7 +145,7 @@ EXPORTS = (
     "dimsum_ssm_scan_fwd", "dimsum_ssm_scan_bwd", "dimsum_ssm_scan_bwd_workspace_bytes", "dimsum_ssm_scan_fwd_variant",
     "dimsum_causal_conv1d_fwd", "dimsum_causal_conv1d_bwd",
     "dimsum_norm_fwd", "dimsum_norm_bwd", "dimsum_token_transform", "dimsum_xattn_fusion_fwd", "dimsum_xattn_fusion_bwd",
-    "dimsum_gated_gelu_fwd", "dimsum_gated_gelu_bwd", "dimsum_gated_gelu_fwd_split3", "dimsum_gated_gelu_bwd_split3", "dimsum_gated_gelu_bwd_pair", "dimsum_split3", "dimsum_split3_t",
+    "dimsum_gated_gelu_fwd", "dimsum_gated_gelu_bwd", "dimsum_gated_gelu_fwd_split3", "dimsum_gated_gelu_bwd_split3", "dimsum_gated_gelu_bwd_pair", "dimsum_gated_gelu_bwd_f16s", "dimsum_split3", "dimsum_split3_t",
     "dimsum_gemm_nt", "dimsum_gemm_nt_kernel_for", "dimsum_gemm_tn", "dimsum_rows_f16s", "dimsum_rows_f16s_multi",
 )
 
@@ -183,6 +184,9 @@ def load():
             fn = getattr(lib, name)
             fn.restype = C.c_int
             fn.argtypes = [vp] * nptr + [i64, i64, vp]
+    if hasattr(lib, "dimsum_gated_gelu_bwd_f16s"):
+        lib.dimsum_gated_gelu_bwd_f16s.restype = C.c_int
+        lib.dimsum_gated_gelu_bwd_f16s.argtypes = [vp] * 6 + [i64, i64, vp]
     if hasattr(lib, "dimsum_gemm_nt_kernel_for"):
         lib.dimsum_gemm_nt_kernel_for.restype = C.c_int
         lib.dimsum_gemm_nt_kernel_for.argtypes = [C.POINTER(GemmParams)]

@@ -232,12 +232,14 @@ static int gemm_nt_run(const dimsum_gemm_params_t *pub, void *stream, int *probe
             a.gate_bound = reinterpret_cast<const float *>(p->gate_bound_ptr);
             a.inv_out = reinterpret_cast<float *>(p->h_inv_scale_ptr);
         }
-        if (p->x12_ptr) {       // training forward: keep the fp32 [x1 | x2] for the backward (split-bf16 images only)
-            if (!img || !bf || a.sa) return DIMSUM_ERR_UNSUPPORTED;
+        if (p->x12_ptr) {       // training forward: keep the fp32 [x1 | x2] for the backward: split-bf16 images, or scaled-fp16 operands with the bound-derived h scale
+            const bool f16_train = !img && !bf && a.sa && p->gate_bound_ptr;
+            if (!f16_train && (!img || !bf || a.sa)) return DIMSUM_ERR_UNSUPPORTED;
             if (p->x12_ld % 4 != 0 || p->x12_ld < p->n || !aligned_to<char>(p->x12_ptr, 16) || (int64_t)257 * p->x12_ld * 4 + (int64_t)p->n * 4 >= ((int64_t)1 << 31))
                 return DIMSUM_ERR_STRIDE;
             a.x12 = reinterpret_cast<float *>(p->x12_ptr);
             a.ldx = p->x12_ld;
+            if (f16_train) return launch<kOpF16, kEpiGatedF16, kVarKeepX12>(a, s, e0, e1, probe);
             return launch<kOpBf16, kEpiGatedSplit3, kVarKeepX12>(a, s, e0, e1, probe);
         }
         if (img) return bf ? launch<kOpBf16, kEpiGatedSplit3>(a, s, e0, e1, probe) : launch<kOpF16, kEpiGatedSplit3>(a, s, e0, e1, probe);
@@ -270,6 +272,12 @@ extern "C" int dimsum_gemm_tn(const dimsum_gemm_params_t *pub, int32_t splits, i
     if (p->epilogue != DIMSUM_GEMM_EPI_F32 || p->bias_ptr) return DIMSUM_ERR_UNSUPPORTED;
     if (((p->a_inv_scale_ptr || p->a_block_inv_ptr) == 0) != (p->b_inv_scale_ptr == nullptr)) return DIMSUM_ERR_NULL;
     if ((p->a_inv_scale_ptr || p->a_block_inv_ptr) && (p->operand_dtype != DIMSUM_F16 || splits != 1 || p->tn_pair_a_cols != 0 || p->a_alias_rows != 0)) return DIMSUM_ERR_UNSUPPORTED;
+    if (p->k_scale_ptr) {          // per-reduction-row factors: fp16 operands, plain rows, the factors of one range fit the 32 KB behind the ring
+        if (!p->c_scale_ptr) return DIMSUM_ERR_NULL;
+        if (p->operand_dtype != DIMSUM_F16 || p->a_inv_scale_ptr || p->a_block_inv_ptr || p->tn_pair_a_cols != 0 || p->a_alias_rows != 0) return DIMSUM_ERR_UNSUPPORTED;
+        if (splits < 1 || p->k / splits > 16384) return DIMSUM_ERR_SHAPE;
+        if (!aligned_to<char>(p->k_scale_ptr, 16) || !aligned_to<char>(p->c_scale_ptr, 4)) return DIMSUM_ERR_STRIDE;
+    }
     if (p->a_block_inv_ptr && (p->a_inv_scale_ptr || p->a_block_inv_ld < p->k / kBK || p->k > 64 * kBK)) return DIMSUM_ERR_SHAPE;
     if (p->b_inv_scale_ptr && !aligned_to<char>(p->b_inv_scale_ptr, 16)) return DIMSUM_ERR_STRIDE;
     const int row_splits = (p->tn_pair_a_cols != 0) ? splits / 3 : splits;       // (pairs: the three pieces share the row ranges)
@@ -312,6 +320,8 @@ extern "C" int dimsum_gemm_tn(const dimsum_gemm_params_t *pub, int32_t splits, i
     a.sb = reinterpret_cast<const float *>(p->b_inv_scale_ptr);
     a.a_block_inv = reinterpret_cast<const float *>(p->a_block_inv_ptr);
     a.a_block_inv_ld = (int)p->a_block_inv_ld;
+    a.k_fac = reinterpret_cast<const _Float16 *>(p->k_scale_ptr);
+    a.c_scale = reinterpret_cast<const float *>(p->c_scale_ptr);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t e0 = reinterpret_cast<hipEvent_t>(p->timing_start_event), e1 = reinterpret_cast<hipEvent_t>(p->timing_stop_event);
     constexpr int kShipT = kVarFullLineStores | kVarNtStores | kVarTN;
@@ -319,6 +329,9 @@ extern "C" int dimsum_gemm_tn(const dimsum_gemm_params_t *pub, int32_t splits, i
     if (p->operand_dtype == DIMSUM_BF16) {
         if (e0 || e1) hipExtLaunchKernelGGL((gemm_nt_kernel<kOpBf16, kEpiF32, kShipT>), grid, block, 0, s, e0, e1, 0, a);
         else hipLaunchKernelGGL((gemm_nt_kernel<kOpBf16, kEpiF32, kShipT>), grid, block, 0, s, a);
+    } else if (a.k_fac) {
+        if (e0 || e1) hipExtLaunchKernelGGL((gemm_tn_rowfac_kernel<kOpF16, kEpiF32, kShipT>), grid, block, 0, s, e0, e1, 0, a);
+        else hipLaunchKernelGGL((gemm_tn_rowfac_kernel<kOpF16, kEpiF32, kShipT>), grid, block, 0, s, a);
     } else if (a.a_block_inv) {
         if (e0 || e1) hipExtLaunchKernelGGL((gemm_nt_kernel<kOpF16, kEpiF32, kShipT | kVarRebase>), grid, block, 0, s, e0, e1, 0, a);
         else hipLaunchKernelGGL((gemm_nt_kernel<kOpF16, kEpiF32, kShipT | kVarRebase>), grid, block, 0, s, a);

@@ -89,11 +89,13 @@ struct Args {
     int conv_rows, conv_width, conv_seq, conv_w_ld;     //   output rows [0, conv_rows) get conv + SiLU along the columns, sequences of conv_seq columns (256 % conv_seq == 0)
     const float *a_block_inv;      // kVarRebase (TN, fp16): (M / 32, a_block_inv_ld >= K / 64) inverse scales (powers of two): the A values of token group g = m / 32 in K tile kt were
     int a_block_inv_ld;            //   stored with their own scale 1 / a_block_inv[g][kt]; the kernel puts a group on ONE scale (the largest inverse of its row of the table, K <= 4096)
+    const _Float16 *k_fac;         // kVarRowFac (TN, fp16): one factor (a power of two <= 1) per REDUCTION row (all splits): A's row r is multiplied by k_fac[r] as it is read --
+    const float *c_scale;          //   both operands are scaled-fp16 images with ROW scales (the rows are the reduction index of a weight gradient); *c_scale multiplies the result
     int q_cols;                    // kEpiF16Qkv: columns [0, q_cols) take the per-row scale, the others the per-batch-element one
     int c_pieces2;                 // kEpiGatedSplit3: the h image is written as the pair [hi | lo] (ldc >= 2 F) for a consumer that reads it with a_alias_tiles
 };
 // tuning variants (bit mask; 0 = the shipped schedule)
-enum { kVarLgkmAfterBarrier = 1, kVarNoEpilogue = 2, kVarNtStores = 4, kVarFullLineStores = 8, kVarNoSetprio = 16, kVarSc1Stores = 32, kVarSc0Stores = 64, kVarKeepX12 = 128, kVarTN = 256, kVarM128 = 512, kVarRebase = 1024, kVarPersist = 2048 };
+enum { kVarLgkmAfterBarrier = 1, kVarNoEpilogue = 2, kVarNtStores = 4, kVarFullLineStores = 8, kVarNoSetprio = 16, kVarSc1Stores = 32, kVarSc0Stores = 64, kVarKeepX12 = 128, kVarTN = 256, kVarM128 = 512, kVarRebase = 1024, kVarPersist = 2048, kVarRowFac = 4096 };
 
 __device__ __forceinline__ float dpp_row_ror8(float x) {      // lane l <- lane l ^ 8 (rotation by 8 inside each row of 16 lanes)
     const int v = __builtin_bit_cast(int, x);                  // (old = the source: with a constant `old` hipcc 7.2 merges the calls of an unrolled loop)
@@ -261,6 +263,7 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
     unsigned tn_voff_a[2], tn_voff_b[2];
     const char *tn_a = nullptr, *tn_b = nullptr;
     int64_t tn_a_tile = 0, tn_b_tile = 0;
+    int tn_row_split = 0;          // which range of reduction rows this workgroup adds up
     if constexpr (kTN) {
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc) {
@@ -277,6 +280,7 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
             a_col = piece == 1 ? p.a_pair_cols : 0;
             b_col = piece == 2 ? p.b_pair_cols : 0;
         }
+        tn_row_split = row_split;
         tn_a = p.A + ((int64_t)row_split * p.K * p.lda + m0 + a_col) * 2;
         tn_b = p.B0 + ((int64_t)row_split * p.K * p.ldb + n0 + b_col) * 2;
         tn_a_tile = (int64_t)kBK * p.lda * 2;
@@ -429,7 +433,51 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
             rb[q] = v * __builtin_amdgcn_rcpf(top[q]);                          // (powers of two: exact)
         }
     }
+    // kVarRowFac: the weight gradient dW = dY^T X of a Linear under the scaled-fp16 policy. Both operands are the images the forward / the input
+    // gradient already use -- fp16 rows with ONE power-of-two scale per row -- but here the rows are the reduction index: term r carries the
+    // factor a_inv[r] b_inv[r]. The host hands k_fac[r] = a_inv[r] b_inv[r] / max_r(..) (<= 1, a power of two, as fp16) and the maximum as
+    // *c_scale; A's fragment rows are multiplied by their factors as they are read (v_pk_mul_f16, exact unless the value leaves fp16's normal
+    // range: a term more than 2^14 below the largest row product -- then it keeps >= 11 - (shift - 14) bits, error <= 2^-25 of the largest term).
+    // The factors of this workgroup's reduction range sit in the 32 KB of LDS behind the ring (K <= 16384 rows per range); a lane (t, g) of a
+    // transposing read holds reduction rows kh 32 + {4 g .. 4 g + 3, 16 + 4 g .. 16 + 4 g + 3} of the K tile: four 8-byte LDS reads per K tile.
+    constexpr bool kRowFac = (kVar & kVarRowFac) != 0;
+    static_assert(!kRowFac || (kTN && kOp == kOpF16 && !kRebase), "the row factors serve the fp16 TN variant");
+    unsigned fac_rd = 0;
+    u32x2 fv[4];
+    if constexpr (kRowFac) {
+        char *fl = lds + 2 * kParity;
+        const _Float16 *src = p.k_fac + (int64_t)tn_row_split * p.K;
+        for (int i = threadIdx.x; i < p.K / 8; i += 512) *reinterpret_cast<u32x4 *>(fl + i * 16) = *reinterpret_cast<const u32x4 *>(src + i * 8);
+        __syncthreads();
+        fac_rd = lds0 + 2 * kParity + (lane >> 4) * 8;
+    }
+#define DIMSUM_DS_READ_B64(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+    auto read_fac = [&](int kt_) {          // issued with the operand reads of the phase: the phase's lgkmcnt(0) covers them
+        if constexpr (kRowFac) {
+            const unsigned ad = fac_rd + (unsigned)kt_ * 128u;
+            DIMSUM_DS_READ_B64(fv[0], ad, 0);
+            DIMSUM_DS_READ_B64(fv[1], ad, 32);
+            DIMSUM_DS_READ_B64(fv[2], ad, 64);
+            DIMSUM_DS_READ_B64(fv[3], ad, 96);
+        }
+    };
     auto rebase = [&](u32x4 (&frag)[4][2], int mi, int kt_) {
+        if constexpr (kRowFac) {
+            typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(fv[q]));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh) asm volatile("" : "+v"(frag[i][kh]));
+            const h8_t s0 = __builtin_bit_cast(h8_t, u32x4{fv[0][0], fv[0][1], fv[1][0], fv[1][1]});
+            const h8_t s1 = __builtin_bit_cast(h8_t, u32x4{fv[2][0], fv[2][1], fv[3][0], fv[3][1]});
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                frag[i][0] = __builtin_bit_cast(u32x4, __builtin_bit_cast(h8_t, frag[i][0]) * s0);
+                frag[i][1] = __builtin_bit_cast(u32x4, __builtin_bit_cast(h8_t, frag[i][1]) * s1);
+            }
+        }
         if constexpr (kRebase) {
             const _Float16 f0 = (_Float16)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rb[mi * 2]), kt_));
             const _Float16 f1 = (_Float16)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rb[mi * 2 + 1]), kt_));
@@ -523,6 +571,7 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
     if (wr == 1) __builtin_amdgcn_s_barrier();       // from here on the second wave row runs one barrier behind the first
     __builtin_amdgcn_sched_barrier(0);
     DIMSUM_READ_A(a0, kSlotA0, 0);                    // "phase -1": A0(0), retired in every wave before anything re-stages its slot
+    read_fac(0);
     DIMSUM_PHASE_SYNC();
     rebase(a0, 0, 0);
     DIMSUM_PHASE_END();
@@ -537,9 +586,9 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
         DIMSUM_QUADRANT(0, 0, a0, b0); DIMSUM_PHASE_END();                                                                      \
         DIMSUM_READ_B(b1, kSlotB1, par); ST_B0; if (W12) DIMSUM_WAIT_VM(12); DIMSUM_PHASE_SYNC();                               \
         DIMSUM_QUADRANT(0, 1, a0, b1); DIMSUM_PHASE_END();                                                                      \
-        DIMSUM_READ_A(a1, kSlotA1, par); ST_B1; if (W34) DIMSUM_WAIT_VM(12); DIMSUM_PHASE_SYNC();                               \
+        DIMSUM_READ_A(a1, kSlotA1, par); read_fac(KT); ST_B1; if (W34) DIMSUM_WAIT_VM(12); DIMSUM_PHASE_SYNC();                 \
         rebase(a1, 1, KT); DIMSUM_QUADRANT(1, 1, a1, b1); DIMSUM_PHASE_END();                                                   \
-        DIMSUM_READ_A(a0, kSlotA0, par_next);                                                                                   \
+        DIMSUM_READ_A(a0, kSlotA0, par_next); read_fac((KT) + 1);                                                               \
         ST_A1; if (W34) DIMSUM_WAIT_VM(12); DIMSUM_PHASE_SYNC();                                                                \
         DIMSUM_QUADRANT(1, 0, a1, b0);                                                                                          \
         rebase(a0, 0, (KT) + 1);     /* (under the MFMAs just issued: a0 is next used in P1 of K tile KT + 1) */                \
@@ -596,12 +645,14 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
         DIMSUM_QUADRANT(0, 1, a0, b1);
         DIMSUM_PHASE_END();
         DIMSUM_READ_A(a1, kSlotA1, par);
+        read_fac(kt);
         DIMSUM_WAIT_VM(6);
         DIMSUM_PHASE_SYNC();
         rebase(a1, 1, kt);
         DIMSUM_QUADRANT(1, 1, a1, b1);
         DIMSUM_PHASE_END();
         DIMSUM_READ_A(a0, kSlotA0, par_next);
+        read_fac(kt + 1);
         DIMSUM_WAIT_VM(4);
         DIMSUM_PHASE_SYNC();
         DIMSUM_QUADRANT(1, 0, a1, b0);
@@ -618,6 +669,7 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
         DIMSUM_QUADRANT(0, 1, a0, b1);
         DIMSUM_PHASE_END();
         DIMSUM_READ_A(a1, kSlotA1, par_next);
+        read_fac(kt + 1);
         DIMSUM_PHASE_SYNC();
         rebase(a1, 1, kt + 1);
         DIMSUM_QUADRANT(1, 1, a1, b1);
@@ -752,6 +804,8 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
             const bool has_s = kRebase || p.sa != nullptr;
             const unsigned ms = pick_mask(has_s);
             const float *sap = p.sa ? p.sa + m0 : reinterpret_cast<const float *>(p.A), *sbp = has_s ? p.sb : reinterpret_cast<const float *>(p.B0);
+            float c_scale = 1.0f;
+            if constexpr (kRowFac) c_scale = *p.c_scale;           // (wave-uniform: a scalar load, before the stores)
             bool live[2];
             f4 bv[2], sbv[2], gv[2];
             auto load_cols = [&](int ni) {                 // (ni = 1's vectors are loaded under group 1, before its stores: 12 registers less at the peak)
@@ -777,6 +831,7 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
                 for (int i = 0; i < 4; ++i) {
                     const int lrow = frow + mi * kMiRows + i * 16;
                     if constexpr (kRebase) rs[mi][i][0] = rs[mi][i][1] = top[mi * 2 + (i >> 1)];
+                    else if constexpr (kRowFac) rs[mi][i][0] = rs[mi][i][1] = c_scale;
                     else {                                  // scaled-fp16 operands: exact powers of two
                         rs[mi][i][0] = pick(ms, sap[lrow], 1.0f); rs[mi][i][1] = pick(ms, sap[lrow + 8], 1.0f);
                     }
@@ -1007,7 +1062,9 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const f4 x0 = acc[mi][ni][i][0], x1 = acc[mi][ni][i][1];
+                        // (scaled-fp16 operands: the true x1 / x2 = accumulator x row scale x column scale -- applied before the lane exchange,
+                        // where a lane still holds its own row; 1 x 1 without scales)
+                        const f4 x0 = acc[mi][ni][i][0] * ((ni ? csb2[0] : csb1[0]) * row_sa[mi][i]), x1 = acc[mi][ni][i][1] * ((ni ? csb2[1] : csb1[1]) * row_sa[mi][i]);
                         f4 s0, s1;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -1154,6 +1211,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_persist_kernel(const Args p) {
     gemm_body<kOp, kEpi, kVar | kVarPersist>(p, lds);
 }
 
+// TN with per-reduction-row factors (kVarRowFac): the ring + 32 KB for the factors of the workgroup's reduction range
+template <int kOp, int kEpi, int kVar = 0>
+__global__ __launch_bounds__(512, 2) void gemm_tn_rowfac_kernel(const Args p) {
+    __shared__ __attribute__((aligned(1024))) char lds[2 * kParity + 32768];
+    gemm_body<kOp, kEpi, kVar | kVarRowFac>(p, lds);
+}
+
 // 4 waves, 80 KB: two workgroups per CU (2 waves per SIMD: the same 256-VGPR budget)
 template <int kOp, int kEpi, int kVar = 0>
 __global__ __launch_bounds__(256, 2) void gemm_nt_m128_kernel(const Args p) {
@@ -1171,6 +1235,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_m128_kernel(const Args p) {
 #undef DIMSUM_PHASE_SYNC
 #undef DIMSUM_PHASE_END
 #undef DIMSUM_DS_READ_B128
+#undef DIMSUM_DS_READ_B64
 #undef DIMSUM_WAIT_VM
 #undef DIMSUM_WAIT_LGKM0
 

@@ -545,6 +545,76 @@ __global__ __launch_bounds__(256) void gated_gelu_bwd_kernel(const float *x12, c
     }
 }
 
+// The same adjoint with dx12 written as a scaled-fp16 operand image (common.hpp, f16s): rows of 2H fp16 = fp16(dx12_r 2^s_r) with the exact row
+// maximum's power of two, inv[r] = 2^-s_r -- the operand of BOTH backward GEMMs of w12 under the scaled-fp16 policy (d input = dx12 W12 as an NT
+// product, d weight = dx12^T h as a TN product with per-reduction-row factors, dimsum_gemm_ext_t.k_scale_ptr). A row's maximum needs the whole
+// row: one workgroup walks kGGRowsF rows, a thread holding its 4-column pieces of both halves (H <= 1024 kStrips) in registers between the
+// maximum and the store; the column sums (d bias) accumulate in registers across the rows.
+constexpr int kGGRowsF = 128;
+template <int kStrips>
+__global__ __launch_bounds__(256) void gated_gelu_bwd_f16s_kernel(const float *x12, const float *bias, const float *dh, __half *img, float *inv, float *dbias,
+                                                                  int64_t rows, int64_t H) {
+    __shared__ float red[2][4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float4 ba[kStrips], bg[kStrips], sa[kStrips], sg[kStrips];
+#pragma unroll
+    for (int s = 0; s < kStrips; ++s) {
+        const int64_t c = ((int64_t)s * 256 + threadIdx.x) * 4;
+        ba[s] = bg[s] = sa[s] = sg[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias && c < H) { ba[s] = *reinterpret_cast<const float4 *>(bias + c); bg[s] = *reinterpret_cast<const float4 *>(bias + H + c); }
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * kGGRowsF, r1 = min(rows, r0 + kGGRowsF);
+    for (int64_t r = r0; r < r1; ++r) {
+        float4 da[kStrips], dg[kStrips];
+        float m = 0.f;
+#pragma unroll
+        for (int s = 0; s < kStrips; ++s) {
+            const int64_t c = ((int64_t)s * 256 + threadIdx.x) * 4;
+            da[s] = dg[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < H) {
+                float4 a = *reinterpret_cast<const float4 *>(x12 + r * 2 * H + c);
+                float4 g = *reinterpret_cast<const float4 *>(x12 + r * 2 * H + H + c);
+                const float4 d = *reinterpret_cast<const float4 *>(dh + r * H + c);
+                a.x += ba[s].x; a.y += ba[s].y; a.z += ba[s].z; a.w += ba[s].w;
+                g.x += bg[s].x; g.y += bg[s].y; g.z += bg[s].z; g.w += bg[s].w;
+                da[s] = make_float4(d.x * g.x * gelu_tanh_grad(a.x), d.y * g.y * gelu_tanh_grad(a.y), d.z * g.z * gelu_tanh_grad(a.z), d.w * g.w * gelu_tanh_grad(a.w));
+                dg[s] = make_float4(d.x * gelu_tanh(a.x), d.y * gelu_tanh(a.y), d.z * gelu_tanh(a.z), d.w * gelu_tanh(a.w));
+                m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(da[s].x), fabsf(da[s].y)), fmaxf(fabsf(da[s].z), fabsf(da[s].w))),
+                                   fmaxf(fmaxf(fabsf(dg[s].x), fabsf(dg[s].y)), fmaxf(fabsf(dg[s].z), fabsf(dg[s].w)))));
+                sa[s].x += da[s].x; sa[s].y += da[s].y; sa[s].z += da[s].z; sa[s].w += da[s].w;
+                sg[s].x += dg[s].x; sg[s].y += dg[s].y; sg[s].z += dg[s].z; sg[s].w += dg[s].w;
+            }
+        }
+        m = wave_allmax(m);
+        const int par = (int)(r & 1);               // two slots: the next row's maxima are written while slow waves still read this row's
+        if (lane == 0) red[par][w] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(red[par][0], red[par][1]), fmaxf(red[par][2], red[par][3]));
+        float scale, iv;
+        f16s_scales(m, scale, iv);
+        if (threadIdx.x == 0) inv[r] = iv;
+        __half *row = img + r * 2 * H;
+#pragma unroll
+        for (int s = 0; s < kStrips; ++s) {
+            const int64_t c = ((int64_t)s * 256 + threadIdx.x) * 4;
+            if (c < H) {
+                *reinterpret_cast<uint2 *>(row + c) = f16s_pack4(f32x4{{da[s].x, da[s].y, da[s].z, da[s].w}}, scale);
+                *reinterpret_cast<uint2 *>(row + H + c) = f16s_pack4(f32x4{{dg[s].x, dg[s].y, dg[s].z, dg[s].w}}, scale);
+            }
+        }
+    }
+    if (dbias) {
+#pragma unroll
+        for (int s = 0; s < kStrips; ++s) {
+            const int64_t c = ((int64_t)s * 256 + threadIdx.x) * 4;
+            if (c < H) {
+                atomicAdd(dbias + c, sa[s].x); atomicAdd(dbias + c + 1, sa[s].y); atomicAdd(dbias + c + 2, sa[s].z); atomicAdd(dbias + c + 3, sa[s].w);
+                atomicAdd(dbias + H + c, sg[s].x); atomicAdd(dbias + H + c + 1, sg[s].y); atomicAdd(dbias + H + c + 2, sg[s].z); atomicAdd(dbias + H + c + 3, sg[s].w);
+            }
+        }
+    }
+}
+
 }  // namespace dimsum
 
 extern "C" int dimsum_token_transform(const dimsum_tt_params_t *p, void *stream) {
@@ -626,4 +696,29 @@ extern "C" int dimsum_gated_gelu_bwd_split3(const void *x12, const void *bias, c
 extern "C" int dimsum_gated_gelu_bwd_pair(const void *x12, const void *bias, const void *dh, void *dx12_pair, void *dbias, int64_t rows,
                                           int64_t hidden, void *stream) {
     return launch_gated_gelu_bwd<2>(x12, bias, dh, dx12_pair, dbias, rows, hidden, stream);
+}
+
+/* dx12 as the scaled-fp16 image (rows, 2 hidden) float16 + inv_scale (rows) f32: see gated_gelu_bwd_f16s_kernel */
+extern "C" int dimsum_gated_gelu_bwd_f16s(const void *x12, const void *bias, const void *dh, void *dx12_image, void *inv_scale, void *dbias, int64_t rows,
+                                          int64_t hidden, void *stream) {
+    using namespace dimsum;
+    if (!x12 || !dh || !dx12_image || !inv_scale) return DIMSUM_ERR_NULL;
+    if (rows < 0 || hidden <= 0 || hidden % 4 != 0 || hidden > 5 * 1024) return DIMSUM_ERR_SHAPE;
+    if (!aligned_to<char>(x12, 16) || !aligned_to<char>(dh, 16) || !aligned_to<char>(dx12_image, 8) || (bias && !aligned_to<char>(bias, 16))) return DIMSUM_ERR_STRIDE;
+    if (rows == 0) return DIMSUM_OK;
+    const dim3 grid((unsigned)((rows + kGGRowsF - 1) / kGGRowsF));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int strips = (int)((hidden + 1023) / 1024);
+#define DIMSUM_GGF(K) hipLaunchKernelGGL(gated_gelu_bwd_f16s_kernel<K>, grid, dim3(256), 0, s, reinterpret_cast<const float *>(x12), reinterpret_cast<const float *>(bias), \
+                                         reinterpret_cast<const float *>(dh), reinterpret_cast<__half *>(dx12_image), reinterpret_cast<float *>(inv_scale),                \
+                                         reinterpret_cast<float *>(dbias), rows, hidden)
+    switch (strips) {
+        case 1: DIMSUM_GGF(1); break;
+        case 2: DIMSUM_GGF(2); break;
+        case 3: DIMSUM_GGF(3); break;
+        case 4: DIMSUM_GGF(4); break;
+        default: DIMSUM_GGF(5); break;
+    }
+#undef DIMSUM_GGF
+    return launch_status();
 }

@@ -272,8 +272,12 @@ def _rows_ok(x):
 
 def linear(x, weight):
     """x (..., K) @ weight (N, K)^T -> (..., N), no bias (the bias rides in the consumer kernel)"""
-    if (x.requires_grad or weight.requires_grad) and weight.shape[0] % 4 == 0 and _rows_ok(x) and split3_train_enabled(x, weight):
-        return _LinearImagesFn.apply(x, weight)
+    if (x.requires_grad or weight.requires_grad) and weight.shape[0] % 4 == 0 and _rows_ok(x):
+        mode = split3_train_enabled(x, weight)
+        if mode == "f16s":
+            return _LinearF16sFn.apply(x, weight)
+        if mode:
+            return _LinearImagesFn.apply(x, weight)
     if not _use_fp16(x, weight):
         return F.linear(x, weight)
     K = x.shape[-1]
@@ -606,13 +610,81 @@ def gated_mlp_hidden_split3_train(x3, w12, b12):
 
 
 def split3_train_enabled(x, weight):
-    """the operand-image carrier under autograd (mlp.py: forward AND backward GEMMs of the gated MLP): fp32 CUDA training under
-    allow_tf32, outside autocast; DIMSUM_SPLIT3_TRAIN=0 / DIMSUM_SPLIT3=0 switch it off; same row threshold as inference"""
+    """the operand-image carrier under autograd (mlp.py: forward AND backward GEMMs of the gated MLP; `linear`: qkv / proj; the Mamba GEMMs):
+    fp32 CUDA training under allow_tf32, outside autocast; DIMSUM_SPLIT3_TRAIN=0 / DIMSUM_SPLIT3=0 switch it off; same row threshold as
+    inference. -> False, True (split-bf16 images: three bf16 products per fp32 product) or "f16s" (policy "f16s": scaled-fp16 images, ONE fp16
+    product per element in the forward, the input-gradient AND the weight-gradient GEMMs -- the reference trains under TF32 too,
+    dimsum/train.py:20-21; DIMSUM_F16S_TRAIN=0 keeps the three-product images under that policy)"""
     import os
-    # (policy "f16s" is an inference carrier: under autograd it runs the same three-product images as "default")
     if not (_policy in ("default", "f16s") and torch.backends.cuda.matmul.allow_tf32 and os.environ.get("DIMSUM_SPLIT3", "1") != "0"
             and os.environ.get("DIMSUM_SPLIT3_TRAIN", "1") != "0" and x.is_cuda and x.dtype == torch.float32
             and weight.dtype == torch.float32 and x.shape[-1] % 4 == 0 and torch.is_grad_enabled()
             and not torch.is_autocast_enabled("cuda")):
         return False
-    return x.numel() // x.shape[-1] >= int(os.environ.get("DIMSUM_SPLIT3_MIN_ROWS", "8192"))
+    if x.numel() // x.shape[-1] < int(os.environ.get("DIMSUM_SPLIT3_MIN_ROWS", "8192")):
+        return False
+    if _policy == "f16s" and os.environ.get("DIMSUM_F16S_TRAIN", "1") != "0" and own_gemm_enabled():
+        return "f16s"
+    return True
+
+
+def weight_f16s_train(weight, want_l1=False):
+    """training: the scaled-fp16 image of a weight, rebuilt on every call (the optimizer changes it between steps) -> F16Image [, l1]"""
+    from . import native
+    return native.rows_f16s(weight.detach(), want_l1=want_l1)
+
+
+def weight_t_f16s_train(weight):
+    """training: the scaled-fp16 image of weight^T ((K, N) rows: one scale per INPUT feature) -- the right operand of the input-gradient
+    product dx = dy W as an NT GEMM over the output features"""
+    from . import native
+    return native.rows_f16s(weight.detach().t().contiguous())
+
+
+def nt_f16s_any(a, b):
+    """F16Image a (M, K) x F16Image b (N, K)^T -> (M, N) float32, on the hand-written kernel where the shape fits, else the library on the decoded rows"""
+    from . import native
+    if own_gemm_enabled() and native.gemm_nt_supported(a.data, b.data):
+        return native.gemm_nt(a.data, b.data, scales=(a.inv.reshape(-1), b.inv))
+    return torch.mm(a.data, b.data.t(), out_dtype=torch.float32) * a.inv.reshape(-1)[:, None] * b.inv[None, :]
+
+
+def dw_f16s(dy16, x16):
+    """dW = dy^T x (N, K) float32 from two scaled-fp16 images whose rows (tokens) are the reduction index: the TN kernel with per-reduction-row
+    factors (native.gemm_tn(row_scales=...)) -- ONE fp16 product per element -- else the library on the decoded rows"""
+    from . import native
+    a, b = dy16.data.reshape(-1, dy16.data.shape[-1]), x16.data.reshape(-1, x16.data.shape[-1])
+    ai, bi = dy16.inv.reshape(-1), x16.inv.reshape(-1)
+    if own_gemm_enabled() and native.gemm_tn_supported(a, b):
+        return native.gemm_tn(a, b, row_scales=native.row_factors(ai, bi))
+    return mm_tn(a.float() * ai[:, None], b.float() * bi[:, None])
+
+
+class _LinearF16sFn(torch.autograd.Function):
+    """y = x W^T under autograd with all three GEMMs (y, dx, dW) as ONE fp16 product per element over scaled-fp16 images (policy "f16s"; the
+    reference's TF32 training arithmetic, dimsum/train.py:20-21: 10-bit operand mantissas, fp32 accumulation): x and dy are converted once each
+    (row scales = exact row maxima); y = x16 W16^T and dx = dy16 (W^T)16^T are NT products whose epilogue undoes the row scales, dW = dy16^T x16
+    reduces over the rows, so the row scales become per-reduction-row factors inside the TN kernel (dw_f16s)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        from . import native
+        K = x.shape[-1]
+        x16 = native.rows_f16s(x.reshape(-1, K))
+        ctx.save_for_backward(x16.data, x16.inv, weight)
+        ctx.x_shape = x.shape
+        return nt_f16s_any(x16, weight_f16s_train(weight)).view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import native
+        xd, xi, weight = ctx.saved_tensors
+        N, K = weight.shape
+        M = xd.shape[0]
+        dy16 = native.rows_f16s(dy.reshape(M, N).contiguous())
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = nt_f16s_any(dy16, weight_t_f16s_train(weight)).view(ctx.x_shape)
+        if ctx.needs_input_grad[1]:
+            dw = dw_f16s(dy16, native.F16Image(xd, xi))
+        return dx, dw

@@ -97,8 +97,67 @@ class _ModGatedMlpImagesFn(torch.autograd.Function):
         return dnormed, dshift, dscale, dw12, db12, dw3
 
 
+class _ModGatedMlpF16sFn(torch.autograd.Function):
+    """the same module function with every GEMM of the forward and the backward as ONE fp16 product per element over scaled-fp16 images (policy
+    "f16s", gemm.py; the reference trains under TF32 as well, dimsum/train.py:20-21):
+        forward : h16 = image(modulate(normed))  [token_transform y_split3 = 2]     g16, x12 = gate epilogue of h16 . W12_16^T (row scale of g from the
+                  epilogue's bound, x12 kept in fp32 for the adjoint)               m = g16 . W3_16^T
+        backward: dm16 = image(dm)                dg = dm16 . (W3^T)16^T            dW3 = dm16^T g16   [TN, per-reduction-row factors]
+                  dx12_16 = image(gated GeLU adjoint)  [one pass, exact row maxima]  dh = dx12_16 . (W12^T)16^T     dW12 = dx12_16^T h16
+    Six products, each a third of the three-product carrier's MFMA work; the images are 2 bytes per element instead of 4 (pairs) / 6."""
+
+    @staticmethod
+    def forward(ctx, normed, shift, scale, w12, b12, w3):
+        B, L, H = normed.shape
+        M = B * L
+        normed = normed if normed.stride(-1) == 1 else normed.contiguous()
+        h16 = native.token_transform(normed, "none", True, scale=scale, shift=shift, split3="f16s")      # data (B, L, H) float16, inv (B, L)
+        b12f = None if b12 is None else b12.float()
+        w12_16, l1 = gemm.weight_f16s_train(w12, want_l1=True)
+        bound = torch.cat([l1 * gemm._K10, gemm._absmax(b12f, w12)]).contiguous()
+        g16, x12 = native.gemm_nt(h16.data.view(M, H), w12_16.data, bias=b12f, epilogue="gated_f16", scales=(h16.inv.view(M), w12_16.inv), gate_bound=bound, keep_x12=True)
+        m = gemm.nt_f16s_any(g16, gemm.weight_f16s_train(w3))
+        ctx.save_for_backward(normed, scale, h16.data, h16.inv, x12, g16.data, g16.inv, w12, b12f, w3)
+        return m.view(B, L, w3.shape[0])
+
+    @staticmethod
+    def backward(ctx, dm):
+        normed, scale, hd, hi, x12, gd, gi, w12, b12f, w3 = ctx.saved_tensors
+        B, L, H = normed.shape
+        M = B * L
+        Ho = w3.shape[0]
+        F16 = native.F16Image
+        dm16 = native.rows_f16s(dm.reshape(M, Ho).contiguous())
+        dg = gemm.nt_f16s_any(dm16, gemm.weight_t_f16s_train(w3))                                            # (M, F)
+        dw3 = gemm.dw_f16s(dm16, F16(gd, gi)) if ctx.needs_input_grad[5] else None                            # (Ho, F)
+        dx12_16, db12 = native.gated_gelu_bwd(x12, b12f, dg, need_dbias=b12f is not None and ctx.needs_input_grad[4], split3="f16s")
+        dh = gemm.nt_f16s_any(dx12_16, gemm.weight_t_f16s_train(w12)).view(B, L, H)                            # (M, H)
+        dw12 = gemm.dw_f16s(dx12_16, F16(hd, hi)) if ctx.needs_input_grad[3] else None                        # (2F, H)
+        dnormed = dshift = dscale = None
+        if ctx.needs_input_grad[0] and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            dnormed, dscale, _, dshift = native.token_transform(dh, "none", True, scale=scale, w=normed, want_y=True, want_tsum=True)
+        elif ctx.needs_input_grad[0]:
+            dnormed = native.token_transform(dh, "none", False, gate=1.0 + scale)
+        elif ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            _, dscale, dshift = native.token_transform(normed, "none", True, w=dh, want_y=False, want_wsum=True)
+        if db12 is not None and b12f is not None:
+            db12 = db12.to(b12f.dtype)
+        return dnormed, dshift, dscale, dw12, db12, dw3
+
+
+def f16s_mlp_train_ok(mlp, normed):
+    """shapes the single-product training MLP takes: the gate epilogue's tiling (M % 256, H % 64, F % 128), the token pass's image (H <= 2048), the
+    gated-GeLU adjoint's row kernel (F <= 5120)"""
+    H, F2 = mlp.w12.weight.shape[1], mlp.w12.weight.shape[0]
+    M = normed.numel() // normed.shape[-1]
+    return M % 256 == 0 and H % 64 == 0 and H >= 128 and H <= 2048 and (F2 // 2) % 128 == 0 and F2 // 2 <= 5120 and mlp.w3.weight.shape[0] % 4 == 0
+
+
 def mod_gated_mlp_images(mlp, normed, shift, scale):
-    """-> (m, b): mlp(modulate(normed, shift, scale)) = m + b for a fused GatedMLP, all GEMMs on operand images (training)"""
+    """-> (m, b): mlp(modulate(normed, shift, scale)) = m + b for a fused GatedMLP, all GEMMs on operand images (training): scaled-fp16 images
+    (one product) under the "f16s" policy, split-bf16 images (three products) otherwise"""
+    if gemm.split3_train_enabled(normed, mlp.w12.weight) == "f16s" and f16s_mlp_train_ok(mlp, normed):
+        return _ModGatedMlpF16sFn.apply(normed, shift, scale, mlp.w12.weight, mlp.w12.bias, mlp.w3.weight), mlp.w3.bias
     return _ModGatedMlpImagesFn.apply(normed, shift, scale, mlp.w12.weight, mlp.w12.bias, mlp.w3.weight), mlp.w3.bias
 
 

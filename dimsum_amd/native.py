@@ -751,16 +751,33 @@ def gemm_tn_pairs(a, b, splits=None):
     return out.sum(0)
 
 
-def gemm_tn(a, b, splits=None, events=None, alias_rows=0, scales=None):
+def row_factors(a_inv, b_inv):
+    """(R,) float32 inverse row scales of two scaled-fp16 images whose ROWS are the reduction index of a product a^T b -> (k_fac (R,) float16,
+    c_scale (1,) float32): term r carries a_inv[r] b_inv[r]; k_fac = that / its maximum (powers of two <= 1; below 2^-24: 0), c_scale = the
+    maximum (include/dimsum_hip.h, dimsum_gemm_ext_t.k_scale_ptr)"""
+    f = a_inv * b_inv
+    top = f.max().reshape(1)
+    return (f / top).to(torch.float16), top
+
+
+def gemm_tn(a, b, splits=None, events=None, alias_rows=0, scales=None, row_scales=None):
     """a (R, P)^T @ b (R, Q) -> (P, Q) float32 on the hand-written MFMA kernel's TN variant: the weight-gradient product of a Linear
     (reduction over the rows). The reduction is cut into `splits` ranges whose partial results are added in a fixed order.
     alias_rows = D: a is a (2 D, P) pair of planes [hi; lo] read as the row stack [hi; hi; lo] (b: (3 D, Q)); one range.
     scales = (a_inv, b_inv (Q,)): float16 operands carrying power-of-two scales (one range): a_inv (P,) -> the result is multiplied by
     a_inv[p] b_inv[q]; a_inv (P / 32, R / 64) -> block-scaled a (the scan's fp16 out_z with its table, selective_scan_fwd(out_z_f16=True)):
     the values of tokens [32 g, 32 g + 32) x reduction rows [64 t, 64 t + 64) stand for value * a_inv[g][t]; R <= 4096 (out_proj of a
-    Mamba mixer as ONE fp16 product per element)."""
+    Mamba mixer as ONE fp16 product per element).
+    row_scales = (k_fac (R,) float16, c_scale (1,) float32) from row_factors(a_inv, b_inv): both operands are scaled-fp16 images with one scale
+    per ROW and the rows are the reduction index (the weight gradient dW = dy^T x of a Linear under the scaled-fp16 policy): a's row r is
+    multiplied by k_fac[r] as it is read, the result by c_scale; ranges of at most 16384 rows."""
     _gpu(a, b)
     blocks = None
+    if row_scales is not None:
+        kf, cs = row_scales
+        _gpu(kf, cs)
+        _check(scales is None and not alias_rows and a.dtype == torch.float16 and kf.dtype == torch.float16 and kf.numel() == a.shape[0] and kf.is_contiguous()
+               and cs.dtype == torch.float32 and cs.numel() == 1, "gemm_tn: row_scales = (k_fac (R,) float16, c_scale (1,) float32) with float16 operands")
     if scales is not None:
         _gpu(*scales)
         sa, sb = scales
@@ -784,6 +801,10 @@ def gemm_tn(a, b, splits=None, events=None, alias_rows=0, scales=None):
     Q = b.shape[1]
     if splits is None:
         splits = gemm_tn_splits(R, P, Q)
+        while row_scales is not None and R // splits > 16384 and R % (2 * splits * 64) == 0:          # (the factors of one range live in 32 KB of LDS)
+            splits *= 2
+    if row_scales is not None:
+        _check(R // splits <= 16384, "gemm_tn: row_scales needs ranges of at most 16384 reduction rows")
     _check(splits >= 1 and R % (splits * 64) == 0 and R // splits >= 128, "gemm_tn: splits must cut R into ranges of whole 64-row tiles (>= 2)")
     out = torch.empty((splits, P, Q), device=a.device, dtype=torch.float32)
     G = _lib.GemmParams()
@@ -801,6 +822,8 @@ def gemm_tn(a, b, splits=None, events=None, alias_rows=0, scales=None):
             X.a_block_inv_ptr, X.a_block_inv_ld = _ptr(blocks), blocks.stride(0)
         else:
             G.a_inv_scale_ptr = _ptr(scales[0])
+    if row_scales is not None:
+        X.k_scale_ptr, X.c_scale_ptr = _ptr(row_scales[0]), _ptr(row_scales[1])
     if events is not None:
         X.timing_start_event, X.timing_stop_event = events
     with torch.cuda.device(a.device):
@@ -931,7 +954,8 @@ def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=Non
     P.a_ptr, P.b_ptr, P.bias_ptr, P.c_ptr = _ptr(a), _ptr(b), _ptr(bias), _ptr(out)
     x12 = None
     if keep_x12:
-        _check(epilogue == "gated_split3" and a.dtype == torch.bfloat16 and scales is None, "gemm_nt: keep_x12 goes with the gated_split3 epilogue over bf16 images")
+        _check((epilogue == "gated_split3" and a.dtype == torch.bfloat16 and scales is None) or (epilogue == "gated_f16" and a.dtype == torch.float16 and h_inv is not None),
+               "gemm_nt: keep_x12 goes with the gated_split3 epilogue over bf16 images or the gated_f16 epilogue over scaled-fp16 operands with gate_bound")
         x12 = torch.empty((M, N), device=a.device, dtype=torch.float32)
         X.x12_ptr, X.x12_ld = _ptr(x12), N
     if events is not None:
@@ -946,6 +970,8 @@ def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=Non
             _gemm_kernel_log.append((epilogue if conv is None else "f32_conv", int(_lib.load().dimsum_gemm_nt_kernel_for(P))))
         _lib.check(_lib.load().dimsum_gemm_nt(P, _stream(a)), "gemm_nt")
     if x12 is not None:
+        if h_inv is not None:
+            return F16Image(out, h_inv), x12
         return (PairImage(out) if pair_out else out), x12
     if pair_out:
         return PairImage(out)
@@ -953,10 +979,20 @@ def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=Non
 
 
 def gated_gelu_bwd(x12, bias, dh, need_dbias=True, split3=False):
-    """-> (dx12, dbias or None).  split3: dx12 as a split-bf16 operand image in weight order, (..., 3 * 2H) bfloat16 [hi | lo | hi]"""
+    """-> (dx12, dbias or None).  split3: dx12 as a split-bf16 operand image in weight order, (..., 3 * 2H) bfloat16 [hi | lo | hi];
+    split3="f16s": as a scaled-fp16 image (F16Image: (..., 2H) float16 + one inverse scale per row, the exact row maximum; H <= 5120)"""
     _gpu(x12, bias, dh)
     dh = dh.contiguous()
     H = x12.shape[-1] // 2
+    if split3 == "f16s":
+        _check(x12.is_contiguous() and x12.dtype == torch.float32 and dh.dtype == torch.float32 and H % 4 == 0 and H <= 5120, "gated_gelu_bwd: the f16s image needs contiguous float32 rows, H % 4 == 0, H <= 5120")
+        rows = x12.numel() // (2 * H)
+        img = torch.empty(x12.shape, device=x12.device, dtype=torch.float16)
+        inv = torch.empty(x12.shape[:-1], device=x12.device, dtype=torch.float32)
+        dbias = torch.zeros(2 * H, device=x12.device, dtype=torch.float32) if (bias is not None and need_dbias) else None
+        with torch.cuda.device(x12.device):
+            _lib.check(_lib.load().dimsum_gated_gelu_bwd_f16s(_ptr(x12), _ptr(bias), _ptr(dh), _ptr(img), _ptr(inv), _ptr(dbias), rows, H, _stream(x12)), "gated_gelu_bwd")
+        return F16Image(img, inv), dbias
     pair = split3 == "pair"        # (..., 2 * 2H) bfloat16 [hi | lo] (PairImage)
     dx12 = torch.empty(x12.shape[:-1] + ((4 if pair else 6) * H,), device=x12.device, dtype=torch.bfloat16) if split3 else torch.empty_like(x12)
     dbias = torch.zeros(2 * H, device=x12.device, dtype=torch.float32) if (bias is not None and need_dbias) else None

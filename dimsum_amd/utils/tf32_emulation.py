@@ -25,9 +25,35 @@ _MATMULS = {torch.nn.functional.linear, torch.matmul, torch.mm, torch.bmm, torch
 _ADDMMS = {torch.addmm, torch.baddbmm, torch.Tensor.addmm, torch.Tensor.baddbmm}
 
 
+class _EmuLinearFn(torch.autograd.Function):
+    """F.linear under emulated TF32 in BOTH directions: torch's own autograd of F.linear runs its two backward matmuls inside the C++ engine,
+    where a TorchFunctionMode does not see them -- the reference's backward GEMMs run under allow_tf32 too (dimsum/train.py:20-21)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        y = torch.mm(round_tf32(x.reshape(-1, x.shape[-1])), round_tf32(weight).t()).view(*x.shape[:-1], weight.shape[0])
+        return y if bias is None else y + bias
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy2 = round_tf32(dy.reshape(-1, dy.shape[-1]).contiguous())
+        dx = torch.mm(dy2, round_tf32(weight)).view(x.shape) if ctx.needs_input_grad[0] else None
+        dw = torch.mm(dy2.t(), round_tf32(x.reshape(-1, x.shape[-1]))) if ctx.needs_input_grad[1] else None
+        db = dy.reshape(-1, dy.shape[-1]).sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db
+
+
 class _Tf32Mode(TorchFunctionMode):
     def __torch_function__(self, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
+        if func is torch.nn.functional.linear and torch.is_grad_enabled():
+            x, w = args[0], (args[1] if len(args) > 1 else kwargs["weight"])
+            b = args[2] if len(args) > 2 else kwargs.get("bias")
+            if x.dtype == torch.float32 and w.dtype == torch.float32 and (x.requires_grad or w.requires_grad or (b is not None and b.requires_grad)):
+                return _EmuLinearFn.apply(x, w, b)
         if func in _MATMULS:
             args = tuple(round_tf32(a) for a in args[:2]) + tuple(args[2:])
             if func is torch.nn.functional.linear and "weight" in kwargs:

@@ -437,6 +437,10 @@ int dimsum_gated_gelu_bwd_split3(const void *x12, const void *bias, const void *
                                  int64_t hidden, void *stream);
 /* the same with dx12 as the PAIR [hi | lo] (rows of 2 x 2 hidden bf16): see dimsum_gemm_ext_t.a_alias_weight_order / tn_pair_a_cols */
 int dimsum_gated_gelu_bwd_pair(const void *x12, const void *bias, const void *dh, void *dx12_pair, void *dbias, int64_t rows, int64_t hidden, void *stream);
+/* the same with dx12 as a scaled-fp16 operand image (dimsum_rows_f16s): dx12_image (rows, 2 hidden) float16, inv_scale (rows) f32 (exact row maxima):
+ * the operand of both backward GEMMs of w12 under the scaled-fp16 policy (dimsum_gemm_nt; dimsum_gemm_tn with k_scale_ptr). hidden <= 5120. */
+int dimsum_gated_gelu_bwd_f16s(const void *x12, const void *bias, const void *dh, void *dx12_image, void *inv_scale, void *dbias, int64_t rows,
+                               int64_t hidden, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * NT GEMM with a fused Linear epilogue: C (m, n) = A (m, k) . B (n, k)^T, 16-bit operands (bf16 or fp16 rows, k contiguous), fp32
@@ -519,6 +523,13 @@ typedef struct {
     const void *a_block_inv_ptr;
     int64_t a_block_inv_ld;
     int64_t tn_pair_a_cols, tn_pair_b_cols;
+    /* dimsum_gemm_tn, float16 operands: the weight gradient dW = dY^T X of a Linear under the scaled-fp16 policy (torch.mm(dy.t(), x) under
+     * train.py:20-21's TF32). Both operands are scaled-fp16 images with one power-of-two scale per ROW -- the images the forward and the input
+     * gradient use -- but their rows are the reduction index here: k_scale_ptr[r] (k float16: a_inv[r] b_inv[r] / max_r(a_inv b_inv), powers of
+     * two <= 1) multiplies A's row r as it is read and *c_scale_ptr (one f32 on the device: that maximum) multiplies the result;
+     * a_inv_scale_ptr / b_inv_scale_ptr NULL. k / splits <= 16384 reduction rows per range. */
+    const void *k_scale_ptr;
+    const void *c_scale_ptr;
 } dimsum_gemm_ext_t;
 
 /* The Linear itself: what F.linear(x, weight, bias) is given (plus the operand dtype and the power-of-two scales the scaled-fp16 operand
