@@ -498,13 +498,12 @@ class Bench:
         self.free()
         return out
 
-    TRAIN_MATMUL = ("allow_tf32=True served by the three-product split-bf16 images (fp32-class): the scaled-fp16 single-product carrier of "
-                    "`--matmul f16s` is an inference carrier")
+    TRAIN_MATMUL = {"f16s": "allow_tf32=True (dimsum/train.py:20-21 turns TF32 on for training too) served as ONE fp16 MFMA product per element over scaled-fp16 operand "
+                            "images in the forward, input-gradient and weight-gradient GEMMs (dW: row scales become per-reduction-row factors inside the TN kernel)",
+                    "tf32": "allow_tf32=True served by the three-product split-bf16 images (fp32-class)", "fp32": "exact fp32", "fp16": "as tf32"}
 
     def leg_block(self, model_name, image_size, batch, steps, warmup):
         r = image_size // 8
-        if self.args.matmul == "f16s":
-            self.set_matmul("tf32")
         model, hidden = build_block(model_name, self.dev)
         _, _, _, gen = self.inputs(1, r)
         ntok = (r // 2) ** 2
@@ -519,6 +518,12 @@ class Bench:
             hs.grad = res.grad = cond.grad = None
             out, res_out = model(hs, res, cond)
             torch.autograd.backward((out, res_out), (dy, dy))
+
+        def grads():
+            g = {"dx": hs.grad, "dc": cond.grad, "d w12": model.mlp.w12.weight.grad, "d w3": model.mlp.w3.weight.grad, "d qkv1": model.proj.qkv1.weight.grad,
+                 "d in_proj (spatial)": model.spatial_mamba.mixer.in_proj.weight.grad, "d out_proj (freq)": model.freq_mamba.mixer.out_proj.weight.grad,
+                 "d x_proj (spatial)": model.spatial_mamba.mixer.x_proj.weight.grad}
+            return {k: v.detach().clone() for k, v in g.items()}
         elapsed = self.timed(step, steps, warmup)
         out = {"workload": f"ONE DiMBlockCombined({hidden}) of {model_name} (scan + Haar + attention fusion + gated MLP) forward+backward, "
                            f"{ntok} tokens, batch {batch}, " + WEIGHTS,
@@ -527,9 +532,23 @@ class Bench:
             rf = self.timer.roofline(which)
             if rf is not None:
                 out[key] = rf
-        if self.args.matmul == "f16s":
-            out["matmul"] = self.TRAIN_MATMUL
+        out["matmul"] = self.TRAIN_MATMUL[self.args.matmul]
+        if self.args.matmul == "f16s" and not self.args.no_fp32_leg:
+            # the other two arithmetic legs of the same step and the gradient deviations: max |g - g_exact| / max |g_exact| per checked gradient
+            mine = grads()
+            self.set_matmul("tf32")
+            e3 = self.timed(step, 3, 1, time_scans=False)
+            three = grads()
+            self.set_matmul("fp32")
+            step()
+            torch.cuda.synchronize()
+            exact = grads()
             self.set_matmul("f16s")
+            dev = lambda g: {k: float((g[k] - exact[k]).abs().max() / exact[k].abs().max()) for k in exact}
+            out["three_product_split_bf16"] = {"ms_per_step": 1e3 * e3 / 3, "what": self.TRAIN_MATMUL["tf32"]}
+            out["gradient_deviation_vs_exact_fp32"] = {"single_product_f16s": dev(mine), "three_product_split_bf16": dev(three),
+                                                       "what": "max |g - g_exact| / max |g_exact|, g_exact = the same step with exact-fp32 matmuls (allow_tf32 off)"}
+            del mine, three, exact
         del model, hs, res, cond, dy
         self.free()
         return out
@@ -576,8 +595,6 @@ class Bench:
         from dimsum_amd.train import build_training, train_step
         from dimsum_amd.transport import create_transport
         r = image_size // 8
-        if self.args.matmul == "f16s":
-            self.set_matmul("tf32")
         model = build_model(model_name, self.dev, image_size)
         x, _, y, _ = self.inputs(batch, r)
         ddp, ema, opt = build_training(model.train(), self.dev, 1e-4, self.world, [self.local_rank])
@@ -589,9 +606,12 @@ class Bench:
         rb = self.timer.roofline("bwd")
         if rb is not None:
             out["roofline_bwd"] = rb
-        if self.args.matmul == "f16s":
-            out["matmul"] = self.TRAIN_MATMUL
+        out["matmul"] = self.TRAIN_MATMUL[self.args.matmul]
+        if self.args.matmul == "f16s" and not self.args.no_fp32_leg:
+            self.set_matmul("tf32")
+            e3 = self.timed(lambda: train_step(ddp, ema, opt, transport, x, y), 2, 1, time_scans=False)
             self.set_matmul("f16s")
+            out["three_product_split_bf16"] = {"value": batch * self.world * 2 / e3, "ms_per_step": 1e3 * e3 / 2, "what": self.TRAIN_MATMUL["tf32"]}
         del ddp, ema, opt, model
         self.free()
         return out
@@ -649,7 +669,7 @@ def main():
                          "sample_ddp.py:56) is served. f16s (default, the headline since round 5) = TF32's own arithmetic -- 10-bit operand "
                          "mantissas, fp32 accumulation -- as ONE fp16 MFMA product per element over scaled-fp16 operand images (exact "
                          "power-of-two row scales restore TF32's exponent range; deviation from exact fp32 below an emulated-TF32 run's); "
-                         "inference only: training legs run the three-product images. tf32 = three bf16 products per element (split-bf16, "
+                         "training legs run it too since round 6 (forward, input- and weight-gradient GEMMs). tf32 = three bf16 products per element (split-bf16, "
                          "4e-6 rms: fp32-class, the headline of rounds 1-4). fp32 = exact fp32 MFMA. fp16 = opt-in: plain fp16 operands "
                          "(TF32's mantissa, NOT its exponent range); never the headline.")
     args = ap.parse_args()
@@ -664,7 +684,7 @@ def main():
               "f16s": "allow_tf32=True like the reference (train.py:20-21), served as the TF32-equivalent SINGLE product: the large Linears (in_proj, qkv, proj, "
                       "w12 + gate, w3) and the attention fusion's QK^T / PV on scaled-fp16 operand images (10-bit mantissas like TF32, exact power-of-two "
                       "row scales: no range loss; one v_mfma_f32_16x16x32_f16 per element, fp32 accumulation); split-bf16 (3 products, fp32-class) for "
-                      "out_proj / x_proj / dt_proj and every training GEMM; deviation from exact fp32 on this line under `deviation_vs_exact_fp32`, "
+                      "x_proj / dt_proj (small library GEMMs); training legs on the same carrier (gradient deviations under `block_fwdbwd`); deviation from exact fp32 on this line under `deviation_vs_exact_fp32`, "
                       "next to the emulated-TF32 run's and the three-product carrier's (`--matmul tf32`, the headline of rounds 1-4, timed as "
                       "`tf32_three_product_split_bf16`)",
               "fp16": "OPT-IN: fp16 operands (TF32 mantissa, fp16 exponent range) + fp32 accumulation for the large Linears, split-bf16 elsewhere"}[args.matmul]

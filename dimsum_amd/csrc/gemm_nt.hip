@@ -341,3 +341,51 @@ extern "C" int dimsum_gemm_tn(const dimsum_gemm_params_t *pub, int32_t splits, i
     }
     return launch_status();
 }
+
+// C[s] (m, n) = sum over the rows r of range s of A[0..m, r] B[r, 0..n): A rows contiguous along the reduction (NT-style), B rows over it (TN-style)
+extern "C" int dimsum_gemm_nn(const dimsum_gemm_params_t *pub, int32_t splits, int64_t c_split_stride, void *stream) {
+    using namespace dimsum;
+    using namespace dimsum::gemm_nt;
+    gemm_flat_t flat;
+    {
+        const int frc = gemm_flat_from(pub, flat);
+        if (frc != DIMSUM_OK) return frc;
+    }
+    const gemm_flat_t *p = &flat;
+    if (!p->a_ptr || !p->b_ptr || !p->c_ptr || !p->k_scale_ptr || !p->c_scale_ptr) return DIMSUM_ERR_NULL;
+    if (p->operand_dtype != DIMSUM_F16) return DIMSUM_ERR_DTYPE;
+    if (p->epilogue != DIMSUM_GEMM_EPI_F32 || p->bias_ptr || p->b_inv_scale_ptr || p->a_block_inv_ptr || p->tn_pair_a_cols != 0 || p->a_alias_rows != 0 ||
+        p->b_alias_rows != 0 || p->a_alias_weight_order)
+        return DIMSUM_ERR_UNSUPPORTED;
+    if (splits < 1 || p->m <= 0 || p->n <= 0 || p->m % kBM != 0 || p->n % kBN != 0 || p->k % ((int64_t)splits * kBK) != 0 || p->k / splits < 2 * kBK ||
+        p->k / splits > 16384)
+        return DIMSUM_ERR_SHAPE;
+    if (p->lda % 8 != 0 || p->ldb % 8 != 0 || p->lda < p->k || p->ldb < p->n || !aligned_to<char>(p->a_ptr, 16) || !aligned_to<char>(p->b_ptr, 16) ||
+        p->ldc % 4 != 0 || p->ldc < p->n || !aligned_to<char>(p->c_ptr, 16) || (splits > 1 && (c_split_stride % 4 != 0 || c_split_stride < (int64_t)p->m * p->ldc)) ||
+        !aligned_to<char>(p->k_scale_ptr, 16) || !aligned_to<char>(p->c_scale_ptr, 4))
+        return DIMSUM_ERR_STRIDE;
+    if ((int64_t)256 * p->lda * 2 >= ((int64_t)1 << 31) || (int64_t)64 * p->ldb * 2 + 512 >= ((int64_t)1 << 31) || (int64_t)257 * p->ldc * 4 >= ((int64_t)1 << 31))
+        return DIMSUM_ERR_STRIDE;
+    Args a{};
+    a.A = reinterpret_cast<const char *>(p->a_ptr);
+    a.B0 = a.B1 = reinterpret_cast<const char *>(p->b_ptr);
+    a.C = p->c_ptr;
+    a.lda = p->lda; a.ldb = p->ldb; a.ldc = p->ldc;
+    a.M = p->m; a.N = p->n; a.K = p->k / splits;
+    a.tiles_m = p->m / kBM;
+    a.tiles_n = p->n / kBN;
+    a.group_m = p->tune_group_m > 0 ? p->tune_group_m : (a.tiles_m <= 16 ? a.tiles_m : 4);
+    a.splits = splits;
+    a.c_split_stride = c_split_stride;
+    a.out_scale = 1.0f;
+    a.sa = reinterpret_cast<const float *>(p->a_inv_scale_ptr);
+    a.k_fac = reinterpret_cast<const _Float16 *>(p->k_scale_ptr);
+    a.c_scale = reinterpret_cast<const float *>(p->c_scale_ptr);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipEvent_t e0 = reinterpret_cast<hipEvent_t>(p->timing_start_event), e1 = reinterpret_cast<hipEvent_t>(p->timing_stop_event);
+    constexpr int kShipN = kVarFullLineStores | kVarNtStores;
+    const dim3 grid((unsigned)(a.tiles_m * a.tiles_n * splits)), block(512);
+    if (e0 || e1) hipExtLaunchKernelGGL((gemm_nn_rowfac_kernel<kOpF16, kEpiF32, kShipN>), grid, block, 0, s, e0, e1, 0, a);
+    else hipLaunchKernelGGL((gemm_nn_rowfac_kernel<kOpF16, kEpiF32, kShipN>), grid, block, 0, s, a);
+    return launch_status();
+}

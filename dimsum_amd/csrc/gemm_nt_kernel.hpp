@@ -37,6 +37,12 @@
 // r order inside an MFMA differs from the NT kernel's; both operands use the same one, which is all a dot product needs. The 32-byte
 // pair u of row r sits at u ^ (r & 7): the 8 rows a 32-lane half of the read touches land in 8 distinct bank ranges. A launch may
 // split the reduction (grid = tiles x splits, partial results `c_split_stride` apart: the host adds them in a fixed order).
+//
+// NN variant (kVarNN: C (P, Q) = sum_r A[p, r] B[r, q] -- A rows contiguous ALONG the reduction like the NT kernel's, B rows OVER the reduction like the
+// TN kernel's: the weight gradients of the Mamba projections, whose one operand is a d-major activation (channels x tokens: in_proj's d xz,
+// out_proj's out_z) and whose other operand is token-major): A is staged and read exactly like the NT kernel's A, B like the TN kernel's B --
+// except that the DMA of B puts source row 8 g + 4 blk + e of every 32-row group into LDS row 16 blk + 4 g + e, so that the transposing read
+// hands lane group g the reduction rows 8 g .. 8 g + 7 the NT read gives it for A (an MFMA needs both operands on the same k).
 #pragma once
 #include "common.hpp"
 
@@ -95,7 +101,7 @@ struct Args {
     int c_pieces2;                 // kEpiGatedSplit3: the h image is written as the pair [hi | lo] (ldc >= 2 F) for a consumer that reads it with a_alias_tiles
 };
 // tuning variants (bit mask; 0 = the shipped schedule)
-enum { kVarLgkmAfterBarrier = 1, kVarNoEpilogue = 2, kVarNtStores = 4, kVarFullLineStores = 8, kVarNoSetprio = 16, kVarSc1Stores = 32, kVarSc0Stores = 64, kVarKeepX12 = 128, kVarTN = 256, kVarM128 = 512, kVarRebase = 1024, kVarPersist = 2048, kVarRowFac = 4096 };
+enum { kVarLgkmAfterBarrier = 1, kVarNoEpilogue = 2, kVarNtStores = 4, kVarFullLineStores = 8, kVarNoSetprio = 16, kVarSc1Stores = 32, kVarSc0Stores = 64, kVarKeepX12 = 128, kVarTN = 256, kVarM128 = 512, kVarRebase = 1024, kVarPersist = 2048, kVarRowFac = 4096, kVarNN = 8192 };
 
 __device__ __forceinline__ float dpp_row_ror8(float x) {      // lane l <- lane l ^ 8 (rotation by 8 inside each row of 16 lanes)
     const int v = __builtin_bit_cast(int, x);                  // (old = the source: with a constant `old` hipcc 7.2 merges the calls of an unrolled loop)
@@ -185,8 +191,10 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
     // rows (consecutive tiles walk down the rows of a group, then to the next tile column): the 32 workgroups an XCD runs at a time
     // form an 8 x 4 patch that shares its A and B panels through that XCD's L2.
     constexpr bool kTN = (kVar & kVarTN) != 0;
-    static_assert(!kTN || kEpi == kEpiF32, "the TN variant has the plain fp32 epilogue");
-    static_assert(!(kTN && kM1), "the TN variant has 256 x 256 tiles only");
+    constexpr bool kNN = (kVar & kVarNN) != 0;            // A like NT, B like TN (rows permuted at staging)
+    constexpr bool kBT = kTN || kNN;                      // B is stored over the reduction index
+    static_assert(!kBT || kEpi == kEpiF32, "the TN / NN variants have the plain fp32 epilogue");
+    static_assert(!(kBT && kM1) && !(kTN && kNN), "the TN / NN variants have 256 x 256 tiles only");
     // kVarPersist: gridDim.x (a multiple of 8, <= the tile count) workgroups walk the tile list, workgroup b taking the list positions b,
     // b + gridDim.x, .. -- the positions the hardware dispatcher would hand to the CU one after the other -- as ONE stream of K tiles: the
     // last two K tiles of an output tile stage the first two of the next one, the epilogue runs with those DMAs in flight, and the K loop
@@ -198,7 +206,7 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
         const int nwg = kPersist ? p.tiles_m * p.tiles_n : (int)gridDim.x;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        if constexpr (kTN) {       // (the splits of one tile are `tiles` apart in the list: they run at the same time on different XCDs' ranges)
+        if constexpr (kBT) {       // (the splits of one tile are `tiles` apart in the list: they run at the same time on different XCDs' ranges)
             const int tiles = p.tiles_m * p.tiles_n;
             split = t / tiles;
             t -= split * tiles;
@@ -264,13 +272,15 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
     const char *tn_a = nullptr, *tn_b = nullptr;
     int64_t tn_a_tile = 0, tn_b_tile = 0;
     int tn_row_split = 0;          // which range of reduction rows this workgroup adds up
-    if constexpr (kTN) {
+    if constexpr (kBT) {
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc) {
             const int row = w * 8 + pc * 4 + (lane >> 4), key = pc * 4 + (lane >> 4);
             const int chunk = ((((lane & 15) >> 1) ^ key) << 1) | (lane & 1);
-            tn_voff_a[pc] = (unsigned)(row * p.lda * 2 + chunk * 16);
-            tn_voff_b[pc] = (unsigned)(row * p.ldb * 2 + chunk * 16);
+            // NN: LDS row 16 blk + 4 g + e of a 32-row group holds SOURCE row 8 g + 4 blk + e (the swizzle key stays the LDS row's)
+            const int rl = row & 31, srow = kNN ? ((row & ~31) | (((rl & 15) >> 2) << 3) | ((rl >> 4) << 2) | (rl & 3)) : row;
+            tn_voff_a[pc] = (unsigned)(srow * p.lda * 2 + chunk * 16);
+            tn_voff_b[pc] = (unsigned)(srow * p.ldb * 2 + chunk * 16);
         }
         int row_split = split;
         int64_t a_col = 0, b_col = 0;
@@ -281,6 +291,7 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
             b_col = piece == 2 ? p.b_pair_cols : 0;
         }
         tn_row_split = row_split;
+        if constexpr (kNN) cur.a_base += (int64_t)row_split * p.K * 2;          // A rows run along the reduction: the range starts K elements further
         tn_a = p.A + ((int64_t)row_split * p.K * p.lda + m0 + a_col) * 2;
         tn_b = p.B0 + ((int64_t)row_split * p.K * p.ldb + n0 + b_col) * 2;
         tn_a_tile = (int64_t)kBK * p.lda * 2;
@@ -310,8 +321,8 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
     };
     auto stage_a0 = [&](int kt) { if constexpr (kTN) stage_tn_a(kSlotA0, tn_a, kt); else stage(kSlotA0, a_base, a_voff, kt, p.a_alias_tiles); };
     auto stage_a1 = [&](int kt) { if constexpr (kTN) stage_tn_a(kSlotA1, tn_a + 256, kt); else stage(kSlotA1, a_base + a_half, a_voff, kt, p.a_alias_tiles); };
-    auto stage_b0 = [&](int kt) { if constexpr (kTN) stage_tn(kSlotB0, tn_b, tn_b_tile, tn_voff_b, kt); else stage(kSlotB0, b_base[0], b_voff[0], kt, p.b_alias_tiles); };
-    auto stage_b1 = [&](int kt) { if constexpr (kTN) stage_tn(kSlotB1, tn_b + 256, tn_b_tile, tn_voff_b, kt); else stage(kSlotB1, b_base[1], b_voff[1], kt, p.b_alias_tiles); };
+    auto stage_b0 = [&](int kt) { if constexpr (kBT) stage_tn(kSlotB0, tn_b, tn_b_tile, tn_voff_b, kt); else stage(kSlotB0, b_base[0], b_voff[0], kt, p.b_alias_tiles); };
+    auto stage_b1 = [&](int kt) { if constexpr (kBT) stage_tn(kSlotB1, tn_b + 256, tn_b_tile, tn_voff_b, kt); else stage(kSlotB1, b_base[1], b_voff[1], kt, p.b_alias_tiles); };
     // (persistent: half tile `which` of K tile kt of the tile whose panels are s_)
     auto stage_of = [&](const Src &s_, int which, int kt) {
         if (which == 0) stage(kSlotA0, s_.a_base, a_voff, kt, p.a_alias_tiles);
@@ -327,7 +338,7 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
 
     // TN: lane (t, g) addresses row 4 g + (t >> 2) of a 16-row block, 8 bytes at (t & 3) * 8 of the 32-byte pair (column block ^ key)
     unsigned a_rd_tn[4], b_rd_tn[2];
-    if constexpr (kTN) {
+    if constexpr (kBT) {
         const int t = lane & 15, g = lane >> 4, key = ((g & 1) << 2) | (t >> 2);
         const unsigned base = lds0 + (unsigned)((4 * g + (t >> 2)) * 256 + (t & 3) * 8);
 #pragma unroll
@@ -377,7 +388,7 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
     } while (0)
 #define DIMSUM_READ_B(dst, slot, par)                                                      \
     do {                                                                                   \
-        if constexpr (kTN) {                                                               \
+        if constexpr (kBT) {                                                               \
             _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                             \
                 const unsigned ad_ = b_rd_tn[j_] + (par);                                  \
                 DIMSUM_READ_TN1(dst[j_][0], ad_, slot, 0);                                 \
@@ -441,7 +452,7 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
     // The factors of this workgroup's reduction range sit in the 32 KB of LDS behind the ring (K <= 16384 rows per range); a lane (t, g) of a
     // transposing read holds reduction rows kh 32 + {4 g .. 4 g + 3, 16 + 4 g .. 16 + 4 g + 3} of the K tile: four 8-byte LDS reads per K tile.
     constexpr bool kRowFac = (kVar & kVarRowFac) != 0;
-    static_assert(!kRowFac || (kTN && kOp == kOpF16 && !kRebase), "the row factors serve the fp16 TN variant");
+    static_assert(!kRowFac || (kBT && kOp == kOpF16 && !kRebase), "the row factors serve the fp16 TN / NN variants");
     unsigned fac_rd = 0;
     u32x2 fv[4];
     if constexpr (kRowFac) {
@@ -449,16 +460,24 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
         const _Float16 *src = p.k_fac + (int64_t)tn_row_split * p.K;
         for (int i = threadIdx.x; i < p.K / 8; i += 512) *reinterpret_cast<u32x4 *>(fl + i * 16) = *reinterpret_cast<const u32x4 *>(src + i * 8);
         __syncthreads();
-        fac_rd = lds0 + 2 * kParity + (lane >> 4) * 8;
+        // (NN: A's fragment of lane group g holds reduction rows kh 32 + 8 g .. 8 g + 7: one 16-byte read per k half)
+        fac_rd = lds0 + 2 * kParity + (lane >> 4) * (kNN ? 16 : 8);
     }
 #define DIMSUM_DS_READ_B64(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
     auto read_fac = [&](int kt_) {          // issued with the operand reads of the phase: the phase's lgkmcnt(0) covers them
         if constexpr (kRowFac) {
             const unsigned ad = fac_rd + (unsigned)kt_ * 128u;
-            DIMSUM_DS_READ_B64(fv[0], ad, 0);
-            DIMSUM_DS_READ_B64(fv[1], ad, 32);
-            DIMSUM_DS_READ_B64(fv[2], ad, 64);
-            DIMSUM_DS_READ_B64(fv[3], ad, 96);
+            if constexpr (kNN) {
+                DIMSUM_DS_READ_B64(fv[0], ad, 0);
+                DIMSUM_DS_READ_B64(fv[1], ad, 8);
+                DIMSUM_DS_READ_B64(fv[2], ad, 64);
+                DIMSUM_DS_READ_B64(fv[3], ad, 72);
+            } else {
+                DIMSUM_DS_READ_B64(fv[0], ad, 0);
+                DIMSUM_DS_READ_B64(fv[1], ad, 32);
+                DIMSUM_DS_READ_B64(fv[2], ad, 64);
+                DIMSUM_DS_READ_B64(fv[3], ad, 96);
+            }
         }
     };
     auto rebase = [&](u32x4 (&frag)[4][2], int mi, int kt_) {
@@ -787,7 +806,7 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
         }
         // one buffer descriptor per tile (base = the tile's first element: wave-uniform), a 32-bit byte offset per lane
         constexpr int kAux = ((kVar & kVarNtStores) ? 2 : 0) | ((kVar & kVarSc1Stores) ? 16 : 0) | ((kVar & kVarSc0Stores) ? 1 : 0);
-        float *Ct = reinterpret_cast<float *>(p.C) + (int64_t)m0 * p.ldc + n0 + (kTN ? (int64_t)split * p.c_split_stride : (int64_t)0);
+        float *Ct = reinterpret_cast<float *>(p.C) + (int64_t)m0 * p.ldc + n0 + (kBT ? (int64_t)split * p.c_split_stride : (int64_t)0);
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(Ct, 0, 0x7fffffff, 0x00020000);
         if constexpr (kVar & kVarFullLineStores) {
             // 128-byte row segments per store: lanes r and r + 8 of a 16-lane row trade their j = 1 / j = 0 registers (row_ror:8), after
@@ -803,7 +822,9 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
             // makes hipcc wait vmcnt(0) at every later use)
             const bool has_s = kRebase || p.sa != nullptr;
             const unsigned ms = pick_mask(has_s);
-            const float *sap = p.sa ? p.sa + m0 : reinterpret_cast<const float *>(p.A), *sbp = has_s ? p.sb : reinterpret_cast<const float *>(p.B0);
+            const bool has_sb = has_s && !kRowFac;          // (row factors: no column scales -- the B rows' scales are inside the factors)
+            const unsigned msb = pick_mask(has_sb);
+            const float *sap = p.sa ? p.sa + m0 : reinterpret_cast<const float *>(p.A), *sbp = has_sb ? p.sb : reinterpret_cast<const float *>(p.B0);
             float c_scale = 1.0f;
             if constexpr (kRowFac) c_scale = *p.c_scale;           // (wave-uniform: a scalar load, before the stores)
             bool live[2];
@@ -819,7 +840,7 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
                     gv[ni] = pick(pick_mask(p.gate != nullptr),
                                   *reinterpret_cast<const f4 *>((p.gate ? p.gate + (int64_t)(m0 / p.rows_per_batch) * p.ldg : reinterpret_cast<const float *>(p.B0)) + lc), gv[ni]);
                 }
-                sbv[ni] = pick(ms, *reinterpret_cast<const f4 *>(sbp + lc), sbv[ni]);
+                sbv[ni] = pick(msb, *reinterpret_cast<const f4 *>(sbp + lc), sbv[ni]);
             };
             load_cols(0);
             live[1] = n0 + 128 + fcol < p.N;
@@ -831,7 +852,9 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
                 for (int i = 0; i < 4; ++i) {
                     const int lrow = frow + mi * kMiRows + i * 16;
                     if constexpr (kRebase) rs[mi][i][0] = rs[mi][i][1] = top[mi * 2 + (i >> 1)];
-                    else if constexpr (kRowFac) rs[mi][i][0] = rs[mi][i][1] = c_scale;
+                    else if constexpr (kRowFac) {           // (NN: A's rows are OUTPUT rows and may carry their own scale)
+                        rs[mi][i][0] = c_scale * pick(ms, sap[lrow], 1.0f); rs[mi][i][1] = c_scale * pick(ms, sap[lrow + 8], 1.0f);
+                    }
                     else {                                  // scaled-fp16 operands: exact powers of two
                         rs[mi][i][0] = pick(ms, sap[lrow], 1.0f); rs[mi][i][1] = pick(ms, sap[lrow + 8], 1.0f);
                     }
@@ -1216,6 +1239,12 @@ template <int kOp, int kEpi, int kVar = 0>
 __global__ __launch_bounds__(512, 2) void gemm_tn_rowfac_kernel(const Args p) {
     __shared__ __attribute__((aligned(1024))) char lds[2 * kParity + 32768];
     gemm_body<kOp, kEpi, kVar | kVarRowFac>(p, lds);
+}
+
+template <int kOp, int kEpi, int kVar = 0>
+__global__ __launch_bounds__(512, 2) void gemm_nn_rowfac_kernel(const Args p) {
+    __shared__ __attribute__((aligned(1024))) char lds[2 * kParity + 32768];
+    gemm_body<kOp, kEpi, kVar | kVarRowFac | kVarNN>(p, lds);
 }
 
 // 4 waves, 80 KB: two workgroups per CU (2 waves per SIMD: the same 256-VGPR budget)

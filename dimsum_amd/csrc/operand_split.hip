@@ -107,6 +107,52 @@ __global__ __launch_bounds__(256) void rows_f16s_kernel(const float *src, int64_
     }
 }
 
+// The same image for LONG rows (a d-major activation: channels x (batch x tokens), 65536 columns at DiM-L/2 batch 256 -- the operand of the Mamba
+// projections' training GEMMs whose reduction runs over the tokens): one workgroup per row, 4 independent 16-byte loads per thread in flight
+// (a wave per row as above keeps 1 KB in flight per row: a quarter of the chip's rate on 2048 rows), two passes over the row.
+__global__ __launch_bounds__(256) void rows_f16s_long_kernel(const float *src, int64_t rows, int64_t cols, int64_t src_stride, __half *dst, int64_t dst_stride,
+                                                            float *inv_scale) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float *x = src + row * src_stride;
+        float m = 0.f;
+        int64_t c = (int64_t)threadIdx.x * 4;
+        for (; c + 3 * 1024 < cols; c += 4 * 1024) {
+            float4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4 *>(x + c + k * 1024);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[k].x), fabsf(v[k].y))), fmaxf(fabsf(v[k].z), fabsf(v[k].w)));
+        }
+        for (; c < cols; c += 1024) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + c);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+        m = wave_allmax(m);
+        __syncthreads();                      // (the previous row's maxima have been read)
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float sc, inv;
+        f16s_scales(m, sc, inv);
+        if (threadIdx.x == 0) inv_scale[row] = inv;
+        __half *d = dst + row * dst_stride;
+        c = (int64_t)threadIdx.x * 4;
+        for (; c + 3 * 1024 < cols; c += 4 * 1024) {
+            float4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4 *>(x + c + k * 1024);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<uint2 *>(d + c + k * 1024) = f16s_pack4(f32x4{{v[k].x, v[k].y, v[k].z, v[k].w}}, sc);
+        }
+        for (; c < cols; c += 1024) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + c);
+            *reinterpret_cast<uint2 *>(d + c) = f16s_pack4(f32x4{{v.x, v.y, v.z, v.w}}, sc);
+        }
+    }
+}
+
 // Many conversions in ONE launch (dimsum_rows_f16s_multi): what a denoiser forward under the scaled-fp16 policy needs of its weights --
 // the images of every large Linear (7 per DiMBlockCombined), their largest row L1 norms and the bias maxima of the bound-derived scales
 // -- used to be ~150 launches of 5-30 us per DiM-L/2 forward (2.2 ms of small grids + ~1 ms of torch reductions between the big kernels);
@@ -220,6 +266,12 @@ extern "C" int dimsum_rows_f16s(const void *src, int64_t rows, int64_t cols, int
         !aligned_to<char>(dst, 8))
         return DIMSUM_ERR_STRIDE;
     if (rows == 0) return DIMSUM_OK;
+    if (cols > 8192 && !l1max) {           // long rows (d-major activations): one workgroup per row
+        const int64_t nb = rows < 8192 ? rows : 8192;
+        hipLaunchKernelGGL(rows_f16s_long_kernel, dim3((unsigned)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const float *>(src),
+                           rows, cols, src_row_stride, reinterpret_cast<__half *>(dst), dst_row_stride, reinterpret_cast<float *>(inv_scale));
+        return launch_status();
+    }
     int64_t blocks = (rows + 3) / 4;
     const int64_t cap = l1max ? 512 : 256 * 8;      // (with the L1 maximum every workgroup ends in an atomic on ONE address: ~35 ns each, serialised)
     if (blocks > cap) blocks = cap;

@@ -548,12 +548,11 @@ __global__ __launch_bounds__(256) void gated_gelu_bwd_kernel(const float *x12, c
 // The same adjoint with dx12 written as a scaled-fp16 operand image (common.hpp, f16s): rows of 2H fp16 = fp16(dx12_r 2^s_r) with the exact row
 // maximum's power of two, inv[r] = 2^-s_r -- the operand of BOTH backward GEMMs of w12 under the scaled-fp16 policy (d input = dx12 W12 as an NT
 // product, d weight = dx12^T h as a TN product with per-reduction-row factors, dimsum_gemm_ext_t.k_scale_ptr). A row's maximum needs the whole
-// row: one workgroup walks kGGRowsF rows, a thread holding its 4-column pieces of both halves (H <= 1024 kStrips) in registers between the
+// row: one workgroup walks rows_per_wg rows (16 .. 128: >= ~1024 workgroups at every batch size), a thread holding its 4-column pieces of both halves (H <= 1024 kStrips) in registers between the
 // maximum and the store; the column sums (d bias) accumulate in registers across the rows.
-constexpr int kGGRowsF = 128;
 template <int kStrips>
 __global__ __launch_bounds__(256) void gated_gelu_bwd_f16s_kernel(const float *x12, const float *bias, const float *dh, __half *img, float *inv, float *dbias,
-                                                                  int64_t rows, int64_t H) {
+                                                                  int64_t rows, int64_t H, int rows_per_wg) {
     __shared__ float red[2][4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float4 ba[kStrips], bg[kStrips], sa[kStrips], sg[kStrips];
@@ -563,7 +562,7 @@ __global__ __launch_bounds__(256) void gated_gelu_bwd_f16s_kernel(const float *x
         ba[s] = bg[s] = sa[s] = sg[s] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (bias && c < H) { ba[s] = *reinterpret_cast<const float4 *>(bias + c); bg[s] = *reinterpret_cast<const float4 *>(bias + H + c); }
     }
-    const int64_t r0 = (int64_t)blockIdx.x * kGGRowsF, r1 = min(rows, r0 + kGGRowsF);
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg, r1 = min(rows, r0 + rows_per_wg);
     for (int64_t r = r0; r < r1; ++r) {
         float4 da[kStrips], dg[kStrips];
         float m = 0.f;
@@ -706,12 +705,16 @@ extern "C" int dimsum_gated_gelu_bwd_f16s(const void *x12, const void *bias, con
     if (rows < 0 || hidden <= 0 || hidden % 4 != 0 || hidden > 5 * 1024) return DIMSUM_ERR_SHAPE;
     if (!aligned_to<char>(x12, 16) || !aligned_to<char>(dh, 16) || !aligned_to<char>(dx12_image, 8) || (bias && !aligned_to<char>(bias, 16))) return DIMSUM_ERR_STRIDE;
     if (rows == 0) return DIMSUM_OK;
-    const dim3 grid((unsigned)((rows + kGGRowsF - 1) / kGGRowsF));
+    // rows per workgroup: enough workgroups to fill the chip several times over (>= ~1024) at every batch size, at most 128 rows (the column sums
+    // of a workgroup cost one atomic per column: 16 rows per workgroup at 16384 rows is the same atomic traffic as 128 at 131072)
+    int rpw = (int)(rows / 1024);
+    rpw = rpw < 16 ? 16 : (rpw > 128 ? 128 : rpw);
+    const dim3 grid((unsigned)((rows + rpw - 1) / rpw));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int strips = (int)((hidden + 1023) / 1024);
 #define DIMSUM_GGF(K) hipLaunchKernelGGL(gated_gelu_bwd_f16s_kernel<K>, grid, dim3(256), 0, s, reinterpret_cast<const float *>(x12), reinterpret_cast<const float *>(bias), \
                                          reinterpret_cast<const float *>(dh), reinterpret_cast<__half *>(dx12_image), reinterpret_cast<float *>(inv_scale),                \
-                                         reinterpret_cast<float *>(dbias), rows, hidden)
+                                         reinterpret_cast<float *>(dbias), rows, hidden, rpw)
     switch (strips) {
         case 1: DIMSUM_GGF(1); break;
         case 2: DIMSUM_GGF(2); break;

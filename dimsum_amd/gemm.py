@@ -287,12 +287,51 @@ def linear(x, weight):
     return y.view(*x.shape[:-1], weight.shape[0])
 
 
+class _MatmulWxF16sFn(torch.autograd.Function):
+    """the in_proj site under autograd on the single-product carrier (policy "f16s"): xz (N, M) = W (N, K) x^T as an NT product of scaled-fp16
+    images (d-major output, no copy); backward from ONE image of the d-major gradient dxz (N, M) -- fp16 rows with one scale per channel
+    (native.rows_f16s, long rows):
+        dW (N, K) = dxz x       the mixed-layout product (native.gemm_nn): dxz rows run along the reduction (tokens), x rows over it;
+                                x's per-token scales travel as per-reduction-row factors
+        dx (M, K) = dxz^T W     the TN product (native.gemm_tn(row_scales=..)): both operands' rows are the reduction index (channels)
+    (mamba_simple.py in_proj under train.py:20-21's TF32: torch's autograd runs the same two products on TF32-rounded operands.)"""
+
+    @staticmethod
+    def forward(ctx, weight, x2):
+        from . import native
+        x16 = native.rows_f16s(x2)
+        w16 = weight_f16s_train(weight)
+        ctx.save_for_backward(weight, x16.data, x16.inv)
+        return native.gemm_nt(w16.data, x16.data, scales=(w16.inv, x16.inv))
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import native
+        weight, xd, xi = ctx.saved_tensors
+        dy16 = native.rows_f16s(dy.contiguous())                 # (N, M): one scale per channel
+        dw = native.gemm_nn(dy16.data, dy16.inv, xd, xi) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[1]:
+            w16 = weight_f16s_train(weight)
+            dx = native.gemm_tn(dy16.data, w16.data, row_scales=native.row_factors(dy16.inv, w16.inv))
+        return dw, dx
+
+
+def mamba_f16s_train_ok(M, d_model, d_inner):
+    """shapes the single-product training GEMMs of a Mamba mixer take (in_proj / out_proj forward, input- and weight-gradients): whole tiles of the
+    NT / TN / NN kernels on both sides, 32-bit in-tile offsets of the (channels, M) d-major operands"""
+    return (own_gemm_enabled() and M % 256 == 0 and d_model % 256 == 0 and d_inner % 256 == 0 and d_model >= 128 and 256 * M * 2 < 2 ** 31)
+
+
 def matmul_wx(weight, xt):
     """weight (N, K) @ xt (K, M) -> (N, M): the in_proj site, whose output is consumed d-major without a copy"""
     if not _use_fp16(xt, weight):
         x2 = xt.t()
         if (torch.is_grad_enabled() and weight.requires_grad and xt.is_cuda and x2.is_contiguous()
                 and not torch.is_autocast_enabled("cuda")):          # (under autocast the plain product differentiates with mixed dtypes)
+            if (split3_train_enabled(x2, weight) == "f16s" and mamba_f16s_train_ok(x2.shape[0], weight.shape[1], weight.shape[0] // 2)
+                    and weight.shape[1] % 64 == 0 and x2.data_ptr() % 16 == 0):
+                return _MatmulWxF16sFn.apply(weight, x2)
             return _MatmulWxFn.apply(weight, x2)
         return weight @ xt
     return torch.mm(_w16(weight), xt.to(torch.float16), out_dtype=torch.float32)

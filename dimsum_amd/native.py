@@ -846,6 +846,48 @@ def gemm_kernel_log():
         _gemm_kernel_log = old
 
 
+def gemm_nn_supported(a, b):
+    """shapes dimsum_gemm_nn takes: a (P, R) float16 rows contiguous along the reduction, b (R, Q) float16 rows over it; whole 256 x 256 output
+    tiles, whole 64-row reduction tiles"""
+    if not (a.is_cuda and a.dim() == 2 and b.dim() == 2 and a.dtype == torch.float16 and b.dtype == torch.float16):
+        return False
+    P, R = a.shape
+    Q = b.shape[1]
+    return (b.shape[0] == R and R % 64 == 0 and R >= 128 and P % 256 == 0 and Q % 256 == 0 and a.stride(1) == 1 and b.stride(1) == 1
+            and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
+            and 256 * a.stride(0) * 2 < 2 ** 31 and 64 * b.stride(0) * 2 + 512 < 2 ** 31)
+
+
+def gemm_nn(a, a_inv, b, b_inv, splits=None):
+    """a (P, R) @ b (R, Q) -> (P, Q) float32 from two scaled-fp16 images: a = fp16 rows with one scale per row (a_inv (P,): its rows are OUTPUT rows --
+    a d-major activation, channels x tokens), b = fp16 rows with one scale per row (b_inv (R,): its rows are the REDUCTION index -- a token-major
+    activation): the weight gradients of the Mamba projections (d in_proj.weight = dxz x, d out_proj.weight^T = out_z dout) as ONE fp16 product
+    per element. b's scales travel as per-reduction-row factors (row_factors with a constant partner)."""
+    _gpu(a, a_inv, b, b_inv)
+    _check(gemm_nn_supported(a, b) and a_inv.dtype == torch.float32 and a_inv.numel() == a.shape[0] and a_inv.is_contiguous()
+           and b_inv.dtype == torch.float32 and b_inv.numel() == b.shape[0], "gemm_nn: unsupported operands")
+    P, R = a.shape
+    Q = b.shape[1]
+    if splits is None:
+        splits = gemm_tn_splits(R, P, Q)
+        while R // splits > 16384 and R % (2 * splits * 64) == 0:
+            splits *= 2
+    _check(splits >= 1 and R % (splits * 64) == 0 and 128 <= R // splits <= 16384, "gemm_nn: splits must cut R into ranges of 2 .. 256 whole 64-row tiles")
+    top = b_inv.max().reshape(1)
+    fac = (b_inv / top).to(torch.float16)
+    out = torch.empty((splits, P, Q), device=a.device, dtype=torch.float32)
+    G = _lib.GemmParams()
+    G.m, G.n, G.k = P, Q, R
+    G.operand_dtype, G.epilogue, G.out_scale = _DT[a.dtype], _lib.GEMM_EPI_F32, 1.0
+    G.lda, G.ldb, G.ldc = a.stride(0), b.stride(0), Q
+    G.a_ptr, G.b_ptr, G.c_ptr, G.a_inv_scale_ptr = _ptr(a), _ptr(b), _ptr(out), _ptr(a_inv)
+    X = _lib.attach_ext(G, _lib.GemmExt)
+    X.k_scale_ptr, X.c_scale_ptr = _ptr(fac), _ptr(top)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.load().dimsum_gemm_nn(G, splits, P * Q, _stream(a)), "gemm_nn")
+    return out[0] if splits == 1 else out.sum(0)
+
+
 def gemm_nt(a, b, bias=None, epilogue="f32", out=None, out_scale=1.0, events=None, tune=None, scales=None, gate_bound=None, residual=None,
             gate=None, rows_per_batch=None, keep_x12=False, pair_out=False, weight_order=False, q_cols=None, conv=None):
     """a (M, K) @ b (N, K)^T on the hand-written MFMA kernel, 16-bit operands (bfloat16: split-bf16 images over 3 K; float16: scaled rows),

@@ -73,6 +73,25 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
                                  _will_backprop(u, delta, A, B, C, D, z, delta_bias))
 
 
+def _f16s_train(xz, out_proj_weight, will_backprop):
+    """whether this training call's out_proj GEMMs run on the single-product carrier (gemm.split3_train_enabled == "f16s" and shapes the kernels take)"""
+    if not will_backprop or out_proj_weight is None or not xz.is_cuda or xz.dtype != torch.float32:
+        return False
+    bsz, d2, L = xz.shape
+    return (gemm.split3_train_enabled(_Rows(bsz * L, d2, xz), out_proj_weight) == "f16s"
+            and gemm.mamba_f16s_train_ok(bsz * L, out_proj_weight.shape[0], d2 // 2))
+
+
+class _Rows:
+    """a shape-only stand-in for the (tokens, features) view of a d-major tensor: what gemm.split3_train_enabled looks at"""
+
+    def __init__(self, rows, cols, like):
+        self.shape, self.is_cuda, self.dtype, self._n = (rows, cols), like.is_cuda, like.dtype, rows * cols
+
+    def numel(self):
+        return self._n
+
+
 def _will_backprop(*tensors):
     """True when autograd will record this call: only then is it worth storing the scan's saved states"""
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
@@ -90,9 +109,11 @@ class _MambaInner(torch.autograd.Function):
     @custom_fwd(device_type="cuda")
     def forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
                 A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, init_states, has_out_proj, checkpoint_lvl,
-                need_ckpt=False, conv_done=False):
+                need_ckpt=False, conv_done=False, f16s_train=False):
         # conv_done (inference extra, not in the reference's signature): xz[:, :d_inner] already holds the causal conv1d + SiLU of the in_proj
         # output (the GEMM's epilogue formed it, modules/mamba_simple.py) -- the conv kernel is skipped
+        # f16s_train (training extra, decided by the caller like need_ckpt: grad mode is off in here): out_proj's forward, input-gradient and
+        # weight-gradient GEMMs as ONE fp16 product per element over scaled-fp16 images (gemm.py, policy "f16s")
         assert checkpoint_lvl in (0, 1)
         assert not (conv_done and need_ckpt), "conv_done is an inference extra"
         if A.is_complex():
@@ -188,9 +209,21 @@ class _MambaInner(torch.autograd.Function):
         if checkpoint_lvl >= 1:
             conv_out, delta = None, None            # recomputed in the backward (:663-664)
         keep_out_z = has_out_proj and need and os.environ.get("DIMSUM_RECOMPUTE_OUT_Z", "0") != "1"
+        f16s = bool(f16s_train) and has_out_proj and need and out_proj_bias is None and keep_out_z
+        ctx.f16s = f16s
+        if f16s:
+            # out = out_z^T W_out^T as the TN product of two images whose rows are the reduction index (channels): out_z (d, b l) with one scale per
+            # channel, W_out^T (d, e) with one per channel -> per-reduction-row factors. The image replaces the fp32 out_z among the saved tensors
+            # (d out_proj.weight reads it again): half the bytes kept per mixer.
+            oz16 = native.rows_f16s(_rows(out_z))
+            wt16 = gemm.weight_t_f16s_train(out_proj_weight)
+            y = native.gemm_tn(oz16.data, wt16.data, row_scales=native.row_factors(oz16.inv, wt16.inv))
+            ctx.save_for_backward(xz, conv_w, conv_b, x_dbl, x_proj_weight, delta_proj_weight, out_proj_weight, conv_out, delta, A, Bm, Cm, D, delta_bias,
+                                  scan_x, out, ckpt, None, oz16.data, oz16.inv)
+            return y.view(bsz, L, out_proj_weight.shape[0])
         ctx.save_for_backward(xz, conv_w, conv_b, x_dbl, x_proj_weight, delta_proj_weight,
                               out_proj_weight if has_out_proj else None, conv_out, delta, A, Bm, Cm, D, delta_bias, scan_x, out, ckpt,
-                              out_z if keep_out_z else None)
+                              out_z if keep_out_z else None, None, None)
         if not has_out_proj:
             return out_z                                                                                # (b, d, l)
         if out_proj_bias is None:
@@ -201,7 +234,7 @@ class _MambaInner(torch.autograd.Function):
     @custom_bwd(device_type="cuda")
     def backward(ctx, dout):
         (xz, conv_w, conv_b, x_dbl, x_proj_weight, delta_proj_weight, out_proj_weight, conv_out, delta, A, Bm, Cm, D,
-         delta_bias, scan_x, out, ckpt, kept_out_z) = ctx.saved_tensors
+         delta_bias, scan_x, out, ckpt, kept_out_z, oz16_data, oz16_inv) = ctx.saved_tensors
         has_conv_b, has_D, has_dbias, has_Bb, has_Cb, has_ob = ctx.flags
         L = xz.shape[-1]
         R = delta_proj_weight.shape[1]
@@ -214,19 +247,29 @@ class _MambaInner(torch.autograd.Function):
             delta = (delta_proj_weight @ x_dbl[:, :R].t()).view(d_inner, bsz, L).permute(1, 0, 2)
         dxz = torch.empty_like(xz)
         dx, dz = dxz.chunk(2, dim=1)
-        if ctx.has_out_proj:
+        dout16 = None
+        if ctx.f16s:
+            # dout_y (d, b l) = W_out^T dout^T as an NT product of the images of W_out^T (one scale per channel = output row) and dout (one per token)
+            dout16 = native.rows_f16s(dout.reshape(bsz * L, -1))
+            wt16 = gemm.weight_t_f16s_train(out_proj_weight)
+            dout_y = native.gemm_nt(wt16.data, dout16.data, scales=(wt16.inv, dout16.inv)).view(d_inner, bsz, L).permute(1, 0, 2)
+        elif ctx.has_out_proj:
             dout2 = dout.reshape(bsz * L, -1).t()                                                       # "b l e -> e (b l)"
             dout_y = (out_proj_weight.t() @ dout2).view(d_inner, bsz, L).permute(1, 0, 2)               # d-major like delta
         else:
             dout_y = dout
-        recompute = ctx.has_out_proj and kept_out_z is None      # only d out_proj.weight needs out_z
+        recompute = ctx.has_out_proj and kept_out_z is None and not ctx.f16s     # only d out_proj.weight needs out_z
         dconv_out, ddelta, dA, dB, dC, dD, ddelta_bias, dz, *rest = native.selective_scan_bwd(
             conv_out, delta, A, Bm, Cm, D, z, delta_bias, dout_y, scan_x, out, dz, ctx.delta_softplus, recompute, ckpt=ckpt)
         out_z = rest[0] if recompute else kept_out_z
         dout_proj_weight = dout_proj_bias = None
-        if ctx.has_out_proj:
+        if ctx.f16s:
+            # "eB,dB->ed" as the mixed-layout product out_z (d, B) dout (B, e): the saved image's rows run along the reduction, dout's over it
+            dout_proj_weight = native.gemm_nn(oz16_data, oz16_inv, dout16.data, dout16.inv).t()
+        elif ctx.has_out_proj:
             # "eB,dB->ed": a (d_model, d_inner) output over a b*l-long reduction -- sliced, it would fill 8 of 256 CUs otherwise
             dout_proj_weight = gemm.mm_nn_rows(_rows(out_z), dout.reshape(bsz * L, -1)).t()
+        if ctx.has_out_proj:
             dout_proj_bias = dout.sum(dim=(0, 1)) if has_ob else None
         dx_dbl = torch.empty_like(x_dbl)
         dBf = dB.squeeze(1).permute(0, 2, 1).reshape(bsz * L, N)                                        # "b 1 n l -> (b l) n"
@@ -245,24 +288,26 @@ class _MambaInner(torch.autograd.Function):
         _, dconv_w, dconv_b = native.causal_conv1d_bwd(x, conv_w, conv_b, dconv_out, dx, True)
         return (dxz, dconv_w.unsqueeze(1), dconv_b if has_conv_b else None, dx_proj_weight, ddelta_proj_weight,
                 dout_proj_weight, dout_proj_bias, dA, None, None, dD if has_D else None,
-                ddelta_bias if has_dbias else None, dB_proj_bias, dC_proj_bias, None, None, None, None, None, None)
+                ddelta_bias if has_dbias else None, dB_proj_bias, dC_proj_bias, None, None, None, None, None, None, None)
 
 
 def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias, A,
                    B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True):
+    wb = _will_backprop(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias, A, B, C, D, delta_bias,
+                        B_proj_bias, C_proj_bias, None)
     return _MambaInner.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
                              out_proj_bias, A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, None, True, 1,
-                             _will_backprop(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias, A, B, C, D, delta_bias,
-                                            B_proj_bias, C_proj_bias, None))
+                             wb, False, _f16s_train(xz, out_proj_weight, wb))
 
 
 def mamba_inner_fn_cond(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
                         A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None,
                         delta_softplus=True, init_states=None, conv_done=False):
+    wb = _will_backprop(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias, A, B, C, D, delta_bias,
+                        B_proj_bias, C_proj_bias, init_states)
     return _MambaInner.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
                              out_proj_bias, A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, init_states,
-                             True, 1, _will_backprop(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias, A, B, C, D, delta_bias,
-                                            B_proj_bias, C_proj_bias, init_states), conv_done)
+                             True, 1, wb, conv_done, _f16s_train(xz, out_proj_weight, wb))
 
 
 def mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B=None, C=None,

@@ -565,6 +565,14 @@ int dimsum_gemm_nt_kernel_for(const dimsum_gemm_params_t *p);
    the caller adds them (a fixed order: bitwise reproducible). m % 256 == 0, n % 256 == 0; epilogue F32 only; the other fields as above. */
 int dimsum_gemm_tn(const dimsum_gemm_params_t *p, int32_t splits, int64_t c_split_stride, void *stream);
 
+/* The weight-gradient shape of the Mamba projections under autograd (selective_scan_interface.py:954-981: "eB,dB->ed" d out_proj.weight,
+   d in_proj.weight = dxz x): one operand is a d-major activation -- A (m, k) float16 rows CONTIGUOUS along the reduction index (channels x tokens,
+   lda) -- the other token-major -- B (k, n) float16 rows OVER the reduction index (ldb): C[s] (m, n) float32 = sum over the rows r of range s of
+   A[0..m, r] B[r, 0..n). Scaled-fp16 images only: a_inv_scale_ptr (m) = A's row scales (its rows are output rows; NULL = 1), ext->k_scale_ptr (k)
+   float16 = B's row scales as per-reduction-row factors (/ their maximum), ext->c_scale_ptr = that maximum; b_inv_scale_ptr NULL. `splits`
+   ranges of k / splits <= 16384 rows, k % (64 splits) == 0; m % 256 == 0, n % 256 == 0; partial results c_split_stride floats apart. */
+int dimsum_gemm_nn(const dimsum_gemm_params_t *p, int32_t splits, int64_t c_split_stride, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

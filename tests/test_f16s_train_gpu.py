@@ -234,3 +234,36 @@ def test_block_combined_1024_fwd_bwd_on_one_product_vs_reference_golden(f16s_tra
         assert e1.max() <= 1.25 * e2.max() + 2e-5 * s and np.sqrt((e1 ** 2).mean()) <= 1.1 * np.sqrt((e2 ** 2).mean()) + 2e-6 * s, key
         worst = max(worst, e1.max() / s)
     print("worst relative-to-max error under the single-product training carrier:", worst)
+
+
+@pytest.mark.parametrize("P,R,Q", [(256, 2048, 256), (2048, 65536, 512), (1024, 16384, 512)])
+def test_mixed_layout_weight_gradient_product_vs_tf32(P, R, Q):
+    """dimsum_gemm_nn: C = A B with A (P, R) rows contiguous along the reduction (a d-major activation: channels x tokens, one scale per channel)
+    and B (R, Q) rows over it (token-major, one scale per token -> per-reduction-row factors): d in_proj.weight = dxz x and d out_proj.weight^T =
+    out_z dout of a Mamba mixer (selective_scan_interface.py:954-981). Against float64, never less accurate than TF32-rounded operands; token
+    magnitudes over 2^-12 .. 1; the long-row image kernel (one workgroup per row) against the per-wave one."""
+    from dimsum_amd import native
+    g = torch.Generator(device="cuda").manual_seed(P + R)
+    a = torch.randn(P, R, device="cuda", generator=g) * torch.exp2(6 * torch.rand(P, 1, device="cuda", generator=g) - 3)
+    b = torch.randn(R, Q, device="cuda", generator=g) * torch.exp2(-12 * torch.rand(R, 1, device="cuda", generator=g))
+    a16, b16 = native.rows_f16s(a), native.rows_f16s(b)
+    if R > 8192:        # the long-row kernel wrote a16: the same image as the generic two-pass kernel on a column slice
+        ref16 = native.rows_f16s(a[:, :4096].contiguous())
+        wide = a.abs().amax(1) == a[:, :4096].abs().amax(1)
+        assert wide.any() and torch.equal(a16.data[wide][:, :4096], ref16.data[wide]) and torch.equal(a16.inv[wide], ref16.inv[wide])
+    got = native.gemm_nn(a16.data, a16.inv, b16.data, b16.inv)
+    assert torch.equal(got, native.gemm_nn(a16.data, a16.inv, b16.data, b16.inv))
+    ref = a.double() @ b.double()
+    tf = _tf32(a).double() @ _tf32(b).double()
+    (em, er), (tm, tr) = _errs(got, ref), _errs(tf.float(), ref)
+    s = ref.abs().max().item()
+    print(f"NN ({P} x {R} x {Q}): f16s {em / s:.2e} / {er / s:.2e}, TF32 operands {tm / s:.2e} / {tr / s:.2e}")
+    assert em <= 1.1 * tm + 2.0 ** -22 * s and er <= 1.1 * tr + 2.0 ** -24 * s
+    # a single live reduction row of every residue class picks a[:, r] b[r, :]
+    for r in (0, 3, 9, 20, 37, 62, 64 + 45, R - 1):
+        az, bz = torch.zeros_like(a), torch.zeros_like(b)
+        az[:, r], bz[r] = a[:, r], b[r]
+        x16, y16 = native.rows_f16s(az), native.rows_f16s(bz)
+        one = native.gemm_nn(x16.data, x16.inv, y16.data, y16.inv)
+        want = torch.outer(az[:, r].double(), bz[r].double())
+        assert (one.double() - want).abs().max().item() <= 2.0 ** -9 * want.abs().max().item(), r

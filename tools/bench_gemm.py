@@ -219,6 +219,8 @@ def main():
     ap.add_argument("--stagger", default="", help="--tiles: also time these start delays of the odd CUs (x 1024 cycles), e.g. 4,8,16 (a library built with -DDIMSUM_GEMM_TUNE: tools/scratch/build_variant.sh)")
     ap.add_argument("--tiles", action="store_true", help="A / B of the 256-row against the 128-row tile variant on the scaled-fp16 launch shapes")
     ap.add_argument("--pmc-run", action="store_true", help="a few launches of the w12-shape kernels (under rocprofv3 --pmc)")
+    ap.add_argument("--pmc-run-f16s", action="store_true", help="a few launches of every scaled-fp16 GEMM launch class of the headline forward (w12 + gate persistent, w3 + gate residual, "
+                                                                 "in_proj + conv, qkv -> fp16, out_proj TN over block-scaled out_z) and of the training TN with row factors (under rocprofv3 --pmc)")
     ap.add_argument("--pmc-run-tn", action="store_true", help="a few launches of the dW12-shape TN kernels (three-piece row stacks, pairs) and of the library's batched TN GEMM")
     args = ap.parse_args()
     ok = True
@@ -242,6 +244,33 @@ def main():
             native.gemm_nt(a, b, epilogue="gated_split3", out=h3)
             native.gemm_nt(a, b, out=c, tune=(2, 8, 0))
             torch.mm(a, b.t(), out_dtype=torch.float32)
+        torch.cuda.synchronize()
+    if args.pmc_run_f16s:
+        M = 65536
+        f16 = lambda shape, seed, scale=1.0: native.rows_f16s(rnd(shape, torch.float32, seed, scale))
+        x1024, x512, h4096 = f16((M, 1024), 1), f16((M, 512), 2), f16((M, 4096), 3)
+        w12, l1 = native.rows_f16s(rnd((8192, 1024), torch.float32, 4, 1024 ** -0.5), want_l1=True)
+        b12 = rnd((8192,), torch.float32, 5, 0.1)
+        bound = torch.cat([l1 * (1 + 2.0 ** -10), b12.abs().max().reshape(1)]).contiguous()
+        w3, win, wqkv = f16((1024, 4096), 6, 4096 ** -0.5), f16((2048, 512), 7, 512 ** -0.5), f16((1536, 512), 8, 512 ** -0.5)
+        wq, lq = native.rows_f16s(rnd((1536, 512), torch.float32, 8, 512 ** -0.5), want_l1=True)
+        bq = rnd((1536,), torch.float32, 9, 0.1)
+        qb = torch.cat([lq * (1 + 2.0 ** -10), bq.abs().max().reshape(1)]).contiguous()
+        res, gate, b3 = rnd((M, 1024), torch.float32, 10), rnd((256, 1024), torch.float32, 11), rnd((1024,), torch.float32, 12)
+        cw, cb = rnd((1024, 4), torch.float32, 13), rnd((1024,), torch.float32, 14)
+        oz = rnd((1024, M), torch.float16, 15, 1000.0)
+        tab = torch.exp2(torch.randint(-20, -10, (M // 32, 16), device="cuda").float())
+        wo_t = f16((512, 1024), 16, 1024 ** -0.5)
+        wot, wo_inv = wo_t.data.t().contiguous(), wo_t.inv
+        dy16, xx16 = f16((M, 8192), 17), x1024
+        fac, cs = native.row_factors(dy16.inv, xx16.inv)
+        for _ in range(3):
+            native.gemm_nt(x1024.data, w12.data, bias=b12, epilogue="gated_f16", scales=(x1024.inv, w12.inv), gate_bound=bound)                                     # w12 + gate (persistent)
+            native.gemm_nt(h4096.data, w3.data, bias=b3, scales=(h4096.inv, w3.inv), residual=res, gate=gate, rows_per_batch=256)                                   # w3 + gate residual
+            native.gemm_nt(win.data, x512.data, scales=(win.inv, x512.inv), conv=(cw, cb, 256))                                                                      # in_proj + conv (m128)
+            native.gemm_nt(x512.data, wq.data, bias=bq, epilogue="f16_qkv", scales=(x512.inv, wq.inv), gate_bound=qb, rows_per_batch=256, q_cols=512)                # qkv -> fp16
+            native.gemm_tn(oz, wot, scales=(tab, wo_inv))                                                                                                            # out_proj TN rebase
+            native.gemm_tn(dy16.data, xx16.data, row_scales=(fac, cs))                                                                                               # training dW12 (row factors)
         torch.cuda.synchronize()
     if args.pmc_run_tn:
         M = 65536
