@@ -316,3 +316,32 @@ extern "C" int dimsum_split3_t(const void *src, int64_t rows, int64_t cols, int6
                        src_row_stride, reinterpret_cast<unsigned short *>(dst));
     return launch_status();
 }
+
+// ---- per-reduction-row factors of a weight-gradient product over two row-scaled images (dimsum_gemm_ext_t.k_scale_ptr) --------------------------------
+// fac[r] = fp16(a_inv[r] b_inv[r] / top), top = max_r a_inv[r] b_inv[r] (b_inv NULL = 1): ONE small launch (a single workgroup: n <= a few 10^5)
+// instead of five torch launches (product, max, divide, cast) in front of every such GEMM -- 160 of them per DiM-L/2 training step.
+namespace dimsum {
+__global__ __launch_bounds__(1024) void row_factors_kernel(const float *a_inv, const float *b_inv, int64_t n, __half *fac, float *top) {
+    __shared__ float red[16];
+    float m = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, a_inv[i] * (b_inv ? b_inv[i] : 1.0f));
+    m = wave_allmax(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = red[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
+    if (threadIdx.x == 0) *top = m;
+    const float r = m > 0.f ? 1.0f / m : 0.f;            // (powers of two: exact; an all-zero pair of operands has factors 0)
+    for (int64_t i = threadIdx.x; i < n; i += 1024) fac[i] = __float2half_rn(a_inv[i] * (b_inv ? b_inv[i] : 1.0f) * r);
+}
+}  // namespace dimsum
+
+extern "C" int dimsum_row_factors(const void *a_inv, const void *b_inv, int64_t n, void *k_scale, void *c_scale, void *stream) {
+    using namespace dimsum;
+    if (!a_inv || !k_scale || !c_scale) return DIMSUM_ERR_NULL;
+    if (n <= 0) return DIMSUM_ERR_SHAPE;
+    hipLaunchKernelGGL(row_factors_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const float *>(a_inv),
+                       reinterpret_cast<const float *>(b_inv), n, reinterpret_cast<__half *>(k_scale), reinterpret_cast<float *>(c_scale));
+    return launch_status();
+}

@@ -710,15 +710,17 @@ def gemm_tn_supported(a, b):
             and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and 128 * max(a.stride(0), b.stride(0)) + 512 < 2 ** 31)
 
 
-def gemm_tn_splits(R, P, Q):
+def gemm_tn_splits(R, P, Q, second_round=True):
     """reduction ranges of a TN launch: enough workgroups to fill the 256 CUs when the output has few tiles (a weight gradient (8192, 1024)
-    is 128 tiles, (1536, 512) is 12), ranges of whole 64-row tiles, at least 2048 rows each"""
+    is 128 tiles, (1536, 512) is 12), ranges of whole 64-row tiles, at least 2048 rows each. second_round=False (the single-product fp16
+    launches: a third of the three-product kernel's time per range, so the partial results' write + sum weigh three times as much): one
+    round of workgroups -- tools/scratch/tn_splits.py: d w12 at 16384 rows 335 -> 297 us, d w3 180 -> 144"""
     tiles = (P // 256) * (Q // 256)
     s = 1
     ok = lambda s2: R % (s2 * 64) == 0 and R // s2 >= 2048
     while tiles * s < 192 and ok(2 * s):         # three quarters of the 256 CUs at least ...
         s *= 2
-    if tiles >= 64 and tiles * s < 512 and ok(2 * s):       # ... and a second round where the partial results are few (tools/scratch/tn_perf.py)
+    if second_round and tiles >= 64 and tiles * s < 512 and ok(2 * s):       # ... and a second round where the partial results are few (tools/scratch/tn_perf.py)
         s *= 2
     return s
 
@@ -751,13 +753,21 @@ def gemm_tn_pairs(a, b, splits=None):
     return out.sum(0)
 
 
-def row_factors(a_inv, b_inv):
+def row_factors(a_inv, b_inv=None):
     """(R,) float32 inverse row scales of two scaled-fp16 images whose ROWS are the reduction index of a product a^T b -> (k_fac (R,) float16,
     c_scale (1,) float32): term r carries a_inv[r] b_inv[r]; k_fac = that / its maximum (powers of two <= 1; below 2^-24: 0), c_scale = the
-    maximum (include/dimsum_hip.h, dimsum_gemm_ext_t.k_scale_ptr)"""
-    f = a_inv * b_inv
-    top = f.max().reshape(1)
-    return (f / top).to(torch.float16), top
+    maximum (include/dimsum_hip.h, dimsum_gemm_ext_t.k_scale_ptr). b_inv None = 1. One small launch (csrc/operand_split.hip)."""
+    _gpu(a_inv, b_inv)
+    a_inv = a_inv.reshape(-1)
+    _check(a_inv.dtype == torch.float32 and a_inv.is_contiguous() and (b_inv is None or (b_inv.dtype == torch.float32 and b_inv.numel() == a_inv.numel())),
+           "row_factors: (R,) float32 inverse scales")
+    if b_inv is not None:
+        b_inv = b_inv.reshape(-1).contiguous()
+    fac = torch.empty(a_inv.numel(), device=a_inv.device, dtype=torch.float16)
+    top = torch.empty(1, device=a_inv.device, dtype=torch.float32)
+    with torch.cuda.device(a_inv.device):
+        _lib.check(_lib.load().dimsum_row_factors(_ptr(a_inv), _ptr(b_inv), a_inv.numel(), _ptr(fac), _ptr(top), _stream(a_inv)), "row_factors")
+    return fac, top
 
 
 def gemm_tn(a, b, splits=None, events=None, alias_rows=0, scales=None, row_scales=None):
@@ -800,7 +810,7 @@ def gemm_tn(a, b, splits=None, events=None, alias_rows=0, scales=None, row_scale
         R, P = a.shape
     Q = b.shape[1]
     if splits is None:
-        splits = gemm_tn_splits(R, P, Q)
+        splits = gemm_tn_splits(R, P, Q, second_round=row_scales is None)
         while row_scales is not None and R // splits > 16384 and R % (2 * splits * 64) == 0:          # (the factors of one range live in 32 KB of LDS)
             splits *= 2
     if row_scales is not None:
@@ -869,12 +879,11 @@ def gemm_nn(a, a_inv, b, b_inv, splits=None):
     P, R = a.shape
     Q = b.shape[1]
     if splits is None:
-        splits = gemm_tn_splits(R, P, Q)
+        splits = gemm_tn_splits(R, P, Q, second_round=False)
         while R // splits > 16384 and R % (2 * splits * 64) == 0:
             splits *= 2
     _check(splits >= 1 and R % (splits * 64) == 0 and 128 <= R // splits <= 16384, "gemm_nn: splits must cut R into ranges of 2 .. 256 whole 64-row tiles")
-    top = b_inv.max().reshape(1)
-    fac = (b_inv / top).to(torch.float16)
+    fac, top = row_factors(b_inv)
     out = torch.empty((splits, P, Q), device=a.device, dtype=torch.float32)
     G = _lib.GemmParams()
     G.m, G.n, G.k = P, Q, R

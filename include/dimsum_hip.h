@@ -572,6 +572,9 @@ int dimsum_gemm_tn(const dimsum_gemm_params_t *p, int32_t splits, int64_t c_spli
    float16 = B's row scales as per-reduction-row factors (/ their maximum), ext->c_scale_ptr = that maximum; b_inv_scale_ptr NULL. `splits`
    ranges of k / splits <= 16384 rows, k % (64 splits) == 0; m % 256 == 0, n % 256 == 0; partial results c_split_stride floats apart. */
 int dimsum_gemm_nn(const dimsum_gemm_params_t *p, int32_t splits, int64_t c_split_stride, void *stream);
+/* the k_scale_ptr / c_scale_ptr operands of the two entry points above from the row scales of the two images: k_scale[r] = float16(a_inv[r] b_inv[r] /
+   c_scale), c_scale = max_r a_inv[r] b_inv[r]; a_inv, b_inv (n) f32 inverse row scales (b_inv NULL = 1), k_scale (n) float16, c_scale 1 f32. One launch. */
+int dimsum_row_factors(const void *a_inv, const void *b_inv, int64_t n, void *k_scale, void *c_scale, void *stream);
 
 #ifdef __cplusplus
 }
