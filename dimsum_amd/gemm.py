@@ -301,19 +301,18 @@ class _MatmulWxF16sFn(torch.autograd.Function):
         from . import native
         x16 = native.rows_f16s(x2)
         w16 = weight_f16s_train(weight)
-        ctx.save_for_backward(weight, x16.data, x16.inv)
+        ctx.save_for_backward(w16.data, w16.inv, x16.data, x16.inv)
         return native.gemm_nt(w16.data, x16.data, scales=(w16.inv, x16.inv))
 
     @staticmethod
     def backward(ctx, dy):
         from . import native
-        weight, xd, xi = ctx.saved_tensors
+        wd, wi, xd, xi = ctx.saved_tensors
         dy16 = native.rows_f16s(dy.contiguous())                 # (N, M): one scale per channel
         dw = native.gemm_nn(dy16.data, dy16.inv, xd, xi) if ctx.needs_input_grad[0] else None
         dx = None
         if ctx.needs_input_grad[1]:
-            w16 = weight_f16s_train(weight)
-            dx = native.gemm_tn(dy16.data, w16.data, row_scales=native.row_factors(dy16.inv, w16.inv))
+            dx = native.gemm_tn(dy16.data, wd, row_scales=native.row_factors(dy16.inv, wi))
         return dw, dx
 
 
@@ -688,6 +687,17 @@ def nt_f16s_any(a, b):
     return torch.mm(a.data, b.data.t(), out_dtype=torch.float32) * a.inv.reshape(-1)[:, None] * b.inv[None, :]
 
 
+def dx_f16s(dy16, w16):
+    """dx (M, K) = dy (M, N) W (N, K) from the image of dy (one scale per token) and THE FORWARD'S image of W (one scale per output feature n --
+    the reduction index here): the mixed-layout kernel (native.gemm_nn: dy's rows run along the reduction, W's over it, W's scales travel as
+    per-reduction-row factors) -- no transposed weight image, no second conversion of the weight"""
+    from . import native
+    a = dy16.data.reshape(-1, dy16.data.shape[-1])
+    if own_gemm_enabled() and native.gemm_nn_supported(a, w16.data) and w16.data.shape[0] <= 16384:
+        return native.gemm_nn(a, dy16.inv.reshape(-1).contiguous(), w16.data, w16.inv)
+    return torch.mm(a.float() * dy16.inv.reshape(-1)[:, None], w16.data.float() * w16.inv[:, None])
+
+
 def dw_f16s(dy16, x16):
     """dW = dy^T x (N, K) float32 from two scaled-fp16 images whose rows (tokens) are the reduction index: the TN kernel with per-reduction-row
     factors (native.gemm_tn(row_scales=...)) -- ONE fp16 product per element -- else the library on the decoded rows"""
@@ -701,29 +711,30 @@ def dw_f16s(dy16, x16):
 
 class _LinearF16sFn(torch.autograd.Function):
     """y = x W^T under autograd with all three GEMMs (y, dx, dW) as ONE fp16 product per element over scaled-fp16 images (policy "f16s"; the
-    reference's TF32 training arithmetic, dimsum/train.py:20-21: 10-bit operand mantissas, fp32 accumulation): x and dy are converted once each
-    (row scales = exact row maxima); y = x16 W16^T and dx = dy16 (W^T)16^T are NT products whose epilogue undoes the row scales, dW = dy16^T x16
-    reduces over the rows, so the row scales become per-reduction-row factors inside the TN kernel (dw_f16s)."""
+    reference's TF32 training arithmetic, dimsum/train.py:20-21: 10-bit operand mantissas, fp32 accumulation): x, W and dy are converted once each
+    (row scales = exact row maxima); y = x16 W16^T is an NT product whose epilogue undoes the row scales; dx = dy16 W16 reduces over W's rows
+    (gemm_nn: W's row scales as per-reduction-row factors), dW = dy16^T x16 over the tokens (gemm_tn: both operands' row scales as factors)."""
 
     @staticmethod
     def forward(ctx, x, weight):
         from . import native
         K = x.shape[-1]
         x16 = native.rows_f16s(x.reshape(-1, K))
-        ctx.save_for_backward(x16.data, x16.inv, weight)
+        w16 = weight_f16s_train(weight)
+        ctx.save_for_backward(x16.data, x16.inv, w16.data, w16.inv)          # (the weight's image serves the backward too: half the weight's bytes)
         ctx.x_shape = x.shape
-        return nt_f16s_any(x16, weight_f16s_train(weight)).view(*x.shape[:-1], weight.shape[0])
+        return nt_f16s_any(x16, w16).view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
         from . import native
-        xd, xi, weight = ctx.saved_tensors
-        N, K = weight.shape
+        xd, xi, wd, wi = ctx.saved_tensors
+        N = wd.shape[0]
         M = xd.shape[0]
         dy16 = native.rows_f16s(dy.reshape(M, N).contiguous())
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = nt_f16s_any(dy16, weight_t_f16s_train(weight)).view(ctx.x_shape)
+            dx = dx_f16s(dy16, native.F16Image(wd, wi)).view(ctx.x_shape)
         if ctx.needs_input_grad[1]:
             dw = dw_f16s(dy16, native.F16Image(xd, xi))
         return dx, dw

@@ -102,8 +102,9 @@ class _ModGatedMlpF16sFn(torch.autograd.Function):
     "f16s", gemm.py; the reference trains under TF32 as well, dimsum/train.py:20-21):
         forward : h16 = image(modulate(normed))  [token_transform y_split3 = 2]     g16, x12 = gate epilogue of h16 . W12_16^T (row scale of g from the
                   epilogue's bound, x12 kept in fp32 for the adjoint)               m = g16 . W3_16^T
-        backward: dm16 = image(dm)                dg = dm16 . (W3^T)16^T            dW3 = dm16^T g16   [TN, per-reduction-row factors]
-                  dx12_16 = image(gated GeLU adjoint)  [one pass, exact row maxima]  dh = dx12_16 . (W12^T)16^T     dW12 = dx12_16^T h16
+        backward: dm16 = image(dm)                dg = dm16 . W3_16                 dW3 = dm16^T g16   [TN, per-reduction-row factors]
+                  dx12_16 = image(gated GeLU adjoint)  [one pass, exact row maxima]  dh = dx12_16 . W12_16          dW12 = dx12_16^T h16
+                  (dg / dh: gemm.dx_f16s -- the forward's weight images again, reduced over their rows: no transposed weight image)
     Six products, each a third of the three-product carrier's MFMA work; the images are 2 bytes per element instead of 4 (pairs) / 6."""
 
     @staticmethod
@@ -116,22 +117,24 @@ class _ModGatedMlpF16sFn(torch.autograd.Function):
         w12_16, l1 = gemm.weight_f16s_train(w12, want_l1=True)
         bound = torch.cat([l1 * gemm._K10, gemm._absmax(b12f, w12)]).contiguous()
         g16, x12 = native.gemm_nt(h16.data.view(M, H), w12_16.data, bias=b12f, epilogue="gated_f16", scales=(h16.inv.view(M), w12_16.inv), gate_bound=bound, keep_x12=True)
-        m = gemm.nt_f16s_any(g16, gemm.weight_f16s_train(w3))
-        ctx.save_for_backward(normed, scale, h16.data, h16.inv, x12, g16.data, g16.inv, w12, b12f, w3)
+        w3_16 = gemm.weight_f16s_train(w3)
+        m = gemm.nt_f16s_any(g16, w3_16)
+        # (the weights' forward images serve the backward's input-gradient products too: gemm.dx_f16s reduces over their rows)
+        ctx.save_for_backward(normed, scale, h16.data, h16.inv, x12, g16.data, g16.inv, w12_16.data, w12_16.inv, b12f, w3_16.data, w3_16.inv)
         return m.view(B, L, w3.shape[0])
 
     @staticmethod
     def backward(ctx, dm):
-        normed, scale, hd, hi, x12, gd, gi, w12, b12f, w3 = ctx.saved_tensors
+        normed, scale, hd, hi, x12, gd, gi, w12d, w12i, b12f, w3d, w3i = ctx.saved_tensors
         B, L, H = normed.shape
         M = B * L
-        Ho = w3.shape[0]
+        Ho = w3d.shape[0]
         F16 = native.F16Image
         dm16 = native.rows_f16s(dm.reshape(M, Ho).contiguous())
-        dg = gemm.nt_f16s_any(dm16, gemm.weight_t_f16s_train(w3))                                            # (M, F)
+        dg = gemm.dx_f16s(dm16, F16(w3d, w3i))                                                                # (M, F)
         dw3 = gemm.dw_f16s(dm16, F16(gd, gi)) if ctx.needs_input_grad[5] else None                            # (Ho, F)
         dx12_16, db12 = native.gated_gelu_bwd(x12, b12f, dg, need_dbias=b12f is not None and ctx.needs_input_grad[4], split3="f16s")
-        dh = gemm.nt_f16s_any(dx12_16, gemm.weight_t_f16s_train(w12)).view(B, L, H)                            # (M, H)
+        dh = gemm.dx_f16s(dx12_16, F16(w12d, w12i)).view(B, L, H)                                              # (M, H)
         dw12 = gemm.dw_f16s(dx12_16, F16(hd, hi)) if ctx.needs_input_grad[3] else None                        # (2F, H)
         dnormed = dshift = dscale = None
         if ctx.needs_input_grad[0] and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):

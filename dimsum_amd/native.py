@@ -261,8 +261,10 @@ def causal_conv1d_bwd(x, weight, bias, dout, dx, silu_activation):
         _check(dx.shape == x.shape and dx.dtype == x.dtype and dx.stride(2) == 1, "causal_conv1d_bwd: bad dx")
     w32 = weight.float()
     b32 = bias.float().contiguous() if bias is not None else None
-    dweight = torch.zeros(weight.shape, device=x.device, dtype=torch.float32)   # fp32 accumulate, then cast (cpp:405-425)
-    dbias = torch.zeros(weight.shape[0], device=x.device, dtype=torch.float32) if bias is not None else None
+    # fp32 accumulate, then cast (cpp:405-425); ONE zero-filled buffer for both accumulators (one fill launch instead of two)
+    acc = torch.zeros(weight.numel() + (weight.shape[0] if bias is not None else 0), device=x.device, dtype=torch.float32)
+    dweight = acc[:weight.numel()].view(weight.shape)
+    dbias = acc[weight.numel():] if bias is not None else None
     if x.numel() > 0:
         Q = _lib.ConvBwdParams()
         _fill_conv(Q.fwd, x, w32, b32, silu_activation, None)
@@ -353,8 +355,9 @@ def layer_norm_bwd(dy, x, weight, bias, eps, mean, rstd, dresidual=None, has_res
     dyf = dy if dy.dtype == torch.float32 else dy.float()
     drf = None if dresidual is None else (dresidual if dresidual.dtype == torch.float32 else dresidual.float())
     dx32 = torch.empty((M, N), device=x.device, dtype=torch.float32)
-    dw = torch.zeros((N,), device=x.device, dtype=torch.float32)
-    db = torch.zeros((N,), device=x.device, dtype=torch.float32) if bias is not None else None
+    acc = torch.zeros((2 * N if bias is not None else N,), device=x.device, dtype=torch.float32)        # (one fill for both accumulators)
+    dw = acc[:N]
+    db = acc[N:] if bias is not None else None
     if M > 0:
         P = _lib.NormBwdParams()
         P.rows, P.cols, P.is_rms_norm, P.eps = M, N, int(is_rms_norm), float(eps)
@@ -394,11 +397,14 @@ def selective_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, dz, de
     out_z = torch.empty_like(out) if (has_z and recompute_out_z) else None
     du = torch.empty_like(u)
     ddelta = torch.empty_like(delta)
-    dA = torch.zeros_like(A)
+    # the three zero-filled fp32 accumulators (selective_scan.cpp:458-466) out of ONE buffer: one fill launch instead of three
+    nA, nD = A.numel(), (dim if D is not None else 0)
+    acc = torch.zeros(nA + nD + (dim if delta_bias is not None else 0), device=u.device, dtype=torch.float32)
+    dA = acc[:nA].view(A.shape)
     dB = torch.empty(B.shape, device=u.device, dtype=torch.float32)      # fp32 then cast (cpp:461-462,488)
     dC = torch.empty(C.shape, device=u.device, dtype=torch.float32)
-    dD = torch.zeros_like(D) if D is not None else None
-    ddelta_bias = torch.zeros_like(delta_bias) if delta_bias is not None else None
+    dD = acc[nA:nA + nD] if D is not None else None
+    ddelta_bias = acc[nA + nD:] if delta_bias is not None else None
     if u.numel() > 0:
         Q = _lib.SsmBwdParams()
         if ckpt is not None:

@@ -219,11 +219,11 @@ class _MambaInner(torch.autograd.Function):
             wt16 = gemm.weight_t_f16s_train(out_proj_weight)
             y = native.gemm_tn(oz16.data, wt16.data, row_scales=native.row_factors(oz16.inv, wt16.inv))
             ctx.save_for_backward(xz, conv_w, conv_b, x_dbl, x_proj_weight, delta_proj_weight, out_proj_weight, conv_out, delta, A, Bm, Cm, D, delta_bias,
-                                  scan_x, out, ckpt, None, oz16.data, oz16.inv)
+                                  scan_x, out, ckpt, None, oz16.data, oz16.inv, wt16.data, wt16.inv)
             return y.view(bsz, L, out_proj_weight.shape[0])
         ctx.save_for_backward(xz, conv_w, conv_b, x_dbl, x_proj_weight, delta_proj_weight,
                               out_proj_weight if has_out_proj else None, conv_out, delta, A, Bm, Cm, D, delta_bias, scan_x, out, ckpt,
-                              out_z if keep_out_z else None, None, None)
+                              out_z if keep_out_z else None, None, None, None, None)
         if not has_out_proj:
             return out_z                                                                                # (b, d, l)
         if out_proj_bias is None:
@@ -234,7 +234,7 @@ class _MambaInner(torch.autograd.Function):
     @custom_bwd(device_type="cuda")
     def backward(ctx, dout):
         (xz, conv_w, conv_b, x_dbl, x_proj_weight, delta_proj_weight, out_proj_weight, conv_out, delta, A, Bm, Cm, D,
-         delta_bias, scan_x, out, ckpt, kept_out_z, oz16_data, oz16_inv) = ctx.saved_tensors
+         delta_bias, scan_x, out, ckpt, kept_out_z, oz16_data, oz16_inv, wt16_data, wt16_inv) = ctx.saved_tensors
         has_conv_b, has_D, has_dbias, has_Bb, has_Cb, has_ob = ctx.flags
         L = xz.shape[-1]
         R = delta_proj_weight.shape[1]
@@ -251,8 +251,7 @@ class _MambaInner(torch.autograd.Function):
         if ctx.f16s:
             # dout_y (d, b l) = W_out^T dout^T as an NT product of the images of W_out^T (one scale per channel = output row) and dout (one per token)
             dout16 = native.rows_f16s(dout.reshape(bsz * L, -1))
-            wt16 = gemm.weight_t_f16s_train(out_proj_weight)
-            dout_y = native.gemm_nt(wt16.data, dout16.data, scales=(wt16.inv, dout16.inv)).view(d_inner, bsz, L).permute(1, 0, 2)
+            dout_y = native.gemm_nt(wt16_data, dout16.data, scales=(wt16_inv, dout16.inv)).view(d_inner, bsz, L).permute(1, 0, 2)
         elif ctx.has_out_proj:
             dout2 = dout.reshape(bsz * L, -1).t()                                                       # "b l e -> e (b l)"
             dout_y = (out_proj_weight.t() @ dout2).view(d_inner, bsz, L).permute(1, 0, 2)               # d-major like delta
