@@ -449,14 +449,26 @@ def forward_scope(model, rows):
             or rows < int(os.environ.get("DIMSUM_SPLIT3_MIN_ROWS", "8192")) or os.environ.get("DIMSUM_FORWARD_SCOPE", "1") == "0"):
         yield
         return
-    plan = getattr(model, "_f16s_plan", None)
-    if plan is None:
-        plan = model._f16s_plan = f16s_plan(model)
+    # the plan is cached on the model, keyed by the identity of its parameters: a Linear swapped (or re-created) after the first forward rebuilds it
+    ident = tuple(id(p_) for p_ in model.parameters())
+    cached = model.__dict__.get("_f16s_plan")
+    if cached is None or cached[0] != ident:
+        cached = model.__dict__["_f16s_plan"] = (ident, f16s_plan(model))
+    plan = cached[1]
+
+    def src_ok(t):          # what dimsum_rows_f16s_multi takes as a job's source: fp32 rows, 16-byte aligned, lengths / strides % 4
+        if t is None:
+            return True
+        t2 = t if t.dim() == 2 else t.reshape(1, -1)
+        return (t.is_cuda and t.dtype == torch.float32 and t2.stride(1) == 1 and t2.shape[1] % 4 == 0 and (t2.shape[0] == 1 or t2.stride(0) % 4 == 0)
+                and t.data_ptr() % 16 == 0)
     jobs, slot = [], 0
     tbufs = {}                      # "plain_t": weight shape -> job indices
     layout = []                     # per plan entry: (first job index, slot of its l1 [, ...])
     for w, kind, bias, partner in plan:
-        ok = w.dtype == torch.float32 and w.is_cuda and w.stride(1) == 1 and w.shape[1] % 4 == 0 and w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0
+        # every source of the entry's jobs is validated up front (the weight, its bias, the partner qkv Linear's weight and bias): an entry
+        # with anything the multi-job kernel does not take drops to the lazy per-weight path instead of failing the whole forward
+        ok = src_ok(w) and src_ok(bias) and (partner is None or (src_ok(partner.weight) and src_ok(partner.bias)))
         if not ok:
             layout.append(None)
             continue
@@ -492,7 +504,7 @@ def forward_scope(model, rows):
             jobs[j] = jobs[j][:5] + ((data[n], inv[n]),)
             tdata[j] = (shape, n)
         tbufs[shape] = (data, inv)
-    images, scal = native.rows_f16s_multi(jobs)
+    images, scal = native.rows_f16s_multi(jobs, n_slots=slot)      # (every entry's slots exist, also a trailing bias-free one's)
     tbufs = {shape: (data.transpose(1, 2).contiguous(), inv) for shape, (data, inv) in tbufs.items()}
     cache = {}
     key = lambda kind, w: (kind, w.data_ptr(), tuple(w.shape), tuple(w.stride()), w.dtype)

@@ -637,7 +637,7 @@ def rows_f16s(x, want_l1=False):
     return (img, l1) if want_l1 else img
 
 
-def rows_f16s_multi(jobs):
+def rows_f16s_multi(jobs, n_slots=None):
     """ONE launch per 24 jobs (csrc/operand_split.hip, dimsum_rows_f16s_multi). jobs: list of (x, image, l1_slot, absmax_slot, l1_factor):
     x (R, K) float32 rows (or a (K,) vector: one row); image: build the F16Image; l1_slot / absmax_slot: index into the returned float32
     scalar buffer that receives l1_factor * max_r sum_k |x_rk| / max |x| (None: not wanted; several jobs may NOT share a slot's meaning but
@@ -646,7 +646,8 @@ def rows_f16s_multi(jobs):
     if not jobs:
         return [], None
     dev = jobs[0][0].device
-    n_slots = 1 + max([-1] + [s_ for j in jobs for s_ in j[2:4] if s_ is not None])
+    used = 1 + max([-1] + [s_ for j in jobs for s_ in j[2:4] if s_ is not None])
+    n_slots = used if n_slots is None else max(int(n_slots), used)        # (a caller that slices the scalars by its own slot layout passes its total)
     scal = torch.zeros(max(n_slots, 1), device=dev, dtype=torch.float32)
     arr = (_lib.F16sJob * len(jobs))()
     images, keep = [], []

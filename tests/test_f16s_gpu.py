@@ -390,7 +390,7 @@ def test_forward_scope_changes_launch_counts_not_bits(monkeypatch):
     singles, multis = [], []
     real1, realm = native.rows_f16s, native.rows_f16s_multi
     monkeypatch.setattr(native, "rows_f16s", lambda *a, **k: (singles.append(1), real1(*a, **k))[1])
-    monkeypatch.setattr(native, "rows_f16s_multi", lambda jobs: (multis.append(len(jobs)), realm(jobs))[1])
+    monkeypatch.setattr(native, "rows_f16s_multi", lambda jobs, **k: (multis.append(len(jobs)), realm(jobs, **k))[1])
     monkeypatch.setattr(torch.backends.cuda.matmul, "allow_tf32", True)
     gemm.set_policy("f16s")
     try:
@@ -409,6 +409,26 @@ def test_forward_scope_changes_launch_counts_not_bits(monkeypatch):
             assert len(multis) == 2 and not torch.equal(changed, ref)
             w.data.div_(1.5)
             assert torch.equal(m(x, t, y), ref)
+            # fallbacks (what the multi-job kernel does not take drops to the lazy per-weight path, never an error): a swapped Linear is seen (the plan
+            # is keyed by the parameters' identity); a bias-free trailing gated entry still finds its slots
+            old_lin = m.blocks[2].mlp.w3
+            new_lin = torch.nn.Linear(old_lin.in_features, old_lin.out_features, bias=True).cuda()
+            with torch.no_grad():
+                new_lin.weight.copy_(old_lin.weight * 0.5)
+                new_lin.bias.copy_(old_lin.bias)
+            m.blocks[2].mlp.w3 = new_lin
+            swapped = m(x, t, y)
+            assert not torch.equal(swapped, ref)
+            m.blocks[2].mlp.w3 = old_lin
+            assert torch.equal(m(x, t, y), ref)
+            last = m.blocks[-1].mlp.w12
+            keep = last.bias
+            last.bias = None
+            no_bias = m(x, t, y)                                # (a gated entry without its bias job: the bound tensor must still be two slots long)
+            monkeypatch.setenv("DIMSUM_FORWARD_SCOPE", "0")
+            assert torch.equal(no_bias, m(x, t, y))
+            monkeypatch.delenv("DIMSUM_FORWARD_SCOPE")
+            last.bias = keep
     finally:
         gemm.set_policy("default")
 

@@ -1,3 +1,4 @@
+# tools/profile_train.sh (GPU box): rocprofv3 kernel-trace + stats of the block_fwdbwd and train_step legs on one stream -> gpurun_out/now_{block,train}_kernel_stats.csv
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export DIMSUM_BRANCH_STREAMS=0
 for mode in block train; do
