@@ -51,4 +51,15 @@ __device__ __forceinline__ void split_c2(const f4 &t0, const f4 &t1, u4v &hi, u4
     split2(t1[2], t1[3], hi.w[3], lo.w[3]);
 }
 
+// XCD-aware block order. The blocks of one (batch, head, direction) -- its `per_group` query (or key) blocks -- read the same K / V (Q / dO):
+// 2 x L x hd values, 64 KB as fp16 at DiM-L/2, 288 KB at XL/2-512. The dispatcher hands block i to XCD i % 8, so consecutive block ids
+// fetch that data into `per_group` different L2s (the fp16 forward at DiM-L/2: 0.81 GB from HBM per launch for 0.54 GB of distinct bytes;
+// at XL/2-512, 8 blocks per group: 2.7 GB for 0.6). Block 8 j + x takes work item ((j / per_group) 8 + x) per_group + j % per_group: one
+// XCD runs all blocks of a group back to back and the re-reads hit its L2. A bijection when the number of groups is a multiple of 8.
+__device__ __forceinline__ int xcd_group_blocks(int idx, int nblocks, int per_group) {
+    if (((nblocks / per_group) & 7) != 0 || nblocks % per_group != 0) return idx;
+    const int x = idx & 7, j = idx >> 3;
+    return ((j / per_group) * 8 + x) * per_group + (j % per_group);
+}
+
 }  // namespace dimsum

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void xattn_fusion_fwd_kernel(const dimsum_xatt
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = p.seqlen, H = p.heads;
     const int qblocks = (L + 63) / 64;
-    int idx = blockIdx.x;
+    int idx = xcd_group_blocks(blockIdx.x, (int)gridDim.x, qblocks);      // (xattn_common.hpp: a group's blocks on ONE XCD)
     const int qb = idx % qblocks; idx /= qblocks;
     const int ndir = p.n_dirs == 1 ? 1 : 2;
     const int dir = idx % ndir; idx /= ndir;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256, (QT == 2 && HD <= 64) ? 3 : (QT == 2 ? 2 : 1))
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = p.seqlen, H = p.heads;
     const int qblocks = (L + 64 * QT - 1) / (64 * QT);
-    int idx = blockIdx.x;
+    int idx = xcd_group_blocks(blockIdx.x, (int)gridDim.x, qblocks);      // (xattn_common.hpp: a group's blocks on ONE XCD)
     const int qb = idx % qblocks; idx /= qblocks;
     const int ndir = p.n_dirs == 1 ? 1 : 2;
     const int dir = idx % ndir; idx /= ndir;

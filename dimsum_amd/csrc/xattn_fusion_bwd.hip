@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void xattn_bwd_dq_kernel(const dimsum_xattn_bw
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = p.fwd.seqlen, H = p.fwd.heads;
     const int qblocks = (L + 63) / 64;
-    int idx = blockIdx.x;
+    int idx = xcd_group_blocks(blockIdx.x, (int)gridDim.x, qblocks);      // (xattn_common.hpp: a group's blocks on ONE XCD)
     const int qblk = idx % qblocks; idx /= qblocks;
     const int ndir = p.fwd.n_dirs == 1 ? 1 : 2;
     const int dir = idx % ndir; idx /= ndir;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void xattn_bwd_dkv_kernel(const dimsum_xattn_b
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = p.fwd.seqlen, H = p.fwd.heads;
     const int kblocks = (L + 63) / 64;
-    int idx = blockIdx.x;
+    int idx = xcd_group_blocks(blockIdx.x, (int)gridDim.x, kblocks);      // (xattn_common.hpp: a group's blocks on ONE XCD)
     const int kblk = idx % kblocks; idx /= kblocks;
     const int ndir = p.fwd.n_dirs == 1 ? 1 : 2;
     const int dir = idx % ndir; idx /= ndir;
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(kSQW / QT * 4, (QT == 1 && HD <= 64) ? 4 : 2) void 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = p.fwd.seqlen, H = p.fwd.heads;
     const int qblocks = (L + kSQW - 1) / kSQW;
-    int idx = blockIdx.x;
+    int idx = xcd_group_blocks(blockIdx.x, (int)gridDim.x, qblocks);      // (xattn_common.hpp: a group's blocks on ONE XCD)
     const int qblk = idx % qblocks; idx /= qblocks;
     const int ndir = p.fwd.n_dirs == 1 ? 1 : 2;
     const int dir = idx % ndir; idx /= ndir;
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256, (HD > 64 || KT == 2) ? 2 : 3) void xattn_bwd_d
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = p.fwd.seqlen, H = p.fwd.heads;
     const int kblocks = (L + 64 * KT - 1) / (64 * KT);
-    int idx = blockIdx.x;
+    int idx = xcd_group_blocks(blockIdx.x, (int)gridDim.x, kblocks);      // (xattn_common.hpp: a group's blocks on ONE XCD)
     const int kblk = idx % kblocks; idx /= kblocks;
     const int ndir = p.fwd.n_dirs == 1 ? 1 : 2;
     const int dir = idx % ndir; idx /= ndir;

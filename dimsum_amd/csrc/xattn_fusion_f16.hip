@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256, (QT == 2 && HD <= 64) ? 3 : 2) void xattn_fusi
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = p.seqlen, H = p.heads;
     const int qblocks = (L + 64 * QT - 1) / (64 * QT);
-    int idx = blockIdx.x;
+    int idx = xcd_group_blocks(blockIdx.x, (int)gridDim.x, qblocks);          // (xattn_common.hpp: a group's q-blocks on ONE XCD: K / V re-reads hit its L2)
     const int qb = idx % qblocks; idx /= qblocks;
     const int ndir = p.n_dirs == 1 ? 1 : 2;
     const int dir = idx % ndir; idx /= ndir;
@@ -153,6 +153,11 @@ __global__ __launch_bounds__(256, (QT == 2 && HD <= 64) ? 3 : 2) void xattn_fusi
 
     constexpr int kItems = (kKT16 / 2) * (HD / 4), kIters = (kItems + 255) / 256;
     constexpr int kItems16 = (kKT16 / 2) * (HD / 8), kIters16 = (kItems16 + 255) / 256;
+    // (Round 6, measured and NOT kept: requesting the next key tile's K / V pieces before the current tile is computed -- register-staged double
+    // buffering, +16 VGPRs per staging iteration -- changed nothing at head_dim 64 (0.170 ms either way) and cost head_dim 72 its third wave per
+    // SIMD (0.63 -> 0.66 ms): with 3 workgroups per CU the loads are hidden already. Counters (profiles/r06_xattn_f16_fwd_pmc.txt): VALU busy 0.60
+    // + MFMA busy 0.18 with little overlap -- the softmax's v_exp_f32 (quarter rate) and its 100 VALU instructions per 16 x 64 score tile bound
+    // the kernel, not memory: the XCD-aware block order above cut its HBM traffic from 0.81 to 0.54 GB per launch at the same duration.)
     for (int k0 = 0; k0 < L; k0 += kKT16) {
         __syncthreads();
         if constexpr (kIn16) {

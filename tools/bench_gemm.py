@@ -264,6 +264,7 @@ def main():
         wot, wo_inv = wo_t.data.t().contiguous(), wo_t.inv
         dy16, xx16 = f16((M, 8192), 17), x1024
         fac, cs = native.row_factors(dy16.inv, xx16.inv)
+        dxz16 = native.rows_f16s(rnd((2048, M), torch.float32, 18))                                   # a d-major gradient: one scale per channel (long-row image kernel)
         for _ in range(3):
             native.gemm_nt(x1024.data, w12.data, bias=b12, epilogue="gated_f16", scales=(x1024.inv, w12.inv), gate_bound=bound)                                     # w12 + gate (persistent)
             native.gemm_nt(h4096.data, w3.data, bias=b3, scales=(h4096.inv, w3.inv), residual=res, gate=gate, rows_per_batch=256)                                   # w3 + gate residual
@@ -271,6 +272,7 @@ def main():
             native.gemm_nt(x512.data, wq.data, bias=bq, epilogue="f16_qkv", scales=(x512.inv, wq.inv), gate_bound=qb, rows_per_batch=256, q_cols=512)                # qkv -> fp16
             native.gemm_tn(oz, wot, scales=(tab, wo_inv))                                                                                                            # out_proj TN rebase
             native.gemm_tn(dy16.data, xx16.data, row_scales=(fac, cs))                                                                                               # training dW12 (row factors)
+            native.gemm_nn(dxz16.data, dxz16.inv, x512.data, x512.inv)                                                                                               # training d in_proj.weight (mixed layout)
         torch.cuda.synchronize()
     if args.pmc_run_tn:
         M = 65536

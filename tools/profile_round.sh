@@ -29,6 +29,7 @@ stats fwd --mode fwd --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg --no-b
 stats fwd_tf32 --mode fwd --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg --no-box-probe --matmul tf32
 stats block --mode block --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg --no-box-probe
 stats xl512 --mode xl512 --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg --no-box-probe
+stats train --mode train --batch 64 --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg --no-box-probe
 unset DIMSUM_BRANCH_STREAMS
 stats all --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg --no-box-probe --nfe 10
 # PMC: forward as the headline runs it (inference: no out / x stores, dt_proj fused), the same without the fusion, the full reference
@@ -48,10 +49,10 @@ bash tools/pmc_scan.sh $out/pmc_fwd_inf_b128 --dmajor --dt-fused --B 128 > $out/
 bash tools/pmc_scan.sh $out/pmc_fwd_xl --dmajor --B 64 --D 1152 --L 1024 > $out/${tag}_scan_fwd_xl512_pmc.txt 2>&1
 bash tools/pmc_scan.sh $out/pmc_fwd_xl_inf --dmajor --infer --B 64 --D 1152 --L 1024 > $out/${tag}_scan_fwd_xl512_infer_pmc.txt 2>&1
 bash tools/pmc_scan.sh $out/pmc_fwd_stress --dmajor --B 16 --D 1152 --L 4096 > $out/${tag}_scan_fwd_stress_pmc.txt 2>&1
-timeout 600 bash tools/scratch/gemm_pmc.sh $tag > /dev/null 2>&1; cp gpurun_out/gemm/pmc_${tag}.txt $out/${tag}_gemm_gated_pmc.txt; rm -rf gpurun_out/gemm/pmc_${tag}
+# the scaled-fp16 GEMM launch classes of the headline forward + the training TN / NN with row factors, and the fp16 attention forward (round 6)
+timeout 900 bash tools/pmc_gemm_f16s.sh $out/${tag}_gemm_f16s_pmc.txt > /dev/null 2>&1; mv $out/${tag}_gemm_f16s_pmc.txt.xattn $out/${tag}_xattn_f16_fwd_pmc.txt
 timeout 300 python3 tools/bench_gemm.py --perf --rounds 5 2>/dev/null | grep -v amdgpu > $out/${tag}_gemm_perf.jsonl
 timeout 300 python3 tools/bench_gemm.py --tiles --rounds 5 2>/dev/null | grep -v amdgpu > $out/${tag}_gemm_tiles.jsonl
-bash tools/scratch/xattn_pmc.sh fwd > $out/${tag}_xattn_fwd_pmc.txt 2>&1
-bash tools/scratch/xattn_pmc.sh bwd > $out/${tag}_xattn_bwd_pmc.txt 2>&1
+bash tools/scratch/xattn_pmc.sh bwd > $out/${tag}_xattn_bwd_pmc.txt 2>&1      # (the training backward pair: split-bf16 kernels)
 rm -rf $out/pmc_*     # raw csv trees: only the summaries travel back
 ls -la $out
