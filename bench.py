@@ -731,6 +731,9 @@ def main():
                 for long_key in ("pricing", "timed_in"):
                     if long_key in rf:
                         notes[f"{k}.{long_key}"] = rf.pop(long_key)
+                if isinstance(rf.get("valu"), dict) and "what" in rf["valu"]:
+                    rf["valu"] = dict(rf["valu"])
+                    notes["roofline.valu.what"] = rf["valu"].pop("what")
                 line[k] = rf
         if world == 1 and not args.no_cpu_baseline and args.mode in ("all", "fwd", "sample"):
             cb = cpu_baseline(args.model, 4, args.image_size)
