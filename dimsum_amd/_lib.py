@@ -146,7 +146,7 @@ EXPORTS = (
     "dimsum_causal_conv1d_fwd", "dimsum_causal_conv1d_bwd",
     "dimsum_norm_fwd", "dimsum_norm_bwd", "dimsum_token_transform", "dimsum_xattn_fusion_fwd", "dimsum_xattn_fusion_bwd",
     "dimsum_gated_gelu_fwd", "dimsum_gated_gelu_bwd", "dimsum_gated_gelu_fwd_split3", "dimsum_gated_gelu_bwd_split3", "dimsum_gated_gelu_bwd_pair", "dimsum_gated_gelu_bwd_f16s", "dimsum_split3", "dimsum_split3_t",
-    "dimsum_gemm_nt", "dimsum_gemm_nt_kernel_for", "dimsum_gemm_tn", "dimsum_gemm_nn", "dimsum_row_factors", "dimsum_rows_f16s", "dimsum_rows_f16s_multi",
+    "dimsum_gemm_nt", "dimsum_gemm_nt_kernel_for", "dimsum_gemm_tn", "dimsum_gemm_nn", "dimsum_row_factors", "dimsum_rows_block_f16s", "dimsum_rows_f16s", "dimsum_rows_f16s_multi",
 )
 
 _lib = None
@@ -193,6 +193,9 @@ def load():
     if hasattr(lib, "dimsum_gemm_tn"):
         lib.dimsum_gemm_tn.restype = C.c_int
         lib.dimsum_gemm_tn.argtypes = [C.POINTER(GemmParams), i32, i64, vp]
+    if hasattr(lib, "dimsum_rows_block_f16s"):
+        lib.dimsum_rows_block_f16s.restype = C.c_int
+        lib.dimsum_rows_block_f16s.argtypes = [vp, i64, i64, i64, vp, i64, vp, i64, vp]
     if hasattr(lib, "dimsum_row_factors"):
         lib.dimsum_row_factors.restype = C.c_int
         lib.dimsum_row_factors.argtypes = [vp, vp, i64, vp, vp, vp]

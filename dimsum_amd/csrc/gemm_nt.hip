@@ -281,8 +281,10 @@ extern "C" int dimsum_gemm_tn(const dimsum_gemm_params_t *pub, int32_t splits, i
     if (p->a_block_inv_ptr && (p->a_inv_scale_ptr || p->a_block_inv_ld < p->k / kBK || p->k > 64 * kBK)) return DIMSUM_ERR_SHAPE;
     if (p->b_inv_scale_ptr && !aligned_to<char>(p->b_inv_scale_ptr, 16)) return DIMSUM_ERR_STRIDE;
     const int row_splits = (p->tn_pair_a_cols != 0) ? splits / 3 : splits;       // (pairs: the three pieces share the row ranges)
-    if (splits < 1 || row_splits < 1 || p->m <= 0 || p->n <= 0 || p->m % kBM != 0 || p->n % kBN != 0 || p->k % ((int64_t)row_splits * kBK) != 0 ||
-        p->k / row_splits < 2 * kBK)
+    // (n % 256 != 0: the caller zero-pads B's rows to whole 256-column tiles -- ldb says so -- and only columns < n are stored)
+    const int64_t n_pad = (p->n + kBN - 1) / kBN * kBN;
+    if (splits < 1 || row_splits < 1 || p->m <= 0 || p->n <= 0 || p->m % kBM != 0 || p->n % 4 != 0 || (p->n % kBN != 0 && (p->ldb < n_pad || p->tn_pair_a_cols != 0)) ||
+        p->k % ((int64_t)row_splits * kBK) != 0 || p->k / row_splits < 2 * kBK)
         return DIMSUM_ERR_SHAPE;
     if (p->lda % 8 != 0 || p->ldb % 8 != 0 || p->lda < p->m || p->ldb < p->n || !aligned_to<char>(p->a_ptr, 16) || !aligned_to<char>(p->b_ptr, 16) ||
         p->ldc % 4 != 0 || p->ldc < p->n || !aligned_to<char>(p->c_ptr, 16) || (splits > 1 && (c_split_stride % 4 != 0 || c_split_stride < (int64_t)p->m * p->ldc)))
@@ -297,7 +299,7 @@ extern "C" int dimsum_gemm_tn(const dimsum_gemm_params_t *pub, int32_t splits, i
     a.lda = p->lda; a.ldb = p->ldb; a.ldc = p->ldc;
     a.M = p->m; a.N = p->n; a.K = p->k / row_splits;
     a.tiles_m = p->m / kBM;
-    a.tiles_n = p->n / kBN;
+    a.tiles_n = (int)(n_pad / kBN);
     a.group_m = p->tune_group_m > 0 ? p->tune_group_m : (a.tiles_m <= 16 ? a.tiles_m : 4);
     if (p->b_alias_rows != 0 || p->a_alias_weight_order) return DIMSUM_ERR_UNSUPPORTED;
     if (p->tn_pair_a_cols != 0 || p->tn_pair_b_cols != 0) {

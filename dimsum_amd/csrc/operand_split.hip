@@ -345,3 +345,49 @@ extern "C" int dimsum_row_factors(const void *a_inv, const void *b_inv, int64_t 
                        reinterpret_cast<const float *>(b_inv), n, reinterpret_cast<__half *>(k_scale), reinterpret_cast<float *>(c_scale));
     return launch_status();
 }
+
+// ---- block-scaled fp16 image of a d-major fp32 matrix (channels x tokens) ---------------------------------------------------------------------------
+// The layout the 64-channel scan kernel writes out_z in (dimsum_ssm_ext_t.out_z_f16): every 64 channels x 32 tokens block as fp16(x 2^s) with the
+// block's own power-of-two scale, 2^-s in table[token / 32][channel / 64] -- the A operand of out_proj as ONE fp16 product (dimsum_gemm_tn with
+// a_block_inv_ptr). For launches the state-split scan kernels serve (16 channels per wave: no wave sees a whole block), this pass converts their fp32
+// out_z: a workgroup = 64 channels x 256 tokens, a wave 16 channel rows (16 x 16 B in flight per lane, 1-KB row segments), block maxima over the 8
+// lanes of a token group (3 DPP steps) and the 4 waves (LDS). 6 bytes per element: 0.45 GB in ~90 us at DiM-XL/2 512 px, batch 64.
+namespace dimsum {
+__global__ __launch_bounds__(256) void rows_block_f16s_kernel(const float *src, int64_t src_stride, __half *dst, int64_t dst_stride, float *table, int64_t table_ld) {
+    __shared__ float red[4][8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t d0 = (int64_t)blockIdx.y * 64 + wave * 16, m0 = (int64_t)blockIdx.x * 256 + lane * 4;
+    float4 v[16];
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = *reinterpret_cast<const float4 *>(src + (d0 + i) * src_stride + m0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
+    mx = fmaxf(mx, dpp_mov<0xB1>(mx));         // the 8 lanes of a 32-token group: quad_perm, quad_perm, row_half_mirror
+    mx = fmaxf(mx, dpp_mov<0x4E>(mx));
+    mx = fmaxf(mx, dpp_mov<0x141>(mx));
+    if ((lane & 7) == 0) red[wave][lane >> 3] = mx;
+    __syncthreads();
+    const int g = lane >> 3;
+    mx = fmaxf(fmaxf(red[0][g], red[1][g]), fmaxf(red[2][g], red[3][g]));
+    float sc, inv;
+    f16s_scales(mx, sc, inv);
+    if (wave == 0 && (lane & 7) == 0) table[((int64_t)blockIdx.x * 8 + g) * table_ld + blockIdx.y] = inv;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        *reinterpret_cast<uint2 *>(dst + (d0 + i) * dst_stride + m0) = f16s_pack4(f32x4{{v[i].x, v[i].y, v[i].z, v[i].w}}, sc);
+}
+}  // namespace dimsum
+
+extern "C" int dimsum_rows_block_f16s(const void *src, int64_t rows, int64_t cols, int64_t src_row_stride, void *dst, int64_t dst_row_stride, void *table,
+                                      int64_t table_ld, void *stream) {
+    using namespace dimsum;
+    if (!src || !dst || !table) return DIMSUM_ERR_NULL;
+    if (rows <= 0 || cols <= 0 || rows % 64 != 0 || cols % 256 != 0 || cols / 256 > 0x7fffffff || rows / 64 > 65535) return DIMSUM_ERR_SHAPE;
+    if (src_row_stride % 4 != 0 || src_row_stride < cols || dst_row_stride % 4 != 0 || dst_row_stride < cols || table_ld < rows / 64 || !aligned_to<char>(src, 16) ||
+        !aligned_to<char>(dst, 8))
+        return DIMSUM_ERR_STRIDE;
+    hipLaunchKernelGGL(rows_block_f16s_kernel, dim3((unsigned)(cols / 256), (unsigned)(rows / 64)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float *>(src), src_row_stride, reinterpret_cast<__half *>(dst), dst_row_stride, reinterpret_cast<float *>(table), table_ld);
+    return launch_status();
+}

@@ -135,12 +135,39 @@ def out_proj_f16_enabled(xz, weight, rows, seqlen, scan_kernel=1):
             and all(st % 4 == 0 for st in xz.stride()[:-1]) and xz.stride(-1) == 1 and rows >= int(os.environ.get("DIMSUM_SPLIT3_MIN_ROWS", "8192")))
 
 
+def _pad_cols_256(t):
+    """(.., K, N) -> the same values as a column slice of a ZERO-padded (.., K, ceil(N / 256) 256) buffer (the TN kernel reads whole 256-column tiles of its
+    right operand: native.gemm_tn_supported); a no-op copy when N % 256 == 0"""
+    N = t.shape[-1]
+    Np = (N + 255) // 256 * 256
+    if Np == N:
+        return t.contiguous()
+    buf = torch.zeros(t.shape[:-1] + (Np,), device=t.device, dtype=t.dtype)
+    buf[..., :N] = t
+    return buf[..., :N]
+
+
+def out_proj_f16_convert_enabled(xz, weight, rows, seqlen, scan_kernel):
+    """whether MambaInnerFn's out_proj runs as ONE fp16 product per element where a STATE-SPLIT scan kernel serves the launch (scan_kernel != 1: fewer
+    than 2048 waves, e.g. DiM-XL/2 at 512 px, batch 64): those kernels write fp32 out_z (16 channels per wave: no wave sees a 64-channel block), a
+    conversion pass (native.rows_block_f16s, 6 bytes per element) builds the block-scaled image the 64-channel kernel would have written and the same
+    TN product follows (out_proj_f16) -- instead of the library's fp32 GEMM on the d-major operand (three products + a transposing read: 361 -> ~200 us
+    per mixer at XL/2-512). DIMSUM_OUT_PROJ_F16=0 switches it off."""
+    import os
+    D = weight.shape[1]
+    return (_policy == "f16s" and scan_kernel != 1 and os.environ.get("DIMSUM_OUT_PROJ_F16", "1") != "0" and torch.backends.cuda.matmul.allow_tf32
+            and os.environ.get("DIMSUM_SPLIT3", "1") != "0" and own_gemm_enabled() and xz.is_cuda and xz.dtype == torch.float32
+            and weight.dtype == torch.float32 and weight.stride(1) == 1 and rows % 256 == 0 and seqlen % 32 == 0 and weight.shape[0] % 4 == 0
+            and D % 64 == 0 and 128 <= D <= 4096 and 128 * rows + 512 < 2 ** 31 and xz.data_ptr() % 16 == 0
+            and all(st % 4 == 0 for st in xz.stride()[:-1]) and xz.stride(-1) == 1 and rows >= int(os.environ.get("DIMSUM_SPLIT3_MIN_ROWS", "8192")))
+
+
 def weight_f16s_t(weight):
     """weight (N, K) float32 -> (image^T (K, N) float16, inv (N,)): the scaled-fp16 rows of the weight as the right operand of a TN product
-    (columns carry the scales)"""
+    (columns carry the scales); N % 256 != 0 (DiM-XL/2: 576): rows zero-padded to whole 256-column tiles behind the returned slice"""
     def make():
         img = weight_f16s(weight)
-        return img.data.t().contiguous(), img.inv
+        return _pad_cols_256(img.data.t()), img.inv
     return _cached("w16t", weight, make)
 
 
@@ -505,7 +532,7 @@ def forward_scope(model, rows):
             tdata[j] = (shape, n)
         tbufs[shape] = (data, inv)
     images, scal = native.rows_f16s_multi(jobs, n_slots=slot)      # (every entry's slots exist, also a trailing bias-free one's)
-    tbufs = {shape: (data.transpose(1, 2).contiguous(), inv) for shape, (data, inv) in tbufs.items()}
+    tbufs = {shape: (_pad_cols_256(data.transpose(1, 2)), inv) for shape, (data, inv) in tbufs.items()}
     cache = {}
     key = lambda kind, w: (kind, w.data_ptr(), tuple(w.shape), tuple(w.stride()), w.dtype)
     for (w, kind, bias, partner), lay in zip(plan, layout):

@@ -637,6 +637,21 @@ def rows_f16s(x, want_l1=False):
     return (img, l1) if want_l1 else img
 
 
+def rows_block_f16s(x):
+    """(D, M) float32 rows (a d-major activation: channels x tokens; D % 64 == 0, M % 256 == 0) -> (image (D, M) float16, table (M / 32, D / 64) float32):
+    every 64 x 32 block as fp16(x 2^s) with 2^-s in the table -- the layout selective_scan_fwd(out_z_f16=True) returns, for launches the state-split scan
+    kernels serve (csrc/operand_split.hip, rows_block_f16s_kernel)"""
+    _gpu(x)
+    _check(x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1 and x.shape[0] % 64 == 0 and x.shape[1] % 256 == 0 and x.stride(0) % 4 == 0
+           and x.data_ptr() % 16 == 0, "rows_block_f16s: x must be (D % 64, M % 256) float32 rows, 16-byte aligned")
+    D, M = x.shape
+    img = torch.empty((D, M), device=x.device, dtype=torch.float16)
+    table = torch.empty((M // 32, D // 64), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().dimsum_rows_block_f16s(_ptr(x), D, M, x.stride(0), _ptr(img), M, _ptr(table), table.stride(0), _stream(x)), "rows_block_f16s")
+    return img, table
+
+
 def rows_f16s_multi(jobs, n_slots=None):
     """ONE launch per 24 jobs (csrc/operand_split.hip, dimsum_rows_f16s_multi). jobs: list of (x, image, l1_slot, absmax_slot, l1_factor):
     x (R, K) float32 rows (or a (K,) vector: one row); image: build the F16Image; l1_slot / absmax_slot: index into the returned float32
@@ -712,7 +727,9 @@ def gemm_tn_supported(a, b):
         return False
     R, P = a.shape
     Q = b.shape[1]
-    return (b.shape[0] == R and R % 64 == 0 and R >= 128 and P % 256 == 0 and Q % 256 == 0 and P > 0 and Q > 0
+    # (Q % 256 != 0: b must be a column slice of rows ZERO-PADDED to whole 256-column tiles -- its row stride says so; gemm.weight_f16s_t pads)
+    q_ok = Q % 256 == 0 or (Q % 4 == 0 and b.stride(0) >= (Q + 255) // 256 * 256)
+    return (b.shape[0] == R and R % 64 == 0 and R >= 128 and P % 256 == 0 and q_ok and P > 0 and Q > 0
             and a.stride(1) == 1 and b.stride(1) == 1 and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0
             and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and 128 * max(a.stride(0), b.stride(0)) + 512 < 2 ** 31)
 

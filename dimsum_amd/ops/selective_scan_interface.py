@@ -186,20 +186,32 @@ class _MambaInner(torch.autograd.Function):
         keep = need or keep_stores
         # inference under allow_tf32: out_z leaves the scan as its split-bf16 pair of planes (the same 4 bytes per element) and out_proj runs
         # on the hand-written kernel's transposing-read variant straight from them (0.26 -> 0.17 ms per mixer at 65536 tokens)
-        planes = (has_out_proj and not need and out_proj_bias is None and L % 8 == 0
+        scan_k = native.scan_fwd_kernel_for(bsz, d_inner, L, N, Bm.shape[1]) if xz.is_cuda else 1
+        # ... under the scaled-fp16 policy where a state-split kernel serves the launch (fp32 out_z: 16 channels per wave, no wave sees a 64-channel
+        # block): ONE fp16 product behind a conversion pass that builds the block-scaled image (gemm.out_proj_f16_convert_enabled); takes precedence
+        # over the planes (three products): 22.97 -> 22.77 ms per DiM-L/2 forward at batch 32, 176.6 -> 170.6 ms at DiM-XL/2 512 px (whose d_model
+        # 576 the planes' TN product does not take)
+        conv16 = (has_out_proj and not keep and out_proj_bias is None and xz.is_cuda and not torch.is_autocast_enabled("cuda")
+                  and gemm.out_proj_f16_convert_enabled(xz, out_proj_weight, bsz * L, L, scan_k))
+        planes = (has_out_proj and not need and not conv16 and out_proj_bias is None and L % 8 == 0
                   and d_inner % 64 == 0 and xz.is_cuda
-                  and gemm.out_proj_planes_enabled(xz, out_proj_weight, bsz * L, native.scan_fwd_kernel_for(bsz, d_inner, L, N, Bm.shape[1])))
+                  and gemm.out_proj_planes_enabled(xz, out_proj_weight, bsz * L, scan_k))
         # inference under the scaled-fp16 policy on the 64-channel kernel: out_z leaves the scan as block-scaled fp16 (half the bytes) and
         # out_proj is ONE fp16 product per element on the hand-written TN GEMM (gemm.out_proj_f16) instead of the library's fp32 GEMM
-        z16 = (has_out_proj and not keep and not planes and out_proj_bias is None and xz.is_cuda and not torch.is_autocast_enabled("cuda")
+        z16 = (has_out_proj and not keep and not planes and not conv16 and out_proj_bias is None and xz.is_cuda and not torch.is_autocast_enabled("cuda")
                and native.scan_out_z_f16_supported(conv_out, z, A, Bm.shape[1])
-               and gemm.out_proj_f16_enabled(xz, out_proj_weight, bsz * L, L, native.scan_fwd_kernel_for(bsz, d_inner, L, N, Bm.shape[1])))
+               and gemm.out_proj_f16_enabled(xz, out_proj_weight, bsz * L, L, scan_k))
         out, scan_x, out_z, *rest = native.selective_scan_fwd(conv_out, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus,
                                                               need_out=keep, need_x=keep, need_ckpt=need, **({"out_z_planes": True} if planes else {}),
                                                               **({"out_z_f16": True} if z16 else {}),
                                                               **({"dt_proj": (delta_proj_weight, x_dbl_t[:R])} if delta is None else {}))
         if z16:
             return gemm.out_proj_f16(out_z[0], out_z[1], out_proj_weight).view(bsz, L, out_proj_weight.shape[0])
+        if conv16:
+            oz_rows = _rows(out_z)
+            if oz_rows.stride(1) == 1 and oz_rows.stride(0) % 4 == 0:
+                img, tab = native.rows_block_f16s(oz_rows)
+                return gemm.out_proj_f16(img, tab, out_proj_weight).view(bsz, L, out_proj_weight.shape[0])
         if planes:
             return gemm.out_proj_planes(out_z, out_proj_weight).view(bsz, L, out_proj_weight.shape[0])
         ckpt = rest[0] if need else None

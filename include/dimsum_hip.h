@@ -296,6 +296,13 @@ int dimsum_split3_t(const void *src, int64_t rows, int64_t cols, int64_t src_row
 int dimsum_rows_f16s(const void *src, int64_t rows, int64_t cols, int64_t src_row_stride, void *dst, int64_t dst_row_stride,
                      void *inv_scale, void *l1max, void *stream);
 
+/* Block-scaled fp16 image of a d-major f32 matrix (rows = channels, cols = batch x tokens): every 64 rows x 32 cols block as fp16(x 2^s), 2^-s (f32) at
+ * table[(col / 32) * table_ld + row / 64] -- the layout dimsum_ssm_ext_t.out_z_f16 makes the 64-channel scan kernel write, produced here from the f32
+ * out_z of a launch the state-split scan kernels serve, for dimsum_gemm_tn's a_block_inv_ptr (out_proj as one fp16 product). rows % 64 == 0,
+ * cols % 256 == 0, src rows 16-byte aligned. */
+int dimsum_rows_block_f16s(const void *src, int64_t rows, int64_t cols, int64_t src_row_stride, void *dst, int64_t dst_row_stride, void *table,
+                           int64_t table_ld, void *stream);
+
 /* Many scaled-fp16 conversions in ONE launch (per 24 jobs): the weight images, largest row L1 norms and bias maxima a whole denoiser forward
  * needs under the scaled-fp16 policy (host: dimsum_amd/gemm.py forward_scope). No reference counterpart: the reference's cuBLAS TF32 GEMMs
  * read the fp32 weights directly (dimsum/train.py:20-21). Same image as dimsum_rows_f16s, bit for bit. */
@@ -562,7 +569,8 @@ int dimsum_gemm_nt_kernel_for(const dimsum_gemm_params_t *p);
    attention_fusion.py:44-79): C[s] (m, n) float32 = sum over the rows r of reduction range s of A[r, 0..m)^T B[r, 0..n). a_ptr: (k, m) rows
    with stride lda, b_ptr: (k, n) rows with stride ldb (16-bit, the split-bf16 images viewed as (3 rows, features) stacks), k = all
    reduction rows, cut into `splits` equal ranges (k % (64 splits) == 0) whose partial results lie c_split_stride floats apart in c_ptr --
-   the caller adds them (a fixed order: bitwise reproducible). m % 256 == 0, n % 256 == 0; epilogue F32 only; the other fields as above. */
+   the caller adds them (a fixed order: bitwise reproducible). m % 256 == 0; n % 256 == 0, or n % 4 == 0 with B's rows ZERO-PADDED to the next multiple
+   of 256 columns (ldb >= that multiple: the last column tile reads the padding; only columns < n are stored); epilogue F32 only; the other fields as above. */
 int dimsum_gemm_tn(const dimsum_gemm_params_t *p, int32_t splits, int64_t c_split_stride, void *stream);
 
 /* The weight-gradient shape of the Mamba projections under autograd (selective_scan_interface.py:954-981: "eB,dB->ed" d out_proj.weight,

@@ -480,3 +480,38 @@ def test_mamba_inner_out_proj_as_one_fp16_product_vs_tf32(B, L, d_model, d_inner
     assert e16.abs().max() <= 1.1 * e32.abs().max() and e16.pow(2).mean().sqrt() <= 1.1 * e32.pow(2).mean().sqrt(), \
         (e16.abs().max().item(), e32.abs().max().item(), e16.pow(2).mean().sqrt().item(), e32.pow(2).mean().sqrt().item())
     assert (lib.double() - exact).abs().max() <= 1.1 * e32.abs().max()
+
+
+@pytest.mark.parametrize("D,M,N", [(1152, 2048, 576), (128, 256, 132), (1024, 4096, 512)])
+def test_block_scaled_image_of_a_d_major_matrix_and_ragged_tn(D, M, N):
+    """dimsum_rows_block_f16s: the conversion pass that gives launches of the state-split scan kernels the block-scaled fp16 out_z the 64-channel kernel
+    writes itself (64 channels x 32 tokens per scale): decoded, it is the input to half an fp16 ulp of each block's maximum, scales are the block
+    maxima's powers of two, an all-zero block decodes to zeros; and out_proj over it -- dimsum_gemm_tn with the table and a right operand whose
+    columns (d_model = 576 at DiM-XL/2, not a multiple of the kernel's 256-column tiles) are zero-padded behind the slice -- against float64, within
+    the emulated-TF32 product's error"""
+    from dimsum_amd import gemm, native
+    from dimsum_amd.utils.tf32_emulation import round_tf32
+    g = torch.Generator(device="cuda").manual_seed(D + N)
+    x = torch.randn(D, M, device="cuda", generator=g) * torch.exp2(8 * torch.rand(1, M, device="cuda", generator=g) - 4)      # token magnitudes over 2^-4 .. 2^4
+    x[:64, :32] = 0
+    x[64:128, 32:64] *= 1e-9
+    img, tab = native.rows_block_f16s(x)
+    assert img.shape == (D, M) and img.dtype == torch.float16 and tab.shape == (M // 32, D // 64)
+    blocks = lambda t: t.reshape(D // 64, 64, M // 32, 32).permute(2, 0, 1, 3)
+    dec = blocks(img.float()) * tab[:, :, None, None]
+    want = blocks(x)
+    bmax = want.abs().amax((2, 3))
+    assert torch.all((dec - want).abs().amax((2, 3)) <= 2.0 ** -11 * bmax * 1.001 + 1e-37)
+    assert torch.all(torch.frexp(tab)[0] == 0.5) and torch.all(dec[0, 0] == 0)
+    top = blocks(img.float()).abs().amax((2, 3))
+    assert torch.all(top[bmax > 0] >= 2.0 ** 14) and torch.all(top <= 2.0 ** 15)          # (a maximum just below 2^15 may round up to it)
+    w = torch.randn(N, D, device="cuda", generator=g) * D ** -0.5
+    if M % 256 == 0 and D >= 128:
+        got = gemm.out_proj_f16(img, tab, w)                                  # (M, N)
+        ref = x.double().t() @ w.double().t()
+        tf = round_tf32(x).double().t() @ round_tf32(w).double().t()
+        e, et = (got.double() - ref).abs(), (tf - ref).abs()
+        s_ = ref.abs().max().item()
+        print(f"out_proj over the converted image ({D} x {M} x {N}): f16s {e.max().item() / s_:.2e} / {e.pow(2).mean().sqrt().item() / s_:.2e}, "
+              f"TF32 operands {et.max().item() / s_:.2e} / {et.pow(2).mean().sqrt().item() / s_:.2e}")
+        assert got.shape == (M, N) and e.max().item() <= 1.1 * et.max().item() + 2.0 ** -22 * s_ and e.pow(2).mean().sqrt().item() <= 1.1 * et.pow(2).mean().sqrt().item() + 2.0 ** -24 * s_
