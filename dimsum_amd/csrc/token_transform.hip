@@ -548,7 +548,7 @@ __global__ __launch_bounds__(256) void gated_gelu_bwd_kernel(const float *x12, c
 // The same adjoint with dx12 written as a scaled-fp16 operand image (common.hpp, f16s): rows of 2H fp16 = fp16(dx12_r 2^s_r) with the exact row
 // maximum's power of two, inv[r] = 2^-s_r -- the operand of BOTH backward GEMMs of w12 under the scaled-fp16 policy (d input = dx12 W12 as an NT
 // product, d weight = dx12^T h as a TN product with per-reduction-row factors, dimsum_gemm_ext_t.k_scale_ptr). A row's maximum needs the whole
-// row: one workgroup walks rows_per_wg rows (16 .. 128: >= ~1024 workgroups at every batch size), a thread holding its 4-column pieces of both halves (H <= 1024 kStrips) in registers between the
+// row: one workgroup walks rows_per_wg rows (rows / 512: one round of 512 workgroups), a thread holding its 4-column pieces of both halves (H <= 1024 kStrips) in registers between the
 // maximum and the store; the column sums (d bias) accumulate in registers across the rows.
 template <int kStrips>
 __global__ __launch_bounds__(256) void gated_gelu_bwd_f16s_kernel(const float *x12, const float *bias, const float *dh, __half *img, float *inv, float *dbias,
@@ -705,10 +705,12 @@ extern "C" int dimsum_gated_gelu_bwd_f16s(const void *x12, const void *bias, con
     if (rows < 0 || hidden <= 0 || hidden % 4 != 0 || hidden > 5 * 1024) return DIMSUM_ERR_SHAPE;
     if (!aligned_to<char>(x12, 16) || !aligned_to<char>(dh, 16) || !aligned_to<char>(dx12_image, 8) || (bias && !aligned_to<char>(bias, 16))) return DIMSUM_ERR_STRIDE;
     if (rows == 0) return DIMSUM_OK;
-    // rows per workgroup: enough workgroups to fill the chip several times over (>= ~1024) at every batch size, at most 128 rows (the column sums
-    // of a workgroup cost one atomic per column: 16 rows per workgroup at 16384 rows is the same atomic traffic as 128 at 131072)
-    int rpw = (int)(rows / 1024);
-    rpw = rpw < 16 ? 16 : (rpw > 128 ? 128 : rpw);
+    // rows per workgroup: ONE round of 512 workgroups (two per CU; three fit), whatever the batch size. Measured (tools/scratch/gg_bwd_time.py,
+    // rows per workgroup = rows / div): 16384 rows: 128 workgroups 538 us, 256: 320, 390-512: 262, 780: 348 (a dozen workgroups left over for a
+    // second round run alone for a whole workgroup's duration), 1024: 309, 2048+: 350; 65536 rows: 512 workgroups 862 us, 1024: 937, 2048: 882,
+    // 8192: 1117 (the column sums cost one atomic per column and workgroup: 8192 each).
+    int rpw = (int)((rows + 511) / 512);
+    rpw = rpw < 8 ? 8 : rpw;
     const dim3 grid((unsigned)((rows + rpw - 1) / rpw));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int strips = (int)((hidden + 1023) / 1024);
