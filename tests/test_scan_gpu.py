@@ -381,19 +381,25 @@ def test_timing_events_bracket_the_whole_backward_call(monkeypatch):
     dout = torch.randn(B, D, L, device="cuda", generator=g)
     out, x, out_z, ckpt = native.selective_scan_fwd(u, dl, A, Bm, Cm, Dv, z, bias, True, need_ckpt=True)
     assert not timer.records["fwd"]                       # timer off: the call above carried no events
-    ms = {}
-    for name, ck in (("saved", ckpt), ("rebuilt", None)):
-        for _ in range(2):
+    # (interleaved rounds, best time of each: the two variants see the same clocks -- one averaged loop after the other failed once on a box whose clock
+    # was still ramping during the first loop)
+    lib = _lib.load()
+    best = {"saved": float("inf"), "rebuilt": float("inf")}
+    for _ in range(2):
+        for ck in (ckpt, None):
             native.selective_scan_bwd(u, dl, A, Bm, Cm, Dv, z, bias, dout, x, out, None, True, False, ckpt=ck)
-        torch.cuda.synchronize()
-        timer.reset()
-        timer.enabled = True
-        for _ in range(5):
-            native.selective_scan_bwd(u, dl, A, Bm, Cm, Dv, z, bias, dout, x, out, None, True, False, ckpt=ck)
-        timer.enabled = False
-        torch.cuda.synchronize()
-        assert len(timer.records["bwd"]) == 5 and not timer.records["fwd"]     # the internal sweep is not a second record
-        ms[name] = timer.roofline("bwd")["avg_launch_ms"]
+    torch.cuda.synchronize()
+    for _ in range(4):
+        for name, ck in (("saved", ckpt), ("rebuilt", None)):
+            timer.reset()
+            timer.enabled = True
+            for _ in range(3):
+                native.selective_scan_bwd(u, dl, A, Bm, Cm, Dv, z, bias, dout, x, out, None, True, False, ckpt=ck)
+            timer.enabled = False
+            torch.cuda.synchronize()
+            assert len(timer.records["bwd"]) == 3 and not timer.records["fwd"]     # the internal sweep is not a second record
+            best[name] = min([best[name]] + [float(lib.dimsum_event_elapsed_ms(r[0], r[1])) for r in timer.records["bwd"]])
+    ms = best
     assert ms["saved"] > 0 and ms["rebuilt"] > 1.15 * ms["saved"], ms
 
 
