@@ -25,13 +25,14 @@ class _XattnCoreFn(torch.autograd.Function):
             return native.xattn_fusion_fwd(qkv1, qkv2, heads, bias1=b1, bias2=b2)
         out, lse = native.xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=True, bias1=b1, bias2=b2)
         ctx.heads = heads
+        ctx.f16 = gemm.attn_bwd_f16_enabled(qkv1)      # policy "f16s" under training: the backward pair on ONE fp16 product per element
         ctx.save_for_backward(qkv1, qkv2, b1, b2, out, lse)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv1, qkv2, b1, b2, out, lse = ctx.saved_tensors
-        dqkv1, dqkv2 = native.xattn_fusion_bwd(qkv1, qkv2, out, lse, dout, ctx.heads, bias1=b1, bias2=b2)
+        dqkv1, dqkv2 = native.xattn_fusion_bwd(qkv1, qkv2, out, lse, dout, ctx.heads, bias1=b1, bias2=b2, f16=ctx.f16)
         W = dqkv1.shape[-1]
         db1 = dqkv1.reshape(-1, W).sum(0) if (b1 is not None and ctx.needs_input_grad[2]) else None
         db2 = dqkv2.reshape(-1, W).sum(0) if (b2 is not None and dqkv2 is not None and ctx.needs_input_grad[3]) else None

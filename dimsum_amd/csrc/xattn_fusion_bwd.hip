@@ -15,6 +15,8 @@
 // S and dP are recomputed in both (7 GEMM-equivalents instead of 5): cheaper on fp32 MFMA than contended fp32 atomics
 // on dq, and bitwise reproducible. All products are v_mfma_f32_16x16x4_f32 (exact fp32).
 // Optional qkv Linear biases are added while q / k / v are fetched, like in the forward.
+#include <stdlib.h>
+
 #include "xattn_common.hpp"
 
 namespace dimsum {
@@ -50,6 +52,7 @@ __device__ __forceinline__ XSrc xattn_src(const dimsum_xattn_bwd_params_t &p, in
     s.dq = dqs; s.dk = dkvs + C; s.dv = dkvs + 2 * C;
     return s;
 }
+__device__ __forceinline__ float4 add4(const float4 &a, const float4 &b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 ld_bias4(const float *row, const float *bias, int e) {
     float4 t = *reinterpret_cast<const float4 *>(row + e);
     if (bias) { const float4 bb = *reinterpret_cast<const float4 *>(bias + e); t.x += bb.x; t.y += bb.y; t.z += bb.z; t.w += bb.w; }
@@ -295,13 +298,27 @@ __global__ __launch_bounds__(256) void xattn_bwd_dkv_kernel(const dimsum_xattn_b
 }
 
 // =====================================================================================================================
-// Split-bf16 variants (fwd.precision = 1): the same two kernels on v_mfma_f32_16x16x32_bf16 with every fp32 operand carried
-// as hi + lo bf16 (xattn_common.hpp). The register-resident C results (dS^T; P and dS) become the B operand of the next
-// product through the slot convention of xattn_fusion.hip: K-slot 8g + j of a 32-deep chunk is the row the lane already
-// holds in the C registers of two stacked 16-row tiles, and the transposed LDS images (K^T; Q^T, dO^T) are staged with
-// that permutation (cslot), so no operand changes layout. Softmax probabilities, D and all accumulators stay fp32.
+// Matrix-core variants on v_mfma_f32_16x16x32_{bf16,f16}: the same two kernels with every fp32 operand carried
+//   fwd.precision = 1 (F16 = false): as hi + lo bf16, three products per element (xattn_common.hpp);
+//   fwd.precision = 2 (F16 = true):  as ONE fp16 image, one product per element -- the TF32-equivalent arithmetic of the reference's
+//                                    allow_tf32 policy (train.py:20-21 covers the backward matmuls too), the training counterpart of
+//                                    xattn_fusion_f16.hip.
+// The register-resident C results (dS^T; P and dS) become the B operand of the next product through the slot convention of
+// xattn_fusion.hip: K-slot 8g + j of a 32-deep chunk is the row the lane already holds in the C registers of two stacked 16-row tiles,
+// and the transposed LDS images (K^T; Q^T, dO^T) are staged with that permutation (cslot), so no operand changes layout. Softmax
+// probabilities, D and all accumulators stay fp32.
+// fp16 carrier, what keeps the exponent range: q (times scale log2 e), k, v are post-projection activations and go to fp16 as they are
+// (|.| <= 65504; the scores only need ABSOLUTE accuracy, 2^-11 per product like TF32). Gradients have no a-priori magnitude: every dO
+// row (one query of one head) is scaled by an exact power of two g_q that brings its maximum to [2^-5, 2^-4) (row_pow2_scale), D with it;
+// dP, dS of that row live in the scaled domain and dq is unscaled on store (exact). P travels as 2^8 P (kPShift, folded into the
+// log-sum-exp the accumulators start from): 11 bits down to P = 2^-22 where fp16 alone would fade below 2^-14. The dq kernel, which owns
+// D, also leaves g_q behind the D rows of the scratch (delta: 2 x (batch, n_dirs', heads, L) floats under this carrier). dk / dv sum over
+// queries: there P also carries g_min / g_q <= 1 (g_min = the scale of the (batch, head, direction)'s LARGEST gradient row; a power of
+// two, so it too lives in the log-sum-exp), every row enters the sums at the scale of the largest one -- rows more than 2^10 below it
+// fade, as they do in the fp32 sum -- and the result is multiplied by 2^-8 / g_min on store. Range: |dP - D| <= 2 hd 2^-4 max|v|, times
+// 2^8: inside fp16 for max|v| <= 32 at head_dim 64 even if every product aligned.
 // =====================================================================================================================
-constexpr int kSQW = 128;        // queries per workgroup of the split dq kernel
+constexpr int kSQW = 128;        // queries per workgroup of the matrix-core dq kernel
 
 // QT = 16-query tiles per wave, NW waves per workgroup (NW * QT * 16 = 128 queries either way). QT = 2 (4 waves): every K / V / K^T
 // fragment read serves two query tiles and the two tiles' MFMA chains interleave -- used for head_dim <= 32, where two tiles take 163
@@ -310,18 +327,19 @@ constexpr int kSQW = 128;        // queries per workgroup of the split dq kernel
 // occupancy wins there; head_dim 72 does not fit two tiles at all.
 // (head_dim 72: 76 KB of LDS allow 2 workgroups per CU anyway -- asking for 4 waves per SIMD capped the kernel at 128 VGPRs and 292 B of
 // scratch per lane: 5.2 ms per launch at 1024 tokens, profiles/r03_xattn_bwd_pmc.txt)
-template <int HD, int QT>
+template <int HD, int QT, bool F16>
 __global__ __launch_bounds__(kSQW / QT * 4, (QT == 1 && HD <= 64) ? 4 : 2) void xattn_bwd_dq_split_kernel(const dimsum_xattn_bwd_params_t p) {
     constexpr int NT = kSQW / QT * 4;        // threads per workgroup: 512 (QT = 1) or 256 (QT = 2)
     constexpr int EP = (HD + 31) / 32 * 32, EC = EP / 32, ET = (HD + 15) / 16;
-    constexpr int KS = EP + 8;               // [key][e] rows of K and V (bf16 elements, 16 B of padding)
+    constexpr int KS = EP + 8;               // [key][e] rows of K and V (16-bit elements, 16 B of padding)
     constexpr int TS = kBKT + 8;             // [e][key slot] rows of K^T
-    __shared__ __attribute__((aligned(16))) unsigned short Kh[kBKT * KS], Kl[kBKT * KS], Vh[kBKT * KS], Vl[kBKT * KS];
-    __shared__ __attribute__((aligned(16))) unsigned short Th[ET * 16 * TS], Tl[ET * 16 * TS];
+    constexpr int LO = F16 ? 0 : 1;          // the lo images exist under the split-bf16 carrier only
+    __shared__ __attribute__((aligned(16))) unsigned short Kh[kBKT * KS], Vh[kBKT * KS], Th[ET * 16 * TS];
+    __shared__ __attribute__((aligned(16))) unsigned short Kl[LO * kBKT * KS + 8], Vl[LO * kBKT * KS + 8], Tl[LO * ET * 16 * TS + 8];
     static_assert((KS / 8) % 2 == 1 && (TS / 8) % 2 == 1, "odd number of 16-byte slots per row");
     // conflict-free fragment reads (xattn_fusion.hip): a ds_read_b128 is serviced in four fixed groups of 16 lanes, in which rows 4-11
     // of a 16-row fragment read k-slot a ^ 1 while rows 0-3 / 12-15 read slot a -- rows 4-11 keep their 16-byte slot PAIRS swapped
-    // (8 bf16 elements), in the staging writes and in the lanes' base addresses alike
+    // (8 elements), in the staging writes and in the lanes' base addresses alike
     auto flip = [](int row) { return (((row & 15) + 4) & 8); };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -336,20 +354,22 @@ __global__ __launch_bounds__(kSQW / QT * 4, (QT == 1 && HD <= 64) ? 4 : 2) void 
     const int C = H * HD;
     const XSrc s = xattn_src(p, b, h, dir, HD);
     const int64_t ts = p.fwd.qkv_token_stride, dts = p.dqkv_token_stride;
+    const int64_t nstat = (int64_t)p.fwd.batch * ndir * H * L;            // fp16 carrier: the row scales follow the D rows
 
     const int qi = lane & 15, kg = lane >> 4;
     const float qscale = p.fwd.scale * kLog2e;
     // Q^T (scaled into the log2 domain) and dO^T fragments (B operands) of the wave's QT query tiles: chunk c, slots j <-> e = 32c + 8 kg + j
     int q_tok[QT];
-    float dpart[QT], lse2[QT];
-    u4v qh[QT][EC], ql[QT][EC], gh[QT][EC], gl[QT][EC];
+    float dpart[QT], lse2[QT], ginv[F16 ? QT : 1];
+    Frag<F16> qf[QT][EC], gf[QT][EC];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         q_tok[t] = qblk * kSQW + (wave * QT + t) * 16 + qi;
         const int q_ld = min(q_tok[t], L - 1);
         const float *dorow = reinterpret_cast<const float *>(p.dout_ptr) + (int64_t)b * p.fwd.out_batch_stride + (int64_t)q_ld * p.fwd.out_token_stride + dir * C + h * HD;
         const float *orow = reinterpret_cast<const float *>(p.fwd.out_ptr) + (int64_t)b * p.fwd.out_batch_stride + (int64_t)q_ld * p.fwd.out_token_stride + dir * C + h * HD;
-        float dp = 0.f;
+        float dp = 0.f, gmax = 0.f;
+        float gkeep[F16 ? EC : 1][8];         // fp16 carrier: the dO row waits for its scale
 #pragma unroll
         for (int c = 0; c < EC; ++c) {
             float qv[8], gv[8];
@@ -362,17 +382,41 @@ __global__ __launch_bounds__(kSQW / QT * 4, (QT == 1 && HD <= 64) ? 4 : 2) void 
                     g = *reinterpret_cast<const float4 *>(dorow + e0);
                     const float4 o = *reinterpret_cast<const float4 *>(orow + e0);
                     dp += g.x * o.x + g.y * o.y + g.z * o.z + g.w * o.w;
+                    if constexpr (F16) gmax = fmaxf(fmaxf(gmax, fmaxf(fabsf(g.x), fabsf(g.y))), fmaxf(fabsf(g.z), fabsf(g.w)));
                 }
                 qv[4 * half + 0] = tq.x * qscale; qv[4 * half + 1] = tq.y * qscale; qv[4 * half + 2] = tq.z * qscale; qv[4 * half + 3] = tq.w * qscale;
                 gv[4 * half + 0] = g.x; gv[4 * half + 1] = g.y; gv[4 * half + 2] = g.z; gv[4 * half + 3] = g.w;
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { split2(qv[2 * i], qv[2 * i + 1], qh[t][c].w[i], ql[t][c].w[i]); split2(gv[2 * i], gv[2 * i + 1], gh[t][c].w[i], gl[t][c].w[i]); }
+            for (int i = 0; i < 4; ++i) {
+                frag_put2<F16>(qf[t][c], i, qv[2 * i], qv[2 * i + 1]);
+                if constexpr (!F16) frag_put2<F16>(gf[t][c], i, gv[2 * i], gv[2 * i + 1]);
+            }
+            if constexpr (F16) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) gkeep[c][i] = gv[i];
+            }
+        }
+        float gs = 1.f;
+        if constexpr (F16) {
+            gs = row_pow2_scale(quad_max(gmax));     // the query's 4 lanes hold its whole dO row between them
+#pragma unroll
+            for (int c = 0; c < EC; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) frag_put2<F16>(gf[t][c], i, gkeep[c][2 * i] * gs, gkeep[c][2 * i + 1] * gs);
         }
         dpart[t] = quad_sum(dp);                              // D of this lane's query
         const int64_t stat = (((int64_t)b * ndir + dir) * H + h) * L + q_ld;
         lse2[t] = reinterpret_cast<const float *>(p.fwd.lse_ptr)[stat] * kLog2e;
-        if (q_tok[t] < L && kg == 0) reinterpret_cast<float *>(p.delta_ptr)[stat] = dpart[t];
+        if (q_tok[t] < L && kg == 0) {
+            reinterpret_cast<float *>(p.delta_ptr)[stat] = dpart[t];
+            if constexpr (F16) reinterpret_cast<float *>(p.delta_ptr)[nstat + stat] = gs;
+        }
+        if constexpr (F16) {      // D in the row's scaled domain; P as 2^kPShift P (folded into the log-sum-exp); both undone, exactly, on store
+            dpart[t] *= gs;
+            lse2[t] -= (float)kPShift;
+            ginv[t] = (1.f / gs) * (1.f / (float)(1 << kPShift));
+        }
     }
 
     f4 acc[QT][ET];
@@ -381,55 +425,52 @@ __global__ __launch_bounds__(kSQW / QT * 4, (QT == 1 && HD <= 64) ? 4 : 2) void 
 #pragma unroll
         for (int e = 0; e < ET; ++e) acc[t][e] = f4{0.f, 0.f, 0.f, 0.f};
     if constexpr (EP > HD) {      // padding that is never rewritten: columns e in [hd, EP) of K and V
-        for (int i = tid; i < kBKT * (EP - HD); i += NT) { const int key = i / (EP - HD), e = (HD + i % (EP - HD)) ^ flip(key); Kh[key * KS + e] = 0; Kl[key * KS + e] = 0; Vh[key * KS + e] = 0; Vl[key * KS + e] = 0; }
+        for (int i = tid; i < kBKT * (EP - HD); i += NT) { const int key = i / (EP - HD), e = (HD + i % (EP - HD)) ^ flip(key); img_zero<F16>(Kh, Kl, key * KS + e); img_zero<F16>(Vh, Vl, key * KS + e); }
     }
     if constexpr (ET * 16 > HD) {  // rows e in [hd, ET*16) of K^T
-        for (int i = tid; i < (ET * 16 - HD) * kBKT; i += NT) { const int e = HD + i / kBKT, k = (i % kBKT) ^ flip(e); Th[e * TS + k] = 0; Tl[e * TS + k] = 0; }
+        for (int i = tid; i < (ET * 16 - HD) * kBKT; i += NT) { const int e = HD + i / kBKT, k = (i % kBKT) ^ flip(e); img_zero<F16>(Th, Tl, e * TS + k); }
     }
 
     // The K / V rows of the NEXT key tile are requested right after the current tile has been staged (register-staged
     // prefetch: one thread = 2 keys x 4 e, kIt items per tile), so their HBM latency hides under the tile's MFMA work.
     constexpr int kItems = (kBKT / 2) * (HD / 4), kIt = (kItems + NT - 1) / NT;
-    float4 pka[kIt], pkb[kIt], pva[kIt], pvb[kIt];
+    // (the loads stay RAW: adding the bias inside fetch would wait for the data there and expose the latency the prefetch is meant to
+    // hide -- the thread's bias values are loop constants, added when the tile is staged)
+    float4 pka[kIt], pkb[kIt], pva[kIt], pvb[kIt], kbias[kIt], vbias[kIt];
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+        const int i = min(tid + it * NT, kItems - 1), e4 = i % (HD / 4);
+        kbias[it] = s.kb ? *reinterpret_cast<const float4 *>(s.kb + e4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        vbias[it] = s.vb ? *reinterpret_cast<const float4 *>(s.vb + e4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int it = 0; it < kIt; ++it) {
             const int i = min(tid + it * NT, kItems - 1);
             const int kp = i / (HD / 4), e4 = i - kp * (HD / 4), key = 2 * kp;
             const int tok0 = min(k0 + key, L - 1), tok1 = min(k0 + key + 1, L - 1);
-            pka[it] = ld_bias4(s.k + (int64_t)tok0 * ts, s.kb, e4 * 4); pkb[it] = ld_bias4(s.k + (int64_t)tok1 * ts, s.kb, e4 * 4);
-            pva[it] = ld_bias4(s.v + (int64_t)tok0 * ts, s.vb, e4 * 4); pvb[it] = ld_bias4(s.v + (int64_t)tok1 * ts, s.vb, e4 * 4);
+            pka[it] = *reinterpret_cast<const float4 *>(s.k + (int64_t)tok0 * ts + e4 * 4); pkb[it] = *reinterpret_cast<const float4 *>(s.k + (int64_t)tok1 * ts + e4 * 4);
+            pva[it] = *reinterpret_cast<const float4 *>(s.v + (int64_t)tok0 * ts + e4 * 4); pvb[it] = *reinterpret_cast<const float4 *>(s.v + (int64_t)tok1 * ts + e4 * 4);
         }
     };
     fetch(0);
 
     for (int k0 = 0; k0 < L; k0 += kBKT) {
         __syncthreads();
-        // ---- stage K, V [key][e] and K^T [e][slot(key)] as hi / lo bf16 images; one thread = 2 keys x 4 e -----------------
+        // ---- stage K, V [key][e] and K^T [e][slot(key)] as operand images; one thread = 2 keys x 4 e ---------------------------
 #pragma unroll
         for (int it = 0; it < kIt; ++it) {
             const int i = tid + it * NT;
             if (i >= kItems) break;
             const int kp = i / (HD / 4), e4 = i - kp * (HD / 4), key = 2 * kp;
-            const float4 ka = pka[it], kb = pkb[it], va = pva[it], vb = pvb[it];
-            unsigned h0, l0, h1, l1;
+            const float4 ka = add4(pka[it], kbias[it]), kb = add4(pkb[it], kbias[it]), va = add4(pva[it], vbias[it]), vb = add4(pvb[it], vbias[it]);
             const int ke = (e4 * 4) ^ flip(key);                    // key even: key and key + 1 are rows of the same kind
-            split2(ka.x, ka.y, h0, l0); split2(ka.z, ka.w, h1, l1);
-            *reinterpret_cast<uint2 *>(&Kh[key * KS + ke]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Kl[key * KS + ke]) = make_uint2(l0, l1);
-            split2(kb.x, kb.y, h0, l0); split2(kb.z, kb.w, h1, l1);
-            *reinterpret_cast<uint2 *>(&Kh[(key + 1) * KS + ke]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Kl[(key + 1) * KS + ke]) = make_uint2(l0, l1);
-            split2(va.x, va.y, h0, l0); split2(va.z, va.w, h1, l1);
-            *reinterpret_cast<uint2 *>(&Vh[key * KS + ke]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Vl[key * KS + ke]) = make_uint2(l0, l1);
-            split2(vb.x, vb.y, h0, l0); split2(vb.z, vb.w, h1, l1);
-            *reinterpret_cast<uint2 *>(&Vh[(key + 1) * KS + ke]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Vl[(key + 1) * KS + ke]) = make_uint2(l0, l1);
+            img_st4<F16>(Kh, Kl, key * KS + ke, ka); img_st4<F16>(Kh, Kl, (key + 1) * KS + ke, kb);
+            img_st4<F16>(Vh, Vl, key * KS + ke, va); img_st4<F16>(Vh, Vl, (key + 1) * KS + ke, vb);
             const int pos = ((key & ~31) + cslot(key & 31)) ^ flip(e4 * 4);      // rows e4*4 .. +3 of K^T: one kind
             const float a4[4] = {ka.x, ka.y, ka.z, ka.w}, b4[4] = {kb.x, kb.y, kb.z, kb.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                split2(a4[e], b4[e], h0, l0);
-                *reinterpret_cast<unsigned *>(&Th[(e4 * 4 + e) * TS + pos]) = h0;
-                *reinterpret_cast<unsigned *>(&Tl[(e4 * 4 + e) * TS + pos]) = l0;
-            }
+            for (int e = 0; e < 4; ++e) img_st2<F16>(Th, Tl, (e4 * 4 + e) * TS + pos, a4[e], b4[e]);
         }
         __syncthreads();
         if (k0 + kBKT < L) fetch(k0 + kBKT);
@@ -437,43 +478,50 @@ __global__ __launch_bounds__(kSQW / QT * 4, (QT == 1 && HD <= 64) ? 4 : 2) void 
         f4 ds[QT][4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
+            // the accumulators start at -lse and -D: the MFMA chains then end in S^T - lse and dP^T - D
             f4 sacc[QT], pacc[QT];
 #pragma unroll
-            for (int t = 0; t < QT; ++t) { sacc[t] = f4{0.f, 0.f, 0.f, 0.f}; pacc[t] = f4{0.f, 0.f, 0.f, 0.f}; }
+            for (int t = 0; t < QT; ++t) { sacc[t] = f4{-lse2[t], -lse2[t], -lse2[t], -lse2[t]}; pacc[t] = f4{-dpart[t], -dpart[t], -dpart[t], -dpart[t]}; }
             const int krow = (kt * 16 + qi) * KS + ((8 * kg) ^ flip(qi));
 #pragma unroll
             for (int c = 0; c < EC; ++c) {
-                const u4v kh = *reinterpret_cast<const u4v *>(&Kh[krow + 32 * c]), kl = *reinterpret_cast<const u4v *>(&Kl[krow + 32 * c]);
-                const u4v vh = *reinterpret_cast<const u4v *>(&Vh[krow + 32 * c]), vl = *reinterpret_cast<const u4v *>(&Vl[krow + 32 * c]);
+                const Frag<F16> kf = frag_ld<F16>(Kh, Kl, krow + 32 * c), vf = frag_ld<F16>(Vh, Vl, krow + 32 * c);
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
-                    sacc[t] = mfma_split(kh, kl, qh[t][c], ql[t][c], sacc[t]);      // S^T  (log2 domain)
-                    pacc[t] = mfma_split(vh, vl, gh[t][c], gl[t][c], pacc[t]);      // dP^T
+                    sacc[t] = frag_mfma<F16>(kf, qf[t][c], sacc[t]);      // S^T - lse  (log2 domain)
+                    pacc[t] = frag_mfma<F16>(vf, gf[t][c], pacc[t]);      // dP^T - D   (fp16 carrier: times the query's g)
                 }
             }
 #pragma unroll
             for (int t = 0; t < QT; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {     // dS^T = P^T o (dP^T - D); keys beyond L contribute nothing
-                    const float pr = (k0 + kt * 16 + kg * 4 + r < L) ? fast_exp2(sacc[t][r] - lse2[t]) : 0.f;
-                    ds[t][kt][r] = pr * (pacc[t][r] - dpart[t]);
-                }
+                for (int r = 0; r < 4; ++r) ds[t][kt][r] = fast_exp2(sacc[t][r]) * pacc[t][r];      // dS^T = P^T o (dP^T - D)
+        }
+        if (k0 + kBKT > L) {      // the last tile: keys beyond L (clamped loads) contribute nothing
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (k0 + kt * 16 + kg * 4 + r >= L) {
+#pragma unroll
+                        for (int t = 0; t < QT; ++t) ds[t][kt][r] = 0.f;
+                    }
         }
         // ---- dQ^T += K^T dS^T: chunk c = key tiles 2c, 2c + 1 -----------------------------------------------------------------
-        u4v dh[QT][2], dl[QT][2];
+        Frag<F16> df[QT][2];
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-            split_c2(ds[t][0], ds[t][1], dh[t][0], dl[t][0]);
-            split_c2(ds[t][2], ds[t][3], dh[t][1], dl[t][1]);
+            df[t][0] = frag_c2<F16>(ds[t][0], ds[t][1]);
+            df[t][1] = frag_c2<F16>(ds[t][2], ds[t][3]);
         }
 #pragma unroll
         for (int e = 0; e < ET; ++e) {
             const int trow = (e * 16 + qi) * TS + ((8 * kg) ^ flip(qi));
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const u4v th = *reinterpret_cast<const u4v *>(&Th[trow + 32 * c]), tl = *reinterpret_cast<const u4v *>(&Tl[trow + 32 * c]);
+                const Frag<F16> tf = frag_ld<F16>(Th, Tl, trow + 32 * c);
 #pragma unroll
-                for (int t = 0; t < QT; ++t) acc[t][e] = mfma_split(th, tl, dh[t][c], dl[t][c], acc[t][e]);
+                for (int t = 0; t < QT; ++t) acc[t][e] = frag_mfma<F16>(tf, df[t][c], acc[t][e]);
             }
         }
     }
@@ -481,7 +529,8 @@ __global__ __launch_bounds__(kSQW / QT * 4, (QT == 1 && HD <= 64) ? 4 : 2) void 
     for (int t = 0; t < QT; ++t) {
         if (q_tok[t] >= L) continue;
         float *dst = s.dq + (int64_t)q_tok[t] * dts;
-        const float sc = p.fwd.scale;
+        float sc = p.fwd.scale;
+        if constexpr (F16) sc *= ginv[t];
 #pragma unroll
         for (int e = 0; e < ET; ++e) {
             const int e0 = e * 16 + kg * 4;
@@ -493,14 +542,16 @@ __global__ __launch_bounds__(kSQW / QT * 4, (QT == 1 && HD <= 64) ? 4 : 2) void 
 // KT = 16-key tiles per wave: a workgroup covers 64 * KT keys, so the staging of a query tile (loads, 16 hi / lo splits and 24 LDS
 // writes per thread: more VALU work than the tile's 48 MFMAs per key tile take on the matrix cores) and every A-operand
 // ds_read_b128 are shared by KT key tiles -- the forward's QT = 2 trick; 2 workgroups per CU instead of 3 (head_dim <= 64).
-template <int HD, int KT>
+template <int HD, int KT, bool F16>
 __global__ __launch_bounds__(256, (HD > 64 || KT == 2) ? 2 : 3) void xattn_bwd_dkv_split_kernel(const dimsum_xattn_bwd_params_t p) {
     constexpr int EP = (HD + 31) / 32 * 32, EC = EP / 32, ET = (HD + 15) / 16;
     constexpr int RS = EP + 8;               // [query][e] rows of Q and dO
     constexpr int TS = kBQT + 8;             // [e][query slot] rows of Q^T and dO^T
-    __shared__ __attribute__((aligned(16))) unsigned short Qh[kBQT * RS], Ql[kBQT * RS], Gh[kBQT * RS], Gl[kBQT * RS];
-    __shared__ __attribute__((aligned(16))) unsigned short QTh[ET * 16 * TS], QTl[ET * 16 * TS], GTh[ET * 16 * TS], GTl[ET * 16 * TS];
-    __shared__ __attribute__((aligned(16))) float sL[kBQT], sD[kBQT];      // lse (log2 domain) and D of the tile's queries
+    constexpr int LO = F16 ? 0 : 1;
+    __shared__ __attribute__((aligned(16))) unsigned short Qh[kBQT * RS], Gh[kBQT * RS], QTh[ET * 16 * TS], GTh[ET * 16 * TS];
+    __shared__ __attribute__((aligned(16))) unsigned short Ql[LO * kBQT * RS + 8], Gl[LO * kBQT * RS + 8], QTl[LO * ET * 16 * TS + 8], GTl[LO * ET * 16 * TS + 8];
+    __shared__ __attribute__((aligned(16))) float sL[kBQT], sD[kBQT];      // lse (log2 domain; fp16 carrier: minus the row's shifts) and D of the tile's queries
+    __shared__ float sRed[4];
     static_assert((RS / 8) % 2 == 1 && (TS / 8) % 2 == 1, "odd number of 16-byte slots per row");
     auto flip = [](int row) { return (((row & 15) + 4) & 8); };      // slot-pair swap of rows 4-11 of a fragment (see the dq kernel)
 
@@ -520,13 +571,26 @@ __global__ __launch_bounds__(256, (HD > 64 || KT == 2) ? 2 : 3) void xattn_bwd_d
     const int64_t stat0 = (((int64_t)b * ndir + dir) * H + h) * L;
     const float *lse = reinterpret_cast<const float *>(p.fwd.lse_ptr) + stat0;
     const float *dlt = reinterpret_cast<const float *>(p.delta_ptr) + stat0;
+    const float *gsc = dlt + (int64_t)p.fwd.batch * ndir * H * L;        // fp16 carrier: the dO row scales the dq kernel left
+
+    // fp16 carrier: g_min = the scale of this (batch, head, direction)'s largest gradient row
+    float gsmin = 1.f;
+    if constexpr (F16) {
+        float m = 3.0e38f;
+        for (int i = tid; i < L; i += 256) m = fminf(m, gsc[i]);
+#pragma unroll
+        for (int o = 32; o; o >>= 1) m = fminf(m, __shfl_xor(m, o));
+        if (lane == 0) sRed[wave] = m;
+        __syncthreads();
+        gsmin = fminf(fminf(sRed[0], sRed[1]), fminf(sRed[2], sRed[3]));
+    }
 
     const int ki = lane & 15, kg = lane >> 4;
     const float kscale = p.fwd.scale * kLog2e;
     // K^T (scaled) and V^T fragments of this lane's keys (B operands): chunk c, slots j <-> e = 32c + 8 kg + j
     int k_tok[KT];
     bool key_live[KT];
-    u4v kh[KT][EC], kl[KT][EC], vh[KT][EC], vl[KT][EC];
+    Frag<F16> kf[KT][EC], vf[KT][EC];
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
         k_tok[t] = kblk * (64 * KT) + (wave * KT + t) * 16 + ki;
@@ -544,7 +608,7 @@ __global__ __launch_bounds__(256, (HD > 64 || KT == 2) ? 2 : 3) void xattn_bwd_d
                 vv[4 * half + 0] = v4.x; vv[4 * half + 1] = v4.y; vv[4 * half + 2] = v4.z; vv[4 * half + 3] = v4.w;
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { split2(kv[2 * i], kv[2 * i + 1], kh[t][c].w[i], kl[t][c].w[i]); split2(vv[2 * i], vv[2 * i + 1], vh[t][c].w[i], vl[t][c].w[i]); }
+            for (int i = 0; i < 4; ++i) { frag_put2<F16>(kf[t][c], i, kv[2 * i], kv[2 * i + 1]); frag_put2<F16>(vf[t][c], i, vv[2 * i], vv[2 * i + 1]); }
         }
     }
     f4 dk[KT][ET], dv[KT][ET];
@@ -553,63 +617,82 @@ __global__ __launch_bounds__(256, (HD > 64 || KT == 2) ? 2 : 3) void xattn_bwd_d
 #pragma unroll
         for (int e = 0; e < ET; ++e) { dk[t][e] = f4{0.f, 0.f, 0.f, 0.f}; dv[t][e] = f4{0.f, 0.f, 0.f, 0.f}; }
     if constexpr (EP > HD) {
-        for (int i = tid; i < kBQT * (EP - HD); i += 256) { const int q = i / (EP - HD), e = (HD + i % (EP - HD)) ^ flip(q); Qh[q * RS + e] = 0; Ql[q * RS + e] = 0; Gh[q * RS + e] = 0; Gl[q * RS + e] = 0; }
+        for (int i = tid; i < kBQT * (EP - HD); i += 256) { const int q = i / (EP - HD), e = (HD + i % (EP - HD)) ^ flip(q); img_zero<F16>(Qh, Ql, q * RS + e); img_zero<F16>(Gh, Gl, q * RS + e); }
     }
     if constexpr (ET * 16 > HD) {
-        for (int i = tid; i < (ET * 16 - HD) * kBQT; i += 256) { const int e = HD + i / kBQT, q = (i % kBQT) ^ flip(e); QTh[e * TS + q] = 0; QTl[e * TS + q] = 0; GTh[e * TS + q] = 0; GTl[e * TS + q] = 0; }
+        for (int i = tid; i < (ET * 16 - HD) * kBQT; i += 256) { const int e = HD + i / kBQT, q = (i % kBQT) ^ flip(e); img_zero<F16>(QTh, QTl, e * TS + q); img_zero<F16>(GTh, GTl, e * TS + q); }
     }
 
     // The Q / dO rows of the NEXT query tile are requested right after the current tile has been staged, so their HBM
     // latency hides under the tile's MFMA work (register-staged prefetch: one thread = 2 queries x 4 e, kIt items per tile).
     constexpr int kItems = (kBQT / 2) * (HD / 4), kIt = (kItems + 255) / 256;
-    float4 pqa[kIt], pqb[kIt], pga[kIt], pgb[kIt];
+    // (raw loads, the bias is added when the tile is staged: see the dq kernel; the tile's per-query statistics -- lse, D, the dO row
+    // scale -- ride along in the first kBQT threads)
+    float4 pqa[kIt], pqb[kIt], pga[kIt], pgb[kIt], qbias[kIt];
+    float2 pgs[kIt];
+    float pl = 0.f, pd = 0.f, pg = 1.f;
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+        const int i = min(tid + it * 256, kItems - 1), e4 = i % (HD / 4);
+        qbias[it] = s.qb ? *reinterpret_cast<const float4 *>(s.qb + e4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     auto fetch = [&](int q0) {
 #pragma unroll
         for (int it = 0; it < kIt; ++it) {
             const int i = min(tid + it * 256, kItems - 1);
             const int qp = i / (HD / 4), e4 = i - qp * (HD / 4), q = 2 * qp;
             const int tok0 = min(q0 + q, L - 1), tok1 = min(q0 + q + 1, L - 1);
-            pqa[it] = ld_bias4(s.q + (int64_t)tok0 * ts, s.qb, e4 * 4); pqb[it] = ld_bias4(s.q + (int64_t)tok1 * ts, s.qb, e4 * 4);
+            pqa[it] = *reinterpret_cast<const float4 *>(s.q + (int64_t)tok0 * ts + e4 * 4); pqb[it] = *reinterpret_cast<const float4 *>(s.q + (int64_t)tok1 * ts + e4 * 4);
             pga[it] = *reinterpret_cast<const float4 *>(dobase + (int64_t)tok0 * p.fwd.out_token_stride + e4 * 4);
             pgb[it] = *reinterpret_cast<const float4 *>(dobase + (int64_t)tok1 * p.fwd.out_token_stride + e4 * 4);
+            if constexpr (F16) pgs[it] = make_float2(gsc[tok0], gsc[tok1]);
+        }
+        if (tid < kBQT) {
+            const int tok = min(q0 + tid, L - 1);
+            pl = lse[tok]; pd = dlt[tok];
+            if constexpr (F16) pg = gsc[tok];
         }
     };
     fetch(0);
 
     for (int q0 = 0; q0 < L; q0 += kBQT) {
         __syncthreads();
-        // ---- stage Q, dO [query][e] and Q^T, dO^T [e][slot(query)] as hi / lo bf16 images; one thread = 2 queries x 4 e --------
+        // ---- stage Q, dO [query][e] and Q^T, dO^T [e][slot(query)] as operand images; one thread = 2 queries x 4 e ---------------
 #pragma unroll
         for (int it = 0; it < kIt; ++it) {
             const int i = tid + it * 256;
             if (i >= kItems) break;
             const int qp = i / (HD / 4), e4 = i - qp * (HD / 4), q = 2 * qp;
-            const float4 qa = pqa[it], qb = pqb[it], ga = pga[it], gb = pgb[it];
-            unsigned h0, l0, h1, l1;
+            const float4 qa = add4(pqa[it], qbias[it]), qb = add4(pqb[it], qbias[it]);
+            float4 ga = pga[it], gb = pgb[it];
+            if constexpr (F16) {                                     // dO rows in their scaled domain (exact)
+                const float s0 = pgs[it].x, s1 = pgs[it].y;
+                ga.x *= s0; ga.y *= s0; ga.z *= s0; ga.w *= s0; gb.x *= s1; gb.y *= s1; gb.z *= s1; gb.w *= s1;
+            }
             const int qe = (e4 * 4) ^ flip(q);                      // q even: q and q + 1 are rows of the same kind
-            split2(qa.x, qa.y, h0, l0); split2(qa.z, qa.w, h1, l1);
-            *reinterpret_cast<uint2 *>(&Qh[q * RS + qe]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Ql[q * RS + qe]) = make_uint2(l0, l1);
-            split2(qb.x, qb.y, h0, l0); split2(qb.z, qb.w, h1, l1);
-            *reinterpret_cast<uint2 *>(&Qh[(q + 1) * RS + qe]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Ql[(q + 1) * RS + qe]) = make_uint2(l0, l1);
-            split2(ga.x, ga.y, h0, l0); split2(ga.z, ga.w, h1, l1);
-            *reinterpret_cast<uint2 *>(&Gh[q * RS + qe]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Gl[q * RS + qe]) = make_uint2(l0, l1);
-            split2(gb.x, gb.y, h0, l0); split2(gb.z, gb.w, h1, l1);
-            *reinterpret_cast<uint2 *>(&Gh[(q + 1) * RS + qe]) = make_uint2(h0, h1); *reinterpret_cast<uint2 *>(&Gl[(q + 1) * RS + qe]) = make_uint2(l0, l1);
+            img_st4<F16>(Qh, Ql, q * RS + qe, qa); img_st4<F16>(Qh, Ql, (q + 1) * RS + qe, qb);
+            img_st4<F16>(Gh, Gl, q * RS + qe, ga); img_st4<F16>(Gh, Gl, (q + 1) * RS + qe, gb);
             const int pos = cslot(q) ^ flip(e4 * 4);                // rows e4*4 .. +3 of Q^T / dO^T: one kind
             const float qa4[4] = {qa.x, qa.y, qa.z, qa.w}, qb4[4] = {qb.x, qb.y, qb.z, qb.w};
             const float ga4[4] = {ga.x, ga.y, ga.z, ga.w}, gb4[4] = {gb.x, gb.y, gb.z, gb.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                split2(qa4[e], qb4[e], h0, l0);
-                *reinterpret_cast<unsigned *>(&QTh[(e4 * 4 + e) * TS + pos]) = h0; *reinterpret_cast<unsigned *>(&QTl[(e4 * 4 + e) * TS + pos]) = l0;
-                split2(ga4[e], gb4[e], h0, l0);
-                *reinterpret_cast<unsigned *>(&GTh[(e4 * 4 + e) * TS + pos]) = h0; *reinterpret_cast<unsigned *>(&GTl[(e4 * 4 + e) * TS + pos]) = l0;
+                img_st2<F16>(QTh, QTl, (e4 * 4 + e) * TS + pos, qa4[e], qb4[e]);
+                img_st2<F16>(GTh, GTl, (e4 * 4 + e) * TS + pos, ga4[e], gb4[e]);
             }
         }
         if (tid < kBQT) {
-            const int tok = q0 + tid;
-            sL[tid] = tok < L ? lse[tok] * kLog2e : 1e30f;       // queries beyond L: P = exp2(S - inf) = 0
-            sD[tid] = tok < L ? dlt[tok] : 0.f;
+            const bool live = q0 + tid < L;
+            float l = live ? pl * kLog2e : 1e30f;                // queries beyond L: P = exp2(S - inf) = 0
+            float d = live ? pd : 0.f;
+            if constexpr (F16) {
+                // P of this query travels as 2^kPShift (g_min / g) P: both factors are powers of two and live in the log-sum-exp
+                const unsigned ef = (__float_as_uint(gsmin / pg) >> 23) & 0xffu;      // g_min / g is exact; more than 2^126 apart: the row adds nothing
+                l = ef == 0u ? 1e30f : l - (float)((int)ef - 127 + kPShift);
+                d *= pg;
+            }
+            sL[tid] = l;
+            sD[tid] = d;
         }
         __syncthreads();
         if (q0 + kBQT < L) fetch(q0 + kBQT);
@@ -619,83 +702,91 @@ __global__ __launch_bounds__(256, (HD > 64 || KT == 2) ? 2 : 3) void xattn_bwd_d
         f4 pp[KT][2], dsv[KT][2];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
+            // the accumulators start at -lse and -D of their rows (queries): the MFMA chains end in S - lse and dP - D
+            const float4 l4 = *reinterpret_cast<const float4 *>(&sL[qt * 16 + kg * 4]);
+            const float4 d4 = *reinterpret_cast<const float4 *>(&sD[qt * 16 + kg * 4]);
             f4 sacc[KT], pacc[KT];
 #pragma unroll
-            for (int t = 0; t < KT; ++t) { sacc[t] = f4{0.f, 0.f, 0.f, 0.f}; pacc[t] = f4{0.f, 0.f, 0.f, 0.f}; }
+            for (int t = 0; t < KT; ++t) { sacc[t] = f4{-l4.x, -l4.y, -l4.z, -l4.w}; pacc[t] = f4{-d4.x, -d4.y, -d4.z, -d4.w}; }
             const int qrow = (qt * 16 + ki) * RS + ((8 * kg) ^ flip(ki));
 #pragma unroll
             for (int c = 0; c < EC; ++c) {
-                const u4v qh_ = *reinterpret_cast<const u4v *>(&Qh[qrow + 32 * c]), ql_ = *reinterpret_cast<const u4v *>(&Ql[qrow + 32 * c]);
-                const u4v gh_ = *reinterpret_cast<const u4v *>(&Gh[qrow + 32 * c]), gl_ = *reinterpret_cast<const u4v *>(&Gl[qrow + 32 * c]);
+                const Frag<F16> qf = frag_ld<F16>(Qh, Ql, qrow + 32 * c), gf = frag_ld<F16>(Gh, Gl, qrow + 32 * c);
 #pragma unroll
                 for (int t = 0; t < KT; ++t) {
-                    sacc[t] = mfma_split(qh_, ql_, kh[t][c], kl[t][c], sacc[t]);
-                    pacc[t] = mfma_split(gh_, gl_, vh[t][c], vl[t][c], pacc[t]);
+                    sacc[t] = frag_mfma<F16>(qf, kf[t][c], sacc[t]);
+                    pacc[t] = frag_mfma<F16>(gf, vf[t][c], pacc[t]);
                 }
             }
-            const float4 l4 = *reinterpret_cast<const float4 *>(&sL[qt * 16 + kg * 4]);
-            const float4 d4 = *reinterpret_cast<const float4 *>(&sD[qt * 16 + kg * 4]);
+            // (keys beyond L -- clamped loads -- fill columns of dK^T / dV^T that are never stored: no mask)
 #pragma unroll
-            for (int t = 0; t < KT; ++t) {
-                pp[t][qt][0] = key_live[t] ? fast_exp2(sacc[t][0] - l4.x) : 0.f; pp[t][qt][1] = key_live[t] ? fast_exp2(sacc[t][1] - l4.y) : 0.f;
-                pp[t][qt][2] = key_live[t] ? fast_exp2(sacc[t][2] - l4.z) : 0.f; pp[t][qt][3] = key_live[t] ? fast_exp2(sacc[t][3] - l4.w) : 0.f;
-                dsv[t][qt][0] = pp[t][qt][0] * (pacc[t][0] - d4.x); dsv[t][qt][1] = pp[t][qt][1] * (pacc[t][1] - d4.y);
-                dsv[t][qt][2] = pp[t][qt][2] * (pacc[t][2] - d4.z); dsv[t][qt][3] = pp[t][qt][3] * (pacc[t][3] - d4.w);
-            }
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pp[t][qt][r] = fast_exp2(sacc[t][r]);
+                    dsv[t][qt][r] = pp[t][qt][r] * pacc[t][r];
+                }
         }
         // ---- dV^T += dO^T P, dK^T += Q^T dS: ONE 32-deep chunk whose slots are the tile's queries --------------------------------
-        u4v ph[KT], pl[KT], sh_[KT], sl_[KT];
+        Frag<F16> pf[KT], sf[KT];
 #pragma unroll
-        for (int t = 0; t < KT; ++t) { split_c2(pp[t][0], pp[t][1], ph[t], pl[t]); split_c2(dsv[t][0], dsv[t][1], sh_[t], sl_[t]); }
+        for (int t = 0; t < KT; ++t) { pf[t] = frag_c2<F16>(pp[t][0], pp[t][1]); sf[t] = frag_c2<F16>(dsv[t][0], dsv[t][1]); }
 #pragma unroll
         for (int e = 0; e < ET; ++e) {
             const int row = (e * 16 + ki) * TS + ((8 * kg) ^ flip(ki));
-            const u4v gth = *reinterpret_cast<const u4v *>(&GTh[row]), gtl = *reinterpret_cast<const u4v *>(&GTl[row]);
-            const u4v qth = *reinterpret_cast<const u4v *>(&QTh[row]), qtl = *reinterpret_cast<const u4v *>(&QTl[row]);
+            const Frag<F16> gt = frag_ld<F16>(GTh, GTl, row), qt_ = frag_ld<F16>(QTh, QTl, row);
 #pragma unroll
             for (int t = 0; t < KT; ++t) {
-                dv[t][e] = mfma_split(gth, gtl, ph[t], pl[t], dv[t][e]);
-                dk[t][e] = mfma_split(qth, qtl, sh_[t], sl_[t], dk[t][e]);
+                dv[t][e] = frag_mfma<F16>(gt, pf[t], dv[t][e]);
+                dk[t][e] = frag_mfma<F16>(qt_, sf[t], dk[t][e]);
             }
         }
     }
+    const float unscale = F16 ? (1.f / gsmin) * (1.f / (float)(1 << kPShift)) : 1.f;        // exact
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
         if (!key_live[t]) continue;
         float *dkd = s.dk + (int64_t)k_tok[t] * dts, *dvd = s.dv + (int64_t)k_tok[t] * dts;
-        const float sc = p.fwd.scale;
+        const float sc = p.fwd.scale * unscale;
 #pragma unroll
         for (int e = 0; e < ET; ++e) {
             const int e0 = e * 16 + kg * 4;
             if (e0 < HD) {
                 *reinterpret_cast<float4 *>(dkd + e0) = make_float4(dk[t][e][0] * sc, dk[t][e][1] * sc, dk[t][e][2] * sc, dk[t][e][3] * sc);
-                *reinterpret_cast<float4 *>(dvd + e0) = make_float4(dv[t][e][0], dv[t][e][1], dv[t][e][2], dv[t][e][3]);
+                *reinterpret_cast<float4 *>(dvd + e0) = make_float4(dv[t][e][0] * unscale, dv[t][e][1] * unscale, dv[t][e][2] * unscale, dv[t][e][3] * unscale);
             }
         }
     }
+}
+
+template <int HD, bool F16>
+static int launch_xbwd_mc(const dimsum_xattn_bwd_params_t &p, hipStream_t s) {
+    const int64_t nblk = (int64_t)p.fwd.batch * p.fwd.heads * (p.fwd.n_dirs == 1 ? 1 : 2) * ((p.fwd.seqlen + 63) / 64);
+    const int64_t nq = (int64_t)p.fwd.batch * p.fwd.heads * (p.fwd.n_dirs == 1 ? 1 : 2) * ((p.fwd.seqlen + kSQW - 1) / kSQW);
+    static const bool qt2 = getenv("DIMSUM_XATTN_BWD_QT2") && atoi(getenv("DIMSUM_XATTN_BWD_QT2")) != 0;      // (experiment)
+    if constexpr (HD <= 32) hipLaunchKernelGGL((xattn_bwd_dq_split_kernel<HD, 2, F16>), dim3((unsigned)nq), dim3(256), 0, s, p);
+    else if (F16 && HD <= 64 && qt2) hipLaunchKernelGGL((xattn_bwd_dq_split_kernel<HD, (F16 && HD <= 64) ? 2 : 1, F16>), dim3((unsigned)nq), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((xattn_bwd_dq_split_kernel<HD, 1, F16>), dim3((unsigned)nq), dim3(512), 0, s, p);
+    if (launch_status() != DIMSUM_OK) return DIMSUM_ERR_LAUNCH;
+    // two key tiles per wave (128 keys per workgroup) halve the per-key staging work; short sequences and the wide head keep one
+    bool two = false;
+    if constexpr (HD <= 64) {
+        if (p.fwd.seqlen >= 128) {
+            const int64_t nk2 = (int64_t)p.fwd.batch * p.fwd.heads * (p.fwd.n_dirs == 1 ? 1 : 2) * ((p.fwd.seqlen + 127) / 128);
+            hipLaunchKernelGGL((xattn_bwd_dkv_split_kernel<HD, 2, F16>), dim3((unsigned)nk2), dim3(256), 0, s, p);
+            two = true;
+        }
+    }
+    if (!two) hipLaunchKernelGGL((xattn_bwd_dkv_split_kernel<HD, 1, F16>), dim3((unsigned)nblk), dim3(256), 0, s, p);
+    return launch_status();
 }
 
 template <int HD>
 static int launch_xbwd(const dimsum_xattn_bwd_params_t &p, hipStream_t s) {
     const int64_t nblk = (int64_t)p.fwd.batch * p.fwd.heads * (p.fwd.n_dirs == 1 ? 1 : 2) * ((p.fwd.seqlen + 63) / 64);
     if (nblk > 0x7fffffff) return DIMSUM_ERR_SHAPE;
-    if (p.fwd.precision == 1) {
-        const int64_t nq = (int64_t)p.fwd.batch * p.fwd.heads * (p.fwd.n_dirs == 1 ? 1 : 2) * ((p.fwd.seqlen + kSQW - 1) / kSQW);
-        if constexpr (HD <= 32) hipLaunchKernelGGL((xattn_bwd_dq_split_kernel<HD, 2>), dim3((unsigned)nq), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((xattn_bwd_dq_split_kernel<HD, 1>), dim3((unsigned)nq), dim3(512), 0, s, p);
-        if (launch_status() != DIMSUM_OK) return DIMSUM_ERR_LAUNCH;
-        // two key tiles per wave (128 keys per workgroup) halve the per-key staging work; short sequences and the wide head keep one
-        bool two = false;
-        if constexpr (HD <= 64) {
-            if (p.fwd.seqlen >= 128) {
-                const int64_t nk2 = (int64_t)p.fwd.batch * p.fwd.heads * (p.fwd.n_dirs == 1 ? 1 : 2) * ((p.fwd.seqlen + 127) / 128);
-                hipLaunchKernelGGL((xattn_bwd_dkv_split_kernel<HD, 2>), dim3((unsigned)nk2), dim3(256), 0, s, p);
-                two = true;
-            }
-        }
-        if (!two) hipLaunchKernelGGL((xattn_bwd_dkv_split_kernel<HD, 1>), dim3((unsigned)nblk), dim3(256), 0, s, p);
-        return launch_status();
-    }
+    if (p.fwd.precision == 2) return launch_xbwd_mc<HD, true>(p, s);
+    if (p.fwd.precision == 1) return launch_xbwd_mc<HD, false>(p, s);
     hipLaunchKernelGGL(xattn_bwd_dq_kernel<HD>, dim3((unsigned)nblk), dim3(256), 0, s, p);
     if (launch_status() != DIMSUM_OK) return DIMSUM_ERR_LAUNCH;
     hipLaunchKernelGGL(xattn_bwd_dkv_kernel<HD>, dim3((unsigned)nblk), dim3(256), 0, s, p);
@@ -714,7 +805,8 @@ extern "C" int dimsum_xattn_fusion_bwd(const dimsum_xattn_bwd_params_t *p, void 
         return DIMSUM_ERR_NULL;
     const dimsum_xattn_params_t &f = p->fwd;
     if (f.batch < 0 || f.seqlen <= 0 || f.heads <= 0 || (f.n_dirs != 0 && f.n_dirs != 1 && f.n_dirs != 2)) return DIMSUM_ERR_SHAPE;
-    if (f.precision != 0 && f.precision != 1) return DIMSUM_ERR_SHAPE;
+    if (f.precision != 0 && f.precision != 1 && f.precision != 2) return DIMSUM_ERR_SHAPE;
+    if (f.precision == 2 && f.qkv_f16 != 0) return DIMSUM_ERR_SHAPE;      // the backward reads the fp32 qkv tensors
     if (!self_attn && (f.bias1_ptr == nullptr) != (f.bias2_ptr == nullptr)) return DIMSUM_ERR_NULL;
     const void *ptrs[] = {f.qkv1_ptr, self_attn ? nullptr : f.qkv2_ptr, f.out_ptr, p->dout_ptr, p->dqkv1_ptr, self_attn ? nullptr : p->dqkv2_ptr,
                           f.bias1_ptr, self_attn ? nullptr : f.bias2_ptr};

@@ -21,13 +21,7 @@
 
 namespace dimsum {
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ f16x8 as_f16x8(const u4v &v) { return __builtin_bit_cast(f16x8, v); }
-__device__ __forceinline__ unsigned pack_h2(float a, float b) {
-    const __half2 h = __floats2half2_rn(a, b);
-    return __builtin_bit_cast(unsigned, h);
-}
-
+// (f16x8, as_f16x8, pack_h2: xattn_common.hpp)
 constexpr int kKT16 = 64;        // keys per tile
 constexpr int kQW16 = 16;        // queries per 16-query tile
 

@@ -705,6 +705,15 @@ def split3_train_enabled(x, weight):
     return True
 
 
+def attn_bwd_f16_enabled(qkv):
+    """the attention backward pair (csrc/xattn_fusion_bwd.hip) on the single-product fp16 carrier: the "f16s" policy's training arithmetic
+    (split3_train_enabled's switches, no row threshold: the kernels are the same at every size)"""
+    import os
+    return bool(_policy == "f16s" and torch.backends.cuda.matmul.allow_tf32 and os.environ.get("DIMSUM_F16S_TRAIN", "1") != "0"
+                and os.environ.get("DIMSUM_SPLIT3_TRAIN", "1") != "0" and os.environ.get("DIMSUM_SPLIT3", "1") != "0"
+                and qkv.is_cuda and qkv.dtype == torch.float32 and not torch.is_autocast_enabled("cuda"))
+
+
 def weight_f16s_train(weight, want_l1=False):
     """training: the scaled-fp16 image of a weight, rebuilt on every call (the optimizer changes it between steps) -> F16Image [, l1]"""
     from . import native

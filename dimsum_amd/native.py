@@ -1152,9 +1152,11 @@ def xattn_fusion_fwd(qkv1, qkv2, heads, need_lse=False, bias1=None, bias2=None, 
     return (out, lse) if need_lse else out
 
 
-def xattn_fusion_bwd(qkv1, qkv2, out, lse, dout, heads, bias1=None, bias2=None, split_bf16=None):
+def xattn_fusion_bwd(qkv1, qkv2, out, lse, dout, heads, bias1=None, bias2=None, split_bf16=None, f16=False):
     """backward of xattn_fusion_fwd -> (dqkv1, dqkv2), each (B, L, 3*heads*hd); `out`, `lse` are the forward's results.
-    qkv2 = None (self-attention): -> (dqkv1, None)."""
+    qkv2 = None (self-attention): -> (dqkv1, None).
+    f16: ONE fp16 MFMA product per element (precision 2: the TF32-equivalent carrier of the "f16s" policy; dout rows scaled by exact powers of
+    two inside the kernels, csrc/xattn_fusion_bwd.hip) instead of the three split-bf16 products."""
     self_attn = qkv2 is None
     _gpu(qkv1, qkv2, out, lse, dout, bias1, bias2)
     B, L, W = qkv1.shape
@@ -1169,7 +1171,7 @@ def xattn_fusion_bwd(qkv1, qkv2, out, lse, dout, heads, bias1=None, bias2=None, 
     _check(self_attn or (bias1 is None) == (bias2 is None), "xattn_fusion_bwd: pass both biases or none")
     dqkv1 = torch.empty((B, L, W), device=qkv1.device, dtype=torch.float32)
     dqkv2 = None if self_attn else torch.empty((B, L, W), device=qkv1.device, dtype=torch.float32)
-    delta = torch.empty((B, nd, heads, L), device=qkv1.device, dtype=torch.float32)
+    delta = torch.empty((2 if f16 else 1, B, nd, heads, L), device=qkv1.device, dtype=torch.float32)      # D rows (+ the dout row scales, f16)
     if B > 0:
         Q = _lib.XattnBwdParams()
         P = Q.fwd
@@ -1180,7 +1182,7 @@ def xattn_fusion_bwd(qkv1, qkv2, out, lse, dout, heads, bias1=None, bias2=None, 
         P.bias1_ptr, P.bias2_ptr = _ptr(bias1), _ptr(bias2)
         if split_bf16 is None:                    # same policy switch as the forward and the library GEMMs
             split_bf16 = bool(torch.backends.cuda.matmul.allow_tf32)
-        P.precision = 1 if split_bf16 else 0
+        P.precision = 2 if f16 else (1 if split_bf16 else 0)
         Q.dqkv_batch_stride, Q.dqkv_token_stride = dqkv1.stride(0), dqkv1.stride(1)
         Q.dout_ptr, Q.dqkv1_ptr, Q.dqkv2_ptr, Q.delta_ptr = _ptr(dout), _ptr(dqkv1), _ptr(dqkv2), _ptr(delta)
         with torch.cuda.device(qkv1.device):

@@ -390,7 +390,7 @@ typedef struct {
     void *out_ptr, *lse_ptr;
     const void *bias1_ptr, *bias2_ptr;   /* optional (3*heads*hd) f32: the qkv Linear biases, added while q / k / v are
                                             fetched, so that the qkv GEMMs can run without a bias epilogue */
-    int32_t precision;  /* forward only. 0: exact fp32 MFMA (v_mfma_f32_16x16x4_f32). 1: split-bf16 -- every fp32 operand
+    int32_t precision;  /* 0: exact fp32 MFMA (v_mfma_f32_16x16x4_f32). 1: split-bf16 -- every fp32 operand
                            x = hi + lo (two bf16), products hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_bf16 with fp32
                            accumulation, ~1e-5 relative: the same arithmetic hipBLASLt uses for the reference's
                            torch.backends.cuda.matmul.allow_tf32 = True policy (train.py:20-21) on gfx950 */
@@ -416,7 +416,13 @@ int dimsum_xattn_fusion_fwd(const dimsum_xattn_params_t *p, void *stream);
  *   fwd      : the forward's operands; out_ptr = the forward's `out`, lse_ptr = its saved log-sum-exp (both required)
  *   dout     : (batch, L, 2*heads*hd) f32, strides like `out`
  *   dqkv1/2  : (batch, L, 3*heads*hd) f32, fully overwritten (direction 0 -> dq1, dk2, dv2; direction 1 -> dq2, dk1, dv1)
- *   delta    : (batch, 2, heads, L) f32 scratch (row sums of dout o out) */
+ *   delta    : (batch, 2, heads, L) f32 scratch (row sums of dout o out); TWICE that under fwd.precision == 2
+ *   fwd.precision: 0 exact fp32 MFMA, 1 split-bf16 (three products), 2 = ONE fp16 product per element (qkv_f16 must be 0: the fp32 qkv
+ *                  tensors are read). Under 2 q (times scale), k, v go to fp16 as they are (|.| <= 65504); every dout row (one query of
+ *                  one head) is scaled by an exact power of two that brings its maximum to [2^-5, 2^-4), D with it, P travels as 2^8 P, and
+ *                  dq is unscaled on store; in the sums over queries (dk, dv) P also carries g_min / g_q <= 1, so that all rows enter
+ *                  at the scale of the (batch, head, direction)'s largest gradient row (the second half of `delta` carries the row
+ *                  scales from the dq kernel to the dk / dv kernel). Range: max|v| <= 32 at head_dim 64 in the worst case. */
 typedef struct {
     uint32_t struct_size;   /* sizeof(dimsum_xattn_bwd_params_t) */
     uint32_t reserved;      /* 0 */

@@ -292,3 +292,145 @@ def test_linearity_in_v_at_full_size(split):
     rhs = 2 * f(a1, b1) - 3 * f(a2, b2)
     err, scale = (lhs - rhs).abs().max().item(), rhs.abs().max().item()
     assert err <= (5e-5 if split else 2e-5) * scale, (err, scale)
+
+
+# ---- the backward pair on the single-product fp16 carrier (precision 2; the "f16s" policy's training arithmetic) -----------------------
+def _attn_backward_f64(q1, q2, b1, b2, dout, heads, rnd=None):
+    """dqkv1, dqkv2 of the fusion core written out matmul by matmul in float64 (attention_fusion.py:64-79 and its adjoint); `rnd` rounds the
+    operands of every matmul first (the reference's allow_tf32 arithmetic when rnd = round-to-TF32)."""
+    B, L, W = q1.shape
+    hd = W // (3 * heads)
+    r = (lambda t: t) if rnd is None else (lambda t: rnd(t.float()).double())
+
+    def split(t, bb):
+        t = t.double() if bb is None else t.double() + bb.double()
+        return t.reshape(B, L, 3, heads, hd).permute(2, 0, 3, 1, 4).unbind(0)        # (B, heads, L, hd) each
+    (qa, ka, va), (qb, kb, vb) = split(q1, b1), split(q2 if q2 is not None else q1, b2 if q2 is not None else b1)
+    dirs = [(qa, kb, vb), (qb, ka, va)] if q2 is not None else [(qa, ka, va)]
+    C = heads * hd
+    grads = []
+    for d, (q, k, v) in enumerate(dirs):
+        do = dout.double()[..., d * C:(d + 1) * C].reshape(B, L, heads, hd).permute(0, 2, 1, 3)
+        S = r(q) @ r(k).transpose(-1, -2) * hd ** -0.5
+        P = torch.softmax(S, dim=-1)
+        O = r(P) @ r(v)
+        dP = r(do) @ r(v).transpose(-1, -2)
+        dS = P * (dP - (do * O).sum(-1, keepdim=True))
+        grads.append((r(dS) @ r(k) * hd ** -0.5, r(dS).transpose(-1, -2) @ r(q) * hd ** -0.5, r(P).transpose(-1, -2) @ r(do)))
+    rows = lambda t: t.permute(0, 2, 1, 3).reshape(B, L, C)
+    if q2 is None:
+        return torch.cat([rows(g) for g in grads[0]], dim=-1), None
+    (dqa, dkb, dvb), (dqb, dka, dva) = grads
+    return torch.cat((rows(dqa), rows(dka), rows(dva)), dim=-1), torch.cat((rows(dqb), rows(dkb), rows(dvb)), dim=-1)
+
+
+@pytest.mark.parametrize("B,L,heads,hd,self_attn", [(2, 256, 8, 64, False), (1, 1024, 8, 72, False), (2, 100, 4, 24, False), (2, 256, 8, 48, False),
+                                                    (1, 200, 4, 32, False), (1, 328, 8, 64, False), (2, 256, 16, 64, True), (1, 100, 4, 24, True)])
+def test_fp16_backward_vs_float64_and_emulated_tf32(B, L, heads, hd, self_attn):
+    """precision = 2 in the two backward kernels (ONE fp16 MFMA product per element, dout rows scaled by exact powers of two) against float64
+    math on the CPU, with the reference's own arithmetic as the yardstick: the same math with every matmul operand rounded to TF32
+    (train.py:20-21 turns TF32 on for the backward matmuls too; rounded to NEAREST -- the kinder reading of that hardware). Per tensor:
+    rms error <= 1.5 x and max error <= 2.5 x the emulated-TF32 run's (measured: rms 1.0 - 1.4 x, max 0.75 - 1.85 x: the kernels take P from
+    the forward's exact log-sum-exp, the emulation re-normalises its rounded scores), and within 5e-3 of the scale in absolute terms (emulated TF32 itself: up to 3.2e-3 on dq at 1024 tokens)."""
+    from dimsum_amd import native
+    from dimsum_amd.utils.tf32_emulation import round_tf32
+    W = 3 * heads * hd
+    gen = torch.Generator().manual_seed(11 * L + hd)
+    q1 = torch.randn(B, L, W, generator=gen)
+    q2 = None if self_attn else torch.randn(B, L, W, generator=gen)
+    b1 = torch.randn(W, generator=gen)
+    b2 = None if self_attn else torch.randn(W, generator=gen)
+    dout = torch.randn(B, L, (1 if self_attn else 2) * heads * hd, generator=gen) * 1e-3
+    ref = _attn_backward_f64(q1, q2, b1, b2, dout, heads)
+    emu = _attn_backward_f64(q1, q2, b1, b2, dout, heads, rnd=round_tf32)
+    c = lambda t: None if t is None else t.cuda()
+    out, lse = native.xattn_fusion_fwd(c(q1), c(q2), heads, need_lse=True, bias1=c(b1), bias2=c(b2), split_bf16=True)
+    got = native.xattn_fusion_bwd(c(q1), c(q2), out, lse, c(dout), heads, bias1=c(b1), bias2=c(b2), f16=True)
+    for name, g, r_, e in zip(("dqkv1", "dqkv2"), got, ref, emu):
+        if r_ is None:
+            assert g is None
+            continue
+        g = g.double().cpu()
+        assert torch.isfinite(g).all(), name
+        for part, sl in zip(("dq", "dk", "dv"), (slice(0, W // 3), slice(W // 3, 2 * W // 3), slice(2 * W // 3, W))):
+            eg, ee, sc = (g[..., sl] - r_[..., sl]), (e[..., sl] - r_[..., sl]), r_[..., sl].abs().max().item()
+            assert eg.abs().max().item() <= 2.5 * ee.abs().max().item() + 1e-6 * sc, (name, part, eg.abs().max().item(), ee.abs().max().item(), sc)
+            assert eg.pow(2).mean().sqrt().item() <= 1.5 * ee.pow(2).mean().sqrt().item() + 1e-7 * sc, (name, part, eg.pow(2).mean().sqrt().item(), ee.pow(2).mean().sqrt().item())
+            assert eg.abs().max().item() <= 5e-3 * sc, (name, part, eg.abs().max().item(), sc)
+
+
+@pytest.mark.parametrize("hd,L", [(64, 256), (72, 160), (24, 100)])
+def test_fp16_backward_takes_gradient_rows_of_any_magnitude(hd, L):
+    """What the row scales are for. (a) dout rows spread over 2^-60 .. 1 (and some exactly zero): every dq row keeps its own accuracy -- within
+    3 x the row's error under emulated TF32 (the reference's arithmetic, whose 8-bit exponent covers any row) + 5e-4 of the row's maximum;
+    a carrier without row scales would flush the small rows to zero, an error of the whole row. dk / dv, sums over rows of all magnitudes,
+    are held to the same yardstick per (batch, head). (b) Scaling dout by a power of two scales every result by exactly that power, bit
+    for bit, from 2^-100 to 2^+60: the kernels' arithmetic does not depend on the gradient's magnitude. (c) dout = 0 -> zeros."""
+    from dimsum_amd import native
+    from dimsum_amd.utils.tf32_emulation import round_tf32
+    B, heads = 2, 4
+    W = 3 * heads * hd
+    gen = torch.Generator().manual_seed(hd + L)
+    q1, q2 = torch.randn(B, L, W, generator=gen), torch.randn(B, L, W, generator=gen)
+    dout = torch.randn(B, L, 2 * heads * hd, generator=gen)
+    expo = torch.randint(-60, 1, (B, L, 2 * heads, 1), generator=gen).float()
+    live = (torch.rand(B, L, 2 * heads, 1, generator=gen) > 0.1).float()
+    dout = (dout.view(B, L, 2 * heads, hd) * torch.exp2(expo) * live).view(B, L, -1)
+    ref = _attn_backward_f64(q1, q2, None, None, dout, heads)
+    emu = _attn_backward_f64(q1, q2, None, None, dout, heads, rnd=round_tf32)
+    out, lse = native.xattn_fusion_fwd(q1.cuda(), q2.cuda(), heads, need_lse=True, split_bf16=True)
+    got = native.xattn_fusion_bwd(q1.cuda(), q2.cuda(), out, lse, dout.cuda(), heads, f16=True)
+    C = heads * hd
+    for name, g, r_, e_ in zip(("dqkv1", "dqkv2"), got, ref, emu):
+        g = g.double().cpu()
+        assert torch.isfinite(g).all(), name
+        dq, rq, eq = (t[..., :C].reshape(B, L, heads, hd) for t in (g, r_, e_))
+        rowmax = rq.abs().amax(-1)
+        err, err_emu = (dq - rq).abs().amax(-1), (eq - rq).abs().amax(-1)
+        bad = err > 3 * err_emu + 5e-4 * rowmax
+        assert not bad.any(), (name, "dq rows", int(bad.sum()), (err / rowmax.clamp_min(1e-300))[bad].max().item())
+        assert (rowmax > 0).sum() > 0.8 * rowmax.numel() and (rowmax[rowmax > 0].max() / rowmax[rowmax > 0].min()) > 2.0 ** 40      # the rows do span the range
+        for part, sl in (("dk", slice(C, 2 * C)), ("dv", slice(2 * C, 3 * C))):
+            # per (batch, head): the sums over queries are accurate relative to the head's own largest entry
+            a, b, e = (t[..., sl].reshape(B, L, heads, hd) for t in (g, r_, e_))
+            sc = b.abs().amax((1, 3))
+            err, err_emu = (a - b).abs().amax((1, 3)), (e - b).abs().amax((1, 3))
+            assert (err <= 3 * err_emu + 5e-4 * sc).all(), (name, part, (err / sc).max().item(), (err_emu / sc).max().item())
+    for k in (-100, 60):
+        s = 2.0 ** k
+        scaled = native.xattn_fusion_bwd(q1.cuda(), q2.cuda(), out, lse, (dout * s).cuda(), heads, f16=True)
+        for a, b in zip(scaled, got):
+            keep = (b.abs() * s > 1e-30) & (b.abs() * s < 1e30)       # away from fp32's own under / overflow
+            assert torch.equal(a[keep], (b * s)[keep]), k
+    zero = native.xattn_fusion_bwd(q1.cuda(), q2.cuda(), out, lse, torch.zeros_like(dout).cuda(), heads, f16=True)
+    assert all((z == 0).all() for z in zero)
+
+
+def test_fp16_backward_follows_the_training_policy():
+    """_XattnCoreFn picks the carrier from the matmul policy: three split-bf16 products by default, ONE fp16 product under gemm.set_policy("f16s")
+    (DIMSUM_F16S_TRAIN=0 keeps the three products)"""
+    from dimsum_amd import gemm, native
+    from dimsum_amd.attention_fusion import _XattnCoreFn
+    gen = torch.Generator().manual_seed(3)
+    W = 3 * 8 * 64
+    base1, base2 = torch.randn(2, 128, W, generator=gen).cuda(), torch.randn(2, 128, W, generator=gen).cuda()
+    dout = torch.randn(2, 128, 2 * 8 * 64, generator=gen).cuda()
+    seen = []
+    real = native.xattn_fusion_bwd
+    old_tf32 = torch.backends.cuda.matmul.allow_tf32
+
+    def spy(*a, **k):
+        seen.append(bool(k.get("f16")))
+        return real(*a, **k)
+    native.xattn_fusion_bwd = spy
+    try:
+        torch.backends.cuda.matmul.allow_tf32 = True
+        for policy, want in (("default", False), ("f16s", True)):
+            gemm.set_policy(policy)
+            a, b = base1.clone().requires_grad_(), base2.clone().requires_grad_()
+            _XattnCoreFn.apply(a, b, None, None, 8).backward(dout)
+            assert seen[-1] is want, (policy, seen)
+    finally:
+        native.xattn_fusion_bwd = real
+        gemm.set_policy("default")
+        torch.backends.cuda.matmul.allow_tf32 = old_tf32

@@ -43,7 +43,7 @@ def main():
     if a.bwd:
         out, lse = native.xattn_fusion_fwd(q1, q2, a.heads, need_lse=True, bias1=b1, bias2=b2, split_bf16=not a.exact)
         dout = torch.randn(out.shape, device="cuda", generator=g)
-        f = lambda: native.xattn_fusion_bwd(q1, q2, out, lse, dout, a.heads, bias1=b1, bias2=b2, split_bf16=not a.exact)
+        f = lambda: native.xattn_fusion_bwd(q1, q2, out, lse, dout, a.heads, bias1=b1, bias2=b2, split_bf16=not a.exact, f16=a.f16)      # --f16: ONE fp16 product (precision 2)
     for _ in range(3):
         f()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.iters + 1)]

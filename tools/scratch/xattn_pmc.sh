@@ -1,13 +1,13 @@
 #!/bin/bash
-# tools/scratch/xattn_pmc.sh [fwd|bwd] (GPU box): rocprofv3 counter passes (kernel-trace only, one counter set per run) over
+# tools/scratch/xattn_pmc.sh [fwd|bwd|bwd16] (GPU box): rocprofv3 counter passes (kernel-trace only, one counter set per run) over
 # tools/bench_xattn.py at the DiM-L/2 and DiM-XL/2-512 launch shapes of the split-bf16 attention kernels
-which=${1:-fwd}; extra=""; [ "$which" = bwd ] && extra="--bwd"
+which=${1:-fwd}; extra=""; [ "$which" = bwd ] && extra="--bwd"; mops=BF16; [ "$which" = bwd16 ] && extra="--bwd --f16" && mops=F16      # bwd16: the backward pair on the fp16 carrier
 out=gpurun_out/xattn_$which; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 python3 tools/bench_xattn.py $extra; python3 tools/bench_xattn.py $extra --B 64 --L 1024 --hd 72
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" \
-           "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_SALU"; do
+           "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_$mops SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_SALU"; do
   i=$((i+1))
   for shape in "l2 --B 256 --L 256 --hd 64" "xl --B 64 --L 1024 --hd 72"; do
     set -- $shape; tagn=$1; shift
