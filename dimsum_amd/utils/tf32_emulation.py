@@ -5,7 +5,9 @@ The reference runs its Linears under torch.backends.cuda.matmul.allow_tf32 = Tru
 hardware every matmul operand is rounded to TF32 (8-bit exponent, 10-bit mantissa), products are accumulated in fp32. `emulated_tf32()`
 reproduces that on any device: inside the context every torch matmul-class call (linear, matmul, mm, addmm, bmm, baddbmm) gets its
 floating-point operands rounded to 10 mantissa bits (round to nearest even -- the kinder reading of the hardware, which may truncate)
-and is then evaluated exactly in fp32 (allow_tf32 off). Kernels of libdimsum_hip.so are not torch ops and stay as they are."""
+and is then evaluated exactly in fp32 (allow_tf32 off). Kernels of libdimsum_hip.so are not torch ops and stay as they are -- except the
+attention core: the reference evaluates it with matmuls under the same flag (dimsum/attention_fusion.py:44-57), so inside the context
+`attention_fusion._XattnCoreFn` is replaced by the same math written out in torch with rounded matmul operands, forward and backward."""
 import contextlib
 
 import torch
@@ -46,6 +48,63 @@ class _EmuLinearFn(torch.autograd.Function):
         return dx, dw, db
 
 
+class _EmuXattnFn(torch.autograd.Function):
+    """the fusion core (attention_fusion.py:44-79: q * scale, q k^T, softmax, attn v; both directions, or self-attention with qkv2 = None) with
+    every matmul operand rounded to TF32, and its adjoint written out the same way -- same signature as attention_fusion._XattnCoreFn"""
+
+    @staticmethod
+    def _split(qkv, bias, heads):
+        B, L, W = qkv.shape
+        t = qkv if bias is None else qkv + bias
+        return t.reshape(B, L, 3, heads, W // (3 * heads)).permute(2, 0, 3, 1, 4).unbind(0)
+
+    @staticmethod
+    def _dirs(qkv1, qkv2, bias1, bias2, heads):
+        qa, ka, va = _EmuXattnFn._split(qkv1, bias1, heads)
+        if qkv2 is None:
+            return [(qa, ka, va)]
+        qb, kb, vb = _EmuXattnFn._split(qkv2, bias2, heads)
+        return [(qa, kb, vb), (qb, ka, va)]
+
+    @staticmethod
+    def forward(ctx, qkv1, qkv2, bias1, bias2, heads):
+        B, L, W = qkv1.shape
+        hd = W // (3 * heads)
+        outs, probs = [], []
+        for q, k, v in _EmuXattnFn._dirs(qkv1, qkv2, bias1, bias2, heads):
+            p = torch.softmax(torch.matmul(round_tf32(q * hd ** -0.5), round_tf32(k).transpose(-1, -2)), dim=-1)
+            outs.append(torch.matmul(round_tf32(p), round_tf32(v)))
+            probs.append(p)
+        ctx.heads = heads
+        ctx.save_for_backward(qkv1, qkv2, bias1, bias2, *probs, *outs)
+        return torch.cat([o.transpose(1, 2).reshape(B, L, heads * hd) for o in outs], dim=-1)
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv1, qkv2, bias1, bias2, *rest = ctx.saved_tensors
+        heads = ctx.heads
+        B, L, W = qkv1.shape
+        hd, C = W // (3 * heads), W // 3
+        dirs = _EmuXattnFn._dirs(qkv1, qkv2, bias1, bias2, heads)
+        probs, outs = rest[:len(dirs)], rest[len(dirs):]
+        rows = lambda t: t.permute(0, 2, 1, 3).reshape(B, L, C)
+        grads = []
+        for d, ((q, k, v), p, o) in enumerate(zip(dirs, probs, outs)):
+            do = dout[..., d * C:(d + 1) * C].reshape(B, L, heads, hd).permute(0, 2, 1, 3)
+            dp = torch.matmul(round_tf32(do), round_tf32(v).transpose(-1, -2))
+            ds = round_tf32(p * (dp - (do * o).sum(-1, keepdim=True)))
+            grads.append((torch.matmul(ds, round_tf32(k)) * hd ** -0.5, torch.matmul(ds.transpose(-1, -2), round_tf32(q * hd ** -0.5)),
+                          torch.matmul(round_tf32(p).transpose(-1, -2), round_tf32(do))))
+        if qkv2 is None:
+            d1, d2 = torch.cat([rows(g) for g in grads[0]], dim=-1), None
+        else:
+            (dqa, dkb, dvb), (dqb, dka, dva) = grads
+            d1, d2 = torch.cat((rows(dqa), rows(dka), rows(dva)), dim=-1), torch.cat((rows(dqb), rows(dkb), rows(dvb)), dim=-1)
+        db1 = d1.reshape(-1, W).sum(0) if bias1 is not None else None
+        db2 = d2.reshape(-1, W).sum(0) if (bias2 is not None and d2 is not None) else None
+        return d1, d2, db1, db2, None
+
+
 class _Tf32Mode(TorchFunctionMode):
     def __torch_function__(self, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
@@ -65,10 +124,13 @@ class _Tf32Mode(TorchFunctionMode):
 
 @contextlib.contextmanager
 def emulated_tf32():
-    old = torch.backends.cuda.matmul.allow_tf32
+    from .. import attention_fusion
+    old, core = torch.backends.cuda.matmul.allow_tf32, attention_fusion._XattnCoreFn
     torch.backends.cuda.matmul.allow_tf32 = False
+    attention_fusion._XattnCoreFn = _EmuXattnFn
     try:
         with _Tf32Mode():
             yield
     finally:
         torch.backends.cuda.matmul.allow_tf32 = old
+        attention_fusion._XattnCoreFn = core
