@@ -15,8 +15,6 @@
 // S and dP are recomputed in both (7 GEMM-equivalents instead of 5): cheaper on fp32 MFMA than contended fp32 atomics
 // on dq, and bitwise reproducible. All products are v_mfma_f32_16x16x4_f32 (exact fp32).
 // Optional qkv Linear biases are added while q / k / v are fetched, like in the forward.
-#include <stdlib.h>
-
 #include "xattn_common.hpp"
 
 namespace dimsum {
@@ -356,6 +354,30 @@ __global__ __launch_bounds__(kSQW / QT * 4, (QT == 1 && HD <= 64) ? 4 : 2) void 
     const int64_t ts = p.fwd.qkv_token_stride, dts = p.dqkv_token_stride;
     const int64_t nstat = (int64_t)p.fwd.batch * ndir * H * L;            // fp16 carrier: the row scales follow the D rows
 
+    // The K / V rows of the NEXT key tile are requested right after the current tile has been staged (register-staged
+    // prefetch: one thread = 2 keys x 4 e, kIt items per tile), so their HBM latency hides under the tile's MFMA work.
+    constexpr int kItems = (kBKT / 2) * (HD / 4), kIt = (kItems + NT - 1) / NT;
+    // (the loads stay RAW: adding the bias inside fetch would wait for the data there and expose the latency the prefetch is meant to
+    // hide -- the thread's bias values are loop constants, added when the tile is staged)
+    float4 pka[kIt], pkb[kIt], pva[kIt], pvb[kIt], kbias[kIt], vbias[kIt];
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+        const int i = min(tid + it * NT, kItems - 1), e4 = i % (HD / 4);
+        kbias[it] = s.kb ? *reinterpret_cast<const float4 *>(s.kb + e4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        vbias[it] = s.vb ? *reinterpret_cast<const float4 *>(s.vb + e4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int i = min(tid + it * NT, kItems - 1);
+            const int kp = i / (HD / 4), e4 = i - kp * (HD / 4), key = 2 * kp;
+            const int tok0 = min(k0 + key, L - 1), tok1 = min(k0 + key + 1, L - 1);
+            pka[it] = *reinterpret_cast<const float4 *>(s.k + (int64_t)tok0 * ts + e4 * 4); pkb[it] = *reinterpret_cast<const float4 *>(s.k + (int64_t)tok1 * ts + e4 * 4);
+            pva[it] = *reinterpret_cast<const float4 *>(s.v + (int64_t)tok0 * ts + e4 * 4); pvb[it] = *reinterpret_cast<const float4 *>(s.v + (int64_t)tok1 * ts + e4 * 4);
+        }
+    };
+    fetch(0);      // (first: its latency overlaps the Q / dO / O loads of the prologue)
+
     const int qi = lane & 15, kg = lane >> 4;
     const float qscale = p.fwd.scale * kLog2e;
     // Q^T (scaled into the log2 domain) and dO^T fragments (B operands) of the wave's QT query tiles: chunk c, slots j <-> e = 32c + 8 kg + j
@@ -431,29 +453,6 @@ __global__ __launch_bounds__(kSQW / QT * 4, (QT == 1 && HD <= 64) ? 4 : 2) void 
         for (int i = tid; i < (ET * 16 - HD) * kBKT; i += NT) { const int e = HD + i / kBKT, k = (i % kBKT) ^ flip(e); img_zero<F16>(Th, Tl, e * TS + k); }
     }
 
-    // The K / V rows of the NEXT key tile are requested right after the current tile has been staged (register-staged
-    // prefetch: one thread = 2 keys x 4 e, kIt items per tile), so their HBM latency hides under the tile's MFMA work.
-    constexpr int kItems = (kBKT / 2) * (HD / 4), kIt = (kItems + NT - 1) / NT;
-    // (the loads stay RAW: adding the bias inside fetch would wait for the data there and expose the latency the prefetch is meant to
-    // hide -- the thread's bias values are loop constants, added when the tile is staged)
-    float4 pka[kIt], pkb[kIt], pva[kIt], pvb[kIt], kbias[kIt], vbias[kIt];
-#pragma unroll
-    for (int it = 0; it < kIt; ++it) {
-        const int i = min(tid + it * NT, kItems - 1), e4 = i % (HD / 4);
-        kbias[it] = s.kb ? *reinterpret_cast<const float4 *>(s.kb + e4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        vbias[it] = s.vb ? *reinterpret_cast<const float4 *>(s.vb + e4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    auto fetch = [&](int k0) {
-#pragma unroll
-        for (int it = 0; it < kIt; ++it) {
-            const int i = min(tid + it * NT, kItems - 1);
-            const int kp = i / (HD / 4), e4 = i - kp * (HD / 4), key = 2 * kp;
-            const int tok0 = min(k0 + key, L - 1), tok1 = min(k0 + key + 1, L - 1);
-            pka[it] = *reinterpret_cast<const float4 *>(s.k + (int64_t)tok0 * ts + e4 * 4); pkb[it] = *reinterpret_cast<const float4 *>(s.k + (int64_t)tok1 * ts + e4 * 4);
-            pva[it] = *reinterpret_cast<const float4 *>(s.v + (int64_t)tok0 * ts + e4 * 4); pvb[it] = *reinterpret_cast<const float4 *>(s.v + (int64_t)tok1 * ts + e4 * 4);
-        }
-    };
-    fetch(0);
 
     for (int k0 = 0; k0 < L; k0 += kBKT) {
         __syncthreads();
@@ -573,6 +572,38 @@ __global__ __launch_bounds__(256, (HD > 64 || KT == 2) ? 2 : 3) void xattn_bwd_d
     const float *dlt = reinterpret_cast<const float *>(p.delta_ptr) + stat0;
     const float *gsc = dlt + (int64_t)p.fwd.batch * ndir * H * L;        // fp16 carrier: the dO row scales the dq kernel left
 
+    // The Q / dO rows of the NEXT query tile are requested right after the current tile has been staged, so their HBM
+    // latency hides under the tile's MFMA work (register-staged prefetch: one thread = 2 queries x 4 e, kIt items per tile).
+    constexpr int kItems = (kBQT / 2) * (HD / 4), kIt = (kItems + 255) / 256;
+    // (raw loads, the bias is added when the tile is staged: see the dq kernel; the tile's per-query statistics -- lse, D, the dO row
+    // scale -- ride along in the first kBQT threads)
+    float4 pqa[kIt], pqb[kIt], pga[kIt], pgb[kIt], qbias[kIt];
+    float2 pgs[kIt];
+    float pl = 0.f, pd = 0.f, pg = 1.f;
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+        const int i = min(tid + it * 256, kItems - 1), e4 = i % (HD / 4);
+        qbias[it] = s.qb ? *reinterpret_cast<const float4 *>(s.qb + e4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    auto fetch = [&](int q0) {
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int i = min(tid + it * 256, kItems - 1);
+            const int qp = i / (HD / 4), e4 = i - qp * (HD / 4), q = 2 * qp;
+            const int tok0 = min(q0 + q, L - 1), tok1 = min(q0 + q + 1, L - 1);
+            pqa[it] = *reinterpret_cast<const float4 *>(s.q + (int64_t)tok0 * ts + e4 * 4); pqb[it] = *reinterpret_cast<const float4 *>(s.q + (int64_t)tok1 * ts + e4 * 4);
+            pga[it] = *reinterpret_cast<const float4 *>(dobase + (int64_t)tok0 * p.fwd.out_token_stride + e4 * 4);
+            pgb[it] = *reinterpret_cast<const float4 *>(dobase + (int64_t)tok1 * p.fwd.out_token_stride + e4 * 4);
+            if constexpr (F16) pgs[it] = make_float2(gsc[tok0], gsc[tok1]);
+        }
+        if (tid < kBQT) {
+            const int tok = min(q0 + tid, L - 1);
+            pl = lse[tok]; pd = dlt[tok];
+            if constexpr (F16) pg = gsc[tok];
+        }
+    };
+    fetch(0);      // (first: its latency overlaps the g_min reduction and the K / V fragment loads)
+
     // fp16 carrier: g_min = the scale of this (batch, head, direction)'s largest gradient row
     float gsmin = 1.f;
     if constexpr (F16) {
@@ -623,37 +654,6 @@ __global__ __launch_bounds__(256, (HD > 64 || KT == 2) ? 2 : 3) void xattn_bwd_d
         for (int i = tid; i < (ET * 16 - HD) * kBQT; i += 256) { const int e = HD + i / kBQT, q = (i % kBQT) ^ flip(e); img_zero<F16>(QTh, QTl, e * TS + q); img_zero<F16>(GTh, GTl, e * TS + q); }
     }
 
-    // The Q / dO rows of the NEXT query tile are requested right after the current tile has been staged, so their HBM
-    // latency hides under the tile's MFMA work (register-staged prefetch: one thread = 2 queries x 4 e, kIt items per tile).
-    constexpr int kItems = (kBQT / 2) * (HD / 4), kIt = (kItems + 255) / 256;
-    // (raw loads, the bias is added when the tile is staged: see the dq kernel; the tile's per-query statistics -- lse, D, the dO row
-    // scale -- ride along in the first kBQT threads)
-    float4 pqa[kIt], pqb[kIt], pga[kIt], pgb[kIt], qbias[kIt];
-    float2 pgs[kIt];
-    float pl = 0.f, pd = 0.f, pg = 1.f;
-#pragma unroll
-    for (int it = 0; it < kIt; ++it) {
-        const int i = min(tid + it * 256, kItems - 1), e4 = i % (HD / 4);
-        qbias[it] = s.qb ? *reinterpret_cast<const float4 *>(s.qb + e4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    auto fetch = [&](int q0) {
-#pragma unroll
-        for (int it = 0; it < kIt; ++it) {
-            const int i = min(tid + it * 256, kItems - 1);
-            const int qp = i / (HD / 4), e4 = i - qp * (HD / 4), q = 2 * qp;
-            const int tok0 = min(q0 + q, L - 1), tok1 = min(q0 + q + 1, L - 1);
-            pqa[it] = *reinterpret_cast<const float4 *>(s.q + (int64_t)tok0 * ts + e4 * 4); pqb[it] = *reinterpret_cast<const float4 *>(s.q + (int64_t)tok1 * ts + e4 * 4);
-            pga[it] = *reinterpret_cast<const float4 *>(dobase + (int64_t)tok0 * p.fwd.out_token_stride + e4 * 4);
-            pgb[it] = *reinterpret_cast<const float4 *>(dobase + (int64_t)tok1 * p.fwd.out_token_stride + e4 * 4);
-            if constexpr (F16) pgs[it] = make_float2(gsc[tok0], gsc[tok1]);
-        }
-        if (tid < kBQT) {
-            const int tok = min(q0 + tid, L - 1);
-            pl = lse[tok]; pd = dlt[tok];
-            if constexpr (F16) pg = gsc[tok];
-        }
-    };
-    fetch(0);
 
     for (int q0 = 0; q0 < L; q0 += kBQT) {
         __syncthreads();
@@ -763,9 +763,9 @@ template <int HD, bool F16>
 static int launch_xbwd_mc(const dimsum_xattn_bwd_params_t &p, hipStream_t s) {
     const int64_t nblk = (int64_t)p.fwd.batch * p.fwd.heads * (p.fwd.n_dirs == 1 ? 1 : 2) * ((p.fwd.seqlen + 63) / 64);
     const int64_t nq = (int64_t)p.fwd.batch * p.fwd.heads * (p.fwd.n_dirs == 1 ? 1 : 2) * ((p.fwd.seqlen + kSQW - 1) / kSQW);
-    static const bool qt2 = getenv("DIMSUM_XATTN_BWD_QT2") && atoi(getenv("DIMSUM_XATTN_BWD_QT2")) != 0;      // (experiment)
+    // (fp16 carrier at head_dim 64: two query tiles per wave fit -- 214 VGPRs -- and measured 1.18 against 1.05 ms for the pair; one key tile
+    // per wave in the dk / dv kernel at 4 waves per SIMD: 0.856 against 0.838 ms. The split carrier's choices stand.)
     if constexpr (HD <= 32) hipLaunchKernelGGL((xattn_bwd_dq_split_kernel<HD, 2, F16>), dim3((unsigned)nq), dim3(256), 0, s, p);
-    else if (F16 && HD <= 64 && qt2) hipLaunchKernelGGL((xattn_bwd_dq_split_kernel<HD, (F16 && HD <= 64) ? 2 : 1, F16>), dim3((unsigned)nq), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((xattn_bwd_dq_split_kernel<HD, 1, F16>), dim3((unsigned)nq), dim3(512), 0, s, p);
     if (launch_status() != DIMSUM_OK) return DIMSUM_ERR_LAUNCH;
     // two key tiles per wave (128 keys per workgroup) halve the per-key staging work; short sequences and the wide head keep one
