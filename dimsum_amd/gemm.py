@@ -243,6 +243,17 @@ def mm_nn_rows(a_rows, b, out_dtype=None):
     return torch.bmm(a_rows.view(N, s, R // s).permute(1, 0, 2), b.view(s, R // s, K), **kw).sum(0)
 
 
+def mm_nt_rows(a_rows, b_rows, out_dtype=None):
+    """a_rows (N, R), b_rows (K, R), both contiguous along the (long) reduction -> a_rows @ b_rows^T (N, K), split like mm_tn"""
+    N, R = a_rows.shape
+    K = b_rows.shape[0]
+    kw = {} if out_dtype is None else {"out_dtype": out_dtype}
+    s = _slices(R, N, K) if a_rows.is_cuda else 1
+    if s == 1:
+        return torch.mm(a_rows, b_rows.t(), **kw)
+    return torch.bmm(a_rows.view(N, s, R // s).permute(1, 0, 2), b_rows.view(K, s, R // s).permute(1, 2, 0), **kw).sum(0)
+
+
 class _MatmulWxFn(torch.autograd.Function):
     """weight (N, K) @ x^T (K, M) -> (N, M) (the in_proj site) with the weight gradient as a sliced reduction (mm_nn_rows)"""
 

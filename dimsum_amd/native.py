@@ -377,7 +377,7 @@ def layer_norm_bwd(dy, x, weight, bias, eps, mean, rstd, dresidual=None, has_res
     return dx, dw.to(weight.dtype), db.to(bias.dtype) if bias is not None else None, dresidual_in
 
 
-def selective_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, dz, delta_softplus, recompute_out_z, ckpt=None):
+def selective_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, dz, delta_softplus, recompute_out_z, ckpt=None, dB=None, dC=None):
     """-> [du, ddelta, dA, dB, dC, dD, ddelta_bias, (dz), (out_z)] exactly like selective_scan_cuda.bwd
     (selective_scan.cpp:338-492). dz may be a caller-provided view (fused chunk backward, :433-441).
     `ckpt` (extra): the tile-boundary states of selective_scan_fwd(need_ckpt=True); without it they are rebuilt by one
@@ -401,8 +401,11 @@ def selective_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, dz, de
     nA, nD = A.numel(), (dim if D is not None else 0)
     acc = torch.zeros(nA + nD + (dim if delta_bias is not None else 0), device=u.device, dtype=torch.float32)
     dA = acc[:nA].view(A.shape)
-    dB = torch.empty(B.shape, device=u.device, dtype=torch.float32)      # fp32 then cast (cpp:461-462,488)
-    dC = torch.empty(C.shape, device=u.device, dtype=torch.float32)
+    # dB / dC: fp32 then cast (cpp:461-462,488); a caller may hand in fp32 views of B's / C's shape (unit stride along l) to have them written in place
+    for t, like in ((dB, B), (dC, C)):
+        _check(t is None or (t.shape == like.shape and t.dtype == torch.float32 and t.is_cuda and t.stride(-1) == 1), "selective_scan_bwd: bad dB / dC buffer")
+    dB = torch.empty(B.shape, device=u.device, dtype=torch.float32) if dB is None else dB
+    dC = torch.empty(C.shape, device=u.device, dtype=torch.float32) if dC is None else dC
     dD = acc[nA:nA + nD] if D is not None else None
     ddelta_bias = acc[nA + nD:] if delta_bias is not None else None
     if u.numel() > 0:

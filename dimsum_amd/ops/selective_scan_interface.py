@@ -97,6 +97,14 @@ def _will_backprop(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
+def _checkpoint_lvl():
+    """The reference hard-codes checkpoint_lvl = 1 (selective_scan_interface.py:588: conv_out and delta are dropped after the forward and recomputed in
+    the backward -- a conv1d launch and a dt_proj GEMM per mixer, to save 2 b d l 4 bytes of activations on 40 / 80-GB parts). With 288 GB per GPU the
+    default here is 0: both tensors stay (4.4 GB at DiM-L/2, 64 latents) and the backward starts from them; the gradients are bit-identical
+    (the recomputation is deterministic). DIMSUM_MAMBA_CHECKPOINT_LVL=1 restores the reference's trade."""
+    return 1 if os.environ.get("DIMSUM_MAMBA_CHECKPOINT_LVL", "0") == "1" else 0
+
+
 def _rows(t):   # "b d l -> d (b l)" as a view-friendly reshape
     b, d, l = t.shape
     return t.permute(1, 0, 2).reshape(d, b * l)
@@ -163,7 +171,17 @@ class _MambaInner(torch.autograd.Function):
             delta = None if dt_fused else (delta_proj_weight @ x_dbl_t[:R]).view(d_inner, bsz, L).permute(1, 0, 2)
             Bm = x_dbl_t[R:R + N].view(N, bsz, L).permute(1, 0, 2).unsqueeze(1)
             Cm = x_dbl_t[R + N:].view(N, bsz, L).permute(1, 0, 2).unsqueeze(1)
+        elif need_ckpt and B_proj_bias is None and C_proj_bias is None and conv_rows.stride(1) == 1 and xz.is_cuda \
+                and not torch.is_autocast_enabled("cuda") and os.environ.get("DIMSUM_XDBL_T_TRAIN", "1") != "0":
+            # training, the same transposed x_proj: B and C are read in place by both scan kernels, and the backward writes dB / dC straight into
+            # the rows of d x_dbl^T -- 7 transposing / slicing copies per mixer less than the (b l, R + 2N) layout of the reference (:840-860)
+            x_dbl = x_dbl_t = x_proj_weight @ conv_rows                                                  # (R + 2N, b l), saved as x_dbl
+            dt_fused = False
+            delta = (delta_proj_weight @ x_dbl_t[:R]).view(d_inner, bsz, L).permute(1, 0, 2)
+            Bm = x_dbl_t[R:R + N].view(N, bsz, L).permute(1, 0, 2).unsqueeze(1)
+            Cm = x_dbl_t[R + N:].view(N, bsz, L).permute(1, 0, 2).unsqueeze(1)
         else:
+            x_dbl_t = None
             x_dbl = F.linear(conv_out.transpose(1, 2).reshape(bsz * L, d_inner), x_proj_weight)        # (b l, R + 2N)
             delta = (delta_proj_weight @ x_dbl[:, :R].t()).view(d_inner, bsz, L).permute(1, 0, 2)       # (b, d, l), strides (L, bL, 1)
             Bm = x_dbl[:, R:R + N]
@@ -216,6 +234,7 @@ class _MambaInner(torch.autograd.Function):
             return gemm.out_proj_planes(out_z, out_proj_weight).view(bsz, L, out_proj_weight.shape[0])
         ckpt = rest[0] if need else None
         ctx.delta_softplus, ctx.has_out_proj, ctx.checkpoint_lvl = delta_softplus, has_out_proj, checkpoint_lvl
+        ctx.xdbl_t = x_dbl is not None and x_dbl is x_dbl_t       # (training: x_dbl is saved as its transpose)
         ctx.flags = (conv1d_bias is not None, D is not None, delta_bias is not None, B_proj_bias is not None,
                      C_proj_bias is not None, has_out_proj and out_proj_bias is not None)
         if checkpoint_lvl >= 1:
@@ -256,7 +275,7 @@ class _MambaInner(torch.autograd.Function):
         dout = _last_contig(dout)
         if ctx.checkpoint_lvl == 1:
             conv_out = native.causal_conv1d_fwd(x, conv_w, conv_b, True)         # the NON-cond entry, as in :929
-            delta = (delta_proj_weight @ x_dbl[:, :R].t()).view(d_inner, bsz, L).permute(1, 0, 2)
+            delta = (delta_proj_weight @ (x_dbl[:R] if ctx.xdbl_t else x_dbl[:, :R].t())).view(d_inner, bsz, L).permute(1, 0, 2)
         dxz = torch.empty_like(xz)
         dx, dz = dxz.chunk(2, dim=1)
         dout16 = None
@@ -270,8 +289,12 @@ class _MambaInner(torch.autograd.Function):
         else:
             dout_y = dout
         recompute = ctx.has_out_proj and kept_out_z is None and not ctx.f16s     # only d out_proj.weight needs out_z
+        dx_dbl = torch.empty_like(x_dbl)
+        into = {}
+        if ctx.xdbl_t:      # dB / dC land in rows R .. R + 2N of d x_dbl^T (R + 2N, b l)
+            into = {"dB": dx_dbl[R:R + N].view(N, bsz, L).permute(1, 0, 2).unsqueeze(1), "dC": dx_dbl[R + N:].view(N, bsz, L).permute(1, 0, 2).unsqueeze(1)}
         dconv_out, ddelta, dA, dB, dC, dD, ddelta_bias, dz, *rest = native.selective_scan_bwd(
-            conv_out, delta, A, Bm, Cm, D, z, delta_bias, dout_y, scan_x, out, dz, ctx.delta_softplus, recompute, ckpt=ckpt)
+            conv_out, delta, A, Bm, Cm, D, z, delta_bias, dout_y, scan_x, out, dz, ctx.delta_softplus, recompute, ckpt=ckpt, **into)
         out_z = rest[0] if recompute else kept_out_z
         dout_proj_weight = dout_proj_bias = None
         if ctx.f16s:
@@ -282,7 +305,18 @@ class _MambaInner(torch.autograd.Function):
             dout_proj_weight = gemm.mm_nn_rows(_rows(out_z), dout.reshape(bsz * L, -1)).t()
         if ctx.has_out_proj:
             dout_proj_bias = dout.sum(dim=(0, 1)) if has_ob else None
-        dx_dbl = torch.empty_like(x_dbl)
+        if ctx.xdbl_t:
+            ddelta2, conv_rows = _rows(ddelta), _rows(conv_out)                                         # (d, b l) views
+            conv_rows = conv_rows if conv_rows.stride(1) == 1 else conv_rows.contiguous()
+            ddelta_proj_weight = gemm.mm_nt_rows(ddelta2, x_dbl[:R])                                    # "dB,rB->dr", sliced reduction
+            torch.mm(delta_proj_weight.t(), ddelta2, out=dx_dbl[:R])                                    # "dr,dB->rB"
+            dx_proj_weight = gemm.mm_nt_rows(dx_dbl, conv_rows)                                         # "rB,dB->rd", sliced reduction
+            dconv2 = torch.addmm(_rows(dconv_out), x_proj_weight.t(), dx_dbl)
+            dconv_out = dconv2.view(d_inner, bsz, L).permute(1, 0, 2)
+            _, dconv_w, dconv_b = native.causal_conv1d_bwd(x, conv_w, conv_b, dconv_out, dx, True)
+            return (dxz, dconv_w.unsqueeze(1), dconv_b if has_conv_b else None, dx_proj_weight, ddelta_proj_weight,
+                    dout_proj_weight, dout_proj_bias, dA, None, None, dD if has_D else None,
+                    ddelta_bias if has_dbias else None, None, None, None, None, None, None, None, None, None)
         dBf = dB.squeeze(1).permute(0, 2, 1).reshape(bsz * L, N)                                        # "b 1 n l -> (b l) n"
         dCf = dC.squeeze(1).permute(0, 2, 1).reshape(bsz * L, N)
         dB_proj_bias = dBf.sum(0) if has_Bb else None
@@ -307,7 +341,7 @@ def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_wei
     wb = _will_backprop(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias, A, B, C, D, delta_bias,
                         B_proj_bias, C_proj_bias, None)
     return _MambaInner.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
-                             out_proj_bias, A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, None, True, 1,
+                             out_proj_bias, A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, None, True, _checkpoint_lvl(),
                              wb, False, _f16s_train(xz, out_proj_weight, wb))
 
 
@@ -318,13 +352,13 @@ def mamba_inner_fn_cond(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
                         B_proj_bias, C_proj_bias, init_states)
     return _MambaInner.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
                              out_proj_bias, A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, init_states,
-                             True, 1, wb, conv_done, _f16s_train(xz, out_proj_weight, wb))
+                             True, _checkpoint_lvl(), wb, conv_done, _f16s_train(xz, out_proj_weight, wb))
 
 
 def mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B=None, C=None,
                                D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True):
     return _MambaInner.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, None, None, A, B, C, D,
-                             delta_bias, B_proj_bias, C_proj_bias, delta_softplus, None, False, 1,
+                             delta_bias, B_proj_bias, C_proj_bias, delta_softplus, None, False, _checkpoint_lvl(),
                              _will_backprop(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, None))
 
 
@@ -332,7 +366,7 @@ def mamba_inner_fn_no_out_proj_cond(xz, conv1d_weight, conv1d_bias, x_proj_weigh
                                     D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True,
                                     init_states=None):
     return _MambaInner.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, None, None, A, B, C, D,
-                             delta_bias, B_proj_bias, C_proj_bias, delta_softplus, init_states, False, 1,
+                             delta_bias, B_proj_bias, C_proj_bias, delta_softplus, init_states, False, _checkpoint_lvl(),
                              _will_backprop(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, init_states))
 
 

@@ -307,6 +307,25 @@ def test_mamba_inner_fn_fwd_bwd_gpu():
         assert_close(p[k].grad.cpu().numpy(), g["g_" + k], 1e-3, 0, "g_" + k, scale_atol=2e-4)
 
 
+def test_mamba_inner_checkpoint_levels_are_bit_identical(monkeypatch):
+    """checkpoint_lvl 0 (the default here: conv_out and delta stay resident between forward and backward) against the reference's hard-coded
+    level 1 (selective_scan_interface.py:588: both recomputed in the backward): output and every gradient bit for bit."""
+    from dimsum_amd.ops import mamba_inner_fn
+    g = golden("mamba_inner")
+    names = ["conv_w", "conv_b", "x_proj_w", "dt_proj_w", "out_proj_w", "A", "Dv", "dt_bias"]
+    res = []
+    for lvl in ("0", "1"):
+        monkeypatch.setenv("DIMSUM_MAMBA_CHECKPOINT_LVL", lvl)
+        p = {k: T(g[k]).cuda().requires_grad_() for k in names}
+        xz = T(g["xz"]).cuda().requires_grad_()
+        out = mamba_inner_fn(xz, p["conv_w"], p["conv_b"], p["x_proj_w"], p["dt_proj_w"], p["out_proj_w"], None, p["A"], None, None,
+                             p["Dv"], delta_bias=p["dt_bias"], delta_softplus=True)
+        out.backward(T(g["dout"]).cuda())
+        res.append([out.detach(), xz.grad] + [p[k].grad for k in names])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("tf32", [False, True])
 def test_block_combined_384_fwd_bwd_all_hip(tf32):
     """BASELINE configs[2]'s block at a width whose attention runs on the MFMA kernels (hidden 384, head_dim 24): forward,
