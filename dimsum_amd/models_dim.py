@@ -300,13 +300,20 @@ def _mlp_tail(mlp, x, normed, shift, scale, gate):
     return token_ops.gate_residual(x, mlp(h), gate, None)
 
 
-def _mix_through_images(mixer, hidden_states, kind, table, shift, scale, c):
+def _mix_through_images(mixer, hidden_states, kind, table, shift, scale, c, fork=False):
     """mixer(pre_mixer(hidden_states)); at inference under allow_tf32 the pre-mixer pass writes the in_proj operand as a
-    split-bf16 image (gemm.py, split3) instead of fp32"""
+    split-bf16 image (gemm.py, split3) instead of fp32.
+    fork: -> (mixer output, hidden_states for the residual tail). Under autograd the second is an alias handed out by the pre-mixer
+    pass itself, whose backward kernel then adds the tail's gradient to its own (token_ops.pre_mixer_fork): hidden_states has ONE consumer."""
     if getattr(mixer, "takes_image", lambda: False)() and gemm.split3_enabled(hidden_states, mixer.in_proj.weight, left=False):
-        return mixer(None, c, x3=token_ops.pre_mixer(hidden_states, kind, table, shift, scale,
-                                                     split3=gemm.split3_enabled(hidden_states, mixer.in_proj.weight, left=False)))
-    return mixer(token_ops.pre_mixer(hidden_states, kind, table, shift, scale), c)
+        m = mixer(None, c, x3=token_ops.pre_mixer(hidden_states, kind, table, shift, scale,
+                                                  split3=gemm.split3_enabled(hidden_states, mixer.in_proj.weight, left=False)))
+        return (m, hidden_states) if fork else m
+    if fork and hidden_states.is_cuda and torch.is_grad_enabled() and hidden_states.requires_grad:
+        t, hidden_states = token_ops.pre_mixer_fork(hidden_states, kind, table, shift, scale)
+        return mixer(t, c), hidden_states
+    m = mixer(token_ops.pre_mixer(hidden_states, kind, table, shift, scale), c)
+    return (m, hidden_states) if fork else m
 
 
 # ---- shared block plumbing ----------------------------------------------------------------------------------------------
@@ -377,7 +384,7 @@ class DiMBlockRaw(_BlockBase):
         hidden_states, residual = self._prenorm(hidden_states, residual)
         table = self._table(hidden_states.shape[1], hidden_states.device, self._order)
         shift, scale, gate = self.adaLN_modulation(c).chunk(3, dim=1)
-        m = _mix_through_images(self.mixer, hidden_states, "none", table, shift, scale, c)
+        m, hidden_states = _mix_through_images(self.mixer, hidden_states, "none", table, shift, scale, c, fork=True)
         return token_ops.post_mixer(hidden_states, m, gate, "none", table, **({"split3": out_split3} if out_split3 else {})), residual
 
 
@@ -404,7 +411,7 @@ class _FreqBlock(_BlockBase):
         mods = self.adaLN_modulation(c).chunk(3 if self.no_ffn else 6, dim=1)
         shift, scale, gate = mods[:3]
         if self.no_ffn:
-            m = _mix_through_images(self.mixer, hidden_states, self.kind, table, shift, scale, c)
+            m, hidden_states = _mix_through_images(self.mixer, hidden_states, self.kind, table, shift, scale, c, fork=True)
             return token_ops.post_mixer(hidden_states, m, gate, self.kind, table, **({"split3": out_split3} if out_split3 else {})), residual
         assert not out_split3
         # with an FFN the reference keeps working in the transformed / reordered token space (models_dim.py:678-684)
@@ -518,6 +525,11 @@ class _CombinedBase(_BlockBase):
             m, mb = self.mlp.forward_deferred(hidden_states, x3=y) if s3 else self.mlp.forward_deferred(y.view(B, L, H))
             return token_ops.gate_residual(hnew.view(B, L, H), m, gate, mb), residual
         hidden_states = token_ops.gate_residual(hidden_states, fused, None, pb)
+        if isinstance(self.norm_2, RMSNorm) and hidden_states.is_cuda and torch.is_grad_enabled():
+            # training: the norm hands the stream on (prenorm), so that "d norm + d tail" is formed inside the norm's backward kernel
+            # (its dresidual input) instead of by an add of two (B, L, dim) gradients in the autograd engine
+            normed, hidden_states = self.norm_2(hidden_states, prenorm=True)
+            return _mlp_tail(self.mlp, hidden_states, normed, shift, scale, gate), residual
         return _mlp_tail(self.mlp, hidden_states, self.norm_2(hidden_states), shift, scale, gate), residual
 
 

@@ -151,6 +151,35 @@ class _PreMixer(torch.autograd.Function):
         return dx, dshift, dscale, None, None
 
 
+class _PreMixerFork(torch.autograd.Function):
+    """_PreMixer that also hands x on: (y, x). The consumer of the second output is the residual tail "x + gate * mixer(y)"; its gradient
+    comes back here and is added inside the adjoint pass (the kernel's `residual` operand) -- x then has one consumer in the graph and the
+    autograd engine has no (B, L, C) add to do."""
+
+    @staticmethod
+    def forward(ctx, x, shift, scale, kind, inv32):
+        from .. import native
+        xc = _cc(x)
+        ctx.kind, ctx.inv32 = kind, inv32
+        ctx.save_for_backward(xc, scale)
+        return native.token_transform(xc, kind, True, out_index=inv32, scale=scale, shift=shift), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dtail):
+        from .. import native
+        x, scale = ctx.saved_tensors
+        dx = dshift = dscale = None
+        if ctx.needs_input_grad[0]:
+            if dy is None:
+                dx = dtail
+            else:
+                dx = native.token_transform(_cc(dy), ctx.kind, False, in_index=ctx.inv32, gate=(1.0 + scale) * _ADJ[ctx.kind],
+                                            residual=None if dtail is None else _cc(dtail))
+        if dy is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            _, dscale, dshift = native.token_transform(x, ctx.kind, True, out_index=ctx.inv32, w=_cc(dy), want_y=False, want_wsum=True)
+        return dx, dshift, dscale, None, None
+
+
 class _PostMixer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, m, gate, kind, inv32):
@@ -224,6 +253,12 @@ def pre_mixer(x, kind, table, shift, scale, split3=False):
         from .. import native
         return native.token_transform(_cc(x), kind, True, out_index=None if table is None else table["inv32"], scale=scale, shift=shift, split3=split3)
     return _PreMixer.apply(x, shift, scale, kind, None if table is None else table["inv32"])
+
+
+def pre_mixer_fork(x, kind, table, shift, scale):
+    """-> (modulate(P(T(x))), x): pre_mixer whose backward also takes the gradient of the residual tail fed from the second output"""
+    _require_gpu(x)
+    return _PreMixerFork.apply(x, shift, scale, kind, None if table is None else table["inv32"])
 
 
 def post_mixer(x, m, gate, kind, table, split3=False):

@@ -35,6 +35,9 @@ def sites(step):
                     for u in (t if isinstance(t, (list, tuple)) else [t]):
                         if torch.is_tensor(u):
                             nb += u.numel() * u.element_size()
+                if site == "<engine>" and name in ("add", "cat", "copy_", "mul", "sum", "mm"):
+                    shp = [tuple(u.shape) for t in args for u in (t if isinstance(t, (list, tuple)) else [t]) if torch.is_tensor(u)]
+                    site = "<engine> " + str(shp)[:120]
                 k = (name, site)
                 agg[k][0] += 1
                 agg[k][1] += nb
