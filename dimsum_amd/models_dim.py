@@ -470,6 +470,29 @@ class DCTBlock(_FreqBlock):
         return so.block_order_table(H, self.reverse, self.transpose, self.scanning_continuity)
 
 
+class _ForkHalves(torch.autograd.Function):
+    """hidden -> (first channel half, second half, hidden): the branch inputs and the stream of the fusion's residual tail. The backward joins
+    the three gradients in two strided adds -- 3 x (B, L, dim) of traffic instead of the 5 x of the engine's cat + add."""
+
+    @staticmethod
+    def forward(ctx, h):
+        C = h.shape[-1] // 2
+        return h[..., :C], h[..., C:], h.view_as(h)
+
+    @staticmethod
+    def backward(ctx, d1, d2, dres):
+        if dres is None:
+            return torch.cat((d1, d2), dim=-1)
+        C = dres.shape[-1] // 2
+        out = torch.empty(dres.shape, device=dres.device, dtype=dres.dtype)
+        for d, sl in ((d1, slice(0, C)), (d2, slice(C, 2 * C))):
+            if d is None:
+                out[..., sl] = dres[..., sl]
+            else:
+                torch.add(d, dres[..., sl], out=out[..., sl])
+        return out
+
+
 class _CombinedBase(_BlockBase):
     def _init_tail(self, dim, norm_cls, drop_path, use_gated_mlp, swap_k_kw):
         self.proj = CrossAttentionFusion(dim, num_heads=8, qkv_bias=True, **swap_k_kw)
@@ -480,7 +503,10 @@ class _CombinedBase(_BlockBase):
 
     def forward(self, hidden_states, residual=None, c=None, inference_params=None):
         hidden_states, residual = self._prenorm(hidden_states, residual)
-        x1, x2 = hidden_states.chunk(2, dim=2)
+        if hidden_states.is_cuda and torch.is_grad_enabled() and hidden_states.requires_grad:
+            x1, x2, hidden_states = _ForkHalves.apply(hidden_states)        # training: ONE consumer of hidden_states in the graph (see there)
+        else:
+            x1, x2 = hidden_states.chunk(2, dim=2)
         # inference under allow_tf32: the branches hand their results over as split-bf16 operand images of the qkv Linears
         img = self.proj.takes_images(hidden_states) and gemm.split3_enabled(x1, self.proj.qkv1.weight)      # False / True / "f16s"
         kw = {"out_split3": img} if img else {}
