@@ -499,7 +499,8 @@ class Bench:
         return out
 
     TRAIN_MATMUL = {"f16s": "allow_tf32=True (dimsum/train.py:20-21 turns TF32 on for training too) served as ONE fp16 MFMA product per element over scaled-fp16 operand "
-                            "images in the forward, input-gradient and weight-gradient GEMMs (dW: row scales become per-reduction-row factors inside the TN kernel)",
+                            "images in the forward, input-gradient and weight-gradient GEMMs (dW: row scales become per-reduction-row factors inside the TN kernel) and in the attention "
+                            "backward pair (dout rows scaled by exact powers of two in-kernel; the attention forward under autograd keeps three split-bf16 products)",
                     "tf32": "allow_tf32=True served by the three-product split-bf16 images (fp32-class)", "fp32": "exact fp32", "fp16": "as tf32"}
 
     def leg_block(self, model_name, image_size, batch, steps, warmup):

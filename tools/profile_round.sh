@@ -53,6 +53,7 @@ bash tools/pmc_scan.sh $out/pmc_fwd_stress --dmajor --B 16 --D 1152 --L 4096 > $
 timeout 900 bash tools/pmc_gemm_f16s.sh $out/${tag}_gemm_f16s_pmc.txt > /dev/null 2>&1; mv $out/${tag}_gemm_f16s_pmc.txt.xattn $out/${tag}_xattn_f16_fwd_pmc.txt
 timeout 300 python3 tools/bench_gemm.py --perf --rounds 5 2>/dev/null | grep -v amdgpu > $out/${tag}_gemm_perf.jsonl
 timeout 300 python3 tools/bench_gemm.py --tiles --rounds 5 2>/dev/null | grep -v amdgpu > $out/${tag}_gemm_tiles.jsonl
-bash tools/scratch/xattn_pmc.sh bwd > $out/${tag}_xattn_bwd_pmc.txt 2>&1      # (the training backward pair: split-bf16 kernels)
+bash tools/scratch/xattn_pmc.sh bwd > $out/${tag}_xattn_bwd_pmc.txt 2>&1      # (the training backward pair: split-bf16 carrier, --matmul tf32)
+bash tools/scratch/xattn_pmc.sh bwd16 > $out/${tag}_xattn_bwd16_pmc.txt 2>&1  # (the same pair on the fp16 carrier: what training runs under the f16s policy)
 rm -rf $out/pmc_*     # raw csv trees: only the summaries travel back
 ls -la $out
