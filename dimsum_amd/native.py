@@ -20,6 +20,39 @@ from . import _lib
 _DT = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
 
 
+class _ZeroArena:
+    """Zero-filled fp32 scratch for the small accumulators the backward kernels ADD into (conv / norm / scan weight-gradient sums, the token
+    passes' (3, B, C) reductions, bias-gradient sums): one fill launch per 16-MB chunk instead of one per accumulator -- ~300 fills of a few KB
+    .. 800 KB per DiM-L/2 training step. A slice is handed out once and never again; a chunk lives as long as any of its slices (a parameter
+    gradient that is such a slice keeps its chunk until the next zero_grad). Per (device, stream); bypassed under stream capture."""
+    CHUNK = 1 << 22          # floats
+
+    def __init__(self):
+        import threading
+        self._lock, self._cur = threading.Lock(), {}
+
+    def take(self, n, device):
+        n = int(n)
+        if n <= 0 or n > self.CHUNK // 4 or torch.cuda.is_current_stream_capturing() or os.environ.get("DIMSUM_ZERO_ARENA", "1") == "0":
+            return torch.zeros(max(n, 0), device=device, dtype=torch.float32)
+        pad = (n + 63) // 64 * 64                          # 256-byte slices: vectorised consumers (fused optimizers) stay on their fast path
+        key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+        with self._lock:
+            buf, used = self._cur.get(key, (None, 0))
+            if buf is None or used + pad > self.CHUNK:
+                buf, used = torch.zeros(self.CHUNK, device=device, dtype=torch.float32), 0
+            self._cur[key] = (buf, used + pad)
+        return buf[used:used + n]
+
+
+_zero_arena = _ZeroArena()
+
+
+def _zeros(n, device):
+    """n zero floats (a fresh slice of the zero arena)"""
+    return _zero_arena.take(n, device)
+
+
 def _check(cond, msg):
     if not cond:
         raise RuntimeError(msg)
@@ -262,7 +295,7 @@ def causal_conv1d_bwd(x, weight, bias, dout, dx, silu_activation):
     w32 = weight.float()
     b32 = bias.float().contiguous() if bias is not None else None
     # fp32 accumulate, then cast (cpp:405-425); ONE zero-filled buffer for both accumulators (one fill launch instead of two)
-    acc = torch.zeros(weight.numel() + (weight.shape[0] if bias is not None else 0), device=x.device, dtype=torch.float32)
+    acc = _zeros(weight.numel() + (weight.shape[0] if bias is not None else 0), x.device)
     dweight = acc[:weight.numel()].view(weight.shape)
     dbias = acc[weight.numel():] if bias is not None else None
     if x.numel() > 0:
@@ -355,7 +388,7 @@ def layer_norm_bwd(dy, x, weight, bias, eps, mean, rstd, dresidual=None, has_res
     dyf = dy if dy.dtype == torch.float32 else dy.float()
     drf = None if dresidual is None else (dresidual if dresidual.dtype == torch.float32 else dresidual.float())
     dx32 = torch.empty((M, N), device=x.device, dtype=torch.float32)
-    acc = torch.zeros((2 * N if bias is not None else N,), device=x.device, dtype=torch.float32)        # (one fill for both accumulators)
+    acc = _zeros(2 * N if bias is not None else N, x.device)        # (both accumulators out of the zero arena)
     dw = acc[:N]
     db = acc[N:] if bias is not None else None
     if M > 0:
@@ -399,7 +432,7 @@ def selective_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, dz, de
     ddelta = torch.empty_like(delta)
     # the three zero-filled fp32 accumulators (selective_scan.cpp:458-466) out of ONE buffer: one fill launch instead of three
     nA, nD = A.numel(), (dim if D is not None else 0)
-    acc = torch.zeros(nA + nD + (dim if delta_bias is not None else 0), device=u.device, dtype=torch.float32)
+    acc = _zeros(nA + nD + (dim if delta_bias is not None else 0), u.device)
     dA = acc[:nA].view(A.shape)
     # dB / dC: fp32 then cast (cpp:461-462,488); a caller may hand in fp32 views of B's / C's shape (unit stride along l) to have them written in place
     for t, like in ((dB, B), (dC, C)):
@@ -490,7 +523,7 @@ def token_transform(x, kind, forward, in_index=None, out_index=None, gate=None, 
     if w is not None:
         _check(w.shape == x.shape and w.dtype == torch.float32 and w.stride(2) == 1, "token_transform: bad w")
     if w is not None or want_tsum:
-        red = torch.zeros((3, B, C), device=x.device, dtype=torch.float32)
+        red = _zeros(3 * B * C, x.device).view(3, B, C)
         wdot, wsum = (red[0] if w is not None else None), (red[1] if (w is not None and want_wsum) else None)
         tsum = red[2] if want_tsum else None
     if B > 0:
@@ -1067,13 +1100,13 @@ def gated_gelu_bwd(x12, bias, dh, need_dbias=True, split3=False):
         rows = x12.numel() // (2 * H)
         img = torch.empty(x12.shape, device=x12.device, dtype=torch.float16)
         inv = torch.empty(x12.shape[:-1], device=x12.device, dtype=torch.float32)
-        dbias = torch.zeros(2 * H, device=x12.device, dtype=torch.float32) if (bias is not None and need_dbias) else None
+        dbias = _zeros(2 * H, x12.device) if (bias is not None and need_dbias) else None
         with torch.cuda.device(x12.device):
             _lib.check(_lib.load().dimsum_gated_gelu_bwd_f16s(_ptr(x12), _ptr(bias), _ptr(dh), _ptr(img), _ptr(inv), _ptr(dbias), rows, H, _stream(x12)), "gated_gelu_bwd")
         return F16Image(img, inv), dbias
     pair = split3 == "pair"        # (..., 2 * 2H) bfloat16 [hi | lo] (PairImage)
     dx12 = torch.empty(x12.shape[:-1] + ((4 if pair else 6) * H,), device=x12.device, dtype=torch.bfloat16) if split3 else torch.empty_like(x12)
-    dbias = torch.zeros(2 * H, device=x12.device, dtype=torch.float32) if (bias is not None and need_dbias) else None
+    dbias = _zeros(2 * H, x12.device) if (bias is not None and need_dbias) else None
     rows = x12.numel() // (2 * H)
     with torch.cuda.device(x12.device):
         lib = _lib.load()

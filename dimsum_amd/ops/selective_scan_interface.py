@@ -311,7 +311,8 @@ class _MambaInner(torch.autograd.Function):
             ddelta_proj_weight = gemm.mm_nt_rows(ddelta2, x_dbl[:R])                                    # "dB,rB->dr", sliced reduction
             torch.mm(delta_proj_weight.t(), ddelta2, out=dx_dbl[:R])                                    # "dr,dB->rB"
             dx_proj_weight = gemm.mm_nt_rows(dx_dbl, conv_rows)                                         # "rB,dB->rd", sliced reduction
-            dconv2 = torch.addmm(_rows(dconv_out), x_proj_weight.t(), dx_dbl)
+            dconv2 = _rows(dconv_out)                  # (d, b l) view of the scan's own du: the product is added in place (no copy of the addend)
+            dconv2 = dconv2.addmm_(x_proj_weight.t(), dx_dbl) if dconv2.stride(1) == 1 else torch.addmm(dconv2, x_proj_weight.t(), dx_dbl)
             dconv_out = dconv2.view(d_inner, bsz, L).permute(1, 0, 2)
             _, dconv_w, dconv_b = native.causal_conv1d_bwd(x, conv_w, conv_b, dconv_out, dx, True)
             return (dxz, dconv_w.unsqueeze(1), dconv_b if has_conv_b else None, dx_proj_weight, ddelta_proj_weight,

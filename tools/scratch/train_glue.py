@@ -17,14 +17,19 @@ def sites(step):
     """call sites of the glue ops: a TorchDispatchMode (propagated to the autograd threads) that records op, innermost dimsum_amd frame, bytes touched"""
     import traceback
     from torch.utils._python_dispatch import TorchDispatchMode
-    watch = ("sum", "copy_", "add", "add_", "fill_", "mul", "cat", "neg", "sub", "zero_", "clone", "mm", "addmm", "bmm", "silu", "silu_backward", "exp")
+    watch = ("sum", "copy_", "add", "add_", "fill_", "mul", "cat", "neg", "sub", "zero_", "clone", "mm", "addmm", "bmm", "silu", "silu_backward", "exp",
+             "zeros", "_to_copy", "zeros_like", "new_zeros", "full", "ones_like", "ones", "div", "abs", "max", "amax", "expand_copy", "index_select", "gather")
+    if os.environ.get("GLUE_ALL"):
+        watch = None
+    names = collections.Counter()
     agg = collections.defaultdict(lambda: [0, 0])
 
     class Mode(TorchDispatchMode):
         def __torch_dispatch__(self, func, types, args=(), kwargs=None):
             out = func(*args, **(kwargs or {}))
             name = func.__name__.split(".")[0]
-            if name in watch:
+            names[name] += 1
+            if watch is None or name in watch:
                 site = "<engine>"
                 for fr in reversed(traceback.extract_stack()[:-1]):
                     if "dimsum_amd/" in fr.filename and "train.py" not in fr.filename:
@@ -46,7 +51,7 @@ def sites(step):
     with Mode():
         step()
     torch.cuda.synchronize()
-    lines = ["glue op call sites (count, MB touched):"]
+    lines = ["ops by count: " + ", ".join(f"{k} {v}" for k, v in names.most_common(60)), "glue op call sites (count, MB touched):"]
     for (name, site), (n, nb) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:120]:
         lines.append(f"{n:5d} {nb / 1e6:10.1f} MB  {name:14s} {site}")
     open("gpurun_out/train_glue_sites.txt", "w").write("\n".join(lines) + "\n")
