@@ -224,3 +224,63 @@ def test_f16image_quacks_like_its_tensor():
     flat = img.reshape(12, -1)
     assert tuple(flat.shape) == (12, 8) and tuple(flat.inv.shape) == (12,) and tuple(img.shape) == (2, 6, 8)
     assert tuple(flat.view(2, 6, 8).inv.shape) == (2, 6) and img.float().shape == (2, 6, 8)
+
+
+# ---- host-side pieces of the round-6 training path that run without a GPU ---------------------------------------------------------------
+def test_sliced_reduction_products_match_plain_matmul():
+    """gemm.mm_nn_rows / mm_nt_rows (the Mamba projections' weight gradients as sliced reductions over b * l): the CPU route is the plain product"""
+    import torch
+    from dimsum_amd import gemm
+    g = torch.Generator().manual_seed(0)
+    a, b, c = torch.randn(24, 4096, generator=g), torch.randn(4096, 16, generator=g), torch.randn(16, 4096, generator=g)
+    assert torch.allclose(gemm.mm_nn_rows(a, b), a @ b, rtol=1e-5, atol=1e-4)
+    assert torch.allclose(gemm.mm_nt_rows(a, c), a @ c.t(), rtol=1e-5, atol=1e-4)
+
+
+def test_fork_halves_joins_three_gradients():
+    """models_dim._ForkHalves: (x1, x2, h) = halves + the stream itself; its backward = cat(d1, d2) + dres, also with a missing branch"""
+    import torch
+    from dimsum_amd.models_dim import _ForkHalves
+    g = torch.Generator().manual_seed(1)
+    h = torch.randn(2, 6, 8, generator=g, dtype=torch.float64, requires_grad=True)
+    w1, w2, w3 = (torch.randn(s, generator=g, dtype=torch.float64) for s in ((2, 6, 4), (2, 6, 4), (2, 6, 8)))
+    x1, x2, hs = _ForkHalves.apply(h)
+    ((x1 * w1).sum() + (x2 * w2).sum() + (hs * w3).sum()).backward()
+    assert torch.equal(h.grad, torch.cat((w1, w2), dim=-1) + w3)
+    h2 = h.detach().clone().requires_grad_()
+    x1, x2, hs = _ForkHalves.apply(h2)
+    ((x1 * w1).sum() + (x2 * w2).sum()).backward()
+    assert torch.equal(h2.grad, torch.cat((w1, w2), dim=-1))
+
+
+def test_emulated_tf32_attention_core_is_the_reference_math():
+    """utils/tf32_emulation._EmuXattnFn (what emulated_tf32() puts in place of the attention kernels) in float64, where rounding is the identity:
+    output and all four gradients = torch autograd through scaled_dot_product_attention (attention_fusion.py:44-79), cross and self attention"""
+    import torch
+    from dimsum_amd.utils.tf32_emulation import _EmuXattnFn
+    F = torch.nn.functional.scaled_dot_product_attention
+    B, L, heads, hd = 2, 24, 2, 8
+    W = 3 * heads * hd
+    g = torch.Generator().manual_seed(2)
+    q1, q2 = torch.randn(B, L, W, generator=g, dtype=torch.float64), torch.randn(B, L, W, generator=g, dtype=torch.float64)
+    b1, b2 = torch.randn(W, generator=g, dtype=torch.float64), torch.randn(W, generator=g, dtype=torch.float64)
+    dout = torch.randn(B, L, 2 * heads * hd, generator=g, dtype=torch.float64)
+    split = lambda t, bb: (t + bb).reshape(B, L, 3, heads, hd).permute(2, 0, 3, 1, 4).unbind(0)
+    a = [t.clone().requires_grad_() for t in (q1, q2, b1, b2)]
+    o = _EmuXattnFn.apply(*a, heads)
+    o.backward(dout)
+    r = [t.clone().requires_grad_() for t in (q1, q2, b1, b2)]
+    (qa, ka, va), (qb, kb, vb) = split(r[0], r[2]), split(r[1], r[3])
+    ref = torch.cat((F(qa, kb, vb).transpose(1, 2).reshape(B, L, -1), F(qb, ka, va).transpose(1, 2).reshape(B, L, -1)), dim=-1)
+    ref.backward(dout)
+    assert torch.allclose(o, ref, rtol=0, atol=1e-12)
+    for x, y in zip(a, r):
+        assert torch.allclose(x.grad, y.grad, rtol=0, atol=1e-11)
+    a = [q1.clone().requires_grad_(), b1.clone().requires_grad_()]
+    o = _EmuXattnFn.apply(a[0], None, a[1], None, heads)
+    o.backward(dout[..., :heads * hd])
+    r = [q1.clone().requires_grad_(), b1.clone().requires_grad_()]
+    qa, ka, va = split(r[0], r[1])
+    ref = F(qa, ka, va).transpose(1, 2).reshape(B, L, -1)
+    ref.backward(dout[..., :heads * hd])
+    assert torch.allclose(o, ref, rtol=0, atol=1e-12) and all(torch.allclose(x.grad, y.grad, rtol=0, atol=1e-11) for x, y in zip(a, r))
