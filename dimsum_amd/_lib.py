@@ -121,7 +121,7 @@ class GemmExt(_Sized):
                    ("a_alias_weight_order", i32), ("qkv_q_cols", i32), ("conv_weight_ptr", vp), ("conv_bias_ptr", vp),
                    ("conv_rows", i32), ("conv_width", i32), ("conv_seq", i32), ("conv_weight_ld", i32),
                    ("a_block_inv_ptr", vp), ("a_block_inv_ld", i64), ("tn_pair_a_cols", i64), ("tn_pair_b_cols", i64),
-                   ("k_scale_ptr", vp), ("c_scale_ptr", vp)])
+                   ("k_scale_ptr", vp), ("c_scale_ptr", vp), ("k_inv_a_ptr", vp), ("k_inv_b_ptr", vp)])
 
 
 class GemmParams(_Sized):

@@ -272,11 +272,14 @@ extern "C" int dimsum_gemm_tn(const dimsum_gemm_params_t *pub, int32_t splits, i
     if (p->epilogue != DIMSUM_GEMM_EPI_F32 || p->bias_ptr) return DIMSUM_ERR_UNSUPPORTED;
     if (((p->a_inv_scale_ptr || p->a_block_inv_ptr) == 0) != (p->b_inv_scale_ptr == nullptr)) return DIMSUM_ERR_NULL;
     if ((p->a_inv_scale_ptr || p->a_block_inv_ptr) && (p->operand_dtype != DIMSUM_F16 || splits != 1 || p->tn_pair_a_cols != 0 || p->a_alias_rows != 0)) return DIMSUM_ERR_UNSUPPORTED;
-    if (p->k_scale_ptr) {          // per-reduction-row factors: fp16 operands, plain rows, the factors of one range fit the 32 KB behind the ring
-        if (!p->c_scale_ptr) return DIMSUM_ERR_NULL;
+    if (p->k_inv_b_ptr && !p->k_inv_a_ptr) return DIMSUM_ERR_NULL;
+    if (p->k_scale_ptr || p->k_inv_a_ptr) {          // per-reduction-row factors: fp16 operands, plain rows, the factors of one range fit the 32 KB behind the ring
+        if (p->k_inv_a_ptr ? (p->k_scale_ptr || p->c_scale_ptr) : !p->c_scale_ptr) return DIMSUM_ERR_NULL;      // the table + its maximum, OR the row scales (formed in the kernel)
         if (p->operand_dtype != DIMSUM_F16 || p->a_inv_scale_ptr || p->a_block_inv_ptr || p->tn_pair_a_cols != 0 || p->a_alias_rows != 0) return DIMSUM_ERR_UNSUPPORTED;
         if (splits < 1 || p->k / splits > 16384) return DIMSUM_ERR_SHAPE;
-        if (!aligned_to<char>(p->k_scale_ptr, 16) || !aligned_to<char>(p->c_scale_ptr, 4)) return DIMSUM_ERR_STRIDE;
+        if ((p->k_scale_ptr && (!aligned_to<char>(p->k_scale_ptr, 16) || !aligned_to<char>(p->c_scale_ptr, 4))) ||
+            (p->k_inv_a_ptr && (!aligned_to<char>(p->k_inv_a_ptr, 16) || (p->k_inv_b_ptr && !aligned_to<char>(p->k_inv_b_ptr, 16)) || p->k / splits % 8 != 0)))
+            return DIMSUM_ERR_STRIDE;
     }
     if (p->a_block_inv_ptr && (p->a_inv_scale_ptr || p->a_block_inv_ld < p->k / kBK || p->k > 64 * kBK)) return DIMSUM_ERR_SHAPE;
     if (p->b_inv_scale_ptr && !aligned_to<char>(p->b_inv_scale_ptr, 16)) return DIMSUM_ERR_STRIDE;
@@ -324,6 +327,8 @@ extern "C" int dimsum_gemm_tn(const dimsum_gemm_params_t *pub, int32_t splits, i
     a.a_block_inv_ld = (int)p->a_block_inv_ld;
     a.k_fac = reinterpret_cast<const _Float16 *>(p->k_scale_ptr);
     a.c_scale = reinterpret_cast<const float *>(p->c_scale_ptr);
+    a.k_inv_a = reinterpret_cast<const float *>(p->k_inv_a_ptr);
+    a.k_inv_b = reinterpret_cast<const float *>(p->k_inv_b_ptr);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t e0 = reinterpret_cast<hipEvent_t>(p->timing_start_event), e1 = reinterpret_cast<hipEvent_t>(p->timing_stop_event);
     constexpr int kShipT = kVarFullLineStores | kVarNtStores | kVarTN;
@@ -331,7 +336,7 @@ extern "C" int dimsum_gemm_tn(const dimsum_gemm_params_t *pub, int32_t splits, i
     if (p->operand_dtype == DIMSUM_BF16) {
         if (e0 || e1) hipExtLaunchKernelGGL((gemm_nt_kernel<kOpBf16, kEpiF32, kShipT>), grid, block, 0, s, e0, e1, 0, a);
         else hipLaunchKernelGGL((gemm_nt_kernel<kOpBf16, kEpiF32, kShipT>), grid, block, 0, s, a);
-    } else if (a.k_fac) {
+    } else if (a.k_fac || a.k_inv_a) {
         if (e0 || e1) hipExtLaunchKernelGGL((gemm_tn_rowfac_kernel<kOpF16, kEpiF32, kShipT>), grid, block, 0, s, e0, e1, 0, a);
         else hipLaunchKernelGGL((gemm_tn_rowfac_kernel<kOpF16, kEpiF32, kShipT>), grid, block, 0, s, a);
     } else if (a.a_block_inv) {
@@ -354,7 +359,9 @@ extern "C" int dimsum_gemm_nn(const dimsum_gemm_params_t *pub, int32_t splits, i
         if (frc != DIMSUM_OK) return frc;
     }
     const gemm_flat_t *p = &flat;
-    if (!p->a_ptr || !p->b_ptr || !p->c_ptr || !p->k_scale_ptr || !p->c_scale_ptr) return DIMSUM_ERR_NULL;
+    if (!p->a_ptr || !p->b_ptr || !p->c_ptr) return DIMSUM_ERR_NULL;
+    if (p->k_inv_a_ptr ? (p->k_scale_ptr || p->c_scale_ptr) : (!p->k_scale_ptr || !p->c_scale_ptr)) return DIMSUM_ERR_NULL;      // the factor table + maximum, OR the row scales
+    if (p->k_inv_b_ptr && !p->k_inv_a_ptr) return DIMSUM_ERR_NULL;
     if (p->operand_dtype != DIMSUM_F16) return DIMSUM_ERR_DTYPE;
     if (p->epilogue != DIMSUM_GEMM_EPI_F32 || p->bias_ptr || p->b_inv_scale_ptr || p->a_block_inv_ptr || p->tn_pair_a_cols != 0 || p->a_alias_rows != 0 ||
         p->b_alias_rows != 0 || p->a_alias_weight_order)
@@ -364,7 +371,8 @@ extern "C" int dimsum_gemm_nn(const dimsum_gemm_params_t *pub, int32_t splits, i
         return DIMSUM_ERR_SHAPE;
     if (p->lda % 8 != 0 || p->ldb % 8 != 0 || p->lda < p->k || p->ldb < p->n || !aligned_to<char>(p->a_ptr, 16) || !aligned_to<char>(p->b_ptr, 16) ||
         p->ldc % 4 != 0 || p->ldc < p->n || !aligned_to<char>(p->c_ptr, 16) || (splits > 1 && (c_split_stride % 4 != 0 || c_split_stride < (int64_t)p->m * p->ldc)) ||
-        !aligned_to<char>(p->k_scale_ptr, 16) || !aligned_to<char>(p->c_scale_ptr, 4))
+        (p->k_scale_ptr && (!aligned_to<char>(p->k_scale_ptr, 16) || !aligned_to<char>(p->c_scale_ptr, 4))) ||
+        (p->k_inv_a_ptr && (!aligned_to<char>(p->k_inv_a_ptr, 16) || (p->k_inv_b_ptr && !aligned_to<char>(p->k_inv_b_ptr, 16)))))
         return DIMSUM_ERR_STRIDE;
     if ((int64_t)256 * p->lda * 2 >= ((int64_t)1 << 31) || (int64_t)64 * p->ldb * 2 + 512 >= ((int64_t)1 << 31) || (int64_t)257 * p->ldc * 4 >= ((int64_t)1 << 31))
         return DIMSUM_ERR_STRIDE;
@@ -383,6 +391,8 @@ extern "C" int dimsum_gemm_nn(const dimsum_gemm_params_t *pub, int32_t splits, i
     a.sa = reinterpret_cast<const float *>(p->a_inv_scale_ptr);
     a.k_fac = reinterpret_cast<const _Float16 *>(p->k_scale_ptr);
     a.c_scale = reinterpret_cast<const float *>(p->c_scale_ptr);
+    a.k_inv_a = reinterpret_cast<const float *>(p->k_inv_a_ptr);
+    a.k_inv_b = reinterpret_cast<const float *>(p->k_inv_b_ptr);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t e0 = reinterpret_cast<hipEvent_t>(p->timing_start_event), e1 = reinterpret_cast<hipEvent_t>(p->timing_stop_event);
     constexpr int kShipN = kVarFullLineStores | kVarNtStores;

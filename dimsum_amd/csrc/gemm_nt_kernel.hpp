@@ -97,6 +97,7 @@ struct Args {
     int a_block_inv_ld;            //   stored with their own scale 1 / a_block_inv[g][kt]; the kernel puts a group on ONE scale (the largest inverse of its row of the table, K <= 4096)
     const _Float16 *k_fac;         // kVarRowFac (TN, fp16): one factor (a power of two <= 1) per REDUCTION row (all splits): A's row r is multiplied by k_fac[r] as it is read --
     const float *c_scale;          //   both operands are scaled-fp16 images with ROW scales (the rows are the reduction index of a weight gradient); *c_scale multiplies the result
+    const float *k_inv_a, *k_inv_b; //   ... or the two images' inverse row scales themselves (k_inv_b NULL = 1): the workgroup forms the factors of its range, normalised by the range's maximum
     int q_cols;                    // kEpiF16Qkv: columns [0, q_cols) take the per-row scale, the others the per-batch-element one
     int c_pieces2;                 // kEpiGatedSplit3: the h image is written as the pair [hi | lo] (ldc >= 2 F) for a consumer that reads it with a_alias_tiles
 };
@@ -455,10 +456,52 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
     static_assert(!kRowFac || (kBT && kOp == kOpF16 && !kRebase), "the row factors serve the fp16 TN / NN variants");
     unsigned fac_rd = 0;
     u32x2 fv[4];
+    float c_scale_own = 1.0f;              // (factors formed here: the maximum of this workgroup's range)
     if constexpr (kRowFac) {
         char *fl = lds + 2 * kParity;
-        const _Float16 *src = p.k_fac + (int64_t)tn_row_split * p.K;
-        for (int i = threadIdx.x; i < p.K / 8; i += 512) *reinterpret_cast<u32x4 *>(fl + i * 16) = *reinterpret_cast<const u32x4 *>(src + i * 8);
+        if (p.k_inv_a) {
+            // the factors of this range from the images' row scales: products in registers (<= 4 chunks of 8 rows per thread: K <= 16384), the
+            // range's maximum through LDS, then fp16(product / maximum) -- powers of two, exact -- into the factor table. One launch less per product
+            // (320 per DiM-L/2 training step, ~9 us each as a single-workgroup kernel), and the normalisation is per range instead of per tensor.
+            const float *ia = p.k_inv_a + (int64_t)tn_row_split * p.K, *ib = p.k_inv_b ? p.k_inv_b + (int64_t)tn_row_split * p.K : nullptr;
+            float pr[4][8], m = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int i = threadIdx.x + c * 512;
+                const bool in = i < p.K / 8;
+                const float *a8 = ia + (in ? i : 0) * 8;
+                const f4 a0 = *reinterpret_cast<const f4 *>(a8), a1 = *reinterpret_cast<const f4 *>(a8 + 4);
+                f4 b0 = f4{1.f, 1.f, 1.f, 1.f}, b1 = b0;
+                if (ib) { b0 = *reinterpret_cast<const f4 *>(ib + (in ? i : 0) * 8); b1 = *reinterpret_cast<const f4 *>(ib + (in ? i : 0) * 8 + 4); }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { pr[c][e] = in ? a0[e] * b0[e] : 0.f; pr[c][4 + e] = in ? a1[e] * b1[e] : 0.f; }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m = fmaxf(m, pr[c][e]);
+            }
+            float *red = reinterpret_cast<float *>(lds);          // (the ring is not in use yet)
+            m = wave_allmax(m);
+            if (lane == 0) red[threadIdx.x >> 6] = m;
+            __syncthreads();
+            m = red[0];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w]);
+            c_scale_own = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m)));
+            const float r = m > 0.f ? 1.0f / m : 0.f;             // (a power of two: exact; an all-zero range has factors 0)
+            typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int i = threadIdx.x + c * 512;
+                if (i < p.K / 8) {
+                    h8v h;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) h[e] = (_Float16)(pr[c][e] * r);
+                    *reinterpret_cast<u32x4 *>(fl + i * 16) = __builtin_bit_cast(u32x4, h);
+                }
+            }
+        } else {
+            const _Float16 *src = p.k_fac + (int64_t)tn_row_split * p.K;
+            for (int i = threadIdx.x; i < p.K / 8; i += 512) *reinterpret_cast<u32x4 *>(fl + i * 16) = *reinterpret_cast<const u32x4 *>(src + i * 8);
+        }
         __syncthreads();
         // (NN: A's fragment of lane group g holds reduction rows kh 32 + 8 g .. 8 g + 7: one 16-byte read per k half)
         fac_rd = lds0 + 2 * kParity + (lane >> 4) * (kNN ? 16 : 8);
@@ -826,7 +869,7 @@ __device__ __forceinline__ void gemm_body(const Args &p, char *lds) {
             const unsigned msb = pick_mask(has_sb);
             const float *sap = p.sa ? p.sa + m0 : reinterpret_cast<const float *>(p.A), *sbp = has_sb ? p.sb : reinterpret_cast<const float *>(p.B0);
             float c_scale = 1.0f;
-            if constexpr (kRowFac) c_scale = *p.c_scale;           // (wave-uniform: a scalar load, before the stores)
+            if constexpr (kRowFac) c_scale = p.k_inv_a ? c_scale_own : *p.c_scale;           // (wave-uniform: a scalar load, before the stores)
             bool live[2];
             f4 bv[2], sbv[2], gv[2];
             auto load_cols = [&](int ni) {                 // (ni = 1's vectors are loaded under group 1, before its stores: 12 registers less at the peak)

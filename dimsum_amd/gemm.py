@@ -350,7 +350,7 @@ class _MatmulWxF16sFn(torch.autograd.Function):
         dw = native.gemm_nn(dy16.data, dy16.inv, xd, xi) if ctx.needs_input_grad[0] else None
         dx = None
         if ctx.needs_input_grad[1]:
-            dx = native.gemm_tn(dy16.data, wd, row_scales=native.row_factors(dy16.inv, wi))
+            dx = native.gemm_tn(dy16.data, wd, row_invs=(dy16.inv.reshape(-1).contiguous(), wi.contiguous()))
         return dw, dx
 
 
@@ -764,7 +764,7 @@ def dw_f16s(dy16, x16):
     a, b = dy16.data.reshape(-1, dy16.data.shape[-1]), x16.data.reshape(-1, x16.data.shape[-1])
     ai, bi = dy16.inv.reshape(-1), x16.inv.reshape(-1)
     if own_gemm_enabled() and native.gemm_tn_supported(a, b):
-        return native.gemm_tn(a, b, row_scales=native.row_factors(ai, bi))
+        return native.gemm_tn(a, b, row_invs=(ai.contiguous(), bi.contiguous()))
     return mm_tn(a.float() * ai[:, None], b.float() * bi[:, None])
 
 

@@ -830,7 +830,7 @@ def row_factors(a_inv, b_inv=None):
     return fac, top
 
 
-def gemm_tn(a, b, splits=None, events=None, alias_rows=0, scales=None, row_scales=None):
+def gemm_tn(a, b, splits=None, events=None, alias_rows=0, scales=None, row_scales=None, row_invs=None):
     """a (R, P)^T @ b (R, Q) -> (P, Q) float32 on the hand-written MFMA kernel's TN variant: the weight-gradient product of a Linear
     (reduction over the rows). The reduction is cut into `splits` ranges whose partial results are added in a fixed order.
     alias_rows = D: a is a (2 D, P) pair of planes [hi; lo] read as the row stack [hi; hi; lo] (b: (3 D, Q)); one range.
@@ -840,9 +840,19 @@ def gemm_tn(a, b, splits=None, events=None, alias_rows=0, scales=None, row_scale
     Mamba mixer as ONE fp16 product per element).
     row_scales = (k_fac (R,) float16, c_scale (1,) float32) from row_factors(a_inv, b_inv): both operands are scaled-fp16 images with one scale
     per ROW and the rows are the reduction index (the weight gradient dW = dy^T x of a Linear under the scaled-fp16 policy): a's row r is
-    multiplied by k_fac[r] as it is read, the result by c_scale; ranges of at most 16384 rows."""
+    multiplied by k_fac[r] as it is read, the result by c_scale; ranges of at most 16384 rows.
+    row_invs = (a_inv (R,), b_inv (R,) or None) float32: the same product with the factors formed INSIDE the kernel from the two images' row scales
+    (every workgroup normalises by the maximum of its own range): no row_factors launch in front of the GEMM."""
     _gpu(a, b)
     blocks = None
+    if row_invs is not None:
+        ia, ib = row_invs
+        _gpu(ia, ib)
+        _check(row_scales is None and scales is None and not alias_rows and a.dtype == torch.float16 and ia.dtype == torch.float32 and ia.numel() == a.shape[0]
+               and ia.is_contiguous() and (ib is None or (ib.dtype == torch.float32 and ib.numel() == a.shape[0] and ib.is_contiguous())),
+               "gemm_tn: row_invs = (a_inv (R,), b_inv (R,) or None) float32 with float16 operands")
+        if os.environ.get("DIMSUM_ROW_FACTORS_KERNEL", "0") == "1":        # (A / B: the factor table from its own launch, as before)
+            row_scales, row_invs = row_factors(ia, ib), None
     if row_scales is not None:
         kf, cs = row_scales
         _gpu(kf, cs)
@@ -870,11 +880,12 @@ def gemm_tn(a, b, splits=None, events=None, alias_rows=0, scales=None, row_scale
         R, P = a.shape
     Q = b.shape[1]
     if splits is None:
-        splits = gemm_tn_splits(R, P, Q, second_round=row_scales is None)
-        while row_scales is not None and R // splits > 16384 and R % (2 * splits * 64) == 0:          # (the factors of one range live in 32 KB of LDS)
+        rowfac = row_scales is not None or row_invs is not None
+        splits = gemm_tn_splits(R, P, Q, second_round=not rowfac)
+        while rowfac and R // splits > 16384 and R % (2 * splits * 64) == 0:          # (the factors of one range live in 32 KB of LDS)
             splits *= 2
-    if row_scales is not None:
-        _check(R // splits <= 16384, "gemm_tn: row_scales needs ranges of at most 16384 reduction rows")
+    if row_scales is not None or row_invs is not None:
+        _check(R // splits <= 16384, "gemm_tn: row factors need ranges of at most 16384 reduction rows")
     _check(splits >= 1 and R % (splits * 64) == 0 and R // splits >= 128, "gemm_tn: splits must cut R into ranges of whole 64-row tiles (>= 2)")
     out = torch.empty((splits, P, Q), device=a.device, dtype=torch.float32)
     G = _lib.GemmParams()
@@ -894,6 +905,8 @@ def gemm_tn(a, b, splits=None, events=None, alias_rows=0, scales=None, row_scale
             G.a_inv_scale_ptr = _ptr(scales[0])
     if row_scales is not None:
         X.k_scale_ptr, X.c_scale_ptr = _ptr(row_scales[0]), _ptr(row_scales[1])
+    if row_invs is not None:
+        X.k_inv_a_ptr, X.k_inv_b_ptr = _ptr(row_invs[0]), _ptr(row_invs[1])
     if events is not None:
         X.timing_start_event, X.timing_stop_event = events
     with torch.cuda.device(a.device):
@@ -943,7 +956,8 @@ def gemm_nn(a, a_inv, b, b_inv, splits=None):
         while R // splits > 16384 and R % (2 * splits * 64) == 0:
             splits *= 2
     _check(splits >= 1 and R % (splits * 64) == 0 and 128 <= R // splits <= 16384, "gemm_nn: splits must cut R into ranges of 2 .. 256 whole 64-row tiles")
-    fac, top = row_factors(b_inv)
+    in_kernel = os.environ.get("DIMSUM_ROW_FACTORS_KERNEL", "0") != "1" and b_inv.is_contiguous()       # factors formed inside the GEMM (no launch in front)
+    fac, top = (None, None) if in_kernel else row_factors(b_inv)
     out = torch.empty((splits, P, Q), device=a.device, dtype=torch.float32)
     G = _lib.GemmParams()
     G.m, G.n, G.k = P, Q, R
@@ -951,7 +965,10 @@ def gemm_nn(a, a_inv, b, b_inv, splits=None):
     G.lda, G.ldb, G.ldc = a.stride(0), b.stride(0), Q
     G.a_ptr, G.b_ptr, G.c_ptr, G.a_inv_scale_ptr = _ptr(a), _ptr(b), _ptr(out), _ptr(a_inv)
     X = _lib.attach_ext(G, _lib.GemmExt)
-    X.k_scale_ptr, X.c_scale_ptr = _ptr(fac), _ptr(top)
+    if in_kernel:
+        X.k_inv_a_ptr = _ptr(b_inv)
+    else:
+        X.k_scale_ptr, X.c_scale_ptr = _ptr(fac), _ptr(top)
     with torch.cuda.device(a.device):
         _lib.check(_lib.load().dimsum_gemm_nn(G, splits, P * Q, _stream(a)), "gemm_nn")
     return out[0] if splits == 1 else out.sum(0)

@@ -248,7 +248,7 @@ class _MambaInner(torch.autograd.Function):
             # (d out_proj.weight reads it again): half the bytes kept per mixer.
             oz16 = native.rows_f16s(_rows(out_z))
             wt16 = gemm.weight_t_f16s_train(out_proj_weight)
-            y = native.gemm_tn(oz16.data, wt16.data, row_scales=native.row_factors(oz16.inv, wt16.inv))
+            y = native.gemm_tn(oz16.data, wt16.data, row_invs=(oz16.inv, wt16.inv))
             ctx.save_for_backward(xz, conv_w, conv_b, x_dbl, x_proj_weight, delta_proj_weight, out_proj_weight, conv_out, delta, A, Bm, Cm, D, delta_bias,
                                   scan_x, out, ckpt, None, oz16.data, oz16.inv, wt16.data, wt16.inv)
             return y.view(bsz, L, out_proj_weight.shape[0])

@@ -543,6 +543,12 @@ typedef struct {
      * a_inv_scale_ptr / b_inv_scale_ptr NULL. k / splits <= 16384 reduction rows per range. */
     const void *k_scale_ptr;
     const void *c_scale_ptr;
+    /* the same factors formed INSIDE the kernel (no dimsum_row_factors launch in front of the product): k_inv_a_ptr (k f32) and k_inv_b_ptr (k f32
+     * or NULL = 1) are the two images' inverse row scales; every workgroup multiplies the pair over its OWN reduction range, normalises by the
+     * range's maximum (powers of two: exact), keeps the factors in LDS as float16 and multiplies its partial result by that maximum -- ranges
+     * are summed in fp32 afterwards, so no global maximum is needed. k_scale_ptr / c_scale_ptr must be NULL then. */
+    const void *k_inv_a_ptr;
+    const void *k_inv_b_ptr;
 } dimsum_gemm_ext_t;
 
 /* The Linear itself: what F.linear(x, weight, bias) is given (plus the operand dtype and the power-of-two scales the scaled-fp16 operand
@@ -583,7 +589,8 @@ int dimsum_gemm_tn(const dimsum_gemm_params_t *p, int32_t splits, int64_t c_spli
    d in_proj.weight = dxz x): one operand is a d-major activation -- A (m, k) float16 rows CONTIGUOUS along the reduction index (channels x tokens,
    lda) -- the other token-major -- B (k, n) float16 rows OVER the reduction index (ldb): C[s] (m, n) float32 = sum over the rows r of range s of
    A[0..m, r] B[r, 0..n). Scaled-fp16 images only: a_inv_scale_ptr (m) = A's row scales (its rows are output rows; NULL = 1), ext->k_scale_ptr (k)
-   float16 = B's row scales as per-reduction-row factors (/ their maximum), ext->c_scale_ptr = that maximum; b_inv_scale_ptr NULL. `splits`
+   float16 = B's row scales as per-reduction-row factors (/ their maximum), ext->c_scale_ptr = that maximum -- or ext->k_inv_a_ptr (k f32) = B's row
+   scales themselves, normalised inside the kernel; b_inv_scale_ptr NULL. `splits`
    ranges of k / splits <= 16384 rows, k % (64 splits) == 0; m % 256 == 0, n % 256 == 0; partial results c_split_stride floats apart. */
 int dimsum_gemm_nn(const dimsum_gemm_params_t *p, int32_t splits, int64_t c_split_stride, void *stream);
 /* the k_scale_ptr / c_scale_ptr operands of the two entry points above from the row scales of the two images: k_scale[r] = float16(a_inv[r] b_inv[r] /

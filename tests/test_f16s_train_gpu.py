@@ -60,6 +60,15 @@ def test_weight_gradient_product_with_row_factors_vs_tf32(M, P, Q, adversarial):
     scale = ref.abs().max().item()
     print(f"dW ({M} rows{' adversarial' if adversarial else ''}): f16s {e_max / scale:.2e} / {e_rms / scale:.2e}, TF32 operands {t_max / scale:.2e} / {t_rms / scale:.2e}")
     assert e_max <= 1.1 * t_max + 2.0 ** -22 * scale and e_rms <= 1.1 * t_rms + 2.0 ** -24 * scale
+    # the same product with the factors formed INSIDE the kernel from the row scales (ext->k_inv_a_ptr / k_inv_b_ptr: what training runs -- no factor
+    # launch in front of the GEMM): every range normalised by its own maximum. Same bars; bit-identical to the table route where the ranges' maxima
+    # coincide with the tensor's (plain data: all ranges hold a row at the top scale)
+    inside = native.gemm_tn(dy16.data, x16.data, row_invs=(dy16.inv, x16.inv))
+    assert torch.equal(inside, native.gemm_tn(dy16.data, x16.data, row_invs=(dy16.inv, x16.inv)))
+    i_max, i_rms = _errs(inside, ref)
+    assert i_max <= 1.1 * t_max + 2.0 ** -22 * scale and i_rms <= 1.1 * t_rms + 2.0 ** -24 * scale
+    if not adversarial:
+        assert (inside - got).abs().max().item() <= 2.0 ** -20 * scale
     # the order of the factors inside a fragment: a product whose only non-zero reduction row is r picks dy[r] x[r]^T, for rows of every residue mod 64
     for r in (0, 1, 5, 18, 23, 33, 47, 63, 64 + 38, M - 1):
         dz, xz = torch.zeros_like(dy), torch.zeros_like(x)
@@ -71,6 +80,8 @@ def test_weight_gradient_product_with_row_factors_vs_tf32(M, P, Q, adversarial):
         one = native.gemm_tn(a16.data, b16.data, row_scales=native.row_factors(a16.inv, b16.inv))
         want = torch.outer(dz[r].double(), xz[r].double())
         assert (one.double() - want).abs().max().item() <= 2.0 ** -9 * want.abs().max().item(), r
+        one = native.gemm_tn(a16.data, b16.data, row_invs=(a16.inv, b16.inv))
+        assert (one.double() - want).abs().max().item() <= 2.0 ** -9 * want.abs().max().item(), ("in-kernel factors", r)
 
 
 def test_row_factor_limits_are_refused():
