@@ -478,11 +478,17 @@ def forward_scope(model, rows):
     and ~250 small torch reductions between the big kernels (3 ms of a 90-ms DiM-L/2 forward at batch 256), and lives exactly as long as
     the forward -- weights cannot change inside one. Everything is still rebuilt on EVERY forward (`.data` updates between forwards are
     seen); inside a frozen_weights() scope, under hipGraph capture (the conversion kernels must be part of the graph and their outputs
-    live in its pool: _cached bypasses the cache there), under autograd or another policy this is a no-op."""
+    live in its pool: _cached bypasses the cache there) or another policy this is a no-op. Under autograd (training under the policy) the same
+    launch serves the training forward's weight images (weight_f16s_train, gated_bound_train)."""
     import os
     from . import native
     first = next(model.parameters(), None)
-    if (_policy != "f16s" or _tls.frozen is not None or torch.is_grad_enabled() or not torch.backends.cuda.matmul.allow_tf32 or first is None
+    # under autograd (training on the single-product carrier, section 3.7 of DESIGN.md) the scope serves the forward's weight images too:
+    # gemm.weight_f16s_train finds them here (~150 conversion launches per step); the transposed out_proj images are inference-only
+    training = torch.is_grad_enabled()
+    if (_policy != "f16s" or _tls.frozen is not None or not torch.backends.cuda.matmul.allow_tf32 or first is None
+            or (training and (os.environ.get("DIMSUM_F16S_TRAIN", "1") == "0" or os.environ.get("DIMSUM_SPLIT3_TRAIN", "1") == "0"
+                              or os.environ.get("DIMSUM_FORWARD_SCOPE_TRAIN", "1") == "0" or first.dtype != torch.float32 or torch.is_autocast_enabled("cuda")))
             or not first.is_cuda or torch.cuda.is_current_stream_capturing() or not own_gemm_enabled() or os.environ.get("DIMSUM_SPLIT3", "1") == "0"
             or rows < int(os.environ.get("DIMSUM_SPLIT3_MIN_ROWS", "8192")) or os.environ.get("DIMSUM_FORWARD_SCOPE", "1") == "0"):
         yield
@@ -514,7 +520,7 @@ def forward_scope(model, rows):
         if kind == "plain":
             jobs.append((w.detach(), True, slot, None, 1.0))            # (the L1 norm rides along: one cache entry kind per weight)
             slot += 1
-        elif kind == "plain_t" and os.environ.get("DIMSUM_OUT_PROJ_F16", "1") == "0":
+        elif kind == "plain_t" and (training or os.environ.get("DIMSUM_OUT_PROJ_F16", "1") == "0"):
             layout[-1] = None
         elif kind == "plain_t":
             # all transposed images of one shape share ONE buffer: one transposing copy per shape after the launch instead of one per weight
@@ -726,9 +732,17 @@ def attn_bwd_f16_enabled(qkv):
 
 
 def weight_f16s_train(weight, want_l1=False):
-    """training: the scaled-fp16 image of a weight, rebuilt on every call (the optimizer changes it between steps) -> F16Image [, l1]"""
+    """training: the scaled-fp16 image of a weight, rebuilt on every forward (the optimizer changes it between steps) -> F16Image [, l1]: from the
+    forward's one multi-job launch when DiM.forward opened a forward_scope, else by a launch of its own"""
     from . import native
+    if _tls.frozen is not None and not torch.cuda.is_current_stream_capturing():
+        return weight_f16s(weight, want_l1=want_l1)
     return native.rows_f16s(weight.detach(), want_l1=want_l1)
+
+
+def train_scope_active():
+    """whether a forward_scope holds this forward's weight images (training under the f16s policy through DiM.forward)"""
+    return _tls.frozen is not None and not torch.cuda.is_current_stream_capturing()
 
 
 def weight_t_f16s_train(weight):

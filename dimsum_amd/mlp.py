@@ -114,8 +114,11 @@ class _ModGatedMlpF16sFn(torch.autograd.Function):
         normed = normed if normed.stride(-1) == 1 else normed.contiguous()
         h16 = native.token_transform(normed, "none", True, scale=scale, shift=shift, split3="f16s")      # data (B, L, H) float16, inv (B, L)
         b12f = None if b12 is None else b12.float()
-        w12_16, l1 = gemm.weight_f16s_train(w12, want_l1=True)
-        bound = torch.cat([l1 * gemm._K10, gemm._absmax(b12f, w12)]).contiguous()
+        if gemm.train_scope_active():          # (DiM.forward's forward_scope built every weight image and the gate's bound in one launch)
+            w12_16, bound = gemm.weight_f16s_train(w12), gemm.gated_bound(w12, b12)
+        else:
+            w12_16, l1 = gemm.weight_f16s_train(w12, want_l1=True)
+            bound = torch.cat([l1 * gemm._K10, gemm._absmax(b12f, w12)]).contiguous()
         g16, x12 = native.gemm_nt(h16.data.view(M, H), w12_16.data, bias=b12f, epilogue="gated_f16", scales=(h16.inv.view(M), w12_16.inv), gate_bound=bound, keep_x12=True)
         w3_16 = gemm.weight_f16s_train(w3)
         m = gemm.nt_f16s_any(g16, w3_16)
