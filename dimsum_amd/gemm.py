@@ -572,11 +572,28 @@ def forward_scope(model, rows):
                 cache[key("kvbound", w)] = (scal[sl:sl + 4], w)
             else:
                 cache[key("kvbound", w)] = (torch.cat([scal[sl:sl + 2], scal[sl:sl + 2]]), w)
+    if not training and os.environ.get("DIMSUM_FORWARD_MEMO", "1") != "0":
+        # A = -exp(A_log) of every mixer (mamba_simple.py:120: two tiny launches per mixer call) as two multi-tensor launches per forward
+        alogs = [a for m in model.modules() for a in (getattr(m, "A_log", None), getattr(m, "A_b_log", None)) if isinstance(a, torch.nn.Parameter) and a.is_cuda]
+        if alogs:
+            vals = torch._foreach_neg(torch._foreach_exp([a.detach().float() for a in alogs]))
+            for a, v in zip(alogs, vals):
+                cache[key("negexpA", a)] = (v, a)
     _tls.frozen = cache
     try:
         yield
     finally:
         _tls.frozen = None
+
+
+def neg_exp(a_log):
+    """-exp(A_log.float()) (mamba_simple.py:120); inside an inference forward_scope: the value built for all mixers at once"""
+    frozen = _tls.frozen
+    if frozen is not None and not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing():
+        hit = frozen.get(("negexpA", a_log.data_ptr(), tuple(a_log.shape), tuple(a_log.stride()), a_log.dtype))
+        if hit is not None:
+            return hit[0]
+    return -torch.exp(a_log.float())
 
 
 def own_gemm_enabled():

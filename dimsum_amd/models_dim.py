@@ -182,7 +182,7 @@ class FinalLayer(nn.Module):
         self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(hidden_size, 2 * hidden_size, bias=True))
 
     def forward(self, x, c):
-        shift, scale = self.adaLN_modulation(c).chunk(2, dim=1)
+        shift, scale = _modulation(self.adaLN_modulation, c).chunk(2, dim=1)
         h = _ln_modulate(self.norm_final, x, shift, scale)
         return self.linear(modulate(self.norm_final(x), shift, scale) if h is None else h)
 
@@ -287,6 +287,15 @@ def _make_mlp(dim, use_gated_mlp=True):
     return cls(in_features=dim, hidden_features=int(dim * 4), act_layer=_approx_gelu, drop=0)
 
 
+def _modulation(seq, c):
+    """seq(c) for an adaLN head `nn.Sequential(nn.SiLU(), nn.Linear)` (models_dim.py:1455, 1544): every block of a DiM applies the SAME SiLU to the
+    same conditioning vector -- inside one DiM forward it is computed once (54 launches per DiM-L/2 forward otherwise), bit-identical"""
+    hit = getattr(gemm._tls, "cond", None)
+    if hit is not None and hit[0] is c and len(seq) == 2 and isinstance(seq[0], nn.SiLU):
+        return seq[1](hit[1])
+    return seq(c)
+
+
 def _mlp_tail(mlp, x, normed, shift, scale, gate):
     """x + gate * mlp(modulate(normed, shift, scale))  (models_dim.py:1111-1115, 1551-1553)"""
     if getattr(mlp, "_fused", False) and gemm.split3_train_enabled(normed, mlp.w12.weight):
@@ -383,7 +392,7 @@ class DiMBlockRaw(_BlockBase):
         """out_split3 (inference, set by an enclosing combined block): the result as the split-bf16 operand image of the qkv Linear"""
         hidden_states, residual = self._prenorm(hidden_states, residual)
         table = self._table(hidden_states.shape[1], hidden_states.device, self._order)
-        shift, scale, gate = self.adaLN_modulation(c).chunk(3, dim=1)
+        shift, scale, gate = _modulation(self.adaLN_modulation, c).chunk(3, dim=1)
         m, hidden_states = _mix_through_images(self.mixer, hidden_states, "none", table, shift, scale, c, fork=True)
         return token_ops.post_mixer(hidden_states, m, gate, "none", table, **({"split3": out_split3} if out_split3 else {})), residual
 
@@ -408,7 +417,7 @@ class _FreqBlock(_BlockBase):
     def forward(self, hidden_states, residual=None, c=None, inference_params=None, out_split3=False):
         hidden_states, residual = self._prenorm(hidden_states, residual)
         table = self._table(hidden_states.shape[1], hidden_states.device, self._order)
-        mods = self.adaLN_modulation(c).chunk(3 if self.no_ffn else 6, dim=1)
+        mods = _modulation(self.adaLN_modulation, c).chunk(3 if self.no_ffn else 6, dim=1)
         shift, scale, gate = mods[:3]
         if self.no_ffn:
             m, hidden_states = _mix_through_images(self.mixer, hidden_states, self.kind, table, shift, scale, c, fork=True)
@@ -536,7 +545,7 @@ class _CombinedBase(_BlockBase):
         # (inference on operand images: "h + proj(..) + b" already in the proj GEMM's epilogue, the norm pass then reads ONE tensor)
         in_epilogue = bool(img) and fast_tail and hidden_states.is_contiguous()
         fused, pb = self.proj.forward_deferred(x1, x2, **({"images": True} if img else {}), **({"residual": hidden_states} if in_epilogue else {}))
-        shift, scale, gate = self.adaLN_modulation(c).chunk(3, dim=1)
+        shift, scale, gate = _modulation(self.adaLN_modulation, c).chunk(3, dim=1)
         if fast_tail:
             # inference: h' = h + proj(..) + b, RMSNorm(h'), modulate -- ONE pass (csrc/norm.hip with x_bias + modulation)
             from . import native
@@ -604,7 +613,7 @@ class DiTBlock(nn.Module):
         self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(hidden_size, 6 * hidden_size, bias=True))
 
     def forward(self, x, c=None, **kwargs):
-        sa, ca, ga, sm, cm, gm = self.adaLN_modulation(c).chunk(6, dim=1)
+        sa, ca, ga, sm, cm, gm = _modulation(self.adaLN_modulation, c).chunk(6, dim=1)
         s3 = gemm.split3_enabled(x, self.attn.qkv.weight, producer="norm")      # inference under allow_tf32: the norm passes write operand images
         h = _ln_modulate(self.norm1, x, sa, ca, split3=s3)
         from . import native
@@ -778,6 +787,13 @@ class DiM(nn.Module):
 
     def _forward(self, x, t, y, inference_params):
         c = self.t_embedder(t) + self.y_embedder(y, self.training)
+        gemm._tls.cond = (c, F.silu(c)) if os.environ.get("DIMSUM_FORWARD_MEMO", "1") != "0" else None      # (the adaLN heads' shared SiLU(c): _modulation)
+        try:
+            return self._forward_blocks(x, c, inference_params)
+        finally:
+            gemm._tls.cond = None
+
+    def _forward_blocks(self, x, c, inference_params):
         x = self.x_embedder(x) + self.pos_embed
         residual = None
         for idx, block in enumerate(self.blocks):

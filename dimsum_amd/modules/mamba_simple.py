@@ -117,9 +117,9 @@ class _MambaBase(nn.Module):
             xz = xz + self.in_proj.bias.to(xz.dtype).view(1, -1, 1)
         # recomputed on every call (two tiny launches): a cached copy could not see in-place parameter updates made through
         # `.data` (EMA, load_state_dict), which do not bump the version counter, and would be frozen into a captured hipGraph
-        A = -torch.exp(self.A_log.float())
+        A = gemm.neg_exp(self.A_log)
         if self.scan_type == "v2":
-            A_b = -torch.exp(self.A_b_log.float())
+            A_b = gemm.neg_exp(self.A_b_log)
             out = mamba_inner_fn_no_out_proj_cond(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
                                                   self.dt_proj.weight, A, None, None, self.D.float(),
                                                   delta_bias=self.dt_proj.bias.float(), delta_softplus=True, init_states=cond)
