@@ -150,47 +150,64 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const dimsum_norm_bwd_par
         dw[i] = {{0.f, 0.f, 0.f, 0.f}};
         db[i] = {{0.f, 0.f, 0.f, 0.f}};
     }
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < p.rows; row += (int64_t)gridDim.x * 4) {
-        const float *r = reinterpret_cast<const float *>(p.r_ptr) + row * p.r_row_stride;
-        const float *dy = reinterpret_cast<const float *>(p.dy_ptr) + row * p.dy_row_stride;
-        const float *dres = p.dres_ptr ? reinterpret_cast<const float *>(p.dres_ptr) + row * p.dres_row_stride : nullptr;
-        float *dx = reinterpret_cast<float *>(p.dx_ptr) + row * p.dx_row_stride;
-        const float rstd = reinterpret_cast<const float *>(p.rstd_ptr)[row];
-        const float mean = (p.is_rms_norm || !p.mean_ptr) ? 0.f : reinterpret_cast<const float *>(p.mean_ptr)[row];
-        f32x4 xh[kPieces], wdy[kPieces], dr[kPieces];
-        float c1 = 0.f, c2 = 0.f;
-        // all three row streams are requested up front (dres is only needed after the row reduction: loading it there would
-        // expose its latency once per row)
+    // TWO rows per trip, all six row streams requested before the first reduction: a wave that walks its rows one at a time exposes a full
+    // memory round trip per row (the grid is capped at ~2 waves per SIMD because every workgroup ends in N atomics), 3.4 TB/s at 16384 rows.
+    // dres is only needed after the row reduction but is requested up front with the rest.
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    constexpr int kRows = kPieces <= 5 ? 2 : 1;          // (8 pieces: two rows in flight would need 336 VGPRs)
+    for (int64_t row0 = (int64_t)blockIdx.x * 4 + wave; row0 < p.rows; row0 += kRows * stride) {
+        f32x4 rv[kRows][kPieces], g[kRows][kPieces], dr[kRows][kPieces];
+        float rstd[kRows], mean[kRows];
+        bool live[kRows];
 #pragma unroll
-        for (int i = 0; i < kPieces; ++i) {
-            const int c = (i * kWave + lane) * 4;
-            dr[i] = (dres && c < N) ? ld_cols<float>(dres, c, N, vec) : f32x4{{0.f, 0.f, 0.f, 0.f}};
-        }
+        for (int u = 0; u < kRows; ++u) {
+            const int64_t row = row0 + u * stride;
+            live[u] = row < p.rows;
+            const int64_t lr = live[u] ? row : row0;          // (a missing second row re-reads the first: no branch around the loads)
+            const float *r = reinterpret_cast<const float *>(p.r_ptr) + lr * p.r_row_stride;
+            const float *dy = reinterpret_cast<const float *>(p.dy_ptr) + lr * p.dy_row_stride;
+            const float *dres = p.dres_ptr ? reinterpret_cast<const float *>(p.dres_ptr) + lr * p.dres_row_stride : nullptr;
+            rstd[u] = reinterpret_cast<const float *>(p.rstd_ptr)[lr];
+            mean[u] = (p.is_rms_norm || !p.mean_ptr) ? 0.f : reinterpret_cast<const float *>(p.mean_ptr)[lr];
 #pragma unroll
-        for (int i = 0; i < kPieces; ++i) {
-            const int c = (i * kWave + lane) * 4;
-            const f32x4 rv = ld_cols<float>(r, c, N, vec), g = ld_cols<float>(dy, c, N, vec);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const bool in = c + e < N;
-                xh[i].v[e] = in ? (rv.v[e] - mean) * rstd : 0.f;
-                wdy[i].v[e] = wreg[i].v[e] * g.v[e];
-                c1 += xh[i].v[e] * wdy[i].v[e];
-                c2 += wdy[i].v[e];
-                dw[i].v[e] = fmaf(g.v[e], xh[i].v[e], dw[i].v[e]);
-                db[i].v[e] += g.v[e];
+            for (int i = 0; i < kPieces; ++i) {
+                const int c = (i * kWave + lane) * 4;
+                rv[u][i] = ld_cols<float>(r, c, N, vec);
+                g[u][i] = ld_cols<float>(dy, c, N, vec);
+                dr[u][i] = (dres && c < N) ? ld_cols<float>(dres, c, N, vec) : f32x4{{0.f, 0.f, 0.f, 0.f}};
             }
         }
-        c1 = wave_allsum(c1) * inv_n;
-        c2 = p.is_rms_norm ? 0.f : wave_allsum(c2) * inv_n;
 #pragma unroll
-        for (int i = 0; i < kPieces; ++i) {
-            const int c = (i * kWave + lane) * 4;
-            if (c < N) {
-                f32x4 o = dr[i];
+        for (int u = 0; u < kRows; ++u) {
+            if (!live[u]) continue;                            // (wave-uniform)
+            float *dx = reinterpret_cast<float *>(p.dx_ptr) + (row0 + u * stride) * p.dx_row_stride;
+            f32x4 xh[kPieces], wdy[kPieces];
+            float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o.v[e] += (wdy[i].v[e] - (xh[i].v[e] * c1 + c2)) * rstd;
-                st_cols<float>(dx, c, N, vec, o);
+            for (int i = 0; i < kPieces; ++i) {
+                const int c = (i * kWave + lane) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool in = c + e < N;
+                    xh[i].v[e] = in ? (rv[u][i].v[e] - mean[u]) * rstd[u] : 0.f;
+                    wdy[i].v[e] = wreg[i].v[e] * g[u][i].v[e];
+                    c1 += xh[i].v[e] * wdy[i].v[e];
+                    c2 += wdy[i].v[e];
+                    dw[i].v[e] = fmaf(g[u][i].v[e], xh[i].v[e], dw[i].v[e]);
+                    db[i].v[e] += g[u][i].v[e];
+                }
+            }
+            c1 = wave_allsum(c1) * inv_n;
+            c2 = p.is_rms_norm ? 0.f : wave_allsum(c2) * inv_n;
+#pragma unroll
+            for (int i = 0; i < kPieces; ++i) {
+                const int c = (i * kWave + lane) * 4;
+                if (c < N) {
+                    f32x4 o = dr[u][i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o.v[e] += (wdy[i].v[e] - (xh[i].v[e] * c1 + c2)) * rstd[u];
+                    st_cols<float>(dx, c, N, vec, o);
+                }
             }
         }
     }
@@ -198,7 +215,9 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const dimsum_norm_bwd_par
     // ~40 % of the kernel's time with one per wave), which also leaves room for twice the waves in flight.
     __shared__ __attribute__((aligned(16))) float sred[4 * kPieces * kWave * 4];
     float *dwp = reinterpret_cast<float *>(p.dweight_ptr), *dbp = reinterpret_cast<float *>(p.dbias_ptr);
-    for (int pass = 0; pass < (dbp ? 2 : 1); ++pass) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {          // (unrolled: `pass ? db : dw` on a runtime index put both arrays into scratch)
+        if (pass && !dbp) break;
         if (pass) __syncthreads();
 #pragma unroll
         for (int i = 0; i < kPieces; ++i)
@@ -308,7 +327,10 @@ extern "C" int dimsum_norm_bwd(const dimsum_norm_bwd_params_t *p, void *stream) 
     const int pieces = (N + 255) / 256;
     // few, fat workgroups: every workgroup ends with N atomics, so cap the grid at ~2 waves per SIMD
     const int64_t blocks = (p->rows + 3) / 4;
-    const dim3 grid((unsigned)(blocks < 512 ? blocks : 512)), block(256);    // measured: 256 -> 370 us, 512 -> 256 us, 1024 -> 308 us
+    // measured with two rows per trip (tools/scratch/norm_bwd_time.py), 65536 x 1024: 256 workgroups 382 us, 384: 303, 512: 266 (one round at 2 per CU),
+    // 768: 336, 1024: 301; 16384 x 1024 (a training step at 64 latents; the N atomics per workgroup weigh more): 256: 87, 384: 83, 512: 93, 768: 112
+    const int64_t cap = p->rows >= 32768 ? 512 : 384;
+    const dim3 grid((unsigned)(blocks < cap ? blocks : cap)), block(256);
 #define DIMSUM_NB(K) hipLaunchKernelGGL((norm_bwd_kernel<K>), grid, block, 0, s, *p, vec)
     if (pieces <= 1) DIMSUM_NB(1);
     else if (pieces <= 2) DIMSUM_NB(2);
