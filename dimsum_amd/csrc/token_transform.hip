@@ -119,7 +119,11 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
 #pragma unroll
         for (int k = 0; k < 16; ++k) s_of[k] = (bh * 4 + (k >> 2)) * G + bw * 4 + (k & 3);
     }
-    auto pos_of = [&](int k) { return KIND == DIMSUM_TT_NONE ? (int)blockIdx.x * 16 + k : s_of[k]; };   // NONE: k may be dynamic
+    // KIND NONE with reductions: a workgroup walks several 16-token groups (grid-stride over the groups) and flushes its per-(batch, channel)
+    // partial sums ONCE -- the atomics were most of such a pass (64 x 256 x 512 with three sums: 56 us against 18 for the plain pass)
+    int grp = blockIdx.x;
+    const int ngrp = KIND == DIMSUM_TT_NONE ? (p.tokens + 15) / 16 : 1;
+    auto pos_of = [&](int k) { return KIND == DIMSUM_TT_NONE ? grp * 16 + k : s_of[k]; };   // NONE: k may be dynamic
     float stash[F16S ? 16 : 1][VEC], tmax[F16S ? 16 : 1];      // F16S: the outputs of this thread's channel group, the running row maxima
     if constexpr (F16S) {
 #pragma unroll
@@ -214,11 +218,13 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
             if (sub < nsub) {
                 auto pass = [&](auto perc) {
                     constexpr int PER = decltype(perc)::value;
-                    float v[PER][VEC];
+                    for (grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
+                        float v[PER][VEC];
 #pragma unroll
-                    for (int k = 0; k < PER; ++k) load_in(sub * PER + k, c, v[k]);
+                        for (int k = 0; k < PER; ++k) load_in(sub * PER + k, c, v[k]);
 #pragma unroll
-                    for (int k = 0; k < PER; ++k) store_out(sub * PER + k, c, v[k]);
+                        for (int k = 0; k < PER; ++k) store_out(sub * PER + k, c, v[k]);
+                    }
                     flush_red(c);
                 };
                 if (nsub == 2) pass(std::integral_constant<int, 8>{});
@@ -279,6 +285,20 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) o[e] = (KIND == DIMSUM_TT_NONE) ? X[e][k] : Y[e][k];
                     store_out(k, c, o); }
+                if constexpr (KIND == DIMSUM_TT_NONE && !F16S) {        // the further token groups of this workgroup (X holds group blockIdx.x)
+                    for (grp = blockIdx.x + gridDim.x; grp < ngrp; grp += gridDim.x) {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) { float v[VEC]; load_in(k, c, v);
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) X[e][k] = v[e]; }
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) { float o[VEC];
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) o[e] = X[e][k];
+                            store_out(k, c, o); }
+                    }
+                    grp = blockIdx.x;
+                }
                 flush_red(c);
             }
         }
@@ -401,7 +421,15 @@ static int launch_tt(const dimsum_tt_params_t &p, hipStream_t s) {
     // a thread owns 4 channels of all 16 tokens of a 4 x 4 block: with 512 channels (a branch of DiM-L/2) a 256-thread block would idle half
     // its threads at 2 blocks per CU (230-240 VGPRs): the blocked kinds get a block of the channel-group count instead
     const int cgs = (p.channels + VEC - 1) / VEC;
-    const dim3 grid(nblk, p.batch), block(blocked ? (cgs <= 64 ? 64 : (cgs <= 128 ? 128 : kTTThreads)) : kTTThreads);
+    // KIND NONE with reductions: fewer, longer workgroups (see the kernel) as long as ~2 per CU remain
+    int gx = nblk;
+    if (!blocked && (p.w_ptr || p.tsum_ptr) && p.y_split3 != 2) {
+        // measured (tools/scratch/tt_red_time.py; us at 64 / 256 latents x 256 tokens x 512 channels): sums only 38 / 123 with one group per
+        // workgroup, 28 / 63 down to 512 workgroups; y + wdot 33 / 122 -> 33 / 108 down to 1024 but 43 / 157 at 512 (the stores want the waves)
+        const int min_wgs = p.y_ptr ? 1024 : 512;
+        while (gx % 2 == 0 && (int64_t)(gx / 2) * p.batch >= min_wgs) gx /= 2;
+    }
+    const dim3 grid(gx, p.batch), block(blocked ? (cgs <= 64 ? 64 : (cgs <= 128 ? 128 : kTTThreads)) : kTTThreads);
     size_t lds = (p.kind == DIMSUM_TT_HAAR_FWD || p.kind == DIMSUM_TT_HAAR_INV) ? (size_t)((p.channels + 3) / 4) * 68 * 4 : 0;
     if (lds > 160 * 1024) return DIMSUM_ERR_SHAPE;
     // kind NONE without reductions (every inference token pass outside the frequency branch): one wave per token row
