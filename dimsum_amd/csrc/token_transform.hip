@@ -17,6 +17,7 @@
 // output token p of the block, channel c' holds band q of input channel c with  q*C + c = c'*16 + p.  That regrouping
 // mixes channels across threads, so the coefficients go through an LDS image indexed by the flat j = q*C + c, stored
 // as [c'/4][p][c'%4] with 68-dword rows: 16-B reads by the storing thread (4 channels of one token) are conflict free.
+#include <stdlib.h>
 #include <type_traits>
 
 #include "common.hpp"
@@ -102,7 +103,12 @@ __device__ __forceinline__ void dct16(const float *X, float *Y, bool inverse) { 
 // F16S: y is the scaled-fp16 operand image of the Linear that consumes it (common.hpp, f16s): a token's row of C channels is spread over
 // the workgroup's threads, so the 16 tokens' outputs wait in registers for their exact row maxima (wave butterflies + 4 x 16 floats of
 // LDS); C <= 4 * kTTThreads (one channel group per thread).
-template <int KIND, int VEC, bool F16S = false>
+// kFix (blocked kinds with the image output: the two passes around the frequency branch's mixer): which optional operands exist is a COMPILE-TIME
+// fact -- 1 = scale + shift only (the pre-mixer pass), 2 = gate + residual only (the post-mixer pass), 0 = decided at run time. A run-time
+// `if (ptr)` around a vector load is a uniform branch per token and per operand: ~2800 scalar instructions in the unrolled 16-token body, and
+// no load moves across a branch, so every token's loads waited for the previous token's (Haar forward + image 94 us = 2.1 TB/s at 256 latents).
+// With the presence known and the 16 token indices fetched up front the body is straight-line code.
+template <int KIND, int VEC, bool F16S = false, int kFix = 0>
 __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsum_tt_params_t p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -124,6 +130,24 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
     int grp = blockIdx.x;
     const int ngrp = KIND == DIMSUM_TT_NONE ? (p.tokens + 15) / 16 : 1;
     auto pos_of = [&](int k) { return KIND == DIMSUM_TT_NONE ? grp * 16 + k : s_of[k]; };   // NONE: k may be dynamic
+    // blocked kinds: the source / destination token of the 16 positions, fetched once (ONE branch per table instead of one per token and use)
+    int tin[KIND == DIMSUM_TT_NONE ? 1 : 16], tout[KIND == DIMSUM_TT_NONE ? 1 : 16];
+    if constexpr (KIND != DIMSUM_TT_NONE) {
+        if (p.in_index_ptr) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) tin[k] = p.in_index_ptr[s_of[k]];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) tin[k] = s_of[k];
+        }
+        if (p.out_index_ptr) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) tout[k] = p.out_index_ptr[s_of[k]];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) tout[k] = s_of[k];
+        }
+    }
     float stash[F16S ? 16 : 1][VEC], tmax[F16S ? 16 : 1];      // F16S: the outputs of this thread's channel group, the running row maxima
     if constexpr (F16S) {
 #pragma unroll
@@ -137,6 +161,11 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
     const float *shift = p.shift_ptr ? reinterpret_cast<const float *>(p.shift_ptr) + (int64_t)b * p.mod_batch_stride : nullptr;
 
     const float *wb = p.w_ptr ? reinterpret_cast<const float *>(p.w_ptr) + (int64_t)b * p.w_batch_stride : nullptr;
+    const bool has_gate = kFix == 2 ? true : (kFix == 1 ? false : gate != nullptr);
+    const bool has_mod = kFix == 1 ? true : (kFix == 2 ? false : scale != nullptr);          // scale (kFix: scale AND shift)
+    const bool has_shift = kFix == 1 ? true : (kFix == 2 ? false : shift != nullptr);
+    const bool has_res = kFix == 2 ? true : (kFix == 1 ? false : rb != nullptr);
+    const bool has_w = kFix != 0 ? false : wb != nullptr, has_tsum = kFix != 0 ? false : p.tsum_ptr != nullptr;
     float wdot[VEC], wsum[VEC], tsum[VEC];       // this thread's partial reductions for the channel group it is storing
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { wdot[e] = 0.f; wsum[e] = 0.f; tsum[e] = 0.f; }
@@ -157,25 +186,32 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
         else dst[0] = *ptr;
     };
     auto store_out = [&](int k, int c, const float *val) {       // position k of the block, channels c..c+VEC-1
-        if (pos_of(k) >= p.tokens) return;
-        const int tok = p.out_index_ptr ? p.out_index_ptr[pos_of(k)] : pos_of(k);
+#pragma clang fp contract(off)      // (the image of y must be the image of the fp32 pass's y: with the operands' presence known at compile time the
+                                    //  multiply by (1 + scale), the shift and the residual add sit in one basic block and would fuse into FMAs)
+        int tok;
+        if constexpr (KIND == DIMSUM_TT_NONE) {
+            if (pos_of(k) >= p.tokens) return;
+            tok = p.out_index_ptr ? p.out_index_ptr[pos_of(k)] : pos_of(k);
+        } else {
+            tok = tout[k];                                        // (blocked kinds: the grid covers whole 4 x 4 blocks)
+        }
         float o[VEC], t[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) o[e] = val[e];
-        if (wb) { load_vec(wb + (int64_t)tok * p.w_token_stride + c, t);
+        if (has_w) { load_vec(wb + (int64_t)tok * p.w_token_stride + c, t);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) { wdot[e] = fmaf(o[e], t[e], wdot[e]); wsum[e] += t[e]; } }
-        if (p.tsum_ptr) {
+        if (has_tsum) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) tsum[e] += o[e]; }
-        if (!yb) return;
-        if (scale) { load_vec(scale + c, t);
+        if (kFix == 0 && !yb) return;
+        if (has_mod) { load_vec(scale + c, t);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) o[e] *= 1.0f + t[e]; }
-        if (shift) { load_vec(shift + c, t);
+        if (has_shift) { load_vec(shift + c, t);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) o[e] += t[e]; }
-        if (rb) { load_vec(rb + (int64_t)tok * p.res_token_stride + c, t);
+        if (has_res) { load_vec(rb + (int64_t)tok * p.res_token_stride + c, t);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) o[e] += t[e]; }
         if constexpr (F16S) {
@@ -195,14 +231,20 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
         else dst[0] = o[0];
     };
     auto load_in = [&](int k, int c, float *dst) {               // gated input of position k
-        if (pos_of(k) >= p.tokens) {
+#pragma clang fp contract(off)
+        int tok;
+        if constexpr (KIND == DIMSUM_TT_NONE) {
+            if (pos_of(k) >= p.tokens) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) dst[e] = 0.f;
-            return;
+                for (int e = 0; e < VEC; ++e) dst[e] = 0.f;
+                return;
+            }
+            tok = p.in_index_ptr ? p.in_index_ptr[pos_of(k)] : pos_of(k);
+        } else {
+            tok = tin[k];
         }
-        const int tok = p.in_index_ptr ? p.in_index_ptr[pos_of(k)] : pos_of(k);
         load_vec(xb + (int64_t)tok * p.x_token_stride + c, dst);
-        if (gate) { float t[VEC]; load_vec(gate + c, t);
+        if (has_gate) { float t[VEC]; load_vec(gate + c, t);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) dst[e] *= t[e]; }
     };
@@ -341,12 +383,14 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
         float *inv_out = reinterpret_cast<float *>(p.y_inv_scale_ptr) + (int64_t)b * p.tokens;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            if (pos_of(k) >= p.tokens) continue;
+            if (KIND == DIMSUM_TT_NONE && pos_of(k) >= p.tokens) continue;
             float m = red[k];
             for (int w = 1; w < (nthreads >> 6); ++w) m = fmaxf(m, red[w * 16 + k]);
             float sc, inv;
             f16s_scales(m, sc, inv);
-            const int tok = p.out_index_ptr ? p.out_index_ptr[pos_of(k)] : pos_of(k);
+            int tok;
+            if constexpr (KIND == DIMSUM_TT_NONE) tok = p.out_index_ptr ? p.out_index_ptr[pos_of(k)] : pos_of(k);
+            else tok = tout[k];
             if (c < C) *reinterpret_cast<uint2 *>(yh + (int64_t)tok * p.y_token_stride + c) = f16s_pack4(f32x4{{stash[k][0], stash[k][1], stash[k][2], stash[k][3]}}, sc);
             if (tid == k) inv_out[tok] = inv;
         }
@@ -458,7 +502,12 @@ static int launch_tt(const dimsum_tt_params_t &p, hipStream_t s) {
             lds += 64 * 4;
             const int cg = (p.channels + 3) / 4;
             const dim3 blockh(cg <= 64 ? 64 : (cg <= 128 ? 128 : kTTThreads));
-#define DIMSUM_TTH(K) hipLaunchKernelGGL((token_transform_kernel<K, 4, true>), grid, blockh, lds, s, q)
+            // the two passes around the frequency branch's mixer as the model issues them: operand presence fixed at compile time (kFix, see the kernel)
+            static const bool fix = !(getenv("DIMSUM_TT_FIX") && atoi(getenv("DIMSUM_TT_FIX")) == 0);          // (A / B: 0 = the run-time checks)
+            const bool pre = fix && p.scale_ptr && p.shift_ptr && !p.gate_ptr && !p.residual_ptr, post = fix && p.gate_ptr && p.residual_ptr && !p.scale_ptr && !p.shift_ptr;
+#define DIMSUM_TTH(K) do { if (blocked && pre) hipLaunchKernelGGL((token_transform_kernel<K, 4, true, (K) == DIMSUM_TT_NONE ? 0 : 1>), grid, blockh, lds, s, q);          \
+                           else if (blocked && post) hipLaunchKernelGGL((token_transform_kernel<K, 4, true, (K) == DIMSUM_TT_NONE ? 0 : 2>), grid, blockh, lds, s, q);    \
+                           else hipLaunchKernelGGL((token_transform_kernel<K, 4, true, 0>), grid, blockh, lds, s, q); } while (0)
             switch (p.kind) {
                 case DIMSUM_TT_NONE: DIMSUM_TTH(DIMSUM_TT_NONE); break;
                 case DIMSUM_TT_HAAR_FWD: DIMSUM_TTH(DIMSUM_TT_HAAR_FWD); break;
@@ -471,6 +520,26 @@ static int launch_tt(const dimsum_tt_params_t &p, hipStream_t s) {
             return launch_status();
         }
         return DIMSUM_ERR_STRIDE;
+    }
+    // (the same compile-time operand presence for the fp32 / split-bf16 outputs of the blocked kinds: the training forward's two passes and the
+    // pre-mixer's adjoint with the tail gradient as its residual)
+    if constexpr (VEC == 4) {
+        static const bool fix = !(getenv("DIMSUM_TT_FIX") && atoi(getenv("DIMSUM_TT_FIX")) == 0);
+        const bool plain = fix && blocked && p.y_ptr && !p.w_ptr && !p.tsum_ptr;
+        const int kf = !plain ? 0 : (p.scale_ptr && p.shift_ptr && !p.gate_ptr && !p.residual_ptr) ? 1 : (p.gate_ptr && p.residual_ptr && !p.scale_ptr && !p.shift_ptr) ? 2 : 0;
+        if (kf) {
+#define DIMSUM_TTF(K) do { if (kf == 1) hipLaunchKernelGGL((token_transform_kernel<K, 4, false, 1>), grid, block, lds, s, p);      \
+                           else hipLaunchKernelGGL((token_transform_kernel<K, 4, false, 2>), grid, block, lds, s, p); } while (0)
+            switch (p.kind) {
+                case DIMSUM_TT_HAAR_FWD: DIMSUM_TTF(DIMSUM_TT_HAAR_FWD); break;
+                case DIMSUM_TT_HAAR_INV: DIMSUM_TTF(DIMSUM_TT_HAAR_INV); break;
+                case DIMSUM_TT_DCT_FWD: DIMSUM_TTF(DIMSUM_TT_DCT_FWD); break;
+                case DIMSUM_TT_DCT_INV: DIMSUM_TTF(DIMSUM_TT_DCT_INV); break;
+                default: return DIMSUM_ERR_SHAPE;
+            }
+#undef DIMSUM_TTF
+            return launch_status();
+        }
     }
 #define DIMSUM_TT(K) hipLaunchKernelGGL((token_transform_kernel<K, VEC>), grid, block, lds, s, p)
     switch (p.kind) {
