@@ -161,11 +161,15 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
     const float *shift = p.shift_ptr ? reinterpret_cast<const float *>(p.shift_ptr) + (int64_t)b * p.mod_batch_stride : nullptr;
 
     const float *wb = p.w_ptr ? reinterpret_cast<const float *>(p.w_ptr) + (int64_t)b * p.w_batch_stride : nullptr;
-    const bool has_gate = kFix == 2 ? true : (kFix == 1 ? false : gate != nullptr);
-    const bool has_mod = kFix == 1 ? true : (kFix == 2 ? false : scale != nullptr);          // scale (kFix: scale AND shift)
-    const bool has_shift = kFix == 1 ? true : (kFix == 2 ? false : shift != nullptr);
-    const bool has_res = kFix == 2 ? true : (kFix == 1 ? false : rb != nullptr);
-    const bool has_w = kFix != 0 ? false : wb != nullptr, has_tsum = kFix != 0 ? false : p.tsum_ptr != nullptr;
+    // kFix:            0 run time | 1 scale + shift | 2 gate + residual | 3 scale + w | 4 w, no y | 5 scale + w + token sums
+    //                  (1, 2: the forward passes around a mixer and the pre-mixer's adjoint; 3, 4, 5: the training backward's passes with reductions)
+    const bool has_gate = kFix == 0 ? gate != nullptr : kFix == 2;
+    const bool has_mod = kFix == 0 ? scale != nullptr : (kFix == 1 || kFix == 3 || kFix == 5);
+    const bool has_shift = kFix == 0 ? shift != nullptr : kFix == 1;
+    const bool has_res = kFix == 0 ? rb != nullptr : kFix == 2;
+    const bool has_w = kFix == 0 ? wb != nullptr : kFix >= 3;
+    const bool has_tsum = kFix == 0 ? p.tsum_ptr != nullptr : kFix == 5;
+    const bool has_y = kFix == 0 ? yb != nullptr : kFix != 4;
     float wdot[VEC], wsum[VEC], tsum[VEC];       // this thread's partial reductions for the channel group it is storing
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { wdot[e] = 0.f; wsum[e] = 0.f; tsum[e] = 0.f; }
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(kTTThreads) void token_transform_kernel(const dimsu
         if (has_tsum) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) tsum[e] += o[e]; }
-        if (kFix == 0 && !yb) return;
+        if (!has_y) return;
         if (has_mod) { load_vec(scale + c, t);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) o[e] *= 1.0f + t[e]; }
@@ -525,12 +529,19 @@ static int launch_tt(const dimsum_tt_params_t &p, hipStream_t s) {
     // pre-mixer's adjoint with the tail gradient as its residual)
     if constexpr (VEC == 4) {
         static const bool fix = !(getenv("DIMSUM_TT_FIX") && atoi(getenv("DIMSUM_TT_FIX")) == 0);
-        const bool plain = fix && blocked && p.y_ptr && !p.w_ptr && !p.tsum_ptr;
-        const int kf = !plain ? 0 : (p.scale_ptr && p.shift_ptr && !p.gate_ptr && !p.residual_ptr) ? 1 : (p.gate_ptr && p.residual_ptr && !p.scale_ptr && !p.shift_ptr) ? 2 : 0;
+        const bool sc = p.scale_ptr != nullptr, sh = p.shift_ptr != nullptr, ga = p.gate_ptr != nullptr, re = p.residual_ptr != nullptr;
+        const bool w = p.w_ptr != nullptr, ts = p.tsum_ptr != nullptr, y = p.y_ptr != nullptr;
+        int kf = 0;
+        if (fix && !w && !ts && y) kf = (blocked && sc && sh && !ga && !re) ? 1 : (blocked && ga && re && !sc && !sh) ? 2 : 0;
+        else if (fix && w && !sh && !ga && !re) kf = (sc && !ts && y) ? 3 : (!sc && !ts && !y) ? 4 : (sc && ts && y) ? 5 : 0;
         if (kf) {
 #define DIMSUM_TTF(K) do { if (kf == 1) hipLaunchKernelGGL((token_transform_kernel<K, 4, false, 1>), grid, block, lds, s, p);      \
-                           else hipLaunchKernelGGL((token_transform_kernel<K, 4, false, 2>), grid, block, lds, s, p); } while (0)
+                           else if (kf == 2) hipLaunchKernelGGL((token_transform_kernel<K, 4, false, 2>), grid, block, lds, s, p); \
+                           else if (kf == 3) hipLaunchKernelGGL((token_transform_kernel<K, 4, false, 3>), grid, block, lds, s, p); \
+                           else if (kf == 4) hipLaunchKernelGGL((token_transform_kernel<K, 4, false, 4>), grid, block, lds, s, p); \
+                           else hipLaunchKernelGGL((token_transform_kernel<K, 4, false, 5>), grid, block, lds, s, p); } while (0)
             switch (p.kind) {
+                case DIMSUM_TT_NONE: DIMSUM_TTF(DIMSUM_TT_NONE); break;
                 case DIMSUM_TT_HAAR_FWD: DIMSUM_TTF(DIMSUM_TT_HAAR_FWD); break;
                 case DIMSUM_TT_HAAR_INV: DIMSUM_TTF(DIMSUM_TT_HAAR_INV); break;
                 case DIMSUM_TT_DCT_FWD: DIMSUM_TTF(DIMSUM_TT_DCT_FWD); break;
