@@ -59,24 +59,36 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const dimsum_norm_params_
         TY *y = reinterpret_cast<TY *>(p.y_ptr) + row * p.y_row_stride;
         f32x4 r[kPieces];
         float s = 0.f;
+        // one branch per OPERAND, not per piece: no load moves across a branch, so `if (res)` inside the piece loop made every piece's loads wait
+        // for the previous piece's (the same finding as in the blocked token passes)
 #pragma unroll
-        for (int i = 0; i < kPieces; ++i) {
-            const int c = (i * kWave + lane) * 4;
-            r[i] = ld_cols<TX>(x, c, N, vec);
-            if (xb) {
-                const f32x4 q = ld_cols<float>(xb, c, N, vec);
+        for (int i = 0; i < kPieces; ++i) r[i] = ld_cols<TX>(x, (i * kWave + lane) * 4, N, vec);
+        if (xb) {
+            f32x4 q[kPieces];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) r[i].v[e] += q.v[e];
-            }
-            if (res) {
-                const f32x4 q = ld_cols<TR>(res, c, N, vec);
+            for (int i = 0; i < kPieces; ++i) q[i] = ld_cols<float>(xb, (i * kWave + lane) * 4, N, vec);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) r[i].v[e] += q.v[e];
-            }
-            if (ro) st_cols<TR>(ro, c, N, vec, r[i]);
+            for (int i = 0; i < kPieces; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[i].v[e] += q[i].v[e];
+        }
+        if (res) {
+            f32x4 q[kPieces];
+#pragma unroll
+            for (int i = 0; i < kPieces; ++i) q[i] = ld_cols<TR>(res, (i * kWave + lane) * 4, N, vec);
+#pragma unroll
+            for (int i = 0; i < kPieces; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[i].v[e] += q[i].v[e];
+        }
+        if (ro) {
+#pragma unroll
+            for (int i = 0; i < kPieces; ++i) st_cols<TR>(ro, (i * kWave + lane) * 4, N, vec, r[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < kPieces; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) s += p.is_rms_norm ? r[i].v[e] * r[i].v[e] : r[i].v[e];
-        }
         s = wave_allsum(s);
         float mean = 0.f, var;
         if (p.is_rms_norm) {
