@@ -420,20 +420,42 @@ __global__ __launch_bounds__(256) void token_rows_kernel(const dimsum_tt_params_
         const float *shift = p.shift_ptr ? reinterpret_cast<const float *>(p.shift_ptr) + (int64_t)b * p.mod_batch_stride : nullptr;
         f32x4 v[kPieces];
         float m = 0.f;
+        // one branch per optional OPERAND, not per piece (no load moves across a branch: DESIGN 3.3); the order of the operations per element is
+        // the old one -- gate, 1 + scale, shift, residual -- and they stay separate instructions (separate basic blocks: no FMA contraction)
+        auto ld = [&](const float *ptr, f32x4 (&q)[kPieces]) {
 #pragma unroll
-        for (int i = 0; i < kPieces; ++i) {
-            const int c = (i * 64 + lane) * 4;
-            if (c < C) {
-                const float4 t = *reinterpret_cast<const float4 *>(x + c);
-                v[i] = f32x4{{t.x, t.y, t.z, t.w}};
-                if (gate) { const float4 g = *reinterpret_cast<const float4 *>(gate + c); v[i].v[0] *= g.x; v[i].v[1] *= g.y; v[i].v[2] *= g.z; v[i].v[3] *= g.w; }
-                if (scale) { const float4 g = *reinterpret_cast<const float4 *>(scale + c); v[i].v[0] *= 1.0f + g.x; v[i].v[1] *= 1.0f + g.y; v[i].v[2] *= 1.0f + g.z; v[i].v[3] *= 1.0f + g.w; }
-                if (shift) { const float4 g = *reinterpret_cast<const float4 *>(shift + c); v[i].v[0] += g.x; v[i].v[1] += g.y; v[i].v[2] += g.z; v[i].v[3] += g.w; }
-                if (res) { const float4 g = *reinterpret_cast<const float4 *>(res + c); v[i].v[0] += g.x; v[i].v[1] += g.y; v[i].v[2] += g.z; v[i].v[3] += g.w; }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v[i].v[e]));
+            for (int i = 0; i < kPieces; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                const float4 t = c < C ? *reinterpret_cast<const float4 *>(ptr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                q[i] = f32x4{{t.x, t.y, t.z, t.w}};
             }
-        }
+        };
+        f32x4 q[kPieces];
+        ld(x, v);
+        if (gate) { ld(gate, q);
+#pragma unroll
+            for (int i = 0; i < kPieces; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[i].v[e] *= q[i].v[e]; }
+        if (scale) { ld(scale, q);
+#pragma unroll
+            for (int i = 0; i < kPieces; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[i].v[e] *= 1.0f + q[i].v[e]; }
+        if (shift) { ld(shift, q);
+#pragma unroll
+            for (int i = 0; i < kPieces; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[i].v[e] += q[i].v[e]; }
+        if (res) { ld(res, q);
+#pragma unroll
+            for (int i = 0; i < kPieces; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[i].v[e] += q[i].v[e]; }
+#pragma unroll
+        for (int i = 0; i < kPieces; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v[i].v[e]));
         if constexpr (kOut == 2) {
             float sc, inv;
             f16s_scales(wave_allmax(m), sc, inv);
